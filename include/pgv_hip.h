@@ -1,0 +1,173 @@
+/*
+ * pgv_hip.h — C ABI of the MI355X (gfx950) conv-VAE train-step hot path.
+ *
+ * The reference (gwendal-lv/preset-gen-vae) has no FFI: its hot path is stock torch.nn ops called from
+ * Python (model/layer.py, model/encoder.py, model/decoder.py, model/VAE.py, model/loss.py, utils/audio.py,
+ * train.py:203-248).  This header is the boundary the build introduces *below* that Python surface: every
+ * entry point names the reference op(s) it replaces.  Conventions (all entry points):
+ *
+ *   - plain C: raw device pointers, ints, floats; no torch / C++ types;
+ *   - tensors are fp32, contiguous, NCHW (the reference's layout);
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing synchronises, nothing
+ *     allocates (graph-capture safe); scratch comes from caller-provided workspaces;
+ *   - return 0 on success, a negative PGV_E_* code otherwise (never throws across the ABI);
+ *     pgv_last_error() returns a thread-local message for the last failure;
+ *   - re-entrant, no hidden global state.
+ *
+ * "big"/"small" naming for convolutions: a stride-s convolution maps a big tensor [B,Cb,Hb,Wb] to a small
+ * one [B,Cs,Hs,Ws]; its transpose maps small to big.  The weight buffer is always [Cs][Cb][kh][kw], which is
+ * torch's Conv2d layout [Cout,Cin,kh,kw] when big is the input and torch's ConvTranspose2d layout
+ * [Cin,Cout,kh,kw] when small is the input, so both layer kinds share kernels and weights are never repacked.
+ */
+#ifndef PGV_HIP_H
+#define PGV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGV_OK 0
+#define PGV_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define PGV_E_LAUNCH (-2)    /* hipLaunch / runtime failure      */
+#define PGV_E_WORKSPACE (-3) /* workspace too small              */
+
+#define PGV_ACT_NONE 0
+#define PGV_ACT_LEAKY_RELU 1 /* nn.LeakyReLU(slope)  encoder.py:239-240, decoder.py:203-204 */
+#define PGV_ACT_HARDTANH 2   /* nn.Hardtanh(-1,1)    decoder.py:98,219 */
+
+typedef struct pgv_conv_desc {
+  int32_t B;               /* batch */
+  int32_t Cb, Hb, Wb;      /* big tensor   [B,Cb,Hb,Wb] */
+  int32_t Cs, Hs, Ws;      /* small tensor [B,Cs,Hs,Ws] */
+  int32_t kh, kw;          /* kernel */
+  int32_t stride, pad;     /* same on both axes (reference uses [2,2]/2 or [1,1]/0) */
+} pgv_conv_desc;
+
+/* ---- library info ------------------------------------------------------------------------------ */
+int pgv_abi_version(void);
+const char* pgv_last_error(void);
+/* 0 = prefer tuned kernels (default), 1 = force the generic one-thread-per-output kernels (test aid). */
+int pgv_set_kernel_policy(int policy);
+
+/* ---- convolutions (layer.Conv2D / layer.TConv2D bodies, model/layer.py:10-46) -------------------- */
+/* small = act(conv_{stride,pad}(in') + bias[Cs]),  in' = big*in_scale[c]+in_shift[c] inside the image and 0
+ * in the zero padding (in_scale/in_shift may be NULL: identity).  The per-channel affine is the *producer's*
+ * BatchNorm2d folded into this consumer's load (layer.py:21-26 puts BN after the activation).
+ * Replaces nn.Conv2d forward (layer.py:19-20) and, called with a gradient as `big`, ConvTranspose2d dgrad.
+ * bias may be NULL.  stats (may be NULL) points to 2*Cs floats that are overwritten with the sum and the sum of
+ * squares of the written outputs per channel (BatchNorm2d batch statistics, fused into the epilogue). */
+int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                  const float* w, const float* bias, int act, float slope, float* small, float* stats,
+                  void* stream);
+
+/* big = act(conv_transpose_{stride,pad}(in') + bias[Cb]); output_padding is implied by Hb/Wb.
+ * Replaces nn.ConvTranspose2d forward (layer.py:38-40, decoder.py:218) and nn.Conv2d dgrad. */
+int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scale, const float* in_shift,
+                const float* w, const float* bias, int act, float slope, float* big, float* stats,
+                void* stream);
+
+/* gw[cs][cb][kh][kw] = sum_{b,oh,ow} small'[b,cs,oh,ow] * big'[b,cb,oh*s-p+kh,ow*s-p+kw]
+ * (autograd of both layer kinds).  Either operand may carry a folded BN affine.
+ * gw is overwritten.  workspace: pgv_conv_wgrad_workspace() bytes. */
+int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d);
+int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                   const float* small, const float* small_scale, const float* small_shift, float* gw,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm (nn.BatchNorm2d / BatchNorm1d train mode, layer.py:21-26, encoder.py:86-87) ------- */
+/* stats[0:C] = sum, stats[C:2C] = sum of squares over (B,HW) of a[B,C,HW]. Overwrites stats. */
+int pgv_bn_stats(const float* a, int B, int C, int HW, float* stats, void* stream);
+/* From stats: mean/biased var -> scale=gamma*rstd, shift=beta-mean*scale; saves mean,rstd;
+ * running_mean/var momentum update with the unbiased variance (torch semantics); any of running_* may be NULL. */
+int pgv_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                    float* mean, float* rstd, void* stream);
+/* Eval-mode BN folded to an affine: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
+ * (validation forward, train.py:261-291). */
+int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, void* stream);
+/* o = a*scale[c]+shift[c]  (materialised BN output; in place allowed). */
+int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int B, int C, int HW, float* o,
+                    void* stream);
+/* red[0:C] = sum g_o, red[C:2C] = sum g_o * a_hat, a_hat=(a-mean)*rstd. Overwrites red. */
+int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C,
+                      int HW, float* red, void* stream);
+/* Backward through [activation -> BN]: given g_o (grad of BN output) produces g_y (grad of the pre-activation
+ * conv output): g_a = scale[c]*(g_o - red[c]/n - a_hat*red[C+c]/n); g_y = g_a * act'(a).
+ * With scale==NULL (block without BN) g_a = g_o; with red==NULL (eval-mode BN) g_a = scale[c]*g_o.
+ * Also emits gbias[c] = sum g_y (bias gradient, may be NULL), and when
+ * BN is present ggamma = red[C:2C], gbeta = red[0:C] are simply read by the caller.
+ * act' is recovered from the saved activated tensor a (sign for LeakyReLU; |a|<1 for Hardtanh). */
+int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
+                   const float* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
+                   void* stream);
+
+/* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */
+/* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.
+ * A element (m,k) at A[m*sam + k*sak]; B element (k,n) at B[k*sbk + n*sbn]; C row-major ldc.
+ * bias_n (len N) / bias_m (len M) optional (NULL).  Overwrites C.  workspace for split-K partials. */
+int64_t pgv_gemm_workspace(int M, int N, int K);
+int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+             int64_t sbn, float* C, int64_t ldc, const float* bias_n, void* workspace, int64_t workspace_bytes,
+             void* stream);
+/* out[n] = sum_m x[m*ld + n]  (bias gradient of Linear). */
+int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, void* stream);
+
+/* ---- dropout / reparameterisation / losses -------------------------------------------------------- */
+/* Counter-based RNG (Philox4x32-10). rng_state: device uint64[2] = {seed, offset}; kernels only read it. */
+/* mask[i] = (u_i >= p) ? 1/(1-p) : 0  (nn.Dropout train mode, encoder.py:85, decoder.py:65). */
+int pgv_dropout_mask(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, float* mask, void* stream);
+/* eps ~ N(0,1) i.i.d. (VAE.py:54-55). */
+int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream);
+/* rng_state[1] += inc (device side, keeps graph replays advancing). */
+int pgv_rng_advance(uint64_t* rng_state, uint64_t inc, void* stream);
+/* y = x * m (mask multiply; used forward and backward). */
+int pgv_mul(const float* x, const float* m, int64_t n, float* y, void* stream);
+
+/* BasicVAE.forward reparameterisation (VAE.py:49-56) + GaussianDkl (loss.py:57-66):
+ *   mu = ml[b,0,:], lv = ml[b,1,:]; z = mu + exp(lv/2)*eps ; kl = 0.5*sum(exp(lv)+mu^2-lv-1) * kl_scale
+ * kl_scale = 1/B or 1/(B*D).  kl (device scalar) is overwritten.  eps NULL => z = mu (eval mode, VAE.py:57-58). */
+int pgv_reparam_kl_fwd(const float* ml, const float* eps, int B, int D, float kl_scale, float* z, float* kl,
+                       void* stream);
+/* g_ml = d/d(ml) [ <g_z, z> + g_kl * kl ] ; g_z may be NULL, g_kl is a device scalar pointer (may be NULL). */
+int pgv_reparam_kl_bwd(const float* ml, const float* eps, const float* g_z, const float* g_kl, int B, int D,
+                       float kl_scale, float* g_ml, void* stream);
+
+/* loss = scale * sum((xhat-x)^2)  (nn.MSELoss('mean'): scale=1/numel, train.py:104,222;
+ * loss.L2Loss: scale=1/B[/numel-per-item], loss.py:37-43).  loss (device scalar) overwritten. */
+int pgv_sqerr_fwd(const float* xhat, const float* x, int64_t n, float scale, float* loss, void* stream);
+/* g[i] = g_loss * 2*scale*(xhat-x) * 1[|xhat|<1 if hardtanh]  — gradient w.r.t. the *pre-Hardtanh* tensor
+ * when hardtanh!=0 (xhat is the clamped output; torch passes zero grad at/after the bounds). */
+int pgv_sqerr_bwd(const float* xhat, const float* x, const float* g_loss, int64_t n, float scale, int hardtanh,
+                  float* g, void* stream);
+
+/* ---- optimizer (torch.optim.Adam, coupled L2, train.py:166-167) ---------------------- */
+/* hyper: device float[4] = {lr, bias_correction1 = 1-b1^t, bias_correction2 = 1-b2^t, grad_scale}. */
+int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                  float beta2, float eps, float weight_decay, void* stream);
+/* Device-side step counter: pows (device double[2], initialised to {1,1}) *= {beta1,beta2};
+ * hyper[1] = 1-pows[0], hyper[2] = 1-pows[1].  Keeps the bias corrections advancing under hipGraph replay. */
+int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* stream);
+
+/* ---- STFT -> mel -> dB front-end (utils/audio.py:20-92, data/abstractbasedataset.py:129-131) -------- */
+/* wav[B][n_samples] fp32 -> out[B][n_mels][n_frames]; n_fft=1024 only, hop any, centre zero padding.
+ * mel CSR: row_ptr[n_mels+1], col[nnz], val[nnz] (Slaney basis built on the host).  n_mels==0 => linear
+ * spectrogram with n_fft/2+1 rows.  out = affine_a * 20*log10(max(mag, floor)) + affine_b. */
+int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_fft, int hop, int n_frames,
+                 const float* window, float norm, const int32_t* mel_row_ptr, const int32_t* mel_col,
+                 const float* mel_val, int n_mels, float floor_lin, float affine_a, float affine_b, float* out,
+                 void* stream);
+
+/* ---- misc -------------------------------------------------------------------------------------------- */
+int pgv_fill(float* p, int64_t n, float v, void* stream);
+/* y = a*x + y */
+int pgv_axpy(int64_t n, float a, const float* x, float* y, void* stream);
+/* Streaming copy used for bandwidth calibration in bench.py. */
+int pgv_copy(const float* src, float* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGV_HIP_H */

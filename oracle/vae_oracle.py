@@ -1,0 +1,256 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's conv-VAE train-step arithmetic.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
+product package (``preset-gen-vae_amd/``) never does.  It restates, function by function, what the reference's
+Python computes with stock torch ops (the reference has no native code), citing the file:line each function follows
+under /root/reference.  It runs on the CPU in float32 or float64 and works on plain ``{state-dict key: tensor}``
+dictionaries with the reference's key names, so it can be fed by the reference's own modules, by the fixtures in
+``tests/golden/`` and by the product modules alike.
+
+Pinning: ``tests/golden/make_goldens.py`` imports the real reference (model/layer.py, encoder.py, decoder.py, VAE.py,
+loss.py) in the build container, runs it on seeded inputs and commits the outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks this restatement against those vectors.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1          # encoder.py:240, decoder.py:204
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch defaults through layer.py:21,41
+
+# (name, in_ch, out_ch, kernel, stride, pad, has_bn) — encoder.py:241-259 and mixer encoder.py:56-69
+ENC_TABLE = [('enc1', 1, 8, 5, 2, 2, False), ('enc2', 8, 16, 4, 2, 2, True), ('enc3', 16, 32, 4, 2, 2, True),
+             ('enc4', 32, 64, 4, 2, 2, True), ('enc5', 64, 128, 4, 2, 2, True), ('enc6', 128, 256, 4, 2, 2, True),
+             ('enc7', 256, 512, 4, 2, 2, True), ('enc8', 512, 2048, 1, 1, 0, False)]
+# (name, in_ch, out_ch, kernel, stride, pad, output_padding, has_bn) — decoder.py:72-75 and :205-218
+DEC_TABLE = [('dec1', 2048, 512, 1, 1, 0, (0, 0), True), ('dec2', 512, 256, 4, 2, 2, (1, 1), True),
+             ('dec3', 256, 128, 4, 2, 2, (1, 0), True), ('dec4', 128, 64, 4, 2, 2, (1, 1), True),
+             ('dec5', 64, 32, 4, 2, 2, (1, 1), True), ('dec6', 32, 16, 4, 2, 2, (1, 0), True),
+             ('dec7', 16, 8, 4, 2, 2, (1, 0), True)]
+
+
+def arch_tables(arch):
+    """Layer tables per architecture string.  'speccnn4l1_bn' = first four encoder rows / last three decoder rows
+    (BASELINE.json's 4-layer conv-VAE, assembled from the reference's own blocks)."""
+    if arch == 'speccnn8l1_bn':
+        return ENC_TABLE, DEC_TABLE, (2048, 3, 4)
+    if arch == 'speccnn4l1_bn':
+        return ENC_TABLE[:4], DEC_TABLE[4:], (64, 17, 23)
+    raise NotImplementedError(arch)
+
+
+def _find(sd, suffix, scope):
+    hits = [k for k in sd if k.endswith(suffix) and scope in k]
+    if len(hits) != 1:
+        raise KeyError(f"{suffix!r} in scope {scope!r}: {hits}")
+    return sd[hits[0]]
+
+
+def _bn_train_or_eval(a, sd, prefix, scope, training, new_buffers):
+    """nn.BatchNorm2d / 1d (layer.py:21-26): train = biased batch variance for normalisation, unbiased for the
+    running estimate, momentum 0.1; eval = running statistics."""
+    gamma, beta = _find(sd, prefix + 'bn.weight', scope), _find(sd, prefix + 'bn.bias', scope)
+    rm, rv = _find(sd, prefix + 'bn.running_mean', scope), _find(sd, prefix + 'bn.running_var', scope)
+    dims = [0] + list(range(2, a.dim()))
+    shape = [1, -1] + [1] * (a.dim() - 2)
+    if training:
+        mean = a.mean(dim=dims)
+        var = a.var(dim=dims, unbiased=False)
+        n = a.numel() / a.shape[1]
+        if new_buffers is not None:
+            new_buffers[prefix + 'bn.running_mean'] = ((1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean).detach()
+            new_buffers[prefix + 'bn.running_var'] = ((1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * n / (n - 1)).detach()
+    else:
+        mean, var = rm, rv
+    return (a - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS) * gamma.view(shape) + beta.view(shape)
+
+
+def conv_block(x, sd, row, scope, training, new_buffers=None, taps=None):
+    """layer.Conv2D (model/layer.py:10-26): Conv2d -> LeakyReLU(0.1) -> BatchNorm2d (BN after the activation)."""
+    name, _, _, k, s, p, has_bn = row
+    w, b = _find(sd, name + 'conv.weight', scope), _find(sd, name + 'conv.bias', scope)
+    a = F.leaky_relu(F.conv2d(x, w, b, stride=s, padding=p), LRELU_SLOPE)
+    if taps is not None:
+        taps[name + '_act'] = a
+    if has_bn:
+        a = _bn_train_or_eval(a, sd, name, scope, training, new_buffers)
+    if taps is not None:
+        taps[name] = a
+    return a
+
+
+def tconv_block(x, sd, row, scope, training, new_buffers=None, taps=None):
+    """layer.TConv2D (model/layer.py:29-46): ConvTranspose2d(output_padding) -> LeakyReLU(0.1) -> BatchNorm2d."""
+    name, _, _, k, s, p, op, has_bn = row
+    w, b = _find(sd, name + 'tconv.weight', scope), _find(sd, name + 'tconv.bias', scope)
+    a = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op), LRELU_SLOPE)
+    if taps is not None:
+        taps[name + '_act'] = a
+    if has_bn:
+        a = _bn_train_or_eval(a, sd, name, scope, training, new_buffers)
+    if taps is not None:
+        taps[name] = a
+    return a
+
+
+def encoder_forward(sd, x, arch, dim_z, training, dropout_mask=None, new_buffers=None, taps=None):
+    """SpectrogramEncoder.forward (model/encoder.py:95-108), single-channel spectrograms.
+    ``dropout_mask`` = nn.Dropout keep-mask already scaled by 1/(1-p) (encoder.py:85), ``None`` = no dropout."""
+    enc_rows, _, _ = arch_tables(arch)
+    h = x
+    for row in enc_rows:
+        h = conv_block(h, sd, row, 'encoder.', training, new_buffers, taps)
+    h = h.reshape(x.shape[0], -1)                                      # encoder.py:104
+    if training and dropout_mask is not None:
+        h = h * dropout_mask.reshape(h.shape)
+    z = F.linear(h, sd['encoder.mlp.1.weight'], sd['encoder.mlp.1.bias'])   # encoder.py:85
+    if 'encoder.mlp.lat_in_regularization.weight' in sd:                # output_bn, encoder.py:86-87
+        lsd = {'latbn.weight': sd['encoder.mlp.lat_in_regularization.weight'],
+               'latbn.bias': sd['encoder.mlp.lat_in_regularization.bias'],
+               'latbn.running_mean': sd['encoder.mlp.lat_in_regularization.running_mean'],
+               'latbn.running_var': sd['encoder.mlp.lat_in_regularization.running_var']}
+        nb = {} if new_buffers is not None else None
+        z = _bn_train_or_eval(z, lsd, 'lat', 'lat', training, nb)
+        if nb:
+            new_buffers['encoder.mlp.lat_in_regularization.running_mean'] = nb['latbn.running_mean']
+            new_buffers['encoder.mlp.lat_in_regularization.running_var'] = nb['latbn.running_var']
+    return z.reshape(x.shape[0], 2, dim_z)                              # encoder.py:108
+
+
+def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, taps=None):
+    """SpectrogramDecoder.forward (model/decoder.py:83-92) + SpectrogramCNN (decoder.py:199-220)."""
+    _, dec_rows, cnn_in = arch_tables(arch)
+    h = F.linear(z, sd['decoder.mlp.0.weight'], sd['decoder.mlp.0.bias'])   # decoder.py:64
+    if training and dropout_mask is not None:                            # decoder.py:65
+        h = h * dropout_mask.reshape(h.shape)
+    h = h.view(-1, *cnn_in)                                              # decoder.py:85-86
+    for row in dec_rows:
+        h = tconv_block(h, sd, row, 'decoder.', training, new_buffers, taps)
+    n_last = len(dec_rows) - (1 if arch == 'speccnn8l1_bn' else 0)      # index of ConvTranspose2d in dec_nn
+    w = sd[f'decoder.single_ch_cnn.dec_nn.{n_last}.weight']
+    b = sd[f'decoder.single_ch_cnn.dec_nn.{n_last}.bias']
+    y = F.conv_transpose2d(h, w, b, stride=2, padding=2)                 # decoder.py:218
+    if taps is not None:
+        taps['dec8_pre'] = y
+    return F.hardtanh(y)                                                 # decoder.py:98,219
+
+
+def reparametrize(z_mu_logvar, eps, training):
+    """BasicVAE.forward sampling (model/VAE.py:49-58)."""
+    mu = z_mu_logvar[:, 0, :]
+    sigma = torch.exp(z_mu_logvar[:, 1, :] / 2.0)
+    return mu + sigma * eps if training else mu
+
+
+def gaussian_dkl(mu, logvar, normalize=True):
+    """loss.GaussianDkl.__call__ (model/loss.py:57-66)."""
+    dkl = 0.5 * torch.sum(torch.exp(logvar) + torch.square(mu) - logvar - 1.0)
+    dkl = dkl / mu.size(0)
+    return dkl / mu.size(1) if normalize else dkl
+
+
+def l2_loss(inferred, target, contents_average=False, batch_average=True):
+    """loss.L2Loss.__call__ (model/loss.py:37-43)."""
+    loss = torch.sum(torch.square(inferred - target))
+    if batch_average:
+        loss = loss / inferred.shape[0]
+    if contents_average:
+        loss = loss / inferred[0, :].numel()
+    return loss
+
+
+def vae_forward(sd, x, arch, dim_z, training, eps=None, enc_mask=None, dec_mask=None, new_buffers=None, taps=None):
+    """BasicVAE.forward (model/VAE.py:37-61) -> (z_mu_logvar, z, z, zeros[B,1], x_out)."""
+    zml = encoder_forward(sd, x, arch, dim_z, training, enc_mask, new_buffers, taps)
+    z = reparametrize(zml, eps, training)
+    x_out = decoder_forward(sd, z, arch, training, dec_mask, new_buffers, taps)
+    return zml, z, z, torch.zeros((x.shape[0], 1), dtype=x.dtype), x_out
+
+
+def adam_update(p, g, m, v, t, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam, torch-1.7 semantics, coupled L2 (train.py:166-167)."""
+    b1, b2 = betas
+    g = g + weight_decay * p
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * m / denom, m, v
+
+
+def is_parameter_key(k):
+    return not (k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'))
+
+
+def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, normalize_losses=True, lr=2e-4,
+               betas=(0.9, 0.999), weight_decay=1e-4, adam_state=None, step=1, taps=None):
+    """One minibatch of train.py:203-248 without the regression network: forward, MSE + beta*Dkl, backward, Adam.
+
+    Returns dict(losses, outputs, grads{key}, new_sd{key}, adam_state)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_parameter_key(k)}
+    full = dict(sd)
+    full.update(params)
+    new_buffers = {}
+    zml, z, _, _, x_out = vae_forward(full, x, arch, dim_z, True, eps, enc_mask, dec_mask, new_buffers, taps)
+    if normalize_losses:
+        recons = F.mse_loss(x_out, x, reduction='mean')                 # train.py:103-104,222
+    else:
+        recons = l2_loss(x_out, x)                                      # train.py:105-106
+    lat = gaussian_dkl(zml[:, 0, :], zml[:, 1, :], normalize=normalize_losses)   # train.py:225
+    total = recons + lat * beta                                         # train.py:227,246
+    keys = list(params.keys())
+    grads = torch.autograd.grad(total, [params[k] for k in keys])
+    grads = dict(zip(keys, grads))
+    if adam_state is None:
+        adam_state = {k: (torch.zeros_like(params[k]), torch.zeros_like(params[k])) for k in keys}
+    new_sd = {k: v for k, v in sd.items()}
+    new_state = {}
+    for k in keys:
+        m, v = adam_state[k]
+        p_new, m_new, v_new = adam_update(params[k].detach(), grads[k], m, v, step, lr, betas, 1e-8, weight_decay)
+        new_sd[k] = p_new
+        new_state[k] = (m_new, v_new)
+    for k_suffix, val in new_buffers.items():
+        hits = [k for k in sd if k.endswith(k_suffix)]
+        assert len(hits) == 1, (k_suffix, hits)
+        new_sd[hits[0]] = val
+    return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(), 'z_mu_logvar': zml.detach(),
+            'z': z.detach(), 'x_out': x_out.detach(), 'grads': grads, 'new_sd': new_sd, 'adam_state': new_state}
+
+
+def closed_form_state_dict(template, seed=1234, dtype=torch.float32):
+    """Deterministic weights without RNG streams or weight files: value_i = amp * sin(i * a + phase) with
+    per-tensor constants derived from the key's position; fan-in scaled like torch's default init
+    (uniform +-1/sqrt(fan_in)).  BN gamma ~ 1 +- 0.1, beta +-0.1, running_mean +-0.1, running_var 1 +- 0.2.
+    ``template``: {key: shape}.  Same generator is used by tests/golden/make_goldens.py for the reference."""
+    sd = {}
+    for idx, (k, shape) in enumerate(template.items()):
+        n = 1
+        for s in shape:
+            n *= s
+        i = torch.arange(n, dtype=torch.float64)
+        a = 0.61803398875 + 0.001 * ((seed + 7 * idx) % 97)
+        ph = 0.37 * ((seed + 13 * idx) % 31)
+        base = torch.sin(i * a + ph)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros(shape, dtype=torch.long)
+            continue
+        if k.endswith('running_var'):
+            val = 1.0 + 0.2 * base
+        elif k.endswith('running_mean'):
+            val = 0.1 * base
+        elif 'bn.weight' in k or 'lat_in_regularization.weight' in k:
+            val = 1.0 + 0.1 * base
+        elif 'bn.bias' in k or 'lat_in_regularization.bias' in k:
+            val = 0.1 * base
+        elif k.endswith('.bias'):
+            val = 0.05 * base
+        else:
+            fan_in = n // shape[0] if len(shape) > 1 else n
+            if 'tconv.weight' in k or (k.startswith('decoder.single_ch_cnn.dec_nn') and len(shape) == 4):
+                fan_in = n // shape[1]  # ConvTranspose2d weight is [Cin, Cout, kh, kw]: fan-in per output = Cin*k*k/..
+                fan_in = shape[0] * shape[2] * shape[3] // 4 if shape[2] > 1 else shape[0]
+            val = base * math.sqrt(3.0 / max(1, fan_in))
+        sd[k] = val.reshape(shape).to(dtype)
+    return sd

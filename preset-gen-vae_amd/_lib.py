@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI library declared in ``include/pgv_hip.h``.
+
+This is the reference-side stub a maintainer would add: the reference has no FFI — its hot
+path is torch ops called from ``model/*.py`` — so the binding is a plain ``ctypes.CDLL`` of ``libpgv_hip.so``.
+There is no CPU fallback: if the library is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgv_hip.so")
+
+PGV_ACT_NONE, PGV_ACT_LEAKY_RELU, PGV_ACT_HARDTANH = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    """Mirror of ``pgv_conv_desc`` (include/pgv_hip.h)."""
+    _fields_ = [(n, c_int32) for n in ("B", "Cb", "Hb", "Wb", "Cs", "Hs", "Ws", "kh", "kw", "stride", "pad")]
+
+
+_P = c_void_p  # device pointers travel as integers
+_DESC = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
+SIGNATURES = {
+    "pgv_abi_version": (c_int, []),
+    "pgv_last_error": (c_char_p, []),
+    "pgv_set_kernel_policy": (c_int, [c_int]),
+    "pgv_conv_down": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_up": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
+    "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
+    "pgv_affine_nchw": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pgv_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pgv_act_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "pgv_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
+    "pgv_gemm": (c_int, [c_int, c_int, c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P,
+                         c_int64, _P]),
+    "pgv_colsum": (c_int, [_P, c_int, c_int, c_int64, _P, _P]),
+    "pgv_dropout_mask": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P]),
+    "pgv_normal": (c_int, [_P, c_uint64, c_int64, _P, _P]),
+    "pgv_rng_advance": (c_int, [_P, c_uint64, _P]),
+    "pgv_mul": (c_int, [_P, _P, c_int64, _P, _P]),
+    "pgv_reparam_kl_fwd": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "pgv_reparam_kl_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P]),
+    "pgv_sqerr_fwd": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
+    "pgv_sqerr_bwd": (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P, _P]),
+    "pgv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, _P]),
+    "pgv_adam_tick": (c_int, [_P, _P, c_float, c_float, _P]),
+    "pgv_stft_mel": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_float,
+                             c_float, c_float, _P, _P]),
+    "pgv_fill": (c_int, [_P, c_int64, c_float, _P]),
+    "pgv_axpy": (c_int, [c_int64, c_float, _P, _P, _P]),
+    "pgv_copy": (c_int, [_P, _P, c_int64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load ``libpgv_hip.so`` (built by ``__graft_entry__.build()`` / ``build_ext.build()``); raise if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Turn a negative PGV_E_* code into a Python exception (error convention of the boundary)."""
+    if rc != 0:
+        msg = load().pgv_last_error()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

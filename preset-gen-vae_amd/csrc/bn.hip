@@ -1,0 +1,298 @@
+// BatchNorm pieces for [B,C,HW] fp32 tensors (nn.BatchNorm2d / BatchNorm1d, train mode; reference
+// model/layer.py:21-26, model/encoder.py:86-87; backward per SURVEY Appendix B).
+//
+// All kernels use a (channel, batch-split) grid: per-channel constants are block-uniform, planes are read
+// with lanes on consecutive hw (coalesced NCHW rows), and every per-channel sum is a wave-shuffle + LDS block
+// reduction followed by ONE float atomic per block.  HBM-bound: one read (two for the backward pieces) and at
+// most one write per element.
+#include "conv_kernels.h"
+
+namespace {
+
+struct Split {
+  int nsplit;
+  int per;  // batch items per split
+};
+
+inline Split pick_split(int B, int C, int HW) {
+  // ~8 blocks per CU (2048) if the data allows; at least ~16K elements per block so the tail reduction and the
+  // atomic are amortised.
+  int64_t want = pgv_cdiv(2048, C);
+  int64_t by_work = pgv_cdiv((int64_t)B * HW, 16384);
+  int ns = (int)max((int64_t)1, min((int64_t)B, min(want, by_work)));
+  Split s;
+  s.per = (int)pgv_cdiv(B, ns);
+  s.nsplit = (int)pgv_cdiv(B, s.per);
+  return s;
+}
+
+__global__ void bn_stats_kernel(const float* __restrict__ a, int B, int C, int HW, int per,
+                                float* __restrict__ stats) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* p = a + ((int64_t)b * C + c) * HW;
+    int i = threadIdx.x;
+    for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
+      const float v0 = p[i], v1 = p[i + blockDim.x];
+      s0 += v0;
+      q0 = fmaf(v0, v0, q0);
+      s1 += v1;
+      q1 = fmaf(v1, v1, q1);
+    }
+    if (i < HW) {
+      const float v0 = p[i];
+      s0 += v0;
+      q0 = fmaf(v0, v0, q0);
+    }
+  }
+  const float s = pgv_block_sum(s0 + s1, red);
+  const float q = pgv_block_sum(q0 + q1, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[c], s);
+    atomicAdd(&stats[C + c], q);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_n, double unbias,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = (double)stats[c] * inv_n;
+  double var = (double)stats[C + c] * inv_n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  if (scale) scale[c] = (float)(g * rstd);
+  if (shift) shift[c] = (float)(bt - mean * g * rstd);
+  if (mean_out) mean_out[c] = (float)mean;
+  if (rstd_out) rstd_out[c] = (float)rstd;
+  if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+  if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double rstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  scale[c] = (float)(g * rstd);
+  shift[c] = (float)(bt - (double)rm[c] * g * rstd);
+}
+
+__global__ void affine_kernel(const float* __restrict__ a, const float* __restrict__ scale,
+                              const float* __restrict__ shift, int B, int C, int HW, int per,
+                              float* __restrict__ o) {
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float sc = scale[c], sh = shift[c];
+  for (int b = b0; b < b1; ++b) {
+    const int64_t base = ((int64_t)b * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) o[base + i] = fmaf(a[base + i], sc, sh);
+  }
+}
+
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, int B, int C,
+                                     int HW, int per, float* __restrict__ red_out) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float mu = mean[c], rs = rstd[c];
+  float s0 = 0.f, s1 = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const int64_t base = ((int64_t)b * C + c) * HW;
+    int i = threadIdx.x;
+    for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
+      const float g0 = g_o[base + i], g1 = g_o[base + i + blockDim.x];
+      const float h0 = (a[base + i] - mu) * rs, h1 = (a[base + i + blockDim.x] - mu) * rs;
+      s0 += g0;
+      d0 = fmaf(g0, h0, d0);
+      s1 += g1;
+      d1 = fmaf(g1, h1, d1);
+    }
+    if (i < HW) {
+      const float g0 = g_o[base + i];
+      s0 += g0;
+      d0 = fmaf(g0, (a[base + i] - mu) * rs, d0);
+    }
+  }
+  const float s = pgv_block_sum(s0 + s1, red);
+  const float dd = pgv_block_sum(d0 + d1, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&red_out[c], s);
+    atomicAdd(&red_out[C + c], dd);
+  }
+}
+
+__global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
+                                  const float* __restrict__ scale, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ redv, float inv_n, int B,
+                                  int C, int HW, int per, int act, float slope, float* __restrict__ g_y,
+                                  float* __restrict__ gbias) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const bool has_bn = scale != nullptr;
+  float sc = 1.f, mu = 0.f, rs = 1.f, c1 = 0.f, c2 = 0.f;
+  if (has_bn) {
+    sc = scale[c];
+    if (redv) {
+      mu = mean[c];
+      rs = rstd[c];
+      c1 = redv[c] * inv_n;
+      c2 = redv[C + c] * inv_n;
+    }
+  }
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const int64_t base = ((int64_t)b * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const float av = a[base + i];
+      float g = g_o[base + i];
+      if (has_bn) g = sc * (g - c1 - (av - mu) * rs * c2);
+      if (act == PGV_ACT_LEAKY_RELU)
+        g = av > 0.f ? g : slope * g;
+      else if (act == PGV_ACT_HARDTANH)
+        g = (av > -1.f && av < 1.f) ? g : 0.f;
+      g_y[base + i] = g;
+      acc += g;
+    }
+  }
+  if (gbias) {
+    const float s = pgv_block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&gbias[c], s);
+  }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ld, float* __restrict__ out) {
+  // block: 64 columns x 4 row-groups; rows split over blockIdx.y.
+  __shared__ float part[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  float acc = 0.f;
+  if (n < N)
+    for (int m = m0 + rg; m < m1; m += 4) acc += x[(int64_t)m * ld + n];
+  part[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && n < N) atomicAdd(&out[n], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                                               part[3][threadIdx.x]);
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t st, const char* who) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, st);
+  if (e != hipSuccess) {
+    pgv_set_error("%s: memset failed: %s", who, hipGetErrorString(e));
+    return PGV_E_LAUNCH;
+  }
+  return PGV_OK;
+}
+
+}  // namespace
+
+int pgv_bn_stats_impl(const float* a, int B, int C, int HW, float* stats, hipStream_t st) {
+  int rc = zero_async(stats, sizeof(float) * 2 * C, st, "pgv_bn_stats");
+  if (rc) return rc;
+  if ((int64_t)B * HW == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, s.nsplit), dim3(256), 0, st, a, B, C, HW, s.per, stats);
+  PGV_CHECK_LAUNCH("bn_stats");
+  return PGV_OK;
+}
+
+extern "C" {
+
+int pgv_bn_stats(const float* a, int B, int C, int HW, float* stats, void* stream) {
+  PGV_CHECK_ARG(a && stats && B >= 0 && C > 0 && HW > 0, "pgv_bn_stats: bad argument");
+  return pgv_bn_stats_impl(a, B, C, HW, stats, pgv_stream(stream));
+}
+
+int pgv_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                    float* mean, float* rstd, void* stream) {
+  PGV_CHECK_ARG(stats && C > 0 && n > 0, "pgv_bn_finalize: bad argument");
+  // torch raises for n==1 in train mode ("Expected more than 1 value per channel"); the host mirrors that.
+  const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), stats,
+                     C, 1.0 / (double)n, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale,
+                     shift, mean, rstd);
+  PGV_CHECK_LAUNCH("bn_finalize");
+  return PGV_OK;
+}
+
+int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, void* stream) {
+  PGV_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "pgv_bn_eval_affine: bad argument");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), gamma,
+                     beta, running_mean, running_var, eps, C, scale, shift);
+  PGV_CHECK_LAUNCH("bn_eval_affine");
+  return PGV_OK;
+}
+
+int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int B, int C, int HW, float* o,
+                    void* stream) {
+  PGV_CHECK_ARG(a && scale && shift && o && B >= 0 && C > 0 && HW > 0, "pgv_affine_nchw: bad argument");
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(affine_kernel, dim3(C, s.nsplit), dim3(256), 0, pgv_stream(stream), a, scale, shift, B, C, HW,
+                     s.per, o);
+  PGV_CHECK_LAUNCH("affine_nchw");
+  return PGV_OK;
+}
+
+int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
+                      float* red, void* stream) {
+  PGV_CHECK_ARG(g_o && a && mean && rstd && red && B >= 0 && C > 0 && HW > 0, "pgv_bn_bwd_reduce: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  int rc = zero_async(red, sizeof(float) * 2 * C, st, "pgv_bn_bwd_reduce");
+  if (rc) return rc;
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, mean, rstd, B, C, HW, s.per,
+                     red);
+  PGV_CHECK_LAUNCH("bn_bwd_reduce");
+  return PGV_OK;
+}
+
+int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
+                   const float* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
+                   void* stream) {
+  PGV_CHECK_ARG(g_o && a && g_y && B >= 0 && C > 0 && HW > 0, "pgv_act_bn_bwd: bad argument");
+  PGV_CHECK_ARG(red == nullptr || (scale && mean && rstd), "pgv_act_bn_bwd: train-mode BN needs scale/mean/rstd");
+  hipStream_t st = pgv_stream(stream);
+  if (gbias) {
+    int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_act_bn_bwd");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  const float inv_n = 1.0f / (float)((double)B * HW);
+  hipLaunchKernelGGL(act_bn_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, scale, mean, rstd, red, inv_n,
+                     B, C, HW, s.per, act, slope, g_y, gbias);
+  PGV_CHECK_LAUNCH("act_bn_bwd");
+  return PGV_OK;
+}
+
+int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, void* stream) {
+  PGV_CHECK_ARG(x && out && M >= 0 && N > 0 && ld >= N, "pgv_colsum: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  int rc = zero_async(out, sizeof(float) * N, st, "pgv_colsum");
+  if (rc) return rc;
+  if (M == 0) return PGV_OK;
+  const int gy = (int)max((int64_t)1, min((int64_t)pgv_cdiv(M, 32), pgv_cdiv(1024, pgv_cdiv(N, 64))));
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)pgv_cdiv(N, 64), gy), dim3(256), 0, st, x, M, N, ld, out);
+  PGV_CHECK_LAUNCH("colsum");
+  return PGV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// extern "C" convolution entry points: validate, pick a tuned gfx950 kernel, fall back to the generic one.
+#include <stdarg.h>
+#include <string.h>
+#include "conv_kernels.h"
+
+static thread_local char g_err[512] = "";
+static int g_policy = 0;
+
+void pgv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int pgv_kernel_policy() { return g_policy; }
+
+static int check_desc(const pgv_conv_desc* d, const char* who) {
+  PGV_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  PGV_CHECK_ARG(d->B >= 0 && d->Cb > 0 && d->Cs > 0 && d->Hb > 0 && d->Wb > 0 && d->Hs > 0 && d->Ws > 0,
+                "%s: non-positive dimension", who);
+  PGV_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "%s: bad kernel/stride/pad", who);
+  // The small tensor must be a legal Conv2d output of the big one (floor division), equivalently the big
+  // tensor a legal ConvTranspose2d output of the small one for some 0 <= output_padding < stride.
+  const int hs = (d->Hb + 2 * d->pad - d->kh) / d->stride + 1;
+  const int ws = (d->Wb + 2 * d->pad - d->kw) / d->stride + 1;
+  PGV_CHECK_ARG(hs == d->Hs && ws == d->Ws, "%s: big %dx%d / small %dx%d inconsistent with k=%dx%d s=%d p=%d", who,
+                d->Hb, d->Wb, d->Hs, d->Ws, d->kh, d->kw, d->stride, d->pad);
+  return PGV_OK;
+}
+
+extern "C" {
+
+int pgv_abi_version(void) { return 1; }
+const char* pgv_last_error(void) { return g_err; }
+int pgv_set_kernel_policy(int policy) {
+  g_policy = policy;
+  return PGV_OK;
+}
+
+int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                  const float* w, const float* bias, int act, float slope, float* small_out, float* stats,
+                  void* stream) {
+  int rc = check_desc(d, "pgv_conv_down");
+  if (rc) return rc;
+  PGV_CHECK_ARG(big && w && small_out, "pgv_conv_down: null tensor");
+  PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_down: scale/shift must come together");
+  hipStream_t st = pgv_stream(stream);
+  if (g_policy == 0) {
+    rc = pgv_conv_down_tuned(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return PGV_OK;
+  }
+  rc = pgv_conv_down_generic(d, big, in_scale, in_shift, w, bias, act, slope, small_out, st);
+  if (rc) return rc;
+  if (stats) return pgv_bn_stats_impl(small_out, d->B, d->Cs, d->Hs * d->Ws, stats, st);
+  return PGV_OK;
+}
+
+int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                const float* w, const float* bias, int act, float slope, float* big_out, float* stats,
+                void* stream) {
+  int rc = check_desc(d, "pgv_conv_up");
+  if (rc) return rc;
+  PGV_CHECK_ARG(small_in && w && big_out, "pgv_conv_up: null tensor");
+  PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up: scale/shift must come together");
+  hipStream_t st = pgv_stream(stream);
+  if (g_policy == 0) {
+    rc = pgv_conv_up_tuned(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return PGV_OK;
+  }
+  rc = pgv_conv_up_generic(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, st);
+  if (rc) return rc;
+  if (stats) return pgv_bn_stats_impl(big_out, d->B, d->Cb, d->Hb * d->Wb, stats, st);
+  return PGV_OK;
+}
+
+int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d) {
+  if (!d) return 0;
+  return pgv_conv_wgrad_tuned_workspace(d);
+}
+
+int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                   const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                   void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_desc(d, "pgv_conv_wgrad");
+  if (rc) return rc;
+  PGV_CHECK_ARG(big && small_in && gw, "pgv_conv_wgrad: null tensor");
+  PGV_CHECK_ARG((big_scale == nullptr) == (big_shift == nullptr), "pgv_conv_wgrad: scale/shift must come together");
+  PGV_CHECK_ARG((small_scale == nullptr) == (small_shift == nullptr),
+                "pgv_conv_wgrad: scale/shift must come together");
+  hipStream_t st = pgv_stream(stream);
+  if (g_policy == 0) {
+    rc = pgv_conv_wgrad_tuned(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
+                              workspace_bytes, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return PGV_OK;
+  }
+  return pgv_conv_wgrad_generic(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// Element-wise / reduction kernels of the VAE step: dropout masks and eps (counter-based Philox), the
+// reparameterisation + KL (model/VAE.py:49-58, model/loss.py:57-66), squared-error loss with the Hardtanh
+// gate (train.py:104,222; model/loss.py:37-43; model/decoder.py:98), fused Adam (train.py:166-167).
+// All are HBM-bound streaming kernels: 16 B per lane where alignment allows, grid capped at 2048 blocks with a
+// grid-stride loop, one atomic per block for reductions.
+#include "pgv_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+inline unsigned grid_for(int64_t n, int per_thread = 4) {
+  int64_t blocks = pgv_cdiv(n, (int64_t)kBlock * per_thread);
+  return (unsigned)max((int64_t)1, min((int64_t)2048, blocks));
+}
+
+// ---- Philox4x32-10 -------------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id, uint64_t key) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = (uint32_t)stream_id,
+           c3 = (uint32_t)(stream_id >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                   n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+__global__ void dropout_mask_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
+                                    int64_t n, float* __restrict__ mask) {
+  const uint64_t seed = rng[0], off = rng[1];
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    const float v[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = q * 4 + j;
+      if (i < n) mask[i] = v[j] >= p ? keep_scale : 0.f;
+    }
+  }
+}
+
+__global__ void normal_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, int64_t n,
+                              float* __restrict__ out) {
+  const uint64_t seed = rng[0], off = rng[1];
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    // Box-Muller, two pairs. u in (0,1] for the log.
+    const float u0 = 1.0f - u01(r.x), u1 = u01(r.y), u2 = 1.0f - u01(r.z), u3 = u01(r.w);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0);
+    sincosf(6.283185307179586f * u3, &s1, &c1);
+    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = q * 4 + j;
+      if (i < n) out[i] = v[j];
+    }
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += inc;
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, int64_t n,
+                           float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * m[i];
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__global__ void axpy_kernel(int64_t n, float a, const float* __restrict__ x, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void copy4_kernel(const float4* __restrict__ s, float4* __restrict__ d, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = s[i];
+}
+
+// ---- reparameterisation + KL ------------------------------------------------------------------------------
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ ml, const float* __restrict__ eps, int B, int D,
+                                      float kl_scale, float* __restrict__ z, float* __restrict__ kl) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const int64_t n = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / D;
+    const int dd = (int)(i - b * D);
+    const float mu = ml[(b * 2) * D + dd], lv = ml[(b * 2 + 1) * D + dd];
+    const float var = expf(lv);
+    acc += var + mu * mu - lv - 1.0f;
+    if (z) z[i] = eps ? fmaf(expf(0.5f * lv), eps[i], mu) : mu;
+  }
+  const float s = pgv_block_sum(acc, red);
+  if (threadIdx.x == 0 && kl) atomicAdd(kl, 0.5f * kl_scale * s);
+}
+
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ ml, const float* __restrict__ eps,
+                                      const float* __restrict__ g_z, const float* __restrict__ g_kl, int B, int D,
+                                      float kl_scale, float* __restrict__ g_ml) {
+  const float gk = g_kl ? g_kl[0] * kl_scale : 0.f;
+  const int64_t n = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / D;
+    const int dd = (int)(i - b * D);
+    const float mu = ml[(b * 2) * D + dd], lv = ml[(b * 2 + 1) * D + dd];
+    float gmu = gk * mu, glv = gk * 0.5f * (expf(lv) - 1.0f);
+    if (g_z) {
+      const float gz = g_z[i];
+      gmu += gz;
+      if (eps) glv = fmaf(gz * eps[i], 0.5f * expf(0.5f * lv), glv);
+    }
+    g_ml[(b * 2) * D + dd] = gmu;
+    g_ml[(b * 2 + 1) * D + dd] = glv;
+  }
+}
+
+// ---- squared error -----------------------------------------------------------------------------------------
+__global__ void sqerr_fwd_kernel(const float* __restrict__ xhat, const float* __restrict__ x, int64_t n, float scale,
+                                 float* __restrict__ loss) {
+  __shared__ float red[16];
+  float a0 = 0.f, a1 = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n; i += 2 * stride) {
+    const float d0 = xhat[i] - x[i], d1 = xhat[i + stride] - x[i + stride];
+    a0 = fmaf(d0, d0, a0);
+    a1 = fmaf(d1, d1, a1);
+  }
+  if (i < n) {
+    const float d0 = xhat[i] - x[i];
+    a0 = fmaf(d0, d0, a0);
+  }
+  const float s = pgv_block_sum(a0 + a1, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s * scale);
+}
+
+__global__ void sqerr_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ x,
+                                 const float* __restrict__ g_loss, int64_t n, float scale, int hardtanh,
+                                 float* __restrict__ g) {
+  const float k = 2.0f * scale * (g_loss ? g_loss[0] : 1.0f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xh = xhat[i];
+    float v = k * (xh - x[i]);
+    if (hardtanh && !(xh > -1.0f && xh < 1.0f)) v = 0.f;
+    g[i] = v;
+  }
+}
+
+// ---- Adam (coupled L2) ---------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, const float* __restrict__ hyper, float beta1,
+                            float beta2, float eps, float wd) {
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gs);
+    const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);
+    const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+__global__ void adam_tick_kernel(double* __restrict__ pows, float* __restrict__ hyper, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double p1 = pows[0] * beta1, p2 = pows[1] * beta2;
+    pows[0] = p1;
+    pows[1] = p2;
+    hyper[1] = (float)(1.0 - p1);
+    hyper[2] = (float)(1.0 - p2);
+  }
+}
+
+int zero_scalar(float* p, hipStream_t st, const char* who) {
+  hipError_t e = hipMemsetAsync(p, 0, sizeof(float), st);
+  if (e != hipSuccess) {
+    pgv_set_error("%s: memset failed: %s", who, hipGetErrorString(e));
+    return PGV_E_LAUNCH;
+  }
+  return PGV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgv_dropout_mask(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, float* mask, void* stream) {
+  PGV_CHECK_ARG(rng_state && mask && n >= 0 && p >= 0.f && p < 1.f, "pgv_dropout_mask: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state,
+                     stream_id, p, 1.0f / (1.0f - p), n, mask);
+  PGV_CHECK_LAUNCH("dropout_mask");
+  return PGV_OK;
+}
+
+int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream) {
+  PGV_CHECK_ARG(rng_state && out && n >= 0, "pgv_normal: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(normal_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state, stream_id,
+                     n, out);
+  PGV_CHECK_LAUNCH("normal");
+  return PGV_OK;
+}
+
+int pgv_rng_advance(uint64_t* rng_state, uint64_t inc, void* stream) {
+  PGV_CHECK_ARG(rng_state, "pgv_rng_advance: null state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, pgv_stream(stream), rng_state, inc);
+  PGV_CHECK_LAUNCH("rng_advance");
+  return PGV_OK;
+}
+
+int pgv_mul(const float* x, const float* m, int64_t n, float* y, void* stream) {
+  PGV_CHECK_ARG(x && m && y && n >= 0, "pgv_mul: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(kBlock), 0, pgv_stream(stream), x, m, n, y);
+  PGV_CHECK_LAUNCH("mul");
+  return PGV_OK;
+}
+
+int pgv_reparam_kl_fwd(const float* ml, const float* eps, int B, int D, float kl_scale, float* z, float* kl,
+                       void* stream) {
+  PGV_CHECK_ARG(ml && B >= 0 && D > 0, "pgv_reparam_kl_fwd: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (kl) {
+    int rc = zero_scalar(kl, st, "pgv_reparam_kl_fwd");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for((int64_t)B * D, 1)), dim3(kBlock), 0, st, ml, eps, B, D,
+                     kl_scale, z, kl);
+  PGV_CHECK_LAUNCH("reparam_kl_fwd");
+  return PGV_OK;
+}
+
+int pgv_reparam_kl_bwd(const float* ml, const float* eps, const float* g_z, const float* g_kl, int B, int D,
+                       float kl_scale, float* g_ml, void* stream) {
+  PGV_CHECK_ARG(ml && g_ml && B >= 0 && D > 0, "pgv_reparam_kl_bwd: bad argument");
+  if (B == 0) return PGV_OK;
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for((int64_t)B * D, 1)), dim3(kBlock), 0, pgv_stream(stream),
+                     ml, eps, g_z, g_kl, B, D, kl_scale, g_ml);
+  PGV_CHECK_LAUNCH("reparam_kl_bwd");
+  return PGV_OK;
+}
+
+int pgv_sqerr_fwd(const float* xhat, const float* x, int64_t n, float scale, float* loss, void* stream) {
+  PGV_CHECK_ARG(xhat && x && loss && n >= 0, "pgv_sqerr_fwd: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  int rc = zero_scalar(loss, st, "pgv_sqerr_fwd");
+  if (rc) return rc;
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(sqerr_fwd_kernel, dim3(grid_for(n, 8)), dim3(kBlock), 0, st, xhat, x, n, scale, loss);
+  PGV_CHECK_LAUNCH("sqerr_fwd");
+  return PGV_OK;
+}
+
+int pgv_sqerr_bwd(const float* xhat, const float* x, const float* g_loss, int64_t n, float scale, int hardtanh,
+                  float* g, void* stream) {
+  PGV_CHECK_ARG(xhat && x && g && n >= 0, "pgv_sqerr_bwd: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), xhat, x, g_loss, n,
+                     scale, hardtanh, g);
+  PGV_CHECK_LAUNCH("sqerr_bwd");
+  return PGV_OK;
+}
+
+int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                  float beta2, float eps, float weight_decay, void* stream) {
+  PGV_CHECK_ARG(p && g && m && v && hyper && n >= 0, "pgv_adam_step: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), p, g, m, v, n, hyper,
+                     beta1, beta2, eps, weight_decay);
+  PGV_CHECK_LAUNCH("adam_step");
+  return PGV_OK;
+}
+
+int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* stream) {
+  PGV_CHECK_ARG(pows && hyper, "pgv_adam_tick: bad argument");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, pgv_stream(stream), pows, hyper, (double)beta1,
+                     (double)beta2);
+  PGV_CHECK_LAUNCH("adam_tick");
+  return PGV_OK;
+}
+
+int pgv_fill(float* p, int64_t n, float v, void* stream) {
+  PGV_CHECK_ARG(p && n >= 0, "pgv_fill: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kBlock), 0, pgv_stream(stream), p, n, v);
+  PGV_CHECK_LAUNCH("fill");
+  return PGV_OK;
+}
+
+int pgv_axpy(int64_t n, float a, const float* x, float* y, void* stream) {
+  PGV_CHECK_ARG(x && y && n >= 0, "pgv_axpy: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(kBlock), 0, pgv_stream(stream), n, a, x, y);
+  PGV_CHECK_LAUNCH("axpy");
+  return PGV_OK;
+}
+
+int pgv_copy(const float* src, float* dst, int64_t n, void* stream) {
+  PGV_CHECK_ARG(src && dst && n >= 0 && (n % 4) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                "pgv_copy: needs n%%4==0 and 16-byte aligned pointers");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(copy4_kernel, dim3(2048), dim3(kBlock), 0, pgv_stream(stream), (const float4*)src, (float4*)dst,
+                     n / 4);
+  PGV_CHECK_LAUNCH("copy");
+  return PGV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels. wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pgv_hip.h"
+
+#define PGV_WAVE 64
+
+void pgv_set_error(const char* fmt, ...);
+int pgv_kernel_policy();
+
+#define PGV_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      pgv_set_error(__VA_ARGS__);       \
+      return PGV_E_INVALID;             \
+    }                                   \
+  } while (0)
+
+#define PGV_CHECK_LAUNCH(name)                                                  \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      pgv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return PGV_E_LAUNCH;                                                      \
+    }                                                                           \
+  } while (0)
+
+static inline hipStream_t pgv_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t pgv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float pgv_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). Result valid in thread 0 (and all of wave 0).
+__device__ __forceinline__ float pgv_block_sum(float v, float* smem /* >= 16 floats */) {
+  v = pgv_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (wave == 0) {
+    r = lane < nw ? smem[lane] : 0.f;
+    r = pgv_wave_sum(r);
+  }
+  return r;
+}
+
+__device__ __forceinline__ float pgv_act(float y, int act, float slope) {
+  if (act == PGV_ACT_LEAKY_RELU) return y > 0.f ? y : slope * y;
+  if (act == PGV_ACT_HARDTANH) return fminf(1.f, fmaxf(-1.f, y));
+  return y;
+}

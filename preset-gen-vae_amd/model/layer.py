@@ -1,0 +1,349 @@
+"""Conv building blocks of the spectrogram VAE, MI355X-native.
+
+Mirrors the surface of the reference's ``model/layer.py`` (``Conv2D`` :10-26, ``TConv2D`` :29-46: conv -> activation
+-> BatchNorm2d, BN *after* the activation, ``batch_norm=None`` drops it) with the same sub-module names, so
+state-dict keys are identical (``...enc2conv.weight``, ``...enc2bn.running_mean``, ``...dec2tconv.weight``).
+``nn.Conv2d`` / ``nn.ConvTranspose2d`` / ``nn.BatchNorm2d`` objects are kept purely as *parameter containers*
+(torch-default initialisation, reference key names); their ``forward`` is never called.  All arithmetic runs in the
+HIP kernels behind ``include/pgv_hip.h`` through :class:`ConvStackFn`:
+
+* forward of block l:  a_l = act(conv(o_{l-1}) + b)  with the producer's BatchNorm folded into the consumer's load
+  (o_{l-1} = a_{l-1}*scale+shift inside the image, 0 in the zero padding), BN batch statistics accumulated in the
+  conv epilogue, ``pgv_bn_finalize`` turning them into (scale, shift, mean, rstd) and updating the running stats;
+* backward: ``pgv_bn_bwd_reduce`` -> ``pgv_act_bn_bwd`` (also yields the bias gradient) -> ``pgv_conv_wgrad`` and
+  the transposed convolution for the input gradient.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import PGV_ACT_HARDTANH, PGV_ACT_LEAKY_RELU, PGV_ACT_NONE
+
+
+def _act_code(activation):
+    """Map the reference's activation modules (encoder.py:239-240, decoder.py:98,203-204) to kernel epilogues."""
+    if activation is None or isinstance(activation, nn.Identity):
+        return PGV_ACT_NONE, 0.0
+    if isinstance(activation, nn.LeakyReLU):
+        return PGV_ACT_LEAKY_RELU, float(activation.negative_slope)
+    if isinstance(activation, nn.ReLU):
+        return PGV_ACT_LEAKY_RELU, 0.0
+    if isinstance(activation, nn.Hardtanh) and activation.min_val == -1.0 and activation.max_val == 1.0:
+        return PGV_ACT_HARDTANH, 0.0
+    raise NotImplementedError(f"activation {activation} has no HIP epilogue")
+
+
+def _one(v):
+    if isinstance(v, (list, tuple)):
+        if len(set(v)) != 1:
+            raise NotImplementedError(f"anisotropic kernel/stride/padding {v} not implemented")
+        return int(v[0])
+    return int(v)
+
+
+class _Block:
+    """Host-side description of one conv(+act)(+BN) block, bound to its parameter-container modules."""
+
+    def __init__(self, conv, act_module, bn):
+        self.conv, self.bn = conv, bn
+        self.up = isinstance(conv, nn.ConvTranspose2d)
+        self.act, self.slope = _act_code(act_module)
+        self.k, self.stride, self.pad = _one(conv.kernel_size), _one(conv.stride), _one(conv.padding)
+        if _one(conv.dilation) != 1 or conv.groups != 1 or conv.padding_mode != 'zeros':
+            raise NotImplementedError("dilation/groups/non-zero padding modes are not implemented")
+        self.out_pad = tuple(conv.output_padding) if self.up else (0, 0)
+        if self.up:  # ConvTranspose2d weight [Cin, Cout, kh, kw] = [Cs][Cb][kh][kw]
+            self.Cs, self.Cb = conv.in_channels, conv.out_channels
+        else:        # Conv2d weight [Cout, Cin, kh, kw] = [Cs][Cb][kh][kw]
+            self.Cs, self.Cb = conv.out_channels, conv.in_channels
+        self.c_out = conv.out_channels
+        self._geoms = {}
+
+    def geom(self, H_in, W_in):
+        g = self._geoms.get((H_in, W_in))
+        if g is None:
+            if self.up:
+                Hb = (H_in - 1) * self.stride - 2 * self.pad + self.k + self.out_pad[0]
+                Wb = (W_in - 1) * self.stride - 2 * self.pad + self.k + self.out_pad[1]
+            else:
+                Hb, Wb = H_in, W_in
+            g = ops.ConvGeom(self.Cb, self.Cs, self.k, self.stride, self.pad, Hb, Wb)
+            if self.up and (g.Hs, g.Ws) != (H_in, W_in):
+                raise ValueError("output_padding inconsistent with stride")
+            self._geoms[(H_in, W_in)] = g
+        return g
+
+    def params(self):
+        ps = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            ps += [self.bn.weight, self.bn.bias]
+        return ps
+
+
+def _grad_dest(param):
+    """Where a parameter gradient is written.  Flat-buffer mode (optim.FlatParams): straight into the parameter's
+    slice of the flat gradient buffer (the gradient is OVERWRITTEN — train.py:208 zero-grads every step anyway) and
+    autograd gets ``None``; otherwise a fresh tensor that autograd accumulates as usual."""
+    view = getattr(param, '_pgv_grad_view', None)
+    if view is not None:
+        if param.grad is not view:
+            param.grad = view
+        return view, None
+    t = torch.empty_like(param)
+    return t, t
+
+
+# Set by parallel.GradAllReduce: called with a parameter right after the kernel writing its gradient was launched on
+# the current stream (gradient-ready notification for bucketed all-reduce overlap).
+GRAD_READY_HOOK = None
+
+
+def _grad_done(*params):
+    if GRAD_READY_HOOK is not None:
+        for p in params:
+            if p is not None:
+                GRAD_READY_HOOK(p)
+
+
+class ConvStackFn(torch.autograd.Function):
+    """A chain of conv blocks evaluated with folded BatchNorm between consecutive blocks."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, training, *params):
+        x = x.contiguous()
+        B = x.shape[0]
+        dev = x.device
+        cur, cur_scale, cur_shift = x, None, None
+        saved = []
+        pi = 0
+        for blk in blocks:
+            w, b = params[pi], params[pi + 1]
+            pi += 2
+            g = blk.geom(cur.shape[2], cur.shape[3])
+            has_bn = blk.bn is not None
+            gamma = beta = None
+            if has_bn:
+                gamma, beta = params[pi], params[pi + 1]
+                pi += 2
+            C = blk.c_out
+            stats = torch.empty(2 * C, device=dev, dtype=torch.float32) if (has_bn and training) else None
+            fn = ops.conv_up if blk.up else ops.conv_down
+            a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats)
+            scale = shift = mean = rstd = None
+            if has_bn:
+                vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
+                scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
+                if training:
+                    n = B * a.shape[2] * a.shape[3]
+                    if n <= 1:
+                        raise ValueError("Expected more than 1 value per channel when training")
+                    bn = blk.bn
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    ops.bn_finalize(stats, n, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
+                                    bn.running_var if track else None, scale, shift, mean, rstd)
+                    if track and bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                else:
+                    ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
+                    mean = rstd = None
+            saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g))
+            cur, cur_scale, cur_shift = a, scale, shift
+        out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
+        ctx.blocks, ctx.saved, ctx.params = blocks, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        blocks, saved, params = ctx.blocks, ctx.saved, ctx.params
+        g_o = g_out.contiguous()
+        dev = g_o.device
+        grads = [None] * len(params)
+        pi = len(params)
+        for li in range(len(blocks) - 1, -1, -1):
+            blk = blocks[li]
+            inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
+            has_bn = blk.bn is not None
+            pi -= 4 if has_bn else 2
+            w = params[pi]
+            C = blk.c_out
+            red = None
+            if has_bn and mean is not None:
+                red = torch.empty(2 * C, device=dev, dtype=torch.float32)
+                ops.bn_bwd_reduce(g_o, a, mean, rstd, red)
+                dst, ret = _grad_dest(params[pi + 2])
+                dst.copy_(red[C:])
+                grads[pi + 2] = ret
+                dst, ret = _grad_dest(params[pi + 3])
+                dst.copy_(red[:C])
+                grads[pi + 3] = ret
+                _grad_done(params[pi + 2], params[pi + 3])
+            elif has_bn:  # eval-mode BN: gamma/beta gradients are not produced
+                pass
+            gb, gb_ret = _grad_dest(params[pi + 1])
+            # g_y overwrites g_o unless g_o is the caller's tensor (first iteration)
+            g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
+            ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb)
+            grads[pi + 1] = gb_ret
+            _grad_done(params[pi + 1])
+            gw, gw_ret = _grad_dest(w)
+            if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
+                ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift)
+            else:        # Conv2d: big = block input, small = g_y
+                ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift)
+            grads[pi] = gw_ret
+            _grad_done(w)
+            need_dx = li > 0 or ctx.needs_input_grad[0]
+            if need_dx:
+                if blk.up:
+                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0)
+                else:
+                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0)
+            else:
+                g_o = None
+        return (g_o, None, None) + tuple(grads)
+
+
+def run_stack(x, blocks, training):
+    params = []
+    for blk in blocks:
+        params += blk.params()
+    return ConvStackFn.apply(x, tuple(blocks), bool(training), *params)
+
+
+class _ConvBlockBase(nn.Sequential):
+    """Shared body of Conv2D / TConv2D: children keep the reference names, forward goes through the HIP stack."""
+
+    def _finish(self, conv_name, conv, activation, name_prefix, batch_norm):
+        if batch_norm == 'before':
+            raise NotImplementedError("batch_norm='before' is unused by speccnn8l1_bn and not implemented")
+        self.add_module(name_prefix + conv_name, conv)
+        self.add_module(name_prefix + 'act', activation)
+        bn = None
+        if batch_norm == 'after':
+            bn = nn.BatchNorm2d(conv.out_channels)
+            self.add_module(name_prefix + 'bn', bn)
+        elif batch_norm is not None:
+            raise ValueError(f"batch_norm={batch_norm!r}")
+        self._pgv_block = _Block(conv, activation, bn)
+
+    def pgv_blocks(self):
+        return [self._pgv_block]
+
+    def forward(self, x):
+        return run_stack(x, [self._pgv_block], self.training)
+
+
+class Conv2D(_ConvBlockBase):
+    """conv -> activation -> BatchNorm2d (reference model/layer.py:10-26)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding, dilation,
+                 padding_mode='zeros', activation=None, name_prefix='', batch_norm='after'):
+        super().__init__()
+        activation = nn.ReLU() if activation is None else activation
+        conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, padding, dilation, padding_mode=padding_mode)
+        self._finish('conv', conv, activation, name_prefix, batch_norm)
+
+
+class TConv2D(_ConvBlockBase):
+    """transposed conv -> activation -> BatchNorm2d (reference model/layer.py:29-46)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding, output_padding=0, dilation=1,
+                 padding_mode='zeros', activation=None, name_prefix='', batch_norm='after'):
+        super().__init__()
+        activation = nn.ReLU() if activation is None else activation
+        conv = nn.ConvTranspose2d(in_ch, out_ch, kernel_size, stride, padding, output_padding,
+                                  dilation=dilation, padding_mode=padding_mode)
+        self._finish('tconv', conv, activation, name_prefix, batch_norm)
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the f32-MFMA GEMM (encoder.py:85, decoder.py:64)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.params = (w, b)
+        return ops.linear_fwd(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        wp, bp = ctx.params
+        gy = gy.contiguous()
+        gx = ops.linear_dgrad(gy, w) if ctx.needs_input_grad[0] else None
+        gw, gw_ret = _grad_dest(wp)
+        ops.linear_wgrad(gy, x, gw)
+        gb_ret = None
+        if bp is not None:
+            gb, gb_ret = _grad_dest(bp)
+            ops.colsum(gy, gb)
+        _grad_done(wp, bp)
+        return gx, gw_ret, gb_ret
+
+
+class MaskMulFn(torch.autograd.Function):
+    """y = x * mask with a pre-scaled keep mask (nn.Dropout train mode: encoder.py:85, decoder.py:65)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return ops.mul(x.contiguous(), mask)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (mask,) = ctx.saved_tensors
+        return ops.mul(gy.contiguous(), mask), None
+
+
+class BatchNorm1dFn(torch.autograd.Function):
+    """nn.BatchNorm1d over [B, C] (encoder.py:86-87), same kernels as the 2-D case with HW = 1."""
+
+    @staticmethod
+    def forward(ctx, x, bn, training, gamma, beta):
+        x = x.contiguous()
+        B, C = x.shape
+        dev = x.device
+        vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
+        scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
+        if training:
+            if B <= 1:
+                raise ValueError("Expected more than 1 value per channel when training")
+            stats = torch.empty(2 * C, device=dev, dtype=torch.float32)
+            x3 = x.view(B, C, 1)
+            ops.bn_stats(x3, stats)
+            track = bn.track_running_stats and bn.running_mean is not None
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_finalize(stats, B, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
+                            bn.running_var if track else None, scale, shift, mean, rstd)
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        else:
+            ops.bn_eval_affine(gamma, beta, bn.running_mean, bn.running_var, bn.eps, scale, shift)
+            mean = rstd = None
+        ctx.saved = (x, scale, mean, rstd)
+        ctx.params = (gamma, beta)
+        return ops.affine_nchw(x.view(B, C, 1), scale, shift).view(B, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scale, mean, rstd = ctx.saved
+        gamma, beta = ctx.params
+        B, C = x.shape
+        g = g.contiguous().view(B, C, 1)
+        x3 = x.view(B, C, 1)
+        red = None
+        gg_ret = gb_ret = None
+        if mean is not None:
+            red = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            ops.bn_bwd_reduce(g, x3, mean, rstd, red)
+            dst, gg_ret = _grad_dest(gamma)
+            dst.copy_(red[C:])
+            dst, gb_ret = _grad_dest(beta)
+            dst.copy_(red[:C])
+            _grad_done(gamma, beta)
+        gx = torch.empty_like(x3)
+        ops.act_bn_bwd(g, x3, scale, mean, rstd, red, PGV_ACT_NONE, 0.0, gx, None)
+        return gx.view(B, C), None, None, gg_ret, gb_ret

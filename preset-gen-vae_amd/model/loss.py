@@ -1,0 +1,94 @@
+"""Losses of the VAE train step on HIP kernels (surface of the reference's ``model/loss.py``).
+
+* :class:`L2Loss` (reference loss.py:15-43) and :class:`MSELoss` (``nn.MSELoss('mean')`` as used at train.py:104,222)
+  -> ``pgv_sqerr_fwd`` / ``pgv_sqerr_bwd``;
+* :class:`GaussianDkl` (reference loss.py:46-66) -> ``pgv_reparam_kl_fwd`` / ``pgv_reparam_kl_bwd``.
+Criteria are stateless callables like the reference's.
+"""
+import torch
+
+from .. import ops
+
+
+class _SqErrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inferred, target, scale):
+        inferred = inferred.contiguous()
+        target = target.contiguous()
+        ctx.save_for_backward(inferred, target)
+        ctx.scale = scale
+        return ops.sqerr_fwd(inferred, target, scale)
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        inferred, target = ctx.saved_tensors
+        g_loss = g_loss.contiguous()
+        g_inf = ops.sqerr_bwd(inferred, target, g_loss, ctx.scale) if ctx.needs_input_grad[0] else None
+        g_tgt = None
+        if ctx.needs_input_grad[1]:
+            g_tgt = ops.sqerr_bwd(target, inferred, g_loss, ctx.scale)
+        return g_inf, g_tgt, None
+
+
+class L2Loss:
+    """Sum of squared differences / batch size [/ elements per item] (reference loss.py:15-43)."""
+
+    def __init__(self, contents_average=False, batch_average=True):
+        self.contents_average = contents_average
+        self.batch_average = batch_average
+
+    def __call__(self, inferred, target):
+        scale = 1.0
+        if self.batch_average:
+            scale /= inferred.shape[0]
+        if self.contents_average:
+            scale /= inferred[0, :].numel()
+        return _SqErrFn.apply(inferred, target, scale)
+
+
+class MSELoss:
+    """``nn.MSELoss(reduction='mean')`` — the normalised reconstruction criterion of train.py:103-104."""
+
+    def __init__(self, reduction='mean'):
+        if reduction not in ('mean', 'sum'):
+            raise NotImplementedError(reduction)
+        self.reduction = reduction
+
+    def __call__(self, inferred, target):
+        scale = 1.0 / inferred.numel() if self.reduction == 'mean' else 1.0
+        return _SqErrFn.apply(inferred, target, scale)
+
+
+class _DklFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ml, kl_scale):
+        ml = ml.contiguous()
+        ctx.save_for_backward(ml)
+        ctx.kl_scale = kl_scale
+        _, kl = ops.reparam_kl_fwd(ml, None, kl_scale, want_z=False)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g_kl):
+        (ml,) = ctx.saved_tensors
+        return ops.reparam_kl_bwd(ml, None, None, g_kl.contiguous(), ctx.kl_scale), None
+
+
+class GaussianDkl:
+    """KL(N(mu, diag exp(logvar)) || N(0, I)) averaged over the batch [and over channels] (reference loss.py:46-66)."""
+
+    def __init__(self, normalize=True):
+        self.normalize = normalize
+
+    def __call__(self, mu1, logvar1, mu2=None, logvar2=None):
+        if mu2 is not None or logvar2 is not None:
+            raise NotImplementedError("General Dkl not implemented yet...")
+        return self.from_mu_logvar(torch.stack((mu1, logvar1), dim=1))
+
+    def from_mu_logvar(self, z_mu_logvar):
+        """Same value from the packed [B,2,D] encoder output (no re-packing copy)."""
+        B, _, D = z_mu_logvar.shape
+        kl_scale = 1.0 / B
+        if self.normalize:
+            kl_scale /= D
+        return _DklFn.apply(z_mu_logvar, kl_scale)

@@ -1,0 +1,268 @@
+"""Tensor-level wrappers over the C ABI (``include/pgv_hip.h``): torch supplies device memory and the current
+HIP stream, every arithmetic step runs in the hand-written gfx950 kernels.  No wrapper has a CPU path: tensors must
+be fp32, contiguous and on a ROCm device, otherwise a ``RuntimeError`` is raised."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PGV_ACT_HARDTANH, PGV_ACT_LEAKY_RELU, PGV_ACT_NONE, ConvDesc  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("preset-gen-vae_amd ops need tensors on a ROCm device (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("expected a contiguous (NCHW) tensor")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class ConvGeom:
+    """Geometry of one strided convolution between a big [B,Cb,Hb,Wb] and a small [B,Cs,Hs,Ws] tensor."""
+
+    def __init__(self, Cb, Cs, k, stride, pad, Hb, Wb):
+        self.Cb, self.Cs, self.k, self.stride, self.pad, self.Hb, self.Wb = Cb, Cs, k, stride, pad, Hb, Wb
+        self.Hs = (Hb + 2 * pad - k) // stride + 1
+        self.Ws = (Wb + 2 * pad - k) // stride + 1
+        self._descs = {}
+
+    def desc(self, B):
+        d = self._descs.get(B)
+        if d is None:
+            d = ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
+                         self.pad)
+            self._descs[B] = d
+        return d
+
+
+def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None):
+    B = big.shape[0]
+    if out is None:
+        out = torch.empty((B, geom.Cs, geom.Hs, geom.Ws), device=big.device, dtype=torch.float32)
+    _chk(big, w, bias, in_scale, in_shift, stats, out)
+    lib = _lib.load()
+    _lib.check(lib.pgv_conv_down(ctypes.byref(geom.desc(B)), _p(big), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
+                                 slope, _p(out), _p(stats), _stream()), "pgv_conv_down")
+    return out
+
+
+def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None):
+    B = small.shape[0]
+    if out is None:
+        out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
+    _chk(small, w, bias, in_scale, in_shift, stats, out)
+    lib = _lib.load()
+    _lib.check(lib.pgv_conv_up(ctypes.byref(geom.desc(B)), _p(small), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
+                               slope, _p(out), _p(stats), _stream()), "pgv_conv_up")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    if nbytes <= 0:
+        return None
+    key = (device.index,)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _ws_cache[key] = ws
+    return ws
+
+
+def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None):
+    B = big.shape[0]
+    _chk(big, small, gw, big_scale, big_shift, small_scale, small_shift)
+    lib = _lib.load()
+    d = geom.desc(B)
+    nbytes = lib.pgv_conv_wgrad_workspace(ctypes.byref(d))
+    ws = _workspace(big.device, nbytes)
+    _lib.check(lib.pgv_conv_wgrad(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small), _p(small_scale),
+                                  _p(small_shift), _p(gw), _p(ws), nbytes, _stream()), "pgv_conv_wgrad")
+    return gw
+
+
+def bn_stats(a, stats):
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(a, stats)
+    _lib.check(_lib.load().pgv_bn_stats(_p(a), B, C, HW, _p(stats), _stream()), "pgv_bn_stats")
+
+
+def bn_finalize(stats, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd):
+    C = stats.numel() // 2
+    _lib.check(_lib.load().pgv_bn_finalize(_p(stats), C, n, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+                                           _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd), _stream()),
+               "pgv_bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
+    C = running_mean.numel()
+    _chk(gamma, beta, running_mean, running_var, scale, shift)
+    _lib.check(_lib.load().pgv_bn_eval_affine(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(scale),
+                                              _p(shift), _stream()), "pgv_bn_eval_affine")
+
+
+def affine_nchw(a, scale, shift, out=None):
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    if out is None:
+        out = torch.empty_like(a)
+    _chk(a, scale, shift, out)
+    _lib.check(_lib.load().pgv_affine_nchw(_p(a), _p(scale), _p(shift), B, C, HW, _p(out), _stream()),
+               "pgv_affine_nchw")
+    return out
+
+
+def bn_bwd_reduce(g_o, a, mean, rstd, red):
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(g_o, a, mean, rstd, red)
+    _lib.check(_lib.load().pgv_bn_bwd_reduce(_p(g_o), _p(a), _p(mean), _p(rstd), B, C, HW, _p(red), _stream()),
+               "pgv_bn_bwd_reduce")
+
+
+def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias):
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(g_o, a, scale, mean, rstd, red, g_y, gbias)
+    _lib.check(_lib.load().pgv_act_bn_bwd(_p(g_o), _p(a), _p(scale), _p(mean), _p(rstd), _p(red), B, C, HW, act, slope,
+                                          _p(g_y), _p(gbias), _stream()), "pgv_act_bn_bwd")
+
+
+def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None):
+    _chk(A, Bm, C, bias_n)
+    _lib.check(_lib.load().pgv_gemm(M, N, K, _p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), ldc, _p(bias_n), None, 0,
+                                    _stream()), "pgv_gemm")
+    return C
+
+
+def linear_fwd(x, w, bias):
+    """y[M,N] = x[M,K] @ w[N,K]^T + bias  (nn.Linear)."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    return gemm(M, N, K, x, K, 1, w, 1, K, y, N, bias)
+
+
+def linear_dgrad(gy, w):
+    """gx[M,K] = gy[M,N] @ w[N,K]."""
+    M, N = gy.shape
+    K = w.shape[1]
+    gx = torch.empty((M, K), device=gy.device, dtype=torch.float32)
+    return gemm(M, K, N, gy, N, 1, w, K, 1, gx, K)
+
+
+def linear_wgrad(gy, x, gw):
+    """gw[N,K] = gy[M,N]^T @ x[M,K]."""
+    M, N = gy.shape
+    K = x.shape[1]
+    return gemm(N, K, M, gy, 1, N, x, K, 1, gw, K)
+
+
+def colsum(x, out):
+    M, N = x.shape
+    _chk(x, out)
+    _lib.check(_lib.load().pgv_colsum(_p(x), M, N, N, _p(out), _stream()), "pgv_colsum")
+    return out
+
+
+def dropout_mask(rng_state, stream_id, p, n, device):
+    mask = torch.empty(n, device=device, dtype=torch.float32)
+    _lib.check(_lib.load().pgv_dropout_mask(rng_state.data_ptr(), stream_id, p, n, _p(mask), _stream()),
+               "pgv_dropout_mask")
+    return mask
+
+
+def normal(rng_state, stream_id, shape, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    _lib.check(_lib.load().pgv_normal(rng_state.data_ptr(), stream_id, out.numel(), _p(out), _stream()), "pgv_normal")
+    return out
+
+
+def rng_advance(rng_state, inc):
+    _lib.check(_lib.load().pgv_rng_advance(rng_state.data_ptr(), inc, _stream()), "pgv_rng_advance")
+
+
+def mul(x, m, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(x, m, out)
+    _lib.check(_lib.load().pgv_mul(_p(x), _p(m), x.numel(), _p(out), _stream()), "pgv_mul")
+    return out
+
+
+def reparam_kl_fwd(ml, eps, kl_scale, want_z=True):
+    B, _, D = ml.shape
+    _chk(ml, eps)
+    z = torch.empty((B, D), device=ml.device, dtype=torch.float32) if want_z else None
+    kl = torch.empty((), device=ml.device, dtype=torch.float32)
+    _lib.check(_lib.load().pgv_reparam_kl_fwd(_p(ml), _p(eps), B, D, kl_scale, _p(z), _p(kl), _stream()),
+               "pgv_reparam_kl_fwd")
+    return z, kl
+
+
+def reparam_kl_bwd(ml, eps, g_z, g_kl, kl_scale):
+    B, _, D = ml.shape
+    _chk(ml, eps, g_z, g_kl)
+    g_ml = torch.empty_like(ml)
+    _lib.check(_lib.load().pgv_reparam_kl_bwd(_p(ml), _p(eps), _p(g_z), _p(g_kl), B, D, kl_scale, _p(g_ml), _stream()),
+               "pgv_reparam_kl_bwd")
+    return g_ml
+
+
+def sqerr_fwd(xhat, x, scale):
+    _chk(xhat, x)
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().pgv_sqerr_fwd(_p(xhat), _p(x), x.numel(), scale, _p(loss), _stream()), "pgv_sqerr_fwd")
+    return loss
+
+
+def sqerr_bwd(xhat, x, g_loss, scale, hardtanh=False):
+    _chk(xhat, x, g_loss)
+    g = torch.empty_like(xhat)
+    _lib.check(_lib.load().pgv_sqerr_bwd(_p(xhat), _p(x), _p(g_loss), x.numel(), scale, int(hardtanh), _p(g),
+                                         _stream()), "pgv_sqerr_bwd")
+    return g
+
+
+def adam_step(p, g, m, v, hyper, beta1, beta2, eps, weight_decay):
+    _chk(p, g, m, v, hyper)
+    _lib.check(_lib.load().pgv_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps,
+                                         weight_decay, _stream()), "pgv_adam_step")
+
+
+def stft_mel(wav, hop, n_frames, window, norm, mel_csr, n_mels, floor_lin, affine_a, affine_b):
+    B, n = wav.shape
+    _chk(wav, window)
+    rows = n_mels if n_mels > 0 else 513
+    out = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.float32)
+    rp, col, val = mel_csr if mel_csr is not None else (None, None, None)
+    _lib.check(_lib.load().pgv_stft_mel(_p(wav), B, n, 1024, hop, n_frames, _p(window), norm,
+                                        None if rp is None else rp.data_ptr(), None if col is None else col.data_ptr(),
+                                        _p(val), n_mels, floor_lin, affine_a, affine_b, _p(out), _stream()),
+               "pgv_stft_mel")
+    return out
+
+
+def fill(t, v):
+    _chk(t)
+    _lib.check(_lib.load().pgv_fill(_p(t), t.numel(), v, _stream()), "pgv_fill")
+
+
+def copy(src, dst):
+    _chk(src, dst)
+    _lib.check(_lib.load().pgv_copy(_p(src), _p(dst), src.numel(), _stream()), "pgv_copy")

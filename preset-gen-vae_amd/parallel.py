@@ -1,0 +1,90 @@
+"""Data-parallel minibatch sharding: one process per GPU, persistent model replicas, bucketed gradient all-reduce
+over RCCL (xGMI) overlapped with the rest of backward.
+
+The reference's multi-GPU mode is single-process ``nn.DataParallel`` (train.py:95-97): per step it scatters the batch,
+re-broadcasts all parameters, gathers the outputs to one GPU and reduce-adds the replica gradients there
+(SURVEY.md §2.3).  Here every rank owns its shard of the minibatch and a full replica; the only exchange is the SUM
+all-reduce of the flat gradient buffer (``optim.FlatParams``), scaled by 1/world_size inside the fused Adam kernel
+(mean of shard-means == global mean for equal shards, so losses/gradients match the gathered-batch arithmetic of
+train.py:222-225).  BatchNorm batch statistics stay per rank, exactly like DataParallel's per-replica BN.
+
+Buckets are contiguous slices of the flat gradient in gradient-ready order (decoder output layer first).  When the
+last gradient of a bucket has been launched on the compute stream, an event is recorded and the bucket's all-reduce is
+enqueued on a dedicated communication stream; ``wait()`` joins the streams before the optimizer step.  xGMI is
+point-to-point (7 links/GPU), so a few large buckets (default 4 over 19.7-49.8 MB) are preferred to many small ones.
+"""
+import torch
+import torch.distributed as dist
+
+from .model import layer
+
+
+class GradAllReduce:
+    def __init__(self, flat, n_buckets=4, process_group=None):
+        self.flat = flat
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.ranges = flat.bucket_ranges(n_buckets)
+        self._bucket_of = {}
+        self._need = []
+        for bi, (lo, hi) in enumerate(self.ranges):
+            ps = flat.params_in_range(lo, hi)
+            self._need.append(len(ps))
+            for p in ps:
+                self._bucket_of[id(p)] = bi
+        self._done = [0] * len(self.ranges)
+        self._launched = [False] * len(self.ranges)
+        self.use_cuda = flat.flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat.flat_grad.device) if self.use_cuda else None
+        self._works = []
+
+    # -- hooks ---------------------------------------------------------------------------------------------
+    def install(self):
+        layer.GRAD_READY_HOOK = self._on_grad_ready
+        return self
+
+    def uninstall(self):
+        if layer.GRAD_READY_HOOK == self._on_grad_ready:
+            layer.GRAD_READY_HOOK = None
+
+    def start_step(self):
+        self._done = [0] * len(self.ranges)
+        self._launched = [False] * len(self.ranges)
+        self._works = []
+
+    def _on_grad_ready(self, p):
+        bi = self._bucket_of.get(id(p))
+        if bi is None:
+            return
+        self._done[bi] += 1
+        if self._done[bi] >= self._need[bi] and not self._launched[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        if self.world_size == 1:
+            return
+        lo, hi = self.ranges[bi]
+        buf = self.flat.flat_grad[lo:hi]
+        if self.use_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo / CPU tests
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Flush buckets whose parameters produced no gradient this step, then join communication."""
+        for bi in range(len(self.ranges)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        if self.world_size == 1:
+            return
+        if self.use_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w in self._works:
+                w.wait()
+            self._works = []

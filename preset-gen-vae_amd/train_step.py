@@ -1,0 +1,90 @@
+"""The VAE train step — harness counterpart of the reference's minibatch body (train.py:203-248):
+
+    optimizer.zero_grad(); ae_out = model(x); recons = MSE(x_out, x); lat = latent_loss(...) * beta;
+    (recons + lat [+ controls]).backward(); optimizer.step()
+
+Everything between the input tensor and the updated parameters runs in the HIP kernels; this class only sequences
+them, optionally capturing the whole step into one hipGraph (``torch.cuda.CUDAGraph`` records the launches our C ABI
+makes on the capturing stream) so the ~100 launches replay without host involvement, and optionally exchanging
+gradients across ranks (``parallel.GradAllReduce``)."""
+import torch
+
+from . import optim as optim_mod
+from .model import loss as loss_mod
+
+
+class VAETrainStep:
+    def __init__(self, ae_model, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, beta=0.2, normalize_losses=True,
+                 reg_model=None, grad_sync=None, use_graph=False):
+        self.model = ae_model
+        self.reg_model = reg_model
+        self.beta = float(beta)
+        params = list(ae_model.parameters()) + (list(reg_model.parameters()) if reg_model is not None else [])
+        self.flat = optim_mod.FlatParams(params)
+        world = 1
+        self.grad_sync = None
+        if grad_sync is not None:
+            self.grad_sync = grad_sync(self.flat) if callable(grad_sync) else grad_sync
+            world = self.grad_sync.world_size
+            self.grad_sync.install()
+        self.optimizer = optim_mod.FusedAdam(self.flat, lr=lr, betas=betas, weight_decay=weight_decay,
+                                             grad_scale=1.0 / world)
+        if normalize_losses:   # train.py:103-106
+            self.recons_criterion = loss_mod.MSELoss(reduction='mean')
+        else:
+            self.recons_criterion = loss_mod.L2Loss()
+        self.controls_criterion = loss_mod.MSELoss(reduction='mean')
+        self.use_graph = use_graph
+        self._graph = None
+        self._static_x = None
+        self._static_v = None
+        self._out = None
+
+    # -- one eager step --------------------------------------------------------------------------------------
+    def _step_body(self, x, v_in=None, inject=None):
+        inject = inject or {}
+        self.optimizer.zero_grad()
+        if self.grad_sync is not None:
+            self.grad_sync.start_step()
+        z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
+        recons = self.recons_criterion(x_out, x)
+        lat = self.model.latent_loss(z_mu_logvar, z0, zK, ladj)
+        total = recons + lat * self.beta
+        cont = None
+        if self.reg_model is not None and v_in is not None:
+            v_out = self.reg_model(zK)
+            cont = self.controls_criterion(v_out, v_in)
+            total = total + cont
+        total.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+        self.optimizer.step()
+        return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(),
+                'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
+                'x_out': x_out.detach()}
+
+    def step(self, x, v_in=None, inject=None):
+        if not self.use_graph or inject:
+            return self._step_body(x, v_in, inject)
+        if self._graph is None:
+            self._capture(x, v_in)
+        self._static_x.copy_(x, non_blocking=True)
+        if v_in is not None:
+            self._static_v.copy_(v_in, non_blocking=True)
+        self._graph.replay()
+        return self._out
+
+    def _capture(self, x, v_in):
+        self._static_x = x.clone()
+        self._static_v = None if v_in is None else v_in.clone()
+        # warm-up on a side stream (allocator pools, lazy module state), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._step_body(self._static_x, self._static_v)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._step_body(self._static_x, self._static_v)

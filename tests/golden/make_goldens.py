@@ -1,0 +1,306 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (gwendal-lv/preset-gen-vae, mounted
+read-only at /root/reference) in the build container.  Runs only here (the reference does not exist on the GPU box);
+the resulting small .npz fixtures are committed, the reference's sources are not.
+
+Recipe: stub the absent third-party imports (nflows, librosa, soundfile), import
+model/{layer,encoder,decoder,VAE,loss}.py and utils/audio.py, load closed-form weights (oracle.vae_oracle.
+closed_form_state_dict — a formula, not an RNG stream), inject eps (patched ``Normal``) and the two Dropout masks
+(swapped mask modules), run in float64, record outputs / losses / gradients / post-Adam parameters.
+
+    python tests/golden/make_goldens.py
+"""
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+for name in ['nflows', 'nflows.flows', 'nflows.flows.realnvp', 'nflows.flows.base', 'nflows.transforms',
+             'nflows.transforms.base', 'nflows.transforms.autoregressive', 'nflows.transforms.permutations',
+             'nflows.transforms.coupling', 'nflows.transforms.normalization', 'nflows.nn', 'nflows.nn.nets',
+             'nflows.distributions', 'nflows.distributions.normal', 'librosa', 'librosa.display', 'soundfile']:
+    sys.modules[name] = mock.MagicMock()
+
+from model import VAE as ref_VAE  # noqa: E402
+from model import decoder as ref_decoder  # noqa: E402
+from model import encoder as ref_encoder  # noqa: E402
+from model import layer as ref_layer  # noqa: E402
+from model import loss as ref_loss  # noqa: E402
+from utils import audio as ref_audio  # noqa: E402
+
+from oracle import vae_oracle as vo  # noqa: E402  (only for the closed-form weight/input formulas)
+
+torch.set_num_threads(8)
+
+
+def synth_input(B, H=257, W=347, dtype=torch.float64):
+    """Spectrogram-like deterministic input in [-1, 1] (floor rows at -1, ridges near +1)."""
+    b = torch.arange(B, dtype=torch.float64).view(B, 1, 1, 1)
+    h = torch.arange(H, dtype=torch.float64).view(1, 1, H, 1)
+    w = torch.arange(W, dtype=torch.float64).view(1, 1, 1, W)
+    x = torch.sin(0.05 * h * (1 + 0.3 * b) + 0.5 * b) * torch.cos(0.021 * w + 0.1 * b) * torch.exp(-w / 300.0)
+    x = x + 0.3 * torch.sin(0.37 * h + 0.11 * w * (1 + b))
+    return torch.clamp(x * 1.2 - 0.2, -1.0, 1.0).to(dtype)
+
+
+def synth_vec(shape, a, ph, dtype=torch.float64):
+    n = int(np.prod(shape))
+    return torch.sin(torch.arange(n, dtype=torch.float64) * a + ph).reshape(shape).to(dtype)
+
+
+def keep_mask(shape, p, a, ph):
+    u = 0.5 * (synth_vec(shape, a, ph) + 1.0)            # in [0,1], arcsine-distributed: fine for a fixed mask
+    u = (u * 7919.0) % 1.0                               # scramble
+    return (u >= p).to(torch.float64) / (1.0 - p)
+
+
+class _MaskMul(nn.Module):
+    """Stands in for nn.Dropout inside the reference model so the mask is known."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask.reshape(x.shape) if self.training else x
+
+
+class _FixedNormal:
+    eps = None
+
+    def __init__(self, *a, **k):
+        pass
+
+    def sample(self):
+        return _FixedNormal.eps
+
+
+def checksum(t):
+    t = t.detach().double().reshape(-1)
+    n = t.numel()
+    idx = torch.linspace(0, n - 1, steps=min(n, 64)).long()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.abs().max().item()]), t[idx].numpy(), idx.numpy()
+
+
+def pack_big(prefix, t, out):
+    cs, sample, idx = checksum(t)
+    out[prefix + '/checksum'] = cs
+    out[prefix + '/sample'] = sample
+    out[prefix + '/sample_idx'] = idx
+
+
+class FourLayerEncoder(nn.Module):
+    """BASELINE.json's 4-layer stack assembled from the reference's OWN layer.Conv2D blocks with the hyper-parameters
+    of encoder.py:241-248, followed by Dropout -> Linear (encoder.py:85), reshape (encoder.py:108)."""
+
+    def __init__(self, dim_z, output_bn):
+        super().__init__()
+        act = nn.LeakyReLU
+        self.single_ch_cnn = nn.Module()
+        self.single_ch_cnn.enc_nn = nn.Sequential(
+            ref_layer.Conv2D(1, 8, [5, 5], [2, 2], 2, [1, 1], batch_norm=None, activation=act(0.1), name_prefix='enc1'),
+            ref_layer.Conv2D(8, 16, [4, 4], [2, 2], 2, [1, 1], activation=act(0.1), name_prefix='enc2'),
+            ref_layer.Conv2D(16, 32, [4, 4], [2, 2], 2, [1, 1], activation=act(0.1), name_prefix='enc3'),
+            ref_layer.Conv2D(32, 64, [4, 4], [2, 2], 2, [1, 1], activation=act(0.1), name_prefix='enc4'))
+        self.mlp = nn.Sequential(nn.Dropout(0.3), nn.Linear(64 * 17 * 23, 2 * dim_z))
+        if output_bn:
+            self.mlp.add_module('lat_in_regularization', nn.BatchNorm1d(2 * dim_z))
+        self.dim_z = dim_z
+
+    def forward(self, x):
+        h = self.single_ch_cnn.enc_nn(x).view(x.shape[0], -1)
+        return torch.reshape(self.mlp(h), (x.shape[0], 2, self.dim_z))
+
+
+class FourLayerDecoder(nn.Module):
+    """Mirror: Linear -> Dropout (decoder.py:64-65) -> dec5..dec7 (decoder.py:212-217) -> ConvTranspose2d(8,1,5,2,2)
+    -> Hardtanh (decoder.py:218-219), from the reference's own layer.TConv2D."""
+
+    def __init__(self, dim_z):
+        super().__init__()
+        act = nn.LeakyReLU
+        self.mlp = nn.Sequential(nn.Linear(dim_z, 64 * 17 * 23), nn.Dropout(0.3))
+        self.single_ch_cnn = nn.Module()
+        self.single_ch_cnn.dec_nn = nn.Sequential(
+            ref_layer.TConv2D(64, 32, [4, 4], [2, 2], 2, output_padding=[1, 1], activation=act(0.1), name_prefix='dec5'),
+            ref_layer.TConv2D(32, 16, [4, 4], [2, 2], 2, output_padding=[1, 0], activation=act(0.1), name_prefix='dec6'),
+            ref_layer.TConv2D(16, 8, [4, 4], [2, 2], 2, output_padding=[1, 0], activation=act(0.1), name_prefix='dec7'),
+            nn.ConvTranspose2d(8, 1, [5, 5], [2, 2], 2), nn.Hardtanh())
+
+    def forward(self, z):
+        return self.single_ch_cnn.dec_nn(self.mlp(z).view(-1, 64, 17, 23))
+
+
+def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False):
+    size = (B, 1, 257, 347)
+    if arch == 'speccnn8l1_bn':
+        enc = ref_encoder.SpectrogramEncoder(arch, dim_z, size, 0.3, output_bn=output_bn,
+                                             deepest_features_mix=deepest_mix)
+        dec = ref_decoder.SpectrogramDecoder(arch, dim_z, size, 0.3)
+    else:
+        enc, dec = FourLayerEncoder(dim_z, output_bn), FourLayerDecoder(dim_z)
+    return ref_VAE.BasicVAE(enc, dim_z, dec, True, 'Dkl')
+
+
+def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir):
+    vae = build_reference_vae(arch, dim_z, B, output_bn).double()
+    template = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    sd = vo.closed_form_state_dict(template, seed=1234, dtype=torch.float64)
+    vae.load_state_dict(sd)
+    x = synth_input(B)
+    eps = synth_vec((B, dim_z), 1.2345, 0.4) * 1.3
+    feat_enc = vae.encoder.mlp[1].in_features
+    feat_dec = vae.decoder.mlp[0].out_features
+    enc_mask = keep_mask((B, feat_enc), 0.3, 0.7071, 0.1)
+    dec_mask = keep_mask((B, feat_dec), 0.3, 0.5772, 0.9)
+    vae.encoder.mlp[0] = _MaskMul(enc_mask)
+    vae.decoder.mlp[1] = _MaskMul(dec_mask)
+    _FixedNormal.eps = eps
+    out = {'meta/arch': np.array(arch), 'meta/dim_z': np.array(dim_z), 'meta/B': np.array(B),
+           'meta/output_bn': np.array(output_bn), 'meta/seed': np.array(1234), 'meta/beta': np.array(0.2),
+           'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4),
+           'in/eps': eps.numpy(), 'in/enc_mask_bits': np.packbits((enc_mask > 0).numpy()),
+           'in/dec_mask_bits': np.packbits((dec_mask > 0).numpy()),
+           'in/enc_mask_shape': np.array(enc_mask.shape), 'in/dec_mask_shape': np.array(dec_mask.shape)}
+    # ---- eval-mode forward (train.py:261-291 semantics: z = mu, BN running stats, no dropout)
+    vae.eval()
+    with torch.no_grad():
+        zml, z, _, _, x_out = vae(x)
+    out['eval/z_mu_logvar'] = zml.numpy()
+    pack_big('eval/x_out', x_out, out)
+    # ---- one train step (train.py:203-248 without the regression net)
+    vae.train()
+    opt = torch.optim.Adam(vae.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    with mock.patch.object(ref_VAE, 'Normal', _FixedNormal):
+        opt.zero_grad()
+        zml, z, zk, ladj, x_out = vae(x)
+        recons = nn.MSELoss(reduction='mean')(x_out, x)
+        lat = vae.latent_loss(zml)
+        lat_unnorm = ref_loss.GaussianDkl(normalize=False)(zml[:, 0, :], zml[:, 1, :])
+        l2 = ref_loss.L2Loss()(x_out, x)
+        total = recons + 0.2 * lat
+        total.backward()
+    out['train/z_mu_logvar'] = zml.detach().numpy()
+    out['train/z'] = z.detach().numpy()
+    out['train/recons'] = np.array(recons.item())
+    out['train/latent'] = np.array(lat.item())
+    out['train/latent_unnormalized'] = np.array(lat_unnorm.item())
+    out['train/l2loss'] = np.array(l2.item())
+    out['train/total'] = np.array(total.item())
+    pack_big('train/x_out', x_out, out)
+    for k, p in vae.named_parameters():
+        pack_big('grad/' + k, p.grad, out)
+    opt.step()
+    for k, v in vae.state_dict().items():
+        if v.dtype == torch.long:
+            out['post/' + k] = v.numpy()
+        elif v.numel() <= 4096:
+            out['post_full/' + k] = v.detach().numpy()
+        else:
+            pack_big('post/' + k, v, out)
+    path = os.path.join(out_dir, tag + '.npz')
+    np.savez_compressed(path, **out)
+    print(tag, 'recons', recons.item(), 'lat', lat.item(), '->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def run_layer_cases(out_dir):
+    """Every Conv2D/TConv2D configuration of the reference tables on small inputs, stored whole (fwd + grads)."""
+    out = {}
+    cases = []
+    for (name, ci, co, k, s, p, bn) in vo.ENC_TABLE:
+        cases.append(('conv', name, ci, co, k, s, p, (0, 0), bn))
+    for (name, ci, co, k, s, p, op, bn) in vo.DEC_TABLE:
+        cases.append(('tconv', name, ci, co, k, s, p, op, bn))
+    cases.append(('tconv_last', 'dec8', 8, 1, 5, 2, 2, (0, 0), False))
+    for kind, name, ci, co, k, s, p, op, bn in cases:
+        ci_s, co_s = min(ci, 12), min(co, 10)        # channel-reduced copies keep the fixture small
+        B, H, W = 3, (9 if kind == 'conv' else 5), (11 if kind == 'conv' else 6)
+        if kind == 'conv':
+            blk = ref_layer.Conv2D(ci_s, co_s, [k, k], [s, s], p, [1, 1], activation=nn.LeakyReLU(0.1),
+                                   name_prefix=name, batch_norm=('after' if bn else None))
+        elif kind == 'tconv':
+            blk = ref_layer.TConv2D(ci_s, co_s, [k, k], [s, s], p, output_padding=list(op),
+                                    activation=nn.LeakyReLU(0.1), name_prefix=name,
+                                    batch_norm=('after' if bn else None))
+        else:
+            blk = nn.Sequential(nn.ConvTranspose2d(ci_s, co_s, [k, k], [s, s], p), nn.Hardtanh())
+        blk = blk.double().train()
+        template = {kk: tuple(v.shape) for kk, v in blk.state_dict().items()}
+        sd = vo.closed_form_state_dict(template, seed=77, dtype=torch.float64)
+        blk.load_state_dict(sd)
+        x = (synth_vec((B, ci_s, H, W), 0.9137, 0.3) * 1.5).requires_grad_(True)
+        y = blk(x)
+        gy = synth_vec(tuple(y.shape), 0.7719, 1.1)
+        y.backward(gy)
+        pre = f'{name}/'
+        out[pre + 'kind'] = np.array(kind)
+        out[pre + 'cfg'] = np.array([ci_s, co_s, k, s, p, op[0], op[1], int(bn)])
+        out[pre + 'x'] = x.detach().numpy()
+        out[pre + 'gy'] = gy.numpy()
+        out[pre + 'y'] = y.detach().numpy()
+        out[pre + 'gx'] = x.grad.numpy()
+        for kk, v in blk.named_parameters():
+            out[pre + 'grad/' + kk] = v.grad.numpy()
+        for kk, v in blk.state_dict().items():
+            out[pre + 'sd_in/' + kk] = sd[kk].numpy()
+            out[pre + 'sd_out/' + kk] = v.detach().numpy()
+    path = os.path.join(out_dir, 'layers_small.npz')
+    np.savez_compressed(path, **out)
+    print('layers ->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def synth_wave(n=88576, sr=22050, idx=0):
+    """Dexed-like FM voice: sin(2 pi fc t + I sin(2 pi fm t)) * ADSR, note-off at 3.0 s."""
+    t = np.arange(n, dtype=np.float64) / sr
+    fc = 261.63 * [0.5, 1.0, 2.0, 3.0][idx % 4]
+    fm = fc * [1.0, 2.0, 3.5, 0.5][(idx // 4) % 4]
+    I = 1.0 + 7.0 * ((idx * 37) % 11) / 10.0
+    env = np.minimum(1.0, t / 0.01) * np.exp(-t * (0.3 + 0.2 * (idx % 3)))
+    rel = np.where(t > 3.0, np.exp(-(t - 3.0) * 6.0), 1.0)
+    fade = np.ones(n)
+    nf = min(n, 2205)
+    fade[-nf:] = np.linspace(1.0, 0.0, nf)
+    return (0.9 * np.sin(2 * np.pi * fc * t + I * np.sin(2 * np.pi * fm * t)) * env * rel * fade).astype(np.float32)
+
+
+def run_stft_cases(out_dir):
+    """Reference utils/audio.py Spectrogram (pure torch) on seeded FM audio: STFT magnitude / norm factor / window /
+    log-scale.  The mel stage (librosa, not installed) cannot be run: parity for the filterbank is unpinned."""
+    spec = ref_audio.Spectrogram(1024, 256, -120.0)
+    out = {'window': spec.window.numpy(), 'norm_factor': np.array(spec.spectrogram_norm_factor)}
+    for idx in range(3):
+        wav = synth_wave(idx=idx)
+        stft = spec.get_stft(wav.astype(np.float64))
+        mag = (stft.abs() / spec.spectrogram_norm_factor)
+        db = spec(wav.astype(np.float64))
+        assert tuple(db.shape) == (513, 347)
+        frames = [0, 1, 2, 100, 173, 344, 345, 346]
+        out[f'wave{idx}/frames'] = np.array(frames)
+        out[f'wave{idx}/mag'] = mag[:, frames].numpy()
+        out[f'wave{idx}/db'] = db[:, frames].numpy()
+        out[f'wave{idx}/db_checksum'] = np.array([db.double().sum().item(), db.double().abs().sum().item(),
+                                                  db.max().item(), db.min().item()])
+    # short waveform: ragged/edge case (fewer samples than one FFT)
+    short = synth_wave(n=700, idx=5)
+    out['short/db'] = spec(short.astype(np.float64)).numpy()
+    path = os.path.join(out_dir, 'stft.npz')
+    np.savez_compressed(path, **out)
+    print('stft ->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    run_layer_cases(HERE)
+    run_stft_cases(HERE)
+    run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2', HERE)
+    run_vae_case('speccnn8l1_bn', 64, 2, True, 'vae8l_b2_outbn', HERE)
+    run_vae_case('speccnn4l1_bn', 64, 2, False, 'vae4l_b2', HERE)

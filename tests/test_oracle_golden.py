@@ -1,0 +1,188 @@
+"""CPU tier 1: the oracle (oracle/) reproduces the golden vectors generated from the real reference
+(tests/golden/*.npz, made by tests/golden/make_goldens.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_big, load_golden, rel_l2, synth_input, unpack_mask
+from oracle import audio_oracle as ao
+from oracle import vae_oracle as vo
+
+
+def _template_from_golden(g):
+    tpl = {}
+    for k in g.files:
+        if k.startswith('post_full/'):
+            tpl[k[len('post_full/'):]] = tuple(g[k].shape)
+        elif k.startswith('post/') and k.endswith('/checksum'):
+            tpl[k[len('post/'):-len('/checksum')]] = None
+        elif k.startswith('post/') and k.endswith('num_batches_tracked'):
+            tpl[k[len('post/'):]] = ()
+    return tpl
+
+
+def _param_shapes(arch, dim_z, output_bn):
+    """Reference state-dict template (key order as the reference registers them), from the layer tables."""
+    enc_rows, dec_rows, cnn_in = vo.arch_tables(arch)
+    tpl = {}
+
+    def bn(prefix, c):
+        tpl[prefix + '.weight'] = (c,)
+        tpl[prefix + '.bias'] = (c,)
+        tpl[prefix + '.running_mean'] = (c,)
+        tpl[prefix + '.running_var'] = (c,)
+        tpl[prefix + '.num_batches_tracked'] = ()
+
+    for i, (name, ci, co, k, s, p, has_bn) in enumerate(enc_rows):
+        if arch == 'speccnn8l1_bn' and name == 'enc7':
+            base = 'encoder.features_mixer_cnn.0.'
+        elif arch == 'speccnn8l1_bn' and name == 'enc8':
+            base = 'encoder.features_mixer_cnn.1.'
+        else:
+            base = f'encoder.single_ch_cnn.enc_nn.{i}.'
+        tpl[base + name + 'conv.weight'] = (co, ci, k, k)
+        tpl[base + name + 'conv.bias'] = (co,)
+        if has_bn:
+            bn(base + name + 'bn', co)
+    feat = enc_rows[-1][2] * (3 * 4 if arch == 'speccnn8l1_bn' else 17 * 23)
+    tpl['encoder.mlp.1.weight'] = (2 * dim_z, feat)
+    tpl['encoder.mlp.1.bias'] = (2 * dim_z,)
+    if output_bn:
+        bn('encoder.mlp.lat_in_regularization', 2 * dim_z)
+    tpl['decoder.mlp.0.weight'] = (int(np.prod(cnn_in)), dim_z)
+    tpl['decoder.mlp.0.bias'] = (int(np.prod(cnn_in)),)
+    j = 0
+    for (name, ci, co, k, s, p, op, has_bn) in dec_rows:
+        if name == 'dec1':
+            base = 'decoder.features_unmixer_cnn.'
+        else:
+            base = f'decoder.single_ch_cnn.dec_nn.{j}.'
+            j += 1
+        tpl[base + name + 'tconv.weight'] = (ci, co, k, k)
+        tpl[base + name + 'tconv.bias'] = (co,)
+        if has_bn:
+            bn(base + name + 'bn', co)
+    tpl[f'decoder.single_ch_cnn.dec_nn.{j}.weight'] = (8, 1, 5, 5)
+    tpl[f'decoder.single_ch_cnn.dec_nn.{j}.bias'] = (1,)
+    return tpl
+
+
+def reference_template(g):
+    """Template in the REFERENCE's registration order (the closed-form weights depend on the key index)."""
+    arch, dim_z, output_bn = str(g['meta/arch']), int(g['meta/dim_z']), bool(g['meta/output_bn'])
+    tpl = _param_shapes(arch, dim_z, output_bn)
+    want = set(_template_from_golden(g).keys())
+    assert set(tpl.keys()) == want, (sorted(set(tpl) ^ want))
+    return tpl
+
+
+@pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz"])
+def test_train_step_matches_reference(name):
+    g = load_golden(name)
+    arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
+    tpl = reference_template(g)
+    sd = vo.closed_form_state_dict(tpl, seed=int(g['meta/seed']), dtype=torch.float64)
+    x = synth_input(B)
+    eps = torch.tensor(g['in/eps'])
+    enc_mask, dec_mask = unpack_mask(g, 'enc'), unpack_mask(g, 'dec')
+    # eval-mode forward
+    zml, _, _, _, x_out = vo.vae_forward(sd, x, arch, dim_z, training=False)
+    assert rel_l2(zml, torch.tensor(g['eval/z_mu_logvar'])) < 1e-10
+    check_big('eval x_out', x_out, g, 'eval/x_out', 1e-9)
+    # one train step
+    r = vo.train_step(sd, x, arch, dim_z, eps, enc_mask, dec_mask, beta=float(g['meta/beta']),
+                      lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']))
+    assert rel_l2(r['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < 1e-10
+    assert rel_l2(r['z'], torch.tensor(g['train/z'])) < 1e-10
+    for key in ('recons', 'latent', 'total'):
+        assert abs(r[key].item() - float(g['train/' + key])) <= 1e-10 * abs(float(g['train/' + key]))
+    zml_t = r['z_mu_logvar']
+    assert abs(vo.gaussian_dkl(zml_t[:, 0], zml_t[:, 1], normalize=False).item()
+               - float(g['train/latent_unnormalized'])) < 1e-10
+    assert abs(vo.l2_loss(r['x_out'], x).item() - float(g['train/l2loss'])) < 1e-9 * float(g['train/l2loss'])
+    check_big('x_out', r['x_out'], g, 'train/x_out', 1e-9)
+    for k, gr in r['grads'].items():
+        check_big('grad ' + k, gr, g, 'grad/' + k, 1e-8)
+    for k, v in r['new_sd'].items():
+        if 'post_full/' + k in g.files:
+            ref = torch.tensor(g['post_full/' + k])
+            assert (v.double() - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item()), k
+        elif 'post/' + k + '/checksum' in g.files:
+            check_big('post ' + k, v, g, 'post/' + k, 1e-9)
+
+
+def test_layer_blocks_match_reference():
+    g = load_golden('layers_small.npz')
+    names = sorted({k.split('/')[0] for k in g.files})
+    assert len(names) == 16
+    for name in names:
+        kind = str(g[name + '/kind'])
+        ci, co, k, s, p, oph, opw, bn = (int(v) for v in g[name + '/cfg'])
+        sd = {kk[len(name + '/sd_in/'):]: torch.tensor(g[kk]) for kk in g.files if kk.startswith(name + '/sd_in/')}
+        x = torch.tensor(g[name + '/x']).requires_grad_(True)
+        params = {kk: v.clone().requires_grad_(True) for kk, v in sd.items() if vo.is_parameter_key(kk)}
+        full = dict(sd)
+        full.update(params)
+        nb = {}
+        if kind == 'conv':
+            y = vo.conv_block(x, full, (name, ci, co, k, s, p, bool(bn)), '', True, nb)
+        elif kind == 'tconv':
+            y = vo.tconv_block(x, full, (name, ci, co, k, s, p, (oph, opw), bool(bn)), '', True, nb)
+        else:
+            y = torch.nn.functional.hardtanh(torch.nn.functional.conv_transpose2d(
+                x, full['0.weight'], full['0.bias'], stride=s, padding=p))
+        assert rel_l2(y, torch.tensor(g[name + '/y'])) < 1e-11, name
+        y.backward(torch.tensor(g[name + '/gy']))
+        assert rel_l2(x.grad, torch.tensor(g[name + '/gx'])) < 1e-10, name
+        for kk, v in params.items():
+            assert rel_l2(v.grad, torch.tensor(g[name + '/grad/' + kk])) < 1e-10, (name, kk)
+        for suffix, val in nb.items():
+            ref = [g[kk] for kk in g.files if kk.startswith(name + '/sd_out/') and kk.endswith(suffix)]
+            assert len(ref) == 1 and rel_l2(val, torch.tensor(ref[0])) < 1e-11, (name, suffix)
+
+
+def test_stft_matches_reference_spectrogram():
+    g = load_golden('stft.npz')
+    assert np.abs(ao.hann_symmetric(1024) - g['window']).max() < 1e-6     # reference window is float32
+    assert abs(ao.norm_factor(ao.hann_symmetric(1024)) - float(g['norm_factor'])) < 1e-3
+    assert abs(float(g['norm_factor']) - 511.5) < 1e-3
+    for idx in range(3):
+        wav = ao.synth_fm_wave(idx=idx)
+        frames = g[f'wave{idx}/frames']
+        mag = ao.spectrogram_mag(wav)
+        assert mag.shape == (513, 347)
+        ref_mag = g[f'wave{idx}/mag']            # reference: float32 torch.stft
+        # fp32 STFT noise floor: absolute error relative to the frame's largest bin
+        err = np.abs(mag[:, frames] - ref_mag).max(axis=0) / np.maximum(ref_mag.max(axis=0), 1e-12)
+        assert err.max() < 5e-6, err
+        db = ao.spectrogram_db(wav)
+        ref_db = g[f'wave{idx}/db']
+        strong = ref_mag > 1e-4                   # above -80 dB the fp32 reference is accurate to << 0.01 dB
+        assert np.abs(db[:, frames] - ref_db)[strong].max() < 2e-2
+        cs = g[f'wave{idx}/db_checksum']
+        assert abs(db.max() - cs[2]) < 1e-3 and abs(db.min() - cs[3]) < 1e-3
+    short = ao.spectrogram_db(ao.synth_fm_wave(n=700, idx=5))
+    assert short.shape == g['short/db'].shape == (513, 3)
+    m = g['short/db'] > -80
+    assert np.abs(short - g['short/db'])[m].max() < 2e-2
+
+
+def test_mel_filterbank_known_answers():
+    """SURVEY.md §2.2 known answers of the Slaney basis (librosa itself is not installed: parity unpinned)."""
+    fb = ao.mel_filterbank()
+    assert fb.shape == (257, 513) and fb.dtype == np.float32
+    assert int((fb != 0).sum()) == 1016
+    assert (fb != 0).sum(axis=1).max() == 14 and (fb != 0).sum(axis=1).min() >= 1
+    assert fb[:, 0].max() == 0 and fb[:, 512].max() == 0
+    np.testing.assert_allclose(fb[0, 1], 0.330345, atol=2e-6)
+    np.testing.assert_allclose(fb[1, 1], 0.669655, atol=2e-6)
+    np.testing.assert_allclose(fb[2, 2], 0.660689, atol=2e-6)
+    np.testing.assert_allclose(fb[128, 91:94], [0.116312, 0.938339, 0.249680], atol=2e-6)
+    np.testing.assert_allclose(fb[256].sum(), 6.71158, atol=2e-5)
+    np.testing.assert_allclose(fb.sum(), 508.1044, atol=2e-3)
+    assert fb.sum(axis=0).max() <= 1.0 + 1e-6
+
+
+def test_minmax_normalisation():
+    s = np.array([-120.0, -60.0, 0.0])
+    np.testing.assert_allclose(ao.minmax_normalize(s, -120.0, 0.0), [-1.0, 0.0, 1.0])
