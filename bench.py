@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Headline benchmark: spectrograms/s for one full VAE train step (zero_grad -> fwd -> MSE + beta*KL -> bwd -> Adam)
+on [256,1,257,347] fp32 log-mel inputs per GPU (BASELINE.json ``metric``; workload = ``configs[1]``: the 4-layer
+conv-VAE, z=64, fp32, batch 256; ``--arch speccnn8l1_bn`` runs the reference-exact 8-layer stack instead).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One rank per GPU; each rank owns a 256-row shard (weak scaling), gradients are summed by RCCL all-reduce buckets.
+Rank 0 prints ONE JSON line with the contract fields plus ``roofline`` (dominant kernel, measured live with HIP events
+on the launch stream) and ``cpu_baseline`` (the oracle's train step on the host cores, bounded sample, N=1 only).
+Inputs are synthetic: FM "Dexed-like" audio pushed once through the on-GPU STFT->mel front-end; weights random-init.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak; the path computes in fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
+    ap.add_argument("--arch", default="speccnn4l1_bn", choices=["speccnn4l1_bn", "speccnn8l1_bn"])
+    ap.add_argument("--dim-z", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    return ap.parse_args()
+
+
+def synth_spectrograms(B, device, seed):
+    """[B,1,257,347] min-max normalised log-mel spectrograms of seeded FM voices, via the HIP
+    front-end; 16 distinct voices per rank are tiled to B rows with a per-row gain so rows differ."""
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    from preset_gen_vae_amd.utils.synthetic import fm_voice
+    n_voices = min(B, 16)
+    waves = np.stack([fm_voice(idx=seed * 16 + i) for i in range(n_voices)])
+    reps = (B + n_voices - 1) // n_voices
+    gains = (0.4 + 0.6 * np.random.default_rng(seed).random((reps, n_voices, 1))).astype(np.float32)
+    waves = (waves[None] * gains).reshape(-1, waves.shape[1])[:B]
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050, device=device)
+    mel.set_minmax_normalization(-120.0, 0.0)
+    return mel.batch(torch.tensor(waves, device=device)).clamp_(-1.0, 1.0).contiguous()
+
+
+def layer_ops(ae):
+    """(layer name, ConvGeom args) of every conv block of the model, walked from the product modules."""
+    out = []
+    H, W = 257, 347
+    for blk in ae.encoder._all_blocks():
+        g = blk.geom(H, W)
+        out.append((f"enc{len(out) + 1}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb)))
+        H, W = g.Hs, g.Ws
+    dec_blocks = ae.decoder._all_blocks()
+    first = 9 - len(dec_blocks)
+    for i, blk in enumerate(dec_blocks):
+        g = blk.geom(H, W)
+        out.append((f"dec{first + i}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb)))
+        H, W = g.Hb, g.Wb
+    return out
+
+
+def time_kernel(fn, iters=10):
+    """Average device time of fn() in ms, HIP events recorded on the stream the kernels are launched on."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def measure_roofline(ae, B, device):
+    """Time every conv-layer kernel (forward, input-gradient, weight-gradient) standalone at the bench shapes, pick
+    the one with the largest duration (the dominant kernel of the step) and price it against its roofline."""
+    from preset_gen_vae_amd import ops
+    worst = None
+    table = []
+    for name, (Cb, Cs, k, s, p, Hb, Wb) in layer_ops(ae):
+        geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+        big = torch.randn(B, Cb, Hb, Wb, device=device)
+        small = torch.randn(B, Cs, geom.Hs, geom.Ws, device=device)
+        w = torch.randn(Cs, Cb, k, k, device=device) * 0.05
+        gw = torch.empty_like(w)
+        sc_b, sh_b = torch.ones(Cb, device=device), torch.zeros(Cb, device=device)
+        sc_s, sh_s = torch.ones(Cs, device=device), torch.zeros(Cs, device=device)
+        bias_b, bias_s = torch.zeros(Cb, device=device), torch.zeros(Cs, device=device)
+        stats_b, stats_s = torch.empty(2 * Cb, device=device), torch.empty(2 * Cs, device=device)
+        out_s, out_b = torch.empty_like(small), torch.empty_like(big)
+        macs = B * Cs * geom.Hs * geom.Ws * Cb * k * k
+        flops = 2.0 * macs
+        nb, ns, nw = big.numel() * 4, small.numel() * 4, w.numel() * 4
+        launches = {
+            'conv_down': (lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b,
+                                                stats=stats_s, out=out_s), nb + ns + nw),
+            'conv_up': (lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s,
+                                            stats=stats_b, out=out_b), nb + ns + nw),
+            'conv_wgrad': (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b),
+                           nb + ns + nw),
+        }
+        for kname, (fn, bytes_) in launches.items():
+            ms = time_kernel(fn, iters=5)
+            t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (F32_MATRIX_PEAK_TFLOPS * 1e12)
+            rec = {'layer': name, 'kernel': kname, 'ms': ms, 'flops': flops, 'bytes': bytes_,
+                   'bound': 'hbm' if t_hbm >= t_mfma else 'mfma'}
+            table.append(rec)
+            if worst is None or ms > worst['ms']:
+                worst = rec
+        del big, small, out_b, out_s
+    if worst['bound'] == 'hbm':
+        achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+    else:
+        achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, F32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
+    roof = {'bound': worst['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
+            'frac': round(achieved / peak, 5), 'traffic': None, 'kernel': f"{worst['kernel']}[{worst['layer']}]",
+            'kernel_ms': round(worst['ms'], 4)}
+    return roof, table
+
+
+def cpu_baseline(arch, dim_z, B, max_seconds=25.0):
+    """The oracle's full train step (torch CPU ops, fp32) on the host cores: a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import param_shapes, synth_input, synth_vec
+    from oracle import vae_oracle as vo
+    n_threads = torch.get_num_threads()
+    sd = vo.closed_form_state_dict(param_shapes(arch, dim_z, False), seed=1234, dtype=torch.float32)
+    x = synth_input(B, dtype=torch.float32)
+    eps = synth_vec((B, dim_z), 1.2345, 0.4, dtype=torch.float32)
+    state, times = None, []
+    t_start = time.perf_counter()
+    for i in range(13):
+        t0 = time.perf_counter()
+        r = vo.train_step(sd, x, arch, dim_z, eps, None, None, adam_state=state, step=i + 1)
+        sd, state = r['new_sd'], r['adam_state']
+        dt = time.perf_counter() - t0
+        if i >= 3:
+            times.append(dt)
+        if time.perf_counter() - t_start > max_seconds and len(times) >= 2:
+            break
+    med = float(np.median(times)) if times else dt
+    return {'value': round(B / med, 2), 'unit': 'spectrograms/s', 'cores': n_threads, 'kind': 'port',
+            'sample': f'{len(times)} timed train steps (after 3 warm-up) of {arch} dz={dim_z} fp32 at batch {B} '
+                      f'on torch CPU ops, median {med * 1e3:.1f} ms/step'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    from preset_gen_vae_amd import _lib, config, parallel
+    from preset_gen_vae_amd.model import build as mbuild
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    _lib.load()   # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    mc, tc = copy.copy(config.model), copy.copy(config.train)
+    mc.encoder_architecture, mc.dim_z = args.arch, args.dim_z
+    tc.minibatch_size = args.batch
+    mc.input_tensor_size = (args.batch, 1, 257, 347)
+    tc.latent_flow_input_regularization = 'none'
+    torch.manual_seed(1234)            # identical replicas on every rank
+    _, _, ae = mbuild.build_ae_model(mc, tc)
+    ae = ae.to(device).train()
+    torch.manual_seed(1234 + rank)     # per-rank eps / dropout streams
+    x = synth_spectrograms(args.batch, device, seed=rank)
+
+    use_graph = (not args.no_graph) and world == 1
+    sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=4)) if world > 1 else None
+    step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
+                        beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
+
+    for _ in range(args.warmup):
+        out = step.step(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step.step(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss = out['total'].item()
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+
+    roof, table, cpu = None, None, None
+    if rank == 0 and not args.no_roofline:
+        roof, table = measure_roofline(ae, args.batch, device)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.arch, args.dim_z, args.cpu_batch)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        line = {
+            "metric": "spectrograms/sec per VAE train step (batch 256, 1x257x347)", "value": round(value, 2),
+            "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} fp32 full train step "
+                                   f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "launch": "hipGraph" if use_graph else "eager", "final_loss": round(loss, 6)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if table is not None:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'bench_kernel_table.json'), 'w') as f:
+                json.dump(table, f, indent=1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,3 +59,56 @@ def rel_l2(a, b):
     a = a.detach().double().cpu().reshape(-1)
     b = b.detach().double().cpu().reshape(-1)
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _vo():
+    from oracle import vae_oracle
+    return vae_oracle
+
+
+def param_shapes(arch, dim_z, output_bn):
+    """Reference state-dict template (key order as the reference registers them), from the layer tables."""
+    enc_rows, dec_rows, cnn_in = _vo().arch_tables(arch)
+    tpl = {}
+
+    def bn(prefix, c):
+        tpl[prefix + '.weight'] = (c,)
+        tpl[prefix + '.bias'] = (c,)
+        tpl[prefix + '.running_mean'] = (c,)
+        tpl[prefix + '.running_var'] = (c,)
+        tpl[prefix + '.num_batches_tracked'] = ()
+
+    for i, (name, ci, co, k, s, p, has_bn) in enumerate(enc_rows):
+        if arch == 'speccnn8l1_bn' and name == 'enc7':
+            base = 'encoder.features_mixer_cnn.0.'
+        elif arch == 'speccnn8l1_bn' and name == 'enc8':
+            base = 'encoder.features_mixer_cnn.1.'
+        else:
+            base = f'encoder.single_ch_cnn.enc_nn.{i}.'
+        tpl[base + name + 'conv.weight'] = (co, ci, k, k)
+        tpl[base + name + 'conv.bias'] = (co,)
+        if has_bn:
+            bn(base + name + 'bn', co)
+    feat = enc_rows[-1][2] * (3 * 4 if arch == 'speccnn8l1_bn' else 17 * 23)
+    tpl['encoder.mlp.1.weight'] = (2 * dim_z, feat)
+    tpl['encoder.mlp.1.bias'] = (2 * dim_z,)
+    if output_bn:
+        bn('encoder.mlp.lat_in_regularization', 2 * dim_z)
+    tpl['decoder.mlp.0.weight'] = (int(np.prod(cnn_in)), dim_z)
+    tpl['decoder.mlp.0.bias'] = (int(np.prod(cnn_in)),)
+    j = 0
+    for (name, ci, co, k, s, p, op, has_bn) in dec_rows:
+        if name == 'dec1':
+            base = 'decoder.features_unmixer_cnn.'
+        else:
+            base = f'decoder.single_ch_cnn.dec_nn.{j}.'
+            j += 1
+        tpl[base + name + 'tconv.weight'] = (ci, co, k, k)
+        tpl[base + name + 'tconv.bias'] = (co,)
+        if has_bn:
+            bn(base + name + 'bn', co)
+    tpl[f'decoder.single_ch_cnn.dec_nn.{j}.weight'] = (8, 1, 5, 5)
+    tpl[f'decoder.single_ch_cnn.dec_nn.{j}.bias'] = (1,)
+    return tpl
+
+

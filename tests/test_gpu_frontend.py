@@ -1,0 +1,95 @@
+"""GPU: the fused STFT -> mel -> dB kernel against the numpy oracle and the reference's own Spectrogram outputs.
+
+fp32 STFT noise: the reference's float32 torch.stft differs from float64 by ~1e-7 of the frame's largest bin, which
+is a large *relative* error for bins near the -120 dB floor, so the comparison is absolute in the linear domain
+(<= 3e-6 of the frame maximum) and 0.02 dB wherever the magnitude is above -80 dB."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import audio_oracle as ao
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+
+
+def _compare_db(got_db, ref_db, strong_db=-80.0):
+    got_db, ref_db = np.asarray(got_db, dtype=np.float64), np.asarray(ref_db, dtype=np.float64)
+    assert got_db.shape == ref_db.shape
+    lin_g, lin_r = 10 ** (got_db / 20), 10 ** (ref_db / 20)
+    frame_max = np.maximum(lin_r.max(axis=-2, keepdims=True), 1e-6)
+    assert (np.abs(lin_g - lin_r) / frame_max).max() < 3e-6
+    strong = ref_db > strong_db
+    if strong.any():
+        assert np.abs(got_db - ref_db)[strong].max() < 2e-2
+
+
+def test_mel_batch_matches_oracle():
+    _need_gpu()
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    waves = np.stack([ao.synth_fm_wave(idx=i) for i in range(5)])
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+    out = mel.batch(torch.tensor(waves).cuda())
+    assert out.shape == (5, 1, 257, 347) and out.dtype == torch.float32
+    out = out.cpu().numpy()
+    for i in range(5):
+        _compare_db(out[i, 0], ao.mel_spectrogram_db(waves[i]))
+    assert out.min() >= -120.0 - 1e-4
+    # reference call convention: 1-D float64 numpy array -> Tensor[n_mels, T]
+    single = mel(waves[0].astype(np.float64))
+    assert tuple(single.shape) == (257, 347)
+    np.testing.assert_allclose(single.cpu().numpy(), out[0, 0], atol=1e-5)
+    # product filterbank == oracle filterbank (independent restatements of the Slaney construction)
+    np.testing.assert_allclose(mel.mel_basis, ao.mel_filterbank(), atol=1e-6)
+
+
+def test_linear_spectrogram_matches_reference_golden():
+    _need_gpu()
+    from preset_gen_vae_amd.utils.audio import Spectrogram
+    g = load_golden('stft.npz')
+    spec = Spectrogram(1024, 256, -120.0)
+    assert abs(spec.spectrogram_norm_factor - float(g['norm_factor'])) < 1e-3
+    np.testing.assert_allclose(spec.window.numpy(), g['window'], atol=1e-6)
+    for idx in range(3):
+        wav = ao.synth_fm_wave(idx=idx)
+        db = spec(wav).cpu().numpy()
+        assert db.shape == (513, 347)
+        frames = g[f'wave{idx}/frames']
+        _compare_db(db[:, frames], ao.spectrogram_db(wav)[:, frames])
+        # against the float32 reference itself: both carry fp32 noise -> compare where the signal is
+        ref = g[f'wave{idx}/db']
+        strong = ref > -70
+        assert np.abs(db[:, frames] - ref)[strong].max() < 5e-2
+    short = spec(ao.synth_fm_wave(n=700, idx=5)).cpu().numpy()     # ragged input shorter than one FFT
+    assert short.shape == (513, 3)
+    _compare_db(short, ao.spectrogram_db(ao.synth_fm_wave(n=700, idx=5)))
+
+
+def test_minmax_fused_and_odd_lengths():
+    _need_gpu()
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+    mel.set_minmax_normalization(-120.0, 3.5)
+    for n in (88200, 4096, 256 * 33 + 17):        # 345 frames; 17 frames (FT+1: ragged last tile); odd tail
+        wav = ao.synth_fm_wave(n=n, idx=2)
+        out = mel.batch(torch.tensor(wav[None]).cuda())[0, 0].cpu().numpy()
+        ref = ao.minmax_normalize(ao.mel_spectrogram_db(wav), -120.0, 3.5)
+        assert out.shape == ref.shape == (257, 1 + n // 256)
+        undo = (out + 1.0) * ((3.5 + 120.0) / 2.0) - 120.0
+        _compare_db(undo, ao.mel_spectrogram_db(wav))
+        assert out.min() >= -1.0 - 1e-5
+
+
+def test_frontend_feeds_encoder_shape():
+    """Raw-audio minibatch -> [B,1,257,347] is exactly what 88 576-sample Dexed renders give."""
+    _need_gpu()
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+    out = mel.batch(torch.zeros(3, 88576, device='cuda'))
+    assert out.shape == (3, 1, 257, 347)
+    assert torch.all(out == -120.0)              # silence sits on the floor

@@ -1,0 +1,316 @@
+"""GPU tier 2: every HIP kernel behind the C ABI against the oracle (CPU, float64) on seeded inputs.
+
+Tolerances (fp32 path vs fp64 oracle): activations rel-L2 <= 1e-5, scalar losses rel <= 1e-5,
+gradients rel-L2 <= 5e-4 per kernel (5e-3 through the whole network)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden, rel_l2, synth_vec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    from preset_gen_vae_amd import _lib, ops as _ops
+    _lib.load()   # raises loudly if the HIP library is missing
+    return _ops
+
+
+def dev(t):
+    return t.to(device='cuda', dtype=torch.float32).contiguous()
+
+
+# (Cb, Cs, k, s, p, Hb, Wb, B) — every reference layer shape family incl. odd sizes, output_padding variants, 1x1
+CONV_CASES = [
+    (1, 8, 5, 2, 2, 257, 347, 2),     # enc1 / dec8 full size
+    (8, 16, 4, 2, 2, 129, 174, 2),    # enc2 / dec7 full size
+    (16, 32, 4, 2, 2, 65, 88, 2),     # enc3 / dec6
+    (32, 64, 4, 2, 2, 33, 45, 3),     # enc4 / dec5
+    (64, 128, 4, 2, 2, 17, 23, 3),    # enc5 / dec4
+    (128, 256, 4, 2, 2, 9, 12, 3),    # enc6 / dec3
+    (256, 512, 4, 2, 2, 5, 7, 4),     # enc7 / dec2
+    (512, 2048, 1, 1, 0, 3, 4, 4),    # enc8 / dec1 (1x1)
+    (3, 5, 4, 2, 2, 10, 13, 2),       # ragged generic
+    (5, 3, 5, 2, 2, 12, 9, 1),        # ragged generic k5
+    (4, 4, 3, 1, 1, 6, 7, 2),         # stride 1
+]
+
+
+def _conv_inputs(case):
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    Hs, Ws = (Hb + 2 * p - k) // s + 1, (Wb + 2 * p - k) // s + 1
+    big = synth_vec((B, Cb, Hb, Wb), 0.9137, 0.3) * 1.5
+    small = synth_vec((B, Cs, Hs, Ws), 0.7719, 1.1)
+    w = synth_vec((Cs, Cb, k, k), 0.6180, 0.7) * (1.0 / np.sqrt(Cb * k * k / (s * s)))
+    bias_s = synth_vec((Cs,), 1.37, 0.2) * 0.1
+    bias_b = synth_vec((Cb,), 1.73, 0.5) * 0.1
+    sc_b, sh_b = 1.0 + 0.2 * synth_vec((Cb,), 2.1, 0.1), 0.3 * synth_vec((Cb,), 2.9, 0.6)
+    sc_s, sh_s = 1.0 + 0.2 * synth_vec((Cs,), 3.1, 0.4), 0.3 * synth_vec((Cs,), 3.7, 0.9)
+    return big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws
+
+
+def _affine(t, sc, sh):
+    return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_down_up_wgrad(ops, case, policy):
+    from preset_gen_vae_amd import _lib
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    assert (geom.Hs, geom.Ws) == (Hs, Ws)
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    try:
+        # down: conv of the lazily-normalised big tensor, LeakyReLU epilogue, fused BN statistics
+        ref = F.leaky_relu(F.conv2d(_affine(big, sc_b, sh_b), w, bias_s, stride=s, padding=p), 0.1)
+        stats = torch.empty(2 * Cs, device='cuda')
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats)
+        assert rel_l2(got, ref) < 1e-5
+        ref_stats = torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])
+        assert rel_l2(stats, ref_stats) < 2e-5
+        # down without affine / bias / activation (the form used for ConvTranspose2d input gradients)
+        ref = F.conv2d(big, w, None, stride=s, padding=p)
+        got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+        assert rel_l2(got, ref) < 1e-5
+        # up: transposed conv of the lazily-normalised small tensor; output_padding implied by Hb/Wb
+        oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+        ref = F.conv_transpose2d(_affine(small, sc_s, sh_s), w, bias_b, stride=s, padding=p,
+                                 output_padding=(oph, opw))
+        ref_act = F.leaky_relu(ref, 0.1)
+        stats = torch.empty(2 * Cb, device='cuda')
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats)
+        assert rel_l2(got, ref_act) < 1e-5
+        ref_stats = torch.cat([ref_act.sum(dim=(0, 2, 3)), (ref_act * ref_act).sum(dim=(0, 2, 3))])
+        assert rel_l2(stats, ref_stats) < 2e-5
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_HARDTANH, 0.0, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s))
+        assert rel_l2(got, F.hardtanh(ref)) < 1e-5
+        # wgrad with either operand lazily normalised
+        bigr = _affine(big, sc_b, sh_b).requires_grad_(False)
+        wv = w.clone().requires_grad_(True)
+        y = F.conv2d(bigr, wv, None, stride=s, padding=p)
+        y.backward(small)
+        gw = torch.empty((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, big_scale=dev(sc_b), big_shift=dev(sh_b))
+        assert rel_l2(gw, wv.grad) < 2e-5
+        wv = w.clone().requires_grad_(True)
+        y = F.conv2d(big, wv, None, stride=s, padding=p)
+        y.backward(_affine(small, sc_s, sh_s))
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, small_scale=dev(sc_s), small_shift=dev(sh_s))
+        assert rel_l2(gw, wv.grad) < 2e-5
+    finally:
+        lib.pgv_set_kernel_policy(0)
+
+
+def test_conv_desc_validation(ops):
+    from preset_gen_vae_amd import _lib
+    geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
+    geom.Hs += 1   # inconsistent geometry must be refused with an error code, not executed
+    x = torch.zeros((1, 2, 9, 9), device='cuda')
+    w = torch.zeros((3, 2, 4, 4), device='cuda')
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        ops.conv_down(geom, x, w, None, 0, 0.0)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
+    assert _lib.load().pgv_abi_version() == 1
+
+
+def test_empty_batch(ops):
+    geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
+    x = torch.zeros((0, 2, 9, 9), device='cuda')
+    w = torch.zeros((3, 2, 4, 4), device='cuda')
+    out = ops.conv_down(geom, x, w, None, 0, 0.0)
+    assert out.shape == (0, 3, geom.Hs, geom.Ws)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 65 * 88), (3, 7, 33 * 45), (6, 2048, 12), (256, 128, 1), (2, 8, 129 * 174)])
+def test_batchnorm_pieces(ops, shape):
+    B, C, HW = shape
+    a = synth_vec((B, C, HW), 0.831, 0.2) * 1.3 + 0.4 * synth_vec((1, C, 1), 1.9, 0.3)
+    g_o = synth_vec((B, C, HW), 0.557, 1.2)
+    gamma, beta = 1.0 + 0.1 * synth_vec((C,), 2.3, 0.1), 0.1 * synth_vec((C,), 3.3, 0.2)
+    rm, rv = 0.1 * synth_vec((C,), 4.1, 0.3), 1.0 + 0.2 * synth_vec((C,), 5.1, 0.4)
+    # oracle: torch batch_norm in float64 with autograd
+    a_r = a.clone().requires_grad_(True)
+    gam_r, bet_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    lre = F.leaky_relu(a_r, 0.1)
+    o = F.batch_norm(lre, rm_r, rv_r, gam_r, bet_r, training=True, momentum=0.1, eps=1e-5)
+    o.backward(g_o)
+    act = lre.detach()
+    # HIP
+    d_act = dev(act)
+    stats = torch.empty(2 * C, device='cuda')
+    ops.bn_stats(d_act, stats)
+    vec = torch.empty(4 * C, device='cuda')
+    scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
+    d_rm, d_rv = dev(rm), dev(rv)
+    ops.bn_finalize(stats, B * HW, dev(gamma), dev(beta), 1e-5, 0.1, d_rm, d_rv, scale, shift, mean, rstd)
+    out = ops.affine_nchw(d_act, scale, shift)
+    assert rel_l2(out, o) < 1e-5
+    assert rel_l2(d_rm, rm_r) < 1e-5 and rel_l2(d_rv, rv_r) < 1e-5
+    red = torch.empty(2 * C, device='cuda')
+    d_go = dev(g_o)
+    ops.bn_bwd_reduce(d_go, d_act, mean, rstd, red)
+    assert rel_l2(red[C:], gam_r.grad) < 1e-4 and rel_l2(red[:C], bet_r.grad) < 1e-4
+    g_y = torch.empty_like(d_go)
+    gbias = torch.empty(C, device='cuda')
+    ops.act_bn_bwd(d_go, d_act, scale, mean, rstd, red, ops.PGV_ACT_LEAKY_RELU, 0.1, g_y, gbias)
+    assert rel_l2(g_y, a_r.grad) < 1e-4
+    assert rel_l2(gbias, a_r.grad.sum(dim=(0, 2))) < 1e-3 or a_r.grad.sum(dim=(0, 2)).abs().max() < 1e-6
+    # eval-mode affine
+    ops.bn_eval_affine(dev(gamma), dev(beta), dev(rm), dev(rv), 1e-5, scale, shift)
+    ref = F.batch_norm(act, rm.clone(), rv.clone(), gamma, beta, training=False, eps=1e-5)
+    assert rel_l2(ops.affine_nchw(d_act, scale, shift), ref) < 1e-5
+
+
+@pytest.mark.parametrize("mnk", [(256, 128, 25024), (256, 25024, 64), (16, 128, 24576), (5, 7, 3), (64, 64, 64),
+                                 (2, 24576, 64), (130, 70, 33)])
+def test_linear_gemm(ops, mnk):
+    M, N, K = mnk
+    x = synth_vec((M, K), 0.771, 0.3)
+    w = synth_vec((N, K), 0.613, 0.8) / np.sqrt(K)
+    b = synth_vec((N,), 1.1, 0.2)
+    gy = synth_vec((M, N), 0.913, 0.5)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.linear(xr, wr, br)
+    y.backward(gy)
+    dx, dw, db, dgy = dev(x), dev(w), dev(b), dev(gy)
+    assert rel_l2(ops.linear_fwd(dx, dw, db), y) < 1e-5
+    assert rel_l2(ops.linear_dgrad(dgy, dw), xr.grad) < 1e-5
+    gw = torch.empty_like(dw)
+    ops.linear_wgrad(dgy, dx, gw)
+    assert rel_l2(gw, wr.grad) < 1e-5
+    gb = torch.empty(N, device='cuda')
+    ops.colsum(dgy, gb)
+    assert rel_l2(gb, br.grad) < 1e-5
+
+
+def test_reparam_kl_and_sqerr(ops):
+    from oracle import vae_oracle as vo
+    B, D = 37, 64
+    ml = (synth_vec((B, 2, D), 0.77, 0.1) * 0.8).requires_grad_(True)
+    eps = synth_vec((B, D), 1.31, 0.4) * 1.2
+    gz = synth_vec((B, D), 0.41, 0.9)
+    z = vo.reparametrize(ml, eps, True)
+    kl = vo.gaussian_dkl(ml[:, 0], ml[:, 1], normalize=True)
+    (z * gz).sum().backward(retain_graph=True)
+    g_from_z = ml.grad.clone()
+    ml.grad = None
+    (kl * 0.7).backward()
+    g_from_kl = ml.grad.clone()
+    d_ml, d_eps = dev(ml.detach()), dev(eps)
+    z_hip, _ = ops.reparam_kl_fwd(d_ml, d_eps, 0.0)
+    assert rel_l2(z_hip, z) < 1e-6
+    z_eval, kl_hip = ops.reparam_kl_fwd(d_ml, None, 1.0 / (B * D))
+    assert rel_l2(z_eval, ml[:, 0]) == 0 or rel_l2(z_eval, ml[:, 0]) < 1e-7
+    assert abs(kl_hip.item() - kl.item()) < 1e-5 * abs(kl.item())
+    assert rel_l2(ops.reparam_kl_bwd(d_ml, d_eps, dev(gz), None, 0.0), g_from_z) < 1e-5
+    gk = torch.tensor(0.7, device='cuda')
+    assert rel_l2(ops.reparam_kl_bwd(d_ml, None, None, gk, 1.0 / (B * D)), g_from_kl) < 1e-5
+    # squared error, with and without the Hardtanh gate
+    n = 2 * 257 * 347
+    xhat = (synth_vec((n,), 0.31, 0.2) * 1.4).clamp(-1, 1).requires_grad_(True)
+    x = synth_vec((n,), 0.47, 0.7)
+    loss = F.mse_loss(xhat, x)
+    (loss * 1.7).backward()
+    l_hip = ops.sqerr_fwd(dev(xhat.detach()), dev(x), 1.0 / n)
+    assert abs(l_hip.item() - loss.item()) < 1e-5 * loss.item()
+    g = ops.sqerr_bwd(dev(xhat.detach()), dev(x), torch.tensor(1.7, device='cuda'), 1.0 / n)
+    assert rel_l2(g, xhat.grad) < 1e-5
+    gate = ((xhat.detach() > -1) & (xhat.detach() < 1)).double()
+    g = ops.sqerr_bwd(dev(xhat.detach()), dev(x), torch.tensor(1.7, device='cuda'), 1.0 / n, hardtanh=True)
+    assert rel_l2(g, xhat.grad * gate) < 1e-5
+
+
+def test_adam_matches_torch_semantics(ops):
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd import optim
+    n = 100003
+    p0, g1, g2 = synth_vec((n,), 0.3, 0.1), synth_vec((n,), 0.7, 0.2) * 1e-2, synth_vec((n,), 0.9, 0.3) * 1e-2
+    param = torch.nn.Parameter(dev(p0))
+    flat = optim.FlatParams([param])
+    opt = optim.FusedAdam(flat, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for t, g in enumerate((g1, g2), start=1):
+        flat.flat_grad[:n].copy_(dev(g))
+        opt.step()
+        p, m, v = vo.adam_update(p, g, m, v, t, 2e-4, (0.9, 0.999), 1e-8, 1e-4)
+    assert (param.detach().cpu().double() - p).abs().max().item() < 2e-7
+    assert rel_l2(param.detach() - dev(p0), p - p0) < 1e-4
+    # cross-check against torch.optim.Adam itself
+    tp = torch.nn.Parameter(p0.clone())
+    topt = torch.optim.Adam([tp], lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    for g in (g1, g2):
+        tp.grad = g.clone()
+        topt.step()
+    assert (tp.detach() - p).abs().max().item() < 1e-12
+
+
+def test_rng_distributions(ops):
+    from preset_gen_vae_amd.rng import DeviceRNG
+    rng = DeviceRNG(torch.device('cuda'), seed=42)
+    m1 = rng.dropout_mask(0.3, (256, 24576))
+    m2 = rng.dropout_mask(0.3, (256, 24576))
+    keep = (m1 > 0).float().mean().item()
+    assert abs(keep - 0.7) < 2e-3
+    vals = torch.unique(m1)
+    assert vals.numel() == 2 and abs(vals.max().item() - 1 / 0.7) < 1e-6 and vals.min().item() == 0
+    assert (m1 != m2).float().mean().item() > 0.3          # the stream advances between calls
+    e = rng.normal((256, 4096))
+    assert abs(e.mean().item()) < 5e-3 and abs(e.std().item() - 1.0) < 5e-3
+    assert abs((e ** 4).mean().item() - 3.0) < 0.1
+    rng_b = DeviceRNG(torch.device('cuda'), seed=42)
+    assert torch.equal(rng_b.dropout_mask(0.3, (256, 24576)), m1)   # reproducible from the seed
+
+
+def test_layer_blocks_against_reference_goldens(ops):
+    """The reference's own Conv2D/TConv2D outputs (tests/golden/layers_small.npz) through the product modules."""
+    from preset_gen_vae_amd.model import layer
+    import torch.nn as nn
+    g = load_golden('layers_small.npz')
+    names = sorted({k.split('/')[0] for k in g.files})
+    for name in names:
+        kind = str(g[name + '/kind'])
+        ci, co, k, s, p, oph, opw, bn = (int(v) for v in g[name + '/cfg'])
+        if kind == 'conv':
+            blk = layer.Conv2D(ci, co, [k, k], [s, s], p, [1, 1], activation=nn.LeakyReLU(0.1), name_prefix=name,
+                               batch_norm=('after' if bn else None))
+        elif kind == 'tconv':
+            blk = layer.TConv2D(ci, co, [k, k], [s, s], p, output_padding=[oph, opw], activation=nn.LeakyReLU(0.1),
+                                name_prefix=name, batch_norm=('after' if bn else None))
+        else:
+            conv = nn.ConvTranspose2d(ci, co, [k, k], [s, s], p)
+            act = nn.Hardtanh()
+            blk = nn.Sequential(conv, act)
+            blk._pgv = layer._Block(conv, act, None)
+        sd = {kk[len(name + '/sd_in/'):]: torch.tensor(g[kk]) for kk in g.files if kk.startswith(name + '/sd_in/')}
+        blk.load_state_dict(sd)
+        blk = blk.float().cuda().train()
+        x = dev(torch.tensor(g[name + '/x'])).requires_grad_(True)
+        y = blk(x) if kind != 'tconv_last' else layer.run_stack(x, [blk._pgv], True)
+        assert rel_l2(y, torch.tensor(g[name + '/y'])) < 1e-5, name
+        y.backward(dev(torch.tensor(g[name + '/gy'])))
+        assert rel_l2(x.grad, torch.tensor(g[name + '/gx'])) < 1e-4, name
+        for kk, v in blk.named_parameters():
+            ref = torch.tensor(g[name + '/grad/' + kk])
+            if ref.abs().max() < 1e-9:   # conv bias under BN: mathematically zero gradient
+                assert v.grad.abs().max().item() < 1e-5, (name, kk)
+            else:
+                assert rel_l2(v.grad, ref) < 2e-4, (name, kk)
+        for kk, v in blk.state_dict().items():
+            ref = torch.tensor(g[name + '/sd_out/' + kk])
+            if 'running' in kk:
+                assert rel_l2(v, ref) < 1e-5, (name, kk)
+            elif 'num_batches' in kk:
+                assert int(v) == int(ref)

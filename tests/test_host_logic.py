@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the product package — builders / config surface, reference state-dict keys, flat parameter
+storage and bucketing, mel filterbank, layer geometry.  No kernel is launched."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, param_shapes
+
+
+def _cfg(arch, B=4, output_bn=False, dim_z=64):
+    from preset_gen_vae_amd import config
+    mc, tc = copy.copy(config.model), copy.copy(config.train)
+    mc.encoder_architecture, mc.dim_z = arch, dim_z
+    mc.input_tensor_size = (B, 1, 257, 347)
+    tc.latent_flow_input_regularization = 'bn' if output_bn else 'none'
+    return mc, tc
+
+
+@pytest.mark.parametrize("arch,output_bn,golden", [('speccnn8l1_bn', False, 'vae8l_b2.npz'),
+                                                   ('speccnn8l1_bn', True, 'vae8l_b2_outbn.npz'),
+                                                   ('speccnn4l1_bn', False, 'vae4l_b2.npz')])
+def test_state_dict_keys_match_reference(arch, output_bn, golden):
+    """Key names and shapes equal the REFERENCE's state dict (recorded in the goldens from the real modules)."""
+    from preset_gen_vae_amd.model import build
+    enc, dec, ae = build.build_ae_model(*_cfg(arch, output_bn=output_bn))
+    sd = ae.state_dict()
+    tpl = param_shapes(arch, 64, output_bn)
+    assert list(sd.keys()) == list(tpl.keys())           # same keys, same registration order
+    for k, shape in tpl.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    g = load_golden(golden)
+    ref_keys = {k[len('post_full/'):] for k in g.files if k.startswith('post_full/')}
+    ref_keys |= {k[len('post/'):-len('/checksum')] for k in g.files if k.startswith('post/') and k.endswith('/checksum')}
+    ref_keys |= {k[len('post/'):] for k in g.files if k.startswith('post/') and k.endswith('num_batches_tracked')}
+    assert ref_keys == set(sd.keys())
+    n_params = sum(p.numel() for p in ae.parameters())
+    if arch == 'speccnn8l1_bn':
+        assert n_params == 12440017 + (256 if output_bn else 0)      # SURVEY.md §2.2 [probed]
+
+
+def test_builder_surface_and_errors():
+    from preset_gen_vae_amd.model import VAE, build, extendedAE, regression
+
+    class Helper:
+        learnable_preset_size = 144
+
+    mc, tc = _cfg('speccnn8l1_bn')
+    enc, dec, ae, ext = build.build_extended_ae_model(mc, tc, Helper())
+    assert isinstance(ae, VAE.BasicVAE) and isinstance(ext, extendedAE.ExtendedAE)
+    assert isinstance(ext.reg_model, regression.MLPRegression)
+    assert ext.is_flow_based_latent_space is False and ext.is_flow_based_regression is False
+    assert ext.ae_model is ae and ae.encoder is enc and ae.decoder is dec and ae.dim_z == 64
+    assert ae.is_profiled is False
+    assert enc.cnn_out_size == torch.Size((1, 2048, 3, 4))
+    assert [k for k in ext.reg_model.state_dict()][:3] == ['reg_model.fc1.weight', 'reg_model.fc1.bias',
+                                                           'reg_model.bn1.weight']
+    mc.latent_flow_arch = 'realnvp_6l300'
+    with pytest.raises(NotImplementedError):
+        build.build_ae_model(mc, tc)
+    mc, tc = _cfg('wavenet_baseline')
+    with pytest.raises(NotImplementedError):
+        build.build_ae_model(mc, tc)
+    mc, tc = _cfg('speccnn8l1_bn')
+    mc.params_regression_architecture = 'flow_realnvp_6l300'
+    with pytest.raises(NotImplementedError):
+        build.build_extended_ae_model(mc, tc, Helper())
+    mc, tc = _cfg('speccnn8l1_bn')
+    mc.stack_specs_deepest_features_mix = True
+    enc, dec, ae = build.build_ae_model(mc, tc)
+    assert 'encoder.single_ch_cnn.enc_nn.4x4conv.enc7conv.weight' in ae.state_dict()
+    assert 'encoder.features_mixer_cnn.enc8conv.weight' in ae.state_dict()
+
+
+def test_layer_geometry_traces_reference_shapes():
+    """257x347 -> 129x174 -> ... -> 3x4 and back with the per-axis output_padding."""
+    from preset_gen_vae_amd.model import build
+    enc, dec, ae = build.build_ae_model(*_cfg('speccnn8l1_bn'))
+    H, W = 257, 347
+    seen = []
+    for blk in enc._all_blocks():
+        g = blk.geom(H, W)
+        H, W = g.Hs, g.Ws
+        seen.append((blk.c_out, H, W))
+    assert seen == [(8, 129, 174), (16, 65, 88), (32, 33, 45), (64, 17, 23), (128, 9, 12), (256, 5, 7), (512, 3, 4),
+                    (2048, 3, 4)]
+    seen = []
+    for blk in dec._all_blocks():
+        g = blk.geom(H, W)
+        H, W = g.Hb, g.Wb
+        seen.append((blk.c_out, H, W))
+    assert seen == [(512, 3, 4), (256, 5, 7), (128, 9, 12), (64, 17, 23), (32, 33, 45), (16, 65, 88), (8, 129, 174),
+                    (1, 257, 347)]
+
+
+def test_flat_params_and_buckets():
+    from preset_gen_vae_amd import optim
+    from preset_gen_vae_amd.model import build
+    enc, dec, ae = build.build_ae_model(*_cfg('speccnn4l1_bn'))
+    before = {k: v.clone() for k, v in ae.state_dict().items()}
+    flat = optim.FlatParams(ae.parameters())
+    for k, v in ae.state_dict().items():
+        assert torch.equal(v, before[k]), k                       # values preserved, keys unchanged
+    n = sum(p.numel() for p in ae.parameters())
+    assert n <= flat.numel < n + 4 * len(flat.params)
+    for p, o in zip(flat.params, flat.offsets):
+        assert o % 4 == 0
+        assert p.data.data_ptr() == flat.flat_param.data_ptr() + 4 * o
+        assert p.grad is not None and p.grad.data_ptr() == flat.flat_grad.data_ptr() + 4 * o
+    # gradient-ready order: the decoder's output layer comes first, the encoder's first conv last
+    names = {id(p): k for k, p in ae.named_parameters()}
+    assert names[id(flat.params[0])].startswith('decoder.single_ch_cnn.dec_nn.3')
+    assert names[id(flat.params[-1])] == 'encoder.single_ch_cnn.enc_nn.0.enc1conv.weight'
+    ranges = flat.bucket_ranges(4)
+    assert ranges[0][0] == 0 and ranges[-1][1] == flat.numel
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert sum(len(flat.params_in_range(lo, hi)) for lo, hi in ranges) == len(flat.params)
+    flat.flat_param.mul_(2.0)
+    assert torch.equal(ae.state_dict()['decoder.mlp.0.weight'], 2 * before['decoder.mlp.0.weight'])
+
+
+def test_product_mel_basis_known_answers():
+    from preset_gen_vae_amd.utils.audio import dense_to_csr, slaney_mel_basis
+    fb = slaney_mel_basis(22050, 1024, 257)
+    assert fb.shape == (257, 513) and int((fb != 0).sum()) == 1016
+    rp, col, val = dense_to_csr(fb)
+    assert rp[0] == 0 and rp[-1] == 1016 and np.all(np.diff(rp) >= 1) and np.diff(rp).max() == 14
+    dense = np.zeros_like(fb)
+    for r in range(257):
+        dense[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+    assert np.array_equal(dense, fb)
+    np.testing.assert_allclose(fb[128, 91:94], [0.116312, 0.938339, 0.249680], atol=2e-6)
+
+
+def test_config_surface():
+    from preset_gen_vae_amd import config
+    config.update_dynamic_config_params()
+    assert config.model.input_tensor_size == (config.train.minibatch_size, 1, 257, 347)
+    assert config.model.concat_midi_to_z is False and config.model.stft_args == (1024, 256)
+    assert config.train.adam_betas == (0.9, 0.999) and config.train.weight_decay == 1e-4
