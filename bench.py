@@ -103,7 +103,8 @@ def measure_roofline(ae, B, device):
         sc_b, sh_b = torch.ones(Cb, device=device), torch.zeros(Cb, device=device)
         sc_s, sh_s = torch.ones(Cs, device=device), torch.zeros(Cs, device=device)
         bias_b, bias_s = torch.zeros(Cb, device=device), torch.zeros(Cs, device=device)
-        stats_b, stats_s = torch.empty(2 * Cb, device=device), torch.empty(2 * Cs, device=device)
+        stats_b = torch.empty(2 * Cb, device=device, dtype=torch.float64)
+        stats_s = torch.empty(2 * Cs, device=device, dtype=torch.float64)
         out_s, out_b = torch.empty_like(small), torch.empty_like(big)
         macs = B * Cs * geom.Hs * geom.Ws * Cb * k * k
         flops = 2.0 * macs

@@ -56,16 +56,16 @@ int pgv_set_kernel_policy(int policy);
  * in the zero padding (in_scale/in_shift may be NULL: identity).  The per-channel affine is the *producer's*
  * BatchNorm2d folded into this consumer's load (layer.py:21-26 puts BN after the activation).
  * Replaces nn.Conv2d forward (layer.py:19-20) and, called with a gradient as `big`, ConvTranspose2d dgrad.
- * bias may be NULL.  stats (may be NULL) points to 2*Cs floats that are overwritten with the sum and the sum of
+ * bias may be NULL.  stats (may be NULL) points to 2*Cs DOUBLES that are overwritten with the sum and the sum of
  * squares of the written outputs per channel (BatchNorm2d batch statistics, fused into the epilogue). */
 int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
-                  const float* w, const float* bias, int act, float slope, float* small, float* stats,
+                  const float* w, const float* bias, int act, float slope, float* small, double* stats,
                   void* stream);
 
 /* big = act(conv_transpose_{stride,pad}(in') + bias[Cb]); output_padding is implied by Hb/Wb.
  * Replaces nn.ConvTranspose2d forward (layer.py:38-40, decoder.py:218) and nn.Conv2d dgrad. */
 int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scale, const float* in_shift,
-                const float* w, const float* bias, int act, float slope, float* big, float* stats,
+                const float* w, const float* bias, int act, float slope, float* big, double* stats,
                 void* stream);
 
 /* gw[cs][cb][kh][kw] = sum_{b,oh,ow} small'[b,cs,oh,ow] * big'[b,cb,oh*s-p+kh,ow*s-p+kw]
@@ -77,11 +77,13 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm (nn.BatchNorm2d / BatchNorm1d train mode, layer.py:21-26, encoder.py:86-87) ------- */
-/* stats[0:C] = sum, stats[C:2C] = sum of squares over (B,HW) of a[B,C,HW]. Overwrites stats. */
-int pgv_bn_stats(const float* a, int B, int C, int HW, float* stats, void* stream);
+/* stats[0:C] = sum, stats[C:2C] = sum of squares over (B,HW) of a[B,C,HW]. Overwrites stats.
+ * Cross-workgroup accumulation is in float64 (one double atomic per workgroup): the per-channel sums feed
+ * E[x^2]-E[x]^2 and the BN-backward projections, which cancel heavily (numerics). */
+int pgv_bn_stats(const float* a, int B, int C, int HW, double* stats, void* stream);
 /* From stats: mean/biased var -> scale=gamma*rstd, shift=beta-mean*scale; saves mean,rstd;
  * running_mean/var momentum update with the unbiased variance (torch semantics); any of running_* may be NULL. */
-int pgv_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
+int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                     float* mean, float* rstd, void* stream);
 /* Eval-mode BN folded to an affine: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
@@ -93,7 +95,7 @@ int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int 
                     void* stream);
 /* red[0:C] = sum g_o, red[C:2C] = sum g_o * a_hat, a_hat=(a-mean)*rstd. Overwrites red. */
 int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C,
-                      int HW, float* red, void* stream);
+                      int HW, double* red, void* stream);
 /* Backward through [activation -> BN]: given g_o (grad of BN output) produces g_y (grad of the pre-activation
  * conv output): g_a = scale[c]*(g_o - red[c]/n - a_hat*red[C+c]/n); g_y = g_a * act'(a).
  * With scale==NULL (block without BN) g_a = g_o; with red==NULL (eval-mode BN) g_a = scale[c]*g_o.
@@ -101,7 +103,7 @@ int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const
  * BN is present ggamma = red[C:2C], gbeta = red[0:C] are simply read by the caller.
  * act' is recovered from the saved activated tensor a (sign for LeakyReLU; |a|<1 for Hardtanh). */
 int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
-                   const float* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
+                   const double* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
                    void* stream);
 
 /* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */

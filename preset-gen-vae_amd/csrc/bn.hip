@@ -27,36 +27,36 @@ inline Split pick_split(int B, int C, int HW) {
 }
 
 __global__ void bn_stats_kernel(const float* __restrict__ a, int B, int C, int HW, int per,
-                                float* __restrict__ stats) {
-  __shared__ float red[16];
+                                double* __restrict__ stats) {
+  __shared__ double red[16];
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
   for (int b = b0; b < b1; ++b) {
     const float* p = a + ((int64_t)b * C + c) * HW;
     int i = threadIdx.x;
     for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
-      const float v0 = p[i], v1 = p[i + blockDim.x];
+      const double v0 = p[i], v1 = p[i + blockDim.x];
       s0 += v0;
-      q0 = fmaf(v0, v0, q0);
+      q0 = fma(v0, v0, q0);
       s1 += v1;
-      q1 = fmaf(v1, v1, q1);
+      q1 = fma(v1, v1, q1);
     }
     if (i < HW) {
-      const float v0 = p[i];
+      const double v0 = p[i];
       s0 += v0;
-      q0 = fmaf(v0, v0, q0);
+      q0 = fma(v0, v0, q0);
     }
   }
-  const float s = pgv_block_sum(s0 + s1, red);
-  const float q = pgv_block_sum(q0 + q1, red);
+  const double s = pgv_block_sum_d(s0 + s1, red);
+  const double q = pgv_block_sum_d(q0 + q1, red);
   if (threadIdx.x == 0) {
     atomicAdd(&stats[c], s);
     atomicAdd(&stats[C + c], q);
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_n, double unbias,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double inv_n, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ scale,
@@ -102,31 +102,31 @@ __global__ void affine_kernel(const float* __restrict__ a, const float* __restri
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, int B, int C,
-                                     int HW, int per, float* __restrict__ red_out) {
-  __shared__ float red[16];
+                                     int HW, int per, double* __restrict__ red_out) {
+  __shared__ double red[16];
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  const float mu = mean[c], rs = rstd[c];
-  float s0 = 0.f, s1 = 0.f, d0 = 0.f, d1 = 0.f;
+  const double mu = mean[c], rs = rstd[c];
+  double s0 = 0.0, s1 = 0.0, d0 = 0.0, d1 = 0.0;
   for (int b = b0; b < b1; ++b) {
     const int64_t base = ((int64_t)b * C + c) * HW;
     int i = threadIdx.x;
     for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
-      const float g0 = g_o[base + i], g1 = g_o[base + i + blockDim.x];
-      const float h0 = (a[base + i] - mu) * rs, h1 = (a[base + i + blockDim.x] - mu) * rs;
+      const double g0 = g_o[base + i], g1 = g_o[base + i + blockDim.x];
+      const double h0 = ((double)a[base + i] - mu) * rs, h1 = ((double)a[base + i + blockDim.x] - mu) * rs;
       s0 += g0;
-      d0 = fmaf(g0, h0, d0);
+      d0 = fma(g0, h0, d0);
       s1 += g1;
-      d1 = fmaf(g1, h1, d1);
+      d1 = fma(g1, h1, d1);
     }
     if (i < HW) {
-      const float g0 = g_o[base + i];
+      const double g0 = g_o[base + i];
       s0 += g0;
-      d0 = fmaf(g0, (a[base + i] - mu) * rs, d0);
+      d0 = fma(g0, ((double)a[base + i] - mu) * rs, d0);
     }
   }
-  const float s = pgv_block_sum(s0 + s1, red);
-  const float dd = pgv_block_sum(d0 + d1, red);
+  const double s = pgv_block_sum_d(s0 + s1, red);
+  const double dd = pgv_block_sum_d(d0 + d1, red);
   if (threadIdx.x == 0) {
     atomicAdd(&red_out[c], s);
     atomicAdd(&red_out[C + c], dd);
@@ -135,7 +135,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float*
 
 __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
                                   const float* __restrict__ scale, const float* __restrict__ mean,
-                                  const float* __restrict__ rstd, const float* __restrict__ redv, float inv_n, int B,
+                                  const float* __restrict__ rstd, const double* __restrict__ redv, double inv_n, int B,
                                   int C, int HW, int per, int act, float slope, float* __restrict__ g_y,
                                   float* __restrict__ gbias) {
   __shared__ float red[16];
@@ -148,8 +148,8 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
     if (redv) {
       mu = mean[c];
       rs = rstd[c];
-      c1 = redv[c] * inv_n;
-      c2 = redv[C + c] * inv_n;
+      c1 = (float)(redv[c] * inv_n);
+      c2 = (float)(redv[C + c] * inv_n);
     }
   }
   float acc = 0.f;
@@ -200,8 +200,8 @@ int zero_async(void* p, size_t bytes, hipStream_t st, const char* who) {
 
 }  // namespace
 
-int pgv_bn_stats_impl(const float* a, int B, int C, int HW, float* stats, hipStream_t st) {
-  int rc = zero_async(stats, sizeof(float) * 2 * C, st, "pgv_bn_stats");
+int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st) {
+  int rc = zero_async(stats, sizeof(double) * 2 * C, st, "pgv_bn_stats");
   if (rc) return rc;
   if ((int64_t)B * HW == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
@@ -212,12 +212,12 @@ int pgv_bn_stats_impl(const float* a, int B, int C, int HW, float* stats, hipStr
 
 extern "C" {
 
-int pgv_bn_stats(const float* a, int B, int C, int HW, float* stats, void* stream) {
+int pgv_bn_stats(const float* a, int B, int C, int HW, double* stats, void* stream) {
   PGV_CHECK_ARG(a && stats && B >= 0 && C > 0 && HW > 0, "pgv_bn_stats: bad argument");
   return pgv_bn_stats_impl(a, B, C, HW, stats, pgv_stream(stream));
 }
 
-int pgv_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
+int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                     float* mean, float* rstd, void* stream) {
   PGV_CHECK_ARG(stats && C > 0 && n > 0, "pgv_bn_finalize: bad argument");
@@ -251,10 +251,10 @@ int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int 
 }
 
 int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
-                      float* red, void* stream) {
+                      double* red, void* stream) {
   PGV_CHECK_ARG(g_o && a && mean && rstd && red && B >= 0 && C > 0 && HW > 0, "pgv_bn_bwd_reduce: bad argument");
   hipStream_t st = pgv_stream(stream);
-  int rc = zero_async(red, sizeof(float) * 2 * C, st, "pgv_bn_bwd_reduce");
+  int rc = zero_async(red, sizeof(double) * 2 * C, st, "pgv_bn_bwd_reduce");
   if (rc) return rc;
   if (B == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
@@ -265,7 +265,7 @@ int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const
 }
 
 int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
-                   const float* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
+                   const double* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
                    void* stream) {
   PGV_CHECK_ARG(g_o && a && g_y && B >= 0 && C > 0 && HW > 0, "pgv_act_bn_bwd: bad argument");
   PGV_CHECK_ARG(red == nullptr || (scale && mean && rstd), "pgv_act_bn_bwd: train-mode BN needs scale/mean/rstd");
@@ -276,7 +276,7 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
   }
   if (B == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
-  const float inv_n = 1.0f / (float)((double)B * HW);
+  const double inv_n = 1.0 / ((double)B * HW);
   hipLaunchKernelGGL(act_bn_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, scale, mean, rstd, red, inv_n,
                      B, C, HW, s.per, act, slope, g_y, gbias);
   PGV_CHECK_LAUNCH("act_bn_bwd");

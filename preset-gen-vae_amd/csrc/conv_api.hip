@@ -38,10 +38,11 @@ int pgv_set_kernel_policy(int policy) {
 }
 
 int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
-                  const float* w, const float* bias, int act, float slope, float* small_out, float* stats,
+                  const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                   void* stream) {
   int rc = check_desc(d, "pgv_conv_down");
   if (rc) return rc;
+  if (d->B == 0) return PGV_OK;  // empty minibatch: nothing to do (pointers may be null)
   PGV_CHECK_ARG(big && w && small_out, "pgv_conv_down: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_down: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
@@ -57,10 +58,11 @@ int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scal
 }
 
 int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
-                const float* w, const float* bias, int act, float slope, float* big_out, float* stats,
+                const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                 void* stream) {
   int rc = check_desc(d, "pgv_conv_up");
   if (rc) return rc;
+  if (d->B == 0) return PGV_OK;  // empty minibatch: nothing to do (pointers may be null)
   PGV_CHECK_ARG(small_in && w && big_out, "pgv_conv_up: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
@@ -85,7 +87,7 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
                    void* workspace, int64_t workspace_bytes, void* stream) {
   int rc = check_desc(d, "pgv_conv_wgrad");
   if (rc) return rc;
-  PGV_CHECK_ARG(big && small_in && gw, "pgv_conv_wgrad: null tensor");
+  PGV_CHECK_ARG(gw && (d->B == 0 || (big && small_in)), "pgv_conv_wgrad: null tensor");
   PGV_CHECK_ARG((big_scale == nullptr) == (big_shift == nullptr), "pgv_conv_wgrad: scale/shift must come together");
   PGV_CHECK_ARG((small_scale == nullptr) == (small_shift == nullptr),
                 "pgv_conv_wgrad: scale/shift must come together");

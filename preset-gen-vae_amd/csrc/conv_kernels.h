@@ -15,14 +15,14 @@ int pgv_conv_wgrad_generic(const pgv_conv_desc* d, const float* big, const float
 // Tuned kernels: return 1 when they handled the call, 0 when the shape is not covered (caller falls back to
 // the generic kernel), <0 on error.
 int pgv_conv_down_tuned(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
-                        const float* w, const float* bias, int act, float slope, float* small_out, float* stats,
+                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                         hipStream_t st);
 int pgv_conv_up_tuned(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
-                      const float* w, const float* bias, int act, float slope, float* big_out, float* stats,
+                      const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                       hipStream_t st);
 int pgv_conv_wgrad_tuned(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                          const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                          void* workspace, int64_t workspace_bytes, hipStream_t st);
 int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc* d);
 
-int pgv_bn_stats_impl(const float* a, int B, int C, int HW, float* stats, hipStream_t st);
+int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st);

@@ -2,11 +2,11 @@
 #include "conv_kernels.h"
 
 int pgv_conv_down_tuned(const pgv_conv_desc*, const float*, const float*, const float*, const float*, const float*,
-                        int, float, float*, float*, hipStream_t) {
+                        int, float, float*, double*, hipStream_t) {
   return 0;
 }
 int pgv_conv_up_tuned(const pgv_conv_desc*, const float*, const float*, const float*, const float*, const float*,
-                      int, float, float*, float*, hipStream_t) {
+                      int, float, float*, double*, hipStream_t) {
   return 0;
 }
 int pgv_conv_wgrad_tuned(const pgv_conv_desc*, const float*, const float*, const float*, const float*, const float*,

@@ -52,6 +52,28 @@ __device__ __forceinline__ float pgv_block_sum(float v, float* smem /* >= 16 flo
   return r;
 }
 
+__device__ __forceinline__ double pgv_wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// float64 block sum (per-channel statistics: the sums cancel heavily downstream, see DESIGN.md numerics).
+__device__ __forceinline__ double pgv_block_sum_d(double v, double* smem /* >= 16 doubles */) {
+  v = pgv_wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (wave == 0) {
+    r = lane < nw ? smem[lane] : 0.0;
+    r = pgv_wave_sum_d(r);
+  }
+  return r;
+}
+
 __device__ __forceinline__ float pgv_act(float y, int act, float slope) {
   if (act == PGV_ACT_LEAKY_RELU) return y > 0.f ? y : slope * y;
   if (act == PGV_ACT_HARDTANH) return fminf(1.f, fmaxf(-1.f, y));

@@ -126,7 +126,7 @@ class ConvStackFn(torch.autograd.Function):
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
             C = blk.c_out
-            stats = torch.empty(2 * C, device=dev, dtype=torch.float32) if (has_bn and training) else None
+            stats = torch.empty(2 * C, device=dev, dtype=torch.float64) if (has_bn and training) else None
             fn = ops.conv_up if blk.up else ops.conv_down
             a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats)
             scale = shift = mean = rstd = None
@@ -169,7 +169,7 @@ class ConvStackFn(torch.autograd.Function):
             C = blk.c_out
             red = None
             if has_bn and mean is not None:
-                red = torch.empty(2 * C, device=dev, dtype=torch.float32)
+                red = torch.empty(2 * C, device=dev, dtype=torch.float64)
                 ops.bn_bwd_reduce(g_o, a, mean, rstd, red)
                 dst, ret = _grad_dest(params[pi + 2])
                 dst.copy_(red[C:])
@@ -311,7 +311,7 @@ class BatchNorm1dFn(torch.autograd.Function):
         if training:
             if B <= 1:
                 raise ValueError("Expected more than 1 value per channel when training")
-            stats = torch.empty(2 * C, device=dev, dtype=torch.float32)
+            stats = torch.empty(2 * C, device=dev, dtype=torch.float64)
             x3 = x.view(B, C, 1)
             ops.bn_stats(x3, stats)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -337,7 +337,7 @@ class BatchNorm1dFn(torch.autograd.Function):
         red = None
         gg_ret = gb_ret = None
         if mean is not None:
-            red = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            red = torch.empty(2 * C, device=x.device, dtype=torch.float64)
             ops.bn_bwd_reduce(g, x3, mean, rstd, red)
             dst, gg_ret = _grad_dest(gamma)
             dst.copy_(red[C:])

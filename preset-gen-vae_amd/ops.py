@@ -25,6 +25,15 @@ def _chk(*tensors):
             raise RuntimeError("expected a contiguous (NCHW) tensor")
 
 
+def _chk64(*tensors):
+    """Per-channel reduction buffers (BN statistics / BN-backward projections) are float64 on the device."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+            raise RuntimeError("expected a contiguous float64 tensor on a ROCm device for reduction buffers")
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -51,7 +60,8 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
     B = big.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cs, geom.Hs, geom.Ws), device=big.device, dtype=torch.float32)
-    _chk(big, w, bias, in_scale, in_shift, stats, out)
+    _chk(big, w, bias, in_scale, in_shift, out)
+    _chk64(stats)
     lib = _lib.load()
     _lib.check(lib.pgv_conv_down(ctypes.byref(geom.desc(B)), _p(big), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
                                  slope, _p(out), _p(stats), _stream()), "pgv_conv_down")
@@ -62,7 +72,8 @@ def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stat
     B = small.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
-    _chk(small, w, bias, in_scale, in_shift, stats, out)
+    _chk(small, w, bias, in_scale, in_shift, out)
+    _chk64(stats)
     lib = _lib.load()
     _lib.check(lib.pgv_conv_up(ctypes.byref(geom.desc(B)), _p(small), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
                                slope, _p(out), _p(stats), _stream()), "pgv_conv_up")
@@ -98,12 +109,14 @@ def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale
 def bn_stats(a, stats):
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(a, stats)
+    _chk(a)
+    _chk64(stats)
     _lib.check(_lib.load().pgv_bn_stats(_p(a), B, C, HW, _p(stats), _stream()), "pgv_bn_stats")
 
 
 def bn_finalize(stats, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd):
     C = stats.numel() // 2
+    _chk64(stats)
     _lib.check(_lib.load().pgv_bn_finalize(_p(stats), C, n, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
                                            _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd), _stream()),
                "pgv_bn_finalize")
@@ -130,7 +143,8 @@ def affine_nchw(a, scale, shift, out=None):
 def bn_bwd_reduce(g_o, a, mean, rstd, red):
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(g_o, a, mean, rstd, red)
+    _chk(g_o, a, mean, rstd)
+    _chk64(red)
     _lib.check(_lib.load().pgv_bn_bwd_reduce(_p(g_o), _p(a), _p(mean), _p(rstd), B, C, HW, _p(red), _stream()),
                "pgv_bn_bwd_reduce")
 
@@ -138,7 +152,8 @@ def bn_bwd_reduce(g_o, a, mean, rstd, red):
 def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias):
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(g_o, a, scale, mean, rstd, red, g_y, gbias)
+    _chk(g_o, a, scale, mean, rstd, g_y, gbias)
+    _chk64(red)
     _lib.check(_lib.load().pgv_act_bn_bwd(_p(g_o), _p(a), _p(scale), _p(mean), _p(rstd), _p(red), B, C, HW, act, slope,
                                           _p(g_y), _p(gbias), _stream()), "pgv_act_bn_bwd")
 

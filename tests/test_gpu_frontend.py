@@ -92,4 +92,4 @@ def test_frontend_feeds_encoder_shape():
     mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
     out = mel.batch(torch.zeros(3, 88576, device='cuda'))
     assert out.shape == (3, 1, 257, 347)
-    assert torch.all(out == -120.0)              # silence sits on the floor
+    assert (out + 120.0).abs().max().item() < 1e-4   # silence sits on the floor

@@ -71,7 +71,7 @@ def test_conv_down_up_wgrad(ops, case, policy):
     try:
         # down: conv of the lazily-normalised big tensor, LeakyReLU epilogue, fused BN statistics
         ref = F.leaky_relu(F.conv2d(_affine(big, sc_b, sh_b), w, bias_s, stride=s, padding=p), 0.1)
-        stats = torch.empty(2 * Cs, device='cuda')
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
         got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
                             in_shift=dev(sh_b), stats=stats)
         assert rel_l2(got, ref) < 1e-5
@@ -86,7 +86,7 @@ def test_conv_down_up_wgrad(ops, case, policy):
         ref = F.conv_transpose2d(_affine(small, sc_s, sh_s), w, bias_b, stride=s, padding=p,
                                  output_padding=(oph, opw))
         ref_act = F.leaky_relu(ref, 0.1)
-        stats = torch.empty(2 * Cb, device='cuda')
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
         got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                           in_shift=dev(sh_s), stats=stats)
         assert rel_l2(got, ref_act) < 1e-5
@@ -150,7 +150,7 @@ def test_batchnorm_pieces(ops, shape):
     act = lre.detach()
     # HIP
     d_act = dev(act)
-    stats = torch.empty(2 * C, device='cuda')
+    stats = torch.empty(2 * C, device='cuda', dtype=torch.float64)
     ops.bn_stats(d_act, stats)
     vec = torch.empty(4 * C, device='cuda')
     scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
@@ -159,7 +159,7 @@ def test_batchnorm_pieces(ops, shape):
     out = ops.affine_nchw(d_act, scale, shift)
     assert rel_l2(out, o) < 1e-5
     assert rel_l2(d_rm, rm_r) < 1e-5 and rel_l2(d_rv, rv_r) < 1e-5
-    red = torch.empty(2 * C, device='cuda')
+    red = torch.empty(2 * C, device='cuda', dtype=torch.float64)
     d_go = dev(g_o)
     ops.bn_bwd_reduce(d_go, d_act, mean, rstd, red)
     assert rel_l2(red[C:], gam_r.grad) < 1e-4 and rel_l2(red[:C], bet_r.grad) < 1e-4

