@@ -435,6 +435,178 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD:  gw[cs][cb][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,cb,2oh-2+kh,2ow-2+kw]
+// GEMM with M = cs, N = (cb, tap) — one 16-wide N tile per (cb, 16 taps) — and K = output pixels, 4 consecutive ow
+// per MFMA.  A[cs][pixel] comes from the small tile, B[pixel][tap] again straight from the raw big tile:
+// lane (tap j, pixel k) reads  cb*plane + (2r+kh)*Wt + 2*(ow0+k) + kw.
+// Workgroups are persistent over (sample, band) units: accumulators stay in registers across units and are flushed
+// once at the end with float atomics (Cs*Cb*k*k values per wave), so atomic traffic is grid-size x weight-size, not
+// unit-count x weight-size.  Waves split the N tiles WN ways and the pixel steps 4/WN ways.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int MT, int NB, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, const float* __restrict__ big,
+                                                              const float* __restrict__ big_scale,
+                                                              const float* __restrict__ big_shift,
+                                                              const float* __restrict__ small_in,
+                                                              const float* __restrict__ small_scale,
+                                                              const float* __restrict__ small_shift,
+                                                              float* __restrict__ gw, int R, int Wt, int WsP, int SP,
+                                                              int bands, int units) {
+  constexpr int KK = KS * KS;
+  constexpr int NTAP_T = (KK + 15) / 16;  // N tiles per big channel
+  constexpr int WK = 4 / WN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int rows_in = 2 * (R - 1) + KS;
+  const int plane = rows_in * Wt;
+  float* big_tile = lds;                      // [Cb][rows_in][Wt]
+  float* small_tile = lds + d.Cb * plane;     // [Cs][SP]  (SP >= R*WsP, SP % 32 == 2)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gn = wave % WN, wk = wave / WN;
+  const int n_tiles = d.Cb * NTAP_T;
+
+  int offB[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    int nt = gn * NB + n;
+    if (nt >= n_tiles) nt = 0;
+    const int cb = nt / NTAP_T;
+    const int tau = (nt - cb * NTAP_T) * 16 + (lane & 15);
+    const int kh = tau < KK ? tau / KS : 0, kw = tau < KK ? tau - (tau / KS) * KS : 0;
+    offB[n] = cb * plane + kh * Wt + kw + 2 * (lane >> 4);
+  }
+  int offA[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) offA[m] = min(m * 16 + (lane & 15), d.Cs - 1) * SP + (lane >> 4);
+
+  f32x4 acc[MT][NB];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int steps_per_row = WsP / 4;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int b = u / bands, band = u - b * bands;
+    const int oh0 = band * R;
+    const int rows_out = min(R, d.Hs - oh0);
+    const int ih0 = oh0 * 2 - d.pad;
+    __syncthreads();
+    for (int row_id = wave; row_id < d.Cb * rows_in; row_id += 4) {
+      const int c = row_id / rows_in, rr = row_id - c * rows_in;
+      const int ih = ih0 + rr;
+      const bool row_ok = ih >= 0 && ih < d.Hb;
+      float sc = 1.f, sh = 0.f;
+      if (big_scale) {
+        sc = big_scale[c];
+        sh = big_shift[c];
+      }
+      const float* src = big + (((int64_t)b * d.Cb + c) * d.Hb + (row_ok ? ih : 0)) * d.Wb;
+      float* dst = big_tile + c * plane + rr * Wt;
+      for (int cc = lane; cc < Wt; cc += 64) {
+        const int iw = cc - d.pad;
+        float v = 0.f;
+        if (row_ok && iw >= 0 && iw < d.Wb) v = fmaf(src[iw], sc, sh);
+        dst[cc] = v;
+      }
+    }
+    for (int row_id = wave; row_id < d.Cs * R; row_id += 4) {
+      const int cs = row_id / R, r = row_id - cs * R;
+      const bool row_ok = r < rows_out;
+      float sc = 1.f, sh = 0.f;
+      if (small_scale) {
+        sc = small_scale[cs];
+        sh = small_shift[cs];
+      }
+      const float* src = small_in + (((int64_t)b * d.Cs + cs) * d.Hs + (row_ok ? oh0 + r : 0)) * d.Ws;
+      float* dst = small_tile + cs * SP + r * WsP;
+      for (int cc = lane; cc < WsP; cc += 64) {
+        float v = 0.f;
+        if (row_ok && cc < d.Ws) v = fmaf(src[cc], sc, sh);
+        dst[cc] = v;
+      }
+    }
+    __syncthreads();
+    const int S = rows_out * steps_per_row;
+    for (int s = wk; s < S; s += WK) {
+      const int r = s / steps_per_row, ow0 = (s - r * steps_per_row) * 4;
+      const float* ap = small_tile + r * WsP + ow0;
+      const float* bp = big_tile + 2 * r * Wt + 2 * ow0;
+      float a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = ap[offA[m]];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const float bv = bp[offB[n]];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  // ---- flush: D col = lane&15 = tap within the N tile, row = (lane>>4)*4 + reg = cs within the M tile
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int nt = gn * NB + n;
+    if (nt < n_tiles) {
+      const int cb = nt / NTAP_T;
+      const int tau = (nt - cb * NTAP_T) * 16 + (lane & 15);
+      if (tau < KK) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int cs = m * 16 + (lane >> 4) * 4 + reg;
+            if (cs < d.Cs) atomicAdd(&gw[((int64_t)cs * d.Cb + cb) * KK + tau], acc[m][n][reg]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int MT, int NB, int WN>
+int launch_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                 const float* small_in, const float* small_scale, const float* small_shift, float* gw, hipStream_t st) {
+  constexpr int KK = KS * KS;
+  const int WsP = (d->Ws + 3) / 4 * 4;
+  const int Wt = max(d->Wb + 2 * d->pad, 2 * (WsP - 1) + KS + 1);
+  int R = min(d->Hs, 4);
+  size_t bytes = 0;
+  int SP = 0;
+  for (; R >= 1; --R) {
+    SP = R * WsP;
+    SP += (34 - (SP % 32)) % 32;  // SP % 32 == 2: conflict-free A-fragment reads
+    bytes = sizeof(float) * ((size_t)d->Cb * (2 * (R - 1) + KS) * Wt + (size_t)d->Cs * SP);
+    if (bytes <= 72 * 1024 || R == 1) break;
+  }
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = conv_wgrad_mfma_kernel<KS, MT, NB, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+      pgv_set_error("conv_wgrad_mfma: cannot raise the dynamic LDS limit");
+      return PGV_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * KK, st) != hipSuccess) {
+    pgv_set_error("conv_wgrad_mfma: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int bands = (int)pgv_cdiv(d->Hs, R);
+  const int units = bands * d->B;
+  if (units == 0) return 1;
+  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / bytes));
+  const int grid = min(units, 256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, *d, big, big_scale, big_shift, small_in, small_scale,
+                     small_shift, gw, R, Wt, WsP, SP, bands, units);
+  PGV_CHECK_LAUNCH("conv_wgrad_mfma");
+  return 1;
+}
+
 }  // namespace
 
 int pgv_conv_down_tuned(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
@@ -476,5 +648,28 @@ int pgv_conv_up_tuned(const pgv_conv_desc* d, const float* small_in, const float
       return launch_up<5, 1, 6, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     return 0;
   }
+  return 0;
+}
+
+int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc*) { return 0; }
+
+int pgv_conv_wgrad_tuned(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                         void* /*workspace*/, int64_t /*workspace_bytes*/, hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != d->kw) return 0;
+#define WG(KS, MT, NB, WN) \
+  return launch_wgrad<KS, MT, NB, WN>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st)
+  if (d->kh == 4) {
+    // N tiles = Cb; a wave group covers NB of them, WN groups cover NB*WN >= Cb
+    if (d->Cs <= 16 && d->Cb <= 8) WG(4, 1, 8, 1);
+    if (d->Cs <= 32 && d->Cb <= 16) WG(4, 2, 8, 2);
+    if (d->Cs <= 64 && d->Cb <= 32) WG(4, 4, 8, 4);
+    return 0;
+  }
+  if (d->kh == 5) {
+    if (d->Cs <= 16 && d->Cb <= 2) WG(5, 1, 4, 1);  // 2 tap tiles per big channel
+    return 0;
+  }
+#undef WG
   return 0;
 }

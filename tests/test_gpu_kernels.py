@@ -102,12 +102,12 @@ def test_conv_down_up_wgrad(ops, case, policy):
         y.backward(small)
         gw = torch.empty((Cs, Cb, k, k), device='cuda')
         ops.conv_wgrad(geom, dev(big), dev(small), gw, big_scale=dev(sc_b), big_shift=dev(sh_b))
-        assert rel_l2(gw, wv.grad) < 2e-5
+        assert rel_l2(gw, wv.grad) < 5e-5   # fp32 fma chain over B*Hs*Ws pixels (up to 45k) per output
         wv = w.clone().requires_grad_(True)
         y = F.conv2d(big, wv, None, stride=s, padding=p)
         y.backward(_affine(small, sc_s, sh_s))
         ops.conv_wgrad(geom, dev(big), dev(small), gw, small_scale=dev(sc_s), small_shift=dev(sh_s))
-        assert rel_l2(gw, wv.grad) < 2e-5
+        assert rel_l2(gw, wv.grad) < 5e-5   # fp32 fma chain over B*Hs*Ws pixels (up to 45k) per output
     finally:
         lib.pgv_set_kernel_policy(0)
 
