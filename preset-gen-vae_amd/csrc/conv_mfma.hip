@@ -12,12 +12,15 @@
 //      phases.  So  D[(cb,ph,pw)][(u,v)] = sum_k W'[(cb,ph,pw)][k] * X[k][(u,v)],  k = (cs, th, tw): M = 4*Cb rows, one
 //      MFMA per (cs, th-group); each lane ends up with the 2x2 output block of its (u,v) for one channel and stores
 //      it as two float2 rows.
+//  * WGRAD gw[cs][cb][tap] = sum_pixels small[cs][pixel] * big[cb][pixel, tap]: M = cs, N = (cb, 16 taps), K = 4
+//      consecutive output pixels per MFMA; persistent workgroups keep the accumulators in registers over many
+//      (sample, band) units and flush once with float atomics.
 //
 // A workgroup (4 waves) owns a full-width band of output rows of one sample, so every global row it touches is a
 // contiguous NCHW segment; the band's input rows (+halo, zero padding, and the producer's BatchNorm affine folded in)
-// are staged once into LDS, weights are staged per channel chunk, each wave owns NT pixel tiles x all MT channel
-// tiles of accumulators.  Epilogue: bias + LeakyReLU/Hardtanh, store, and per-channel sum / sum-of-squares partials
-// (wave shuffle -> LDS -> one float64 atomic per channel per workgroup) for the BatchNorm that follows.
+// are staged into LDS with batched (8 loads in flight per lane) coalesced reads, weights are staged per channel
+// chunk.  Epilogue: bias + LeakyReLU/Hardtanh, store, and per-channel sum / sum-of-squares partials (wave shuffle ->
+// LDS -> one float64 atomic per channel per workgroup) for the BatchNorm that follows.
 #include "conv_kernels.h"
 
 namespace {
@@ -25,6 +28,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kLdsTarget = 76 * 1024;  // aim at two workgroups per CU
 
 __device__ __forceinline__ float group16_sum(float v) {
   // sum over the 16 lanes that share lane>>4 (xor butterflies stay inside the group)
@@ -35,27 +39,146 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// Exact n / d for 0 <= n < 2^20, 1 <= d < 2^12 (tile sizes here), via one float multiply.
+__device__ __forceinline__ int fast_div(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
+// Copy a [nch][rows][Wt] window of one sample's [C][H][W] tensor into LDS: element (c, rr, cc) <-> global
+// (c0+c, ih0+rr, iw0+cc), zero outside the image / beyond C, optional per-channel affine (aff_sc/aff_sh indexed by the
+// global channel) applied inside the image only — i.e. the zero padding stays zero, as nn.Conv2d pads the *BatchNorm
+// output*.  U independent loads are issued per lane before the first one is consumed.
+template <int U>
+__device__ __forceinline__ void stage_window(float* __restrict__ tile, int plane_stride,
+                                             const float* __restrict__ src, int C, int H, int W, int c0, int nch,
+                                             int rows, int Wt, int ih0, int iw0, const float* __restrict__ aff_sc,
+                                             const float* __restrict__ aff_sh, int tid) {
+  const int total = nch * rows * Wt;
+  const float inv_wt = 1.0f / (float)Wt, inv_rows = 1.0f / (float)rows;
+  for (int e0 = tid; e0 < total; e0 += 256 * U) {
+    float v[U];
+    int li[U], ch[U];
+    bool inb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = min(e0 + u * 256, total - 1);
+      const int row = fast_div(e, inv_wt), cc = e - row * Wt;
+      const int c = fast_div(row, inv_rows), rr = row - c * rows;
+      const int cg = c0 + c, ih = ih0 + rr, iw = iw0 + cc;
+      inb[u] = cg < C && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      v[u] = inb[u] ? src[((int64_t)cg * H + ih) * W + iw] : 0.f;
+      li[u] = c * plane_stride + rr * Wt + cc;
+      ch[u] = cg;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * 256 < total) {
+        float x = v[u];
+        if (aff_sc && inb[u]) x = fmaf(x, aff_sc[ch[u]], aff_sh[ch[u]]);
+        tile[li[u]] = x;
+      }
+    }
+  }
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+
+// Row-band copy for tiles whose LDS row stride equals the image width W: rows [ih_lo, ih_hi) of a channel are ONE
+// contiguous NCHW segment, copied 16 bytes per lane per load with U loads in flight (global_load_dwordx4 ->
+// ds_write_b128) to  tile + c*plane_stride + (ih_lo-ih0)*W ; window rows outside the image are zero-filled, channels
+// beyond C are zero planes; the producer's BatchNorm affine is applied to the copied data (the horizontal zero padding
+// is not stored at all: consumers mask out-of-range columns).  Caller guarantees 16-byte alignment of
+// tile + (ih_lo-ih0)*W and plane_stride % 4 == 0.
+template <int U>
+__device__ __forceinline__ void stage_rows_contig(float* __restrict__ tile, int plane_stride,
+                                                  const float* __restrict__ src, int C, int H, int W, int c0, int nch,
+                                                  int rows, int ih0, const float* __restrict__ aff_sc,
+                                                  const float* __restrict__ aff_sh, int tid) {
+  const int ih_lo = max(ih0, 0), ih_hi = min(ih0 + rows, H);
+  const int L = max(ih_hi - ih_lo, 0) * W;  // floats per channel
+  const int Q = (L + 3) >> 2;
+  const int lead = (ih_lo - ih0) * W;
+  const float inv_q = 1.0f / (float)max(Q, 1);
+  const int items = nch * Q;
+  for (int e0 = tid; e0 < items; e0 += 256 * U) {
+    f32x4 v[U];
+    int cc[U], qq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = min(e0 + u * 256, items - 1);
+      const int c = fast_div(e, inv_q), q = e - c * Q;
+      const int cg = c0 + c;
+      cc[u] = c;
+      qq[u] = q;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (cg < C) {
+        const float* g = src + ((int64_t)cg * H + ih_lo) * W + 4 * q;
+        if (4 * q + 4 <= L) {
+          const f4u t = *reinterpret_cast<const f4u*>(g);
+          v[u] = f32x4{t.x, t.y, t.z, t.w};
+        } else {
+          v[u].x = g[0];
+          if (4 * q + 1 < L) v[u].y = g[1];
+          if (4 * q + 2 < L) v[u].z = g[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * 256 < items) {
+        f32x4 x = v[u];
+        const int cg = c0 + cc[u];
+        if (aff_sc && cg < C) {
+          const float sc = aff_sc[cg], sh = aff_sh[cg];
+          const int rem = L - 4 * qq[u];  // elements of this quad inside the segment
+          x.x = fmaf(x.x, sc, sh);
+          x.y = rem > 1 ? fmaf(x.y, sc, sh) : 0.f;
+          x.z = rem > 2 ? fmaf(x.z, sc, sh) : 0.f;
+          x.w = rem > 3 ? fmaf(x.w, sc, sh) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(tile + cc[u] * plane_stride + lead + 4 * qq[u]) = x;
+      }
+    }
+  }
+  // zero rows above / below the image (first and last bands only)
+  const int tail0 = lead + 4 * Q, tail_n = rows * W - tail0;
+  if (lead > 0 || tail_n > 0) {
+    for (int c = 0; c < nch; ++c) {
+      float* p = tile + c * plane_stride;
+      for (int i = tid; i < lead; i += 256) p[i] = 0.f;
+      for (int i = tid; i < tail_n; i += 256) p[tail0 + i] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_affine(float* __restrict__ aff, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int C, int tid) {
+  if (scale)
+    for (int i = tid; i < C; i += 256) {
+      aff[i] = scale[i];
+      aff[C + i] = shift[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int MT, int NT, int CK>
-__global__ __launch_bounds__(256) void conv_down_mfma_kernel(pgv_conv_desc d, const float* __restrict__ big,
+__global__ __launch_bounds__(256, 2) void conv_down_mfma_kernel(pgv_conv_desc d, const float* __restrict__ big,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias, int act, float slope,
                                                              float* __restrict__ out, double* __restrict__ stats,
-                                                             int R, int Wt) {
+                                                             int R, int plane) {
   constexpr int KWS = (KS + 3) / 4;  // MFMA k-groups along kw
   constexpr int KWP = KWS * 4;       // kw padded to a multiple of 4 (zero weights beyond KS)
   constexpr int CSP = MT * 16 + 1;   // padded [k][cs] weight row: odd stride => conflict-free transposing writes
   constexpr int KC = CK * KS * KWP;  // k rows per channel chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rows_in = 2 * (R - 1) + KS;
-  const int plane = rows_in * Wt;
-  float* in_tile = lds;
-  float* w_tile = in_tile + CK * plane;
-  float* st_tile = w_tile + KC * CSP;  // [4 waves][MT*16][2]
+  const int Wb = d.Wb;
+  float* w_tile = lds + 8 + CK * plane;
+  float* st_tile = w_tile + KC * CSP;      // [4 waves][MT*16][2]
+  float* aff = st_tile + 4 * MT * 16 * 2;  // [2][Cb]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
@@ -63,14 +186,24 @@ __global__ __launch_bounds__(256) void conv_down_mfma_kernel(pgv_conv_desc d, co
   const int rows_out = min(R, d.Hs - oh0);
   const int Pb = rows_out * d.Ws;
   const int ih0 = oh0 * 2 - d.pad;
+  const float* src = big + (int64_t)b * d.Cb * d.Hb * Wb;
+  // input tile: row stride = Wb (rows are copied as contiguous NCHW segments); 4 floats of front slack for the
+  // col = -2 reads, plus a shift that makes the first copied row 16-byte aligned in LDS
+  const int lead = (max(ih0, 0) - ih0) * Wb;
+  float* in_tile = lds + 4 + ((4 - (lead & 3)) & 3);
 
   int offB[NT];
+  bool okB[NT][KWS];
+  const float inv_ws = 1.0f / (float)d.Ws;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int p = (wave * NT + t) * 16 + (lane & 15);
     const int pv = p < Pb ? p : 0;
-    const int r = pv / d.Ws, c = pv - r * d.Ws;
-    offB[t] = 2 * r * Wt + 2 * c + (lane >> 4);
+    const int r = fast_div(pv, inv_ws), c = pv - r * d.Ws;
+    const int col = 2 * c - d.pad + (lane >> 4);
+    offB[t] = 2 * r * Wb + col;
+#pragma unroll
+    for (int kws = 0; kws < KWS; ++kws) okB[t][kws] = (unsigned)(col + 4 * kws) < (unsigned)Wb;
   }
   const int offA = (lane >> 4) * CSP + (lane & 15);
   f32x4 acc[MT][NT];
@@ -79,33 +212,31 @@ __global__ __launch_bounds__(256) void conv_down_mfma_kernel(pgv_conv_desc d, co
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  stage_affine(aff, in_scale, in_shift, d.Cb, tid);
+  if (in_scale) __syncthreads();
   for (int cb0 = 0; cb0 < d.Cb; cb0 += CK) {
-    __syncthreads();
-    for (int row_id = wave; row_id < CK * rows_in; row_id += 4) {
-      const int c = row_id / rows_in, rr = row_id - c * rows_in;
-      const int cb = cb0 + c, ih = ih0 + rr;
-      const bool row_ok = cb < d.Cb && ih >= 0 && ih < d.Hb;
-      float sc = 1.f, sh = 0.f;
-      if (in_scale && cb < d.Cb) {
-        sc = in_scale[cb];
-        sh = in_shift[cb];
+    if (cb0) __syncthreads();
+    stage_rows_contig<4>(in_tile, plane, src, d.Cb, d.Hb, Wb, cb0, CK, rows_in, ih0, in_scale ? aff : nullptr,
+                         aff + d.Cb, tid);
+    for (int i0 = tid; i0 < KC * MT * 16; i0 += 256 * 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * 256;
+        const int cs = idx / KC, k = idx - cs * KC;
+        const int c = k / (KS * KWP), rem = k - c * (KS * KWP);
+        const int kh = rem / KWP, kw = rem - kh * KWP;
+        const bool ok = idx < KC * MT * 16 && cs < d.Cs && cb0 + c < d.Cb && kw < KS;
+        v[u] = ok ? w[(((int64_t)cs * d.Cb + cb0 + c) * KS + kh) * KS + kw] : 0.f;
       }
-      const float* src = big + (((int64_t)b * d.Cb + (row_ok ? cb : 0)) * d.Hb + (row_ok ? ih : 0)) * d.Wb;
-      float* dst = in_tile + c * plane + rr * Wt;
-      for (int cc = lane; cc < Wt; cc += 64) {
-        const int iw = cc - d.pad;
-        float v = 0.f;
-        if (row_ok && iw >= 0 && iw < d.Wb) v = fmaf(src[iw], sc, sh);
-        dst[cc] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * 256;
+        if (idx < KC * MT * 16) {
+          const int cs = idx / KC, k = idx - cs * KC;
+          w_tile[k * CSP + cs] = v[u];
+        }
       }
-    }
-    for (int idx = tid; idx < KC * MT * 16; idx += 256) {
-      const int cs = idx / KC, k = idx - cs * KC;
-      const int c = k / (KS * KWP), rem = k - c * (KS * KWP);
-      const int kh = rem / KWP, kw = rem - kh * KWP;
-      float v = 0.f;
-      if (cs < d.Cs && cb0 + c < d.Cb && kw < KS) v = w[(((int64_t)cs * d.Cb + cb0 + c) * KS + kh) * KS + kw];
-      w_tile[k * CSP + cs] = v;
     }
     __syncthreads();
     for (int c = 0; c < CK; ++c) {
@@ -117,10 +248,10 @@ __global__ __launch_bounds__(256) void conv_down_mfma_kernel(pgv_conv_desc d, co
           float a[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) a[m] = w_tile[kidx * CSP + offA + m * 16];
-          const float* bp = in_tile + c * plane + kh * Wt + kws * 4;
+          const float* bp = in_tile + c * plane + kh * Wb + kws * 4;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const float bv = bp[offB[t]];
+            const float bv = okB[t][kws] ? bp[offB[t]] : 0.f;
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][t], 0, 0, 0);
           }
@@ -179,56 +310,46 @@ __global__ __launch_bounds__(256) void conv_down_mfma_kernel(pgv_conv_desc d, co
   }
 }
 
-struct DownPlan {
-  int R, Wt;
-  size_t lds_bytes;
-};
-
-template <int KS, int MT, int NT, int CK>
-bool plan_down(const pgv_conv_desc* d, DownPlan* pl) {
-  constexpr int KWS = (KS + 3) / 4, KWP = KWS * 4, CSP = MT * 16 + 1, KC = CK * KS * KWP;
-  const int Wt = max(d->Wb + 2 * d->pad, 2 * (d->Ws - 1) + KWP);
-  int R = min(d->Hs, (64 * NT) / d->Ws);
-  while (R >= 1) {
-    const size_t bytes = sizeof(float) * ((size_t)CK * (2 * (R - 1) + KS) * Wt + (size_t)KC * CSP + 4 * MT * 16 * 2);
-    if (bytes <= 72 * 1024 || (R == 1 && bytes <= (size_t)kMaxLds)) {
-      pl->R = R;
-      pl->Wt = Wt;
-      pl->lds_bytes = bytes;
-      return true;
+template <typename K>
+int raise_lds_limit(K kern, bool* done, const char* who) {
+  if (!*done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+      pgv_set_error("%s: cannot raise the dynamic LDS limit", who);
+      return PGV_E_LAUNCH;
     }
-    --R;
+    *done = true;
   }
-  return false;
+  return PGV_OK;
 }
 
 template <int KS, int MT, int NT, int CK>
 int launch_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift, const float* w,
                 const float* bias, int act, float slope, float* out, double* stats, hipStream_t st) {
-  DownPlan pl;
-  if (!plan_down<KS, MT, NT, CK>(d, &pl)) return 0;
+  constexpr int KWS = (KS + 3) / 4, KWP = KWS * 4, CSP = MT * 16 + 1, KC = CK * KS * KWP;
+  int R = min(d->Hs, (64 * NT) / d->Ws);
+  if (R < 1) return 0;
+  size_t bytes = 0;
+  int plane = 0;
+  for (; R >= 1; --R) {
+    plane = ((2 * (R - 1) + KS) * d->Wb + 8 + 3) / 4 * 4;
+    bytes = sizeof(float) * (8 + (size_t)CK * plane + (size_t)KC * CSP + 4 * MT * 16 * 2 + 2 * d->Cb);
+    if (bytes <= (size_t)kLdsTarget || R == 1) break;
+  }
+  if (bytes > (size_t)kMaxLds) return 0;
   auto kern = conv_down_mfma_kernel<KS, MT, NT, CK>;
   static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
-      pgv_set_error("conv_down_mfma: cannot raise the dynamic LDS limit");
-      return PGV_E_LAUNCH;
-    }
-    attr_done = true;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_down_mfma");
+  if (rc) return rc;
+  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_mfma: memset failed");
+    return PGV_E_LAUNCH;
   }
-  if (stats) {
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
-      pgv_set_error("conv_down_mfma: memset failed");
-      return PGV_E_LAUNCH;
-    }
-  }
-  dim3 grid((unsigned)pgv_cdiv(d->Hs, pl.R), (unsigned)d->B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds_bytes, st, *d, big, in_scale, in_shift, w, bias, act, slope, out,
-                     stats, pl.R, pl.Wt);
+  dim3 grid((unsigned)pgv_cdiv(d->Hs, R), (unsigned)d->B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, *d, big, in_scale, in_shift, w, bias, act, slope, out, stats, R,
+                     plane);
   PGV_CHECK_LAUNCH("conv_down_mfma");
   return 1;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // UP  (sub-pixel phases; see the header comment)
@@ -253,15 +374,17 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
   const int plane = rows_in * Wt;
   float* in_tile = lds;
   float* w_tile = in_tile + CK * plane;
-  float* st_tile = w_tile + KC * MSP;  // [4 waves][MT*4][2]
+  float* st_tile = w_tile + KC * MSP;     // [4 waves][MT*4][2]
+  float* aff = st_tile + 4 * MT * 4 * 2;  // [2][Cs]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int u0 = blockIdx.x * R;
   const int rows_g = min(R, Hg - u0);
   const int Pb = rows_g * Wg;
-  const int ih0 = u0 + 2 - T;    // input row of local row 0
-  const int iw0 = 2 - TWR;       // input col of local col 0
+  const int ih0 = u0 + 2 - T;  // input row of local row 0
+  const int iw0 = 2 - TWR;     // input col of local col 0
+  const float* src = small_in + (int64_t)b * d.Cs * d.Hs * d.Ws;
 
   int offB[NT];
 #pragma unroll
@@ -283,38 +406,34 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int M = 4 * d.Cb;
+  stage_affine(aff, in_scale, in_shift, d.Cs, tid);
   for (int cs0 = 0; cs0 < d.Cs; cs0 += CK) {
     __syncthreads();
-    for (int row_id = wave; row_id < CK * rows_in; row_id += 4) {
-      const int c = row_id / rows_in, rr = row_id - c * rows_in;
-      const int cs = cs0 + c, ih = ih0 + rr;
-      const bool row_ok = cs < d.Cs && ih >= 0 && ih < d.Hs;
-      float sc = 1.f, sh = 0.f;
-      if (in_scale && cs < d.Cs) {
-        sc = in_scale[cs];
-        sh = in_shift[cs];
-      }
-      const float* src = small_in + (((int64_t)b * d.Cs + (row_ok ? cs : 0)) * d.Hs + (row_ok ? ih : 0)) * d.Ws;
-      float* dst = in_tile + c * plane + rr * Wt;
-      for (int cc = lane; cc < Wt; cc += 64) {
-        const int iw = iw0 + cc;
-        float v = 0.f;
-        if (row_ok && iw >= 0 && iw < d.Ws) v = fmaf(src[iw], sc, sh);
-        dst[cc] = v;
-      }
-    }
+    stage_window<8>(in_tile, plane, src, d.Cs, d.Hs, d.Ws, cs0, CK, rows_in, Wt, ih0, iw0, in_scale ? aff : nullptr,
+                    aff + d.Cs, tid);
     // weights: w_tile[(c*KG + g)*4 + kk][m], m = cb*4 + ph*2 + pw, value w[cs][cb][ph+2th][pw+2tw]
-    for (int idx = tid; idx < KC * MT * 16; idx += 256) {
-      const int krow = idx / (MT * 16), m = idx - krow * (MT * 16);
-      const int c = krow / (KG * 4), rem = krow - c * (KG * 4);
-      const int g = rem >> 2, kk = rem & 3;
-      const int th = (KS == 4) ? (kk >> 1) : g, tw = (KS == 4) ? (kk & 1) : kk;
-      const int cb = m >> 2, ph = (m >> 1) & 1, pw = m & 1;
-      const int kh = ph + 2 * th, kw = pw + 2 * tw;
-      float v = 0.f;
-      if (m < M && cs0 + c < d.Cs && kh < KS && kw < KS)
-        v = w[(((int64_t)(cs0 + c) * d.Cb + cb) * KS + kh) * KS + kw];
-      w_tile[krow * MSP + m] = v;
+    for (int i0 = tid; i0 < KC * MT * 16; i0 += 256 * 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * 256;
+        const int krow = idx / (MT * 16), m = idx - krow * (MT * 16);
+        const int c = krow / (KG * 4), rem = krow - c * (KG * 4);
+        const int g = rem >> 2, kk = rem & 3;
+        const int th = (KS == 4) ? (kk >> 1) : g, tw = (KS == 4) ? (kk & 1) : kk;
+        const int cb = m >> 2, ph = (m >> 1) & 1, pw = m & 1;
+        const int kh = ph + 2 * th, kw = pw + 2 * tw;
+        const bool ok = idx < KC * MT * 16 && m < M && cs0 + c < d.Cs && kh < KS && kw < KS;
+        v[u] = ok ? w[(((int64_t)(cs0 + c) * d.Cb + cb) * KS + kh) * KS + kw] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * 256;
+        if (idx < KC * MT * 16) {
+          const int krow = idx / (MT * 16), m = idx - krow * (MT * 16);
+          w_tile[krow * MSP + m] = v[u];
+        }
+      }
     }
     __syncthreads();
     for (int c = 0; c < CK; ++c) {
@@ -409,24 +528,18 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   if (R < 1) return 0;
   size_t bytes = 0;
   for (; R >= 1; --R) {
-    bytes = sizeof(float) * ((size_t)CK * (R + T - 1) * (Wg + TWR - 1) + (size_t)KC * MSP + 4 * MT * 4 * 2);
-    if (bytes <= 72 * 1024 || R == 1) break;
+    bytes = sizeof(float) *
+            ((size_t)CK * (R + T - 1) * (Wg + TWR - 1) + (size_t)KC * MSP + 4 * MT * 4 * 2 + 2 * d->Cs);
+    if (bytes <= (size_t)kLdsTarget || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
   auto kern = conv_up_mfma_kernel<KS, MT, NT, CK>;
   static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
-      pgv_set_error("conv_up_mfma: cannot raise the dynamic LDS limit");
-      return PGV_E_LAUNCH;
-    }
-    attr_done = true;
-  }
-  if (stats) {
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
-      pgv_set_error("conv_up_mfma: memset failed");
-      return PGV_E_LAUNCH;
-    }
+  int rc = raise_lds_limit(kern, &attr_done, "conv_up_mfma");
+  if (rc) return rc;
+  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_mfma: memset failed");
+    return PGV_E_LAUNCH;
   }
   dim3 grid((unsigned)pgv_cdiv(Hg, R), (unsigned)d->B);
   hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, *d, small_in, in_scale, in_shift, w, bias, act, slope, out,
@@ -434,7 +547,6 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   PGV_CHECK_LAUNCH("conv_up_mfma");
   return 1;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // WGRAD:  gw[cs][cb][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,cb,2oh-2+kh,2ow-2+kw]
@@ -460,8 +572,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, c
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rows_in = 2 * (R - 1) + KS;
   const int plane = rows_in * Wt;
-  float* big_tile = lds;                      // [Cb][rows_in][Wt]
-  float* small_tile = lds + d.Cb * plane;     // [Cs][SP]  (SP >= R*WsP, SP % 32 == 2)
+  float* big_tile = lds;                   // [Cb][rows_in][Wt]
+  float* small_tile = lds + d.Cb * plane;  // [Cs][SP]  (SP >= R*WsP, SP % 32 == 2)
+  float* aff_b = small_tile + d.Cs * SP;   // [2][Cb]
+  float* aff_s = aff_b + 2 * d.Cb;         // [2][Cs]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -488,47 +602,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, c
 #pragma unroll
     for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  stage_affine(aff_b, big_scale, big_shift, d.Cb, tid);
+  stage_affine(aff_s, small_scale, small_shift, d.Cs, tid);
   const int steps_per_row = WsP / 4;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int b = u / bands, band = u - b * bands;
     const int oh0 = band * R;
     const int rows_out = min(R, d.Hs - oh0);
-    const int ih0 = oh0 * 2 - d.pad;
     __syncthreads();
-    for (int row_id = wave; row_id < d.Cb * rows_in; row_id += 4) {
-      const int c = row_id / rows_in, rr = row_id - c * rows_in;
-      const int ih = ih0 + rr;
-      const bool row_ok = ih >= 0 && ih < d.Hb;
-      float sc = 1.f, sh = 0.f;
-      if (big_scale) {
-        sc = big_scale[c];
-        sh = big_shift[c];
-      }
-      const float* src = big + (((int64_t)b * d.Cb + c) * d.Hb + (row_ok ? ih : 0)) * d.Wb;
-      float* dst = big_tile + c * plane + rr * Wt;
-      for (int cc = lane; cc < Wt; cc += 64) {
-        const int iw = cc - d.pad;
-        float v = 0.f;
-        if (row_ok && iw >= 0 && iw < d.Wb) v = fmaf(src[iw], sc, sh);
-        dst[cc] = v;
-      }
-    }
-    for (int row_id = wave; row_id < d.Cs * R; row_id += 4) {
-      const int cs = row_id / R, r = row_id - cs * R;
-      const bool row_ok = r < rows_out;
-      float sc = 1.f, sh = 0.f;
-      if (small_scale) {
-        sc = small_scale[cs];
-        sh = small_shift[cs];
-      }
-      const float* src = small_in + (((int64_t)b * d.Cs + cs) * d.Hs + (row_ok ? oh0 + r : 0)) * d.Ws;
-      float* dst = small_tile + cs * SP + r * WsP;
-      for (int cc = lane; cc < WsP; cc += 64) {
-        float v = 0.f;
-        if (row_ok && cc < d.Ws) v = fmaf(src[cc], sc, sh);
-        dst[cc] = v;
-      }
-    }
+    stage_window<8>(big_tile, plane, big + (int64_t)b * d.Cb * d.Hb * d.Wb, d.Cb, d.Hb, d.Wb, 0, d.Cb, rows_in, Wt,
+                    oh0 * 2 - d.pad, -d.pad, big_scale ? aff_b : nullptr, aff_b + d.Cb, tid);
+    stage_window<8>(small_tile, SP, small_in + (int64_t)b * d.Cs * d.Hs * d.Ws, d.Cs, d.Hs, d.Ws, 0, d.Cs, R, WsP, oh0,
+                    0, small_scale ? aff_s : nullptr, aff_s + d.Cs, tid);
     __syncthreads();
     const int S = rows_out * steps_per_row;
     for (int s = wk; s < S; s += WK) {
@@ -579,19 +664,15 @@ int launch_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scal
   for (; R >= 1; --R) {
     SP = R * WsP;
     SP += (34 - (SP % 32)) % 32;  // SP % 32 == 2: conflict-free A-fragment reads
-    bytes = sizeof(float) * ((size_t)d->Cb * (2 * (R - 1) + KS) * Wt + (size_t)d->Cs * SP);
-    if (bytes <= 72 * 1024 || R == 1) break;
+    bytes = sizeof(float) *
+            ((size_t)d->Cb * (2 * (R - 1) + KS) * Wt + (size_t)d->Cs * SP + 2 * (size_t)(d->Cb + d->Cs));
+    if (bytes <= (size_t)kLdsTarget || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
   auto kern = conv_wgrad_mfma_kernel<KS, MT, NB, WN>;
   static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
-      pgv_set_error("conv_wgrad_mfma: cannot raise the dynamic LDS limit");
-      return PGV_E_LAUNCH;
-    }
-    attr_done = true;
-  }
+  int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_mfma");
+  if (rc) return rc;
   if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * KK, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_mfma: memset failed");
     return PGV_E_LAUNCH;
@@ -624,7 +705,7 @@ int pgv_conv_down_tuned(const pgv_conv_desc* d, const float* big, const float* i
   }
   if (d->kh == 5) {
     if (d->Cs <= 16)
-      return launch_down<5, 1, 6, 1>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+      return launch_down<5, 1, 12, 1>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     return 0;
   }
   return 0;
@@ -657,19 +738,19 @@ int pgv_conv_wgrad_tuned(const pgv_conv_desc* d, const float* big, const float* 
                          const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                          void* /*workspace*/, int64_t /*workspace_bytes*/, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != d->kw) return 0;
-#define WG(KS, MT, NB, WN) \
+#define PGV_WG(KS, MT, NB, WN) \
   return launch_wgrad<KS, MT, NB, WN>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st)
   if (d->kh == 4) {
     // N tiles = Cb; a wave group covers NB of them, WN groups cover NB*WN >= Cb
-    if (d->Cs <= 16 && d->Cb <= 8) WG(4, 1, 8, 1);
-    if (d->Cs <= 32 && d->Cb <= 16) WG(4, 2, 8, 2);
-    if (d->Cs <= 64 && d->Cb <= 32) WG(4, 4, 8, 4);
+    if (d->Cs <= 16 && d->Cb <= 8) PGV_WG(4, 1, 8, 1);
+    if (d->Cs <= 32 && d->Cb <= 16) PGV_WG(4, 2, 8, 2);
+    if (d->Cs <= 64 && d->Cb <= 32) PGV_WG(4, 4, 8, 4);
     return 0;
   }
   if (d->kh == 5) {
-    if (d->Cs <= 16 && d->Cb <= 2) WG(5, 1, 4, 1);  // 2 tap tiles per big channel
+    if (d->Cs <= 16 && d->Cb <= 2) PGV_WG(5, 1, 4, 1);  // 2 tap tiles per big channel
     return 0;
   }
-#undef WG
+#undef PGV_WG
   return 0;
 }
