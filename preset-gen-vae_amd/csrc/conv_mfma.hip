@@ -357,12 +357,13 @@ int launch_down(const pgv_conv_desc* d, const float* big, const float* in_scale,
 // KS = 4: T = 2 taps per axis, one MFMA k-group per input channel with k = th*2 + tw.
 // KS = 5: T = 3 taps per axis, three k-groups per input channel (group = th) with k = tw padded to 4 (zero weight).
 template <int KS, int MT, int NT, int CK>
-__global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, const float* __restrict__ small_in,
+__global__ __launch_bounds__(256, 2) void conv_up_mfma_kernel(pgv_conv_desc d, const float* __restrict__ small_in,
                                                            const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            int act, float slope, float* __restrict__ out,
-                                                           double* __restrict__ stats, int R, int Wg, int Hg) {
+                                                           double* __restrict__ stats, int R, int Wg, int Hg,
+                                                           int plane) {
   constexpr int T = (KS + 1) / 2;         // taps per axis
   constexpr int KG = (KS == 4) ? 1 : T;   // MFMA k-groups per input channel
   constexpr int TWR = (KS == 4) ? 2 : 4;  // tw values a k-group reads along the row
@@ -370,10 +371,8 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
   constexpr int KC = CK * KG * 4;         // k rows per channel chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rows_in = R + T - 1;
-  const int Wt = Wg + TWR - 1;
-  const int plane = rows_in * Wt;
-  float* in_tile = lds;
-  float* w_tile = in_tile + CK * plane;
+  const int Ws = d.Ws;
+  float* w_tile = lds + 8 + CK * plane;
   float* st_tile = w_tile + KC * MSP;     // [4 waves][MT*4][2]
   float* aff = st_tile + 4 * MT * 4 * 2;  // [2][Cs]
 
@@ -383,20 +382,24 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
   const int rows_g = min(R, Hg - u0);
   const int Pb = rows_g * Wg;
   const int ih0 = u0 + 2 - T;  // input row of local row 0
-  const int iw0 = 2 - TWR;     // input col of local col 0
-  const float* src = small_in + (int64_t)b * d.Cs * d.Hs * d.Ws;
+  const float* src = small_in + (int64_t)b * d.Cs * d.Hs * Ws;
+  // input tile with row stride = Ws (contiguous NCHW row segments), front slack for col < 0 reads (masked)
+  const int lead = (max(ih0, 0) - ih0) * Ws;
+  float* in_tile = lds + 4 + ((4 - (lead & 3)) & 3);
 
   int offB[NT];
+  bool okB[NT];
+  const float inv_wg = 1.0f / (float)Wg;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int p = (wave * NT + t) * 16 + (lane & 15);
     const int pv = p < Pb ? p : 0;
-    const int ur = pv / Wg, v = pv - ur * Wg;
+    const int ur = fast_div(pv, inv_wg), v = pv - ur * Wg;
     const int k = lane >> 4;
-    if (KS == 4)
-      offB[t] = (ur + 1 - (k >> 1)) * Wt + v + 1 - (k & 1);
-    else
-      offB[t] = (ur + T - 1) * Wt + v + (TWR - 1) - k;
+    const int col = (KS == 4) ? v + 1 - (k & 1) : v + 1 - k;
+    const int row = (KS == 4) ? ur + 1 - (k >> 1) : ur + T - 1;
+    offB[t] = row * Ws + col;
+    okB[t] = (unsigned)col < (unsigned)Ws;
   }
   const int offA = (lane >> 4) * MSP + (lane & 15);
   f32x4 acc[MT][NT];
@@ -407,10 +410,11 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
 
   const int M = 4 * d.Cb;
   stage_affine(aff, in_scale, in_shift, d.Cs, tid);
+  if (in_scale) __syncthreads();
   for (int cs0 = 0; cs0 < d.Cs; cs0 += CK) {
-    __syncthreads();
-    stage_window<8>(in_tile, plane, src, d.Cs, d.Hs, d.Ws, cs0, CK, rows_in, Wt, ih0, iw0, in_scale ? aff : nullptr,
-                    aff + d.Cs, tid);
+    if (cs0) __syncthreads();
+    stage_rows_contig<4>(in_tile, plane, src, d.Cs, d.Hs, Ws, cs0, CK, rows_in, ih0, in_scale ? aff : nullptr,
+                         aff + d.Cs, tid);
     // weights: w_tile[(c*KG + g)*4 + kk][m], m = cb*4 + ph*2 + pw, value w[cs][cb][ph+2th][pw+2tw]
     for (int i0 = tid; i0 < KC * MT * 16; i0 += 256 * 4) {
       float v[4];
@@ -443,10 +447,10 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
         float a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = w_tile[kidx * MSP + offA + m * 16];
-        const float* bp = in_tile + c * plane - ((KS == 4) ? 0 : g * Wt);
+        const float* bp = in_tile + c * plane - ((KS == 4) ? 0 : g * Ws);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float bv = bp[offB[t]];
+          const float bv = okB[t] ? bp[offB[t]] : 0.f;
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][t], 0, 0, 0);
         }
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pgv_conv_desc d, cons
       for (int t = 0; t < NT; ++t) {
         const int p = (wave * NT + t) * 16 + (lane & 15);
         if (p < Pb) {
-          const int ur = p / Wg, v = p - ur * Wg;
+          const int ur = fast_div(p, inv_wg), v = p - ur * Wg;
           const int ow = 2 * v;
 #pragma unroll
           for (int ph = 0; ph < 2; ++ph) {
@@ -527,9 +531,11 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   int R = min(Hg, (64 * NT) / Wg);
   if (R < 1) return 0;
   size_t bytes = 0;
+  int plane = 0;
+  (void)TWR;
   for (; R >= 1; --R) {
-    bytes = sizeof(float) *
-            ((size_t)CK * (R + T - 1) * (Wg + TWR - 1) + (size_t)KC * MSP + 4 * MT * 4 * 2 + 2 * d->Cs);
+    plane = ((R + T - 1) * d->Ws + 8 + 3) / 4 * 4;
+    bytes = sizeof(float) * (8 + (size_t)CK * plane + (size_t)KC * MSP + 4 * MT * 4 * 2 + 2 * d->Cs);
     if (bytes <= (size_t)kLdsTarget || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
@@ -543,7 +549,7 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   }
   dim3 grid((unsigned)pgv_cdiv(Hg, R), (unsigned)d->B);
   hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, *d, small_in, in_scale, in_shift, w, bias, act, slope, out,
-                     stats, R, Wg, Hg);
+                     stats, R, Wg, Hg, plane);
   PGV_CHECK_LAUNCH("conv_up_mfma");
   return 1;
 }
@@ -558,23 +564,22 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
 // unit-count x weight-size.  Waves split the N tiles WN ways and the pixel steps 4/WN ways.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int MT, int NB, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, const float* __restrict__ big,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(pgv_conv_desc d, const float* __restrict__ big,
                                                               const float* __restrict__ big_scale,
                                                               const float* __restrict__ big_shift,
                                                               const float* __restrict__ small_in,
                                                               const float* __restrict__ small_scale,
                                                               const float* __restrict__ small_shift,
-                                                              float* __restrict__ gw, int R, int Wt, int WsP, int SP,
+                                                              float* __restrict__ gw, int R, int plane, int WsP, int SP,
                                                               int bands, int units) {
   constexpr int KK = KS * KS;
   constexpr int NTAP_T = (KK + 15) / 16;  // N tiles per big channel
   constexpr int WK = 4 / WN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rows_in = 2 * (R - 1) + KS;
-  const int plane = rows_in * Wt;
-  float* big_tile = lds;                   // [Cb][rows_in][Wt]
-  float* small_tile = lds + d.Cb * plane;  // [Cs][SP]  (SP >= R*WsP, SP % 32 == 2)
-  float* aff_b = small_tile + d.Cs * SP;   // [2][Cb]
+  const int Wb = d.Wb, Ws = d.Ws;
+  float* small_tile = lds + 8 + d.Cb * plane;  // [Cs][SP]: R rows of Ws floats, contiguous (SP % 4 == 0)
+  float* aff_b = small_tile + d.Cs * SP;       // [2][Cb]
   float* aff_s = aff_b + 2 * d.Cb;         // [2][Cs]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, c
   const int gn = wave % WN, wk = wave / WN;
   const int n_tiles = d.Cb * NTAP_T;
 
-  int offB[NB];
+  int offB[NB], colB[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
     int nt = gn * NB + n;
@@ -590,7 +595,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, c
     const int cb = nt / NTAP_T;
     const int tau = (nt - cb * NTAP_T) * 16 + (lane & 15);
     const int kh = tau < KK ? tau / KS : 0, kw = tau < KK ? tau - (tau / KS) * KS : 0;
-    offB[n] = cb * plane + kh * Wt + kw + 2 * (lane >> 4);
+    colB[n] = kw - d.pad + 2 * (lane >> 4);  // + 2*ow0 = image column of this lane's B element
+    offB[n] = cb * plane + kh * Wb + colB[n];
   }
   int offA[MT];
 #pragma unroll
@@ -605,29 +611,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(pgv_conv_desc d, c
   stage_affine(aff_b, big_scale, big_shift, d.Cb, tid);
   stage_affine(aff_s, small_scale, small_shift, d.Cs, tid);
   const int steps_per_row = WsP / 4;
+  const int ow_hi = (Wb + d.pad - KS) / 2 - 3;  // ow0 <= ow_hi: all 4 pixels x all taps of the step are inside the row
+  __syncthreads();
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int b = u / bands, band = u - b * bands;
     const int oh0 = band * R;
     const int rows_out = min(R, d.Hs - oh0);
-    __syncthreads();
-    stage_window<8>(big_tile, plane, big + (int64_t)b * d.Cb * d.Hb * d.Wb, d.Cb, d.Hb, d.Wb, 0, d.Cb, rows_in, Wt,
-                    oh0 * 2 - d.pad, -d.pad, big_scale ? aff_b : nullptr, aff_b + d.Cb, tid);
-    stage_window<8>(small_tile, SP, small_in + (int64_t)b * d.Cs * d.Hs * d.Ws, d.Cs, d.Hs, d.Ws, 0, d.Cs, R, WsP, oh0,
-                    0, small_scale ? aff_s : nullptr, aff_s + d.Cs, tid);
+    const int ih0 = oh0 * 2 - d.pad;
+    const int lead = (max(ih0, 0) - ih0) * Wb;
+    float* big_tile = lds + 4 + ((4 - (lead & 3)) & 3);  // [Cb][plane], row stride Wb
+    if (u != (int)blockIdx.x) __syncthreads();
+    stage_rows_contig<4>(big_tile, plane, big + (int64_t)b * d.Cb * d.Hb * Wb, d.Cb, d.Hb, Wb, 0, d.Cb, rows_in, ih0,
+                         big_scale ? aff_b : nullptr, aff_b + d.Cb, tid);
+    stage_rows_contig<4>(small_tile, SP, small_in + (int64_t)b * d.Cs * d.Hs * Ws, d.Cs, d.Hs, Ws, 0, d.Cs, R, oh0,
+                         small_scale ? aff_s : nullptr, aff_s + d.Cs, tid);
     __syncthreads();
     const int S = rows_out * steps_per_row;
     for (int s = wk; s < S; s += WK) {
       const int r = s / steps_per_row, ow0 = (s - r * steps_per_row) * 4;
-      const float* ap = small_tile + r * WsP + ow0;
-      const float* bp = big_tile + 2 * r * Wt + 2 * ow0;
+      const float* ap = small_tile + r * Ws + ow0;
+      const float* bp = big_tile + 2 * r * Wb + 2 * ow0;
       float a[MT];
+      if (ow0 >= 1 && ow0 <= ow_hi && ow0 + 4 <= Ws) {  // interior step (wave-uniform): no masking needed
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = ap[offA[m]];
+        for (int m = 0; m < MT; ++m) a[m] = ap[offA[m]];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const float bv = bp[offB[n]];
+        for (int n = 0; n < NB; ++n) {
+          const float bv = bp[offB[n]];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][n], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][n], 0, 0, 0);
+        }
+      } else {  // row ends: pixels beyond Ws contribute nothing, columns outside the image are the zero padding
+        const bool a_ok = ow0 + (lane >> 4) < Ws;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = a_ok ? ap[offA[m]] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const float bv = ((unsigned)(2 * ow0 + colB[n]) < (unsigned)Wb) ? bp[offB[n]] : 0.f;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][n], 0, 0, 0);
+        }
       }
     }
   }
@@ -657,15 +680,14 @@ int launch_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scal
                  const float* small_in, const float* small_scale, const float* small_shift, float* gw, hipStream_t st) {
   constexpr int KK = KS * KS;
   const int WsP = (d->Ws + 3) / 4 * 4;
-  const int Wt = max(d->Wb + 2 * d->pad, 2 * (WsP - 1) + KS + 1);
   int R = min(d->Hs, 4);
   size_t bytes = 0;
-  int SP = 0;
+  int SP = 0, plane = 0;
   for (; R >= 1; --R) {
-    SP = R * WsP;
-    SP += (34 - (SP % 32)) % 32;  // SP % 32 == 2: conflict-free A-fragment reads
-    bytes = sizeof(float) *
-            ((size_t)d->Cb * (2 * (R - 1) + KS) * Wt + (size_t)d->Cs * SP + 2 * (size_t)(d->Cb + d->Cs));
+    SP = (R * d->Ws + 8 + 3) / 4 * 4;
+    SP += (36 - (SP % 32)) % 32;  // SP % 32 == 4: 16-byte aligned channel rows, at most 2-way A-read conflicts
+    plane = ((2 * (R - 1) + KS) * d->Wb + 16 + 3) / 4 * 4;
+    bytes = sizeof(float) * (8 + (size_t)d->Cb * plane + (size_t)d->Cs * SP + 2 * (size_t)(d->Cb + d->Cs));
     if (bytes <= (size_t)kLdsTarget || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
@@ -683,7 +705,7 @@ int launch_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scal
   const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / bytes));
   const int grid = min(units, 256 * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, *d, big, big_scale, big_shift, small_in, small_scale,
-                     small_shift, gw, R, Wt, WsP, SP, bands, units);
+                     small_shift, gw, R, plane, WsP, SP, bands, units);
   PGV_CHECK_LAUNCH("conv_wgrad_mfma");
   return 1;
 }
