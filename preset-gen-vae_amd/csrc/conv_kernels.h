@@ -25,6 +25,17 @@ int pgv_conv_wgrad_tuned(const pgv_conv_desc* d, const float* big, const float* 
                          void* workspace, int64_t workspace_bytes, hipStream_t st);
 int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc* d);
 
+// Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
+int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                         const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                         hipStream_t st);
+int pgv_conv_up_direct(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                       const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                       hipStream_t st);
+int pgv_conv_wgrad_direct(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                          const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                          hipStream_t st);
+
 // Gather-GEMM kernels for the deep (small-plane, many-channel) layers: same return convention as the tuned ones.
 int pgv_conv_down_gemm(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,

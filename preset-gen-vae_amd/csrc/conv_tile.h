@@ -1,0 +1,153 @@
+// LDS tile staging helpers shared by the band convolution kernels (conv_mfma.hip, conv_pipe.hip).
+#pragma once
+#include "conv_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kLdsTarget = 76 * 1024;  // aim at two workgroups per CU
+
+__device__ __forceinline__ float group16_sum(float v) {
+  // sum over the 16 lanes that share lane>>4 (xor butterflies stay inside the group)
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// Exact n / d for 0 <= n < 2^20, 1 <= d < 2^12 (tile sizes here), via one float multiply.
+__device__ __forceinline__ int fast_div(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
+// Copy a [nch][rows][Wt] window of one sample's [C][H][W] tensor into LDS: element (c, rr, cc) <-> global
+// (c0+c, ih0+rr, iw0+cc), zero outside the image / beyond C, optional per-channel affine (aff_sc/aff_sh indexed by the
+// global channel) applied inside the image only — i.e. the zero padding stays zero, as nn.Conv2d pads the *BatchNorm
+// output*.  U independent loads are issued per lane before the first one is consumed.
+template <int U>
+__device__ __forceinline__ void stage_window(float* __restrict__ tile, int plane_stride,
+                                             const float* __restrict__ src, int C, int H, int W, int c0, int nch,
+                                             int rows, int Wt, int ih0, int iw0, const float* __restrict__ aff_sc,
+                                             const float* __restrict__ aff_sh, int tid) {
+  const int total = nch * rows * Wt;
+  const float inv_wt = 1.0f / (float)Wt, inv_rows = 1.0f / (float)rows;
+  for (int e0 = tid; e0 < total; e0 += 256 * U) {
+    float v[U];
+    int li[U], ch[U];
+    bool inb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = min(e0 + u * 256, total - 1);
+      const int row = fast_div(e, inv_wt), cc = e - row * Wt;
+      const int c = fast_div(row, inv_rows), rr = row - c * rows;
+      const int cg = c0 + c, ih = ih0 + rr, iw = iw0 + cc;
+      inb[u] = cg < C && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      v[u] = inb[u] ? src[((int64_t)cg * H + ih) * W + iw] : 0.f;
+      li[u] = c * plane_stride + rr * Wt + cc;
+      ch[u] = cg;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * 256 < total) {
+        float x = v[u];
+        if (aff_sc && inb[u]) x = fmaf(x, aff_sc[ch[u]], aff_sh[ch[u]]);
+        tile[li[u]] = x;
+      }
+    }
+  }
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+
+// Row-band copy for tiles whose LDS row stride equals the image width W: rows [ih_lo, ih_hi) of a channel are ONE
+// contiguous NCHW segment, copied 16 bytes per lane per load with U loads in flight (global_load_dwordx4 ->
+// ds_write_b128) to  tile + c*plane_stride + (ih_lo-ih0)*W ; window rows outside the image are zero-filled, channels
+// beyond C are zero planes; the producer's BatchNorm affine is applied to the copied data (the horizontal zero padding
+// is not stored at all: consumers mask out-of-range columns).  Caller guarantees 16-byte alignment of
+// tile + (ih_lo-ih0)*W and plane_stride % 4 == 0.
+template <int U>
+__device__ __forceinline__ void stage_rows_contig(float* __restrict__ tile, int plane_stride,
+                                                  const float* __restrict__ src, int C, int H, int W, int c0, int nch,
+                                                  int rows, int ih0, const float* __restrict__ aff_sc,
+                                                  const float* __restrict__ aff_sh, int tid) {
+  const int ih_lo = max(ih0, 0), ih_hi = min(ih0 + rows, H);
+  const int L = max(ih_hi - ih_lo, 0) * W;  // floats per channel
+  const int Q = (L + 3) >> 2;
+  const int lead = (ih_lo - ih0) * W;
+  const float inv_q = 1.0f / (float)max(Q, 1);
+  const int items = nch * Q;
+  for (int e0 = tid; e0 < items; e0 += 256 * U) {
+    f32x4 v[U];
+    int cc[U], qq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = min(e0 + u * 256, items - 1);
+      const int c = fast_div(e, inv_q), q = e - c * Q;
+      const int cg = c0 + c;
+      cc[u] = c;
+      qq[u] = q;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (cg < C) {
+        const float* g = src + ((int64_t)cg * H + ih_lo) * W + 4 * q;
+        if (4 * q + 4 <= L) {
+          const f4u t = *reinterpret_cast<const f4u*>(g);
+          v[u] = f32x4{t.x, t.y, t.z, t.w};
+        } else {
+          v[u].x = g[0];
+          if (4 * q + 1 < L) v[u].y = g[1];
+          if (4 * q + 2 < L) v[u].z = g[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * 256 < items) {
+        f32x4 x = v[u];
+        const int cg = c0 + cc[u];
+        if (aff_sc && cg < C) {
+          const float sc = aff_sc[cg], sh = aff_sh[cg];
+          const int rem = L - 4 * qq[u];  // elements of this quad inside the segment
+          x.x = fmaf(x.x, sc, sh);
+          x.y = rem > 1 ? fmaf(x.y, sc, sh) : 0.f;
+          x.z = rem > 2 ? fmaf(x.z, sc, sh) : 0.f;
+          x.w = rem > 3 ? fmaf(x.w, sc, sh) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(tile + cc[u] * plane_stride + lead + 4 * qq[u]) = x;
+      }
+    }
+  }
+  // zero rows above / below the image (first and last bands only)
+  const int tail0 = lead + 4 * Q, tail_n = rows * W - tail0;
+  if (lead > 0 || tail_n > 0) {
+    for (int c = 0; c < nch; ++c) {
+      float* p = tile + c * plane_stride;
+      for (int i = tid; i < lead; i += 256) p[i] = 0.f;
+      for (int i = tid; i < tail_n; i += 256) p[tail0 + i] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_affine(float* __restrict__ aff, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int C, int tid) {
+  if (scale)
+    for (int i = tid; i < C; i += 256) {
+      aff[i] = scale[i];
+      aff[C + i] = shift[i];
+    }
+}
+
+template <typename K>
+int raise_lds_limit(K kern, bool* done, const char* who) {
+  if (!*done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+      pgv_set_error("%s: cannot raise the dynamic LDS limit", who);
+      return PGV_E_LAUNCH;
+    }
+    *done = true;
+  }
+  return PGV_OK;
+}
+
+
+}  // namespace
