@@ -9,6 +9,8 @@
 
 namespace {
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at a 4-byte aligned address
+
 struct Split {
   int nsplit;
   int per;  // batch items per split
@@ -94,9 +96,19 @@ __global__ void affine_kernel(const float* __restrict__ a, const float* __restri
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   const float sc = scale[c], sh = shift[c];
+  const int HW4 = HW >> 2;
   for (int b = b0; b < b1; ++b) {
     const int64_t base = ((int64_t)b * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) o[base + i] = fmaf(a[base + i], sc, sh);
+    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
+      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
+      f4u r;
+      r.x = fmaf(v.x, sc, sh);
+      r.y = fmaf(v.y, sc, sh);
+      r.z = fmaf(v.z, sc, sh);
+      r.w = fmaf(v.w, sc, sh);
+      *reinterpret_cast<f4u*>(o + base + 4 * i) = r;
+    }
+    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) o[base + i] = fmaf(a[base + i], sc, sh);
   }
 }
 
@@ -106,27 +118,27 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float*
   __shared__ double red[16];
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  const double mu = mean[c], rs = rstd[c];
-  double s0 = 0.0, s1 = 0.0, d0 = 0.0, d1 = 0.0;
+  const float mu = mean[c], rs = rstd[c];
+  double s0 = 0.0, d0 = 0.0;
+  const int HW4 = HW >> 2;
   for (int b = b0; b < b1; ++b) {
     const int64_t base = ((int64_t)b * C + c) * HW;
-    int i = threadIdx.x;
-    for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
-      const double g0 = g_o[base + i], g1 = g_o[base + i + blockDim.x];
-      const double h0 = ((double)a[base + i] - mu) * rs, h1 = ((double)a[base + i + blockDim.x] - mu) * rs;
-      s0 += g0;
-      d0 = fma(g0, h0, d0);
-      s1 += g1;
-      d1 = fma(g1, h1, d1);
+    // 16 bytes per lane (planes are only 4-byte aligned in NCHW with odd H*W): float partials per quad, double across
+    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
+      const f4u g = *reinterpret_cast<const f4u*>(g_o + base + 4 * i);
+      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
+      const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+      s0 += (double)((g.x + g.y) + (g.z + g.w));
+      d0 += (double)fmaf(g.x, h0, fmaf(g.y, h1, fmaf(g.z, h2, g.w * h3)));
     }
-    if (i < HW) {
-      const double g0 = g_o[base + i];
-      s0 += g0;
-      d0 = fma(g0, ((double)a[base + i] - mu) * rs, d0);
+    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) {
+      const float g0 = g_o[base + i];
+      s0 += (double)g0;
+      d0 += (double)(g0 * ((a[base + i] - mu) * rs));
     }
   }
-  const double s = pgv_block_sum_d(s0 + s1, red);
-  const double dd = pgv_block_sum_d(d0 + d1, red);
+  const double s = pgv_block_sum_d(s0, red);
+  const double dd = pgv_block_sum_d(d0, red);
   if (threadIdx.x == 0) {
     atomicAdd(&red_out[c], s);
     atomicAdd(&red_out[C + c], dd);
@@ -153,18 +165,32 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
     }
   }
   float acc = 0.f;
+  auto one = [&](float g, float av) -> float {
+    if (has_bn) g = sc * (g - c1 - (av - mu) * rs * c2);
+    if (act == PGV_ACT_LEAKY_RELU)
+      g = av > 0.f ? g : slope * g;
+    else if (act == PGV_ACT_HARDTANH)
+      g = (av > -1.f && av < 1.f) ? g : 0.f;
+    return g;
+  };
+  const int HW4 = HW >> 2;
   for (int b = b0; b < b1; ++b) {
     const int64_t base = ((int64_t)b * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      const float av = a[base + i];
-      float g = g_o[base + i];
-      if (has_bn) g = sc * (g - c1 - (av - mu) * rs * c2);
-      if (act == PGV_ACT_LEAKY_RELU)
-        g = av > 0.f ? g : slope * g;
-      else if (act == PGV_ACT_HARDTANH)
-        g = (av > -1.f && av < 1.f) ? g : 0.f;
-      g_y[base + i] = g;
-      acc += g;
+    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
+      const f4u g = *reinterpret_cast<const f4u*>(g_o + base + 4 * i);
+      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
+      f4u r;
+      r.x = one(g.x, v.x);
+      r.y = one(g.y, v.y);
+      r.z = one(g.z, v.z);
+      r.w = one(g.w, v.w);
+      *reinterpret_cast<f4u*>(g_y + base + 4 * i) = r;
+      acc += (r.x + r.y) + (r.z + r.w);
+    }
+    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) {
+      const float r = one(g_o[base + i], a[base + i]);
+      g_y[base + i] = r;
+      acc += r;
     }
   }
   if (gbias) {

@@ -512,39 +512,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(pgv_conv_desc d
                          small_scale ? aff_s : nullptr, aff_s + d.Cs, tid);
     __syncthreads();
     const int S = rows_out * steps_per_row;
-    for (int s = wk; s < S; s += WK) {
-      const int r = s / steps_per_row, ow0 = (s - r * steps_per_row) * 4;
+    // pixel steps of this wave: st = wk, wk+WK, ... ; LDS reads of the next step are issued before the MFMAs of the
+    // current one (two register sets, ping-pong)
+    auto load_step = [&](int st, float (&av)[MT], float (&bv)[NB]) {
+      const int r = st / steps_per_row, ow0 = (st - r * steps_per_row) * 4;
       const float* ap = small_tile + r * Ws + ow0;
       const float* bp = big_tile + 2 * r * Wb + 2 * ow0;
-      float a[MT];
-      if (ow0 >= 1 && ow0 <= ow_hi && ow0 + 4 <= Ws) {  // interior step (wave-uniform): no masking needed
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = ap[offA[m]];
-        float bv[NB];
+      for (int m = 0; m < MT; ++m) av[m] = ap[offA[m]];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bv[n] = bp[offB[n]];
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
-      } else {  // row ends: pixels beyond Ws contribute nothing, columns outside the image are the zero padding
+      for (int n = 0; n < NB; ++n) bv[n] = bp[offB[n]];
+    };
+    auto compute_step = [&](int st, float (&av)[MT], float (&bv)[NB]) {
+      const int r = st / steps_per_row, ow0 = (st - r * steps_per_row) * 4;
+      if (!(ow0 >= 1 && ow0 <= ow_hi && ow0 + 4 <= Ws)) {
+        // row ends: pixels beyond Ws contribute nothing, columns outside the image are the zero padding
         const bool a_ok = ow0 + (lane >> 4) < Ws;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float raw = ap[offA[m]];
-          a[m] = a_ok ? raw : 0.f;
-        }
-        float bv[NB];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) bv[n] = bp[offB[n]];
+        for (int m = 0; m < MT; ++m) av[m] = a_ok ? av[m] : 0.f;
 #pragma unroll
         for (int n = 0; n < NB; ++n) bv[n] = ((unsigned)(2 * ow0 + colB[n]) < (unsigned)Wb) ? bv[n] : 0.f;
+      }
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+      for (int n = 0; n < NB; ++n)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+    };
+    {
+      float a0[MT], a1[MT], b0[NB], b1[NB];
+      int st = wk;
+      if (st < S) load_step(st, a0, b0);
+      for (; st < S; st += 2 * WK) {
+        const bool has1 = st + WK < S;
+        if (has1) load_step(st + WK, a1, b1);
+        compute_step(st, a0, b0);
+        if (has1) {
+          if (st + 2 * WK < S) load_step(st + 2 * WK, a0, b0);
+          compute_step(st + WK, a1, b1);
+        }
       }
     }
   }

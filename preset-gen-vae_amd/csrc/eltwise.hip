@@ -83,6 +83,15 @@ __global__ void mul_kernel(const float* __restrict__ x, const float* __restrict_
     y[i] = x[i] * m[i];
 }
 
+// 16-byte-per-lane variants (used when every pointer is 16-byte aligned; the n % 4 tail goes through the scalar kernel)
+__global__ void mul4_kernel(const float4* __restrict__ x, const float4* __restrict__ m, int64_t n4,
+                            float4* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = x[i], b = m[i];
+    y[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     p[i] = v;
@@ -156,6 +165,37 @@ __global__ void sqerr_fwd_kernel(const float* __restrict__ xhat, const float* __
   if (threadIdx.x == 0) atomicAdd(loss, s * scale);
 }
 
+__global__ void sqerr_fwd4_kernel(const float4* __restrict__ xhat, const float4* __restrict__ x, int64_t n4, float scale,
+                                  float* __restrict__ loss) {
+  __shared__ float red[16];
+  float a0 = 0.f, a1 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = xhat[i], q = x[i];
+    const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+    a0 = fmaf(d0, d0, fmaf(d1, d1, a0));
+    a1 = fmaf(d2, d2, fmaf(d3, d3, a1));
+  }
+  const float s = pgv_block_sum(a0 + a1, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s * scale);
+}
+
+__global__ void sqerr_bwd4_kernel(const float4* __restrict__ xhat, const float4* __restrict__ x,
+                                  const float* __restrict__ g_loss, int64_t n4, float scale, int hardtanh,
+                                  float4* __restrict__ g) {
+  const float k = 2.0f * scale * (g_loss ? g_loss[0] : 1.0f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = xhat[i], q = x[i];
+    float4 r = make_float4(k * (p.x - q.x), k * (p.y - q.y), k * (p.z - q.z), k * (p.w - q.w));
+    if (hardtanh) {
+      if (!(p.x > -1.0f && p.x < 1.0f)) r.x = 0.f;
+      if (!(p.y > -1.0f && p.y < 1.0f)) r.y = 0.f;
+      if (!(p.z > -1.0f && p.z < 1.0f)) r.z = 0.f;
+      if (!(p.w > -1.0f && p.w < 1.0f)) r.w = 0.f;
+    }
+    g[i] = r;
+  }
+}
+
 __global__ void sqerr_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ x,
                                  const float* __restrict__ g_loss, int64_t n, float scale, int hardtanh,
                                  float* __restrict__ g) {
@@ -193,6 +233,34 @@ __global__ void adam_tick_kernel(double* __restrict__ pows, float* __restrict__ 
     hyper[1] = (float)(1.0 - p1);
     hyper[2] = (float)(1.0 - p2);
   }
+}
+
+__global__ void adam4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                             float4* __restrict__ v, int64_t n4, const float* __restrict__ hyper, float beta1, float beta2,
+                             float eps, float wd) {
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    gi = fmaf(wd, pi, gi * gs);
+    mi = fmaf(beta1, mi, (1.0f - beta1) * gi);
+    vi = fmaf(beta2, vi, (1.0f - beta2) * gi * gi);
+    pi = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p[i], mm = m[i], vv = v[i];
+    const float4 gg = g[i];
+    upd(pp.x, gg.x, mm.x, vv.x);
+    upd(pp.y, gg.y, mm.y, vv.y);
+    upd(pp.z, gg.z, mm.z, vv.z);
+    upd(pp.w, gg.w, mm.w, vv.w);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
 }
 
 int zero_scalar(float* p, hipStream_t st, const char* who) {
@@ -236,7 +304,15 @@ int pgv_rng_advance(uint64_t* rng_state, uint64_t inc, void* stream) {
 int pgv_mul(const float* x, const float* m, int64_t n, float* y, void* stream) {
   PGV_CHECK_ARG(x && m && y && n >= 0, "pgv_mul: bad argument");
   if (n == 0) return PGV_OK;
-  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(kBlock), 0, pgv_stream(stream), x, m, n, y);
+  int64_t done = 0;
+  if (aligned16(x, m, y) && n >= 4) {
+    done = n & ~(int64_t)3;
+    hipLaunchKernelGGL(mul4_kernel, dim3(grid_for(done, 8)), dim3(kBlock), 0, pgv_stream(stream), (const float4*)x,
+                       (const float4*)m, done / 4, (float4*)y);
+  }
+  if (done < n)
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n - done)), dim3(kBlock), 0, pgv_stream(stream), x + done, m + done,
+                       n - done, y + done);
   PGV_CHECK_LAUNCH("mul");
   return PGV_OK;
 }
@@ -272,7 +348,15 @@ int pgv_sqerr_fwd(const float* xhat, const float* x, int64_t n, float scale, flo
   int rc = zero_scalar(loss, st, "pgv_sqerr_fwd");
   if (rc) return rc;
   if (n == 0) return PGV_OK;
-  hipLaunchKernelGGL(sqerr_fwd_kernel, dim3(grid_for(n, 8)), dim3(kBlock), 0, st, xhat, x, n, scale, loss);
+  int64_t done = 0;
+  if (aligned16(xhat, x) && n >= 4) {
+    done = n & ~(int64_t)3;
+    hipLaunchKernelGGL(sqerr_fwd4_kernel, dim3(grid_for(done, 16)), dim3(kBlock), 0, st, (const float4*)xhat,
+                       (const float4*)x, done / 4, scale, loss);
+  }
+  if (done < n)
+    hipLaunchKernelGGL(sqerr_fwd_kernel, dim3(grid_for(n - done, 8)), dim3(kBlock), 0, st, xhat + done, x + done,
+                       n - done, scale, loss);
   PGV_CHECK_LAUNCH("sqerr_fwd");
   return PGV_OK;
 }
@@ -281,8 +365,15 @@ int pgv_sqerr_bwd(const float* xhat, const float* x, const float* g_loss, int64_
                   float* g, void* stream) {
   PGV_CHECK_ARG(xhat && x && g && n >= 0, "pgv_sqerr_bwd: bad argument");
   if (n == 0) return PGV_OK;
-  hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), xhat, x, g_loss, n,
-                     scale, hardtanh, g);
+  int64_t done = 0;
+  if (aligned16(xhat, x, g) && n >= 4) {
+    done = n & ~(int64_t)3;
+    hipLaunchKernelGGL(sqerr_bwd4_kernel, dim3(grid_for(done, 8)), dim3(kBlock), 0, pgv_stream(stream),
+                       (const float4*)xhat, (const float4*)x, g_loss, done / 4, scale, hardtanh, (float4*)g);
+  }
+  if (done < n)
+    hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(grid_for(n - done, 4)), dim3(kBlock), 0, pgv_stream(stream), xhat + done,
+                       x + done, g_loss, n - done, scale, hardtanh, g + done);
   PGV_CHECK_LAUNCH("sqerr_bwd");
   return PGV_OK;
 }
@@ -291,8 +382,15 @@ int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
                   float beta2, float eps, float weight_decay, void* stream) {
   PGV_CHECK_ARG(p && g && m && v && hyper && n >= 0, "pgv_adam_step: bad argument");
   if (n == 0) return PGV_OK;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), p, g, m, v, n, hyper,
-                     beta1, beta2, eps, weight_decay);
+  int64_t done = 0;
+  if (aligned16(p, g, m, v) && n >= 4) {
+    done = n & ~(int64_t)3;
+    hipLaunchKernelGGL(adam4_kernel, dim3(grid_for(done, 8)), dim3(kBlock), 0, pgv_stream(stream), (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, done / 4, hyper, beta1, beta2, eps, weight_decay);
+  }
+  if (done < n)
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n - done, 4)), dim3(kBlock), 0, pgv_stream(stream), p + done,
+                       g + done, m + done, v + done, n - done, hyper, beta1, beta2, eps, weight_decay);
   PGV_CHECK_LAUNCH("adam_step");
   return PGV_OK;
 }
