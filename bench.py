@@ -176,10 +176,12 @@ def main():
     from preset_gen_vae_amd.train_step import VAETrainStep
     _lib.load()   # fails loudly if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one rank per GPU; PGV_DIST_BACKEND=gloo + a single visible GPU lets the N>1 code path be exercised on a 1-GPU box
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('PGV_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
 
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture, mc.dim_z = args.arch, args.dim_z

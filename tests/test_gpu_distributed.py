@@ -1,0 +1,113 @@
+"""GPU: the N>1 code path of the train step (bucketed gradient all-reduce on a side stream, 1/N in the fused Adam)
+on ONE device: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the 8-GPU run is the
+driver's).  The 2-rank result must equal a single-process emulation of DataParallel semantics: per-shard BatchNorm,
+gradients averaged over shards, identical Adam step on every rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, copy
+sys.path.insert(0, os.environ["PGV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PGV_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from helpers import param_shapes, synth_input, synth_vec
+from oracle import vae_oracle as vo
+from preset_gen_vae_amd import config, parallel
+from preset_gen_vae_amd.model import build
+from preset_gen_vae_amd.train_step import VAETrainStep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+arch, dz, Bs = "speccnn4l1_bn", 16, 2
+mc, tc = copy.copy(config.model), copy.copy(config.train)
+mc.encoder_architecture, mc.dim_z, mc.input_tensor_size = arch, dz, (Bs, 1, 257, 347)
+tc.latent_flow_input_regularization = "none"
+def make():
+    _, _, ae = build.build_ae_model(mc, tc)
+    sd = vo.closed_form_state_dict(param_shapes(arch, dz, False), seed=7, dtype=torch.float32)
+    ae.load_state_dict(sd)
+    return ae.cuda().train()
+c = lambda t: t.to("cuda", torch.float32).contiguous()
+n_shards = int(os.environ["PGV_SHARDS"])
+x_all, eps_all = synth_input(Bs * n_shards), synth_vec((Bs * n_shards, dz), 1.1, 0.3)
+F = 64 * 17 * 23
+ones = torch.ones(Bs, F, device="cuda")
+def inject(sh):
+    return {"eps": c(eps_all[sh * Bs:(sh + 1) * Bs]), "enc_dropout_mask": ones, "dec_dropout_mask": ones}
+if world > 1:
+    ae = make()
+    step = VAETrainStep(ae, grad_sync=lambda flat: parallel.GradAllReduce(flat, n_buckets=3))
+    out = step.step(c(x_all[rank * Bs:(rank + 1) * Bs]), inject=inject(rank))
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in ae.state_dict().items()}, os.environ["PGV_OUT"] + f".rank{rank}")
+    dist.barrier(); dist.destroy_process_group()
+else:
+    # emulation: per-shard forward/backward (own BN statistics), average the flat gradients, one Adam step
+    ae = make()
+    step = VAETrainStep(ae)
+    gsum = torch.zeros_like(step.flat.flat_grad)
+    state0 = {k: v.clone() for k, v in ae.state_dict().items()}
+    for sh in range(n_shards):
+        ae.load_state_dict(state0)          # BN buffers of replica 0 semantics: every shard starts from the same state
+        step.optimizer.zero_grad()
+        o = ae(c(x_all[sh * Bs:(sh + 1) * Bs]), None, **inject(sh))
+        from preset_gen_vae_amd.model import loss as LM
+        tot = LM.MSELoss()(o[4], c(x_all[sh * Bs:(sh + 1) * Bs])) + ae.latent_loss(o[0]) * 0.2
+        tot.backward()
+        gsum += step.flat.flat_grad
+        if sh == 0:
+            bn0 = {k: v.clone() for k, v in ae.state_dict().items() if "running" in k}
+    ae.load_state_dict(state0)
+    step.flat.flat_grad.copy_(gsum / n_shards)
+    step.optimizer.step()
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in ae.state_dict().items()}
+    sd.update({k: v.cpu() for k, v in bn0.items()})
+    torch.save(sd, os.environ["PGV_OUT"] + ".emul")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_equal_dataparallel_emulation(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    out = str(tmp_path / "state")
+    env = dict(os.environ, PGV_ROOT=ROOT, PGV_OUT=out, PGV_SHARDS="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(worker)], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert subprocess.call([sys.executable, str(worker)], env=dict(env, RANK="0", WORLD_SIZE="1")) == 0
+    r0, r1, em = (torch.load(out + s) for s in (".rank0", ".rank1", ".emul"))
+    for k in em:
+        if em[k].dtype == torch.long:
+            continue
+        if "running" in k:          # per-rank BN buffers: rank 0 == shard 0 of the emulation
+            assert torch.allclose(r0[k], em[k], rtol=1e-5, atol=1e-7), k
+            continue
+        assert torch.equal(r0[k], r1[k]), k                      # replicas stay bit-identical
+        # first Adam step = lr * g/(|g|+eps): elements whose gradient is at the float32 noise level may move by up to
+        # +-lr in either direction (sign of a ~0 gradient), everything else must agree to a small fraction of lr=2e-4
+        diff = (r0[k] - em[k]).abs()
+        assert diff.max().item() <= 2.05 * 2e-4, (k, diff.max().item())
+        assert diff.mean().item() < 2e-6, (k, diff.mean().item())
+        assert (diff > 2e-5).float().mean().item() < 0.02, k
