@@ -59,18 +59,18 @@ def synth_spectrograms(B, device, seed):
 
 
 def layer_ops(ae):
-    """(layer name, ConvGeom args) of every conv block of the model, walked from the product modules."""
+    """(layer name, ConvGeom args, has BatchNorm, is transposed) of every conv block, walked from the product modules."""
     out = []
     H, W = 257, 347
     for blk in ae.encoder._all_blocks():
         g = blk.geom(H, W)
-        out.append((f"enc{len(out) + 1}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb)))
+        out.append((f"enc{len(out) + 1}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb), blk.bn is not None, False))
         H, W = g.Hs, g.Ws
     dec_blocks = ae.decoder._all_blocks()
     first = 9 - len(dec_blocks)
     for i, blk in enumerate(dec_blocks):
         g = blk.geom(H, W)
-        out.append((f"dec{first + i}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb)))
+        out.append((f"dec{first + i}", (g.Cb, g.Cs, g.k, g.stride, g.pad, g.Hb, g.Wb), blk.bn is not None, True))
         H, W = g.Hb, g.Wb
     return out
 
@@ -94,7 +94,7 @@ def measure_roofline(ae, B, device):
     from preset_gen_vae_amd import ops
     worst = None
     table = []
-    for name, (Cb, Cs, k, s, p, Hb, Wb) in layer_ops(ae):
+    for name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up in layer_ops(ae):
         geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
         big = torch.randn(B, Cb, Hb, Wb, device=device)
         small = torch.randn(B, Cs, geom.Hs, geom.Ws, device=device)
@@ -109,12 +109,20 @@ def measure_roofline(ae, B, device):
         macs = B * Cs * geom.Hs * geom.Ws * Cb * k * k
         flops = 2.0 * macs
         nb, ns, nw = big.numel() * 4, small.numel() * 4, w.numel() * 4
+        # the launches exactly as the train step issues them: the layer's own direction carries bias + activation
+        # (+ BN statistics when the block has a BatchNorm, + the producer's folded BN), the opposite direction is the
+        # plain input-gradient product
+        fwd_stats_s = stats_s if (has_bn and not is_up) else None
+        fwd_stats_b = stats_b if (has_bn and is_up) else None
         launches = {
-            'conv_down': (lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b,
-                                                stats=stats_s, out=out_s), nb + ns + nw),
-            'conv_up': (lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s,
-                                            stats=stats_b, out=out_b), nb + ns + nw),
-            'conv_wgrad': (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b),
+            'conv_down': ((lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b,
+                                                 stats=fwd_stats_s, out=out_s)) if not is_up else
+                          (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s)), nb + ns + nw),
+            'conv_up': ((lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s,
+                                             stats=fwd_stats_b, out=out_b)) if is_up else
+                        (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b)), nb + ns + nw),
+            'conv_wgrad': ((lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)) if not is_up
+                           else (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s)),
                            nb + ns + nw),
         }
         for kname, (fn, bytes_) in launches.items():
