@@ -269,3 +269,33 @@ def closed_form_state_dict(template, seed=1234, dtype=torch.float32):
             val = base * math.sqrt(3.0 / max(1, fan_in))
         sd[k] = val.reshape(shape).to(dtype)
     return sd
+
+
+def mlp_regression_forward(sd, z, training, masks=None, new_buffers=None):
+    """regression.MLPRegression('3l1024').forward (model/regression.py:76-102): fc -> [BN1d -> Dropout] -> ReLU, the
+    last two fc layers without BN/Dropout, then PresetActivation = Hardtanh(0,1) on every output
+    (regression.py:20-53 with cat_softmax_activation=False).  ``masks``: injected keep/(1-p) dropout masks."""
+    n_fc = len([k for k in sd if k.startswith('reg_model.fc') and k.endswith('.weight')])
+    h = z
+    for l in range(1, n_fc):
+        h = F.linear(h, sd[f'reg_model.fc{l}.weight'], sd[f'reg_model.fc{l}.bias'])
+        if f'reg_model.bn{l}.weight' in sd:
+            bsd = {'rbn.weight': sd[f'reg_model.bn{l}.weight'], 'rbn.bias': sd[f'reg_model.bn{l}.bias'],
+                   'rbn.running_mean': sd[f'reg_model.bn{l}.running_mean'],
+                   'rbn.running_var': sd[f'reg_model.bn{l}.running_var']}
+            nb = {} if new_buffers is not None else None
+            h = _bn_train_or_eval(h, bsd, 'r', 'r', training, nb)
+            if nb:
+                new_buffers[f'reg_model.bn{l}.running_mean'] = nb['rbn.running_mean']
+                new_buffers[f'reg_model.bn{l}.running_var'] = nb['rbn.running_var']
+            if training and masks is not None:
+                h = h * masks[l - 1]
+        h = F.relu(h)
+    h = F.linear(h, sd[f'reg_model.fc{n_fc}.weight'], sd[f'reg_model.fc{n_fc}.bias'])
+    return F.hardtanh(h, 0.0, 1.0)
+
+
+def numeric_params_loss(v_out, v_in):
+    """Numeric branch of loss.SynthParamsLoss with normalize_losses=True (model/loss.py:107-108,136):
+    nn.MSELoss('mean') over the numerical columns (all 144 in the all-numerical representation)."""
+    return F.mse_loss(v_out, v_in, reduction='mean')

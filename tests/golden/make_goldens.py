@@ -36,6 +36,7 @@ from model import decoder as ref_decoder  # noqa: E402
 from model import encoder as ref_encoder  # noqa: E402
 from model import layer as ref_layer  # noqa: E402
 from model import loss as ref_loss  # noqa: E402
+from model import regression as ref_regression  # noqa: E402
 from utils import audio as ref_audio  # noqa: E402
 
 from oracle import vae_oracle as vo  # noqa: E402  (only for the closed-form weight/input formulas)
@@ -298,7 +299,53 @@ def run_stft_cases(out_dir):
     print('stft ->', path, os.path.getsize(path) // 1024, 'KiB')
 
 
+class _AllNumericalHelper:
+    """Duck-typed PresetIndexesHelper for the all-numerical Dexed representation (144 learnable parameters, SURVEY.md
+    §8c): the real class cannot be built here (numpy-2 assert at data/preset.py:41 and no preset database)."""
+    learnable_preset_size = 144
+
+    def get_numerical_learnable_indexes(self):
+        return list(range(144))
+
+    def get_categorical_learnable_indexes(self):
+        return []
+
+
+def run_regression_case(out_dir):
+    """model/regression.py MLPRegression('3l1024') + the numeric branch of loss.SynthParamsLoss (model/loss.py:127-136)
+    on the latent vectors of the 4-layer golden: v_out, preset-regression MSE, gradient w.r.t. z."""
+    helper = _AllNumericalHelper()
+    reg = ref_regression.MLPRegression('3l1024', 64, helper, dropout_p=0.4, cat_softmax_activation=False).double()
+    template = {k: tuple(v.shape) for k, v in reg.state_dict().items()}
+    sd = vo.closed_form_state_dict(template, seed=4321, dtype=torch.float64)
+    reg.load_state_dict(sd)
+    B = 6
+    z = (synth_vec((B, 64), 0.913, 0.2) * 1.1).requires_grad_(True)
+    v_in = 0.5 * (synth_vec((B, 144), 0.377, 0.6) + 1.0)
+    masks = [keep_mask((B, 1024), 0.4, 0.61 + 0.1 * i, 0.2 * i) for i in range(2)]   # keep/(1-p), p = 0.4
+    reg.reg_model.drp1 = _MaskMul(masks[0])
+    reg.reg_model.drp2 = _MaskMul(masks[1])
+    reg.train()
+    v_out = reg(z)
+    crit = ref_loss.SynthParamsLoss(helper, True, prevent_useless_params_loss=False, cat_bce=False, cat_softmax=True,
+                                    cat_softmax_t=0.2)
+    loss = crit(v_out.clone(), v_in.clone())
+    loss.backward()
+    out = {'in/z': z.detach().numpy(), 'in/v_in': v_in.numpy(),
+           'in/mask0_bits': np.packbits((masks[0] > 0).numpy()), 'in/mask1_bits': np.packbits((masks[1] > 0).numpy()),
+           'out/v_out': v_out.detach().numpy(), 'out/mse': np.array(loss.item()), 'out/g_z': z.grad.numpy()}
+    for k, p in reg.named_parameters():
+        pack_big('grad/' + k, p.grad, out)
+    for k, v in reg.state_dict().items():
+        if 'running' in k:
+            out['post_full/' + k] = v.numpy()
+    path = os.path.join(out_dir, 'regression_b6.npz')
+    np.savez_compressed(path, **out)
+    print('regression mse', loss.item(), '->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
+    run_regression_case(HERE)
     run_layer_cases(HERE)
     run_stft_cases(HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2', HERE)

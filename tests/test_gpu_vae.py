@@ -250,3 +250,43 @@ def test_modules_fail_loudly_on_cpu():
     ae = _build('speccnn4l1_bn', 64, 2, False)
     with pytest.raises(RuntimeError, match="no CPU fallback|ROCm device"):
         ae.eval()(torch.zeros(2, 1, 257, 347))
+
+
+def test_regression_parity_a14():
+    """preset-regression output and MSE (reference MLPRegression + numeric SynthParamsLoss golden)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import numpy as np
+    import torch.nn as nn
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd.model import loss as LM, regression
+    from test_oracle_golden import regression_template
+
+    class Helper:
+        learnable_preset_size = 144
+
+    class MaskMul(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            return x * self.m if self.training else x
+
+    g = load_golden('regression_b6.npz')
+    reg = regression.MLPRegression('3l1024', 64, Helper(), 0.4, cat_softmax_activation=False)
+    tpl = regression_template()
+    assert list(reg.state_dict().keys()) == list(tpl.keys())          # reference key names / order
+    sd = vo.closed_form_state_dict(tpl, seed=4321, dtype=torch.float64)
+    reg.load_state_dict({k: (v if v.dtype == torch.long else v.float()) for k, v in sd.items()})
+    masks = [torch.tensor(np.unpackbits(g[f'in/mask{i}_bits'])[:6 * 1024].reshape(6, 1024), dtype=torch.float32) / 0.6
+             for i in range(2)]
+    reg.reg_model.drp1, reg.reg_model.drp2 = MaskMul(masks[0].cuda()), MaskMul(masks[1].cuda())
+    reg = reg.cuda().train()
+    z = _cuda32(torch.tensor(g['in/z'])).requires_grad_(True)
+    v_out = reg(z)
+    mse = LM.MSELoss()(v_out, _cuda32(torch.tensor(g['in/v_in'])))     # HIP squared-error kernel
+    mse.backward()
+    assert rel_l2(v_out, torch.tensor(g['out/v_out'])) < 1e-5
+    assert abs(mse.item() - float(g['out/mse'])) < 1e-5 * float(g['out/mse'])
+    assert rel_l2(z.grad, torch.tensor(g['out/g_z'])) < 1e-4

@@ -140,3 +140,35 @@ def test_mel_filterbank_known_answers():
 def test_minmax_normalisation():
     s = np.array([-120.0, -60.0, 0.0])
     np.testing.assert_allclose(ao.minmax_normalize(s, -120.0, 0.0), [-1.0, 0.0, 1.0])
+
+
+def regression_template():
+    tpl = {}
+    dims = [64, 1024, 1024, 1024, 144]
+    for l in range(1, 5):
+        tpl[f'reg_model.fc{l}.weight'] = (dims[l], dims[l - 1])
+        tpl[f'reg_model.fc{l}.bias'] = (dims[l],)
+        if l < 3:
+            for n, shp in (('weight', (1024,)), ('bias', (1024,)), ('running_mean', (1024,)), ('running_var', (1024,)),
+                           ('num_batches_tracked', ())):
+                tpl[f'reg_model.bn{l}.{n}'] = shp
+    return tpl
+
+
+def test_regression_matches_reference():
+    """a14: MLPRegression + numeric SynthParamsLoss of the reference (tests/golden/regression_b6.npz)."""
+    g = load_golden('regression_b6.npz')
+    sd = vo.closed_form_state_dict(regression_template(), seed=4321, dtype=torch.float64)
+    z = torch.tensor(g['in/z']).requires_grad_(True)
+    v_in = torch.tensor(g['in/v_in'])
+    masks = [torch.tensor(np.unpackbits(g[f'in/mask{i}_bits'])[:6 * 1024].reshape(6, 1024), dtype=torch.float64) / 0.6
+             for i in range(2)]
+    nb = {}
+    v_out = vo.mlp_regression_forward(sd, z, True, masks, nb)
+    loss = vo.numeric_params_loss(v_out, v_in)
+    loss.backward()
+    assert rel_l2(v_out, torch.tensor(g['out/v_out'])) < 1e-10
+    assert abs(loss.item() - float(g['out/mse'])) < 1e-12
+    assert rel_l2(z.grad, torch.tensor(g['out/g_z'])) < 1e-10
+    for k, v in nb.items():
+        assert rel_l2(v, torch.tensor(g['post_full/' + k])) < 1e-10, k
