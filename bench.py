@@ -138,9 +138,18 @@ def measure_roofline(ae, B, device):
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
         achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, F32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
+    label = f"{worst['kernel']}[{worst['layer']}]"
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json), if any
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
+            entry = json.load(f).get(label)
+        if entry and B == 256:
+            traffic = entry['hbm_bytes_per_launch']
+    except (OSError, ValueError):
+        pass
     roof = {'bound': worst['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
-            'frac': round(achieved / peak, 5), 'traffic': None, 'kernel': f"{worst['kernel']}[{worst['layer']}]",
-            'kernel_ms': round(worst['ms'], 4)}
+            'frac': round(achieved / peak, 5), 'traffic': traffic, 'kernel': label,
+            'kernel_ms': round(worst['ms'], 4), 'algorithmic_bytes': worst['bytes'], 'algorithmic_flops': worst['flops']}
     return roof, table
 
 
