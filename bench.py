@@ -75,17 +75,30 @@ def layer_ops(ae):
     return out
 
 
+_FLUSH = None
+
+
 def time_kernel(fn, iters=10):
-    """Average device time of fn() in ms, HIP events recorded on the stream the kernels are launched on."""
+    """Average device time of one fn() launch in ms: HIP events recorded on the stream the kernel is launched on,
+    one pair per launch; between launches a 512 MB buffer is rewritten so that every timed launch starts with its
+    operands in HBM, not in L2 / the 256 MB Infinity Cache (as it does inside the train step, where ~1 GB of other
+    tensors pass between two uses of a tensor) - back-to-back launches on the same buffers time 20 % too fast and
+    disagree with the rocprofv3 kernel trace of the step."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(128 << 20, device='cuda', dtype=torch.float32)
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    pairs = []
     for _ in range(iters):
+        _FLUSH.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) / iters
 
 
 def measure_roofline(ae, B, device):
