@@ -46,8 +46,10 @@ int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scal
   PGV_CHECK_ARG(big && w && small_out, "pgv_conv_down: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_down: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
-  if (g_policy == 0) {
+  if (g_policy != 1) {
     rc = pgv_conv_down_direct(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_down_band(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0) rc = pgv_conv_down_tuned(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0) rc = pgv_conv_down_gemm(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc < 0) return rc;
@@ -68,7 +70,7 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_s
   PGV_CHECK_ARG(small_in && w && big_out, "pgv_conv_up: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
-  if (g_policy == 0) {
+  if (g_policy != 1) {
     rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_tuned(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_gemm(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
@@ -96,7 +98,7 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
   PGV_CHECK_ARG((small_scale == nullptr) == (small_shift == nullptr),
                 "pgv_conv_wgrad: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
-  if (g_policy == 0) {
+  if (g_policy != 1) {
     rc = pgv_conv_wgrad_direct(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0)
       rc = pgv_conv_wgrad_tuned(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,

@@ -1,0 +1,457 @@
+// Shape-specialised band kernels for the stride-2 k=4 layers of the reference tables (model/encoder.py:241-255,
+// model/decoder.py:205-218) at the reference spectrogram size (257x347 -> 129x174 -> 65x88 -> 33x45 -> 17x23).
+//
+// Same implicit GEMM on v_mfma_f32_16x16x4_f32 as conv_mfma.hip, but every tile dimension is a template constant:
+//   * the LDS tile keeps image rows at a padded stride WP (multiple of 4, >= W+2): the pad columns are stored as
+//     zeros, so the column masks (one v_cndmask + hazard nop in front of every MFMA) disappear, and
+//   * every LDS address of the MFMA loop is  per-lane base + immediate offset : no address arithmetic is left in
+//     the loop, which is fully unrolled and software-pipelined (reads of step s+1 issued before the MFMAs of step s).
+// Measured on MI355X (scratch/ubench/mfma_loop.hip): 34 clk per MFMA from one wave per SIMD, against 74 clk for
+// the runtime-stride loop of conv_mfma.hip (the matrix pipe needs 32).
+// Shapes that are not instantiated here fall through to conv_mfma.hip (return 0).
+#include <stdlib.h>
+#include "conv_tile.h"
+
+#ifndef PGV_BAND_U
+#define PGV_BAND_U 4  // 16-byte loads in flight per lane while staging a band
+#endif
+
+#ifdef PGV_PHASE_TIMING
+extern "C" int pgv_dbg_set_tlog_band(void* p);
+__device__ unsigned long long* pgv_tlog_band = nullptr;
+extern "C" int pgv_dbg_set_tlog_band(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(pgv_tlog_band), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+// per-wave accumulated phase durations (100 MHz ticks): slot i = time spent before BAND_ACC(i) since the previous
+// stamp, summed over the work items of a persistent workgroup; slot 7 = number of items
+#define BAND_T0() unsigned long long band_tp = wall_clock64(), band_sum[7] = {0, 0, 0, 0, 0, 0, 0}, band_n = 0
+#define BAND_ACC(i)                                   \
+  do {                                                \
+    const unsigned long long now = wall_clock64();    \
+    band_sum[i] += now - band_tp;                     \
+    band_tp = now;                                    \
+  } while (0)
+#define BAND_ITEM() (++band_n)
+#define BAND_FLUSH()                                                                                         \
+  do {                                                                                                       \
+    if ((threadIdx.x & 63) == 0 && pgv_tlog_band) {                                                          \
+      unsigned long long* o = pgv_tlog_band + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;            \
+      for (int i = 0; i < 7; ++i) o[i] = band_sum[i];                                                        \
+      o[7] = band_n;                                                                                         \
+    }                                                                                                        \
+  } while (0)
+#else
+#define BAND_T0()
+#define BAND_ACC(i)
+#define BAND_ITEM()
+#define BAND_FLUSH()
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register prefetch of a band tile: CK channels x ROWS rows, LDS row stride WP (image columns 0..W-1, then >= 2 zero
+// pad columns which double as the left padding of the next row), channel stride ROWS*WP.  A channel is PC = ROWS*WP/4
+// 16-byte chunks; lane tid owns chunks i = tid + 256*k (k < SPC) of EVERY channel, so the chunk decode (row, column,
+// partial-chunk flag) is done once per kernel for SPC slots, the channel of a register is a compile-time constant,
+// global addresses are (uniform channel base) + (per-slot offset) and LDS addresses are (per-lane base) + immediate.
+//   issue():  one 16-byte load per chunk, no branches, no waits; chunks that hold no image data (rows outside the
+//             image, pad chunks, channels beyond C) load offset 0 of the sample and are zeroed at commit.  The partial
+//             chunk at the end of a row (W % 4 != 0) reads the LAST four floats of the row and is rotated into place
+//             at commit, so nothing outside the tensor is ever read.
+//   commit(): producer's BatchNorm affine (uniform per channel: scalar loads) on image data only, then ds_write_b128.
+// Between the two the workgroup runs the MFMA loop and the epilogue of the previous tile: HBM latency is hidden.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CK, int ROWS, int W, int WP, int H>
+struct BandPrefetch {
+  static constexpr int QR = WP / 4;
+  static constexpr int PC = ROWS * QR;            // chunks per channel
+  static constexpr int SPC = (PC + 255) / 256;    // slots per channel and lane
+  static constexpr int NPF = CK * SPC;
+  static constexpr int NP = W % 4;
+  static_assert(WP % 4 == 0 && WP >= W + 2, "row stride");
+  f32x4 v[NPF];
+  int rr[SPC];         // tile row of slot k
+  int col[SPC];        // first image column loaded by slot k (shifted back for the partial chunk)
+  int ncol[SPC];       // image floats in the chunk: 4, W%4 (partial) or 0 (pad chunk / idle lane)
+  unsigned offb[SPC];  // byte offset inside the channel plane for the current item (0 when not image data)
+  unsigned live;       // bit k: slot k holds image data for the current item
+
+  __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+    for (int k = 0; k < SPC; ++k) {
+      const int i = tid + 256 * k;
+      const int r = i / QR, q = i - r * QR;
+      const int nc = i < PC ? min(max(W - 4 * q, 0), 4) : 0;
+      rr[k] = r;
+      ncol[k] = nc;
+      col[k] = 4 * q - ((NP != 0 && nc > 0 && nc < 4) ? 4 - NP : 0);
+    }
+  }
+  // plane0 = first element of the first channel of this chunk in the current sample (always a valid address)
+  __device__ __forceinline__ void issue(const float* __restrict__ plane0, int ih0, int nch) {
+    live = 0;
+#pragma unroll
+    for (int k = 0; k < SPC; ++k) {
+      const int ih = ih0 + rr[k];
+      const bool ok = (unsigned)ih < (unsigned)H && ncol[k] > 0;
+      offb[k] = ok ? (unsigned)(ih * W + col[k]) * 4u : 0u;
+      live |= ok ? (1u << k) : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const char* pb = reinterpret_cast<const char*>(plane0 + (size_t)(c < nch ? c : 0) * (H * W));
+#pragma unroll
+      for (int k = 0; k < SPC; ++k) {
+        const f4u t = *reinterpret_cast<const f4u*>(pb + offb[k]);
+        v[c * SPC + k] = f32x4{t.x, t.y, t.z, t.w};
+      }
+    }
+  }
+  // aff = LDS copy of the producer's per-channel affine ([C] scales then [C] shifts, stage_affine) or null;
+  // c0 = first channel of this chunk.  Chunks that hold no image data were loaded from a valid dummy address (finite
+  // activations) and are multiplied by 0: they come out as exact zeros.
+  __device__ __forceinline__ void commit(float* __restrict__ tile, const float* __restrict__ aff, int C, int c0,
+                                         int nch, int tid) {
+    float* lane_tile = tile + 4 * tid;
+    float sc[CK], sh[CK];
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {  // all LDS reads first: one latency for the whole chunk
+      const int cg = min(c0 + c, C - 1);
+      sc[c] = aff ? aff[cg] : 1.0f;
+      sh[c] = aff ? aff[C + cg] : 0.0f;
+    }
+    float lk[SPC];
+#pragma unroll
+    for (int k = 0; k < SPC; ++k) lk[k] = ((live >> k) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const float cm = c < nch ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < SPC; ++k) {
+        if (256 * (k + 1) <= PC || tid + 256 * k < PC) {
+          const f32x4 t = v[c * SPC + k];
+          const float m = sc[c] * (lk[k] * cm), a = sh[c] * (lk[k] * cm);
+          f32x4 x;
+          if (NP == 0) {
+            x.x = fmaf(t.x, m, a);
+            x.y = fmaf(t.y, m, a);
+            x.z = fmaf(t.z, m, a);
+            x.w = fmaf(t.w, m, a);
+          } else {
+            // partial chunk (ncol == NP): the window was shifted back by 4-NP floats; floats beyond NP are pad zeros
+            const bool part = ncol[k] < 4;
+            const float e0 = part ? t[(4 - NP) & 3] : t.x;
+            const float e1 = part ? t[(5 - NP) & 3] : t.y;
+            const float e2 = part ? t[(6 - NP) & 3] : t.z;
+            const float m1 = (part && NP < 2) ? 0.f : m, a1 = (part && NP < 2) ? 0.f : a;
+            const float m2 = (part && NP < 3) ? 0.f : m, a2 = (part && NP < 3) ? 0.f : a;
+            const float m3 = part ? 0.f : m, a3 = part ? 0.f : a;
+            x.x = fmaf(e0, m, a);
+            x.y = fmaf(e1, m1, a1);
+            x.z = fmaf(e2, m2, a2);
+            x.w = fmaf(t.w, m3, a3);
+          }
+          *reinterpret_cast<f32x4*>(lane_tile + c * (PC * 4) + 1024 * k) = x;
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN (Conv2d forward / ConvTranspose2d input-gradient), k = 4, stride 2, pad 2.
+//   D[cs][pixel] = sum_{c,kh,kw} W[cs][c][kh][kw] * X[c][2r+kh-2][2col+kw-2]
+// MT M-tiles of 16 output channels, NT N-tiles of 16 pixels per wave, CK input channels per LDS chunk, R output rows
+// per (sample, band) unit, W/H = input image size.  Workgroups are persistent: work items are (unit, channel chunk)
+// pairs, the loads of item i+1 are in flight while item i is multiplied (and, on the last chunk of a unit, while
+// its epilogue runs).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H>
+struct DownCfg {
+  static constexpr int KS = 4;
+  static constexpr int Ws = (W + 4 - KS) / 2 + 1, Hs = (H + 4 - KS) / 2 + 1;
+  static constexpr int ROWS = 2 * (R - 1) + KS;
+  static constexpr int WP = (W + 2 + 3) / 4 * 4;
+  static constexpr int PLANE = ROWS * WP;
+  static constexpr int CSP = MT * 16 + 1;
+  static constexpr int KC = CK * KS * 4;  // k rows per chunk
+  static constexpr int PS = 64 * NT + 4;  // out tile row stride
+  static constexpr int EM = MT > 2 ? 2 : MT;
+  static constexpr int TILE = (CK * PLANE > EM * 16 * PS ? CK * PLANE : EM * 16 * PS);
+  static constexpr int FRONT = 4;  // zero slack in front of the tile (col -2,-1 of row 0 of channel 0)
+  static constexpr int WT = (WRES ? NCH : 1) * KC * CSP;  // weight tile: all chunks resident, or the current one
+  static constexpr int NWQ = KC * MT * 16 / 4 / 256;       // 16-byte weight loads per lane and chunk
+  static constexpr size_t LDS_FLOATS = FRONT + TILE + WT + 4 * MT * 16 * 2 + 2 * NCH * CK;
+  static constexpr int BANDS = (Hs + R - 1) / R;
+  static_assert(R * Ws <= 64 * NT, "band does not fit the wave tiles");
+  static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
+};
+
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H>
+__global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int act, float slope,
+                                                              float* __restrict__ out, double* __restrict__ stats) {
+  using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
+  constexpr int KS = 4, Ws = G::Ws, Hs = G::Hs, WP = G::WP, PLANE = G::PLANE, CSP = G::CSP, KC = G::KC;
+  constexpr int PS = G::PS, EM = G::EM, BANDS = G::BANDS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* in_tile = lds + G::FRONT;
+  float* w_tile = in_tile + G::TILE;
+  float* st_tile = w_tile + G::WT;         // [4 waves][MT*16][2]
+  float* aff = st_tile + 4 * MT * 16 * 2;  // [2][Cb]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int units = B * BANDS;
+  const int nchunk = (Cb + CK - 1) / CK;
+
+  // per-lane B base: pixel (r, c) of tile t, tap kw = lane>>4:  (2r)*WP + 2c - 2 + kw   (+ c*PLANE + kh*WP immediates)
+  int offB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = (wave * NT + t) * 16 + (lane & 15);
+    const int pv = p < R * Ws ? p : 0;
+    const int r = pv / Ws, c = pv - r * Ws;
+    offB[t] = 2 * r * WP + 2 * c - 2 + (lane >> 4);
+  }
+  const int offA = (lane >> 4) * CSP + (lane & 15);
+
+  BandPrefetch<CK, G::ROWS, W, WP, H> pf;
+  pf.init(tid);
+  if (tid < G::FRONT) lds[tid] = 0.f;
+  stage_affine(aff, in_scale, in_shift, Cb, tid);  // visible after the first barrier of the item loop
+  const pgv_act_params actp = pgv_act_setup(act, slope);
+
+  // weights: 16-byte loads of 4 consecutive k = (c, kh, kw0..3) of one output channel, transposed to [k][cs] in LDS.
+  // WRES: every chunk is staged once per workgroup; otherwise the chunk of the next item is prefetched into
+  // registers together with its band.
+  constexpr int NWQ = G::NWQ;
+  f32x4 wv[WRES ? 1 : NWQ];
+  auto load_weights = [&](int cb0, f32x4 (&dst)[NWQ]) {
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+      const int idx = (tid + j * 256) * 4;
+      const int cs = idx / KC, k = idx - cs * KC;
+      const bool ok = cs < Cs && cb0 + (k >> 4) < Cb;
+      const float* g = w + ((int64_t)(ok ? cs : 0) * Cb + (ok ? cb0 : 0)) * 16 + (ok ? k : 0);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(g);
+      dst[j] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_weights = [&](float* wt, const f32x4 (&src)[NWQ]) {
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+      const int idx = (tid + j * 256) * 4;
+      const int cs = idx / KC, k = idx - cs * KC;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wt[(k + i) * CSP + cs] = src[j][i];
+    }
+  };
+  float bias_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int cl = m * 16 + (lane >> 4) * 4 + reg;
+      bias_r[m][reg] = (bias && cl < Cs) ? bias[cl] : 0.f;
+    }
+  auto issue_item = [&](int u, int ch) {
+    const int b = u / BANDS, band = u - b * BANDS;
+    const int ih0 = band * R * 2 - 2;
+    pf.issue(big + ((int64_t)b * Cb + ch * CK) * (H * W), ih0, Cb - ch * CK);
+    if constexpr (!WRES) load_weights(ch * CK, wv);
+  };
+
+  int u = blockIdx.x;
+  if (u >= units) return;
+  BAND_T0();
+#ifdef PGV_SETPRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+  issue_item(u, 0);
+  if constexpr (WRES) {
+    for (int c = 0; c < nchunk; ++c) {
+      f32x4 tmp[NWQ];
+      load_weights(c * CK, tmp);
+      store_weights(w_tile + c * KC * CSP, tmp);
+    }
+  }
+  f32x4 acc[MT][NT];
+  int ch = 0;
+#pragma unroll 1
+  while (true) {
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();  // previous item's MFMA reads / epilogue copy of the tile region are complete
+    BAND_ACC(0);
+    pf.commit(in_tile, in_scale ? aff : nullptr, Cb, ch * CK, Cb - ch * CK, tid);
+    BAND_ACC(1);
+    if constexpr (!WRES) store_weights(w_tile, wv);
+    const float* wt = WRES ? w_tile + ch * KC * CSP : w_tile;
+    BAND_ACC(2);
+    // next item: next chunk of this unit, else first chunk of this workgroup's next unit
+    int nu = u, nch = ch + 1;
+    if (nch == nchunk) {
+      nch = 0;
+      nu = u + gridDim.x;
+    }
+    if (nu < units) issue_item(nu, nch);
+    BAND_ACC(3);
+    __syncthreads();
+    BAND_ACC(4);
+#ifdef PGV_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    {
+      constexpr int S = CK * KS;  // steps (c, kh); one MFMA per (step, m, t) consumes the 4 kw taps
+      float a0[MT], a1[MT], b0[NT], b1[NT];
+      auto load_step = [&](int st, float (&av)[MT], float (&bv)[NT]) {
+        const int c = st / KS, kh = st - c * KS;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = wt[st * 4 * CSP + m * 16 + offA];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = in_tile[c * PLANE + kh * WP + offB[t]];
+      };
+      auto compute_step = [&](const float (&av)[MT], const float (&bv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef PGV_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    BAND_ACC(5);
+    BAND_ITEM();
+    if (ch == nchunk - 1) {
+      // ---- epilogue: bias + activation, statistics, band through LDS, 16-byte stores of contiguous NCHW segments
+      const int b = u / BANDS, band = u - b * BANDS;
+      const int oh0 = band * R;
+      const int Pb = min(R, Hs - oh0) * Ws;
+      float* out_tile = in_tile;
+#pragma unroll
+      for (int m0 = 0; m0 < MT; m0 += EM) {
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < EM; ++mm) {
+          const int m = m0 + mm;
+          float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int cl = m * 16 + (lane >> 4) * 4 + reg;
+            const float bv = bias_r[m][reg];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const int p = (wave * NT + t) * 16 + (lane & 15);
+              const float v = pgv_act_apply(acc[m][t][reg] + bv, actp);
+              out_tile[(cl - m0 * 16) * PS + p] = v;
+              const float vm = p < Pb ? v : 0.f;
+              s[reg] += vm;
+              q[reg] = fmaf(vm, vm, q[reg]);
+            }
+          }
+          if (stats) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const float ss = group16_sum(s[reg]), qq = group16_sum(q[reg]);
+              if ((lane & 15) == 0) {
+                const int cl = m * 16 + (lane >> 4) * 4 + reg;
+                st_tile[(wave * MT * 16 + cl) * 2 + 0] = ss;
+                st_tile[(wave * MT * 16 + cl) * 2 + 1] = qq;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const int nchn = min(Cs - m0 * 16, EM * 16);
+#if defined(PGV_EXP) && PGV_EXP == 5
+        if (nchn > 0 && act == 77)
+#else
+        if (nchn > 0)
+#endif
+          store_rows_contig(out_tile, PS, out + ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws,
+                            (int64_t)Hs * Ws, nchn, Pb, tid);
+      }
+      if (stats && tid < MT * 16 && tid < Cs) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          ss += (double)st_tile[(wv * MT * 16 + tid) * 2 + 0];
+          qq += (double)st_tile[(wv * MT * 16 + tid) * 2 + 1];
+        }
+        atomicAdd(&stats[tid], ss);
+        atomicAdd(&stats[Cs + tid], qq);
+      }
+      BAND_ACC(6);
+    }
+    u = nu;
+    ch = nch;
+    if (u >= units) break;
+  }
+  BAND_FLUSH();
+}
+
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H>
+int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                     hipStream_t st) {
+  using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cb > NCH * CK) return 0;
+  auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_down_band");
+  if (rc) return rc;
+  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_band: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int units = d->B * G::BANDS;
+  int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
+#ifdef PGV_PHASE_TIMING
+  if (getenv("PGV_WG_PER_CU")) per_cu = atoi(getenv("PGV_WG_PER_CU"));
+#endif
+  const int grid = min(units, 256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, in_scale, in_shift, w, bias, act,
+                     slope, out, stats);
+  PGV_CHECK_LAUNCH("conv_down_band");
+  return 1;
+}
+
+}  // namespace
+
+int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                       const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
+                       hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || d->Cb > 64) return 0;
+  if (d->Hb == 129 && d->Wb == 174 && d->Cs <= 16)
+    return launch_down_band<1, 6, 8, 1, true, 4, 174, 129>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats,
+                                                  st);
+  if (d->Hb == 65 && d->Wb == 88 && d->Cs <= 32)
+    return launch_down_band<2, 3, 8, 2, true, 4, 88, 65>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+  if (d->Hb == 33 && d->Wb == 45 && d->Cs <= 64)
+    return launch_down_band<4, 3, 8, 4, false, 8, 45, 33>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+  return 0;
+}

@@ -25,6 +25,11 @@ int pgv_conv_wgrad_tuned(const pgv_conv_desc* d, const float* big, const float* 
                          void* workspace, int64_t workspace_bytes, hipStream_t st);
 int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc* d);
 
+// Shape-specialised band kernels (conv_band.hip): compile-time tile geometry for the reference layer shapes.
+int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                       const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
+                       hipStream_t st);
+
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                          const float* w, const float* bias, int act, float slope, float* out, double* stats,

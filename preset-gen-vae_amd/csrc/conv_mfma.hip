@@ -23,6 +23,35 @@
 // LDS -> one float64 atomic per channel per workgroup) for the BatchNorm that follows.
 #include "conv_tile.h"
 
+// Phase timing for kernel tuning (scratch/phase_timing.py builds a separate debug library with -DPGV_PHASE_TIMING;
+// the product library never defines it).
+#ifdef PGV_PHASE_TIMING
+__device__ unsigned long long* pgv_tlog = nullptr;  // [workgroup][wave][8] wall_clock64() stamps (100 MHz)
+extern "C" int pgv_dbg_set_tlog(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(pgv_tlog), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define PGV_TICK(i)                                                                                       \
+  do {                                                                                                    \
+    if ((threadIdx.x & 63) == 0 && pgv_tlog)                                                              \
+      pgv_tlog[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (i)] =     \
+          wall_clock64();                                                                                 \
+  } while (0)
+#define PGV_TICK_HWID()                                                                                   \
+  do {                                                                                                    \
+    if ((threadIdx.x & 63) == 0 && pgv_tlog)                                                              \
+      pgv_tlog[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + 7] =       \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |                       \
+          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                                            \
+  } while (0)
+#else
+#define PGV_TICK(i)
+#define PGV_TICK_HWID()
+#endif
+
+#ifndef PGV_STAGE_U
+#define PGV_STAGE_U 4  // 16-byte loads in flight per lane while staging a band
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -79,12 +108,24 @@ __global__ __launch_bounds__(256, 2) void conv_down_mfma_kernel(pgv_conv_desc d,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef PGV_STAGGER
+  {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin >= 256 && lin < 512)
+      for (int i = 0; i < PGV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+  PGV_TICK(0);
+  PGV_TICK_HWID();
   stage_affine(aff, in_scale, in_shift, d.Cb, tid);
   if (in_scale) __syncthreads();
   for (int cb0 = 0; cb0 < d.Cb; cb0 += CK) {
     if (cb0) __syncthreads();
-    stage_rows_contig<4>(in_tile, plane, src, d.Cb, d.Hb, Wb, cb0, CK, rows_in, ih0, in_scale ? aff : nullptr,
+#if !defined(PGV_EXP) || (PGV_EXP != 3)
+    stage_rows_contig<PGV_STAGE_U>(in_tile, plane, src, d.Cb, d.Hb, Wb, cb0, CK, rows_in, ih0, in_scale ? aff : nullptr,
                          aff + d.Cb, tid);
+#endif
+    PGV_TICK(1);
     for (int i0 = tid; i0 < KC * MT * 16; i0 += 256 * 4) {
       float v[4];
 #pragma unroll
@@ -106,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_mfma_kernel(pgv_conv_desc d,
       }
     }
     __syncthreads();
+    PGV_TICK(2);
     // MFMA loop, software-pipelined by hand: step s = (c, kh, kws) (kws fastest); the LDS reads of step s+1 are
     // issued into the other register set before the MFMAs of step s, so ds_read latency hides under matrix work.
     {
@@ -123,73 +165,101 @@ __global__ __launch_bounds__(256, 2) void conv_down_mfma_kernel(pgv_conv_desc d,
         for (int t = 0; t < NT; ++t) bv[t] = bp[offB[t]];
       };
       auto compute_step = [&](int kws, const float (&av)[MT], float (&bv)[NT]) {
+#if !defined(PGV_EXP) || (PGV_EXP != 4)
 #pragma unroll
         for (int t = 0; t < NT; ++t) bv[t] = okB[t][kws] ? bv[t] : 0.f;
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
       };
+#if !defined(PGV_EXP) || (PGV_EXP != 1)
+      // sched_barrier(0): nothing crosses.  Without them the compiler sinks the ds_reads of the next step down to
+      // their first use (shorter live ranges) and every step stalls a full LDS latency with the matrix pipe idle.
       load_step(0, a0, b0);
 #pragma unroll 2
       for (int st = 0; st < S; st += 2) {
         load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         compute_step(0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         compute_step(1 % KWS, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#else
+      acc[0][0][0] = in_tile[offB[0]] + w_tile[offA];
+#endif
     }
   }
 
-  // ---- epilogue.  D layout: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel inside the M tile)
-  const int64_t out_base = (int64_t)b * d.Cs * d.Hs * d.Ws + (int64_t)oh0 * d.Ws;
-  const int64_t cstride = (int64_t)d.Hs * d.Ws;
+  PGV_TICK(3);
+#if defined(PGV_EXP) && (PGV_EXP == 1 || PGV_EXP == 2)
+  if (acc[0][0][0] == 12345.678f) out[0] = 1.f;
+  return;
+#endif
+  // ---- epilogue.  D layout: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel inside the M tile).
+  // bias + activation in registers, per-channel statistics by shuffles, then the band goes through LDS (the input
+  // tile is dead by now) so that it leaves as 16-byte stores of contiguous NCHW segments.
+  constexpr int PS = 64 * NT + 4;  // out_tile row stride: % 8 == 4 -> the four lane groups write disjoint banks
+  constexpr int EM = MT > 2 ? 2 : MT;  // M tiles per pass through LDS (keeps the out tile within the input tile)
+  float* out_tile = lds + 8;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < MT; m0 += EM) {
+    __syncthreads();  // every wave is done with the input tile / the previous pass has been copied out
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int cs = m * 16 + (lane >> 4) * 4 + reg;
-      if (cs < d.Cs) {
-        const float bv = bias ? bias[cs] : 0.f;
+    for (int mm = 0; mm < EM; ++mm) {
+      const int m = m0 + mm;
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cl = m * 16 + (lane >> 4) * 4 + reg;
+        const float bv = (bias && cl < d.Cs) ? bias[cl] : 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int p = (wave * NT + t) * 16 + (lane & 15);
+          const float v = pgv_act(acc[m][t][reg] + bv, act, slope);
+          out_tile[(cl - m0 * 16) * PS + p] = v;
           if (p < Pb) {
-            const float v = pgv_act(acc[m][t][reg] + bv, act, slope);
-            out[out_base + cs * cstride + p] = v;
             s[reg] += v;
             q[reg] = fmaf(v, v, q[reg]);
           }
         }
       }
-    }
-    if (stats) {
+      if (stats) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const float ss = group16_sum(s[reg]), qq = group16_sum(q[reg]);
-        if ((lane & 15) == 0) {
-          const int cl = m * 16 + (lane >> 4) * 4 + reg;
-          st_tile[(wave * MT * 16 + cl) * 2 + 0] = ss;
-          st_tile[(wave * MT * 16 + cl) * 2 + 1] = qq;
+        for (int reg = 0; reg < 4; ++reg) {
+          const float ss = group16_sum(s[reg]), qq = group16_sum(q[reg]);
+          if ((lane & 15) == 0) {
+            const int cl = m * 16 + (lane >> 4) * 4 + reg;
+            st_tile[(wave * MT * 16 + cl) * 2 + 0] = ss;
+            st_tile[(wave * MT * 16 + cl) * 2 + 1] = qq;
+          }
         }
       }
     }
-  }
-  if (stats) {
+    if (m0 + EM >= MT) PGV_TICK(4);
     __syncthreads();
-    if (tid < MT * 16 && tid < d.Cs) {
-      double ss = 0.0, qq = 0.0;
-#pragma unroll
-      for (int wv = 0; wv < 4; ++wv) {
-        ss += (double)st_tile[(wv * MT * 16 + tid) * 2 + 0];
-        qq += (double)st_tile[(wv * MT * 16 + tid) * 2 + 1];
-      }
-      atomicAdd(&stats[tid], ss);
-      atomicAdd(&stats[d.Cs + tid], qq);
-    }
+    const int nch = min(d.Cs - m0 * 16, EM * 16);
+    if (nch > 0)
+      store_rows_contig(out_tile, PS,
+                        out + ((int64_t)b * d.Cs + m0 * 16) * d.Hs * d.Ws + (int64_t)oh0 * d.Ws,
+                        (int64_t)d.Hs * d.Ws, nch, Pb, tid);
   }
+  if (stats && tid < MT * 16 && tid < d.Cs) {
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+      ss += (double)st_tile[(wv * MT * 16 + tid) * 2 + 0];
+      qq += (double)st_tile[(wv * MT * 16 + tid) * 2 + 1];
+    }
+    atomicAdd(&stats[tid], ss);
+    atomicAdd(&stats[d.Cs + tid], qq);
+  }
+  PGV_TICK(5);
 }
 
 template <int KS, int MT, int NT, int CK>
@@ -202,10 +272,15 @@ int launch_down(const pgv_conv_desc* d, const float* big, const float* in_scale,
   int plane = 0;
   for (; R >= 1; --R) {
     plane = ((2 * (R - 1) + KS) * d->Wb + 8 + 3) / 4 * 4;
+    // the epilogue re-uses the tile region for the [MT*16][64*NT+4] output band
+    plane = max(plane, ((MT > 2 ? 2 : MT) * 16 * (64 * NT + 4) + CK - 1) / CK + 3) / 4 * 4;
     bytes = sizeof(float) * (8 + (size_t)CK * plane + (size_t)KC * CSP + 4 * MT * 16 * 2 + 2 * d->Cb);
     if (bytes <= (size_t)kLdsTarget || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
+#ifdef PGV_ONE_WG
+  bytes = max(bytes, (size_t)90 * 1024);
+#endif
   auto kern = conv_down_mfma_kernel<KS, MT, NT, CK>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_mfma");
@@ -283,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_mfma_kernel(pgv_conv_desc d, c
   if (in_scale) __syncthreads();
   for (int cs0 = 0; cs0 < d.Cs; cs0 += CK) {
     if (cs0) __syncthreads();
-    stage_rows_contig<4>(in_tile, plane, src, d.Cs, d.Hs, Ws, cs0, CK, rows_in, ih0, in_scale ? aff : nullptr,
+    stage_rows_contig<PGV_STAGE_U>(in_tile, plane, src, d.Cs, d.Hs, Ws, cs0, CK, rows_in, ih0, in_scale ? aff : nullptr,
                          aff + d.Cs, tid);
     // weights: w_tile[(c*KG + g)*4 + kk][m], m = cb*4 + ph*2 + pw, value w[cs][cb][ph+2th][pw+2tw]
     for (int i0 = tid; i0 < KC * MT * 16; i0 += 256 * 4) {
@@ -336,9 +411,13 @@ __global__ __launch_bounds__(256, 2) void conv_up_mfma_kernel(pgv_conv_desc d, c
 #pragma unroll 2
       for (int st = 0; st < S; st += 2) {
         load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -506,11 +585,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(pgv_conv_desc d
     const int lead = (max(ih0, 0) - ih0) * Wb;
     float* big_tile = lds + 4 + ((4 - (lead & 3)) & 3);  // [Cb][plane], row stride Wb
     if (u != (int)blockIdx.x) __syncthreads();
-    stage_rows_contig<4>(big_tile, plane, big + (int64_t)b * d.Cb * d.Hb * Wb, d.Cb, d.Hb, Wb, 0, d.Cb, rows_in, ih0,
+    if (u == (int)blockIdx.x) PGV_TICK(0);
+    stage_rows_contig<PGV_STAGE_U>(big_tile, plane, big + (int64_t)b * d.Cb * d.Hb * Wb, d.Cb, d.Hb, Wb, 0, d.Cb, rows_in, ih0,
                          big_scale ? aff_b : nullptr, aff_b + d.Cb, tid);
-    stage_rows_contig<4>(small_tile, SP, small_in + (int64_t)b * d.Cs * d.Hs * Ws, d.Cs, d.Hs, Ws, 0, d.Cs, R, oh0,
+    stage_rows_contig<PGV_STAGE_U>(small_tile, SP, small_in + (int64_t)b * d.Cs * d.Hs * Ws, d.Cs, d.Hs, Ws, 0, d.Cs, R, oh0,
                          small_scale ? aff_s : nullptr, aff_s + d.Cs, tid);
+    if (u == (int)blockIdx.x) PGV_TICK(1);
     __syncthreads();
+    if (u == (int)blockIdx.x) PGV_TICK(2);
     const int S = rows_out * steps_per_row;
     // pixel steps of this wave: st = wk, wk+WK, ... ; LDS reads of the next step are issued before the MFMAs of the
     // current one (two register sets, ping-pong)
@@ -546,14 +628,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(pgv_conv_desc d
       for (; st < S; st += 2 * WK) {
         const bool has1 = st + WK < S;
         if (has1) load_step(st + WK, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         compute_step(st, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (has1) {
           if (st + 2 * WK < S) load_step(st + 2 * WK, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
           compute_step(st + WK, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+    if (u == (int)blockIdx.x) PGV_TICK(3);
   }
+  PGV_TICK(4);
   // ---- flush: D col = lane&15 = tap within the N tile, row = (lane>>4)*4 + reg = cs within the M tile
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
@@ -573,6 +661,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(pgv_conv_desc d
       }
     }
   }
+  PGV_TICK(5);
 }
 
 template <int KS, int MT, int NB, int WN>

@@ -9,12 +9,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kLdsTarget = 76 * 1024;  // aim at two workgroups per CU
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float group16_sum(float v) {
-  // sum over the 16 lanes that share lane>>4 (xor butterflies stay inside the group)
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  // sum over the 16 lanes that share lane>>4, result in all 16: DPP only (quad xor 1, quad xor 2, half-row mirror,
+  // row mirror) - __shfl_xor would go through ds_bpermute, ~100 cycles of LDS latency per step
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
 
@@ -124,6 +129,31 @@ __device__ __forceinline__ void stage_rows_contig(float* __restrict__ tile, int 
       float* p = tile + c * plane_stride;
       for (int i = tid; i < lead; i += 256) p[i] = 0.f;
       for (int i = tid; i < tail_n; i += 256) p[tail0 + i] = 0.f;
+    }
+  }
+}
+
+// Copy an LDS tile [nch][row_stride] (first len floats of each row) to nch contiguous global segments dst + c*cstride,
+// 16 bytes per lane per store (global_store_dwordx4 to 4-byte aligned addresses): dword stores from the MFMA
+// accumulator layout are store-issue-bound (~6x the time per byte of 16-byte stores on gfx950).
+// row_stride % 4 == 0 and tile 16-byte aligned.
+__device__ __forceinline__ void store_rows_contig(const float* __restrict__ tile, int row_stride,
+                                                  float* __restrict__ dst, int64_t cstride, int nch, int len,
+                                                  int tid) {
+  const int Q = len >> 2, rem = len & 3;
+  const float inv_q = 1.0f / (float)max(Q, 1);
+  const int items = nch * Q;
+  for (int e = tid; e < items; e += 256) {
+    const int c = fast_div(e, inv_q), q = e - c * Q;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + c * row_stride + 4 * q);
+    f4u o;
+    o.x = v.x, o.y = v.y, o.z = v.z, o.w = v.w;
+    *reinterpret_cast<f4u*>(dst + c * cstride + 4 * q) = o;
+  }
+  if (rem) {
+    for (int e = tid; e < nch * 4; e += 256) {
+      const int c = e >> 2, i = e & 3;
+      if (i < rem) dst[c * cstride + 4 * Q + i] = tile[c * row_stride + 4 * Q + i];
     }
   }
 }

@@ -74,6 +74,22 @@ __device__ __forceinline__ double pgv_block_sum_d(double v, double* smem /* >= 1
   return r;
 }
 
+// Branch-free form of pgv_act for unrolled epilogues: bit-identical results, parameters derived once from (act, slope).
+struct pgv_act_params {
+  float ns, lo, hi;
+};
+__device__ __forceinline__ pgv_act_params pgv_act_setup(int act, float slope) {
+  pgv_act_params p;
+  p.ns = act == PGV_ACT_LEAKY_RELU ? slope : 1.0f;
+  p.lo = act == PGV_ACT_HARDTANH ? -1.0f : -__builtin_inff();
+  p.hi = act == PGV_ACT_HARDTANH ? 1.0f : __builtin_inff();
+  return p;
+}
+__device__ __forceinline__ float pgv_act_apply(float y, const pgv_act_params& p) {
+  const float r = y > 0.f ? y : p.ns * y;
+  return fminf(p.hi, fmaxf(p.lo, r));
+}
+
 __device__ __forceinline__ float pgv_act(float y, int act, float slope) {
   if (act == PGV_ACT_LEAKY_RELU) return y > 0.f ? y : slope * y;
   if (act == PGV_ACT_HARDTANH) return fminf(1.f, fmaxf(-1.f, y));

@@ -155,7 +155,7 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
   PGV_CHECK_ARG(lds_bytes <= 160 * 1024, "pgv_stft_mel: %d output rows need %zu B of LDS", n_rows, lds_bytes);
   static bool attr_set = false;  // idempotent; only widens the dynamic-LDS cap of this kernel
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid((unsigned)pgv_cdiv(n_frames, FT), (unsigned)B);
