@@ -72,6 +72,8 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_s
   hipStream_t st = pgv_stream(stream);
   if (g_policy != 1) {
     rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_up_band(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_tuned(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_gemm(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc < 0) return rc;
@@ -100,6 +102,8 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
   hipStream_t st = pgv_stream(stream);
   if (g_policy != 1) {
     rc = pgv_conv_wgrad_direct(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0)
       rc = pgv_conv_wgrad_tuned(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
                                 workspace_bytes, st);

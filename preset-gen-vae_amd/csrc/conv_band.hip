@@ -10,6 +10,7 @@
 // the runtime-stride loop of conv_mfma.hip (the matrix pipe needs 32).
 // Shapes that are not instantiated here fall through to conv_mfma.hip (return 0).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_tile.h"
 
 #ifndef PGV_BAND_U
@@ -62,14 +63,14 @@ namespace {
 //   commit(): producer's BatchNorm affine (uniform per channel: scalar loads) on image data only, then ds_write_b128.
 // Between the two the workgroup runs the MFMA loop and the epilogue of the previous tile: HBM latency is hidden.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CK, int ROWS, int W, int WP, int H>
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
 struct BandPrefetch {
   static constexpr int QR = WP / 4;
   static constexpr int PC = ROWS * QR;            // chunks per channel
   static constexpr int SPC = (PC + 255) / 256;    // slots per channel and lane
   static constexpr int NPF = CK * SPC;
   static constexpr int NP = W % 4;
-  static_assert(WP % 4 == 0 && WP >= W + 2, "row stride");
+  static_assert(WP % 4 == 0 && WP >= W + MINPAD, "row stride");
   f32x4 v[NPF];
   int rr[SPC];         // tile row of slot k
   int col[SPC];        // first image column loaded by slot k (shifted back for the partial chunk)
@@ -159,6 +160,99 @@ struct BandPrefetch {
   }
 };
 
+// Same interface, flat chunk list (chunk e = tid + 256*j over all CK*PC chunks of the tile, channel-major): used when a
+// channel has far fewer than 256 chunks and the per-channel slots of BandPrefetch would leave most lanes idle.  One
+// packed descriptor register per slot; the affine parameters are per-lane LDS reads.
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
+struct FlatPrefetch {
+  static constexpr int QR = WP / 4;
+  static constexpr int PC = ROWS * QR;
+  static constexpr int ITEMS = CK * PC;
+  static constexpr int NPF = (ITEMS + 255) / 256;
+  static constexpr int NP = W % 4;
+  static_assert(WP % 4 == 0 && WP >= W + MINPAD, "row stride");
+  static_assert(ROWS < 256 && CK <= 256 && QR < 4096, "descriptor fields");
+  f32x4 v[NPF];
+  unsigned meta[NPF];  // rr | ncol << 8 | c << 12 | q << 20   (ncol = 0: pad chunk or idle lane)
+  unsigned live;
+
+  __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int e = tid + 256 * j;
+      const int ee = min(e, ITEMS - 1);
+      const int rowi = ee / QR, q = ee - rowi * QR;
+      const int c = rowi / ROWS, rr = rowi - c * ROWS;
+      const int nc = e < ITEMS ? min(max(W - 4 * q, 0), 4) : 0;
+      meta[j] = (unsigned)rr | ((unsigned)nc << 8) | ((unsigned)c << 12) | ((unsigned)q << 20);
+    }
+  }
+  __device__ __forceinline__ void issue(const float* __restrict__ plane0, int ih0, int nch) {
+    live = 0;
+    const char* pb = reinterpret_cast<const char*>(plane0);
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int rr = meta[j] & 255, nc = (meta[j] >> 8) & 15, c = (meta[j] >> 12) & 255, q = meta[j] >> 20;
+      const int ih = ih0 + rr;
+      const bool ok = (unsigned)ih < (unsigned)H && nc > 0 && c < nch;
+      const int col = 4 * q - ((NP != 0 && nc < 4) ? 4 - NP : 0);
+      const unsigned off = ok ? (unsigned)((c * H + ih) * W + col) * 4u : 0u;
+      live |= ok ? (1u << j) : 0u;
+      const f4u t = *reinterpret_cast<const f4u*>(pb + off);
+      v[j] = f32x4{t.x, t.y, t.z, t.w};
+    }
+  }
+  __device__ __forceinline__ void commit(float* __restrict__ tile, const float* __restrict__ aff, int C, int c0,
+                                         int /*nch*/, int tid) {
+    float* lane_tile = tile + 4 * tid;
+    float sc[NPF], sh[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int cg = min(c0 + (int)((meta[j] >> 12) & 255), C - 1);
+      sc[j] = aff ? aff[cg] : 1.0f;
+      sh[j] = aff ? aff[C + cg] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      if (256 * (j + 1) <= ITEMS || tid + 256 * j < ITEMS) {
+        const f32x4 t = v[j];
+        const bool on = (live >> j) & 1u;
+        const float m = on ? sc[j] : 0.f, a = on ? sh[j] : 0.f;
+        f32x4 x;
+        if (NP == 0) {
+          x.x = fmaf(t.x, m, a);
+          x.y = fmaf(t.y, m, a);
+          x.z = fmaf(t.z, m, a);
+          x.w = fmaf(t.w, m, a);
+        } else {
+          const bool part = ((meta[j] >> 8) & 15) < 4;
+          const float e0 = part ? t[(4 - NP) & 3] : t.x;
+          const float e1 = part ? t[(5 - NP) & 3] : t.y;
+          const float e2 = part ? t[(6 - NP) & 3] : t.z;
+          const float m1 = (part && NP < 2) ? 0.f : m, a1 = (part && NP < 2) ? 0.f : a;
+          const float m2 = (part && NP < 3) ? 0.f : m, a2 = (part && NP < 3) ? 0.f : a;
+          const float m3 = part ? 0.f : m, a3 = part ? 0.f : a;
+          x.x = fmaf(e0, m, a);
+          x.y = fmaf(e1, m1, a1);
+          x.z = fmaf(e2, m2, a2);
+          x.w = fmaf(t.w, m3, a3);
+        }
+        *reinterpret_cast<f32x4*>(lane_tile + 1024 * j) = x;
+      }
+    }
+  }
+};
+
+// channel slots when they are at least 80 % occupied, the flat list otherwise
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
+struct PickPrefetch {
+  static constexpr int PC = ROWS * (WP / 4);
+  static constexpr int SPC = (PC + 255) / 256;
+  static constexpr bool kChannelSlots = PC * 10 >= SPC * 256 * 8;
+  using type = typename std::conditional<kChannelSlots, BandPrefetch<CK, ROWS, W, WP, H, MINPAD>,
+                                         FlatPrefetch<CK, ROWS, W, WP, H, MINPAD>>::type;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN (Conv2d forward / ConvTranspose2d input-gradient), k = 4, stride 2, pad 2.
 //   D[cs][pixel] = sum_{c,kh,kw} W[cs][c][kh][kw] * X[c][2r+kh-2][2col+kw-2]
@@ -219,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
   }
   const int offA = (lane >> 4) * CSP + (lane & 15);
 
-  BandPrefetch<CK, G::ROWS, W, WP, H> pf;
+  typename PickPrefetch<CK, G::ROWS, W, WP, H>::type pf;
   pf.init(tid);
   if (tid < G::FRONT) lds[tid] = 0.f;
   stage_affine(aff, in_scale, in_shift, Cb, tid);  // visible after the first barrier of the item loop
@@ -440,6 +534,456 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD, k = 4, stride 2, pad 2:  gw[cs][cb][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,cb,2oh-2+kh,2ow-2+kw]
+// GEMM with M = cs (MT tiles of 16), N = (cb, 16 taps) = one N tile per big channel, K = output pixels, 4 consecutive
+// ow per MFMA.  A[cs][pixel] from the small tile (row stride WsP, zero pad columns), B[pixel][tap] straight from the raw
+// big tile: lane (tap j, pixel k) reads  cb*PLANE_B + (2r+kh)*WP + 2*(ow0+k) + kw - 2.
+// Waves split the N tiles WN ways and the rows of the band WK = 4/WN ways (R = WK*RW rows per unit); the (row, step)
+// loop of a wave is fully unrolled, so all LDS addresses are per-lane base + immediate.  Persistent workgroups keep
+// the accumulators in registers over all their (sample, band) units and flush once with float atomics; the tiles of
+// unit i+1 are prefetched into registers while unit i is multiplied.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NB, int WN, int RW, int W, int H>
+struct WgradCfg {
+  static constexpr int WK = 4 / WN;
+  static constexpr int R = WK * RW;
+  static constexpr int CB = NB * WN, CS = MT * 16;
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;  // (W + 4 - 4) / 2 + 1
+  static constexpr int ROWS_B = 2 * (R - 1) + 4;
+  static constexpr int WP = (W + 2 + 3) / 4 * 4;
+  static constexpr int WsP = (Ws + 3) / 4 * 4;
+  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP;
+  static constexpr int SPR = WsP / 4;  // MFMA k-steps per output row
+  static constexpr int FRONT = 4;
+  static constexpr size_t LDS_FLOATS = FRONT + CB * PLANE_B + CS * PLANE_S + 2 * (CB + CS);
+  static constexpr int BANDS = (Hs + R - 1) / R;
+  // the right-most B read of a row: 2*(WsP-1) + 3 - 2 must stay inside the padded row (or run into the next row's
+  // image columns only where the A operand is a zero pad column)
+  static_assert(2 * (Ws - 1) + 1 < WP, "row stride");
+};
+
+template <int MT, int NB, int WN, int RW, int W, int H>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
+                                                               const float* __restrict__ big_scale,
+                                                               const float* __restrict__ big_shift,
+                                                               const float* __restrict__ small_in,
+                                                               const float* __restrict__ small_scale,
+                                                               const float* __restrict__ small_shift,
+                                                               float* __restrict__ gw) {
+  using G = WgradCfg<MT, NB, WN, RW, W, H>;
+  constexpr int WK = G::WK, R = G::R, CB = G::CB, CS = G::CS, Ws = G::Ws, Hs = G::Hs, WP = G::WP, WsP = G::WsP;
+  constexpr int PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* big_tile = lds + G::FRONT;
+  float* small_tile = big_tile + CB * PLANE_B;
+  float* aff_b = small_tile + CS * PLANE_S;  // [2][Cb]
+  float* aff_s = aff_b + 2 * CB;             // [2][Cs]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gn = wave % WN, wk = wave / WN;
+  const int units = B * BANDS;
+
+  // per-lane bases (rows r = wk + WK*rw and steps i are immediates)
+  int offB[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int cb = gn * NB + n;
+    const int tau = lane & 15, kh = tau >> 2, kw = tau & 3;
+    offB[n] = cb * PLANE_B + (2 * wk + kh) * WP + kw - 2 + 2 * (lane >> 4);
+  }
+  int offA[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) offA[m] = (m * 16 + (lane & 15)) * PLANE_S + wk * WsP + (lane >> 4);
+
+  f32x4 acc[MT][NB];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  typename PickPrefetch<CB, G::ROWS_B, W, WP, H>::type pfb;
+  typename PickPrefetch<CS, R, Ws, WsP, Hs, 0>::type pfs;
+  pfb.init(tid);
+  pfs.init(tid);
+  if (tid < G::FRONT) lds[tid] = 0.f;
+  stage_affine(aff_b, big_scale, big_shift, Cb, tid);
+  stage_affine(aff_s, small_scale, small_shift, Cs, tid);
+  auto issue_unit = [&](int u) {
+    const int b = u / BANDS, band = u - b * BANDS;
+    pfb.issue(big + (int64_t)b * Cb * (H * W), band * R * 2 - 2, Cb);
+    pfs.issue(small_in + (int64_t)b * Cs * (Hs * Ws), band * R, Cs);
+  };
+
+  int u = blockIdx.x;
+  BAND_T0();
+  if (u < units) issue_unit(u);
+#pragma unroll 1
+  for (; u < units; u += gridDim.x) {
+    __syncthreads();  // the previous unit's MFMA reads are complete (and the affine tables are visible)
+    BAND_ACC(0);
+    pfb.commit(big_tile, big_scale ? aff_b : nullptr, Cb, 0, Cb, tid);
+    pfs.commit(small_tile, small_scale ? aff_s : nullptr, Cs, 0, Cs, tid);
+    BAND_ACC(1);
+    if (u + (int)gridDim.x < units) issue_unit(u + gridDim.x);
+    BAND_ACC(3);
+    __syncthreads();
+    BAND_ACC(4);
+    {
+      constexpr int S = RW * SPR;
+      float a0[MT], a1[MT], b0[NB], b1[NB];
+      auto load_step = [&](int st, float (&av)[MT], float (&bv)[NB]) {
+        const int rw = st / SPR, i = st - rw * SPR;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = small_tile[offA[m] + rw * WK * WsP + 4 * i];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bv[n] = big_tile[offB[n] + rw * WK * 2 * WP + 8 * i];
+      };
+      auto compute_step = [&](const float (&av)[MT], const float (&bv)[NB]) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        if (st + 1 < S) load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < S) compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    BAND_ACC(5);
+    BAND_ITEM();
+  }
+  BAND_FLUSH();
+  // ---- flush: D col = lane&15 = tap, row = (lane>>4)*4 + reg = cs within the M tile
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int cb = gn * NB + n;
+    if (cb < Cb) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cs = m * 16 + (lane >> 4) * 4 + reg;
+          if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + (lane & 15)], acc[m][n][reg]);
+        }
+    }
+  }
+}
+
+template <int MT, int NB, int WN, int RW, int W, int H>
+int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                      hipStream_t st) {
+  using G = WgradCfg<MT, NB, WN, RW, W, H>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cb > G::CB || d->Cs > G::CS) return 0;
+  auto kern = conv_wgrad_band_kernel<MT, NB, WN, RW, W, H>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
+  if (rc) return rc;
+  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * 16, st) != hipSuccess) {
+    pgv_set_error("conv_wgrad_band: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int units = d->B * G::BANDS;
+  if (units == 0) return 1;
+  const int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
+  const int grid = min(units, 256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, big_scale, big_shift, small_in,
+                     small_scale, small_shift, gw);
+  PGV_CHECK_LAUNCH("conv_wgrad_band");
+  return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// UP (ConvTranspose2d forward / Conv2d input-gradient), k = 4, stride 2, pad 2, by sub-pixel phases:
+//   out[cb][2u+ph][2v+pw] = sum_{cs,th,tw} w[cs][cb][ph+2th][pw+2tw] * X[cs][u+1-th][v+1-tw]
+// i.e. D[(cb,ph,pw)][(u,v)] with M = 4*Cb rows (MT tiles), one MFMA per input channel (k = th*2+tw), the same input
+// gather for all four phases.  The grid of (u,v) is Hg x Wg = ceil(H/2) x ceil(W/2) for an H x W output; a unit is R
+// grid rows of one sample (2R output rows).  Small tile: R+1 rows at stride WsP >= Ws+1 (zero pad: the v+1 read of the
+// last grid column when W is odd).  The 2R x W output band of EM*4 channels at a time goes through LDS and leaves as
+// 16-byte stores of contiguous NCHW segments.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H>
+struct UpCfg {
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;        // input (small) size
+  static constexpr int Wg = (W + 1) / 2, Hg = (H + 1) / 2;    // sub-pixel grid
+  static constexpr int ROWS = R + 1;
+  static constexpr int WsP = (Ws + 1 + 3) / 4 * 4;
+  static constexpr int PLANE = ROWS * WsP;
+  static constexpr int MSP = MT * 16 + 1;
+  static constexpr int KC = CK * 4;                            // k rows per chunk
+  static constexpr int OPS = (2 * R * W + 3) / 4 * 4;          // out tile channel stride
+  static constexpr int TILE = (CK * PLANE > EM * 4 * OPS ? CK * PLANE : EM * 4 * OPS);
+  static constexpr int WT = (WRES ? NCH : 1) * KC * MSP;
+  static constexpr int NWQ = KC * MT * 16 / 4 / 256;           // 16-byte weight loads per lane and chunk
+  static constexpr size_t LDS_FLOATS = TILE + WT + 4 * MT * 4 * 2 + 2 * NCH * CK;
+  static constexpr int BANDS = (Hg + R - 1) / R;
+  static_assert(R * Wg <= 64 * NT, "band does not fit the wave tiles");
+  static_assert(MT % EM == 0, "epilogue passes");
+  static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
+};
+
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H>
+__global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int Cs, const float* __restrict__ small_in,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int act, float slope,
+                                                            float* __restrict__ out, double* __restrict__ stats) {
+  using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
+  constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, WsP = G::WsP, PLANE = G::PLANE, MSP = G::MSP;
+  constexpr int KC = G::KC, OPS = G::OPS, BANDS = G::BANDS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* in_tile = lds;
+  float* w_tile = in_tile + G::TILE;
+  float* st_tile = w_tile + G::WT;        // [4 waves][MT*4][2]
+  float* aff = st_tile + 4 * MT * 4 * 2;  // [2][Cs]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int units = B * BANDS;
+  const int nchunk = (Cs + CK - 1) / CK;
+
+  // per-lane B base: grid pixel (ur, v) of tile t, tap k = lane>>4 = th*2+tw:  (ur+1-th)*WsP + v+1-tw
+  int offB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = (wave * NT + t) * 16 + (lane & 15);
+    const int pv = p < R * Wg ? p : 0;
+    const int ur = pv / Wg, v = pv - ur * Wg;
+    const int k = lane >> 4;
+    offB[t] = (ur + 1 - (k >> 1)) * WsP + v + 1 - (k & 1);
+  }
+  const int offA = (lane >> 4) * MSP + (lane & 15);
+
+  typename PickPrefetch<CK, G::ROWS, Ws, WsP, Hs, 1>::type pf;
+  pf.init(tid);
+  stage_affine(aff, in_scale, in_shift, Cs, tid);  // visible after the first barrier of the item loop
+  const pgv_act_params actp = pgv_act_setup(act, slope);
+
+  // weights: 16-byte loads of one kernel row (cs, cb, kh, kw0..3), scattered to [k = (c, th, tw)][m = (cb, ph, pw)]
+  constexpr int NWQ = G::NWQ;
+  f32x4 wv[WRES ? 1 : NWQ];
+  auto load_weights = [&](int cs0, f32x4 (&dst)[NWQ]) {
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+      const int idx = tid + j * 256;  // (c, cb, kh)
+      const int kh = idx & 3, cb = (idx >> 2) % (MT * 4), c = idx / (MT * 16);
+      const bool ok = cs0 + c < Cs && cb < Cb;
+      const float* g = w + (((int64_t)(ok ? cs0 + c : 0) * Cb + (ok ? cb : 0)) * 4 + kh) * 4;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(g);
+      dst[j] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_weights = [&](float* wt, const f32x4 (&src)[NWQ]) {
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+      const int idx = tid + j * 256;
+      const int kh = idx & 3, cb = (idx >> 2) % (MT * 4), c = idx / (MT * 16);
+      const int ph = kh & 1, th = kh >> 1;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        const int pw = kw & 1, tw = kw >> 1;
+        wt[(c * 4 + th * 2 + tw) * MSP + cb * 4 + ph * 2 + pw] = src[j][kw];
+      }
+    }
+  };
+  float bias_r[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int cb = m * 4 + (lane >> 4);
+    bias_r[m] = (bias && cb < Cb) ? bias[cb] : 0.f;
+  }
+  auto issue_item = [&](int u, int ch) {
+    const int b = u / BANDS, band = u - b * BANDS;
+    pf.issue(small_in + ((int64_t)b * Cs + ch * CK) * (Hs * Ws), band * R, Cs - ch * CK);
+    if constexpr (!WRES) load_weights(ch * CK, wv);
+  };
+
+  int u = blockIdx.x;
+  if (u >= units) return;
+  BAND_T0();
+  issue_item(u, 0);
+  if constexpr (WRES) {
+    for (int c = 0; c < nchunk; ++c) {
+      f32x4 tmp[NWQ];
+      load_weights(c * CK, tmp);
+      store_weights(w_tile + c * KC * MSP, tmp);
+    }
+  }
+  f32x4 acc[MT][NT];
+  int ch = 0;
+#pragma unroll 1
+  while (true) {
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();  // previous item's MFMA reads / epilogue copy of the tile region are complete
+    BAND_ACC(0);
+    pf.commit(in_tile, in_scale ? aff : nullptr, Cs, ch * CK, Cs - ch * CK, tid);
+    BAND_ACC(1);
+    if constexpr (!WRES) store_weights(w_tile, wv);
+    const float* wt = WRES ? w_tile + ch * KC * MSP : w_tile;
+    BAND_ACC(2);
+    int nu = u, nch = ch + 1;
+    if (nch == nchunk) {
+      nch = 0;
+      nu = u + gridDim.x;
+    }
+    if (nu < units) issue_item(nu, nch);
+    BAND_ACC(3);
+    __syncthreads();
+    BAND_ACC(4);
+    {
+      constexpr int S = CK;  // one k-group (th, tw) per input channel
+      static_assert(S % 2 == 0, "step count must be even");
+      float a0[MT], a1[MT], b0[NT], b1[NT];
+      auto load_step = [&](int st, float (&av)[MT], float (&bv)[NT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = wt[st * 4 * MSP + m * 16 + offA];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = in_tile[st * PLANE + offB[t]];
+      };
+      auto compute_step = [&](const float (&av)[MT], const float (&bv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    BAND_ACC(5);
+    BAND_ITEM();
+    if (ch == nchunk - 1) {
+      // ---- epilogue: lane owns channel cb = m*4 + (lane>>4) at grid pixel (ur, v); regs = (ph, pw)
+      const int b = u / BANDS, band = u - b * BANDS;
+      const int u0 = band * R;
+      const int rows_g = min(R, Hg - u0);
+      const int Pb = rows_g * Wg;
+      const int rows_o = min(2 * rows_g, H - 2 * u0);  // output rows of this band
+      float* out_tile = in_tile;
+#pragma unroll
+      for (int m0 = 0; m0 < MT; m0 += EM) {
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < EM; ++mm) {
+          const int m = m0 + mm;
+          float* ot = out_tile + (mm * 4 + (lane >> 4)) * OPS;
+          const float bv = bias_r[m];
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int p = (wave * NT + t) * 16 + (lane & 15);
+            const int ur = p / Wg, v = p - ur * Wg;
+            const bool pin = p < Pb;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              const float v0 = pgv_act_apply(acc[m][t][ph * 2 + 0] + bv, actp);
+              const float v1 = pgv_act_apply(acc[m][t][ph * 2 + 1] + bv, actp);
+              const int orow = 2 * ur + ph;
+              const bool rin = pin && orow < rows_o;
+              float* o = ot + orow * W + 2 * v;
+              if (W % 2 == 0) {
+                if (p < R * Wg) *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                const float f0 = rin ? v0 : 0.f, f1 = rin ? v1 : 0.f;
+                s += f0 + f1;
+                q = fmaf(f0, f0, fmaf(f1, f1, q));
+              } else {
+                const bool c1 = 2 * v + 1 < W;
+                if (p < R * Wg) {
+                  o[0] = v0;
+                  if (c1) o[1] = v1;
+                }
+                const float f0 = rin ? v0 : 0.f, f1 = (rin && c1) ? v1 : 0.f;
+                s += f0 + f1;
+                q = fmaf(f0, f0, fmaf(f1, f1, q));
+              }
+            }
+          }
+          if (stats) {
+            const float ss = group16_sum(s), qq = group16_sum(q);
+            if ((lane & 15) == 0) {
+              st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 0] = ss;
+              st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 1] = qq;
+            }
+          }
+        }
+        __syncthreads();
+        const int nchn = min(Cb - m0 * 4, EM * 4);
+        if (nchn > 0)
+          store_rows_contig(out_tile, OPS, out + (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W, (int64_t)H * W, nchn,
+                            rows_o * W, tid);
+      }
+      if (stats && tid < MT * 4 && tid < Cb) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int wv2 = 0; wv2 < 4; ++wv2) {
+          ss += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 0];
+          qq += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 1];
+        }
+        atomicAdd(&stats[tid], ss);
+        atomicAdd(&stats[Cb + tid], qq);
+      }
+      BAND_ACC(6);
+    }
+    u = nu;
+    ch = nch;
+    if (u >= units) break;
+  }
+  BAND_FLUSH();
+}
+
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H>
+int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                   const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                   hipStream_t st) {
+  using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cs > NCH * CK || d->Cb > MT * 4) return 0;
+  auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_up_band");
+  if (rc) return rc;
+  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_band: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int units = d->B * G::BANDS;
+  int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
+  const int grid = min(units, 256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in, in_scale, in_shift, w, bias,
+                     act, slope, out, stats);
+  PGV_CHECK_LAUNCH("conv_up_band");
+  return 1;
+}
+
 }  // namespace
 
 int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
@@ -453,5 +997,37 @@ int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in
     return launch_down_band<2, 3, 8, 2, true, 4, 88, 65>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
   if (d->Hb == 33 && d->Wb == 45 && d->Cs <= 64)
     return launch_down_band<4, 3, 8, 4, false, 8, 45, 33>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+  return 0;
+}
+
+int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  if (d->Hb == 129 && d->Wb == 174)
+    return launch_wgrad_band<1, 8, 1, 1, 174, 129>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                                   st);
+  if (d->Hb == 65 && d->Wb == 88)
+    return launch_wgrad_band<2, 8, 2, 1, 88, 65>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                                 st);
+  if (d->Hb == 33 && d->Wb == 45)
+    return launch_wgrad_band<4, 8, 4, 2, 45, 33>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                                 st);
+  return 0;
+}
+
+int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
+                     hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  if (d->Hb == 129 && d->Wb == 174)
+    return launch_up_band<2, 6, 16, 1, true, 2, 4, 174, 129>(d, small_in, in_scale, in_shift, w, bias, act, slope,
+                                                             big_out, stats, st);
+  if (d->Hb == 65 && d->Wb == 88)
+    return launch_up_band<4, 3, 16, 2, true, 4, 4, 88, 65>(d, small_in, in_scale, in_shift, w, bias, act, slope,
+                                                           big_out, stats, st);
+  if (d->Hb == 33 && d->Wb == 45)
+    return launch_up_band<8, 3, 16, 4, false, 2, 8, 45, 33>(d, small_in, in_scale, in_shift, w, bias, act, slope,
+                                                            big_out, stats, st);
   return 0;
 }

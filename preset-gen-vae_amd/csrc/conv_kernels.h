@@ -30,6 +30,13 @@ int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in
                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                        hipStream_t st);
 
+int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
+                     hipStream_t st);
+int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        hipStream_t st);
+
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                          const float* w, const float* bias, int act, float slope, float* out, double* stats,

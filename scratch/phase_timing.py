@@ -39,6 +39,8 @@ def run(name, fn, n_wg):
         return
     t = raw.astype(np.float64) / 100.0  # us, [wg][wave][stamp]
     ok = t[:, 0, 0] > 0
+    if not ok.any():
+        print(f'== {name}: kernel {e0.elapsed_time(e1)*1e3:.1f} us (no stamps)'); return
     t = t[ok]
     t0 = t[:, :, 0].min()
     raw = tlog[:n_wg].cpu().numpy()[ok.nonzero()[0] if False else slice(None)]
