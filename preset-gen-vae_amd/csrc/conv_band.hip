@@ -556,7 +556,10 @@ struct WgradCfg {
   static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP;
   static constexpr int SPR = WsP / 4;  // MFMA k-steps per output row
   static constexpr int FRONT = 4;
-  static constexpr size_t LDS_FLOATS = FRONT + CB * PLANE_B + CS * PLANE_S + 2 * (CB + CS);
+  static constexpr int TILES = CB * PLANE_B + CS * PLANE_S;
+  static constexpr int RED = WK > 1 ? WK * CS * CB * 16 : 0;  // cross-wave reduction buffer of the final flush
+  static constexpr int BODY = TILES > RED ? TILES : RED;
+  static constexpr size_t LDS_FLOATS = FRONT + BODY + 2 * (CB + CS);
   static constexpr int BANDS = (Hs + R - 1) / R;
   // the right-most B read of a row: 2*(WsP-1) + 3 - 2 must stay inside the padded row (or run into the next row's
   // image columns only where the A operand is a zero pad column)
@@ -577,8 +580,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* big_tile = lds + G::FRONT;
   float* small_tile = big_tile + CB * PLANE_B;
-  float* aff_b = small_tile + CS * PLANE_S;  // [2][Cb]
-  float* aff_s = aff_b + 2 * CB;             // [2][Cs]
+  float* aff_b = big_tile + G::BODY;  // [2][Cb]
+  float* aff_s = aff_b + 2 * CB;      // [2][Cs]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -664,18 +667,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
     BAND_ITEM();
   }
   BAND_FLUSH();
-  // ---- flush: D col = lane&15 = tap, row = (lane>>4)*4 + reg = cs within the M tile
+  // ---- flush: D col = lane&15 = tap, row = (lane>>4)*4 + reg = cs within the M tile.  Waves that split the rows of
+  // the band (WK > 1) hold partial sums of the same elements: they are added up through LDS first, so the workgroup
+  // issues one coalesced float atomic per weight element.
+  if constexpr (WK > 1) {
+    __syncthreads();
+    float* red = big_tile;  // [WK][CS][CB][16]
 #pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    const int cb = gn * NB + n;
-    if (cb < Cb) {
+    for (int n = 0; n < NB; ++n)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int cs = m * 16 + (lane >> 4) * 4 + reg;
-          if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + (lane & 15)], acc[m][n][reg]);
+          const int cs = m * 16 + (lane >> 4) * 4 + reg, cb = gn * NB + n;
+          red[((wk * CS + cs) * CB + cb) * 16 + (lane & 15)] = acc[m][n][reg];
         }
+    __syncthreads();
+    for (int e = tid; e < CS * CB * 16; e += 256) {
+      const int cs = e / (CB * 16), rem = e - cs * (CB * 16), cb = rem >> 4, tap = rem & 15;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) v += red[k * CS * CB * 16 + e];
+      if (cs < Cs && cb < Cb) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + tap], v);
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int cb = gn * NB + n;
+      if (cb < Cb) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int cs = m * 16 + (lane >> 4) * 4 + reg;
+            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + (lane & 15)], acc[m][n][reg]);
+          }
+      }
     }
   }
 }

@@ -13,7 +13,8 @@ import torch
 
 from . import _lib, ops
 
-_ALIGN = 4  # floats (16 B) so every parameter slice can be streamed with 16-byte accesses
+_ALIGN = 64  # floats (256 B): 16-byte streaming accesses, and gradient slices start on a cache-line boundary - the
+# weight-gradient kernels flush with float atomics, which run ~1.5x slower when their 64-byte segments straddle lines
 
 
 class FlatParams:

@@ -103,7 +103,8 @@ def test_flat_params_and_buckets():
     for k, v in ae.state_dict().items():
         assert torch.equal(v, before[k]), k                       # values preserved, keys unchanged
     n = sum(p.numel() for p in ae.parameters())
-    assert n <= flat.numel < n + 4 * len(flat.params)
+    assert n <= flat.numel < n + 64 * len(flat.params)
+    assert all(o % 64 == 0 for o in flat.offsets)
     for p, o in zip(flat.params, flat.offsets):
         assert o % 4 == 0
         assert p.data.data_ptr() == flat.flat_param.data_ptr() + 4 * o
