@@ -79,22 +79,30 @@ _FLUSH = None
 
 
 def time_kernel(fn, iters=10):
-    """Average device time of one fn() launch in ms: HIP events recorded on the stream the kernel is launched on,
-    one pair per launch; between launches a 512 MB buffer is rewritten so that every timed launch starts with its
-    operands in HBM, not in L2 / the 256 MB Infinity Cache (as it does inside the train step, where ~1 GB of other
-    tensors pass between two uses of a tensor) - back-to-back launches on the same buffers time 20 % too fast and
-    disagree with the rocprofv3 kernel trace of the step."""
+    """Average device time of one fn() launch in ms.  The launch (kernel + its memset node, as in the train step) is
+    captured into a hipGraph once and replayed, so no host launch latency sits between its nodes; HIP events are
+    recorded on the replay stream around every replay.  Between replays a 512 MB buffer is rewritten so that every
+    timed launch starts with its operands in HBM, not in L2 / the 256 MB Infinity Cache (as inside the train step,
+    where ~1 GB of other tensors pass between two uses of a tensor)."""
     global _FLUSH
     if _FLUSH is None:
         _FLUSH = torch.empty(128 << 20, device='cuda', dtype=torch.float32)
     fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     pairs = []
     for _ in range(iters):
         _FLUSH.fill_(1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        graph.replay()
         e1.record()
         pairs.append((e0, e1))
     torch.cuda.synchronize()

@@ -48,7 +48,8 @@ typedef struct pgv_conv_desc {
 /* ---- library info ------------------------------------------------------------------------------ */
 int pgv_abi_version(void);
 const char* pgv_last_error(void);
-/* 0 = prefer tuned kernels (default), 1 = force the generic one-thread-per-output kernels (test aid). */
+/* 0 = prefer tuned kernels (default), 1 = force the generic one-thread-per-output kernels, 2 = tuned kernels but
+ * without the shape-specialised band kernels of the reference layer shapes (1 and 2 are test aids). */
 int pgv_set_kernel_policy(int policy);
 
 /* ---- convolutions (layer.Conv2D / layer.TConv2D bodies, model/layer.py:10-46) -------------------- */

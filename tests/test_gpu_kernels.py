@@ -58,7 +58,7 @@ def _affine(t, sc, sh):
     return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
 
 
-@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1, 2])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_down_up_wgrad(ops, case, policy):
     from preset_gen_vae_amd import _lib
@@ -110,6 +110,37 @@ def test_conv_down_up_wgrad(ops, case, policy):
         assert rel_l2(gw, wv.grad) < 5e-5   # fp32 fma chain over B*Hs*Ws pixels (up to 45k) per output
     finally:
         lib.pgv_set_kernel_policy(0)
+
+
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64),
+                                  (32, 64, 4, 2, 2, 33, 45, 200)])
+def test_band_kernels_many_units(ops, case):
+    """The persistent band kernels loop over (sample, band) units with the next unit prefetched in registers: batches
+    large enough that every workgroup processes several units (and the last ones fewer), against MIOpen fp32."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = [dev(t) if torch.is_tensor(t) else t
+                                                                     for t in _conv_inputs(case)]
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    ref = F.leaky_relu(F.conv2d(_affine(big, sc_b, sh_b), w, bias_s, stride=s, padding=p), 0.1)
+    stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+    got = ops.conv_down(geom, big, w, bias_s, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=sc_b, in_shift=sh_b, stats=stats)
+    assert rel_l2(got, ref) < 1e-5
+    assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    ref = F.leaky_relu(F.conv_transpose2d(_affine(small, sc_s, sh_s), w, bias_b, stride=s, padding=p,
+                                          output_padding=(oph, opw)), 0.1)
+    stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+    got = ops.conv_up(geom, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=sc_s, in_shift=sh_s, stats=stats)
+    assert rel_l2(got, ref) < 1e-5
+    assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+    wv = w.clone().requires_grad_(True)
+    F.conv2d(_affine(big, sc_b, sh_b), wv, None, stride=s, padding=p).backward(small)
+    gw = torch.empty((Cs, Cb, k, k), device='cuda')
+    ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)
+    assert rel_l2(gw, wv.grad) < 2e-4   # fp32 chains over up to 1.2 M pixels per output, summed in a different order
+    gw2 = torch.empty_like(gw)
+    ops.conv_wgrad(geom, big, small, gw2, big_scale=sc_b, big_shift=sh_b)
+    assert rel_l2(gw2, gw) < 1e-5       # float atomics: run-to-run differences stay at rounding level
 
 
 def test_conv_desc_validation(ops):
