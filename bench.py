@@ -78,35 +78,58 @@ def layer_ops(ae):
 _FLUSH = None
 
 
-def time_kernel(fn, iters=10):
-    """Average device time of one fn() launch in ms.  The launch (kernel + its memset node, as in the train step) is
-    captured into a hipGraph once and replayed, so no host launch latency sits between its nodes; HIP events are
-    recorded on the replay stream around every replay.  Between replays a 512 MB buffer is rewritten so that every
-    timed launch starts with its operands in HBM, not in L2 / the 256 MB Infinity Cache (as inside the train step,
-    where ~1 GB of other tensors pass between two uses of a tensor)."""
-    global _FLUSH
-    if _FLUSH is None:
-        _FLUSH = torch.empty(128 << 20, device='cuda', dtype=torch.float32)
-    fn()
-    torch.cuda.synchronize()
+def _graph_of(body):
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
-            fn()
+            body()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    pairs = []
-    for _ in range(iters):
-        _FLUSH.fill_(1.0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        pairs.append((e0, e1))
+    return graph
+
+
+def _time_graph(graph, reps=3):
+    graph.replay()
     torch.cuda.synchronize()
-    return sum(a.elapsed_time(b) for a, b in pairs) / iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+_FLUSH_MS = {}
+
+
+def time_kernel(fn, iters=5):
+    """Average device time of one fn() launch (kernel + its memset node, as the train step issues it) in ms, measured
+    the way the step runs it: as nodes of a replayed hipGraph, so no host launch latency sits between nodes.  Graph A =
+    iters x [rewrite a 512 MB buffer, fn()], graph B = iters x [rewrite the buffer]; HIP events around the replays on
+    the replay stream; the result is (A - B) / iters.  The rewrite puts every timed launch's operands back in HBM
+    (not L2 / the 256 MB Infinity Cache), as inside the train step, where ~1 GB of other tensors pass between two
+    uses of a tensor."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(128 << 20, device='cuda', dtype=torch.float32)
+    fn()
+    torch.cuda.synchronize()
+
+    def with_fn():
+        for _ in range(iters):
+            _FLUSH.fill_(1.0)
+            fn()
+
+    def without_fn():
+        for _ in range(iters):
+            _FLUSH.fill_(1.0)
+
+    if iters not in _FLUSH_MS:
+        _FLUSH_MS[iters] = _time_graph(_graph_of(without_fn))
+    return max(_time_graph(_graph_of(with_fn)) - _FLUSH_MS[iters], 0.0) / iters
 
 
 def measure_roofline(ae, B, device):

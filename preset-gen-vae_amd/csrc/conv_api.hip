@@ -101,9 +101,10 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
                 "pgv_conv_wgrad: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
   if (g_policy != 1) {
-    rc = pgv_conv_wgrad_direct(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
-    if (rc == 0 && g_policy == 0)
+    rc = 0;
+    if (g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+    if (rc == 0) rc = pgv_conv_wgrad_direct(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0)
       rc = pgv_conv_wgrad_tuned(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
                                 workspace_bytes, st);

@@ -544,29 +544,32 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
 // the accumulators in registers over all their (sample, band) units and flush once with float atomics; the tiles of
 // unit i+1 are prefetched into registers while unit i is multiplied.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT, int NB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
 struct WgradCfg {
+  static constexpr int KK = KS * KS;
+  static constexpr int NTAP = (KK + 15) / 16;  // N tiles per big channel
+  static constexpr int NB = CB * NTAP / WN;    // N tiles per wave
   static constexpr int WK = 4 / WN;
   static constexpr int R = WK * RW;
-  static constexpr int CB = NB * WN, CS = MT * 16;
-  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;  // (W + 4 - 4) / 2 + 1
-  static constexpr int ROWS_B = 2 * (R - 1) + 4;
+  static constexpr int CS = MT * 16;           // M rows; rows >= CSL alias existing channels and are discarded
+  static constexpr int Ws = (W + 4 - KS) / 2 + 1, Hs = (H + 4 - KS) / 2 + 1;
+  static constexpr int ROWS_B = 2 * (R - 1) + KS;
   static constexpr int WP = (W + 2 + 3) / 4 * 4;
   static constexpr int WsP = (Ws + 3) / 4 * 4;
   static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP;
   static constexpr int SPR = WsP / 4;  // MFMA k-steps per output row
   static constexpr int FRONT = 4;
-  static constexpr int TILES = CB * PLANE_B + CS * PLANE_S;
-  static constexpr int RED = WK > 1 ? WK * CS * CB * 16 : 0;  // cross-wave reduction buffer of the final flush
+  static constexpr int TILES = CB * PLANE_B + CSL * PLANE_S;
+  static constexpr int RED = WK > 1 ? WK * CS * CB * NTAP * 16 : 0;  // cross-wave reduction buffer of the final flush
   static constexpr int BODY = TILES > RED ? TILES : RED;
-  static constexpr size_t LDS_FLOATS = FRONT + BODY + 2 * (CB + CS);
+  static constexpr size_t LDS_FLOATS = FRONT + BODY + 2 * (CB + CSL);
   static constexpr int BANDS = (Hs + R - 1) / R;
-  // the right-most B read of a row: 2*(WsP-1) + 3 - 2 must stay inside the padded row (or run into the next row's
-  // image columns only where the A operand is a zero pad column)
-  static_assert(2 * (Ws - 1) + 1 < WP, "row stride");
+  // right-most B read of a real pixel: 2*(Ws-1) + KS-1 - 2 must hit image or zero pad columns of the same row
+  static_assert(2 * (Ws - 1) + KS - 3 < WP, "row stride");
+  static_assert((CB * NTAP) % WN == 0 && (CSL & (CSL - 1)) == 0 && CSL <= CS, "tiling");
 };
 
-template <int MT, int NB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                                const float* __restrict__ big_scale,
                                                                const float* __restrict__ big_shift,
@@ -574,9 +577,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
                                                                const float* __restrict__ small_scale,
                                                                const float* __restrict__ small_shift,
                                                                float* __restrict__ gw) {
-  using G = WgradCfg<MT, NB, WN, RW, W, H>;
-  constexpr int WK = G::WK, R = G::R, CB = G::CB, CS = G::CS, Ws = G::Ws, Hs = G::Hs, WP = G::WP, WsP = G::WsP;
-  constexpr int PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
+  using G = WgradCfg<KS, MT, CSL, CB, WN, RW, W, H>;
+  constexpr int KK = G::KK, NTAP = G::NTAP, NB = G::NB, WK = G::WK, R = G::R, CS = G::CS, Ws = G::Ws, Hs = G::Hs;
+  constexpr int WP = G::WP, WsP = G::WsP, PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* big_tile = lds + G::FRONT;
   float* small_tile = big_tile + CB * PLANE_B;
@@ -588,17 +591,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   const int gn = wave % WN, wk = wave / WN;
   const int units = B * BANDS;
 
-  // per-lane bases (rows r = wk + WK*rw and steps i are immediates)
+  // per-lane bases (rows r = wk + WK*rw and steps i are immediates); taps >= KK of the last tap tile read tap 0 and
+  // are discarded at the flush
   int offB[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
-    const int cb = gn * NB + n;
-    const int tau = lane & 15, kh = tau >> 2, kw = tau & 3;
+    const int nt = gn * NB + n;
+    const int cb = nt / NTAP, tau = (nt - cb * NTAP) * 16 + (lane & 15);
+    const int kh = tau < KK ? tau / KS : 0, kw = tau < KK ? tau - (tau / KS) * KS : 0;
     offB[n] = cb * PLANE_B + (2 * wk + kh) * WP + kw - 2 + 2 * (lane >> 4);
   }
   int offA[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) offA[m] = (m * 16 + (lane & 15)) * PLANE_S + wk * WsP + (lane >> 4);
+  for (int m = 0; m < MT; ++m) offA[m] = ((m * 16 + (lane & 15)) & (CSL - 1)) * PLANE_S + wk * WsP + (lane >> 4);
 
   f32x4 acc[MT][NB];
 #pragma unroll
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
     for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   typename PickPrefetch<CB, G::ROWS_B, W, WP, H>::type pfb;
-  typename PickPrefetch<CS, R, Ws, WsP, Hs, 0>::type pfs;
+  typename PickPrefetch<CSL, R, Ws, WsP, Hs, 0>::type pfs;
   pfb.init(tid);
   pfs.init(tid);
   if (tid < G::FRONT) lds[tid] = 0.f;
@@ -667,59 +672,62 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
     BAND_ITEM();
   }
   BAND_FLUSH();
-  // ---- flush: D col = lane&15 = tap, row = (lane>>4)*4 + reg = cs within the M tile.  Waves that split the rows of
-  // the band (WK > 1) hold partial sums of the same elements: they are added up through LDS first, so the workgroup
-  // issues one coalesced float atomic per weight element.
+  // ---- flush: D col = lane&15 = tap within the tap tile, row = (lane>>4)*4 + reg = cs within the M tile.  Waves that
+  // split the rows of the band (WK > 1) hold partial sums of the same elements: they are added up through LDS first,
+  // so the workgroup issues one coalesced float atomic per weight element.
+  constexpr int NTT = CB * NTAP;  // N tiles in total
   if constexpr (WK > 1) {
     __syncthreads();
-    float* red = big_tile;  // [WK][CS][CB][16]
+    float* red = big_tile;  // [WK][CS][NTT][16]
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int cs = m * 16 + (lane >> 4) * 4 + reg, cb = gn * NB + n;
-          red[((wk * CS + cs) * CB + cb) * 16 + (lane & 15)] = acc[m][n][reg];
+          const int cs = m * 16 + (lane >> 4) * 4 + reg, nt = gn * NB + n;
+          red[((wk * CS + cs) * NTT + nt) * 16 + (lane & 15)] = acc[m][n][reg];
         }
     __syncthreads();
-    for (int e = tid; e < CS * CB * 16; e += 256) {
-      const int cs = e / (CB * 16), rem = e - cs * (CB * 16), cb = rem >> 4, tap = rem & 15;
+    for (int e = tid; e < CS * NTT * 16; e += 256) {
+      const int cs = e / (NTT * 16), rem = e - cs * (NTT * 16), nt = rem >> 4;
+      const int cb = nt / NTAP, tau = (nt - cb * NTAP) * 16 + (rem & 15);
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < WK; ++k) v += red[k * CS * CB * 16 + e];
-      if (cs < Cs && cb < Cb) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + tap], v);
+      for (int k = 0; k < WK; ++k) v += red[k * CS * NTT * 16 + e];
+      if (cs < Cs && cb < Cb && tau < KK) atomicAdd(&gw[((int64_t)cs * Cb + cb) * KK + tau], v);
     }
   } else {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int cb = gn * NB + n;
-      if (cb < Cb) {
+      const int nt = gn * NB + n;
+      const int cb = nt / NTAP, tau = (nt - cb * NTAP) * 16 + (lane & 15);
+      if (cb < Cb && tau < KK) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int cs = m * 16 + (lane >> 4) * 4 + reg;
-            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * 16 + (lane & 15)], acc[m][n][reg]);
+            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * KK + tau], acc[m][n][reg]);
           }
       }
     }
   }
 }
 
-template <int MT, int NB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
 int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                       hipStream_t st) {
-  using G = WgradCfg<MT, NB, WN, RW, W, H>;
+  using G = WgradCfg<KS, MT, CSL, CB, WN, RW, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
-  if (d->Cb > G::CB || d->Cs > G::CS) return 0;
-  auto kern = conv_wgrad_band_kernel<MT, NB, WN, RW, W, H>;
+  if (d->Cb > CB || d->Cs > CSL) return 0;
+  auto kern = conv_wgrad_band_kernel<KS, MT, CSL, CB, WN, RW, W, H>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
   if (rc) return rc;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * 16, st) != hipSuccess) {
+  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * G::KK, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_band: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -1030,16 +1038,15 @@ int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in
 int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st) {
-  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
-  if (d->Hb == 129 && d->Wb == 174)
-    return launch_wgrad_band<1, 8, 1, 1, 174, 129>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                                   st);
-  if (d->Hb == 65 && d->Wb == 88)
-    return launch_wgrad_band<2, 8, 2, 1, 88, 65>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                                 st);
-  if (d->Hb == 33 && d->Wb == 45)
-    return launch_wgrad_band<4, 8, 4, 2, 45, 33>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                                 st);
+  if (d->stride != 2 || d->pad != 2 || d->kh != d->kw) return 0;
+#define PGV_WGB(...) \
+  return launch_wgrad_band<__VA_ARGS__>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st)
+  if (d->kh == 5 && d->Hb == 257 && d->Wb == 347) PGV_WGB(5, 1, 8, 1, 1, 1, 347, 257);
+  if (d->kh != 4) return 0;
+  if (d->Hb == 129 && d->Wb == 174) PGV_WGB(4, 1, 16, 8, 1, 1, 174, 129);
+  if (d->Hb == 65 && d->Wb == 88) PGV_WGB(4, 2, 32, 16, 2, 1, 88, 65);
+  if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 32, 4, 2, 45, 33);
+#undef PGV_WGB
   return 0;
 }
 
