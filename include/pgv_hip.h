@@ -43,7 +43,14 @@ typedef struct pgv_conv_desc {
   int32_t Cs, Hs, Ws;      /* small tensor [B,Cs,Hs,Ws] */
   int32_t kh, kw;          /* kernel */
   int32_t stride, pad;     /* same on both axes (reference uses [2,2]/2 or [1,1]/0) */
+  int32_t flags;           /* PGV_PREZEROED: the accumulated outputs of the call (stats / gw) already hold zeros */
 } pgv_conv_desc;
+
+/* Reduction outputs (BN statistics, weight / bias gradients, BN-backward projections) are accumulated with atomics.
+ * By default every call clears its output first (one memset node per call).  With PGV_PREZEROED the caller promises
+ * the buffer is zero - e.g. one arena cleared once per step, or the zero_grad'ed flat gradient buffer
+ * (train.py:208) - and the call only accumulates. */
+#define PGV_PREZEROED 1
 
 /* ---- library info ------------------------------------------------------------------------------ */
 int pgv_abi_version(void);
@@ -85,8 +92,9 @@ int pgv_bn_stats(const float* a, int B, int C, int HW, double* stats, void* stre
 /* From stats: mean/biased var -> scale=gamma*rstd, shift=beta-mean*scale; saves mean,rstd;
  * running_mean/var momentum update with the unbiased variance (torch semantics); any of running_* may be NULL. */
 int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
-                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                    float* mean, float* rstd, void* stream);
+                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* (num_batches_tracked, may be NULL, is incremented by one: nn.BatchNorm's counter, same launch) */
 /* Eval-mode BN folded to an affine: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
  * (validation forward, train.py:261-291). */
 int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -94,18 +102,18 @@ int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 /* o = a*scale[c]+shift[c]  (materialised BN output; in place allowed). */
 int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int B, int C, int HW, float* o,
                     void* stream);
-/* red[0:C] = sum g_o, red[C:2C] = sum g_o * a_hat, a_hat=(a-mean)*rstd. Overwrites red. */
+/* red[0:C] = sum g_o, red[C:2C] = sum g_o * a_hat, a_hat=(a-mean)*rstd. Overwrites red (flags: PGV_PREZEROED). */
 int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C,
-                      int HW, double* red, void* stream);
+                      int HW, double* red, int flags, void* stream);
 /* Backward through [activation -> BN]: given g_o (grad of BN output) produces g_y (grad of the pre-activation
  * conv output): g_a = scale[c]*(g_o - red[c]/n - a_hat*red[C+c]/n); g_y = g_a * act'(a).
  * With scale==NULL (block without BN) g_a = g_o; with red==NULL (eval-mode BN) g_a = scale[c]*g_o.
- * Also emits gbias[c] = sum g_y (bias gradient, may be NULL), and when
- * BN is present ggamma = red[C:2C], gbeta = red[0:C] are simply read by the caller.
+ * Also emits gbias[c] = sum g_y (bias gradient, may be NULL; flags: PGV_PREZEROED applies to it), and when BN is
+ * present writes ggamma[c] = red[C+c], gbeta[c] = red[c] as float32 (either may be NULL).
  * act' is recovered from the saved activated tensor a (sign for LeakyReLU; |a|<1 for Hardtanh). */
 int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
                    const double* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
-                   void* stream);
+                   float* ggamma, float* gbeta, int flags, void* stream);
 
 /* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */
 /* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.

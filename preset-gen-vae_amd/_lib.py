@@ -12,11 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpgv_hip.so")
 
 PGV_ACT_NONE, PGV_ACT_LEAKY_RELU, PGV_ACT_HARDTANH = 0, 1, 2
+PGV_PREZEROED = 1
 
 
 class ConvDesc(Structure):
     """Mirror of ``pgv_conv_desc`` (include/pgv_hip.h)."""
-    _fields_ = [(n, c_int32) for n in ("B", "Cb", "Hb", "Wb", "Cs", "Hs", "Ws", "kh", "kw", "stride", "pad")]
+    _fields_ = [(n, c_int32) for n in ("B", "Cb", "Hb", "Wb", "Cs", "Hs", "Ws", "kh", "kw", "stride", "pad",
+                                        "flags")]
 
 
 _P = c_void_p  # device pointers travel as integers
@@ -32,11 +34,12 @@ SIGNATURES = {
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
-    "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "pgv_affine_nchw": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
-    "pgv_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
-    "pgv_act_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "pgv_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "pgv_act_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int,
+                               _P]),
     "pgv_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "pgv_gemm": (c_int, [c_int, c_int, c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P,
                          c_int64, _P]),

@@ -61,10 +61,11 @@ __global__ void bn_stats_kernel(const float* __restrict__ a, int B, int C, int H
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double inv_n, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ mean_out,
-                                   float* __restrict__ rstd_out) {
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   if (c >= C) return;
   const double mean = (double)stats[c] * inv_n;
   double var = (double)stats[C + c] * inv_n - mean * mean;
@@ -149,9 +150,14 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const double* __restrict__ redv, double inv_n, int B,
                                   int C, int HW, int per, int act, float slope, float* __restrict__ g_y,
-                                  float* __restrict__ gbias) {
+                                  float* __restrict__ gbias, float* __restrict__ ggamma,
+                                  float* __restrict__ gbeta) {
   __shared__ float red[16];
   const int c = blockIdx.x;
+  if (redv && blockIdx.y == 0 && threadIdx.x == 0) {  // BatchNorm parameter gradients, float32 copies of the sums
+    if (ggamma) ggamma[c] = (float)redv[C + c];
+    if (gbeta) gbeta[c] = (float)redv[c];
+  }
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   const bool has_bn = scale != nullptr;
   float sc = 1.f, mu = 0.f, rs = 1.f, c1 = 0.f, c2 = 0.f;
@@ -244,14 +250,14 @@ int pgv_bn_stats(const float* a, int B, int C, int HW, double* stats, void* stre
 }
 
 int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
-                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                    float* mean, float* rstd, void* stream) {
+                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale, float* shift, float* mean, float* rstd, void* stream) {
   PGV_CHECK_ARG(stats && C > 0 && n > 0, "pgv_bn_finalize: bad argument");
   // torch raises for n==1 in train mode ("Expected more than 1 value per channel"); the host mirrors that.
   const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), stats,
-                     C, 1.0 / (double)n, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale,
-                     shift, mean, rstd);
+                     C, 1.0 / (double)n, unbias, gamma, beta, eps, momentum, running_mean, running_var,
+                     num_batches_tracked, scale, shift, mean, rstd);
   PGV_CHECK_LAUNCH("bn_finalize");
   return PGV_OK;
 }
@@ -277,11 +283,13 @@ int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int 
 }
 
 int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
-                      double* red, void* stream) {
+                      double* red, int flags, void* stream) {
   PGV_CHECK_ARG(g_o && a && mean && rstd && red && B >= 0 && C > 0 && HW > 0, "pgv_bn_bwd_reduce: bad argument");
   hipStream_t st = pgv_stream(stream);
-  int rc = zero_async(red, sizeof(double) * 2 * C, st, "pgv_bn_bwd_reduce");
-  if (rc) return rc;
+  if (!(flags & PGV_PREZEROED)) {
+    int rc = zero_async(red, sizeof(double) * 2 * C, st, "pgv_bn_bwd_reduce");
+    if (rc) return rc;
+  }
   if (B == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, mean, rstd, B, C, HW, s.per,
@@ -292,11 +300,12 @@ int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const
 
 int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
                    const double* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
-                   void* stream) {
+                   float* ggamma, float* gbeta, int flags, void* stream) {
   PGV_CHECK_ARG(g_o && a && g_y && B >= 0 && C > 0 && HW > 0, "pgv_act_bn_bwd: bad argument");
   PGV_CHECK_ARG(red == nullptr || (scale && mean && rstd), "pgv_act_bn_bwd: train-mode BN needs scale/mean/rstd");
   hipStream_t st = pgv_stream(stream);
-  if (gbias) {
+  PGV_CHECK_ARG((ggamma == nullptr && gbeta == nullptr) || red != nullptr, "pgv_act_bn_bwd: ggamma/gbeta need red");
+  if (gbias && !(flags & PGV_PREZEROED)) {
     int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_act_bn_bwd");
     if (rc) return rc;
   }
@@ -304,7 +313,7 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
   Split s = pick_split(B, C, HW);
   const double inv_n = 1.0 / ((double)B * HW);
   hipLaunchKernelGGL(act_bn_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, scale, mean, rstd, red, inv_n,
-                     B, C, HW, s.per, act, slope, g_y, gbias);
+                     B, C, HW, s.per, act, slope, g_y, gbias, ggamma, gbeta);
   PGV_CHECK_LAUNCH("act_bn_bwd");
   return PGV_OK;
 }

@@ -518,7 +518,7 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_band");
   if (rc) return rc;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_band: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -727,7 +727,7 @@ int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
   if (rc) return rc;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * G::KK, st) != hipSuccess) {
+  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * G::KK, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_band: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -1006,7 +1006,7 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_up_band");
   if (rc) return rc;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_band: memset failed");
     return PGV_E_LAUNCH;
   }

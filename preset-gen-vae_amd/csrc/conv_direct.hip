@@ -277,7 +277,7 @@ int pgv_conv_wgrad_direct(const pgv_conv_desc* d, const float* big, const float*
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_direct");
   if (rc) return rc;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * KK, st) != hipSuccess) {
+  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * KK, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_direct: memset failed");
     return PGV_E_LAUNCH;
   }

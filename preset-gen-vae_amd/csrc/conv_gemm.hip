@@ -307,7 +307,7 @@ int pgv_conv_down_gemm(const pgv_conv_desc* d, const float* big, const float* in
                        hipStream_t st) {
   const bool k4 = shape_k4(d), k1 = shape_k1(d);
   if (!k4 && !k1) return 0;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_gemm: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -328,7 +328,7 @@ int pgv_conv_up_gemm(const pgv_conv_desc* d, const float* small_in, const float*
                      hipStream_t st) {
   const bool k4 = shape_k4(d), k1 = shape_k1(d);
   if (!k4 && !k1) return 0;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_gemm: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -352,7 +352,7 @@ int pgv_conv_wgrad_gemm(const pgv_conv_desc* d, const float* big, const float* b
   if (!k4 && !k1) return 0;
   const int KK = d->kh * d->kw;
   const int64_t Nw = (int64_t)d->Cb * KK;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * Nw, st) != hipSuccess) {
+  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * Nw, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_gemm: memset failed");
     return PGV_E_LAUNCH;
   }

@@ -150,7 +150,7 @@ int pgv_conv_wgrad_generic(const pgv_conv_desc* d, const float* big, const float
   const int kk = d->kh * d->kw;
   PGV_CHECK_ARG(kk <= 25, "conv_wgrad: kernel %dx%d larger than 5x5 unsupported", d->kh, d->kw);
   const int64_t nw = (int64_t)d->Cs * d->Cb * kk;
-  hipError_t e = hipMemsetAsync(gw, 0, nw * sizeof(float), st);
+  hipError_t e = (d->flags & PGV_PREZEROED) ? hipSuccess : hipMemsetAsync(gw, 0, nw * sizeof(float), st);
   if (e != hipSuccess) {
     pgv_set_error("conv_wgrad: memset failed: %s", hipGetErrorString(e));
     return PGV_E_LAUNCH;

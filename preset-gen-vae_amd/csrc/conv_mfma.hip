@@ -285,7 +285,7 @@ int launch_down(const pgv_conv_desc* d, const float* big, const float* in_scale,
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_mfma");
   if (rc) return rc;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_mfma: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -507,7 +507,7 @@ int launch_up(const pgv_conv_desc* d, const float* small_in, const float* in_sca
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_up_mfma");
   if (rc) return rc;
-  if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_mfma: memset failed");
     return PGV_E_LAUNCH;
   }
@@ -684,7 +684,7 @@ int launch_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scal
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_mfma");
   if (rc) return rc;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * KK, st) != hipSuccess) {
+  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * KK, st) != hipSuccess) {
     pgv_set_error("conv_wgrad_mfma: memset failed");
     return PGV_E_LAUNCH;
   }

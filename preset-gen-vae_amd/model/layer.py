@@ -80,17 +80,24 @@ class _Block:
         return ps
 
 
-def _grad_dest(param):
+def _grad_dest(param, accumulated=False):
     """Where a parameter gradient is written.  Flat-buffer mode (optim.FlatParams): straight into the parameter's
-    slice of the flat gradient buffer (the gradient is OVERWRITTEN — train.py:208 zero-grads every step anyway) and
-    autograd gets ``None``; otherwise a fresh tensor that autograd accumulates as usual."""
+    slice of the flat gradient buffer and autograd gets ``None``; otherwise a fresh tensor that autograd accumulates
+    as usual.  ``accumulated=True`` is for kernels that add into their output with atomics: a third value tells
+    whether the destination already holds zeros (PGV_PREZEROED) - true for the flat buffer, which
+    ``FusedAdam.zero_grad`` clears with one fill at the start of every step (train.py:208)."""
     view = getattr(param, '_pgv_grad_view', None)
     if view is not None:
         if param.grad is not view:
             param.grad = view
-        return view, None
+        if not accumulated:
+            return view, None
+        flat = param._pgv_flat
+        clean = flat.grad_zeroed and getattr(param, '_pgv_zero_gen', -1) != flat.zero_gen
+        param._pgv_zero_gen = flat.zero_gen  # a second backward before the next zero_grad() must clear for itself
+        return view, None, clean
     t = torch.empty_like(param)
-    return t, t
+    return (t, t, False) if accumulated else (t, t)
 
 
 # Set by parallel.GradAllReduce: called with a parameter right after the kernel writing its gradient was launched on
@@ -116,6 +123,11 @@ class ConvStackFn(torch.autograd.Function):
         cur, cur_scale, cur_shift = x, None, None
         saved = []
         pi = 0
+        # BatchNorm statistics of all blocks in one arena cleared by ONE fill (PGV_PREZEROED): a memset node per block
+        # costs ~5 us of dependent-launch latency each
+        n_stats = sum(2 * blk.c_out for blk in blocks if blk.bn is not None) if training else 0
+        arena = torch.zeros(n_stats, device=dev, dtype=torch.float64) if n_stats else None
+        a_off = 0
         for blk in blocks:
             w, b = params[pi], params[pi + 1]
             pi += 2
@@ -126,9 +138,13 @@ class ConvStackFn(torch.autograd.Function):
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
             C = blk.c_out
-            stats = torch.empty(2 * C, device=dev, dtype=torch.float64) if (has_bn and training) else None
+            stats = None
+            if has_bn and training:
+                stats = arena[a_off:a_off + 2 * C]
+                a_off += 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
-            a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats)
+            a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats,
+                   prezeroed=stats is not None)
             scale = shift = mean = rstd = None
             if has_bn:
                 vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
@@ -141,9 +157,8 @@ class ConvStackFn(torch.autograd.Function):
                     mom = bn.momentum if bn.momentum is not None else 0.1
                     track = bn.track_running_stats and bn.running_mean is not None
                     ops.bn_finalize(stats, n, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
-                                    bn.running_var if track else None, scale, shift, mean, rstd)
-                    if track and bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
+                                    bn.running_var if track else None, scale, shift, mean, rstd,
+                                    num_batches_tracked=bn.num_batches_tracked if track else None)
                 else:
                     ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
                     mean = rstd = None
@@ -160,6 +175,9 @@ class ConvStackFn(torch.autograd.Function):
         dev = g_o.device
         grads = [None] * len(params)
         pi = len(params)
+        n_red = sum(2 * blk.c_out for blk, sv in zip(blocks, saved) if blk.bn is not None and sv[5] is not None)
+        arena = torch.zeros(n_red, device=dev, dtype=torch.float64) if n_red else None  # BN-backward projections
+        a_off = 0
         for li in range(len(blocks) - 1, -1, -1):
             blk = blocks[li]
             inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
@@ -167,30 +185,28 @@ class ConvStackFn(torch.autograd.Function):
             pi -= 4 if has_bn else 2
             w = params[pi]
             C = blk.c_out
-            red = None
+            red = ggamma = gbeta = None
             if has_bn and mean is not None:
-                red = torch.empty(2 * C, device=dev, dtype=torch.float64)
-                ops.bn_bwd_reduce(g_o, a, mean, rstd, red)
-                dst, ret = _grad_dest(params[pi + 2])
-                dst.copy_(red[C:])
-                grads[pi + 2] = ret
-                dst, ret = _grad_dest(params[pi + 3])
-                dst.copy_(red[:C])
-                grads[pi + 3] = ret
-                _grad_done(params[pi + 2], params[pi + 3])
-            elif has_bn:  # eval-mode BN: gamma/beta gradients are not produced
-                pass
-            gb, gb_ret = _grad_dest(params[pi + 1])
+                red = arena[a_off:a_off + 2 * C]
+                a_off += 2 * C
+                ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
+                ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
+                gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
+            # (eval-mode BN: gamma/beta gradients are not produced)
+            gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
             # g_y overwrites g_o unless g_o is the caller's tensor (first iteration)
             g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
-            ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb)
+            ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
+                           ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
             grads[pi + 1] = gb_ret
+            if ggamma is not None:
+                _grad_done(params[pi + 2], params[pi + 3])
             _grad_done(params[pi + 1])
-            gw, gw_ret = _grad_dest(w)
+            gw, gw_ret, gw_zero = _grad_dest(w, accumulated=True)
             if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
-                ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift)
+                ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero)
             else:        # Conv2d: big = block input, small = g_y
-                ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift)
+                ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift, prezeroed=gw_zero)
             grads[pi] = gw_ret
             _grad_done(w)
             need_dx = li > 0 or ctx.needs_input_grad[0]
@@ -317,9 +333,8 @@ class BatchNorm1dFn(torch.autograd.Function):
             track = bn.track_running_stats and bn.running_mean is not None
             mom = bn.momentum if bn.momentum is not None else 0.1
             ops.bn_finalize(stats, B, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
-                            bn.running_var if track else None, scale, shift, mean, rstd)
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                            bn.running_var if track else None, scale, shift, mean, rstd,
+                            num_batches_tracked=bn.num_batches_tracked if track else None)
         else:
             ops.bn_eval_affine(gamma, beta, bn.running_mean, bn.running_var, bn.eps, scale, shift)
             mean = rstd = None
@@ -334,16 +349,15 @@ class BatchNorm1dFn(torch.autograd.Function):
         B, C = x.shape
         g = g.contiguous().view(B, C, 1)
         x3 = x.view(B, C, 1)
-        red = None
+        red = ggamma = gbeta = None
         gg_ret = gb_ret = None
         if mean is not None:
             red = torch.empty(2 * C, device=x.device, dtype=torch.float64)
             ops.bn_bwd_reduce(g, x3, mean, rstd, red)
-            dst, gg_ret = _grad_dest(gamma)
-            dst.copy_(red[C:])
-            dst, gb_ret = _grad_dest(beta)
-            dst.copy_(red[:C])
-            _grad_done(gamma, beta)
+            ggamma, gg_ret = _grad_dest(gamma)
+            gbeta, gb_ret = _grad_dest(beta)
         gx = torch.empty_like(x3)
-        ops.act_bn_bwd(g, x3, scale, mean, rstd, red, PGV_ACT_NONE, 0.0, gx, None)
+        ops.act_bn_bwd(g, x3, scale, mean, rstd, red, PGV_ACT_NONE, 0.0, gx, None, ggamma=ggamma, gbeta=gbeta)
+        if ggamma is not None:
+            _grad_done(gamma, beta)
         return gx.view(B, C), None, None, gg_ret, gb_ret

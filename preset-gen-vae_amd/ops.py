@@ -47,35 +47,36 @@ class ConvGeom:
         self.Ws = (Wb + 2 * pad - k) // stride + 1
         self._descs = {}
 
-    def desc(self, B):
-        d = self._descs.get(B)
+    def desc(self, B, flags=0):
+        d = self._descs.get((B, flags))
         if d is None:
             d = ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
-                         self.pad)
-            self._descs[B] = d
+                         self.pad, flags)
+            self._descs[(B, flags)] = d
         return d
 
 
-def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None):
+def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False):
+    """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it."""
     B = big.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cs, geom.Hs, geom.Ws), device=big.device, dtype=torch.float32)
     _chk(big, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    _lib.check(lib.pgv_conv_down(ctypes.byref(geom.desc(B)), _p(big), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
+    _lib.check(lib.pgv_conv_down(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
                                  slope, _p(out), _p(stats), _stream()), "pgv_conv_down")
     return out
 
 
-def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None):
+def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False):
     B = small.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
     _chk(small, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    _lib.check(lib.pgv_conv_up(ctypes.byref(geom.desc(B)), _p(small), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
+    _lib.check(lib.pgv_conv_up(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
                                slope, _p(out), _p(stats), _stream()), "pgv_conv_up")
     return out
 
@@ -94,11 +95,13 @@ def _workspace(device, nbytes):
     return ws
 
 
-def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None):
+def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None,
+               prezeroed=False):
+    """``prezeroed``: ``gw`` already holds zeros (e.g. a slice of the zero_grad'ed flat gradient buffer)."""
     B = big.shape[0]
     _chk(big, small, gw, big_scale, big_shift, small_scale, small_shift)
     lib = _lib.load()
-    d = geom.desc(B)
+    d = geom.desc(B, int(prezeroed))
     nbytes = lib.pgv_conv_wgrad_workspace(ctypes.byref(d))
     ws = _workspace(big.device, nbytes)
     _lib.check(lib.pgv_conv_wgrad(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small), _p(small_scale),
@@ -114,12 +117,15 @@ def bn_stats(a, stats):
     _lib.check(_lib.load().pgv_bn_stats(_p(a), B, C, HW, _p(stats), _stream()), "pgv_bn_stats")
 
 
-def bn_finalize(stats, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd):
+def bn_finalize(stats, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd,
+                num_batches_tracked=None):
     C = stats.numel() // 2
     _chk64(stats)
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise ValueError("num_batches_tracked must be an int64 device tensor")
     _lib.check(_lib.load().pgv_bn_finalize(_p(stats), C, n, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
-                                           _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd), _stream()),
-               "pgv_bn_finalize")
+                                           _p(running_var), _p(num_batches_tracked), _p(scale), _p(shift), _p(mean),
+                                           _p(rstd), _stream()), "pgv_bn_finalize")
 
 
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
@@ -140,22 +146,24 @@ def affine_nchw(a, scale, shift, out=None):
     return out
 
 
-def bn_bwd_reduce(g_o, a, mean, rstd, red):
+def bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=False):
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
     _chk(g_o, a, mean, rstd)
     _chk64(red)
-    _lib.check(_lib.load().pgv_bn_bwd_reduce(_p(g_o), _p(a), _p(mean), _p(rstd), B, C, HW, _p(red), _stream()),
-               "pgv_bn_bwd_reduce")
+    _lib.check(_lib.load().pgv_bn_bwd_reduce(_p(g_o), _p(a), _p(mean), _p(rstd), B, C, HW, _p(red), int(prezeroed),
+                                             _stream()), "pgv_bn_bwd_reduce")
 
 
-def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias):
+def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=None, gbeta=None, prezeroed=False):
+    """``prezeroed`` refers to ``gbias``; ``ggamma`` / ``gbeta`` (train-mode BN only) are plain float32 stores."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(g_o, a, scale, mean, rstd, g_y, gbias)
+    _chk(g_o, a, scale, mean, rstd, g_y, gbias, ggamma, gbeta)
     _chk64(red)
     _lib.check(_lib.load().pgv_act_bn_bwd(_p(g_o), _p(a), _p(scale), _p(mean), _p(rstd), _p(red), B, C, HW, act, slope,
-                                          _p(g_y), _p(gbias), _stream()), "pgv_act_bn_bwd")
+                                          _p(g_y), _p(gbias), _p(ggamma), _p(gbeta), int(prezeroed), _stream()),
+               "pgv_act_bn_bwd")
 
 
 def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None):

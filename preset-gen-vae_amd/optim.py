@@ -45,7 +45,12 @@ class FlatParams:
             p.data = self.flat_param[o:o + n].view(p.shape)
             gv = self.flat_grad[o:o + n].view(p.shape)
             p._pgv_grad_view = gv
+            p._pgv_flat = self
             p.grad = gv
+        # True between zero_grad() and the next optimizer step: the gradient kernels that accumulate with atomics may
+        # then skip their own clearing pass (PGV_PREZEROED)
+        self.grad_zeroed = False
+        self.zero_gen = 0  # bumped by every zero_grad(): a slice is clean only for the first backward after it
 
     def bucket_ranges(self, n_buckets):
         """Split [0, numel) at parameter boundaries into ~equal contiguous ranges (gradient-ready order)."""
@@ -90,8 +95,12 @@ class FusedAdam(torch.optim.Optimizer):
         ops.fill(self.hyper[0:1], float(lr))
 
     def zero_grad(self, set_to_none=False):
-        """Gradients are overwritten by every backward (layer._grad_dest), so this is a no-op kept for API parity
-        with ``optimizer.zero_grad()`` at train.py:208."""
+        """``optimizer.zero_grad()`` of train.py:208: ONE fill of the flat gradient buffer.  The weight / bias gradient
+        kernels accumulate with atomics; knowing the buffer is clean they skip their per-call memset nodes (~5 us of
+        dependent-launch latency each, 16 per step)."""
+        self.flat.flat_grad.zero_()
+        self.flat.grad_zeroed = True
+        self.flat.zero_gen += 1
         return None
 
     @torch.no_grad()
@@ -106,4 +115,5 @@ class FusedAdam(torch.optim.Optimizer):
         f = self.flat
         ops.adam_step(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, self.hyper, b1, b2, g['eps'],
                       g['weight_decay'])
+        f.grad_zeroed = False
         return None

@@ -143,6 +143,31 @@ def test_band_kernels_many_units(ops, case):
     assert rel_l2(gw2, gw) < 1e-5       # float atomics: run-to-run differences stay at rounding level
 
 
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 2), (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3),
+                                  (3, 5, 4, 2, 2, 10, 13, 2)])
+def test_conv_prezeroed_outputs_accumulate(ops, case):
+    """PGV_PREZEROED (pgv_conv_desc.flags): stats / gw are accumulated into, not cleared - every kernel family."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = [dev(t) if torch.is_tensor(t) else t
+                                                                     for t in _conv_inputs(case)]
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    st1 = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+    ops.conv_down(geom, big, w, bias_s, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st1)
+    st2 = st1.clone()
+    ops.conv_down(geom, big, w, bias_s, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st2, prezeroed=True)
+    assert rel_l2(st2, 2 * st1) < 1e-9
+    st1 = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+    ops.conv_up(geom, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st1)
+    st2 = st1.clone()
+    ops.conv_up(geom, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st2, prezeroed=True)
+    assert rel_l2(st2, 2 * st1) < 1e-9
+    gw1 = torch.empty((Cs, Cb, k, k), device='cuda')
+    ops.conv_wgrad(geom, big, small, gw1)
+    gw2 = gw1.clone()
+    ops.conv_wgrad(geom, big, small, gw2, prezeroed=True)
+    assert rel_l2(gw2, 2 * gw1) < 1e-5
+
+
 def test_conv_desc_validation(ops):
     from preset_gen_vae_amd import _lib
     geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
@@ -153,7 +178,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 1
+    assert _lib.load().pgv_abi_version() == 2
 
 
 def test_empty_batch(ops):
@@ -186,7 +211,10 @@ def test_batchnorm_pieces(ops, shape):
     vec = torch.empty(4 * C, device='cuda')
     scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
     d_rm, d_rv = dev(rm), dev(rv)
-    ops.bn_finalize(stats, B * HW, dev(gamma), dev(beta), 1e-5, 0.1, d_rm, d_rv, scale, shift, mean, rstd)
+    nbt = torch.full((), 41, device='cuda', dtype=torch.int64)
+    ops.bn_finalize(stats, B * HW, dev(gamma), dev(beta), 1e-5, 0.1, d_rm, d_rv, scale, shift, mean, rstd,
+                    num_batches_tracked=nbt)
+    assert int(nbt) == 42   # nn.BatchNorm's counter advances in the same launch
     out = ops.affine_nchw(d_act, scale, shift)
     assert rel_l2(out, o) < 1e-5
     assert rel_l2(d_rm, rm_r) < 1e-5 and rel_l2(d_rv, rv_r) < 1e-5
@@ -196,9 +224,19 @@ def test_batchnorm_pieces(ops, shape):
     assert rel_l2(red[C:], gam_r.grad) < 1e-4 and rel_l2(red[:C], bet_r.grad) < 1e-4
     g_y = torch.empty_like(d_go)
     gbias = torch.empty(C, device='cuda')
-    ops.act_bn_bwd(d_go, d_act, scale, mean, rstd, red, ops.PGV_ACT_LEAKY_RELU, 0.1, g_y, gbias)
+    ggamma, gbeta = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ops.act_bn_bwd(d_go, d_act, scale, mean, rstd, red, ops.PGV_ACT_LEAKY_RELU, 0.1, g_y, gbias, ggamma=ggamma,
+                   gbeta=gbeta)
     assert rel_l2(g_y, a_r.grad) < 1e-4
     assert rel_l2(gbias, a_r.grad.sum(dim=(0, 2))) < 1e-3 or a_r.grad.sum(dim=(0, 2)).abs().max() < 1e-6
+    assert torch.equal(ggamma, red[C:].float()) and torch.equal(gbeta, red[:C].float())
+    # PGV_PREZEROED: the call accumulates into what the buffer holds (the caller cleared it once for many calls)
+    red2 = red.clone()
+    ops.bn_bwd_reduce(d_go, d_act, mean, rstd, red2, prezeroed=True)
+    assert rel_l2(red2, 2 * red) < 1e-12
+    gb2 = gbias.clone()
+    ops.act_bn_bwd(d_go, d_act, scale, mean, rstd, red, ops.PGV_ACT_LEAKY_RELU, 0.1, g_y, gb2, prezeroed=True)
+    assert rel_l2(gb2, 2 * gbias) < 1e-5 or gbias.abs().max() < 1e-6
     # eval-mode affine
     ops.bn_eval_affine(dev(gamma), dev(beta), dev(rm), dev(rv), 1e-5, scale, shift)
     ref = F.batch_norm(act, rm.clone(), rv.clone(), gamma, beta, training=False, eps=1e-5)

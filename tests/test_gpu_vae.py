@@ -57,10 +57,10 @@ def _record_activation_regions(run, arch):
     rec = []
     orig = ops.act_bn_bwd
 
-    def patched(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias):
+    def patched(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, **kw):
         if a.dim() == 4:
             rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
-        return orig(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias)
+        return orig(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, **kw)
 
     ops.act_bn_bwd = patched
     try:
