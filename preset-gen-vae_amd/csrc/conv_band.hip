@@ -63,10 +63,11 @@ namespace {
 //   commit(): producer's BatchNorm affine (uniform per channel: scalar loads) on image data only, then ds_write_b128.
 // Between the two the workgroup runs the MFMA loop and the epilogue of the previous tile: HBM latency is hidden.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2, int CSTRIDE = ROWS * WP>
 struct BandPrefetch {
   static constexpr int QR = WP / 4;
   static constexpr int PC = ROWS * QR;            // chunks per channel
+  static_assert(CSTRIDE >= ROWS * WP && CSTRIDE % 4 == 0, "channel stride");
   static constexpr int SPC = (PC + 255) / 256;    // slots per channel and lane
   static constexpr int NPF = CK * SPC;
   static constexpr int NP = W % 4;
@@ -153,7 +154,7 @@ struct BandPrefetch {
             x.z = fmaf(e2, m2, a2);
             x.w = fmaf(t.w, m3, a3);
           }
-          *reinterpret_cast<f32x4*>(lane_tile + c * (PC * 4) + 1024 * k) = x;
+          *reinterpret_cast<f32x4*>(lane_tile + c * CSTRIDE + 1024 * k) = x;
         }
       }
     }
@@ -163,10 +164,11 @@ struct BandPrefetch {
 // Same interface, flat chunk list (chunk e = tid + 256*j over all CK*PC chunks of the tile, channel-major): used when a
 // channel has far fewer than 256 chunks and the per-channel slots of BandPrefetch would leave most lanes idle.  One
 // packed descriptor register per slot; the affine parameters are per-lane LDS reads.
-template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2, int CSTRIDE = ROWS * WP>
 struct FlatPrefetch {
   static constexpr int QR = WP / 4;
   static constexpr int PC = ROWS * QR;
+  static_assert(CSTRIDE >= ROWS * WP && CSTRIDE % 4 == 0, "channel stride");
   static constexpr int ITEMS = CK * PC;
   static constexpr int NPF = (ITEMS + 255) / 256;
   static constexpr int NP = W % 4;
@@ -237,20 +239,20 @@ struct FlatPrefetch {
           x.z = fmaf(e2, m2, a2);
           x.w = fmaf(t.w, m3, a3);
         }
-        *reinterpret_cast<f32x4*>(lane_tile + 1024 * j) = x;
+        *reinterpret_cast<f32x4*>(lane_tile + 1024 * j + (int)((meta[j] >> 12) & 255) * (CSTRIDE - PC * 4)) = x;
       }
     }
   }
 };
 
 // channel slots when they are at least 80 % occupied, the flat list otherwise
-template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2, int CSTRIDE = ROWS * WP>
 struct PickPrefetch {
   static constexpr int PC = ROWS * (WP / 4);
   static constexpr int SPC = (PC + 255) / 256;
   static constexpr bool kChannelSlots = PC * 10 >= SPC * 256 * 8;
-  using type = typename std::conditional<kChannelSlots, BandPrefetch<CK, ROWS, W, WP, H, MINPAD>,
-                                         FlatPrefetch<CK, ROWS, W, WP, H, MINPAD>>::type;
+  using type = typename std::conditional<kChannelSlots, BandPrefetch<CK, ROWS, W, WP, H, MINPAD, CSTRIDE>,
+                                         FlatPrefetch<CK, ROWS, W, WP, H, MINPAD, CSTRIDE>>::type;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -268,7 +270,7 @@ struct DownCfg {
   static constexpr int ROWS = 2 * (R - 1) + KS;
   static constexpr int WP = (W + 2 + 3) / 4 * 4;
   static constexpr int PLANE = ROWS * WP;
-  static constexpr int CSP = MT * 16 + 1;
+  static constexpr int CSP = MT * 16 + 1;  // odd: conflict-free transposing writes, <= 2-way conflicts on the A reads
   static constexpr int KC = CK * KS * 4;  // k rows per chunk
   static constexpr int PS = 64 * NT + 4;  // out tile row stride
   static constexpr int EM = MT > 2 ? 2 : MT;
@@ -556,7 +558,9 @@ struct WgradCfg {
   static constexpr int ROWS_B = 2 * (R - 1) + KS;
   static constexpr int WP = (W + 2 + 3) / 4 * 4;
   static constexpr int WsP = (Ws + 3) / 4 * 4;
-  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP;
+  // channel stride of the small tile: the A operand is read at  cs*PLANE_S + pixel  by 16 channels x 4 pixels per wave,
+  // stride % 64 == 4 spreads them over all 64 LDS banks (R*WsP itself is 0 or 32 mod 64: 8- to 16-way conflicts)
+  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = (R * WsP - 4 + 63) / 64 * 64 + 4;
   static constexpr int SPR = WsP / 4;  // MFMA k-steps per output row
   static constexpr int FRONT = 4;
   static constexpr int TILES = CB * PLANE_B + CSL * PLANE_S;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
     for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   typename PickPrefetch<CB, G::ROWS_B, W, WP, H>::type pfb;
-  typename PickPrefetch<CSL, R, Ws, WsP, Hs, 0>::type pfs;
+  typename PickPrefetch<CSL, R, Ws, WsP, Hs, 0, PLANE_S>::type pfs;
   pfb.init(tid);
   pfs.init(tid);
   if (tid < G::FRONT) lds[tid] = 0.f;
