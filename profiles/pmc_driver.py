@@ -35,6 +35,8 @@ def run(kind, layer, B=256, reps=5):
             ops.conv_wgrad(g, big, small, gw, big_scale=sc, big_shift=sh)
         elif kind == 'down':
             ops.conv_down(g, big, w, bias, 1, 0.1, in_scale=sc, in_shift=sh, stats=st, out=out_s)
+        elif kind == 'up':
+            ops.conv_up(g, small, w, None, 0, 0.0, out=big)
         else:
             raise SystemExit(kind)
     torch.cuda.synchronize()
