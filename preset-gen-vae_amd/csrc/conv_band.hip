@@ -546,7 +546,7 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
 // the accumulators in registers over all their (sample, band) units and flush once with float atomics; the tiles of
 // unit i+1 are prefetched into registers while unit i is multiplied.
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
 struct WgradCfg {
   static constexpr int KK = KS * KS;
   static constexpr int NTAP = (KK + 15) / 16;  // N tiles per big channel
@@ -573,7 +573,7 @@ struct WgradCfg {
   static_assert((CB * NTAP) % WN == 0 && (CSL & (CSL - 1)) == 0 && CSL <= CS, "tiling");
 };
 
-template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                                const float* __restrict__ big_scale,
                                                                const float* __restrict__ big_shift,
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
                                                                const float* __restrict__ small_scale,
                                                                const float* __restrict__ small_shift,
                                                                float* __restrict__ gw) {
-  using G = WgradCfg<KS, MT, CSL, CB, WN, RW, W, H>;
+  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
   constexpr int KK = G::KK, NTAP = G::NTAP, NB = G::NB, WK = G::WK, R = G::R, CS = G::CS, Ws = G::Ws, Hs = G::Hs;
   constexpr int WP = G::WP, WsP = G::WsP, PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -594,6 +594,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gn = wave % WN, wk = wave / WN;
   const int units = B * BANDS;
+  // NSPLIT > 1: the big channels are divided among workgroups (workgroup g keeps split g % NSPLIT for all its units),
+  // which divides the register-resident accumulators and the final atomic flush by NSPLIT at the price of reading
+  // the small tensor NSPLIT times
+  const int split = blockIdx.x % NSPLIT, cb0 = split * CB;
+  const int ncb = min(CB, Cb - cb0);  // big channels of this split
 
   // per-lane bases (rows r = wk + WK*rw and steps i are immediates); taps >= KK of the last tap tile read tap 0 and
   // are discarded at the flush
@@ -620,25 +625,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   pfb.init(tid);
   pfs.init(tid);
   if (tid < G::FRONT) lds[tid] = 0.f;
-  stage_affine(aff_b, big_scale, big_shift, Cb, tid);
+  if (ncb > 0) stage_affine(aff_b, big_scale ? big_scale + cb0 : nullptr, big_shift ? big_shift + cb0 : nullptr, ncb, tid);
   stage_affine(aff_s, small_scale, small_shift, Cs, tid);
   auto issue_unit = [&](int u) {
     const int b = u / BANDS, band = u - b * BANDS;
-    pfb.issue(big + (int64_t)b * Cb * (H * W), band * R * 2 - 2, Cb);
+    pfb.issue(big + ((int64_t)b * Cb + cb0) * (H * W), band * R * 2 - 2, ncb);
     pfs.issue(small_in + (int64_t)b * Cs * (Hs * Ws), band * R, Cs);
   };
 
-  int u = blockIdx.x;
+  const int ustep = gridDim.x / NSPLIT;  // the launcher makes the grid a multiple of NSPLIT
+  int u = blockIdx.x / NSPLIT;
   BAND_T0();
   if (u < units) issue_unit(u);
 #pragma unroll 1
-  for (; u < units; u += gridDim.x) {
+  for (; u < units; u += ustep) {
     __syncthreads();  // the previous unit's MFMA reads are complete (and the affine tables are visible)
     BAND_ACC(0);
-    pfb.commit(big_tile, big_scale ? aff_b : nullptr, Cb, 0, Cb, tid);
+    pfb.commit(big_tile, big_scale ? aff_b : nullptr, max(ncb, 1), 0, ncb, tid);
     pfs.commit(small_tile, small_scale ? aff_s : nullptr, Cs, 0, Cs, tid);
     BAND_ACC(1);
-    if (u + (int)gridDim.x < units) issue_unit(u + gridDim.x);
+    if (u + ustep < units) issue_unit(u + ustep);
     BAND_ACC(3);
     __syncthreads();
     BAND_ACC(4);
@@ -699,35 +705,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < WK; ++k) v += red[k * CS * NTT * 16 + e];
-      if (cs < Cs && cb < Cb && tau < KK) atomicAdd(&gw[((int64_t)cs * Cb + cb) * KK + tau], v);
+      if (cs < Cs && cb < ncb && tau < KK) atomicAdd(&gw[((int64_t)cs * Cb + cb0 + cb) * KK + tau], v);
     }
   } else {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const int nt = gn * NB + n;
       const int cb = nt / NTAP, tau = (nt - cb * NTAP) * 16 + (lane & 15);
-      if (cb < Cb && tau < KK) {
+      if (cb < ncb && tau < KK) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int cs = m * 16 + (lane >> 4) * 4 + reg;
-            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb) * KK + tau], acc[m][n][reg]);
+            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb0 + cb) * KK + tau], acc[m][n][reg]);
           }
       }
     }
   }
 }
 
-template <int KS, int MT, int CSL, int CB, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
 int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                       hipStream_t st) {
-  using G = WgradCfg<KS, MT, CSL, CB, WN, RW, W, H>;
+  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
-  if (d->Cb > CB || d->Cs > CSL) return 0;
-  auto kern = conv_wgrad_band_kernel<KS, MT, CSL, CB, WN, RW, W, H>;
+  if (d->Cb > CB * NSPLIT || d->Cs > CSL) return 0;
+  auto kern = conv_wgrad_band_kernel<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
   if (rc) return rc;
@@ -737,8 +743,11 @@ int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big
   }
   const int units = d->B * G::BANDS;
   if (units == 0) return 1;
-  const int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
-  const int grid = min(units, 256 * per_cu);
+  int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
+#ifdef PGV_PHASE_TIMING
+  if (getenv("PGV_WGRAD_PER_CU")) per_cu = atoi(getenv("PGV_WGRAD_PER_CU"));
+#endif
+  const int grid = min(units, 256 * per_cu / NSPLIT) * NSPLIT;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, big_scale, big_shift, small_in,
                      small_scale, small_shift, gw);
   PGV_CHECK_LAUNCH("conv_wgrad_band");
@@ -1045,11 +1054,11 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
   if (d->stride != 2 || d->pad != 2 || d->kh != d->kw) return 0;
 #define PGV_WGB(...) \
   return launch_wgrad_band<__VA_ARGS__>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st)
-  if (d->kh == 5 && d->Hb == 257 && d->Wb == 347) PGV_WGB(5, 1, 8, 1, 1, 1, 347, 257);
+  if (d->kh == 5 && d->Hb == 257 && d->Wb == 347) PGV_WGB(5, 1, 8, 1, 1, 1, 1, 347, 257);
   if (d->kh != 4) return 0;
-  if (d->Hb == 129 && d->Wb == 174) PGV_WGB(4, 1, 16, 8, 1, 1, 174, 129);
-  if (d->Hb == 65 && d->Wb == 88) PGV_WGB(4, 2, 32, 16, 2, 1, 88, 65);
-  if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 32, 4, 2, 45, 33);
+  if (d->Hb == 129 && d->Wb == 174) PGV_WGB(4, 1, 16, 8, 1, 1, 1, 174, 129);
+  if (d->Hb == 65 && d->Wb == 88) PGV_WGB(4, 2, 32, 16, 1, 2, 1, 88, 65);
+  if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 16, 2, 4, 2, 45, 33);
 #undef PGV_WGB
   return 0;
 }
