@@ -170,6 +170,8 @@ def measure_roofline(ae, B, device):
                            nb + ns + nw),
         }
         for kname, (fn, bytes_) in launches.items():
+            if name == 'enc1' and kname == 'conv_up':
+                continue  # the first block needs no input gradient: this launch is not part of the train step
             ms = time_kernel(fn, iters=5)
             t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (F32_MATRIX_PEAK_TFLOPS * 1e12)
             rec = {'layer': name, 'kernel': kname, 'ms': ms, 'flops': flops, 'bytes': bytes_,
