@@ -68,11 +68,19 @@ class VAETrainStep:
             return self._step_body(x, v_in, inject)
         if self._graph is None:
             self._capture(x, v_in)
-        self._static_x.copy_(x, non_blocking=True)
-        if v_in is not None:
+        # a loader that writes its minibatch straight into ``static_input`` (and passes that tensor) skips the copy
+        if x.data_ptr() != self._static_x.data_ptr():
+            self._static_x.copy_(x, non_blocking=True)
+        if v_in is not None and v_in.data_ptr() != self._static_v.data_ptr():
             self._static_v.copy_(v_in, non_blocking=True)
         self._graph.replay()
         return self._out
+
+    @property
+    def static_input(self):
+        """The captured graph's input buffer (None before the first graph step): fill it in place - e.g. as the
+        output of ``MelSpectrogram.batch`` or the destination of the host-to-device copy - and pass it to ``step``."""
+        return self._static_x
 
     def _capture(self, x, v_in):
         self._static_x = x.clone()
