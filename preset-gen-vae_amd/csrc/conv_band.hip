@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
   typename PickPrefetch<CK, G::ROWS, W, WP, H>::type pf;
   pf.init(tid);
   if (tid < G::FRONT) lds[tid] = 0.f;
+  for (int i = tid; i < 4 * MT * 16 * 2; i += 256) st_tile[i] = 0.f;
   stage_affine(aff, in_scale, in_shift, Cb, tid);  // visible after the first barrier of the item loop
   const pgv_act_params actp = pgv_act_setup(act, slope);
 
@@ -361,6 +362,12 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
     if constexpr (!WRES) load_weights(ch * CK, wv);
   };
 
+  constexpr bool kRegStats = MT <= 2;
+  float st_s[kRegStats ? MT : 1][4], st_q[kRegStats ? MT : 1][4];
+#pragma unroll
+  for (int m = 0; m < (kRegStats ? MT : 1); ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) st_s[m][reg] = st_q[m][reg] = 0.f;
   int u = blockIdx.x;
   if (u >= units) return;
   BAND_T0();
@@ -468,13 +475,21 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
             }
           }
           if (stats) {
+            if constexpr (kRegStats) {  // per-lane partial sums live in registers over all units of the workgroup
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const float ss = group16_sum(s[reg]), qq = group16_sum(q[reg]);
-              if ((lane & 15) == 0) {
-                const int cl = m * 16 + (lane >> 4) * 4 + reg;
-                st_tile[(wave * MT * 16 + cl) * 2 + 0] = ss;
-                st_tile[(wave * MT * 16 + cl) * 2 + 1] = qq;
+              for (int reg = 0; reg < 4; ++reg) {
+                st_s[m][reg] += s[reg];
+                st_q[m][reg] += q[reg];
+              }
+            } else {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const float ss = group16_sum(s[reg]), qq = group16_sum(q[reg]);
+                if ((lane & 15) == 0) {
+                  const int cl = m * 16 + (lane >> 4) * 4 + reg;
+                  st_tile[(wave * MT * 16 + cl) * 2 + 0] += ss;  // slot owned by this lane: no atomics needed
+                  st_tile[(wave * MT * 16 + cl) * 2 + 1] += qq;
+                }
               }
             }
           }
@@ -489,21 +504,39 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
           store_rows_contig(out_tile, PS, out + ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws,
                             (int64_t)Hs * Ws, nchn, Pb, tid);
       }
-      if (stats && tid < MT * 16 && tid < Cs) {
-        double ss = 0.0, qq = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          ss += (double)st_tile[(wv * MT * 16 + tid) * 2 + 0];
-          qq += (double)st_tile[(wv * MT * 16 + tid) * 2 + 1];
-        }
-        atomicAdd(&stats[tid], ss);
-        atomicAdd(&stats[Cs + tid], qq);
-      }
       BAND_ACC(6);
     }
     u = nu;
     ch = nch;
     if (u >= units) break;
+  }
+  // BatchNorm statistics: the per-wave partial sums of all units of this workgroup sit in st_tile; one float64 atomic
+  // per channel per WORKGROUP (per unit they serialise on 2*Cs addresses: +24 us on the 129x174 layer)
+  if (stats) {
+    if constexpr (kRegStats) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float ss = group16_sum(st_s[m][reg]), qq = group16_sum(st_q[m][reg]);
+          if ((lane & 15) == 0) {
+            const int cl = m * 16 + (lane >> 4) * 4 + reg;
+            st_tile[(wave * MT * 16 + cl) * 2 + 0] = ss;
+            st_tile[(wave * MT * 16 + cl) * 2 + 1] = qq;
+          }
+        }
+    }
+    __syncthreads();
+    if (tid < MT * 16 && tid < Cs) {
+      double ss = 0.0, qq = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        ss += (double)st_tile[(wv * MT * 16 + tid) * 2 + 0];
+        qq += (double)st_tile[(wv * MT * 16 + tid) * 2 + 1];
+      }
+      atomicAdd(&stats[tid], ss);
+      atomicAdd(&stats[Cs + tid], qq);
+    }
   }
   BAND_FLUSH();
 }
@@ -817,6 +850,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
 
   typename PickPrefetch<CK, G::ROWS, Ws, WsP, Hs, 1>::type pf;
   pf.init(tid);
+  for (int i = tid; i < 4 * MT * 4 * 2; i += 256) st_tile[i] = 0.f;
   stage_affine(aff, in_scale, in_shift, Cs, tid);  // visible after the first barrier of the item loop
   const pgv_act_params actp = pgv_act_setup(act, slope);
 
@@ -859,6 +893,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
     if constexpr (!WRES) load_weights(ch * CK, wv);
   };
 
+  constexpr bool kRegStats = MT <= 4;
+  float st_s[kRegStats ? MT : 1], st_q[kRegStats ? MT : 1];
+#pragma unroll
+  for (int m = 0; m < (kRegStats ? MT : 1); ++m) st_s[m] = st_q[m] = 0.f;
   int u = blockIdx.x;
   if (u >= units) return;
   BAND_T0();
@@ -975,10 +1013,15 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
             }
           }
           if (stats) {
-            const float ss = group16_sum(s), qq = group16_sum(q);
-            if ((lane & 15) == 0) {
-              st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 0] = ss;
-              st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 1] = qq;
+            if constexpr (kRegStats) {  // per-lane partial sums live in registers over all units of the workgroup
+              st_s[m] += s;
+              st_q[m] += q;
+            } else {
+              const float ss = group16_sum(s), qq = group16_sum(q);
+              if ((lane & 15) == 0) {
+                st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 0] += ss;  // slot owned by this lane
+                st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 1] += qq;
+              }
             }
           }
         }
@@ -988,21 +1031,34 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
           store_rows_contig(out_tile, OPS, out + (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W, (int64_t)H * W, nchn,
                             rows_o * W, tid);
       }
-      if (stats && tid < MT * 4 && tid < Cb) {
-        double ss = 0.0, qq = 0.0;
-#pragma unroll
-        for (int wv2 = 0; wv2 < 4; ++wv2) {
-          ss += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 0];
-          qq += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 1];
-        }
-        atomicAdd(&stats[tid], ss);
-        atomicAdd(&stats[Cb + tid], qq);
-      }
       BAND_ACC(6);
     }
     u = nu;
     ch = nch;
     if (u >= units) break;
+  }
+  if (stats) {  // one float64 atomic per channel per workgroup (see conv_down_band_kernel)
+    if constexpr (kRegStats) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float ss = group16_sum(st_s[m]), qq = group16_sum(st_q[m]);
+        if ((lane & 15) == 0) {
+          st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 0] = ss;
+          st_tile[(wave * MT * 4 + m * 4 + (lane >> 4)) * 2 + 1] = qq;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < MT * 4 && tid < Cb) {
+      double ss = 0.0, qq = 0.0;
+#pragma unroll
+      for (int wv2 = 0; wv2 < 4; ++wv2) {
+        ss += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 0];
+        qq += (double)st_tile[(wv2 * MT * 4 + tid) * 2 + 1];
+      }
+      atomicAdd(&stats[tid], ss);
+      atomicAdd(&stats[Cb + tid], qq);
+    }
   }
   BAND_FLUSH();
 }
