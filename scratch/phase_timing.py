@@ -79,3 +79,10 @@ for which, (Cb, Cs, k, Hb, Wb) in {'L2': (8, 16, 4, 129, 174), 'L3': (16, 32, 4,
     sc = torch.ones(Cb, device='cuda'); sh = torch.zeros(Cb, device='cuda')
     run(f'down {which}', lambda: ops.conv_down(g, big, w, bias, 1, 0.1, in_scale=sc, in_shift=sh, stats=st, out=out), 1 << 16)
     run(f'wgrad {which}', lambda: ops.conv_wgrad(g, big, small, gw, big_scale=sc, big_shift=sh), 512)
+
+print("---- up kernels (dgrad form)")
+for which, (Cb, Cs, k, Hb, Wb) in {'L2': (8, 16, 4, 129, 174), 'L3': (16, 32, 4, 65, 88), 'L4': (32, 64, 4, 33, 45)}.items():
+    g = ops.ConvGeom(Cb, Cs, k, 2, 2, Hb, Wb)
+    w = torch.randn(Cs, Cb, k, k, device='cuda') * 0.05
+    small = torch.randn(B, Cs, g.Hs, g.Ws, device='cuda'); outb = torch.empty(B, Cb, Hb, Wb, device='cuda')
+    run(f'up {which}', lambda: ops.conv_up(g, small, w, None, 0, 0.0, out=outb), 512)
