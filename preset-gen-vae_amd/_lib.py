@@ -73,6 +73,10 @@ def load():
         raise RuntimeError(
             f"HIP extension not built: {LIB_PATH} is missing. Run `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    # torch first: libpgv_hip.so depends on libamdhip64 and must bind to the HIP runtime torch ships and initialises
+    # (streams and device pointers are shared with it).  Loaded before torch, the dependency would resolve to a second
+    # runtime (/opt/rocm) that never sees the device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

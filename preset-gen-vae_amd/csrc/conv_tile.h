@@ -170,8 +170,9 @@ __device__ __forceinline__ void stage_affine(float* __restrict__ aff, const floa
 template <typename K>
 int raise_lds_limit(K kern, bool* done, const char* who) {
   if (!*done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
-      pgv_set_error("%s: cannot raise the dynamic LDS limit", who);
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    if (e != hipSuccess) {
+      pgv_set_error("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
       return PGV_E_LAUNCH;
     }
     *done = true;
