@@ -76,6 +76,24 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scal
                 const float* w, const float* bias, int act, float slope, float* big, double* stats,
                 void* stream);
 
+/* Optional fusion for input-gradient calls: while the output tensor (a gradient g of the activations `a` saved by the
+ * next-lower block) is written, also accumulate that block's BatchNorm-backward projections
+ *   red[c] += sum g[:,c],   red[C+c] += sum g[:,c] * (a[:,c] - mean[c]) * rstd[c]
+ * (what pgv_bn_bwd_reduce would compute in a separate pass over g and a).  red is accumulated into: the caller clears
+ * it.  The band kernels do this in their epilogue, every other kernel family runs the reduce pass after the product. */
+typedef struct pgv_bn_fuse {
+  const float* a;    /* same shape as the output tensor */
+  const float* mean; /* [C] */
+  const float* rstd; /* [C] */
+  double* red;       /* [2C] */
+} pgv_bn_fuse;
+int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                        const float* w, const float* bias, int act, float slope, float* small, double* stats,
+                        const pgv_bn_fuse* fuse, void* stream);
+int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small, const float* in_scale, const float* in_shift,
+                      const float* w, const float* bias, int act, float slope, float* big, double* stats,
+                      const pgv_bn_fuse* fuse, void* stream);
+
 /* gw[cs][cb][kh][kw] = sum_{b,oh,ow} small'[b,cs,oh,ow] * big'[b,cb,oh*s-p+kh,ow*s-p+kw]
  * (autograd of both layer kinds).  Either operand may carry a folded BN affine.
  * gw is overwritten.  workspace: pgv_conv_wgrad_workspace() bytes. */

@@ -24,6 +24,14 @@ class ConvDesc(Structure):
 _P = c_void_p  # device pointers travel as integers
 _DESC = POINTER(ConvDesc)
 
+
+class BnFuse(Structure):
+    """Mirror of ``pgv_bn_fuse``: BatchNorm-backward projections fused into an input-gradient call."""
+    _fields_ = [("a", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("red", c_void_p)]
+
+
+_FUSE = POINTER(BnFuse)
+
 # name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
     "pgv_abi_version": (c_int, []),
@@ -31,6 +39,8 @@ SIGNATURES = {
     "pgv_set_kernel_policy": (c_int, [c_int]),
     "pgv_conv_down": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_up": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_down_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
+    "pgv_conv_up_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),

@@ -242,6 +242,16 @@ int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipSt
   return PGV_OK;
 }
 
+int pgv_bn_bwd_reduce_impl(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
+                           double* red, hipStream_t st) {
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, mean, rstd, B, C, HW, s.per,
+                     red);
+  PGV_CHECK_LAUNCH("bn_bwd_reduce");
+  return PGV_OK;
+}
+
 extern "C" {
 
 int pgv_bn_stats(const float* a, int B, int C, int HW, double* stats, void* stream) {

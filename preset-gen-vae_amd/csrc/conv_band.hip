@@ -284,13 +284,14 @@ struct DownCfg {
   static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
 };
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H>
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift,
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ bias, int act, float slope,
-                                                              float* __restrict__ out, double* __restrict__ stats) {
+                                                              float* __restrict__ out, double* __restrict__ stats,
+                                                              pgv_bn_fuse fuse) {
   using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
   constexpr int KS = 4, Ws = G::Ws, Hs = G::Hs, WP = G::WP, PLANE = G::PLANE, CSP = G::CSP, KC = G::KC;
   constexpr int PS = G::PS, EM = G::EM, BANDS = G::BANDS;
@@ -496,13 +497,16 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
         }
         __syncthreads();
         const int nchn = min(Cs - m0 * 16, EM * 16);
-#if defined(PGV_EXP) && PGV_EXP == 5
-        if (nchn > 0 && act == 77)
-#else
-        if (nchn > 0)
-#endif
-          store_rows_contig(out_tile, PS, out + ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws,
-                            (int64_t)Hs * Ws, nchn, Pb, tid);
+        if (nchn > 0) {
+          const int64_t off = ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws;
+          if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
+            store_rows_bnred<EM * 16, (16 * NT * EM * 16 + 255) / 256>(out_tile, PS, out + off, fuse.a + off,
+                                                                      (int64_t)Hs * Ws, nchn, Pb, tid,
+                                                                      fuse.mean + m0 * 16, fuse.rstd + m0 * 16,
+                                                                      st_tile + 2 * m0 * 16);
+          else
+            store_rows_contig(out_tile, PS, out + off, (int64_t)Hs * Ws, nchn, Pb, tid);
+        }
       }
       BAND_ACC(6);
     }
@@ -538,21 +542,36 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
       atomicAdd(&stats[Cs + tid], qq);
     }
   }
+  if constexpr (FUSE) {  // (never together with stats: the launcher falls back to a separate reduce pass then)
+    __syncthreads();
+    if (tid < MT * 16 && tid < Cs) {
+      atomicAdd(&fuse.red[tid], (double)st_tile[2 * tid]);
+      atomicAdd(&fuse.red[Cs + tid], (double)st_tile[2 * tid + 1]);
+    }
+  }
   BAND_FLUSH();
 }
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H>
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool CANFUSE>
 int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                     hipStream_t st) {
+                     const pgv_bn_fuse* fuse, hipStream_t st) {
   using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
   if (d->Cb > NCH * CK) return 0;
-  auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H>;
+  // The fused-epilogue variant keeps the saved-activation loads in registers: only instantiated where it pays
+  // (CANFUSE), and only launched when asked for, so the plain kernel's register allocation is unaffected.
+  if (fuse && !CANFUSE) return 0;
+  auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_band");
   if (rc) return rc;
+  auto kernf = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, CANFUSE>;
+  if (CANFUSE) {
+    static bool attr_done_f = false;
+    if ((rc = raise_lds_limit(kernf, &attr_done_f, "conv_down_band"))) return rc;
+  }
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_band: memset failed");
     return PGV_E_LAUNCH;
@@ -563,8 +582,9 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   if (getenv("PGV_WG_PER_CU")) per_cu = atoi(getenv("PGV_WG_PER_CU"));
 #endif
   const int grid = min(units, 256 * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, in_scale, in_shift, w, bias, act,
-                     slope, out, stats);
+  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(fuse ? kernf : kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, in_scale, in_shift,
+                     w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_down_band");
   return 1;
 }
@@ -816,13 +836,14 @@ struct UpCfg {
   static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
 };
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H>
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int Cs, const float* __restrict__ small_in,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias, int act, float slope,
-                                                            float* __restrict__ out, double* __restrict__ stats) {
+                                                            float* __restrict__ out, double* __restrict__ stats,
+                                                            pgv_bn_fuse fuse) {
   using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, WsP = G::WsP, PLANE = G::PLANE, MSP = G::MSP;
   constexpr int KC = G::KC, OPS = G::OPS, BANDS = G::BANDS;
@@ -1027,9 +1048,16 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
         }
         __syncthreads();
         const int nchn = min(Cb - m0 * 4, EM * 4);
-        if (nchn > 0)
-          store_rows_contig(out_tile, OPS, out + (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W, (int64_t)H * W, nchn,
-                            rows_o * W, tid);
+        if (nchn > 0) {
+          const int64_t off = (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W;
+          if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
+            store_rows_bnred<EM * 4, (OPS / 4 * EM * 4 + 255) / 256>(out_tile, OPS, out + off, fuse.a + off,
+                                                                    (int64_t)H * W, nchn, rows_o * W, tid,
+                                                                    fuse.mean + m0 * 4, fuse.rstd + m0 * 4,
+                                                                    st_tile + 2 * m0 * 4);
+          else
+            store_rows_contig(out_tile, OPS, out + off, (int64_t)H * W, nchn, rows_o * W, tid);
+        }
       }
       BAND_ACC(6);
     }
@@ -1060,21 +1088,34 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
       atomicAdd(&stats[Cb + tid], qq);
     }
   }
+  if constexpr (FUSE) {
+    __syncthreads();
+    if (tid < MT * 4 && tid < Cb) {
+      atomicAdd(&fuse.red[tid], (double)st_tile[2 * tid]);
+      atomicAdd(&fuse.red[Cb + tid], (double)st_tile[2 * tid + 1]);
+    }
+  }
   BAND_FLUSH();
 }
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H>
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H, bool CANFUSE>
 int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                   hipStream_t st) {
+                   const pgv_bn_fuse* fuse, hipStream_t st) {
   using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
   if (d->Cs > NCH * CK || d->Cb > MT * 4) return 0;
-  auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H>;
+  if (fuse && !CANFUSE) return 0;
+  auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_up_band");
   if (rc) return rc;
+  auto kernf = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, CANFUSE>;
+  if (CANFUSE) {
+    static bool attr_done_f = false;
+    if ((rc = raise_lds_limit(kernf, &attr_done_f, "conv_up_band"))) return rc;
+  }
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_band: memset failed");
     return PGV_E_LAUNCH;
@@ -1082,8 +1123,9 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   const int units = d->B * G::BANDS;
   int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
   const int grid = min(units, 256 * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in, in_scale, in_shift, w, bias,
-                     act, slope, out, stats);
+  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(fuse ? kernf : kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in, in_scale,
+                     in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_up_band");
   return 1;
 }
@@ -1092,15 +1134,14 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
 
 int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                       hipStream_t st) {
+                       const pgv_bn_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || d->Cb > 64) return 0;
   if (d->Hb == 129 && d->Wb == 174 && d->Cs <= 16)
-    return launch_down_band<1, 6, 8, 1, true, 4, 174, 129>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats,
-                                                  st);
+    return launch_down_band<1, 6, 8, 1, true, 4, 174, 129, true>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88 && d->Cs <= 32)
-    return launch_down_band<2, 3, 8, 2, true, 4, 88, 65>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    return launch_down_band<2, 3, 8, 2, true, 4, 88, 65, true>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 33 && d->Wb == 45 && d->Cs <= 64)
-    return launch_down_band<4, 3, 8, 4, false, 8, 45, 33>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    return launch_down_band<4, 3, 8, 4, false, 8, 45, 33, false>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   return 0;
 }
 
@@ -1121,16 +1162,13 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
 
 int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                     hipStream_t st) {
+                     const pgv_bn_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->Hb == 129 && d->Wb == 174)
-    return launch_up_band<2, 6, 16, 1, true, 2, 4, 174, 129>(d, small_in, in_scale, in_shift, w, bias, act, slope,
-                                                             big_out, stats, st);
+    return launch_up_band<2, 6, 16, 1, true, 2, 4, 174, 129, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)
-    return launch_up_band<4, 3, 16, 2, true, 4, 4, 88, 65>(d, small_in, in_scale, in_shift, w, bias, act, slope,
-                                                           big_out, stats, st);
+    return launch_up_band<4, 3, 16, 2, true, 4, 4, 88, 65, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 33 && d->Wb == 45)
-    return launch_up_band<8, 3, 16, 4, false, 2, 8, 45, 33>(d, small_in, in_scale, in_shift, w, bias, act, slope,
-                                                            big_out, stats, st);
+    return launch_up_band<8, 3, 16, 4, false, 2, 8, 45, 33, false>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   return 0;
 }

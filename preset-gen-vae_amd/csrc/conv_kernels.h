@@ -28,11 +28,11 @@ int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc* d);
 // Shape-specialised band kernels (conv_band.hip): compile-time tile geometry for the reference layer shapes.
 int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                       hipStream_t st);
+                       const pgv_bn_fuse* fuse, hipStream_t st);
 
 int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                     hipStream_t st);
+                     const pgv_bn_fuse* fuse, hipStream_t st);
 int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st);
@@ -60,3 +60,6 @@ int pgv_conv_wgrad_gemm(const pgv_conv_desc* d, const float* big, const float* b
                         hipStream_t st);
 
 int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st);
+// red += projections (no clearing): the fallback of pgv_bn_fuse for kernels without the fused epilogue
+int pgv_bn_bwd_reduce_impl(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
+                           double* red, hipStream_t st);

@@ -158,6 +158,66 @@ __device__ __forceinline__ void store_rows_contig(const float* __restrict__ tile
   }
 }
 
+// store_rows_contig with the BatchNorm-backward projections of the stored band fused in (pgv_bn_fuse): TPC = 256/NCHP
+// lanes own one channel row each, read the saved activation `a` at the offsets they store to (all loads issued before
+// the copy loop), and add  sum g  and  sum g*(a-mean)*rstd  of the row into acc[2*c], acc[2*c+1] (LDS, one owner lane
+// per channel: accumulated over all units of a persistent workgroup, flushed once with float64 atomics).
+template <int NCHP, int MAXIT>
+__device__ __forceinline__ void store_rows_bnred(const float* __restrict__ tile, int row_stride, float* __restrict__ dst,
+                                                 const float* __restrict__ a, int64_t cstride, int nch, int len,
+                                                 int tid, const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, float* __restrict__ acc) {
+  constexpr int TPC = 256 / NCHP;
+  static_assert(TPC == 8 || TPC == 16 || TPC == 32, "lanes per channel");
+  const int c = tid / TPC, j = tid - c * TPC;
+  const int Q = len >> 2, rem = len & 3;
+  const bool cok = c < nch;
+  const float mu = cok ? mean[c] : 0.f, rs = cok ? rstd[c] : 0.f;
+  const float* ap = a + c * cstride;
+  float* dp = dst + c * cstride;
+  const float* tp = tile + c * row_stride;
+  f4u av[MAXIT];
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int q = j + i * TPC;
+    av[i] = (cok && q < Q) ? *reinterpret_cast<const f4u*>(ap + 4 * q) : f4u{0.f, 0.f, 0.f, 0.f};
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int q = j + i * TPC;
+    if (cok && q < Q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tp + 4 * q);
+      f4u o;
+      o.x = v.x, o.y = v.y, o.z = v.z, o.w = v.w;
+      *reinterpret_cast<f4u*>(dp + 4 * q) = o;
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 = fmaf(v.x, (av[i].x - mu) * rs, s2);
+      s2 = fmaf(v.y, (av[i].y - mu) * rs, s2);
+      s2 = fmaf(v.z, (av[i].z - mu) * rs, s2);
+      s2 = fmaf(v.w, (av[i].w - mu) * rs, s2);
+    }
+  }
+  if (rem && cok && j == 0) {
+    for (int i = 0; i < rem; ++i) {
+      const float v = tp[4 * Q + i];
+      dp[4 * Q + i] = v;
+      s1 += v;
+      s2 = fmaf(v, (ap[4 * Q + i] - mu) * rs, s2);
+    }
+  }
+  // sum over the TPC consecutive lanes of the channel
+  s1 += dpp_mov<0xB1>(s1), s2 += dpp_mov<0xB1>(s2);
+  s1 += dpp_mov<0x4E>(s1), s2 += dpp_mov<0x4E>(s2);
+  s1 += dpp_mov<0x141>(s1), s2 += dpp_mov<0x141>(s2);  // 8 lanes
+  if (TPC >= 16) s1 += dpp_mov<0x140>(s1), s2 += dpp_mov<0x140>(s2);
+  if (TPC >= 32) s1 += __shfl_xor(s1, 16, 64), s2 += __shfl_xor(s2, 16, 64);
+  if (cok && j == 0) {
+    acc[2 * c] += s1;
+    acc[2 * c + 1] += s2;
+  }
+}
+
 __device__ __forceinline__ void stage_affine(float* __restrict__ aff, const float* __restrict__ scale,
                                              const float* __restrict__ shift, int C, int tid) {
   if (scale)

@@ -178,6 +178,14 @@ class ConvStackFn(torch.autograd.Function):
         n_red = sum(2 * blk.c_out for blk, sv in zip(blocks, saved) if blk.bn is not None and sv[5] is not None)
         arena = torch.zeros(n_red, device=dev, dtype=torch.float64) if n_red else None  # BN-backward projections
         a_off = 0
+        # arena slice of every train-mode BatchNorm block; the projections of block li-1 are accumulated by the
+        # input-gradient kernel of block li while it writes g (pgv_bn_fuse), only the top block needs its own pass
+        reds = [None] * len(blocks)
+        for li in range(len(blocks)):
+            if blocks[li].bn is not None and saved[li][5] is not None:
+                reds[li] = arena[a_off:a_off + 2 * blocks[li].c_out]
+                a_off += 2 * blocks[li].c_out
+        red_done = False
         for li in range(len(blocks) - 1, -1, -1):
             blk = blocks[li]
             inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
@@ -187,9 +195,9 @@ class ConvStackFn(torch.autograd.Function):
             C = blk.c_out
             red = ggamma = gbeta = None
             if has_bn and mean is not None:
-                red = arena[a_off:a_off + 2 * C]
-                a_off += 2 * C
-                ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
+                red = reds[li]
+                if not red_done:
+                    ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
                 ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
                 gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
             # (eval-mode BN: gamma/beta gradients are not produced)
@@ -210,11 +218,17 @@ class ConvStackFn(torch.autograd.Function):
             grads[pi] = gw_ret
             _grad_done(w)
             need_dx = li > 0 or ctx.needs_input_grad[0]
+            red_done = False
             if need_dx:
+                fuse = None
+                if li > 0 and reds[li - 1] is not None:
+                    _, _, _, a_prev, _, mean_prev, rstd_prev, _ = saved[li - 1]
+                    fuse = (a_prev, mean_prev, rstd_prev, reds[li - 1])
+                    red_done = True
                 if blk.up:
-                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0)
+                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bn_fuse=fuse)
                 else:
-                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0)
+                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bn_fuse=fuse)
             else:
                 g_o = None
         return (g_o, None, None) + tuple(grads)

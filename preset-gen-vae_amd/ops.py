@@ -56,7 +56,21 @@ class ConvGeom:
         return d
 
 
-def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False):
+def _fuse_arg(bn_fuse, out):
+    """``bn_fuse`` = (a, mean, rstd, red): accumulate the BatchNorm-backward projections of ``out`` against the saved
+    activation ``a`` into ``red`` (float64, caller-cleared) in the same call (``pgv_bn_fuse``)."""
+    if bn_fuse is None:
+        return None
+    a, mean, rstd, red = bn_fuse
+    _chk(a, mean, rstd)
+    _chk64(red)
+    if a.shape != out.shape:
+        raise ValueError("bn_fuse: saved activation and output shapes differ")
+    return _lib.BnFuse(_p(a), _p(mean), _p(rstd), _p(red))
+
+
+def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
+              bn_fuse=None):
     """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it."""
     B = big.shape[0]
     if out is None:
@@ -64,20 +78,25 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
     _chk(big, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    _lib.check(lib.pgv_conv_down(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
-                                 slope, _p(out), _p(stats), _stream()), "pgv_conv_down")
+    f = _fuse_arg(bn_fuse, out)
+    _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale),
+                                       _p(in_shift), _p(w), _p(bias), act, slope, _p(out), _p(stats),
+                                       None if f is None else ctypes.byref(f), _stream()), "pgv_conv_down")
     return out
 
 
-def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False):
+def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
+            bn_fuse=None):
     B = small.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
     _chk(small, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    _lib.check(lib.pgv_conv_up(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift), _p(w), _p(bias), act,
-                               slope, _p(out), _p(stats), _stream()), "pgv_conv_up")
+    f = _fuse_arg(bn_fuse, out)
+    _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift),
+                                     _p(w), _p(bias), act, slope, _p(out), _p(stats),
+                                     None if f is None else ctypes.byref(f), _stream()), "pgv_conv_up")
     return out
 
 

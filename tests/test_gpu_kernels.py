@@ -168,6 +168,36 @@ def test_conv_prezeroed_outputs_accumulate(ops, case):
     assert rel_l2(gw2, 2 * gw1) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64), (32, 64, 4, 2, 2, 33, 45, 6),
+                                  (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2)])
+def test_conv_bn_fuse_matches_separate_reduce(ops, case):
+    """pgv_bn_fuse: the BatchNorm-backward projections accumulated while an input-gradient kernel writes its output
+    equal those of a separate pgv_bn_bwd_reduce pass over that output (fused band epilogues and the fallback)."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = [dev(t) if torch.is_tensor(t) else t
+                                                                     for t in _conv_inputs(case)]
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    for out_is_big in (True, False):
+        C = Cb if out_is_big else Cs
+        a = (big if out_is_big else small) * 0.7 + 0.1           # "saved activation" of the block below
+        mean = a.mean(dim=(0, 2, 3)).contiguous()
+        rstd = (1.0 / torch.sqrt(a.var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+        red_f = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+        if out_is_big:
+            out = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bn_fuse=(a, mean, rstd, red_f))
+            ref_out = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0)
+        else:
+            out = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bn_fuse=(a, mean, rstd, red_f))
+            ref_out = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0)
+        assert torch.equal(out, ref_out)
+        red_s = torch.empty(2 * C, device='cuda', dtype=torch.float64)
+        ops.bn_bwd_reduce(ref_out, a, mean, rstd, red_s)
+        # the fused path adds in float32 inside a workgroup (<= ~12k terms per slot) and in float64 across workgroups:
+        # error bound relative to the sum of |terms| (these synthetic sums cancel to ~1e-6 of it)
+        l1 = ref_out.abs().sum(dim=(0, 2, 3)).max().item() * 4.0      # |a_hat| <= ~4
+        assert (red_f - red_s).abs().max().item() <= 1e-6 * l1, (out_is_big, (red_f - red_s).abs().max().item(), l1)
+
+
 def test_conv_desc_validation(ops):
     from preset_gen_vae_amd import _lib
     geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
@@ -178,7 +208,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 2
+    assert _lib.load().pgv_abi_version() == 3
 
 
 def test_empty_batch(ops):
