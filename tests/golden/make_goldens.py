@@ -344,7 +344,70 @@ def run_regression_case(out_dir):
     print('regression mse', loss.item(), '->', path, os.path.getsize(path) // 1024, 'KiB')
 
 
+
+def run_dataset_seam_case(out_dir):
+    """the reference's own PresetDataset.__getitem__ / denormalize_spectrogram (data/abstractbasedataset.py
+    :101-145, :340-346) driven through a fixture subclass that serves synthetic waves and parameter vectors from memory
+    (linear spectrogram: librosa, needed for the mel variant, is not installed)."""
+    from data import abstractbasedataset as ref_ds
+
+    n_presets, notes, n_samples, L = 3, ((60, 85), (72, 100)), 4096, 5
+    waves = np.stack([np.stack([synth_wave(n_samples, idx=10 * p + j) for j in range(len(notes))])
+                      for p in range(n_presets)])
+    params = synth_vec((n_presets, L), 0.733, 0.21).numpy() * 0.5 + 0.5
+    uids = np.array([1007, 23, 501])
+
+    class _Params:
+        def __init__(self, row):
+            self.row = row
+
+        def get_learnable(self):
+            return torch.tensor(self.row).unsqueeze(0)
+
+    class _Fixture(ref_ds.PresetDataset):
+        synth_name = 'fixture'
+        total_nb_presets = n_presets
+        total_nb_params = L
+
+        def get_full_preset_params(self, preset_UID):
+            return _Params(params[int(np.where(uids == preset_UID)[0][0])])
+
+        def _render_audio(self, preset_params, midi_note, midi_velocity):
+            raise NotImplementedError
+
+        def get_wav_file(self, preset_UID, midi_note, midi_velocity):
+            pi = int(np.where(uids == preset_UID)[0][0])
+            ni = [n[0] for n in notes].index(midi_note)
+            return waves[pi, ni], 22050
+
+    out = {'in/waves': waves, 'in/params': params, 'in/uids': uids, 'in/midi_notes': np.array(notes)}
+    stats = {'min': -120.0, 'max': -2.5, 'mean': -71.25, 'std': 23.5}
+    for tag, stacked, norm in (('flat_minmax', False, 'min_max'), ('stacked_minmax', True, 'min_max'),
+                               ('flat_meanstd', False, 'mean_std'), ('flat_none', False, None)):
+        ds = _Fixture((3.0, 1.0), 1024, 256, midi_notes=notes, multichannel_stacked_spectrograms=stacked, n_mel_bins=-1,
+                      spectrogram_min_dB=-120.0, spectrogram_normalization=norm)
+        ds.valid_preset_UIDs = uids
+        ds.spec_stats = stats
+        out[f'{tag}/len'] = np.array(len(ds))
+        for i in range(len(ds)):
+            spec, par, info, labels = ds[i]
+            out[f'{tag}/{i}/spec'] = spec.numpy()
+            out[f'{tag}/{i}/params'] = par.numpy()
+            out[f'{tag}/{i}/info'] = info.numpy()
+            out[f'{tag}/{i}/labels'] = labels.numpy()
+        if norm is not None:
+            out[f'{tag}/denorm0'] = ds.denormalize_spectrogram(torch.tensor(out[f'{tag}/0/spec'])).numpy()
+    for k, v in stats.items():
+        out['in/stats_' + k] = np.array(v)
+    path = os.path.join(out_dir, 'dataset_seam.npz')
+    np.savez_compressed(path, **out)
+    print('dataset seam ->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'dataset_seam':
+        run_dataset_seam_case(HERE)
+        sys.exit(0)
     run_regression_case(HERE)
     run_layer_cases(HERE)
     run_stft_cases(HERE)

@@ -93,3 +93,51 @@ def test_frontend_feeds_encoder_shape():
     out = mel.batch(torch.zeros(3, 88576, device='cuda'))
     assert out.shape == (3, 1, 257, 347)
     assert (out + 120.0).abs().max().item() < 1e-4   # silence sits on the floor
+
+
+def test_dataset_seam_f1_matches_oracle(tmp_path):
+    """the batched, device-side dataset seam (item tuple contract, min-max / mean-std normalisation,
+    denormalisation, statistics pass) against oracle/data_oracle.py (pinned by the reference's PresetDataset golden)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import json
+    from oracle import data_oracle as do
+    from preset_gen_vae_amd.data import BatchedPresetSpectrograms
+    n_presets, notes, n_samples, L = 5, ((60, 85), (72, 100)), 88576 // 4, 7
+    waves = np.stack([np.stack([ao.synth_fm_wave(n_samples, idx=10 * p + j) for j in range(len(notes))])
+                      for p in range(n_presets)])
+    params = np.random.default_rng(0).random((n_presets, L)).astype(np.float32)
+    uids = np.array([1007, 23, 501, 77, 4242])
+    mel = lambda x: ao.mel_spectrogram_db(x)                                  # noqa: E731
+    ref_specs = [mel(waves[p, j]) for p in range(n_presets) for j in range(len(notes))]
+    ref_stats = do.spectrogram_stats(ref_specs)
+    for stacked, mode in ((False, 'min_max'), (True, 'min_max'), (False, 'mean_std'), (False, None)):
+        ds = BatchedPresetSpectrograms(waves, params, uids, midi_notes=notes, spectrogram_normalization=mode,
+                                       multichannel_stacked_spectrograms=stacked)
+        assert len(ds) == do.dataset_len(n_presets, len(notes), stacked)
+        stats, full = ds.compute_and_store_spectrograms_stats(json_path=tmp_path / 'stats.json', batch_size=4)
+        assert json.load(open(tmp_path / 'stats.json')).keys() == {'min', 'max', 'mean', 'std'}
+        assert len(full['min']) == n_presets * len(notes)
+        # float32 front-end vs float64 oracle: dB values agree to ~1e-3 dB above the floor
+        assert abs(stats['min'] - ref_stats['min']) < 1e-3 and abs(stats['max'] - ref_stats['max']) < 5e-3
+        assert abs(stats['mean'] - ref_stats['mean']) < 2e-2 and abs(stats['std'] - ref_stats['std']) < 2e-2
+        ds.set_spec_stats(ref_stats)
+        idx = list(range(len(ds)))[::-1]
+        spec, par, info, labels = ds.get_batch(idx)
+        assert spec.is_cuda and spec.shape[:2] == (len(idx), len(notes) if stacked else 1)
+        assert info.dtype == torch.int32 and info.shape == (len(idx), 3)
+        assert labels.dtype == torch.int8 and labels.shape == (len(idx), 1) and bool((labels == 1).all())
+        for b, i in enumerate(idx):
+            r_spec, r_par, r_info, _ = do.get_item(i, waves, params, uids, notes, ref_stats, mode, stacked, mel)
+            assert np.array_equal(info[b].numpy(), r_info)
+            assert np.array_equal(par[b].numpy(), r_par)
+            got_db = do.denormalize_spectrogram(spec[b].double().cpu().numpy(), ref_stats, mode)
+            ref_db = do.denormalize_spectrogram(r_spec, ref_stats, mode)
+            strong = ref_db > -80.0
+            assert np.abs(got_db - ref_db)[strong].max() < 2e-2
+            assert np.abs(got_db - ref_db).max() < 1.0
+        if mode is not None:
+            back = ds.denormalize_spectrogram(spec)
+            assert torch.allclose(ds.normalize_spectrogram(back), spec, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        BatchedPresetSpectrograms(waves, params, uids, midi_notes=notes).get_batch([0])

@@ -172,3 +172,35 @@ def test_regression_matches_reference():
     assert rel_l2(z.grad, torch.tensor(g['out/g_z'])) < 1e-10
     for k, v in nb.items():
         assert rel_l2(v, torch.tensor(g['post_full/' + k])) < 1e-10, k
+
+
+def test_dataset_seam_matches_reference():
+    """item tuples / normalisation / denormalisation of the reference's PresetDataset (fixture subclass,
+    linear spectrogram) reproduced by oracle/data_oracle.py."""
+    from oracle import data_oracle as do
+    g = load_golden('dataset_seam.npz')
+    waves, params, uids = g['in/waves'], g['in/params'], g['in/uids']
+    notes = [tuple(int(v) for v in n) for n in g['in/midi_notes']]
+    stats = {k: float(g['in/stats_' + k]) for k in ('min', 'max', 'mean', 'std')}
+    for tag, stacked, mode in (('flat_minmax', False, 'min_max'), ('stacked_minmax', True, 'min_max'),
+                               ('flat_meanstd', False, 'mean_std'), ('flat_none', False, None)):
+        n = do.dataset_len(len(uids), len(notes), stacked)
+        assert n == int(g[f'{tag}/len'])
+        for i in range(n):
+            spec, par, info, labels = do.get_item(i, waves, params, uids, notes, stats, mode, stacked,
+                                                  do.linear_spectrogram_db)
+            ref = g[f'{tag}/{i}/spec']
+            assert spec.shape == ref.shape
+            # the reference evaluates its STFT in float32 (utils/audio.py:36): above -80 dB it is accurate to << 0.01 dB
+            # (same criterion as test_stft_matches_reference_spectrogram), below that its own noise floor dominates
+            db_ref = do.denormalize_spectrogram(ref.astype(np.float64), stats, mode)
+            strong = db_ref > -80.0
+            db_err = np.abs(do.denormalize_spectrogram(spec, stats, mode) - db_ref)
+            assert strong.mean() > 0.02 and db_err[strong].max() < 2e-2 and db_err.max() < 3.0
+            assert np.array_equal(par, g[f'{tag}/{i}/params'])
+            assert np.array_equal(info, g[f'{tag}/{i}/info']) and info.dtype == np.int32
+            assert np.array_equal(labels, g[f'{tag}/{i}/labels'])
+        if mode is not None:
+            den = do.denormalize_spectrogram(g[f'{tag}/0/spec'], stats, mode)
+            assert np.abs(den - g[f'{tag}/denorm0']).max() < 1e-4      # float32 arithmetic in the reference
+            assert np.abs(do.normalize_spectrogram(den, stats, mode) - g[f'{tag}/0/spec']).max() < 1e-5
