@@ -52,6 +52,9 @@ def _bn_train_or_eval(a, sd, prefix, scope, training, new_buffers):
     running estimate, momentum 0.1; eval = running statistics."""
     gamma, beta = _find(sd, prefix + 'bn.weight', scope), _find(sd, prefix + 'bn.bias', scope)
     rm, rv = _find(sd, prefix + 'bn.running_mean', scope), _find(sd, prefix + 'bn.running_var', scope)
+    if new_buffers is not None and prefix + 'bn.running_mean' in new_buffers:
+        # a stack applied once per spectrogram channel (encoder.py:101-102) updates its running statistics every time
+        rm, rv = new_buffers[prefix + 'bn.running_mean'], new_buffers[prefix + 'bn.running_var']
     dims = [0] + list(range(2, a.dim()))
     shape = [1, -1] + [1] * (a.dim() - 2)
     if training:
@@ -76,31 +79,32 @@ def _leaky(y, name, act_masks):
     return F.leaky_relu(y, LRELU_SLOPE)
 
 
-def conv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_masks=None):
-    """layer.Conv2D (model/layer.py:10-26): Conv2d -> LeakyReLU(0.1) -> BatchNorm2d (BN after the activation)."""
+def conv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_masks=None, tag=''):
+    """layer.Conv2D (model/layer.py:10-26): Conv2d -> LeakyReLU(0.1) -> BatchNorm2d (BN after the activation).
+    ``tag`` distinguishes the taps / activation masks of repeated applications (stacked spectrogram channels)."""
     name, _, _, k, s, p, has_bn = row
     w, b = _find(sd, name + 'conv.weight', scope), _find(sd, name + 'conv.bias', scope)
-    a = _leaky(F.conv2d(x, w, b, stride=s, padding=p), name, act_masks)
+    a = _leaky(F.conv2d(x, w, b, stride=s, padding=p), name + tag, act_masks)
     if taps is not None:
-        taps[name + '_act'] = a
+        taps[name + tag + '_act'] = a
     if has_bn:
         a = _bn_train_or_eval(a, sd, name, scope, training, new_buffers)
     if taps is not None:
-        taps[name] = a
+        taps[name + tag] = a
     return a
 
 
-def tconv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_masks=None):
+def tconv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_masks=None, tag=''):
     """layer.TConv2D (model/layer.py:29-46): ConvTranspose2d(output_padding) -> LeakyReLU(0.1) -> BatchNorm2d."""
     name, _, _, k, s, p, op, has_bn = row
     w, b = _find(sd, name + 'tconv.weight', scope), _find(sd, name + 'tconv.bias', scope)
-    a = _leaky(F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op), name, act_masks)
+    a = _leaky(F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op), name + tag, act_masks)
     if taps is not None:
-        taps[name + '_act'] = a
+        taps[name + tag + '_act'] = a
     if has_bn:
         a = _bn_train_or_eval(a, sd, name, scope, training, new_buffers)
     if taps is not None:
-        taps[name] = a
+        taps[name + tag] = a
     return a
 
 
@@ -108,9 +112,27 @@ def encoder_forward(sd, x, arch, dim_z, training, dropout_mask=None, new_buffers
     """SpectrogramEncoder.forward (model/encoder.py:95-108), single-channel spectrograms.
     ``dropout_mask`` = nn.Dropout keep-mask already scaled by 1/(1-p) (encoder.py:85), ``None`` = no dropout."""
     enc_rows, _, _ = arch_tables(arch)
-    h = x
-    for row in enc_rows:
-        h = conv_block(h, sd, row, 'encoder.', training, new_buffers, taps, act_masks)
+    n_ch = x.shape[1]
+    if n_ch == 1:
+        h = x
+        for row in enc_rows:
+            h = conv_block(h, sd, row, 'encoder.', training, new_buffers, taps, act_masks)
+    else:
+        # stacked spectrograms (encoder.py:50-70, 99-104): the shared per-channel stack once per input channel, channel-
+        # concatenated, then the features mixer - the 1x1 conv alone (deepest_features_mix, 512*C -> 1024) or the 4x4
+        # conv + the 1x1 conv (256*C -> 768 -> 1024, the reference's config default)
+        assert arch == 'speccnn8l1_bn'
+        deepest = _find(sd, 'enc7conv.weight', 'encoder.').shape[1] == 256
+        n_single = len(enc_rows) - (1 if deepest else 2)
+        outs = []
+        for ch in range(n_ch):
+            h = x[:, ch:ch + 1]
+            for row in enc_rows[:n_single]:
+                h = conv_block(h, sd, row, 'encoder.', training, new_buffers, taps, act_masks, tag='' if ch == 0 else f'#{ch}')
+            outs.append(h)
+        h = torch.cat(outs, dim=1)
+        for row in enc_rows[n_single:]:
+            h = conv_block(h, sd, row, 'encoder.', training, new_buffers, taps, act_masks)
     h = h.reshape(x.shape[0], -1)                                      # encoder.py:104
     if training and dropout_mask is not None:
         h = h * dropout_mask.reshape(h.shape)
@@ -135,17 +157,34 @@ def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, 
     if training and dropout_mask is not None:                            # decoder.py:65
         h = h * dropout_mask.reshape(h.shape)
     h = h.view(-1, *cnn_in)                                              # decoder.py:85-86
-    for row in dec_rows:
-        h = tconv_block(h, sd, row, 'decoder.', training, new_buffers, taps, act_masks)
     n_last = len(dec_rows) - (1 if arch == 'speccnn8l1_bn' else 0)      # index of ConvTranspose2d in dec_nn
     w = sd[f'decoder.single_ch_cnn.dec_nn.{n_last}.weight']
     b = sd[f'decoder.single_ch_cnn.dec_nn.{n_last}.bias']
-    y = F.conv_transpose2d(h, w, b, stride=2, padding=2)                 # decoder.py:218
-    if taps is not None:
-        taps['dec8_pre'] = y
-    if act_masks is not None and 'dec8' in act_masks:                    # pinned Hardtanh gate (True = pass-through)
-        return torch.where(act_masks['dec8'], y, y.detach().clamp(-1.0, 1.0))
-    return F.hardtanh(y)                                                 # decoder.py:98,219
+
+    def tail(h, tag):
+        y = F.conv_transpose2d(h, w, b, stride=2, padding=2)             # decoder.py:218
+        if taps is not None:
+            taps['dec8' + tag + '_pre'] = y
+        if act_masks is not None and 'dec8' + tag in act_masks:          # pinned Hardtanh gate (True = pass-through)
+            return torch.where(act_masks['dec8' + tag], y, y.detach().clamp(-1.0, 1.0))
+        return F.hardtanh(y)                                             # decoder.py:98,219
+
+    n_ch = 1
+    if arch == 'speccnn8l1_bn':
+        n_ch = _find(sd, 'dec1tconv.weight', 'decoder.').shape[1] // 512  # un-mixer: 2048 -> C*512 (decoder.py:72-75)
+    if n_ch == 1:
+        for row in dec_rows:
+            h = tconv_block(h, sd, row, 'decoder.', training, new_buffers, taps, act_masks)
+        return tail(h, '')
+    # stacked spectrograms (decoder.py:85-92): un-mix, split along channels, the shared stack once per chunk
+    h = tconv_block(h, sd, dec_rows[0], 'decoder.', training, new_buffers, taps, act_masks)
+    outs = []
+    for ch, chunk in enumerate(torch.split(h, 512, dim=1)):
+        tag = '' if ch == 0 else f'#{ch}'
+        for row in dec_rows[1:]:
+            chunk = tconv_block(chunk, sd, row, 'decoder.', training, new_buffers, taps, act_masks, tag=tag)
+        outs.append(tail(chunk, tag))
+    return torch.cat(outs, dim=1)
 
 
 def reparametrize(z_mu_logvar, eps, training):

@@ -71,8 +71,9 @@ class SpectrogramDecoder(nn.Module):
         self.fc_dropout = fc_dropout
         if architecture not in ('speccnn8l1_bn', 'speccnn4l1_bn'):
             raise NotImplementedError("Only speccnn8l1_bn / speccnn4l1_bn are available")
-        if self.spectrogram_channels != 1:
-            raise NotImplementedError("stacked multi-channel spectrograms are not implemented yet (SURVEY §8 f3)")
+        if self.spectrogram_channels != 1 and architecture != 'speccnn8l1_bn':
+            raise NotImplementedError("stacked multi-channel spectrograms need the speccnn8l1_bn un-mixer "
+                                      "(decoder.py:35-37)")
         if self.spectrogram_input_size != (257, 347):
             raise NotImplementedError("decoder bottleneck is defined for 257x347 spectrograms only (decoder.py:58-67)")
         if architecture == 'speccnn8l1_bn':
@@ -91,6 +92,10 @@ class SpectrogramDecoder(nn.Module):
         single_spec_size[1] = 1
         self.single_ch_cnn = SpectrogramCNN(self.architecture, single_spec_size, append_1x1_conv=False,
                                             force_bigger_network=force_bigger_network)
+        if self.spectrogram_channels > 1:
+            # applied once per spectrogram channel (decoder.py:89-92): gradients are summed by autograd
+            for p_ in self.single_ch_cnn.parameters():
+                p_._pgv_shared = True
 
     def _all_blocks(self):
         blocks = []
@@ -107,4 +112,11 @@ class SpectrogramDecoder(nn.Module):
                 dropout_mask = device_rng(self, mixed.device).dropout_mask(self.fc_dropout, mixed.shape)
             mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
         mixed = mixed.view(-1, self.cnn_input_shape[0], self.cnn_input_shape[1], self.cnn_input_shape[2])
-        return layer.run_stack(mixed, self._all_blocks(), self.training)
+        if self.spectrogram_channels == 1:
+            return layer.run_stack(mixed, self._all_blocks(), self.training)
+        # stacked spectrograms (decoder.py:85-92): un-mix, split along channels, the shared stack once per chunk
+        unmixed = layer.run_stack(mixed, self.features_unmixer_cnn.pgv_blocks(), self.training)
+        single = self.single_ch_cnn.pgv_blocks()
+        outs = [layer.run_stack(chunk.contiguous(), single, self.training)
+                for chunk in torch.split(unmixed, self.last_4x4conv_ch, dim=1)]
+        return torch.cat(outs, dim=1)

@@ -77,27 +77,42 @@ class SpectrogramEncoder(nn.Module):
         if architecture not in available_architectures():
             # the reference asserts the same restriction (encoder.py:53)
             raise NotImplementedError("Architecture '{}' not available".format(architecture))
-        if self.spectrogram_channels != 1:
-            raise NotImplementedError("stacked multi-channel spectrograms are not implemented yet (SURVEY §8 f3)")
-        self.mixer_1x1conv_ch = 2048
+        n_ch = self.spectrogram_channels
+        if n_ch != 1 and architecture != 'speccnn8l1_bn':
+            raise NotImplementedError("stacked multi-channel spectrograms need the speccnn8l1_bn mixer (encoder.py:53)")
+        # 2048 if single-ch, 1024 if multi-channel mixer (encoder.py:46-47)
+        self.mixer_1x1conv_ch = 1024 if n_ch > 1 else 2048
         if architecture == 'speccnn8l1_bn':
             self.single_ch_cnn = SpectrogramCNN(architecture, last_layers_to_remove=(1 if deepest_features_mix else 2))
             self.features_mixer_cnn = nn.Sequential()
             if deepest_features_mix:
-                self.features_mixer_cnn = layer.Conv2D(512, self.mixer_1x1conv_ch, [1, 1], [1, 1], 0, [1, 1],
+                self.features_mixer_cnn = layer.Conv2D(512 * n_ch, self.mixer_1x1conv_ch, [1, 1], [1, 1], 0, [1, 1],
                                                        activation=_lrelu(), name_prefix='enc8', batch_norm=None)
             else:
-                n_4x4_ch = 512 if not force_bigger_network else 1800
+                if not force_bigger_network:
+                    n_4x4_ch = 512 if n_ch == 1 else 768      # encoder.py:62-63
+                else:
+                    n_4x4_ch = 1800
                 self.features_mixer_cnn = nn.Sequential(
-                    layer.Conv2D(256, n_4x4_ch, [4, 4], [2, 2], 2, [1, 1], activation=_lrelu(), name_prefix='enc7'),
+                    layer.Conv2D(256 * n_ch, n_4x4_ch, [4, 4], [2, 2], 2, [1, 1], activation=_lrelu(),
+                                 name_prefix='enc7'),
                     layer.Conv2D(n_4x4_ch, self.mixer_1x1conv_ch, [1, 1], [1, 1], 0, [1, 1], activation=_lrelu(),
                                  name_prefix='enc8', batch_norm=None))
         else:
             self.single_ch_cnn = SpectrogramCNN(architecture)
             self.features_mixer_cnn = nn.Sequential()
+        if n_ch > 1:
+            # the per-channel stack is applied n_ch times per forward (encoder.py:101-102): its parameter gradients are
+            # the SUM over the applications, so they go through autograd's accumulation instead of being written
+            # straight into the flat gradient buffer
+            for p_ in self.single_ch_cnn.parameters():
+                p_._pgv_shared = True
         # CNN output size by shape arithmetic (the reference runs a dummy forward, encoder.py:73-78)
         C, H, W = 1, input_tensor_size[2], input_tensor_size[3]
-        for blk in self._all_blocks():
+        for blk in self.single_ch_cnn.pgv_blocks():
+            g = blk.geom(H, W)
+            C, H, W = blk.c_out, g.Hs, g.Ws
+        for blk in self._mixer_blocks():
             g = blk.geom(H, W)
             C, H, W = blk.c_out, g.Hs, g.Ws
         self.cnn_out_size = torch.Size((1, C, H, W))
@@ -109,18 +124,28 @@ class SpectrogramEncoder(nn.Module):
         # dropout mask source: None -> on-device Philox stream owned by the enclosing VAE (or a local one)
         self._rng = None
 
-    def _all_blocks(self):
-        blocks = self.single_ch_cnn.pgv_blocks()
+    def _mixer_blocks(self):
         mixer = self.features_mixer_cnn
         if isinstance(mixer, layer._ConvBlockBase):
-            blocks += mixer.pgv_blocks()
-        else:
-            for m in mixer:
-                blocks += m.pgv_blocks()
+            return mixer.pgv_blocks()
+        blocks = []
+        for m in mixer:
+            blocks += m.pgv_blocks()
         return blocks
 
+    def _all_blocks(self):
+        """Single-channel input: per-channel stack and mixer run as ONE fused stack (BatchNorm folded across the seam)."""
+        return self.single_ch_cnn.pgv_blocks() + self._mixer_blocks()
+
     def _forward_cnns(self, x_spectrograms):
-        return layer.run_stack(x_spectrograms, self._all_blocks(), self.training)
+        if self.spectrogram_channels == 1:
+            return layer.run_stack(x_spectrograms, self._all_blocks(), self.training)
+        # stacked spectrograms (encoder.py:99-104): the shared per-channel stack once per input channel - each call has
+        # its own BatchNorm batch statistics and running-stat update, as in the reference - then the features mixer
+        single = self.single_ch_cnn.pgv_blocks()
+        outs = [layer.run_stack(x_spectrograms[:, ch:ch + 1, :, :].contiguous(), single, self.training)
+                for ch in range(self.spectrogram_channels)]
+        return layer.run_stack(torch.cat(outs, dim=1), self._mixer_blocks(), self.training)
 
     def forward(self, x_spectrograms, dropout_mask=None):
         """``dropout_mask`` (optional, [B, features], already scaled by 1/(1-p)) injects the Dropout mask for parity

@@ -87,6 +87,8 @@ def _grad_dest(param, accumulated=False):
     whether the destination already holds zeros (PGV_PREZEROED) - true for the flat buffer, which
     ``FusedAdam.zero_grad`` clears with one fill at the start of every step (train.py:208)."""
     view = getattr(param, '_pgv_grad_view', None)
+    if getattr(param, '_pgv_shared', False):
+        view = None     # parameter of a stack applied several times per forward: autograd sums the applications
     if view is not None:
         if param.grad is not view:
             param.grad = view

@@ -142,8 +142,8 @@ class FourLayerDecoder(nn.Module):
         return self.single_ch_cnn.dec_nn(self.mlp(z).view(-1, 64, 17, 23))
 
 
-def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False):
-    size = (B, 1, 257, 347)
+def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False, n_ch=1):
+    size = (B, n_ch, 257, 347)
     if arch == 'speccnn8l1_bn':
         enc = ref_encoder.SpectrogramEncoder(arch, dim_z, size, 0.3, output_bn=output_bn,
                                              deepest_features_mix=deepest_mix)
@@ -153,12 +153,17 @@ def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False):
     return ref_VAE.BasicVAE(enc, dim_z, dec, True, 'Dkl')
 
 
-def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir):
-    vae = build_reference_vae(arch, dim_z, B, output_bn).double()
+def stack_channels(x1, n_ch):
+    """Extra spectrogram channels of the stacked-input cases: shifted, attenuated copies (a different 'MIDI note')."""
+    return torch.cat([x1] + [torch.roll(x1, shifts=37 * c, dims=3) * (1.0 - 0.2 * c) for c in range(1, n_ch)], dim=1)
+
+
+def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir, n_ch=1, deepest_mix=False):
+    vae = build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=deepest_mix, n_ch=n_ch).double()
     template = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
     sd = vo.closed_form_state_dict(template, seed=1234, dtype=torch.float64)
     vae.load_state_dict(sd)
-    x = synth_input(B)
+    x = stack_channels(synth_input(B), n_ch)
     eps = synth_vec((B, dim_z), 1.2345, 0.4) * 1.3
     feat_enc = vae.encoder.mlp[1].in_features
     feat_dec = vae.decoder.mlp[0].out_features
@@ -169,7 +174,9 @@ def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir):
     _FixedNormal.eps = eps
     out = {'meta/arch': np.array(arch), 'meta/dim_z': np.array(dim_z), 'meta/B': np.array(B),
            'meta/output_bn': np.array(output_bn), 'meta/seed': np.array(1234), 'meta/beta': np.array(0.2),
-           'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4),
+           'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4), 'meta/n_ch': np.array(n_ch),
+           'meta/keys': np.array(list(template.keys())),
+           'meta/shapes': np.array([' '.join(str(d) for d in v) for v in template.values()]),
            'in/eps': eps.numpy(), 'in/enc_mask_bits': np.packbits((enc_mask > 0).numpy()),
            'in/dec_mask_bits': np.packbits((dec_mask > 0).numpy()),
            'in/enc_mask_shape': np.array(enc_mask.shape), 'in/dec_mask_shape': np.array(dec_mask.shape)}
@@ -408,9 +415,14 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'dataset_seam':
         run_dataset_seam_case(HERE)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'stacked':
+        run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
+        sys.exit(0)
     run_regression_case(HERE)
     run_layer_cases(HERE)
     run_stft_cases(HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2', HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, True, 'vae8l_b2_outbn', HERE)
     run_vae_case('speccnn4l1_bn', 64, 2, False, 'vae4l_b2', HERE)
+    run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
+    run_dataset_seam_case(HERE)

@@ -112,3 +112,16 @@ def param_shapes(arch, dim_z, output_bn):
     return tpl
 
 
+
+
+def stack_channels(x1, n_ch):
+    """Extra spectrogram channels of the stacked-input cases (same formula as tests/golden/make_goldens.py)."""
+    return torch.cat([x1] + [torch.roll(x1, shifts=37 * c, dims=3) * (1.0 - 0.2 * c) for c in range(1, n_ch)], dim=1)
+
+
+def template_from_meta(g):
+    """State-dict template (reference registration order) stored in a golden file as meta/keys + meta/shapes."""
+    tpl = {}
+    for k, sh in zip(g['meta/keys'], g['meta/shapes']):
+        tpl[str(k)] = tuple(int(v) for v in str(sh).split()) if str(sh) else ()
+    return tpl

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_big, load_golden, param_shapes, rel_l2, synth_input, unpack_mask
+from helpers import (check_big, load_golden, param_shapes, rel_l2, stack_channels, synth_input, template_from_meta,
+                     unpack_mask)
 from oracle import audio_oracle as ao
 from oracle import vae_oracle as vo
 
@@ -30,13 +31,15 @@ def reference_template(g):
     return tpl
 
 
-@pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz"])
+@pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz", "vae8l_b2_c2.npz"])
 def test_train_step_matches_reference(name):
     g = load_golden(name)
     arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
-    tpl = reference_template(g)
+    n_ch = int(g['meta/n_ch']) if 'meta/n_ch' in g.files else 1
+    # stacked spectrograms: the template travels with the golden (mixer shapes depend on the channels)
+    tpl = template_from_meta(g) if n_ch > 1 else reference_template(g)
     sd = vo.closed_form_state_dict(tpl, seed=int(g['meta/seed']), dtype=torch.float64)
-    x = synth_input(B)
+    x = stack_channels(synth_input(B), n_ch)
     eps = torch.tensor(g['in/eps'])
     enc_mask, dec_mask = unpack_mask(g, 'enc'), unpack_mask(g, 'dec')
     # eval-mode forward
