@@ -13,6 +13,7 @@ loss.py) in the build container, runs it on seeded inputs and commits the output
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -199,6 +200,24 @@ def gaussian_dkl(mu, logvar, normalize=True):
     dkl = 0.5 * torch.sum(torch.exp(logvar) + torch.square(mu) - logvar - 1.0)
     dkl = dkl / mu.size(0)
     return dkl / mu.size(1) if normalize else dkl
+
+
+def standard_gaussian_log_probability(samples):
+    """utils/probability.py:13-18."""
+    return -0.5 * (samples.shape[1] * np.log(2 * np.pi) + torch.sum(samples ** 2, dim=1))
+
+
+def gaussian_log_probability(samples, mu, log_var):
+    """utils/probability.py:21-29."""
+    return -0.5 * (samples.shape[1] * np.log(2 * np.pi)
+                   + torch.sum(log_var + ((samples - mu) ** 2 / torch.exp(log_var)), dim=1))
+
+
+def flow_latent_loss(z_0_mu_logvar, z_0, z_K, log_abs_det_jac, normalize=False):
+    """FlowVAE.latent_loss (model/VAE.py:183-193) for given flow outputs."""
+    log_q = gaussian_log_probability(z_0, z_0_mu_logvar[:, 0, :], z_0_mu_logvar[:, 1, :])
+    loss = -(standard_gaussian_log_probability(z_K) - log_q + log_abs_det_jac).mean()
+    return loss / z_0.shape[1] if normalize else loss
 
 
 def l2_loss(inferred, target, contents_average=False, batch_average=True):

@@ -352,6 +352,26 @@ def run_regression_case(out_dir):
 
 
 
+def run_probability_case(out_dir):
+    """utils/probability.py:13-29 and the ELBO combination of FlowVAE.latent_loss (VAE.py:183-193; the flow output z_K
+    and log|det J| are given tensors here - the nflows transform is out of scope)."""
+    from utils import probability as ref_prob
+    B, D = 6, 16
+    mu, lv = synth_vec((B, D), 0.913, 0.3) * 0.7, synth_vec((B, D), 0.477, 1.1) * 0.9 - 0.2
+    z0 = mu + torch.exp(lv / 2) * synth_vec((B, D), 1.37, 0.5) * 1.2
+    zk = synth_vec((B, D), 0.61, 0.8) * 1.5 + 0.1 * z0
+    ladj = synth_vec((B, 1), 2.3, 0.2) * 0.4
+    log_q = ref_prob.gaussian_log_probability(z0, mu, lv)
+    log_p = ref_prob.standard_gaussian_log_probability(zk)
+    loss = -(log_p - log_q + ladj).mean()
+    out = {'mu': mu.numpy(), 'logvar': lv.numpy(), 'z0': z0.numpy(), 'zk': zk.numpy(), 'ladj': ladj.numpy(),
+           'log_q': log_q.numpy(), 'log_p': log_p.numpy(), 'loss': np.array(loss.item()),
+           'loss_normalized': np.array(loss.item() / D)}
+    path = os.path.join(out_dir, 'probability.npz')
+    np.savez_compressed(path, **out)
+    print('probability ->', path)
+
+
 def run_dataset_seam_case(out_dir):
     """the reference's own PresetDataset.__getitem__ / denormalize_spectrogram (data/abstractbasedataset.py
     :101-145, :340-346) driven through a fixture subclass that serves synthetic waves and parameter vectors from memory
@@ -415,6 +435,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'dataset_seam':
         run_dataset_seam_case(HERE)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'probability':
+        run_probability_case(HERE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'stacked':
         run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
         sys.exit(0)
@@ -426,3 +449,4 @@ if __name__ == '__main__':
     run_vae_case('speccnn4l1_bn', 64, 2, False, 'vae4l_b2', HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
     run_dataset_seam_case(HERE)
+    run_probability_case(HERE)

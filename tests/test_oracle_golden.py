@@ -207,3 +207,14 @@ def test_dataset_seam_matches_reference():
             den = do.denormalize_spectrogram(g[f'{tag}/0/spec'], stats, mode)
             assert np.abs(den - g[f'{tag}/denorm0']).max() < 1e-4      # float32 arithmetic in the reference
             assert np.abs(do.normalize_spectrogram(den, stats, mode) - g[f'{tag}/0/spec']).max() < 1e-5
+
+
+def test_gaussian_log_probabilities_match_reference():
+    """utils/probability.py:13-29 + the ELBO combination of FlowVAE.latent_loss (VAE.py:183-193)."""
+    g = load_golden('probability.npz')
+    mu, lv, z0, zk, ladj = (torch.tensor(g[k]) for k in ('mu', 'logvar', 'z0', 'zk', 'ladj'))
+    assert rel_l2(vo.gaussian_log_probability(z0, mu, lv), torch.tensor(g['log_q'])) < 1e-12
+    assert rel_l2(vo.standard_gaussian_log_probability(zk), torch.tensor(g['log_p'])) < 1e-12
+    zml = torch.stack([mu, lv], dim=1)
+    assert abs(vo.flow_latent_loss(zml, z0, zk, ladj).item() - float(g['loss'])) < 1e-12 * abs(float(g['loss']))
+    assert abs(vo.flow_latent_loss(zml, z0, zk, ladj, normalize=True).item() - float(g['loss_normalized'])) < 1e-12
