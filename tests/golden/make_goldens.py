@@ -12,6 +12,7 @@ closed_form_state_dict — a formula, not an RNG stream), inject eps (patched ``
 """
 import os
 import sys
+import types
 from unittest import mock
 
 import numpy as np
@@ -372,6 +373,75 @@ def run_probability_case(out_dir):
     print('probability ->', path)
 
 
+def run_params_loss_case(out_dir):
+    """the reference's SynthParamsLoss (categorical branches, useless-parameter exclusion),
+    QuantizedNumericalParamsLoss and CategoricalParamsAccuracy (model/loss.py:72-315) driven with a duck-typed
+    14-column PresetIndexesHelper (tests/helpers.py)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import MiniPresetIndexesHelper
+    helper = MiniPresetIndexesHelper()
+    B, L = 8, 14
+    u_in = 0.5 * (synth_vec((B, L), 0.377, 0.6) + 1.0)
+    u_in[:, 1] = torch.round(u_in[:, 1] * 4) / 4
+    u_in[:, 2] = torch.round(u_in[:, 2] * 2) / 2
+    u_in[:, 13] = torch.round(u_in[:, 13] * 3) / 3
+    u_in[2, 0] = 0.0          # rows whose 'operator volume' makes parameters useless
+    u_in[5, 0] = 0.0
+    u_in[3, 1] = 0.0
+    u_in[5, 1] = 0.0
+    for g in helper.get_categorical_learnable_indexes():
+        cls = (torch.arange(B) * 3 + len(g)) % len(g)
+        u_in[:, g] = torch.nn.functional.one_hot(cls, len(g)).double()
+    raw = 0.5 * (synth_vec((B, L), 0.913, 1.7) + 1.0) * 0.98 + 0.01          # in (0, 1)
+    out = {'in/u_in': u_in.numpy(), 'in/u_out': raw.numpy()}
+    variants = {'cce_softmax': dict(cat_bce=False, cat_softmax=True, cat_softmax_t=0.2),
+                'cce_probs': dict(cat_bce=False, cat_softmax=False), 'bce': dict(cat_bce=True, cat_softmax=False)}
+    for norm in (True, False):
+        for useless in (True, False):
+            for name, kw in variants.items():
+                u_out = raw.clone().requires_grad_(True)
+                crit = ref_loss.SynthParamsLoss(helper, norm, categorical_loss_factor=0.2,
+                                                prevent_useless_params_loss=useless, **kw)
+                loss = crit(u_out.clone(), u_in.clone())      # the reference mutates its arguments in place
+                loss.backward()
+                tag = f'{name}/norm{int(norm)}/useless{int(useless)}'
+                out[tag + '/loss'] = np.array(loss.item())
+                out[tag + '/grad'] = u_out.grad.numpy()
+    out['quantized/mse'] = np.array(ref_loss.QuantizedNumericalParamsLoss(helper)(raw, u_in).item())
+    out['quantized/limited'] = np.array(ref_loss.QuantizedNumericalParamsLoss(
+        helper, limited_vst_params_indexes=[1, 5])(raw, u_in).item())
+    out['accuracy/mean'] = np.array(ref_loss.CategoricalParamsAccuracy(helper)(raw, u_in))
+    acc = ref_loss.CategoricalParamsAccuracy(helper, reduce=False, percentage_output=False)(raw, u_in)
+    out['accuracy/keys'] = np.array(list(acc.keys()))
+    out['accuracy/values'] = np.array(list(acc.values()))
+    # the Dexed useless-parameter rule of data/preset.py:259-281 through the reference's own method
+    from data import preset as ref_preset
+    f2l = [None] * 155
+    learn = 0
+    for vst_idx in range(155):
+        if vst_idx % 7 == 3:
+            continue                                   # not learnable
+        if vst_idx % 5 == 2 and vst_idx not in [31 + 22 * i for i in range(6)]:
+            f2l[vst_idx] = [learn, learn + 1, learn + 2]
+            learn += 3
+        else:
+            f2l[vst_idx] = learn
+            learn += 1
+    fake = types.SimpleNamespace(_synth=ref_preset._Synth.DEXED, full_to_learnable=f2l)
+    preset = 0.5 * (synth_vec((learn,), 0.61, 0.3) + 1.0)
+    for op in (1, 4):
+        preset[f2l[31 + 22 * op]] = 0.0
+    nums, cats = ref_preset.PresetIndexesHelper.get_useless_learned_params_indexes(fake, preset)
+    out['dexed/full_to_learnable'] = np.array([-1 if v is None else (v if isinstance(v, int) else -(v[0] + 2))
+                                               for v in f2l])
+    out['dexed/preset'] = preset.numpy()
+    out['dexed/useless_num'] = np.array(nums)
+    out['dexed/useless_cat'] = np.array(cats)
+    path = os.path.join(out_dir, 'params_loss.npz')
+    np.savez_compressed(path, **out)
+    print('params loss ->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 def run_dataset_seam_case(out_dir):
     """the reference's own PresetDataset.__getitem__ / denormalize_spectrogram (data/abstractbasedataset.py
     :101-145, :340-346) driven through a fixture subclass that serves synthetic waves and parameter vectors from memory
@@ -435,6 +505,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'dataset_seam':
         run_dataset_seam_case(HERE)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'params_loss':
+        run_params_loss_case(HERE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'probability':
         run_probability_case(HERE)
         sys.exit(0)
@@ -450,3 +523,4 @@ if __name__ == '__main__':
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
     run_dataset_seam_case(HERE)
     run_probability_case(HERE)
+    run_params_loss_case(HERE)

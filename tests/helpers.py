@@ -125,3 +125,31 @@ def template_from_meta(g):
     for k, sh in zip(g['meta/keys'], g['meta/shapes']):
         tpl[str(k)] = tuple(int(v) for v in str(sh).split()) if str(sh) else ()
     return tpl
+
+
+class MiniPresetIndexesHelper:
+    """Duck-typed PresetIndexesHelper (data/preset.py) of a 14-column learnable representation used by the f4 goldens:
+    numerical columns 0-3 and 13 (13 = a categorical VST parameter learned as numerical), one-hot groups 4-6, 7-10
+    (a numerical VST parameter learned as categorical) and 11-12; columns 0 and 1 act as 'operator volumes' whose
+    zero value makes other parameters useless (same mechanism as the Dexed rule of data/preset.py:259-281)."""
+    learnable_preset_size = 14
+    vst_param_cardinals = {0: -1, 1: 5, 2: 3, 3: -1, 4: 3, 5: 4, 6: 2, 7: 4}
+    num_idx_learned_as_num = {0: 0, 1: 1, 2: 2, 3: 3}
+    num_idx_learned_as_cat = {5: [7, 8, 9, 10]}
+    cat_idx_learned_as_cat = {4: [4, 5, 6], 6: [11, 12]}
+    cat_idx_learned_as_num = {7: 13}
+    useless_rules = [(0, [2, 3], [7]), (1, [], [11])]
+
+    def get_numerical_learnable_indexes(self):
+        return [0, 1, 2, 3, 13]
+
+    def get_categorical_learnable_indexes(self):
+        return [[4, 5, 6], [7, 8, 9, 10], [11, 12]]
+
+    def get_useless_learned_params_indexes(self, preset_GT):
+        nums, cats = [], []
+        for trig, n, c in self.useless_rules:
+            if preset_GT[trig].item() < 1e-3:
+                nums += n
+                cats += c
+        return nums, cats

@@ -218,3 +218,39 @@ def test_gaussian_log_probabilities_match_reference():
     zml = torch.stack([mu, lv], dim=1)
     assert abs(vo.flow_latent_loss(zml, z0, zk, ladj).item() - float(g['loss'])) < 1e-12 * abs(float(g['loss']))
     assert abs(vo.flow_latent_loss(zml, z0, zk, ladj, normalize=True).item() - float(g['loss_normalized'])) < 1e-12
+
+
+PARAMS_LOSS_VARIANTS = {'cce_softmax': dict(cat_bce=False, cat_softmax=True, cat_softmax_t=0.2),
+                        'cce_probs': dict(cat_bce=False, cat_softmax=False), 'bce': dict(cat_bce=True, cat_softmax=False)}
+
+
+def test_params_losses_match_reference():
+    """SynthParamsLoss (all categorical variants, with and without the useless-parameter exclusion),
+    QuantizedNumericalParamsLoss, CategoricalParamsAccuracy and the Dexed useless-parameter rule."""
+    from helpers import MiniPresetIndexesHelper
+    from oracle import params_oracle as po
+    g = load_golden('params_loss.npz')
+    helper = MiniPresetIndexesHelper()
+    u_in, raw = torch.tensor(g['in/u_in']), torch.tensor(g['in/u_out'])
+    for norm in (True, False):
+        for useless in (True, False):
+            for name, kw in PARAMS_LOSS_VARIANTS.items():
+                tag = f'{name}/norm{int(norm)}/useless{int(useless)}'
+                u_out = raw.clone().requires_grad_(True)
+                loss = po.synth_params_loss(u_out, u_in, helper, norm, prevent_useless_params_loss=useless, **kw)
+                loss.backward()
+                assert abs(loss.item() - float(g[tag + '/loss'])) <= 1e-12 * abs(float(g[tag + '/loss'])), tag
+                assert rel_l2(u_out.grad, torch.tensor(g[tag + '/grad'])) < 1e-12, tag
+    # (the reference gathers the columns into float32 buffers, loss.py:218-219: float32-level agreement)
+    assert abs(po.quantized_numerical_params_loss(raw, u_in, helper).item() - float(g['quantized/mse'])) < 1e-6
+    assert abs(po.quantized_numerical_params_loss(raw, u_in, helper, [1, 5]).item()
+               - float(g['quantized/limited'])) < 1e-6
+    acc = po.categorical_params_accuracy(raw, u_in, helper, percentage_output=False)
+    assert list(acc.keys()) == g['accuracy/keys'].tolist()
+    assert np.allclose(list(acc.values()), g['accuracy/values'])
+    acc100 = po.categorical_params_accuracy(raw, u_in, helper)
+    assert abs(np.mean(list(acc100.values())) - float(g['accuracy/mean'])) < 1e-12
+    f2l = po.decode_full_to_learnable(g['dexed/full_to_learnable'])
+    nums, cats = po.dexed_useless_learned_params_indexes(f2l, g['dexed/preset'])
+    assert nums == g['dexed/useless_num'].tolist() and cats == g['dexed/useless_cat'].tolist()
+    assert len(nums) > 0 and len(cats) > 0
