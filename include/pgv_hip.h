@@ -51,6 +51,10 @@ typedef struct pgv_conv_desc {
  * the buffer is zero - e.g. one arena cleared once per step, or the zero_grad'ed flat gradient buffer
  * (train.py:208) - and the call only accumulates. */
 #define PGV_PREZEROED 1
+/* bf16 compute / fp32 storage (BASELINE config 2): the operands of every product (activations after the folded
+ * BatchNorm affine, weights, gradients) are rounded to bfloat16 (RNE) and multiplied on the bf16 matrix cores
+ * (v_mfma_f32_16x16x16_bf16) with fp32 accumulation; tensors in HBM, BatchNorm, losses and Adam stay fp32. */
+#define PGV_COMPUTE_BF16 2
 
 /* ---- library info ------------------------------------------------------------------------------ */
 int pgv_abi_version(void);

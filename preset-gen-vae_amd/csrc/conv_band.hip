@@ -284,7 +284,7 @@ struct DownCfg {
   static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
 };
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool FUSE>
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool FUSE, bool BF16>
 __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift,
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
 #ifdef PGV_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    {
+    if constexpr (!BF16) {
       constexpr int S = CK * KS;  // steps (c, kh); one MFMA per (step, m, t) consumes the 4 kw taps
       float a0[MT], a1[MT], b0[NT], b1[NT];
       auto load_step = [&](int st, float (&av)[MT], float (&bv)[NT]) {
@@ -429,6 +429,42 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // bf16 compute (PGV_COMPUTE_BF16): one v_mfma_f32_16x16x16_bf16 per (channel, m, t) - the lane group supplies its
+      // kw tap for the four kernel rows kh = 0..3 (the operands of four fp32 steps), rounded to bf16 while packing
+      constexpr int S = CK;
+      s16x4 a0[MT], a1[MT], b0[NT], b1[NT];
+      auto load_step = [&](int c, s16x4 (&av)[MT], s16x4 (&bv)[NT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float* ap = wt + c * 16 * CSP + m * 16 + offA;
+          av[m] = pack_bf16x4(ap[0], ap[4 * CSP], ap[8 * CSP], ap[12 * CSP]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float* bp = in_tile + c * PLANE + offB[t];
+          bv[t] = pack_bf16x4(bp[0], bp[WP], bp[2 * WP], bp[3 * WP]);
+        }
+      };
+      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[t], acc[m][t], 0, 0, 0);
       };
       load_step(0, a0, b0);
 #pragma unroll
@@ -563,15 +599,20 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   // The fused-epilogue variant keeps the saved-activation loads in registers: only instantiated where it pays
   // (CANFUSE), and only launched when asked for, so the plain kernel's register allocation is unaffected.
   if (fuse && !CANFUSE) return 0;
-  auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false>;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  if (fuse && bf16) return 0;  // (the fused epilogue is instantiated for the fp32 loop only)
+  auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_band");
   if (rc) return rc;
-  auto kernf = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, CANFUSE>;
+  auto kernf = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, CANFUSE, false>;
   if (CANFUSE) {
     static bool attr_done_f = false;
     if ((rc = raise_lds_limit(kernf, &attr_done_f, "conv_down_band"))) return rc;
   }
+  auto kernb = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false, true>;
+  static bool attr_done_b = false;
+  if ((rc = raise_lds_limit(kernb, &attr_done_b, "conv_down_band"))) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_band: memset failed");
     return PGV_E_LAUNCH;
@@ -583,8 +624,8 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
 #endif
   const int grid = min(units, 256 * per_cu);
   const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(fuse ? kernf : kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, in_scale, in_shift,
-                     w, bias, act, slope, out, stats, fuse ? *fuse : fz);
+  hipLaunchKernelGGL(bf16 ? kernb : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big,
+                     in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_down_band");
   return 1;
 }
@@ -599,7 +640,7 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
 // the accumulators in registers over all their (sample, band) units and flush once with float atomics; the tiles of
 // unit i+1 are prefetched into registers while unit i is multiplied.
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H, bool BF16>
 struct WgradCfg {
   static constexpr int KK = KS * KS;
   static constexpr int NTAP = (KK + 15) / 16;  // N tiles per big channel
@@ -610,7 +651,8 @@ struct WgradCfg {
   static constexpr int Ws = (W + 4 - KS) / 2 + 1, Hs = (H + 4 - KS) / 2 + 1;
   static constexpr int ROWS_B = 2 * (R - 1) + KS;
   static constexpr int WP = (W + 2 + 3) / 4 * 4;
-  static constexpr int WsP = (Ws + 3) / 4 * 4;
+  // bf16 compute: 16 output pixels per MFMA (four fp32 k-steps merged), so rows are padded to a multiple of 16
+  static constexpr int WsP = BF16 ? (Ws + 15) / 16 * 16 : (Ws + 3) / 4 * 4;
   // channel stride of the small tile: the A operand is read at  cs*PLANE_S + pixel  by 16 channels x 4 pixels per wave,
   // stride % 64 == 4 spreads them over all 64 LDS banks (R*WsP itself is 0 or 32 mod 64: 8- to 16-way conflicts)
   static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = (R * WsP - 4 + 63) / 64 * 64 + 4;
@@ -626,7 +668,7 @@ struct WgradCfg {
   static_assert((CB * NTAP) % WN == 0 && (CSL & (CSL - 1)) == 0 && CSL <= CS, "tiling");
 };
 
-template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H, bool BF16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                                const float* __restrict__ big_scale,
                                                                const float* __restrict__ big_shift,
@@ -634,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
                                                                const float* __restrict__ small_scale,
                                                                const float* __restrict__ small_shift,
                                                                float* __restrict__ gw) {
-  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
+  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, BF16>;
   constexpr int KK = G::KK, NTAP = G::NTAP, NB = G::NB, WK = G::WK, R = G::R, CS = G::CS, Ws = G::Ws, Hs = G::Hs;
   constexpr int WP = G::WP, WsP = G::WsP, PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -701,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
     BAND_ACC(3);
     __syncthreads();
     BAND_ACC(4);
-    {
+    if constexpr (!BF16) {
       constexpr int S = RW * SPR;
       float a0[MT], a1[MT], b0[NB], b1[NB];
       auto load_step = [&](int st, float (&av)[MT], float (&bv)[NB]) {
@@ -717,6 +759,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        if (st + 1 < S) load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < S) compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // bf16 compute: 16 output pixels per v_mfma_f32_16x16x16_bf16 - the lane group keeps its pixel offset k and
+      // supplies pixels k, k+4, k+8, k+12 of the 16-pixel step (the operands of four fp32 steps), rounded while packing
+      constexpr int SPR4 = SPR / 4;
+      static_assert(SPR % 4 == 0, "bf16 rows are padded to 16 pixels");
+      constexpr int S = RW * SPR4;
+      s16x4 a0[MT], a1[MT], b0[NB], b1[NB];
+      auto load_step = [&](int st, s16x4 (&av)[MT], s16x4 (&bv)[NB]) {
+        const int rw = st / SPR4, i = st - rw * SPR4;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float* ap = small_tile + offA[m] + rw * WK * WsP + 16 * i;
+          av[m] = pack_bf16x4(ap[0], ap[4], ap[8], ap[12]);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const float* bp = big_tile + offB[n] + rw * WK * 2 * WP + 32 * i;
+          bv[n] = pack_bf16x4(bp[0], bp[8], bp[16], bp[24]);
+        }
+      };
+      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NB]) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[n], acc[m][n], 0, 0, 0);
       };
       load_step(0, a0, b0);
 #pragma unroll
@@ -778,15 +859,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   }
 }
 
-template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
-int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
-                      const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                      hipStream_t st) {
-  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H, bool BF16>
+int launch_wgrad_band_t(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        hipStream_t st) {
+  using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, BF16>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
   if (d->Cb > CB * NSPLIT || d->Cs > CSL) return 0;
-  auto kern = conv_wgrad_band_kernel<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H>;
+  auto kern = conv_wgrad_band_kernel<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, BF16>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
   if (rc) return rc;
@@ -805,6 +886,17 @@ int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big
                      small_scale, small_shift, gw);
   PGV_CHECK_LAUNCH("conv_wgrad_band");
   return 1;
+}
+
+template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H>
+int launch_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                      hipStream_t st) {
+  if (d->flags & PGV_COMPUTE_BF16)
+    return launch_wgrad_band_t<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, true>(d, big, big_scale, big_shift, small_in,
+                                                                          small_scale, small_shift, gw, st);
+  return launch_wgrad_band_t<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, false>(d, big, big_scale, big_shift, small_in,
+                                                                         small_scale, small_shift, gw, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -836,7 +928,7 @@ struct UpCfg {
   static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
 };
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H, bool FUSE>
+template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H, bool FUSE, bool BF16>
 __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int Cs, const float* __restrict__ small_in,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
@@ -955,7 +1047,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
     BAND_ACC(3);
     __syncthreads();
     BAND_ACC(4);
-    {
+    if constexpr (!BF16) {
       constexpr int S = CK;  // one k-group (th, tw) per input channel
       static_assert(S % 2 == 0, "step count must be even");
       float a0[MT], a1[MT], b0[NT], b1[NT];
@@ -971,6 +1063,43 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+      };
+      load_step(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < S; st += 2) {
+        load_step(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < S) load_step(st + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // bf16 compute: one v_mfma_f32_16x16x16_bf16 per (4 input channels, m, t): the lane group keeps its tap (th, tw)
+      // and supplies it for channels 4s..4s+3 (the operands of four fp32 steps), rounded to bf16 while packing
+      constexpr int S = CK / 4;
+      static_assert(CK % 8 == 0, "channel chunk must hold an even number of 4-channel steps");
+      s16x4 a0[MT], a1[MT], b0[NT], b1[NT];
+      auto load_step = [&](int st, s16x4 (&av)[MT], s16x4 (&bv)[NT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float* ap = wt + st * 16 * MSP + m * 16 + offA;
+          av[m] = pack_bf16x4(ap[0], ap[4 * MSP], ap[8 * MSP], ap[12 * MSP]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float* bp = in_tile + st * 4 * PLANE + offB[t];
+          bv[t] = pack_bf16x4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
+        }
+      };
+      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[t], acc[m][t], 0, 0, 0);
       };
       load_step(0, a0, b0);
 #pragma unroll
@@ -1107,15 +1236,20 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
   if (d->Cs > NCH * CK || d->Cb > MT * 4) return 0;
   if (fuse && !CANFUSE) return 0;
-  auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false>;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  if (fuse && bf16) return 0;
+  auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_up_band");
   if (rc) return rc;
-  auto kernf = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, CANFUSE>;
+  auto kernf = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, CANFUSE, false>;
   if (CANFUSE) {
     static bool attr_done_f = false;
     if ((rc = raise_lds_limit(kernf, &attr_done_f, "conv_up_band"))) return rc;
   }
+  auto kernb = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false, true>;
+  static bool attr_done_b = false;
+  if ((rc = raise_lds_limit(kernb, &attr_done_b, "conv_up_band"))) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_band: memset failed");
     return PGV_E_LAUNCH;
@@ -1124,8 +1258,8 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
   const int grid = min(units, 256 * per_cu);
   const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(fuse ? kernf : kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in, in_scale,
-                     in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
+  hipLaunchKernelGGL(bf16 ? kernb : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs,
+                     small_in, in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_up_band");
   return 1;
 }

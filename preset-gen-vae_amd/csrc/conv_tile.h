@@ -6,6 +6,18 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 operands of v_mfma_f32_16x16x16_bf16 (PGV_COMPUTE_BF16): four consecutive k values per lane, packed from
+// fp32 with round-to-nearest-even (v_cvt_pk_bf16_f32); products of bf16 values are exact in fp32, accumulation is fp32
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pack_bf16x4(float a, float b, float c, float d) {
+  const bf16x2_t lo = {(__bf16)a, (__bf16)b}, hi = {(__bf16)c, (__bf16)d};
+  const unsigned u[2] = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, u);
+}
+// fp32 value rounded to bf16 precision (kernels without a bf16 MFMA loop emulate the operand precision this way)
+__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kLdsTarget = 76 * 1024;  // aim at two workgroups per CU
 

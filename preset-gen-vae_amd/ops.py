@@ -38,6 +38,26 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+PGV_PREZEROED, PGV_COMPUTE_BF16 = 1, 2
+_COMPUTE_FLAGS = 0
+
+
+def set_compute_dtype(dtype):
+    """'fp32' (default: exact fp32 products on the f32 matrix cores) or 'bf16' (PGV_COMPUTE_BF16: operands of every
+    convolution / linear product rounded to bfloat16, bf16 matrix cores with fp32 accumulation; storage stays fp32)."""
+    global _COMPUTE_FLAGS
+    if dtype in ('fp32', 'f32', torch.float32):
+        _COMPUTE_FLAGS = 0
+    elif dtype in ('bf16', torch.bfloat16):
+        _COMPUTE_FLAGS = PGV_COMPUTE_BF16
+    else:
+        raise ValueError(f"unknown compute dtype {dtype!r}")
+
+
+def compute_dtype():
+    return 'bf16' if _COMPUTE_FLAGS & PGV_COMPUTE_BF16 else 'fp32'
+
+
 class ConvGeom:
     """Geometry of one strided convolution between a big [B,Cb,Hb,Wb] and a small [B,Cs,Hs,Ws] tensor."""
 
@@ -48,6 +68,7 @@ class ConvGeom:
         self._descs = {}
 
     def desc(self, B, flags=0):
+        flags |= _COMPUTE_FLAGS
         d = self._descs.get((B, flags))
         if d is None:
             d = ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
