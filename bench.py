@@ -26,6 +26,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak; the path computes in fp32
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (--dtype bf16 only)
 
 
 def parse():
@@ -36,6 +37,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
     ap.add_argument("--arch", default="speccnn4l1_bn", choices=["speccnn4l1_bn", "speccnn8l1_bn"])
     ap.add_argument("--dim-z", type=int, default=64)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="operand precision of the conv / linear products (bf16 = BASELINE config 2's arithmetic: bf16 "
+                         "matrix cores, fp32 accumulation and storage); the default line is fp32")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -132,7 +136,7 @@ def time_kernel(fn, iters=5):
     return max(_time_graph(_graph_of(with_fn)) - _FLUSH_MS[iters], 0.0) / iters
 
 
-def measure_roofline(ae, B, device):
+def measure_roofline(ae, B, device, matrix_peak=F32_MATRIX_PEAK_TFLOPS):
     """Time every conv-layer kernel (forward, input-gradient, weight-gradient) standalone at the bench shapes, pick
     the one with the largest duration (the dominant kernel of the step) and price it against its roofline."""
     from preset_gen_vae_amd import ops
@@ -173,7 +177,7 @@ def measure_roofline(ae, B, device):
             if name == 'enc1' and kname == 'conv_up':
                 continue  # the first block needs no input gradient: this launch is not part of the train step
             ms = time_kernel(fn, iters=5)
-            t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (F32_MATRIX_PEAK_TFLOPS * 1e12)
+            t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (matrix_peak * 1e12)
             rec = {'layer': name, 'kernel': kname, 'ms': ms, 'flops': flops, 'bytes': bytes_,
                    'bound': 'hbm' if t_hbm >= t_mfma else 'mfma'}
             table.append(rec)
@@ -183,13 +187,13 @@ def measure_roofline(ae, B, device):
     if worst['bound'] == 'hbm':
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
-        achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, F32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
+        achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, matrix_peak, 'TFLOP/s'
     label = f"{worst['kernel']}[{worst['layer']}]"
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json), if any
     try:
         with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
             entry = json.load(f).get(label)
-        if entry and B == 256:
+        if entry and B == 256 and matrix_peak == F32_MATRIX_PEAK_TFLOPS:
             traffic = entry['hbm_bytes_per_launch']
     except (OSError, ValueError):
         pass
@@ -234,10 +238,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    from preset_gen_vae_amd import _lib, config, parallel
+    from preset_gen_vae_amd import _lib, config, ops, parallel
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.train_step import VAETrainStep
     _lib.load()   # fails loudly if the HIP library is missing
+    ops.set_compute_dtype(args.dtype)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     # one rank per GPU; PGV_DIST_BACKEND=gloo + a single visible GPU lets the N>1 code path be exercised on a 1-GPU box
     dev_index = local_rank % torch.cuda.device_count()
@@ -289,7 +294,8 @@ def main():
 
     roof, table, cpu = None, None, None
     if rank == 0 and not args.no_roofline:
-        roof, table = measure_roofline(ae, args.batch, device)
+        roof, table = measure_roofline(ae, args.batch, device, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
+                                       else F32_MATRIX_PEAK_TFLOPS)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.arch, args.dim_z, args.cpu_batch)
     if world > 1:
@@ -302,8 +308,8 @@ def main():
             "metric": "spectrograms/sec per VAE train step (batch 256, 1x257x347)", "value": round(value, 2),
             "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} fp32 full train step "
+            "dtype": "bf16" if args.dtype == 'bf16' else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
                                    f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": "hipGraph" if use_graph else "eager", "final_loss": round(loss, 6)},

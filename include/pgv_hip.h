@@ -140,11 +140,12 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
 /* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */
 /* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.
  * A element (m,k) at A[m*sam + k*sak]; B element (k,n) at B[k*sbk + n*sbn]; C row-major ldc.
- * bias_n (len N) / bias_m (len M) optional (NULL).  Overwrites C.  workspace for split-K partials. */
+ * bias_n (len N) optional (NULL).  Overwrites C.  flags: PGV_COMPUTE_BF16 rounds both operands to bfloat16 (fp32
+ * accumulation), 0 = fp32.  workspace is reserved (split-K accumulates in C). */
 int64_t pgv_gemm_workspace(int M, int N, int K);
 int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
-             int64_t sbn, float* C, int64_t ldc, const float* bias_n, void* workspace, int64_t workspace_bytes,
-             void* stream);
+             int64_t sbn, float* C, int64_t ldc, const float* bias_n, int flags, void* workspace,
+             int64_t workspace_bytes, void* stream);
 /* out[n] = sum_m x[m*ld + n]  (bias gradient of Linear). */
 int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, void* stream);
 

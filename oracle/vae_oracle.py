@@ -17,6 +17,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import contextlib
+
 LRELU_SLOPE = 0.1          # encoder.py:240, decoder.py:204
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch defaults through layer.py:21,41
 
@@ -80,12 +82,74 @@ def _leaky(y, name, act_masks):
     return F.leaky_relu(y, LRELU_SLOPE)
 
 
+# ---- operand precision of the products ---------------------------------------------------------------------------
+# The reference trains in float32 (train.py builds the model with default dtypes, no autocast).  BASELINE.json's
+# config 2 asks for the 8-layer stack with bf16 matrix cores; the product's definition of that mode (DESIGN.md
+# section 7) is restated here so that it has an oracle too: every convolution / transposed convolution / linear
+# PRODUCT - forward, input gradient and weight gradient - sees both of its operands rounded to bfloat16 (round to
+# nearest even) and accumulates exactly-representable products in float32; biases, activations, BatchNorm, losses,
+# gradients in memory, Adam and the parameters themselves stay float32.  This mode has no golden from the reference
+# (it does not exist there): its anchor is that with the flag off the same code path is the pinned float32 oracle.
+_OPERAND_BF16 = False
+
+
+@contextlib.contextmanager
+def operand_precision(dtype):
+    """``with operand_precision('bf16'):`` runs the oracle with bf16-rounded product operands."""
+    global _OPERAND_BF16
+    old = _OPERAND_BF16
+    _OPERAND_BF16 = dtype in ('bf16', torch.bfloat16)
+    try:
+        yield
+    finally:
+        _OPERAND_BF16 = old
+
+
+def round_bf16(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundOperand(torch.autograd.Function):
+    """Forward: round to bfloat16; backward: identity (the stored tensors are float32, only the product sees bf16)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return round_bf16(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradient(torch.autograd.Function):
+    """Forward: identity; backward: the gradient entering the two backward products is rounded to bfloat16."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return round_bf16(g)
+
+
+def _product(op, x, w, b, **kw):
+    """op(x, w) + b with the mode's operand precision; the bias joins after the product (its gradient is the float32
+    sum of the unrounded output gradient)."""
+    if not _OPERAND_BF16:
+        return op(x, w, b, **kw)
+    y = _RoundGradient.apply(op(_RoundOperand.apply(x), _RoundOperand.apply(w), None, **kw))
+    if b is None:
+        return y
+    return y + (b.view(1, -1, 1, 1) if y.dim() == 4 else b)
+
+
 def conv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_masks=None, tag=''):
     """layer.Conv2D (model/layer.py:10-26): Conv2d -> LeakyReLU(0.1) -> BatchNorm2d (BN after the activation).
     ``tag`` distinguishes the taps / activation masks of repeated applications (stacked spectrogram channels)."""
     name, _, _, k, s, p, has_bn = row
     w, b = _find(sd, name + 'conv.weight', scope), _find(sd, name + 'conv.bias', scope)
-    a = _leaky(F.conv2d(x, w, b, stride=s, padding=p), name + tag, act_masks)
+    a = _leaky(_product(F.conv2d, x, w, b, stride=s, padding=p), name + tag, act_masks)
     if taps is not None:
         taps[name + tag + '_act'] = a
     if has_bn:
@@ -99,7 +163,7 @@ def tconv_block(x, sd, row, scope, training, new_buffers=None, taps=None, act_ma
     """layer.TConv2D (model/layer.py:29-46): ConvTranspose2d(output_padding) -> LeakyReLU(0.1) -> BatchNorm2d."""
     name, _, _, k, s, p, op, has_bn = row
     w, b = _find(sd, name + 'tconv.weight', scope), _find(sd, name + 'tconv.bias', scope)
-    a = _leaky(F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op), name + tag, act_masks)
+    a = _leaky(_product(F.conv_transpose2d, x, w, b, stride=s, padding=p, output_padding=op), name + tag, act_masks)
     if taps is not None:
         taps[name + tag + '_act'] = a
     if has_bn:
@@ -137,7 +201,7 @@ def encoder_forward(sd, x, arch, dim_z, training, dropout_mask=None, new_buffers
     h = h.reshape(x.shape[0], -1)                                      # encoder.py:104
     if training and dropout_mask is not None:
         h = h * dropout_mask.reshape(h.shape)
-    z = F.linear(h, sd['encoder.mlp.1.weight'], sd['encoder.mlp.1.bias'])   # encoder.py:85
+    z = _product(F.linear, h, sd['encoder.mlp.1.weight'], sd['encoder.mlp.1.bias'])   # encoder.py:85
     if 'encoder.mlp.lat_in_regularization.weight' in sd:                # output_bn, encoder.py:86-87
         lsd = {'latbn.weight': sd['encoder.mlp.lat_in_regularization.weight'],
                'latbn.bias': sd['encoder.mlp.lat_in_regularization.bias'],
@@ -154,7 +218,7 @@ def encoder_forward(sd, x, arch, dim_z, training, dropout_mask=None, new_buffers
 def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, taps=None, act_masks=None):
     """SpectrogramDecoder.forward (model/decoder.py:83-92) + SpectrogramCNN (decoder.py:199-220)."""
     _, dec_rows, cnn_in = arch_tables(arch)
-    h = F.linear(z, sd['decoder.mlp.0.weight'], sd['decoder.mlp.0.bias'])   # decoder.py:64
+    h = _product(F.linear, z, sd['decoder.mlp.0.weight'], sd['decoder.mlp.0.bias'])   # decoder.py:64
     if training and dropout_mask is not None:                            # decoder.py:65
         h = h * dropout_mask.reshape(h.shape)
     h = h.view(-1, *cnn_in)                                              # decoder.py:85-86
@@ -163,7 +227,7 @@ def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, 
     b = sd[f'decoder.single_ch_cnn.dec_nn.{n_last}.bias']
 
     def tail(h, tag):
-        y = F.conv_transpose2d(h, w, b, stride=2, padding=2)             # decoder.py:218
+        y = _product(F.conv_transpose2d, h, w, b, stride=2, padding=2)   # decoder.py:218
         if taps is not None:
             taps['dec8' + tag + '_pre'] = y
         if act_masks is not None and 'dec8' + tag in act_masks:          # pinned Hardtanh gate (True = pass-through)
@@ -336,7 +400,7 @@ def mlp_regression_forward(sd, z, training, masks=None, new_buffers=None):
     n_fc = len([k for k in sd if k.startswith('reg_model.fc') and k.endswith('.weight')])
     h = z
     for l in range(1, n_fc):
-        h = F.linear(h, sd[f'reg_model.fc{l}.weight'], sd[f'reg_model.fc{l}.bias'])
+        h = _product(F.linear, h, sd[f'reg_model.fc{l}.weight'], sd[f'reg_model.fc{l}.bias'])
         if f'reg_model.bn{l}.weight' in sd:
             bsd = {'rbn.weight': sd[f'reg_model.bn{l}.weight'], 'rbn.bias': sd[f'reg_model.bn{l}.bias'],
                    'rbn.running_mean': sd[f'reg_model.bn{l}.running_mean'],
@@ -349,7 +413,7 @@ def mlp_regression_forward(sd, z, training, masks=None, new_buffers=None):
             if training and masks is not None:
                 h = h * masks[l - 1]
         h = F.relu(h)
-    h = F.linear(h, sd[f'reg_model.fc{n_fc}.weight'], sd[f'reg_model.fc{n_fc}.bias'])
+    h = _product(F.linear, h, sd[f'reg_model.fc{n_fc}.weight'], sd[f'reg_model.fc{n_fc}.bias'])
     return F.hardtanh(h, 0.0, 1.0)
 
 

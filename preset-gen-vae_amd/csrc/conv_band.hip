@@ -600,7 +600,6 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   // (CANFUSE), and only launched when asked for, so the plain kernel's register allocation is unaffected.
   if (fuse && !CANFUSE) return 0;
   const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
-  if (fuse && bf16) return 0;  // (the fused epilogue is instantiated for the fp32 loop only)
   auto kern = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_band");
@@ -613,6 +612,11 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   auto kernb = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, false, true>;
   static bool attr_done_b = false;
   if ((rc = raise_lds_limit(kernb, &attr_done_b, "conv_down_band"))) return rc;
+  auto kernfb = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, CANFUSE, true>;
+  if (CANFUSE) {
+    static bool attr_done_fb = false;
+    if ((rc = raise_lds_limit(kernfb, &attr_done_fb, "conv_down_band"))) return rc;
+  }
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_band: memset failed");
     return PGV_E_LAUNCH;
@@ -624,7 +628,8 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
 #endif
   const int grid = min(units, 256 * per_cu);
   const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(bf16 ? kernb : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big,
+  hipLaunchKernelGGL(bf16 ? (fuse ? kernfb : kernb) : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B,
+                     d->Cb, d->Cs, big,
                      in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_down_band");
   return 1;
@@ -1237,7 +1242,6 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   if (d->Cs > NCH * CK || d->Cb > MT * 4) return 0;
   if (fuse && !CANFUSE) return 0;
   const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
-  if (fuse && bf16) return 0;
   auto kern = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false, false>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_up_band");
@@ -1250,6 +1254,11 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   auto kernb = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, false, true>;
   static bool attr_done_b = false;
   if ((rc = raise_lds_limit(kernb, &attr_done_b, "conv_up_band"))) return rc;
+  auto kernfb = conv_up_band_kernel<MT, NT, CK, NCH, WRES, EM, R, W, H, CANFUSE, true>;
+  if (CANFUSE) {
+    static bool attr_done_fb = false;
+    if ((rc = raise_lds_limit(kernfb, &attr_done_fb, "conv_up_band"))) return rc;
+  }
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_band: memset failed");
     return PGV_E_LAUNCH;
@@ -1258,8 +1267,8 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
   const int grid = min(units, 256 * per_cu);
   const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(bf16 ? kernb : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs,
-                     small_in, in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
+  hipLaunchKernelGGL(bf16 ? (fuse ? kernfb : kernb) : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B,
+                     d->Cb, d->Cs, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_up_band");
   return 1;
 }

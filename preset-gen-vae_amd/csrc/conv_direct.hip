@@ -14,7 +14,19 @@ namespace {
 constexpr int KS = 5, KK = 25, PAD = 2;
 
 // ---- DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{kh,kw} x[b,0,2oh-2+kh,2ow-2+kw] * w[cs,0,kh,kw]) ------------------
-template <int CS>
+// BF16 (PGV_COMPUTE_BF16): the 25 taps as 13 bf16 pairs through v_dot2c_f32_bf16 (both operands rounded to bfloat16,
+// fp32 accumulation): the weights are rounded and packed once per workgroup (LDS), then live in registers.
+constexpr int KP = (KK + 1) / 2;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+template <int CS, bool BF16>
 __global__ __launch_bounds__(256) void down_c1_kernel(pgv_conv_desc d, const float* __restrict__ big,
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
@@ -32,7 +44,19 @@ __global__ __launch_bounds__(256) void down_c1_kernel(pgv_conv_desc d, const flo
   if (in_scale) __syncthreads();
   stage_rows_contig<4>(tile, plane, big + (int64_t)b * d.Hb * Wb, 1, d.Hb, Wb, 0, 1, rows_in, ih0,
                        in_scale ? aff : nullptr, aff + 1, tid);
+  unsigned* wl = reinterpret_cast<unsigned*>(lds + 16 + plane);  // [CS][KP] packed bf16 weight pairs (BF16 only)
+  if constexpr (BF16) {
+    for (int i = tid; i < CS * KP; i += 256) {
+      const int cs = i / KP, k = 2 * (i - cs * KP);
+      wl[i] = pack_bf16x2(cs < d.Cs ? w[cs * KK + k] : 0.f, (cs < d.Cs && k + 1 < KK) ? w[cs * KK + k + 1] : 0.f);
+    }
+  }
   __syncthreads();
+  unsigned wr[BF16 ? CS * KP : 1];
+  if constexpr (BF16) {
+#pragma unroll
+    for (int i = 0; i < CS * KP; ++i) wr[i] = wl[i];
+  }
   const float inv_ws = 1.0f / (float)d.Ws;
   const int64_t cstride = (int64_t)d.Hs * d.Ws;
   float* ob = out + (int64_t)b * d.Cs * cstride + (int64_t)oh0 * d.Ws;
@@ -49,20 +73,36 @@ __global__ __launch_bounds__(256) void down_c1_kernel(pgv_conv_desc d, const flo
         x[kh * KS + kw] = ok ? raw : 0.f;
       }
     }
+    if constexpr (BF16) {
+      unsigned xp[KP];
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
-      if (cs < d.Cs) {
-        float a = bias ? bias[cs] : 0.f;
+      for (int j = 0; j < KP; ++j) xp[j] = pack_bf16x2(x[2 * j], 2 * j + 1 < KK ? x[2 * j + 1] : 0.f);
 #pragma unroll
-        for (int k = 0; k < KK; ++k) a = fmaf(x[k], w[cs * KK + k], a);
-        ob[cs * cstride + p] = pgv_act(a, act, slope);
+      for (int cs = 0; cs < CS; ++cs) {
+        if (cs < d.Cs) {
+          float a = bias ? bias[cs] : 0.f;
+#pragma unroll
+          for (int j = 0; j < KP; ++j) a = dot2_bf16(xp[j], wr[cs * KP + j], a);
+          ob[cs * cstride + p] = pgv_act(a, act, slope);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cs = 0; cs < CS; ++cs) {
+        if (cs < d.Cs) {
+          float a = bias ? bias[cs] : 0.f;
+#pragma unroll
+          for (int k = 0; k < KK; ++k) a = fmaf(x[k], w[cs * KK + k], a);
+          ob[cs * cstride + p] = pgv_act(a, act, slope);
+        }
       }
     }
   }
 }
 
 // ---- UP: out[b,0,2u+ph,2v+pw] = act(bias + sum_{cs,th,tw} x'[b,cs,u+1-th,v+1-tw] * w[cs,0,ph+2th,pw+2tw]) ----------
-template <int CS>
+// BF16: channel pairs (2c, 2c+1) per v_dot2c_f32_bf16 - 4 x 25 packed weight pairs in registers.
+template <int CS, bool BF16>
 __global__ __launch_bounds__(256) void up_c1_kernel(pgv_conv_desc d, const float* __restrict__ small_in,
                                                     const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, const float* __restrict__ w,
@@ -80,7 +120,21 @@ __global__ __launch_bounds__(256) void up_c1_kernel(pgv_conv_desc d, const float
   if (in_scale) __syncthreads();
   stage_rows_contig<4>(tile, plane, small_in + (int64_t)b * d.Cs * d.Hs * Ws, d.Cs, d.Hs, Ws, 0, CS, rows_in, ih0,
                        in_scale ? aff : nullptr, aff + d.Cs, tid);
+  static_assert(CS % 2 == 0, "channel pairs");
+  constexpr int CP = CS / 2;
+  unsigned* wl = reinterpret_cast<unsigned*>(lds + 2 * CS + 16 + CS * plane);  // [CP][KK] packed pairs (BF16 only)
+  if constexpr (BF16) {
+    for (int i = tid; i < CP * KK; i += 256) {
+      const int c = i / KK, k = i - c * KK;
+      wl[i] = pack_bf16x2(2 * c < d.Cs ? w[(2 * c) * KK + k] : 0.f, 2 * c + 1 < d.Cs ? w[(2 * c + 1) * KK + k] : 0.f);
+    }
+  }
   __syncthreads();
+  unsigned wr[BF16 ? CP * KK : 1];
+  if constexpr (BF16) {
+#pragma unroll
+    for (int i = 0; i < CP * KK; ++i) wr[i] = wl[i];
+  }
   const float inv_wg = 1.0f / (float)Wg;
   const float bv = bias ? bias[0] : 0.f;
   float* ob = out + (int64_t)b * d.Hb * d.Wb;
@@ -92,27 +146,54 @@ __global__ __launch_bounds__(256) void up_c1_kernel(pgv_conv_desc d, const float
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw) okc[tw] = (unsigned)(v + 1 - tw) < (unsigned)Ws;
     float a00 = bv, a01 = bv, a10 = bv, a11 = bv;
+    if constexpr (BF16) {
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
-      if (cs < d.Cs) {
-        float x[3][3];
+      for (int c = 0; c < CP; ++c) {
+        if (2 * c < d.Cs) {
+          const bool hi = 2 * c + 1 < d.Cs;
+          unsigned x[3][3];
 #pragma unroll
-        for (int th = 0; th < 3; ++th)
+          for (int th = 0; th < 3; ++th)
 #pragma unroll
-          for (int tw = 0; tw < 3; ++tw) {
-            const float raw = tp[cs * plane - th * Ws - tw];
-            x[th][tw] = okc[tw] ? raw : 0.f;
-          }
-        const float* wc = w + cs * KK;  // [kh][kw], kh = ph + 2 th, kw = pw + 2 tw
+            for (int tw = 0; tw < 3; ++tw) {
+              const float r0 = tp[(2 * c) * plane - th * Ws - tw], r1 = tp[(2 * c + 1) * plane - th * Ws - tw];
+              x[th][tw] = pack_bf16x2(okc[tw] ? r0 : 0.f, (okc[tw] && hi) ? r1 : 0.f);
+            }
+          const unsigned* wc = wr + c * KK;  // [kh][kw], kh = ph + 2 th, kw = pw + 2 tw
 #pragma unroll
-        for (int th = 0; th < 3; ++th)
+          for (int th = 0; th < 3; ++th)
 #pragma unroll
-          for (int tw = 0; tw < 3; ++tw) {
-            a00 = fmaf(x[th][tw], wc[(2 * th) * KS + 2 * tw], a00);
-            if (tw < 2) a01 = fmaf(x[th][tw], wc[(2 * th) * KS + 2 * tw + 1], a01);
-            if (th < 2) a10 = fmaf(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw], a10);
-            if (th < 2 && tw < 2) a11 = fmaf(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw + 1], a11);
-          }
+            for (int tw = 0; tw < 3; ++tw) {
+              a00 = dot2_bf16(x[th][tw], wc[(2 * th) * KS + 2 * tw], a00);
+              if (tw < 2) a01 = dot2_bf16(x[th][tw], wc[(2 * th) * KS + 2 * tw + 1], a01);
+              if (th < 2) a10 = dot2_bf16(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw], a10);
+              if (th < 2 && tw < 2) a11 = dot2_bf16(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw + 1], a11);
+            }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cs = 0; cs < CS; ++cs) {
+        if (cs < d.Cs) {
+          float x[3][3];
+#pragma unroll
+          for (int th = 0; th < 3; ++th)
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+              const float raw = tp[cs * plane - th * Ws - tw];
+              x[th][tw] = okc[tw] ? raw : 0.f;
+            }
+          const float* wc = w + cs * KK;  // [kh][kw], kh = ph + 2 th, kw = pw + 2 tw
+#pragma unroll
+          for (int th = 0; th < 3; ++th)
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+              a00 = fmaf(x[th][tw], wc[(2 * th) * KS + 2 * tw], a00);
+              if (tw < 2) a01 = fmaf(x[th][tw], wc[(2 * th) * KS + 2 * tw + 1], a01);
+              if (th < 2) a10 = fmaf(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw], a10);
+              if (th < 2 && tw < 2) a11 = fmaf(x[th][tw], wc[(2 * th + 1) * KS + 2 * tw + 1], a11);
+            }
+        }
       }
     }
     const int oh = 2 * (u0 + ur), ow = 2 * v;
@@ -179,12 +260,12 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(pgv_conv_desc d, const fl
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh) {
           const float raw = tp[kh * Wb + kw];
-          x[kh * KS + kw] = ok ? raw : 0.f;
+          x[kh * KS + kw] = ok ? pgv_opnd(raw, (d.flags & PGV_COMPUTE_BF16) != 0) : 0.f;
         }
       }
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
-        const float gsm = small_tile[(g * CG + j) * SP + p];  // channels >= Cs are zero planes
+        const float gsm = pgv_opnd(small_tile[(g * CG + j) * SP + p], (d.flags & PGV_COMPUTE_BF16) != 0);
 #pragma unroll
         for (int k = 0; k < KK; ++k) acc[j * KK + k] = fmaf(gsm, x[k], acc[j * KK + k]);
       }
@@ -219,13 +300,14 @@ int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* 
   int plane = 0;
   for (; R >= 1; --R) {
     plane = ((2 * (R - 1) + KS) * d->Wb + 16 + 3) / 4 * 4;
-    bytes = sizeof(float) * (16 + (size_t)plane);
+    bytes = sizeof(float) * (16 + (size_t)plane + 8 * KP);
     if (bytes <= 40 * 1024 || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
-  auto kern = down_c1_kernel<8>;
-  static bool attr_done = false;
-  int rc = raise_lds_limit(kern, &attr_done, "conv_down_direct");
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? down_c1_kernel<8, true> : down_c1_kernel<8, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_down_direct");
   if (rc) return rc;
   dim3 grid((unsigned)pgv_cdiv(d->Hs, R), (unsigned)d->B);
   hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, *d, big, in_scale, in_shift, w, bias, act, slope, out, R, plane);
@@ -243,13 +325,14 @@ int pgv_conv_up_direct(const pgv_conv_desc* d, const float* small_in, const floa
   int plane = 0;
   for (; R >= 1; --R) {
     plane = ((R + 2) * d->Ws + 16 + 3) / 4 * 4;
-    bytes = sizeof(float) * (16 + 16 + (size_t)8 * plane);
+    bytes = sizeof(float) * (16 + 16 + (size_t)8 * plane + 4 * KK);
     if (bytes <= 40 * 1024 || R == 1) break;
   }
   if (bytes > (size_t)kMaxLds) return 0;
-  auto kern = up_c1_kernel<8>;
-  static bool attr_done = false;
-  int rc = raise_lds_limit(kern, &attr_done, "conv_up_direct");
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? up_c1_kernel<8, true> : up_c1_kernel<8, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_up_direct");
   if (rc) return rc;
   dim3 grid((unsigned)pgv_cdiv(Hg, R), (unsigned)d->B);
   hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, *d, small_in, in_scale, in_shift, w, bias, act, slope, out, R,

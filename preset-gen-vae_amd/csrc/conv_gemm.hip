@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void conv_down_gemm_kernel(pgv_conv_desc d, co
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t.As[k_local][q0 + 16 * j] = ra[j];
-      t.Bs[(KS == 4) ? 4 * j + i0 : i0 + 4 * j][n_local] = rb[j];
+      t.As[k_local][q0 + 16 * j] = pgv_opnd(ra[j], (d.flags & PGV_COMPUTE_BF16) != 0);
+      t.Bs[(KS == 4) ? 4 * j + i0 : i0 + 4 * j][n_local] = pgv_opnd(rb[j], (d.flags & PGV_COMPUTE_BF16) != 0);
     }
     __syncthreads();
     if (s + 1 < nslab) load(s + 1);
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256) void conv_up_gemm_kernel(pgv_conv_desc d, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int krow = (KS == 4) ? 4 * j + i0 : i0 + 4 * j;
-      t.As[krow][m_local] = ra[j];
-      t.Bs[krow][n_local] = rb[j];
+      t.As[krow][m_local] = pgv_opnd(ra[j], (d.flags & PGV_COMPUTE_BF16) != 0);
+      t.Bs[krow][n_local] = pgv_opnd(rb[j], (d.flags & PGV_COMPUTE_BF16) != 0);
     }
     __syncthreads();
     if (s + 1 < nslab) load(s + 1);
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_gemm_kernel(pgv_conv_desc d, c
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t.As[k_local][q0 + 16 * j] = ra[j];
-      t.Bs[k_local][q0 + 16 * j] = rb[j];
+      t.As[k_local][q0 + 16 * j] = pgv_opnd(ra[j], (d.flags & PGV_COMPUTE_BF16) != 0);
+      t.Bs[k_local][q0 + 16 * j] = pgv_opnd(rb[j], (d.flags & PGV_COMPUTE_BF16) != 0);
     }
     __syncthreads();
     if (k0 + BK < kend) load(k0 + BK);

@@ -22,6 +22,7 @@ __global__ void conv_down_generic(pgv_conv_desc d, const float* __restrict__ big
   const int cs = t % d.Cs;
   const int b = t / d.Cs;
   float acc = bias ? bias[cs] : 0.f;
+  const bool bf = (d.flags & PGV_COMPUTE_BF16) != 0;
   const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
   for (int cb = 0; cb < d.Cb; ++cb) {
     const float sc = in_scale ? in_scale[cb] : 1.f, sh = in_shift ? in_shift[cb] : 0.f;
@@ -33,7 +34,7 @@ __global__ void conv_down_generic(pgv_conv_desc d, const float* __restrict__ big
       for (int kw = 0; kw < d.kw; ++kw) {
         const int iw = iw0 + kw;
         if (iw < 0 || iw >= d.Wb) continue;
-        acc = fmaf(fmaf(plane[ih * d.Wb + iw], sc, sh), wk[kh * d.kw + kw], acc);
+        acc = fmaf(pgv_opnd(fmaf(plane[ih * d.Wb + iw], sc, sh), bf), pgv_opnd(wk[kh * d.kw + kw], bf), acc);
       }
     }
   }
@@ -53,6 +54,7 @@ __global__ void conv_up_generic(pgv_conv_desc d, const float* __restrict__ small
   const int cb = t % d.Cb;
   const int b = t / d.Cb;
   float acc = bias ? bias[cb] : 0.f;
+  const bool bf = (d.flags & PGV_COMPUTE_BF16) != 0;
   for (int cs = 0; cs < d.Cs; ++cs) {
     const float sc = in_scale ? in_scale[cs] : 1.f, sh = in_shift ? in_shift[cs] : 0.f;
     const float* plane = small_in + ((int64_t)b * d.Cs + cs) * d.Hs * d.Ws;
@@ -67,7 +69,7 @@ __global__ void conv_up_generic(pgv_conv_desc d, const float* __restrict__ small
         if (tw < 0 || tw % d.stride) continue;
         const int ow = tw / d.stride;
         if (ow >= d.Ws) continue;
-        acc = fmaf(fmaf(plane[oh * d.Ws + ow], sc, sh), wk[kh * d.kw + kw], acc);
+        acc = fmaf(pgv_opnd(fmaf(plane[oh * d.Ws + ow], sc, sh), bf), pgv_opnd(wk[kh * d.kw + kw], bf), acc);
       }
     }
   }
@@ -99,7 +101,8 @@ __global__ void conv_wgrad_generic(pgv_conv_desc d, const float* __restrict__ bi
     int64_t t = p / d.Ws;
     const int oh = t % d.Hs;
     const int b = t / d.Hs;
-    const float g = fmaf(small_in[(((int64_t)b * d.Cs + cs) * d.Hs + oh) * d.Ws + ow], ssc, ssh);
+    const bool bf = (d.flags & PGV_COMPUTE_BF16) != 0;
+    const float g = pgv_opnd(fmaf(small_in[(((int64_t)b * d.Cs + cs) * d.Hs + oh) * d.Ws + ow], ssc, ssh), bf);
     const float* plane = big + ((int64_t)b * d.Cb + cb) * d.Hb * d.Wb;
     const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
 #pragma unroll
@@ -107,7 +110,7 @@ __global__ void conv_wgrad_generic(pgv_conv_desc d, const float* __restrict__ bi
       if (k < kk) {
         const int ih = ih0 + k / d.kw, iw = iw0 + k % d.kw;
         if (ih >= 0 && ih < d.Hb && iw >= 0 && iw < d.Wb)
-          acc[k] = fmaf(g, fmaf(plane[ih * d.Wb + iw], bsc, bsh), acc[k]);
+          acc[k] = fmaf(g, pgv_opnd(fmaf(plane[ih * d.Wb + iw], bsc, bsh), bf), acc[k]);
       }
     }
   }

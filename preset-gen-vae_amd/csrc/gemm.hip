@@ -28,7 +28,8 @@ template <bool A_KFAST, bool B_NFAST>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int64_t sam,
                                                    int64_t sak, const float* __restrict__ Bm, int64_t sbk,
                                                    int64_t sbn, float* __restrict__ C, int64_t ldc,
-                                                   const float* __restrict__ bias_n, int k_per_split, int atomic) {
+                                                   const float* __restrict__ bias_n, int k_per_split, int atomic,
+                                                   int bf16) {
   __shared__ float As[BK][LDP];
   __shared__ float Bs[BK][LDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      As[a_k[i]][a_m[i]] = ra[i];
-      Bs[b_k[i]][b_n[i]] = rb[i];
+      As[a_k[i]][a_m[i]] = pgv_opnd(ra[i], bf16 != 0);  // PGV_COMPUTE_BF16: operand precision of the product
+      Bs[b_k[i]][b_n[i]] = pgv_opnd(rb[i], bf16 != 0);
     }
     __syncthreads();
     if (k0 + BK < kend) load_slab(k0 + BK);
@@ -112,7 +113,7 @@ extern "C" {
 int64_t pgv_gemm_workspace(int, int, int) { return 0; }
 
 int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-             float* C, int64_t ldc, const float* bias_n, void* /*workspace*/, int64_t /*workspace_bytes*/,
+             float* C, int64_t ldc, const float* bias_n, int flags, void* /*workspace*/, int64_t /*workspace_bytes*/,
              void* stream) {
   PGV_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && A && B && C && ldc >= N, "pgv_gemm: bad argument");
   if (M == 0) return PGV_OK;
@@ -134,7 +135,7 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
   const bool akf = (sak == 1), bnf = (sbn == 1);
 #define LAUNCH(AK, BNF)                                                                                         \
   hipLaunchKernelGGL((gemm_kernel<AK, BNF>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, \
-                     bias_n, k_per_split, atomic)
+                     bias_n, k_per_split, atomic, (flags & PGV_COMPUTE_BF16) ? 1 : 0)
   if (akf && bnf)
     LAUNCH(true, true);
   else if (akf)

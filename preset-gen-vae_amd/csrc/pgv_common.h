@@ -90,6 +90,11 @@ __device__ __forceinline__ float pgv_act_apply(float y, const pgv_act_params& p)
   return fminf(p.hi, fmaxf(p.lo, r));
 }
 
+// Operand precision of a product (PGV_COMPUTE_BF16): kernels without a bf16 MFMA loop round their operands to bfloat16
+// (RNE) and keep multiplying on the fp32 pipe - products of bf16 values are exact in fp32, so the result differs from
+// the bf16 matrix cores only by the fp32 summation order.
+__device__ __forceinline__ float pgv_opnd(float x, bool bf16) { return bf16 ? (float)(__bf16)x : x; }
+
 __device__ __forceinline__ float pgv_act(float y, int act, float slope) {
   if (act == PGV_ACT_LEAKY_RELU) return y > 0.f ? y : slope * y;
   if (act == PGV_ACT_HARDTANH) return fminf(1.f, fmaxf(-1.f, y));

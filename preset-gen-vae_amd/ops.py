@@ -208,8 +208,8 @@ def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=No
 
 def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None):
     _chk(A, Bm, C, bias_n)
-    _lib.check(_lib.load().pgv_gemm(M, N, K, _p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), ldc, _p(bias_n), None, 0,
-                                    _stream()), "pgv_gemm")
+    _lib.check(_lib.load().pgv_gemm(M, N, K, _p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), ldc, _p(bias_n),
+                                    _COMPUTE_FLAGS, None, 0, _stream()), "pgv_gemm")
     return C
 
 

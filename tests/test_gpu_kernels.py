@@ -143,6 +143,99 @@ def test_band_kernels_many_units(ops, case):
     assert rel_l2(gw2, gw) < 1e-5       # float atomics: run-to-run differences stay at rounding level
 
 
+def _bf16(t):
+    return t.float().bfloat16().double()
+
+
+def _affine_fma(t, sc, sh):
+    """fmaf(x, scale, shift) as the kernels' loaders evaluate it: one rounding to float32."""
+    return (t.float().double() * sc.float().double().view(1, -1, 1, 1) + sh.float().double().view(1, -1, 1, 1)).float()
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16_operand_mode(ops, case, policy):
+    """PGV_COMPUTE_BF16 (BASELINE config 2): both operands of every product rounded to bfloat16 (after the lazy
+    normalisation), float32 accumulation — against float64 convolutions of the rounded operands.  Products of bf16
+    values are exact in float32, so the tolerance is the fp32 accumulation's, not bf16's."""
+    from preset_gen_vae_amd import _lib
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    ops.set_compute_dtype('bf16')
+    try:
+        assert ops.compute_dtype() == 'bf16'
+        bias_s64, bias_b64 = bias_s.float().double(), bias_b.float().double()
+        big_n, small_n = _bf16(_affine_fma(big, sc_b, sh_b)), _bf16(_affine_fma(small, sc_s, sh_s))
+        ref = F.leaky_relu(F.conv2d(big_n, _bf16(w), bias_s64, stride=s, padding=p), 0.1)
+        ref_fp32 = F.leaky_relu(F.conv2d(_affine(big, sc_b, sh_b), w, bias_s, stride=s, padding=p), 0.1)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b))
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(got, ref_fp32) > 2e-4          # the mode really rounds (bf16 operand noise ~ 2^-9 / term)
+        oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+        ref = F.conv_transpose2d(small_n, _bf16(w), bias_b64, stride=s, padding=p, output_padding=(oph, opw))
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_NONE, 0.0, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s))
+        assert rel_l2(got, ref) < 1e-5
+        # without the lazy normalisation (the input-gradient form)
+        got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+        ref = F.conv_transpose2d(_bf16(small), _bf16(w), None, stride=s, padding=p, output_padding=(oph, opw))
+        assert rel_l2(got, ref) < 1e-5
+        got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+        assert rel_l2(got, F.conv2d(_bf16(big), _bf16(w), None, stride=s, padding=p)) < 1e-5
+        # weight gradient: both the (normalised) layer input and the output gradient are rounded
+        wv = w.double().clone().requires_grad_(True)
+        F.conv2d(big_n, wv, None, stride=s, padding=p).backward(_bf16(small))
+        gw = torch.empty((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, big_scale=dev(sc_b), big_shift=dev(sh_b))
+        assert rel_l2(gw, wv.grad) < 5e-5
+        wv = w.double().clone().requires_grad_(True)
+        F.conv2d(_bf16(big), wv, None, stride=s, padding=p).backward(small_n)
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, small_scale=dev(sc_s), small_shift=dev(sh_s))
+        assert rel_l2(gw, wv.grad) < 5e-5
+    finally:
+        ops.set_compute_dtype('fp32')
+        lib.pgv_set_kernel_policy(0)
+    assert ops.compute_dtype() == 'fp32'
+
+
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64),
+                                  (32, 64, 4, 2, 2, 33, 45, 70)])
+def test_band_kernels_bf16_many_units(ops, case):
+    """The bf16 MFMA loops of the persistent band kernels over many work units per workgroup (register prefetch
+    ping-pong, per-workgroup BN statistics, fused BN-backward projections all keep their fp32 forms)."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    ops.set_compute_dtype('bf16')
+    try:
+        big_n, small_n = _bf16(_affine_fma(big, sc_b, sh_b)), _bf16(_affine_fma(small, sc_s, sh_s))
+        ref = F.leaky_relu(F.conv2d(big_n, _bf16(w), bias_s.float().double(), stride=s, padding=p), 0.1)
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+        ref = F.leaky_relu(F.conv_transpose2d(small_n, _bf16(w), bias_b.float().double(), stride=s, padding=p,
+                                              output_padding=(oph, opw)), 0.1)
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        wv = w.double().clone().requires_grad_(True)
+        F.conv2d(big_n, wv, None, stride=s, padding=p).backward(_bf16(small))
+        gw = torch.empty((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, big_scale=dev(sc_b), big_shift=dev(sh_b))
+        assert rel_l2(gw, wv.grad) < 5e-5
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 2), (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3),
                                   (3, 5, 4, 2, 2, 10, 13, 2)])
 def test_conv_prezeroed_outputs_accumulate(ops, case):
@@ -208,7 +301,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 3
+    assert _lib.load().pgv_abi_version() == 4
 
 
 def test_empty_batch(ops):
@@ -295,6 +388,27 @@ def test_linear_gemm(ops, mnk):
     assert rel_l2(gb, br.grad) < 1e-5
 
 
+def test_linear_gemm_bf16_operand_mode(ops):
+    """pgv_gemm flags = PGV_COMPUTE_BF16: the three nn.Linear products with bf16-rounded operands."""
+    M, N, K = 64, 128, 24576
+    x = synth_vec((M, K), 0.771, 0.3)
+    w = synth_vec((N, K), 0.613, 0.8) / np.sqrt(K)
+    b = synth_vec((N,), 1.1, 0.2)
+    gy = synth_vec((M, N), 0.913, 0.5)
+    dx, dw, db, dgy = dev(x), dev(w), dev(b), dev(gy)
+    ops.set_compute_dtype('bf16')
+    try:
+        y = ops.linear_fwd(dx, dw, db)
+        assert rel_l2(y, _bf16(x) @ _bf16(w).t() + b.float().double()) < 1e-5
+        assert rel_l2(y, F.linear(x, w, b)) > 2e-4
+        assert rel_l2(ops.linear_dgrad(dgy, dw), _bf16(gy) @ _bf16(w)) < 1e-5
+        gw = torch.empty_like(dw)
+        ops.linear_wgrad(dgy, dx, gw)
+        assert rel_l2(gw, _bf16(gy).t() @ _bf16(x)) < 1e-5
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 def test_reparam_kl_and_sqerr(ops):
     from oracle import vae_oracle as vo
     B, D = 37, 64
@@ -371,6 +485,80 @@ def test_rng_distributions(ops):
     assert abs((e ** 4).mean().item() - 3.0) < 0.1
     rng_b = DeviceRNG(torch.device('cuda'), seed=42)
     assert torch.equal(rng_b.dropout_mask(0.3, (256, 24576)), m1)   # reproducible from the seed
+
+
+@pytest.mark.parametrize("kind", ["conv", "tconv"])
+def test_block_chain_bf16_vs_oracle(ops, kind):
+    """Two product blocks chained (so the second one folds the first one's BatchNorm into its loader and rounds the
+    NORMALISED operand) in PGV_COMPUTE_BF16 mode, forward and backward, against the oracle's blocks run with
+    operand_precision('bf16') on the same inputs.  Short chains on purpose: operand rounding is discontinuous, so
+    float32 noise upstream moves a few operands across a bf16 boundary downstream (measured: +1 decade per block) and
+    an 8-block end-to-end comparison can only be statistical (tests/test_gpu_vae.py)."""
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd.model import layer
+    import torch.nn as nn
+    B = 3
+    if kind == 'conv':
+        rows = [('enc2', 8, 16, 4, 2, 2, True), ('enc3', 16, 32, 4, 2, 2, True)]
+        blocks = [layer.Conv2D(r[1], r[2], [4, 4], [2, 2], 2, [1, 1], activation=nn.LeakyReLU(0.1), name_prefix=r[0],
+                               batch_norm='after') for r in rows]
+        x = synth_vec((B, 8, 65, 88), 0.613, 0.4) * 1.3
+        scope = 'enc.'
+    else:
+        rows = [('dec6', 32, 16, 4, 2, 2, (1, 0), True), ('dec7', 16, 8, 4, 2, 2, (1, 0), True)]
+        blocks = [layer.TConv2D(r[1], r[2], [4, 4], [2, 2], 2, output_padding=list(r[6]),
+                                activation=nn.LeakyReLU(0.1), name_prefix=r[0], batch_norm='after') for r in rows]
+        x = synth_vec((B, 32, 33, 45), 0.613, 0.4) * 1.3
+        scope = 'dec.'
+    sd = {}
+    for i, blk in enumerate(blocks):
+        for k, v in blk.state_dict().items():
+            if v.dtype != torch.long:
+                v = synth_vec(tuple(v.shape), 0.37 + 0.11 * i + 0.01 * len(k), 0.3)
+                v = (v * (1.0 / np.sqrt(v[0].numel())) if v.dim() == 4 else
+                     (1.0 + 0.2 * v if k.endswith('bn.weight') else (0.5 + 0.3 * v.abs() if 'var' in k else 0.1 * v)))
+            sd[scope + k] = v.float()
+        blk.load_state_dict({k: sd[scope + k] for k in blk.state_dict()})
+        blocks[i] = blk.float().cuda().train()
+    block_fn = vo.conv_block if kind == 'conv' else vo.tconv_block
+    gy = None
+
+    def oracle(dtype):
+        nonlocal gy
+        xo = x.float().to(dtype).clone().requires_grad_(True)
+        po = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype != torch.long and 'running' not in k}
+        full = {k: (v if v.dtype == torch.long else v.to(dtype)) for k, v in sd.items()}
+        full.update(po)
+        with vo.operand_precision('bf16'):
+            h = xo
+            for r in rows:
+                h = block_fn(h, full, r, scope, True, {})
+            if gy is None:
+                gy = synth_vec(tuple(h.shape), 0.877, 0.2).float()
+            h.backward(gy.to(dtype))
+        return h.detach(), xo.grad, {k: v.grad for k, v in po.items()}
+
+    # the oracle on the same float32 inputs, evaluated in float32 and in float64: their distance is the arithmetic's
+    # own sensitivity to float32-level noise (operands crossing a bf16 boundary), the unit of the tolerances below
+    h, gx, gp = oracle(torch.float32)
+    h64, gx64, gp64 = oracle(torch.float64)
+    xd = dev(x).requires_grad_(True)
+    ops.set_compute_dtype('bf16')
+    try:
+        y = layer.run_stack(xd, [b._pgv_block for b in blocks], True)
+        y.backward(dev(gy))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype('fp32')
+    assert rel_l2(y, h) < 3 * max(rel_l2(h64, h), 1e-5)
+    assert rel_l2(xd.grad, gx) < 3 * max(rel_l2(gx64, gx), 2e-5)
+    for blk in blocks:
+        for k, v in blk.named_parameters():
+            ref = gp[scope + k]
+            if ref.abs().max() < 1e-7:      # (a zero gradient has no relative error)
+                continue
+            assert rel_l2(v.grad, ref) < 3 * max(rel_l2(gp64[scope + k], ref), 2e-5), k
 
 
 def test_layer_blocks_against_reference_goldens(ops):

@@ -7,6 +7,7 @@ larger.  That noise is measured in the test by running the oracle's torch-CPU fl
 at B=2 the deepest BatchNorms see only 24 values per channel (3x4 pixels x 2 items) with variances down to 5e-5, so
 the reference's own float32 run differs from float64 by ~1e-4 (z) / ~3e-3 (x_out) there; a float32 implementation
 cannot be closer to the float64 goldens than that, and the HIP path is required to be as close as torch-CPU fp32 is."""
+import numpy as np
 import pytest
 import torch
 
@@ -195,9 +196,9 @@ def test_train_step_parity(name):
 
 
 def test_train_step_dz512_vs_oracle():
-    """BASELINE config 2 shape (8-layer stack, z = 512) in fp32 — the bf16 arithmetic of that config is not built yet,
-    see DESIGN.md §7 — against the float64 oracle evaluated here (no golden file: the oracle is pinned by the z = 64
-    goldens of the same architecture)."""
+    """BASELINE config 2 shape (8-layer stack, z = 512) in fp32 (the bf16 arithmetic of that config is the next test)
+    against the float64 oracle evaluated here (no golden file: the oracle is pinned by the z = 64 goldens of the same
+    architecture)."""
     from oracle import vae_oracle as vo
     from preset_gen_vae_amd.train_step import VAETrainStep
     arch, dim_z, B = 'speccnn8l1_bn', 512, 2
@@ -225,6 +226,61 @@ def test_train_step_dz512_vs_oracle():
             continue
         r, noise = rel_l2(params[k].grad, gr), rel_l2(ora32['grads'][k], gr)
         assert r < max(5e-3, 4 * noise), (k, r, noise)
+
+
+@pytest.mark.parametrize("arch,dim_z", [('speccnn8l1_bn', 512), ('speccnn4l1_bn', 64)])
+def test_train_step_bf16_operand_mode_vs_oracle(arch, dim_z):
+    """BASELINE config 2 arithmetic: bf16 matrix-core products (operands rounded to bfloat16, fp32 accumulation),
+    everything else fp32 — the whole train step against the oracle run in the same operand precision
+    (oracle.vae_oracle.operand_precision).
+
+    Operand rounding is discontinuous: float32-level differences upstream move a few operands across a bf16 boundary
+    downstream, a 2^-8 relative change each, and the difference grows about a decade per block until it saturates at
+    the bf16 noise floor.  That is a property of the arithmetic, not of an implementation: the oracle evaluated in
+    float32 and the same oracle evaluated in float64 differ by exactly that (measured below as ``self_noise``).  So
+    the end-to-end bar is statistical - the product is as close to the oracle as the oracle is to itself (factor 3) -
+    while the exact per-product check (1e-5) is in tests/test_gpu_kernels.py (test_conv_bf16_operand_mode,
+    test_block_chain_bf16_vs_oracle), where inputs are identical."""
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd import ops
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    B = 2
+    ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
+    sd64 = _load_closed_form(ae, arch, dim_z, False, 4321)
+    ae = ae.cuda().train()
+    x = synth_input(B)
+    eps = torch.sin(torch.arange(B * dim_z, dtype=torch.float64) * 0.37 + 0.2).reshape(B, dim_z) * 1.1
+    sd32 = {k: (v if v.dtype == torch.long else v.float()) for k, v in sd64.items()}
+    ops.set_compute_dtype('bf16')
+    try:
+        step = VAETrainStep(ae, lr=2e-4, weight_decay=1e-4, beta=0.2, normalize_losses=True)
+        out = step.step(_cuda32(x), inject={'eps': _cuda32(eps)})
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype('fp32')
+    kw = dict(beta=0.2, lr=2e-4, weight_decay=1e-4)
+    with vo.operand_precision('bf16'):
+        ora = vo.train_step(sd32, x.float(), arch, dim_z, eps.float(), None, None, **kw)
+        ora64 = vo.train_step(sd64, x, arch, dim_z, eps, None, None, **kw)
+    ora_fp32 = vo.train_step(sd32, x.float(), arch, dim_z, eps.float(), None, None, **kw)
+    for key in ('z_mu_logvar', 'x_out'):
+        err, self_noise = rel_l2(out[key], ora[key]), rel_l2(ora64[key], ora[key])
+        assert err < 3 * max(self_noise, 1e-4), (key, err, self_noise)
+    # the latent code (4 / 8 blocks deep) is still far closer to the bf16 oracle than the fp32 mode is
+    assert rel_l2(out['z_mu_logvar'], ora['z_mu_logvar']) < 0.5 * rel_l2(ora_fp32['z_mu_logvar'], ora['z_mu_logvar'])
+    for key in ('recons', 'latent', 'total'):
+        ref = ora[key].item()
+        self_noise = abs(ora64[key].item() - ref) / abs(ref)
+        assert abs(out[key].item() - ref) <= 3 * max(self_noise, 1e-4) * abs(ref), (key, out[key].item(), ref)
+    params = dict(ae.named_parameters())
+    errs, noises = [], []
+    for k, gr in ora['grads'].items():
+        if gr.abs().max().item() < 1e-9:
+            continue
+        errs.append(rel_l2(params[k].grad, gr))
+        noises.append(rel_l2(ora64['grads'][k], gr))
+    assert np.median(errs) < 3 * max(np.median(noises), 1e-4), (np.median(errs), np.median(noises))
+    assert max(errs) < 3 * max(max(noises), 1e-3), (max(errs), max(noises))
 
 
 def test_train_step_stacked_channels_f3():
