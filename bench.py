@@ -41,6 +41,8 @@ def parse():
                     help="operand precision of the conv / linear products (bf16 = BASELINE config 2's arithmetic: bf16 "
                          "matrix cores, fp32 accumulation and storage); the default line is fp32")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--dist-graph", action="store_true",
+                    help="N > 1: replay [fwd+bwd] and [Adam] as two hipGraphs around an eager, non-overlapped all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -262,7 +264,10 @@ def main():
     torch.manual_seed(1234 + rank)     # per-rank eps / dropout streams
     x = synth_spectrograms(args.batch, device, seed=rank)
 
-    use_graph = (not args.no_graph) and world == 1
+    # N = 1: one hipGraph per step.  N > 1: eager launches with the bucketed all-reduce overlapped with backward (the
+    # step is GPU-bound either way: eager and graph replay measure the same at N = 1); --dist-graph selects the
+    # two-graphs-around-the-exchange mode of train_step.py instead
+    use_graph = (not args.no_graph) and (world == 1 or args.dist_graph)
     sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=4)) if world > 1 else None
     step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
                         beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
@@ -312,7 +317,9 @@ def main():
             "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
                                    f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": "hipGraph" if use_graph else "eager", "final_loss": round(loss, 6)},
+                       "launch": (("hipGraph" if world == 1 else "2 hipGraphs + eager all-reduce") if use_graph
+                                  else "eager"),
+                       "final_loss": round(loss, 6)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if table is not None:

@@ -75,6 +75,13 @@ class GradAllReduce:
         else:  # gloo / CPU tests
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def exchange(self):
+        """All buckets at once, after everything already queued on the compute stream (the graph launch mode: the
+        backward graph has been replayed, the Adam graph follows): launch the all-reduces on the communication stream
+        and make the compute stream wait for them.  Asynchronous with respect to the host."""
+        self.start_step()
+        self.wait()
+
     def wait(self):
         """Flush buckets whose parameters produced no gradient this step, then join communication."""
         for bi in range(len(self.ranges)):

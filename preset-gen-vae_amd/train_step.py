@@ -6,7 +6,17 @@
 Everything between the input tensor and the updated parameters runs in the HIP kernels; this class only sequences
 them, optionally capturing the whole step into one hipGraph (``torch.cuda.CUDAGraph`` records the launches our C ABI
 makes on the capturing stream) so the ~100 launches replay without host involvement, and optionally exchanging
-gradients across ranks (``parallel.GradAllReduce``)."""
+gradients across ranks (``parallel.GradAllReduce``).
+
+Launch modes:
+  eager, 1 rank      every kernel launched from Python;
+  graph, 1 rank      one hipGraph = zero_grad + forward + losses + backward + Adam;
+  eager, N ranks     bucketed all-reduce launched from gradient-ready hooks, overlapped with the rest of backward;
+  graph, N ranks     two hipGraphs around an eagerly launched exchange: [zero_grad + forward + losses + backward],
+                     the bucketed all-reduce on the communication stream, [Adam].  No collective is captured (the
+                     exchange stays an ordinary RCCL launch), the ~100 compute launches still replay from the device;
+                     what is given up is the overlap of the exchange with backward (a 20-50 MB all-reduce over xGMI,
+                     a fraction of the ~0.7 ms of host launch time the graphs save)."""
 import torch
 
 from . import optim as optim_mod
@@ -26,7 +36,8 @@ class VAETrainStep:
         if grad_sync is not None:
             self.grad_sync = grad_sync(self.flat) if callable(grad_sync) else grad_sync
             world = self.grad_sync.world_size
-            self.grad_sync.install()
+            if not use_graph:
+                self.grad_sync.install()      # gradient-ready hooks (the graph mode exchanges between its two graphs)
         self.optimizer = optim_mod.FusedAdam(self.flat, lr=lr, betas=betas, weight_decay=weight_decay,
                                              grad_scale=1.0 / world)
         if normalize_losses:   # train.py:103-106
@@ -36,15 +47,23 @@ class VAETrainStep:
         self.controls_criterion = loss_mod.MSELoss(reduction='mean')
         self.use_graph = use_graph
         self._graph = None
+        self._graph_update = None
         self._static_x = None
         self._static_v = None
         self._out = None
 
     # -- one eager step --------------------------------------------------------------------------------------
     def _step_body(self, x, v_in=None, inject=None):
+        out = self._forward_backward(x, v_in, inject, hooks=True)
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+        self.optimizer.step()
+        return out
+
+    def _forward_backward(self, x, v_in=None, inject=None, hooks=False):
         inject = inject or {}
         self.optimizer.zero_grad()
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and hooks:
             self.grad_sync.start_step()
         z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
         recons = self.recons_criterion(x_out, x)
@@ -56,9 +75,6 @@ class VAETrainStep:
             cont = self.controls_criterion(v_out, v_in)
             total = total + cont
         total.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.wait()
-        self.optimizer.step()
         return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(),
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
                 'x_out': x_out.detach()}
@@ -74,6 +90,9 @@ class VAETrainStep:
         if v_in is not None and v_in.data_ptr() != self._static_v.data_ptr():
             self._static_v.copy_(v_in, non_blocking=True)
         self._graph.replay()
+        if self._graph_update is not None:
+            self.grad_sync.exchange()
+            self._graph_update.replay()
         return self._out
 
     @property
@@ -94,5 +113,14 @@ class VAETrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        if self.grad_sync is None:
+            with torch.cuda.graph(self._graph):
+                self._out = self._step_body(self._static_x, self._static_v)
+            return
+        # N ranks: [zero_grad + forward + backward] | eager exchange | [Adam]; the capture itself leaves the parameters
+        # untouched (captured work does not run), so every rank still holds identical replicas afterwards
         with torch.cuda.graph(self._graph):
-            self._out = self._step_body(self._static_x, self._static_v)
+            self._out = self._forward_backward(self._static_x, self._static_v)
+        self._graph_update = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_update):
+            self.optimizer.step()
