@@ -63,6 +63,8 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
       if (rc == 0 && f)  // shape covered, fused epilogue not instantiated for it: plain band kernel + reduce pass
         rc = pgv_conv_down_band(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, nullptr, st);
     }
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_down_deep(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0 && !(d->flags & PGV_COMPUTE_BF16))  // (the runtime-stride MFMA kernels are fp32-only)
       rc = pgv_conv_down_tuned(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0) rc = pgv_conv_down_gemm(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
@@ -105,6 +107,8 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
       if (rc == 0 && f)
         rc = pgv_conv_up_band(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, nullptr, st);
     }
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_up_deep(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0 && !(d->flags & PGV_COMPUTE_BF16))
       rc = pgv_conv_up_tuned(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_gemm(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
@@ -145,6 +149,8 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
     rc = 0;
     if (g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+    if (rc == 0 && g_policy == 0)
+      rc = pgv_conv_wgrad_deep(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0) rc = pgv_conv_wgrad_direct(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0 && !(d->flags & PGV_COMPUTE_BF16))
       rc = pgv_conv_wgrad_tuned(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,

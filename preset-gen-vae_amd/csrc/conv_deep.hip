@@ -1,0 +1,698 @@
+// Raw-plane implicit-GEMM kernels for the DEEP k4 s2 p2 layers of speccnn8l1_bn (enc5..enc7, dec2..dec4;
+// model/encoder.py:249-255, model/decoder.py:205-210): planes of 17x23, 9x12 and 5x7 pixels against 64..512 channels,
+// i.e. K = 1024..4096 - dense contractions whose operands are the weights (up to 8 MB per layer, streamed through LDS
+// in K-slabs) and a few whole input planes per workgroup.
+//
+// Unlike the gather-GEMM of conv_gemm.hip nothing is expanded (im2col) or gathered element-wise from global memory:
+//   * both operands arrive as contiguous 16-byte global loads (a weight row slab W[cs][cb0..cb0+CK][16] is CK*64
+//     contiguous bytes, the CK planes of a sample are CK*H*W contiguous floats), one K-slab ahead of the MFMA loop in
+//     registers, committed to the other half of a double-buffered LDS stage (one barrier per slab);
+//   * planes sit in LDS zero-padded ([ch][sample][HP][WP]), so the B fragment of output pixel n and tap (kh,kw) is
+//     LDS[base(n) + ch*stride + kh*WP + kw]: a per-lane base computed once plus compile-time immediates, and the
+//     zero padding of the convolution needs no masks;
+//   * the MFMA k index is the kernel tap: lane group j = lane>>4 holds kernel row kh = j, so one ds_read_b128 of the
+//     weight row gives the A operands of the four k-steps (kw = 0..3) of a channel.
+// PGV_COMPUTE_BF16: the same tiles, operands packed to bf16 while they are read (v_cvt_pk_bf16_f32), one
+// v_mfma_f32_16x16x16_bf16 per (channel, tile) instead of four fp32 steps.
+#include "conv_tile.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
+// GEMM: M = cs (64 per workgroup, 16 per wave), N = the NS*Hs*Ws output pixels of NS samples, K = (cb, 16 taps).
+template <int H, int W, int NS, int CK>
+struct DeepDown {
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
+  static constexpr int HP = 2 * Hs + 2, WP = 2 * Ws + 2, PLANE = HP * WP;  // rows / cols -2 .. 2*Hs-1 / 2*Ws-1
+  static constexpr int N = NS * P, NT = (N + 15) / 16;
+  static constexpr int AS = CK * 16 + 4;                 // weight row stride: 16-byte aligned, banks spread by 4
+  static constexpr int A_FLOATS = 64 * AS;
+  static constexpr int CH_STRIDE = NS * PLANE;
+  static constexpr int B_FLOATS = CK * CH_STRIDE;
+  static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+  static constexpr int QA = 64 * CK * 4 / 256;           // float4 weight loads per thread per slab
+  static constexpr int QB_ITEMS = NS * CK * HW / 4;      // float4 plane loads per slab (whole workgroup)
+  static constexpr int QB = (QB_ITEMS + 255) / 256;
+  static_assert(CK % 4 == 0 && (CK * HW) % 4 == 0, "16-byte plane runs");
+  static_assert(PLANE % 2 == 0 && WP % 2 == 0, "8-byte aligned tap rows");
+};
+
+template <int H, int W, int NS, int CK, bool BF16>
+__global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                        const float* __restrict__ in_scale,
+                                                        const float* __restrict__ in_shift,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int act, float slope, float* __restrict__ out,
+                                                        double* __restrict__ stats, int groups) {
+  using G = DeepDown<H, W, NS, CK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* aff = lds + 2 * G::STAGE;  // [2*CB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  const int cs0 = mb * 64, b0 = grp * NS;
+
+  // zero both stages' planes once (the data cells are rewritten every slab, the padding never)
+  for (int i = tid; i < G::B_FLOATS; i += 256) {
+    lds[G::A_FLOATS + i] = 0.f;
+    lds[G::STAGE + G::A_FLOATS + i] = 0.f;
+  }
+  stage_affine(aff, in_scale, in_shift, CB, tid);
+
+  // ---- loader coordinates (identical for every slab)
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 256 * i, row = q / (CK * 4), f = q - row * (CK * 4);
+    a_src[i] = (cs0 + row) * CB * 16 + 4 * f;
+    a_dst[i] = row * G::AS + 4 * f;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_ch[G::QB][4];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int si = q / (CK * G::HW / 4), qq = q - si * (CK * G::HW / 4);
+    const int bs = min(b0 + si, B - 1);  // partial last group: duplicate the last sample (masked at the store)
+    b_src[i] = bs * CB * G::HW + 4 * qq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int el = 4 * qq + e, ch = el / G::HW, rem = el - ch * G::HW, r = rem / W, c = rem - r * W;
+      b_ch[i][e] = ch;
+      b_dst[i][e] = ch * G::CH_STRIDE + si * G::PLANE + (r + 2) * G::WP + c + 2;
+    }
+  }
+  // ---- fragment coordinates
+  const int a_frag = (wave * 16 + m) * G::AS + j * 4;
+  int bn[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) {
+    const int n = min(t * 16 + m, G::N - 1);
+    const int si = n / G::P, pix = n - si * G::P, oh = pix / G::Ws, ow = pix - oh * G::Ws;
+    bn[t] = si * G::PLANE + (2 * oh + j) * G::WP + 2 * ow;
+  }
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[G::QA], rb[G::QB];
+  auto issue = [&](int slab) {
+    const int cb0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + cb0 * 16);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(big + b_src[i] + cb0 * G::HW);
+  };
+  auto commit = [&](int slab, float* st) {
+    const int cb0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
+    float* bt = st + G::A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = rb[i][e];
+          if (in_scale) v = fmaf(v, aff[cb0 + b_ch[i][e]], aff[CB + cb0 + b_ch[i][e]]);
+          bt[b_dst[i][e]] = v;
+        }
+      }
+    }
+  };
+
+  const int nslab = CB / CK;
+  issue(0);
+  __syncthreads();  // planes zeroed, affine staged
+  commit(0, lds);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const float* st = lds + (s & 1) * G::STAGE;
+    if (s + 1 < nslab) issue(s + 1);
+    const float* ap = st + a_frag;
+    const float* bp = st + G::A_FLOATS;
+#pragma unroll
+    for (int ch = 0; ch < CK; ++ch) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + ch * 16);
+      if constexpr (BF16) {
+        const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {
+          const float* p = bp + bn[t] + ch * G::CH_STRIDE;
+          const f32x2 lo = *reinterpret_cast<const f32x2*>(p), hi = *reinterpret_cast<const f32x2*>(p + 2);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(lo[0], lo[1], hi[0], hi[1]), acc[t], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kw], bp[bn[t] + ch * G::CH_STRIDE + kw], acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) commit(s + 1, lds + ((s + 1) & 1) * G::STAGE);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[t][i] = channel cs0 + wave*16 + 4j + i, pixel n = t*16 + m
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int c0 = cs0 + wave * 16 + 4 * j;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) {
+    const int n = t * 16 + m;
+    const int si = n / G::P, pix = n - si * G::P;
+    const bool ok = n < G::N && b0 + si < B;
+    float* o = out + ((int64_t)(b0 + si) * CS + c0) * G::P + pix;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = pgv_act_apply(acc[t][i] + bv[i], ap);
+      if (ok) {
+        o[i * G::P] = v;
+        s1[i] += v;
+        s2[i] += v * v;
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+      if (m == 0) {
+        atomicAdd(&stats[c0 + i], (double)a1);
+        atomicAdd(&stats[CS + c0 + i], (double)a2);
+      }
+    }
+  }
+}
+
+template <int H, int W, int NS, int CK>
+int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                     hipStream_t st) {
+  using G = DeepDown<H, W, NS, CK>;
+  if (d->Cs % 64 || d->Cb % CK) return 0;
+  const size_t bytes = sizeof(float) * (2 * G::STAGE + 2 * (size_t)d->Cb + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? deep_down_kernel<H, W, NS, CK, true> : deep_down_kernel<H, W, NS, CK, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_down_deep");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_deep: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big,
+                     in_scale, in_shift, w, bias, act, slope, out, stats, groups);
+  PGV_CHECK_LAUNCH("conv_down_deep");
+  return 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// UP: out[b,cb,ih,iw] = act(bias[cb] + sum_{cs,kh,kw} w[cs,cb,kh,kw] * s'[b,cs,oh,ow]),  ih = 2oh-2+kh, iw = 2ow-2+kw.
+// Output pixel (ih,iw) = (2u+ph, 2v+pw) only meets the taps kh = ph+2th, kw = pw+2tw (th,tw in {0,1}) at
+// oh = u+1-th, ow = v+1-tw: four 2x2-tap convolutions, one per output phase.  GEMM: M = cb (64 per workgroup),
+// K = (cs, 4 taps), N = the output pixels of NS samples, listed phase by phase (each 16-pixel tile belongs to one
+// phase, so its weight taps are compile-time).  Weights are permuted to [cs][cb][phase][tap] while they are committed.
+template <int H, int W, int NS, int CK>
+struct DeepUp {
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
+  static constexpr int SWP = Ws + 1, SPLANE = ((Hs + 1) * SWP + 1) / 2 * 2;  // zero row below / column right
+  static constexpr int hu(int p) { return (p >> 1) ? H / 2 : (H + 1) / 2; }
+  static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
+  static constexpr int cnt(int p) { return NS * hu(p) * wu(p); }
+  static constexpr int ntp(int p) { return (cnt(p) + 15) / 16; }
+  static constexpr int tile0(int p) { return p == 0 ? 0 : tile0(p - 1) + ntp(p - 1); }
+  static constexpr int NT = tile0(4);
+  static constexpr int AS = 20;                          // floats per (cs, cb) weight row: 16 + 4
+  static constexpr int ACS = 64 * AS;                    // per small channel
+  static constexpr int A_FLOATS = CK * ACS;
+  static constexpr int CH_STRIDE = NS * SPLANE;
+  static constexpr int B_FLOATS = CK * CH_STRIDE;
+  static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+  static constexpr int QA = CK * 64 * 4 / 256;
+  static constexpr int QB_ITEMS = NS * CK * P / 4;
+  static constexpr int QB = (QB_ITEMS + 255) / 256;
+  static_assert(CK % 4 == 0 && (CK * P) % 4 == 0, "16-byte plane runs");
+};
+
+template <int H, int W, int NS, int CK, bool BF16>
+__global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, const float* __restrict__ small_in,
+                                                      const float* __restrict__ in_scale,
+                                                      const float* __restrict__ in_shift,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int act, float slope, float* __restrict__ out,
+                                                      double* __restrict__ stats, int groups) {
+  using G = DeepUp<H, W, NS, CK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* aff = lds + 2 * G::STAGE;  // [2*CS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  const int cb0 = mb * 64, b0 = grp * NS;
+
+  for (int i = tid; i < G::B_FLOATS; i += 256) {
+    lds[G::A_FLOATS + i] = 0.f;
+    lds[G::STAGE + G::A_FLOATS + i] = 0.f;
+  }
+  stage_affine(aff, in_scale, in_shift, CS, tid);
+
+  // ---- loaders: weights W[cs][cb0+row][16] (one float4 = the four kw of a kernel row kh), planes s[b][cs][P]
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 256 * i, c = q / 256, r = q - c * 256, row = r >> 2, kh = r & 3;
+    a_src[i] = (c * CB + cb0 + row) * 16 + 4 * kh;
+    // (kh, kw) -> phase (kh&1)*2 + (kw&1), tap (kh>>1)*2 + (kw>>1): element kw of this float4 goes to
+    // a_dst + (kw&1)*4 + (kw>>1)
+    a_dst[i] = c * G::ACS + row * G::AS + (kh & 1) * 8 + (kh >> 1) * 2;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_ch[G::QB][4];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int si = q / (CK * G::P / 4), qq = q - si * (CK * G::P / 4);
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = bs * CS * G::P + 4 * qq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int el = 4 * qq + e, ch = el / G::P, rem = el - ch * G::P, r = rem / G::Ws, c = rem - r * G::Ws;
+      b_ch[i][e] = ch;
+      b_dst[i][e] = ch * G::CH_STRIDE + si * G::SPLANE + r * G::SWP + c;
+    }
+  }
+  // ---- fragment coordinates.  fp32: lane group j is the tap (th, tw) = (j>>1, j&1) of one small channel;
+  // bf16: lane group j is small channel 4g + j, the four taps are the lane's four consecutive k values.
+  const int a_frag = (wave * 16 + m) * G::AS + (BF16 ? j * G::ACS : j);
+  int bn[G::NT];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int tt = 0; tt < G::ntp(p); ++tt) {
+      const int n = min(tt * 16 + m, G::cnt(p) - 1);
+      const int per = G::hu(p) * G::wu(p);
+      const int si = n / per, rem = n - si * per, u = rem / G::wu(p), v = rem - u * G::wu(p);
+      const int base = si * G::SPLANE + (u + 1) * G::SWP + v + 1;
+      bn[G::tile0(p) + tt] = BF16 ? base + j * G::CH_STRIDE : base - (j >> 1) * G::SWP - (j & 1);
+    }
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[G::QA], rb[G::QB];
+  auto issue = [&](int slab) {
+    const int cs0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + cs0 * CB * 16);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(small_in + b_src[i] + cs0 * G::P);
+  };
+  auto commit = [&](int slab, float* st) {
+    const int cs0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) {
+      float* a = st + a_dst[i];
+      a[0] = ra[i][0];
+      a[4] = ra[i][1];
+      a[1] = ra[i][2];
+      a[5] = ra[i][3];
+    }
+    float* bt = st + G::A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = rb[i][e];
+          if (in_scale) v = fmaf(v, aff[cs0 + b_ch[i][e]], aff[CS + cs0 + b_ch[i][e]]);
+          bt[b_dst[i][e]] = v;
+        }
+      }
+    }
+  };
+
+  const int nslab = CS / CK;
+  issue(0);
+  __syncthreads();
+  commit(0, lds);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const float* st = lds + (s & 1) * G::STAGE;
+    if (s + 1 < nslab) issue(s + 1);
+    const float* ap = st + a_frag;
+    const float* bp = st + G::A_FLOATS;
+    if constexpr (BF16) {
+#pragma unroll
+      for (int g = 0; g < CK / 4; ++g) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * g * G::ACS + 4 * p);
+          const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+          for (int tt = 0; tt < G::ntp(p); ++tt) {
+            const int t = G::tile0(p) + tt;
+            const float* q = bp + bn[t] + 4 * g * G::CH_STRIDE;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(q[0], q[-1], q[-G::SWP], q[-G::SWP - 1]),
+                                                              acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float a = ap[c * G::ACS + 4 * p];
+#pragma unroll
+          for (int tt = 0; tt < G::ntp(p); ++tt) {
+            const int t = G::tile0(p) + tt;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[bn[t] + c * G::CH_STRIDE], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (s + 1 < nslab) commit(s + 1, lds + ((s + 1) & 1) * G::STAGE);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[t][i] = channel cb0 + wave*16 + 4j + i, pixel n of phase p
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int c0 = cb0 + wave * 16 + 4 * j;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int tt = 0; tt < G::ntp(p); ++tt) {
+      const int t = G::tile0(p) + tt;
+      const int n = tt * 16 + m;
+      const int per = G::hu(p) * G::wu(p);
+      const int si = n / per, rem = n - si * per, u = rem / G::wu(p), v = rem - u * G::wu(p);
+      const bool ok = n < G::cnt(p) && b0 + si < B;
+      float* o = out + ((int64_t)(b0 + si) * CB + c0) * G::HW + (2 * u + (p >> 1)) * W + 2 * v + (p & 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float val = pgv_act_apply(acc[t][i] + bv[i], ap);
+        if (ok) {
+          o[i * G::HW] = val;
+          s1[i] += val;
+          s2[i] += val * val;
+        }
+      }
+    }
+  if (stats) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+      if (m == 0) {
+        atomicAdd(&stats[c0 + i], (double)a1);
+        atomicAdd(&stats[CB + c0 + i], (double)a2);
+      }
+    }
+  }
+}
+
+template <int H, int W, int NS, int CK>
+int launch_deep_up(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                   const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                   hipStream_t st) {
+  using G = DeepUp<H, W, NS, CK>;
+  if (d->Cb % 64 || d->Cs % CK) return 0;
+  const size_t bytes = sizeof(float) * (2 * G::STAGE + 2 * (size_t)d->Cs + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? deep_up_kernel<H, W, NS, CK, true> : deep_up_kernel<H, W, NS, CK, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_up_deep");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_deep: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / 64))), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in,
+                     in_scale, in_shift, w, bias, act, slope, out, stats, groups);
+  PGV_CHECK_LAUNCH("conv_up_deep");
+  return 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD: gw[cs,cb,kh,kw] = sum_{b,oh,ow} s'[b,cs,oh,ow] * x'[b,cb,2oh-2+kh,2ow-2+kw]
+// GEMM: M = cs (64 per workgroup), N = (cb, 16 taps) = one 16-column tile per big channel (CBT per workgroup),
+// K = output pixels, 4 consecutive ow per MFMA (rows of the small plane padded to a multiple of 4 with zeros).
+// A[cs][pixel] from the small planes, B[pixel][tap] straight from the zero-padded raw big planes: lane (tap, j) reads
+// plane[(2oh+kh)*WP + 2(ow0+j) + kw].  A workgroup sweeps its range of samples SB at a time (double-buffered stages,
+// register prefetch), keeps the CBT accumulator tiles in registers and flushes once with float atomics (split-K).
+template <int H, int W, int SB, int CBT, bool BF16>
+struct DeepWgrad {
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
+  static constexpr int WsP = (Ws + 3) / 4 * 4, SPL = Hs * WsP, STEPS = SPL / 4;
+  // bf16: one MFMA covers 4 steps (16 pixels): rows of the A tile padded (with zeros) to whole groups
+  static constexpr int GROUPS = (STEPS + 3) / 4;
+  static constexpr int SROW = BF16 ? 16 * GROUPS + 4  // 16-byte reads, rows 20 / 52 floats apart (mod 64): no conflicts
+                                   : ((SPL % 64 == 12 || SPL % 64 == 44) ? SPL : SPL + 4);  // conflict-free 4-byte reads
+  static constexpr int HP = 2 * Hs + 2, WP = 2 * WsP + 2, PLANE = HP * WP;
+  static constexpr int A_FLOATS = SB * 64 * SROW;
+  static constexpr int B_FLOATS = SB * CBT * PLANE;
+  static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+  static constexpr int QA_ITEMS = SB * 64 * P / 4, QA = (QA_ITEMS + 255) / 256;
+  static constexpr int QB_ITEMS = SB * CBT * HW / 4, QB = (QB_ITEMS + 255) / 256;
+  static_assert(CBT % 4 == 0, "16-byte plane runs");
+};
+
+template <int H, int W, int SB, int CBT, bool BF16>
+__global__ __launch_bounds__(256) void deep_wgrad_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                         const float* __restrict__ big_scale,
+                                                         const float* __restrict__ big_shift,
+                                                         const float* __restrict__ small_in,
+                                                         const float* __restrict__ small_scale,
+                                                         const float* __restrict__ small_shift,
+                                                         float* __restrict__ gw, int nblk, int per_split) {
+  using G = DeepWgrad<H, W, SB, CBT, BF16>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int ks = blockIdx.x / nblk, blk = blockIdx.x - ks * nblk;
+  const int ncb = CB / CBT, mb = blk / ncb, nb = blk - mb * ncb;
+  const int cs0 = mb * 64, cb0 = nb * CBT;
+  const int bbeg = ks * per_split, bend = min(B, bbeg + per_split);
+
+  for (int i = tid; i < 2 * G::STAGE; i += 256) lds[i] = 0.f;  // padding cells (never rewritten) must be zero
+
+  // ---- loaders: s[b][cs0 .. cs0+64][P] and x[b][cb0 .. cb0+CBT][HW], both contiguous per sample
+  int a_src[G::QA], a_dst[G::QA][4], a_ch[G::QA][4];
+  bool a_ok[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = min(tid + 256 * i, G::QA_ITEMS - 1);
+    a_ok[i] = tid + 256 * i < G::QA_ITEMS;
+    const int si = q / (64 * G::P / 4), qq = q - si * (64 * G::P / 4);
+    a_src[i] = si * CS * G::P + 4 * qq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int el = 4 * qq + e, c = el / G::P, pix = el - c * G::P, oh = pix / G::Ws, ow = pix - oh * G::Ws;
+      a_ch[i][e] = c;
+      a_dst[i][e] = (si * 64 + c) * G::SROW + oh * G::WsP + ow;
+    }
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_ch[G::QB][4];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int si = q / (CBT * G::HW / 4), qq = q - si * (CBT * G::HW / 4);
+    b_src[i] = si * CB * G::HW + 4 * qq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int el = 4 * qq + e, c = el / G::HW, rem = el - c * G::HW, r = rem / W, cc = rem - r * W;
+      b_ch[i][e] = c;
+      b_dst[i][e] = (si * CBT + c) * G::PLANE + (r + 2) * G::WP + cc + 2;
+    }
+  }
+  const float* sbase = small_in + (int64_t)cs0 * G::P;
+  const float* xbase = big + (int64_t)cb0 * G::HW;
+  f32x4 ra[G::QA], rb[G::QB];
+  // a stage holds samples b .. b+SB-1; samples at or beyond `bend` are loaded from the last valid one and committed
+  // as zeros on the small side (their products vanish)
+  auto issue = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) {
+      const int si = a_src[i] / (CS * G::P);
+      const int bs = min(b + si, bend - 1);
+      ra[i] = *reinterpret_cast<const f32x4*>(sbase + (int64_t)(bs - si) * CS * G::P + a_src[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int si = b_src[i] / (CB * G::HW);
+      const int bs = min(b + si, bend - 1);
+      rb[i] = *reinterpret_cast<const f32x4*>(xbase + (int64_t)(bs - si) * CB * G::HW + b_src[i]);
+    }
+  };
+  auto commit = [&](int b, float* st) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) {
+      if (a_ok[i]) {
+        const bool live = b + a_src[i] / (CS * G::P) < bend;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = ra[i][e];
+          if (small_scale) v = fmaf(v, small_scale[cs0 + a_ch[i][e]], small_shift[cs0 + a_ch[i][e]]);
+          st[a_dst[i][e]] = live ? v : 0.f;
+        }
+      }
+    }
+    float* bt = st + G::A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = rb[i][e];
+          if (big_scale) v = fmaf(v, big_scale[cb0 + b_ch[i][e]], big_shift[cb0 + b_ch[i][e]]);
+          bt[b_dst[i][e]] = v;
+        }
+      }
+    }
+  };
+
+  // fp32: lane group j = pixel j of a 4-pixel step; bf16: lane group j = step 4g + j of a 16-pixel group, the
+  // lane's four consecutive k values are that step's four pixels
+  const int a_frag = (wave * 16 + m) * G::SROW + (BF16 ? 4 * j : j);
+  const int b_frag = (m >> 2) * G::WP + (m & 3) + (BF16 ? 0 : 2 * j);  // tap (kh, kw) = (m>>2, m&3)
+  int stepoff[BF16 ? G::GROUPS : 1];
+  if constexpr (BF16) {
+#pragma unroll
+    for (int g = 0; g < G::GROUPS; ++g) {
+      const int step = 4 * g + j, oh = (4 * step) / G::WsP, ow0 = 4 * step - oh * G::WsP;
+      stepoff[g] = step < G::STEPS ? 2 * oh * G::WP + 2 * ow0 : 0;  // phantom steps: A is zero, any valid address
+    }
+  }
+  f32x4 acc[CBT];
+#pragma unroll
+  for (int t = 0; t < CBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (bbeg < bend) {
+    issue(bbeg);
+    __syncthreads();
+    commit(bbeg, lds);
+    __syncthreads();
+    int stage = 0;
+    for (int b = bbeg; b < bend; b += SB, stage ^= 1) {
+      const float* st = lds + stage * G::STAGE;
+      const bool more = b + SB < bend;
+      if (more) issue(b + SB);
+      const float* ap = st + a_frag;
+      const float* bp = st + G::A_FLOATS + b_frag;
+#pragma unroll
+      for (int si = 0; si < SB; ++si) {
+        if constexpr (BF16) {
+#pragma unroll
+          for (int g = 0; g < G::GROUPS; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + si * 64 * G::SROW + 16 * g);
+            const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+            for (int t = 0; t < CBT; ++t) {
+              const float* q = bp + (si * CBT + t) * G::PLANE + stepoff[g];
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(q[0], q[2], q[4], q[6]), acc[t], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < G::STEPS; ++i) {
+            const int oh = (4 * i) / G::WsP, ow0 = (4 * i) - oh * G::WsP;
+            const float a = ap[si * 64 * G::SROW + 4 * i];
+#pragma unroll
+            for (int t = 0; t < CBT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[(si * CBT + t) * G::PLANE + 2 * oh * G::WP + 2 * ow0],
+                                                            acc[t], 0, 0, 0);
+          }
+        }
+      }
+      if (more) commit(b + SB, lds + (stage ^ 1) * G::STAGE);
+      __syncthreads();
+    }
+  }
+  // ---- flush: acc[t][i] = gw[cs0 + wave*16 + 4j + i][cb0 + t][tap m]
+#pragma unroll
+  for (int t = 0; t < CBT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      atomicAdd(&gw[((int64_t)(cs0 + wave * 16 + 4 * j + i) * CB + cb0 + t) * 16 + m], acc[t][i]);
+}
+
+template <int H, int W, int SB, int CBT>
+int launch_deep_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                      hipStream_t st) {
+  if (d->Cs % 64 || d->Cb % CBT) return 0;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  const size_t bytes = sizeof(float) * 2 * (size_t)(bf16 ? DeepWgrad<H, W, SB, CBT, true>::STAGE
+                                                         : DeepWgrad<H, W, SB, CBT, false>::STAGE);
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = bf16 ? deep_wgrad_kernel<H, W, SB, CBT, true> : deep_wgrad_kernel<H, W, SB, CBT, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_wgrad_deep");
+  if (rc) return rc;
+  if (!(d->flags & PGV_PREZEROED) &&
+      hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * 16, st) != hipSuccess) {
+    pgv_set_error("conv_wgrad_deep: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int nblk = (d->Cs / 64) * (d->Cb / CBT);
+  // split the minibatch until ~512 workgroups, whole stages per split
+  int splits = (int)max((int64_t)1, min((int64_t)pgv_cdiv(512, nblk), pgv_cdiv(d->B, SB)));
+  const int per_split = (int)(pgv_cdiv(pgv_cdiv(d->B, splits), SB) * SB);
+  splits = (int)pgv_cdiv(d->B, per_split);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * splits)), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, big_scale,
+                     big_shift, small_in, small_scale, small_shift, gw, nblk, per_split);
+  PGV_CHECK_LAUNCH("conv_wgrad_deep");
+  return 1;
+}
+
+bool shape_k4(const pgv_conv_desc* d) { return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2; }
+
+}  // namespace
+
+int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                       const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                       hipStream_t st) {
+  if (!shape_k4(d) || d->Cb < 64) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down<17, 23, 1, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down<5, 7, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  return 0;
+}
+
+int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                     hipStream_t st) {
+  if (!shape_k4(d) || d->Cb < 64) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up<5, 7, 4, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  return 0;
+}
+
+int pgv_conv_wgrad_deep(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        hipStream_t st) {
+  if (!shape_k4(d) || d->Cb < 64 || d->B == 0) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_wgrad<17, 23, 1, 4>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_wgrad<9, 12, 2, 8>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_wgrad<5, 7, 4, 8>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+  return 0;
+}

@@ -59,6 +59,19 @@ int pgv_conv_wgrad_gemm(const pgv_conv_desc* d, const float* big, const float* b
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st);
 
+// Raw-plane implicit-GEMM kernels for the deep k4 layers (conv_deep.hip): tried before the gather-GEMM.
+int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                       const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                       hipStream_t st);
+
+int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                     hipStream_t st);
+
+int pgv_conv_wgrad_deep(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        hipStream_t st);
+
 int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st);
 // red += projections (no clearing): the fallback of pgv_bn_fuse for kernels without the fused epilogue
 int pgv_bn_bwd_reduce_impl(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,

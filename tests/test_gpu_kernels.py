@@ -236,6 +236,45 @@ def test_band_kernels_bf16_many_units(ops, case):
         ops.set_compute_dtype('fp32')
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9)])
+def test_deep_kernels_many_units(ops, case, mode):
+    """The raw-plane implicit-GEMM kernels of the deep layers (conv_deep.hip) over several sample groups, including a
+    partial last group, with lazy normalisation, BN statistics and both operand precisions."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    rnd = _bf16 if mode == 'bf16' else (lambda t: t.float().double())
+    ops.set_compute_dtype(mode)
+    try:
+        big_n, small_n = rnd(_affine_fma(big, sc_b, sh_b)), rnd(_affine_fma(small, sc_s, sh_s))
+        ref = F.leaky_relu(F.conv2d(big_n, rnd(w), bias_s.float().double(), stride=s, padding=p), 0.1)
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+        ref = F.leaky_relu(F.conv_transpose2d(small_n, rnd(w), bias_b.float().double(), stride=s, padding=p,
+                                              output_padding=(oph, opw)), 0.1)
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        wv = w.double().clone().requires_grad_(True)
+        F.conv2d(big_n, wv, None, stride=s, padding=p).backward(rnd(small))
+        gw = torch.empty((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, big_scale=dev(sc_b), big_shift=dev(sh_b))
+        assert rel_l2(gw, wv.grad) < 5e-5
+        wv = w.double().clone().requires_grad_(True)
+        F.conv2d(rnd(big), wv, None, stride=s, padding=p).backward(small_n)
+        ops.conv_wgrad(geom, dev(big), dev(small), gw, small_scale=dev(sc_s), small_shift=dev(sh_s))
+        assert rel_l2(gw, wv.grad) < 5e-5
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 2), (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3),
                                   (3, 5, 4, 2, 2, 10, 13, 2)])
 def test_conv_prezeroed_outputs_accumulate(ops, case):

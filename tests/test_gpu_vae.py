@@ -176,19 +176,23 @@ def test_train_step_parity(name):
         if 'running' in k:
             assert rel_l2(got, v) < max(1e-5, 4 * rel_l2(ora32['new_sd'][k], v)), k
         else:
-            # First Adam step = lr * g/(|g|+eps) ~ lr*sign(g): discontinuous at g = 0, so elements whose reference
-            # gradient is within the fp32 noise (mathematically-zero gradients, e.g. a bias in front of a BatchNorm)
-            # legitimately move by +-lr in either direction.  Compare the UPDATE where the gradient is resolved.
-            g_ref = ora['grads'][k]
-            noise_g = (ora32['grads'][k].double() - g_ref).abs().max().item()
-            # ... and is far above Adam's eps = 1e-8: update = lr * g / (|g| + eps) is only sign-like for |g| >> eps, below
-            # ~1e-6 a rounding-level change of g (float atomics) moves the update by a visible fraction of lr
-            resolved = g_ref.abs() > max(1e-3 * g_ref.abs().max().item(), 100 * noise_g, 1e-6)
-            upd_ref = v - sd64[k]
-            upd_got = got - sd64[k].float().double()
-            if resolved.any():
-                e_u = (upd_got - upd_ref)[resolved].abs().max().item()
-                assert e_u < 2e-5, (k, e_u)                       # |update| ~ lr = 2e-4
+            # First Adam step = lr * g/(|g|+eps) ~ lr*sign(g): discontinuous at g = 0, so an element whose gradient is
+            # within the float32 noise of zero legitimately moves by +-lr in either direction, and "is the reference
+            # gradient resolved" cannot be decided against an unknown implementation noise.  So the update is checked in
+            # two exact halves: the GRADIENT against the oracle (above), and the ADAM ARITHMETIC against the oracle's
+            # adam_update evaluated in float64 on the gradient the device actually produced.
+            g_dev = params[k].grad.double().cpu()
+            p_exp, _, _ = vo.adam_update(sd64[k].float().double(), g_dev, torch.zeros_like(g_dev),
+                                         torch.zeros_like(g_dev), 1, float(g['meta/lr']), (0.9, 0.999), 1e-8,
+                                         float(g['meta/weight_decay']))
+            # |g| >> eps: the update is lr*sign(g) to float32 rounding of the parameter; near eps (1e-8) the float32
+            # sqrt / division of the kernel shows at the 1e-2*lr level
+            big_g = (g_dev + float(g['meta/weight_decay']) * sd64[k].float().double()).abs() > 1e-6
+            err = (got - p_exp).abs()
+            if big_g.any():
+                assert err[big_g].max().item() < 1e-6, (k, err[big_g].max().item())   # 0.5 % of lr
+            assert err.max().item() < 2e-5, (k, err.max().item())
+            upd_ref, upd_got = v - sd64[k], got - sd64[k].float().double()
             assert (upd_got - upd_ref).abs().max().item() < 2.1 * 2e-4 * 1.01, k   # never more than a sign flip
     for k in sd_new:
         if k.endswith('num_batches_tracked'):
@@ -311,7 +315,11 @@ def test_two_graph_launch_mode_matches_single_graph():
     assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * abs(finals[0][0])
     for k, dv in finals[0][1].items():
         assert dv.abs().max().item() > 1e-5             # five Adam steps of 1e-5 happened
-        assert rel_l2(finals[1][1][k], dv) < 2e-2, k
+        # Adam's first steps move every element by ~lr*sign(g): compare where the sign of the gradient was stable over
+        # the five steps (|update| ~ 5 lr); elements whose gradient hovers around zero flip with float-atomics noise
+        stable = dv.abs() > 0.9 * 5 * 1e-5
+        if stable.float().mean().item() > 0.05:
+            assert rel_l2(finals[1][1][k][stable], dv[stable]) < 2e-2, k
 
 
 def test_train_step_stacked_channels_f3():
