@@ -663,13 +663,372 @@ int launch_deep_wgrad(const pgv_conv_desc* d, const float* big, const float* big
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions of the features mixer / un-mixer (enc8 = Conv2d(512,2048,1), model/encoder.py:56-69, and
+// dec1 = ConvTranspose2d(2048,512,1), model/decoder.py:72-75) on 3x4 planes: plain GEMMs over (sample, pixel).
+//   DOWN  out[b,cs,p] = act(bias[cs] + sum_cb w[cs,cb] x'[b,cb,p])      A = w rows (K contiguous)        TRANSA = false
+//   UP    out[b,cb,p] = act(bias[cb] + sum_cs w[cs,cb] s'[b,cs,p])      A = w^T: k-major rows of 64 cb   TRANSA = true
+// M = 64 output channels per workgroup, N = NS samples x P pixels, K in slabs of CK input channels.  The MFMA k index
+// is the input channel: lane group j holds channels 16g+4j .. +3 (fp32: one per k-step, bf16: the lane's 4 k values).
+template <int P, int NS, int CK, bool TRANSA>
+struct K1Fwd {
+  static constexpr int N = NS * P, NT = (N + 15) / 16;
+  static constexpr int AS = TRANSA ? 64 + 16 : CK + 4;   // conflict-free fragment reads (see kernel)
+  static constexpr int A_FLOATS = TRANSA ? CK * AS : 64 * AS;
+  static constexpr int CH_STRIDE = NS * P;
+  static constexpr int B_FLOATS = CK * CH_STRIDE;
+  static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+  static constexpr int QA = 64 * CK / 4 / 256;
+  static constexpr int QB_ITEMS = NS * CK * P / 4, QB = (QB_ITEMS + 255) / 256;
+  static_assert(P % 4 == 0 && CK % 16 == 0 && (64 * CK / 4) % 256 == 0, "tile shapes");
+};
+
+template <int P, int NS, int CK, bool TRANSA, bool BF16>
+__global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, const float* __restrict__ in,
+                                                     const float* __restrict__ in_scale,
+                                                     const float* __restrict__ in_shift,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int act, float slope, float* __restrict__ out,
+                                                     double* __restrict__ stats, int groups) {
+  using G = K1Fwd<P, NS, CK, TRANSA>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  const int co0 = mb * 64, b0 = grp * NS;
+
+  // ---- loaders.  Weights: !TRANSA w[co0+row][ci0 + 4f ..] (row-major [COUT][CIN]);
+  //                        TRANSA  w[ci0+r][co0 + 4f ..]    (row-major [CIN][COUT])
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 256 * i;
+    if (TRANSA) {
+      const int r = q / 16, f = q - r * 16;
+      a_src[i] = r * COUT + co0 + 4 * f;
+      a_dst[i] = r * G::AS + 4 * f;
+    } else {
+      const int row = q / (CK / 4), f = q - row * (CK / 4);
+      a_src[i] = (co0 + row) * CIN + 4 * f;
+      a_dst[i] = row * G::AS + 4 * f;
+    }
+  }
+  int b_src[G::QB], b_dst[G::QB], b_ch[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int si = q / (CK * P / 4), qq = q - si * (CK * P / 4);
+    const int ch = (4 * qq) / P, pix = 4 * qq - ch * P;
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = bs * CIN * P + 4 * qq;
+    b_ch[i] = ch;
+    b_dst[i] = ch * G::CH_STRIDE + si * P + pix;
+  }
+  int bn[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) {
+    const int n = min(t * 16 + m, G::N - 1);
+    bn[t] = n + 4 * j * G::CH_STRIDE;  // n = si*P + pix is the offset inside one channel's [NS][P] block
+  }
+  const int a_frag = TRANSA ? 4 * j * G::AS + wave * 16 + m : (wave * 16 + m) * G::AS + 4 * j;
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[G::QA], rb[G::QB];
+  auto issue = [&](int slab) {
+    const int ci0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + (TRANSA ? (int64_t)ci0 * COUT : (int64_t)ci0));
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+  };
+  auto commit = [&](int slab, float* st) {
+    const int ci0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
+    float* bt = st + G::A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      if (b_ok[i]) {
+        f32x4 v = rb[i];
+        if (in_scale) {
+          const float sc = in_scale[ci0 + b_ch[i]], sh = in_shift[ci0 + b_ch[i]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+        }
+        *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
+      }
+    }
+  };
+
+  const int nslab = CIN / CK;
+  issue(0);
+  commit(0, lds);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const float* st = lds + (s & 1) * G::STAGE;
+    if (s + 1 < nslab) issue(s + 1);
+    const float* ap = st + a_frag;
+    const float* bp = st + G::A_FLOATS;
+#pragma unroll
+    for (int g = 0; g < CK / 16; ++g) {
+      f32x4 a;
+      if (TRANSA) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = ap[(16 * g + e) * G::AS];
+      } else {
+        a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
+      }
+      if constexpr (BF16) {
+        const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {
+          const float* q = bp + bn[t] + 16 * g * G::CH_STRIDE;
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+              av, pack_bf16x4(q[0], q[G::CH_STRIDE], q[2 * G::CH_STRIDE], q[3 * G::CH_STRIDE]), acc[t], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bp[bn[t] + (16 * g + e) * G::CH_STRIDE], acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) commit(s + 1, lds + ((s + 1) & 1) * G::STAGE);
+    __syncthreads();
+  }
+
+  const pgv_act_params apar = pgv_act_setup(act, slope);
+  float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int c0 = co0 + wave * 16 + 4 * j;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) {
+    const int n = t * 16 + m;
+    const int si = n / P, pix = n - si * P;
+    const bool ok = n < G::N && b0 + si < B;
+    float* o = out + ((int64_t)(b0 + si) * COUT + c0) * P + pix;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = pgv_act_apply(acc[t][i] + bv[i], apar);
+      if (ok) {
+        o[i * P] = v;
+        s1[i] += v;
+        s2[i] += v * v;
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+      if (m == 0) {
+        atomicAdd(&stats[c0 + i], (double)a1);
+        atomicAdd(&stats[COUT + c0 + i], (double)a2);
+      }
+    }
+  }
+}
+
+template <int P, int NS, int CK, bool TRANSA>
+int launch_k1_fwd(int B, int CIN, int COUT, int flags, const float* in, const float* in_scale, const float* in_shift,
+                  const float* w, const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                  const char* who) {
+  using G = K1Fwd<P, NS, CK, TRANSA>;
+  if (COUT % 64 || CIN % CK) return 0;
+  const size_t bytes = sizeof(float) * 2 * (size_t)G::STAGE;
+  const bool bf16 = (flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? k1_fwd_kernel<P, NS, CK, TRANSA, true> : k1_fwd_kernel<P, NS, CK, TRANSA, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], who);
+  if (rc) return rc;
+  if (stats && !(flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * COUT, st) != hipSuccess) {
+    pgv_set_error("%s: memset failed", who);
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (B + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (COUT / 64))), dim3(256), bytes, st, B, CIN, COUT, in, in_scale,
+                     in_shift, w, bias, act, slope, out, stats, groups);
+  PGV_CHECK_LAUNCH(who);
+  return 1;
+}
+
+// WGRAD 1x1: gw[cs,cb] = sum_{b,p} s'[b,cs,p] * x'[b,cb,p].  M = cs (64 per workgroup), N = cb (CBT per workgroup),
+// K = (sample, pixel) flattened: LDS rows [channel][SB*P] so that 4 (fp32) / 16 (bf16) consecutive k are contiguous.
+template <int P, int SB, int CBT>
+struct K1Wgrad {
+  static constexpr int KS = SB * P, ROW = KS + 4, NT = CBT / 16;
+  static constexpr int A_FLOATS = 64 * ROW, B_FLOATS = CBT * ROW, STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int QA = SB * 64 * P / 4 / 256, QB = SB * CBT * P / 4 / 256;
+  static_assert(KS % 16 == 0 && (SB * 64 * P / 4) % 256 == 0 && (SB * CBT * P / 4) % 256 == 0, "tile shapes");
+};
+
+template <int P, int SB, int CBT, bool BF16>
+__global__ __launch_bounds__(256) void k1_wgrad_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                       const float* __restrict__ big_scale,
+                                                       const float* __restrict__ big_shift,
+                                                       const float* __restrict__ small_in,
+                                                       const float* __restrict__ small_scale,
+                                                       const float* __restrict__ small_shift,
+                                                       float* __restrict__ gw, int nblk, int per_split) {
+  using G = K1Wgrad<P, SB, CBT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int ks = blockIdx.x / nblk, blk = blockIdx.x - ks * nblk;
+  const int ncb = CB / CBT, mb = blk / ncb, nb = blk - mb * ncb;
+  const int cs0 = mb * 64, cb0 = nb * CBT;
+  const int bbeg = ks * per_split, bend = min(B, bbeg + per_split);
+
+  int a_si[G::QA], a_off[G::QA], a_dst[G::QA], a_ch[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 256 * i, si = q / (64 * P / 4), qq = q - si * (64 * P / 4);
+    const int c = (4 * qq) / P, pix = 4 * qq - c * P;
+    a_si[i] = si;
+    a_off[i] = 4 * qq;
+    a_ch[i] = c;
+    a_dst[i] = c * G::ROW + si * P + pix;
+  }
+  int b_si[G::QB], b_off[G::QB], b_dst[G::QB], b_ch[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = tid + 256 * i, si = q / (CBT * P / 4), qq = q - si * (CBT * P / 4);
+    const int c = (4 * qq) / P, pix = 4 * qq - c * P;
+    b_si[i] = si;
+    b_off[i] = 4 * qq;
+    b_ch[i] = c;
+    b_dst[i] = c * G::ROW + si * P + pix;
+  }
+  const float* sbase = small_in + (int64_t)cs0 * P;
+  const float* xbase = big + (int64_t)cb0 * P;
+  f32x4 ra[G::QA], rb[G::QB];
+  auto issue = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(sbase + (int64_t)min(b + a_si[i], bend - 1) * CS * P + a_off[i]);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(xbase + (int64_t)min(b + b_si[i], bend - 1) * CB * P + b_off[i]);
+  };
+  auto commit = [&](int b, float* st) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) {
+      f32x4 v = ra[i];
+      if (small_scale) {
+        const float sc = small_scale[cs0 + a_ch[i]], sh = small_shift[cs0 + a_ch[i]];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+      }
+      if (b + a_si[i] >= bend) v = f32x4{0.f, 0.f, 0.f, 0.f};  // samples beyond the range contribute nothing
+      *reinterpret_cast<f32x4*>(st + a_dst[i]) = v;
+    }
+    float* bt = st + G::A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      f32x4 v = rb[i];
+      if (big_scale) {
+        const float sc = big_scale[cb0 + b_ch[i]], sh = big_shift[cb0 + b_ch[i]];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+      }
+      *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
+    }
+  };
+
+  const int a_frag = (wave * 16 + m) * G::ROW + (BF16 ? 4 * j : j);
+  const int b_frag = m * G::ROW + (BF16 ? 4 * j : j);
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (bbeg < bend) {
+    issue(bbeg);
+    commit(bbeg, lds);
+    __syncthreads();
+    int stage = 0;
+    for (int b = bbeg; b < bend; b += SB, stage ^= 1) {
+      const float* st = lds + stage * G::STAGE;
+      const bool more = b + SB < bend;
+      if (more) issue(b + SB);
+      const float* ap = st + a_frag;
+      const float* bp = st + G::A_FLOATS + b_frag;
+      if constexpr (BF16) {
+#pragma unroll
+        for (int g = 0; g < G::KS / 16; ++g) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
+          const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(bp + 16 * t * G::ROW + 16 * g);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(x[0], x[1], x[2], x[3]), acc[t], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < G::KS / 4; ++i) {
+          const float a = ap[4 * i];
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t * G::ROW + 4 * i], acc[t], 0, 0, 0);
+        }
+      }
+      if (more) commit(b + SB, lds + (stage ^ 1) * G::STAGE);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      atomicAdd(&gw[(int64_t)(cs0 + wave * 16 + 4 * j + i) * CB + cb0 + 16 * t + m], acc[t][i]);
+}
+
+template <int P, int SB, int CBT>
+int launch_k1_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                    const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                    hipStream_t st) {
+  using G = K1Wgrad<P, SB, CBT>;
+  if (d->Cs % 64 || d->Cb % CBT) return 0;
+  const size_t bytes = sizeof(float) * 2 * (size_t)G::STAGE;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? k1_wgrad_kernel<P, SB, CBT, true> : k1_wgrad_kernel<P, SB, CBT, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], "conv_wgrad_deep");
+  if (rc) return rc;
+  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_wgrad_deep: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int nblk = (d->Cs / 64) * (d->Cb / CBT);
+  int splits = (int)max((int64_t)1, min((int64_t)pgv_cdiv(512, nblk), pgv_cdiv(d->B, SB)));
+  const int per_split = (int)(pgv_cdiv(pgv_cdiv(d->B, splits), SB) * SB);
+  splits = (int)pgv_cdiv(d->B, per_split);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * splits)), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, big_scale,
+                     big_shift, small_in, small_scale, small_shift, gw, nblk, per_split);
+  PGV_CHECK_LAUNCH("conv_wgrad_deep");
+  return 1;
+}
+
 bool shape_k4(const pgv_conv_desc* d) { return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2; }
+bool shape_k1_3x4(const pgv_conv_desc* d) {
+  return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->Hb == 3 && d->Wb == 4 && d->Cb >= 64;
+}
 
 }  // namespace
 
 int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
                        hipStream_t st) {
+  if (shape_k1_3x4(d))
+    return launch_k1_fwd<12, 8, 32, false>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
+                                           stats, st, "conv_down_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down<17, 23, 1, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
@@ -680,6 +1039,9 @@ int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in
 int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
                      hipStream_t st) {
+  if (shape_k1_3x4(d))
+    return launch_k1_fwd<12, 8, 32, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
+                                          out, stats, st, "conv_up_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
@@ -690,7 +1052,10 @@ int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float*
 int pgv_conv_wgrad_deep(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st) {
-  if (!shape_k4(d) || d->Cb < 64 || d->B == 0) return 0;
+  if (d->B == 0) return 0;
+  if (shape_k1_3x4(d))
+    return launch_k1_wgrad<12, 4, 64>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+  if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_wgrad<17, 23, 1, 4>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_wgrad<9, 12, 2, 8>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
   if (d->Hb == 5 && d->Wb == 7) return launch_deep_wgrad<5, 7, 4, 8>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);

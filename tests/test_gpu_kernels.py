@@ -237,7 +237,8 @@ def test_band_kernels_bf16_many_units(ops, case):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9)])
+@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9),
+                                  (512, 2048, 1, 1, 0, 3, 4, 19)])
 def test_deep_kernels_many_units(ops, case, mode):
     """The raw-plane implicit-GEMM kernels of the deep layers (conv_deep.hip) over several sample groups, including a
     partial last group, with lazy normalisation, BN statistics and both operand precisions."""
