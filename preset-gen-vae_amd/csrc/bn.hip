@@ -28,28 +28,57 @@ inline Split pick_split(int B, int C, int HW) {
   return s;
 }
 
+
+// Visit every element of channel c in samples [b0, b1): f4(offset) for the 16-byte groups, f1(offset) for the tail of
+// planes whose size is not a multiple of 4.  Large planes: lanes walk one plane at a time; small planes (the deep
+// layers: 12 .. 391 pixels) are flattened over (sample, group) so that all 256 lanes stay busy.
+template <typename F4, typename F1>
+__device__ __forceinline__ void for_each_in_channel(int b0, int b1, int C, int c, int HW, F4 f4, F1 f1) {
+  const int HW4 = HW >> 2, T = HW - (HW4 << 2);
+  if (HW4 >= 256) {
+    for (int b = b0; b < b1; ++b) {
+      const int64_t base = ((int64_t)b * C + c) * HW;
+      for (int i = threadIdx.x; i < HW4; i += blockDim.x) f4(base + 4 * i);
+      for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) f1(base + i);
+    }
+    return;
+  }
+  const int nb = b1 - b0;
+  if (HW4 > 0) {
+    const float inv = 1.0f / (float)HW4;
+    for (int e = threadIdx.x; e < nb * HW4; e += blockDim.x) {
+      const int bi = (int)(((float)e + 0.5f) * inv), i = e - bi * HW4;  // exact for e < 2^20
+      f4(((int64_t)(b0 + bi) * C + c) * HW + 4 * i);
+    }
+  }
+  if (T > 0)
+    for (int e = threadIdx.x; e < nb * T; e += blockDim.x) {
+      const int bi = e / T, i = e - bi * T;
+      f1(((int64_t)(b0 + bi) * C + c) * HW + (HW4 << 2) + i);
+    }
+}
+
 __global__ void bn_stats_kernel(const float* __restrict__ a, int B, int C, int HW, int per,
                                 double* __restrict__ stats) {
   __shared__ double red[16];
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
-  for (int b = b0; b < b1; ++b) {
-    const float* p = a + ((int64_t)b * C + c) * HW;
-    int i = threadIdx.x;
-    for (; i + (int)blockDim.x < HW; i += 2 * blockDim.x) {
-      const double v0 = p[i], v1 = p[i + blockDim.x];
-      s0 += v0;
-      q0 = fma(v0, v0, q0);
-      s1 += v1;
-      q1 = fma(v1, v1, q1);
-    }
-    if (i < HW) {
-      const double v0 = p[i];
-      s0 += v0;
-      q0 = fma(v0, v0, q0);
-    }
-  }
+  for_each_in_channel(
+      b0, b1, C, c, HW,
+      [&](int64_t off) {
+        const f4u v = *reinterpret_cast<const f4u*>(a + off);
+        const double v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+        s0 += v0 + v2;
+        s1 += v1 + v3;
+        q0 = fma(v0, v0, fma(v2, v2, q0));
+        q1 = fma(v1, v1, fma(v3, v3, q1));
+      },
+      [&](int64_t off) {
+        const double v0 = a[off];
+        s0 += v0;
+        q0 = fma(v0, v0, q0);
+      });
   const double s = pgv_block_sum_d(s0 + s1, red);
   const double q = pgv_block_sum_d(q0 + q1, red);
   if (threadIdx.x == 0) {
@@ -97,20 +126,18 @@ __global__ void affine_kernel(const float* __restrict__ a, const float* __restri
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   const float sc = scale[c], sh = shift[c];
-  const int HW4 = HW >> 2;
-  for (int b = b0; b < b1; ++b) {
-    const int64_t base = ((int64_t)b * C + c) * HW;
-    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
-      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
-      f4u r;
-      r.x = fmaf(v.x, sc, sh);
-      r.y = fmaf(v.y, sc, sh);
-      r.z = fmaf(v.z, sc, sh);
-      r.w = fmaf(v.w, sc, sh);
-      *reinterpret_cast<f4u*>(o + base + 4 * i) = r;
-    }
-    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) o[base + i] = fmaf(a[base + i], sc, sh);
-  }
+  for_each_in_channel(
+      b0, b1, C, c, HW,
+      [&](int64_t off) {
+        const f4u v = *reinterpret_cast<const f4u*>(a + off);
+        f4u r;
+        r.x = fmaf(v.x, sc, sh);
+        r.y = fmaf(v.y, sc, sh);
+        r.z = fmaf(v.z, sc, sh);
+        r.w = fmaf(v.w, sc, sh);
+        *reinterpret_cast<f4u*>(o + off) = r;
+      },
+      [&](int64_t off) { o[off] = fmaf(a[off], sc, sh); });
 }
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
@@ -121,23 +148,21 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float*
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   const float mu = mean[c], rs = rstd[c];
   double s0 = 0.0, d0 = 0.0;
-  const int HW4 = HW >> 2;
-  for (int b = b0; b < b1; ++b) {
-    const int64_t base = ((int64_t)b * C + c) * HW;
-    // 16 bytes per lane (planes are only 4-byte aligned in NCHW with odd H*W): float partials per quad, double across
-    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
-      const f4u g = *reinterpret_cast<const f4u*>(g_o + base + 4 * i);
-      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
-      const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
-      s0 += (double)((g.x + g.y) + (g.z + g.w));
-      d0 += (double)fmaf(g.x, h0, fmaf(g.y, h1, fmaf(g.z, h2, g.w * h3)));
-    }
-    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) {
-      const float g0 = g_o[base + i];
-      s0 += (double)g0;
-      d0 += (double)(g0 * ((a[base + i] - mu) * rs));
-    }
-  }
+  // 16 bytes per lane (planes are only 4-byte aligned in NCHW with odd H*W): float partials per quad, double across
+  for_each_in_channel(
+      b0, b1, C, c, HW,
+      [&](int64_t off) {
+        const f4u g = *reinterpret_cast<const f4u*>(g_o + off);
+        const f4u v = *reinterpret_cast<const f4u*>(a + off);
+        const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+        s0 += (double)((g.x + g.y) + (g.z + g.w));
+        d0 += (double)fmaf(g.x, h0, fmaf(g.y, h1, fmaf(g.z, h2, g.w * h3)));
+      },
+      [&](int64_t off) {
+        const float g0 = g_o[off];
+        s0 += (double)g0;
+        d0 += (double)(g0 * ((a[off] - mu) * rs));
+      });
   const double s = pgv_block_sum_d(s0, red);
   const double dd = pgv_block_sum_d(d0, red);
   if (threadIdx.x == 0) {
@@ -179,26 +204,24 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
       g = (av > -1.f && av < 1.f) ? g : 0.f;
     return g;
   };
-  const int HW4 = HW >> 2;
-  for (int b = b0; b < b1; ++b) {
-    const int64_t base = ((int64_t)b * C + c) * HW;
-    for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
-      const f4u g = *reinterpret_cast<const f4u*>(g_o + base + 4 * i);
-      const f4u v = *reinterpret_cast<const f4u*>(a + base + 4 * i);
-      f4u r;
-      r.x = one(g.x, v.x);
-      r.y = one(g.y, v.y);
-      r.z = one(g.z, v.z);
-      r.w = one(g.w, v.w);
-      *reinterpret_cast<f4u*>(g_y + base + 4 * i) = r;
-      acc += (r.x + r.y) + (r.z + r.w);
-    }
-    for (int i = (HW4 << 2) + threadIdx.x; i < HW; i += blockDim.x) {
-      const float r = one(g_o[base + i], a[base + i]);
-      g_y[base + i] = r;
-      acc += r;
-    }
-  }
+  for_each_in_channel(
+      b0, b1, C, c, HW,
+      [&](int64_t off) {
+        const f4u g = *reinterpret_cast<const f4u*>(g_o + off);
+        const f4u v = *reinterpret_cast<const f4u*>(a + off);
+        f4u r;
+        r.x = one(g.x, v.x);
+        r.y = one(g.y, v.y);
+        r.z = one(g.z, v.z);
+        r.w = one(g.w, v.w);
+        *reinterpret_cast<f4u*>(g_y + off) = r;
+        acc += (r.x + r.y) + (r.z + r.w);
+      },
+      [&](int64_t off) {
+        const float r = one(g_o[off], a[off]);
+        g_y[off] = r;
+        acc += r;
+      });
   if (gbias) {
     const float s = pgv_block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(&gbias[c], s);
