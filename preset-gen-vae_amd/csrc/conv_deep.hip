@@ -1027,11 +1027,11 @@ int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
                        hipStream_t st) {
   if (shape_k1_3x4(d))
-    return launch_k1_fwd<12, 8, 32, false>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
+    return launch_k1_fwd<12, 16, 32, false>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
                                            stats, st, "conv_down_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down<17, 23, 1, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 2, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
   if (d->Hb == 5 && d->Wb == 7) return launch_deep_down<5, 7, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
   return 0;
 }
@@ -1040,7 +1040,7 @@ int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float*
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
                      hipStream_t st) {
   if (shape_k1_3x4(d))
-    return launch_k1_fwd<12, 8, 32, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
+    return launch_k1_fwd<12, 4, 32, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
                                           out, stats, st, "conv_up_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
