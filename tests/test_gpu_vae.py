@@ -414,11 +414,13 @@ def test_checkpoint_round_trip(tmp_path):
         assert abs(o1[key].item() - o2[key].item()) <= 1e-5 * abs(o1[key].item()), key
 
 
-def test_batch_tiling_property_b256():
+@pytest.mark.parametrize("name", ["vae4l_b2.npz", "vae8l_b2.npz"])
+def test_batch_tiling_property_b256(name):
     """Full BASELINE size (B=256): a batch made of 128 copies of the 2 golden samples has the same BatchNorm
-    statistics, the same mean losses and the same mean gradients as the B=2 golden batch."""
+    statistics, the same mean losses and the same mean gradients as the B=2 golden batch (4-layer: the band kernels at
+    their persistent-workgroup sizes; 8-layer: also the deep-layer kernels over all 64..256 sample groups)."""
     from preset_gen_vae_amd.train_step import VAETrainStep
-    g = load_golden('vae4l_b2.npz')
+    g = load_golden(name)
     arch, dim_z = str(g['meta/arch']), int(g['meta/dim_z'])
     reps = 128
     ae = _build(arch, dim_z, 2 * reps, False)
