@@ -1,131 +1,249 @@
 // STFT -> |.|/norm -> sparse mel -> clamp -> 20 log10 -> affine, fused (reference: utils/audio.py:24-54 Spectrogram,
 // :73-87 MelSpectrogram, data/abstractbasedataset.py:129-131 min-max normalisation).
 //
-// One 256-thread workgroup handles FT consecutive frames of one waveform:
+// One 256-thread workgroup handles FT = 16 consecutive frames of one waveform:
 //   * the (FT-1)*hop + 1024 samples those frames overlap on are read from HBM once, coalesced, into LDS
 //     (the hop/n_fft = 1/4 overlap is served from LDS; out-of-range samples are the centre zero padding);
-//   * frames are transformed two at a time (two real frames packed as one complex 1024-point signal, split
-//     afterwards by conjugate symmetry) with a 5-pass radix-4 Stockham FFT in LDS, one butterfly per thread and
-//     pass, twiddles from an LDS table;
-//   * the mel projection uses the CSR form of the filterbank (<= 14 taps per row), results are collected in an
-//     LDS [rows][FT] tile and written as FT-float row segments.
+//   * every WAVE transforms a pair of frames (two real frames packed as one complex 1024-point signal, split afterwards
+//     by conjugate symmetry) on its own: 16 points per lane, 1024 = 16 x 16 x 4 - a radix-16 DFT in registers over
+//     n = 64 n1 + lane, a transpose through the wave's 8.7 KB LDS buffer, a second radix-16, a second transpose, a
+//     radix-4 - three passes and three LDS exchanges instead of five block-wide radix-4 passes; the lane-dependent
+//     twiddles and the window live in registers for the whole kernel;
+//   * magnitudes overwrite the spectrum in place as (frame a, frame b) pairs, the mel projection uses the CSR form of
+//     the filterbank (<= 14 taps per row, staged in LDS), results are collected in an LDS [rows][FT] tile and written
+//     as FT-float row segments.
 #include "pgv_common.h"
 
 namespace {
 
 constexpr int NFFT = 1024;
 constexpr int NBIN = NFFT / 2 + 1;
-constexpr int FT = 16;  // frames per workgroup
+constexpr int FT = 16;      // frames per workgroup
+constexpr int NWAVE = 4;    // waves per workgroup: one frame pair each per round, FT/2/NWAVE rounds
+constexpr int XROW = 68;    // exchange-buffer row stride (float2): 64 + 4 keeps both transposes bank-conflict free
+constexpr int XBUF = 16 * XROW;  // float2 per wave (>= 1024: the natural-order spectrum reuses it)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// The exchange buffer of a wave is private to it: LDS operations of one wave are issued and completed in order, so a
+// transpose needs no hardware barrier - only the compiler must keep the order of the accesses.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
+__device__ __forceinline__ void bfly4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+  a = cadd(t0, t2);
+  c = csub(t0, t2);
+  b = make_float2(t1.x + t3.y, t1.y - t3.x);  // t1 - i t3
+  d = make_float2(t1.x - t3.y, t1.y + t3.x);  // t1 + i t3
+}
+
+// forward 16-point DFT in registers (4 x 4 Cooley-Tukey).  Input x[n] natural; output X[k] is left in slot
+// 4*(k&3) + (k>>2)  (see P16).
+__device__ __forceinline__ constexpr int P16(int k) { return ((k & 3) << 2) | (k >> 2); }
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) bfly4(x[b], x[4 + b], x[8 + b], x[12 + b]);  // over a (n = 4a + b): slot 4c+b = u[b][c]
+  // twiddles W16^(b c), W16 = exp(-2 pi i / 16)
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+  x[4 * 1 + 1] = cmul(x[4 * 1 + 1], make_float2(C1, -S1));   // e = 1
+  x[4 * 1 + 2] = cmul(x[4 * 1 + 2], make_float2(R, -R));     // e = 2
+  x[4 * 1 + 3] = cmul(x[4 * 1 + 3], make_float2(S1, -C1));   // e = 3
+  x[4 * 2 + 1] = cmul(x[4 * 2 + 1], make_float2(R, -R));     // e = 2
+  x[4 * 2 + 2] = make_float2(x[4 * 2 + 2].y, -x[4 * 2 + 2].x);  // e = 4: -i
+  x[4 * 2 + 3] = cmul(x[4 * 2 + 3], make_float2(-R, -R));    // e = 6
+  x[4 * 3 + 1] = cmul(x[4 * 3 + 1], make_float2(S1, -C1));   // e = 3
+  x[4 * 3 + 2] = cmul(x[4 * 3 + 2], make_float2(-R, -R));    // e = 6
+  x[4 * 3 + 3] = cmul(x[4 * 3 + 3], make_float2(-C1, S1));   // e = 9
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bfly4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);  // over b: slot 4c+d = X[c+4d]
 }
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(
     const float* __restrict__ wav, int64_t n_samples, int hop, int n_frames, const float* __restrict__ window,
     float inv_norm, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, int n_rows, int use_mel, float floor_lin, float aff_a, float aff_b,
-    float* __restrict__ out, int sig_len) {
+    float* __restrict__ out, int sig_len, int csr_cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2* tw = reinterpret_cast<float2*>(lds);            // [1024]
-  float2* bufA = tw + NFFT;                               // [1024]
-  float2* bufB = bufA + NFFT;                             // [1024]
-  float* mag0 = reinterpret_cast<float*>(bufB + NFFT);    // [513]
-  float* mag1 = mag0 + NBIN + 3;                          // [513]
-  float* win = mag1 + NBIN + 3;                           // [1024]
-  float* tile = win + NFFT;                               // [n_rows][FT+1]
-  float* sig = tile + (size_t)n_rows * (FT + 1);          // [sig_len]
+  float2* xall = reinterpret_cast<float2*>(lds);                   // [NWAVE][XBUF]
+  float* sig = lds + 2 * NWAVE * XBUF;                             // [sig_len]
+  float* tile = sig + ((sig_len + 3) & ~3);                        // [n_rows][FT+1]
+  float2* csr = reinterpret_cast<float2*>(tile + (((size_t)n_rows * (FT + 1) + 3) & ~(size_t)3));  // [csr_cap]
+  int* rowp = reinterpret_cast<int*>(csr + csr_cap);               // [n_rows + 1]
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FT;
   const int nf = min(FT, n_frames - f0);
   const float* w = wav + (int64_t)b * n_samples;
+  float2* xb = xall + wave * XBUF;
 
+  // ---- one-time setup: W_1024 table (in the exchange buffers), signal window, CSR
   for (int i = tid; i < NFFT; i += 256) {
     float s, c;
     sincospif(-2.0f * (float)i / (float)NFFT, &s, &c);
-    tw[i] = make_float2(c, s);
-    win[i] = window[i];
+    xall[i] = make_float2(c, s);
   }
   const int64_t s0 = (int64_t)f0 * hop - NFFT / 2;
   for (int i = tid; i < sig_len; i += 256) {
     const int64_t g = s0 + i;
     sig[i] = (g >= 0 && g < n_samples) ? w[g] : 0.f;
   }
+  bool csr_lds = false;
+  if (use_mel) {
+    const int nnz = row_ptr[n_rows];
+    csr_lds = nnz <= csr_cap;
+    if (csr_lds) {
+      for (int i = tid; i < nnz; i += 256) csr[i] = make_float2(__int_as_float(col[i]), val[i]);
+      for (int i = tid; i <= n_rows; i += 256) rowp[i] = row_ptr[i];
+    }
+  }
+  float wreg[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = window[64 * n1 + lane];
+  __syncthreads();
+  // lane-dependent twiddles: pass A multiplies A[k1] by W_1024^(lane k1); pass B (lane = 4 k1 + m2) multiplies C[j1] by
+  // W_64^(m2 j1) = W_1024^(16 m2 j1)
+  float2 twA[16], twB[16];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    twA[k] = xall[(lane * k) & (NFFT - 1)];
+    twB[k] = xall[(16 * (lane & 3) * k) & (NFFT - 1)];
+  }
   __syncthreads();
 
-  for (int fp = 0; fp < nf; fp += 2) {
-    const bool has2 = fp + 1 < nf;
-    // load: z = frame(fp) + i*frame(fp+1), windowed
-    for (int i = tid; i < NFFT; i += 256) {
-      const float wv = win[i];
-      const float re = sig[fp * hop + i] * wv;
-      const float im = has2 ? sig[(fp + 1) * hop + i] * wv : 0.f;
-      bufA[i] = make_float2(re, im);
-    }
-    __syncthreads();
-    float2* src = bufA;
-    float2* dst = bufB;
+  for (int round = 0; round < FT / 2 / NWAVE; ++round) {
+    const int fp = 2 * (round * NWAVE + wave);
+    const bool valid = fp < nf, has2 = fp + 1 < nf;
+    float2 x[16];
+    // ---- pass A: x[n1] = z[64 n1 + lane]; 16-point DFT over n1; twiddle; transpose
+    if (valid) {
+      const float* sa = sig + fp * hop + lane;
 #pragma unroll
-    for (int pass = 0; pass < 5; ++pass) {
-      const int Ns = 1 << (2 * pass);
-      const int j = tid;
-      const int k = j & (Ns - 1);
-      const int tws = (NFFT / 4) / Ns;  // twiddle index step: 1024/(4*Ns)
-      float2 v0 = src[j], v1 = src[j + 256], v2 = src[j + 512], v3 = src[j + 768];
-      if (pass > 0) {
-        v1 = cmul(v1, tw[k * tws]);
-        v2 = cmul(v2, tw[2 * k * tws]);
-        v3 = cmul(v3, tw[3 * k * tws]);
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const float re = sa[64 * n1] * wreg[n1];
+        const float im = has2 ? sa[hop + 64 * n1] * wreg[n1] : 0.f;
+        x[n1] = make_float2(re, im);
       }
-      // radix-4 butterfly (forward transform: -i rotation)
-      const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y), a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y), a3 = make_float2(v1.x - v3.x, v1.y - v3.y);
-      const float2 o0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-      const float2 o2 = make_float2(a0.x - a2.x, a0.y - a2.y);
-      const float2 o1 = make_float2(a1.x + a3.y, a1.y - a3.x);  // a1 - i*a3
-      const float2 o3 = make_float2(a1.x - a3.y, a1.y + a3.x);  // a1 + i*a3
-      const int j0 = ((j - k) << 2) + k;  // (j/Ns)*Ns*4 + k
-      dst[j0] = o0;
-      dst[j0 + Ns] = o1;
-      dst[j0 + 2 * Ns] = o2;
-      dst[j0 + 3 * Ns] = o3;
-      __syncthreads();
-      float2* t = src;
-      src = dst;
-      dst = t;
+      dft16(x);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const float2 v = k1 ? cmul(x[P16(k1)], twA[k1]) : x[P16(0)];
+        xb[k1 * XROW + lane] = v;
+      }
     }
-    // src holds Z. X1[k] = (Z[k] + conj(Z[N-k]))/2 ; X2[k] = (Z[k] - conj(Z[N-k]))/(2i)
-    for (int k = tid; k < NBIN; k += 256) {
-      const float2 zk = src[k];
-      const float2 zn = src[(NFFT - k) & (NFFT - 1)];
-      const float x1r = 0.5f * (zk.x + zn.x), x1i = 0.5f * (zk.y - zn.y);
-      const float x2r = 0.5f * (zk.y + zn.y), x2i = -0.5f * (zk.x - zn.x);
-      mag0[k] = sqrtf(x1r * x1r + x1i * x1i) * inv_norm;
-      mag1[k] = sqrtf(x2r * x2r + x2i * x2i) * inv_norm;
+    wave_sync();
+    // ---- pass B: lane = 4 k1 + m2 takes B[k1][4 m1 + m2], m1 = 0..15; 16-point DFT over m1; twiddle; transpose
+    if (valid) {
+      const float2* src = xb + (lane >> 2) * XROW + (lane & 3);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) x[m1] = src[4 * m1];
     }
-    __syncthreads();
-    for (int r = tid; r < n_rows; r += 256) {
-      float m0, m1;
-      if (use_mel) {
-        m0 = 0.f;
-        m1 = 0.f;
-        for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
-          const int c = col[e];
-          const float v = val[e];
-          m0 = fmaf(v, mag0[c], m0);
-          m1 = fmaf(v, mag1[c], m1);
+    wave_sync();
+    if (valid) {
+      dft16(x);
+      float2* dst = xb + (lane >> 2) * XROW + (lane & 3);  // [(k1*17 + j1)*4 + m2]
+#pragma unroll
+      for (int j1 = 0; j1 < 16; ++j1) dst[4 * j1] = j1 ? cmul(x[P16(j1)], twB[j1]) : x[P16(0)];
+    }
+    wave_sync();
+    // ---- pass C: lane takes k1 = lane & 15, j1 = (lane >> 4) + 4 r: 4-point DFT over m2 -> Z[lane + 64 r + 256 j2]
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2* src = xb + (lane & 15) * XROW + ((lane >> 4) + 4 * r) * 4;
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) x[4 * r + m2] = src[m2];
+      }
+    }
+    wave_sync();
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bfly4(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3]);
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) xb[lane + 64 * r + 256 * j2] = x[4 * r + j2];
+      }
+    }
+    wave_sync();
+    // ---- split the packed pair and take magnitudes, in place: slot k <- (|Xa[k]|, |Xb[k]|) / norm.
+    // Xa[k] = (Z[k] + conj(Z[N-k]))/2 ; Xb[k] = (Z[k] - conj(Z[N-k]))/(2i).  Slot k <= 512 is written by the lane that
+    // read it; the partner slots N-k (>= 512) are never written, so no lane reads a slot another lane has overwritten.
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int k = lane + 64 * i;
+        if (k < NBIN) {
+          const float2 zk = xb[k];
+          const float2 zn = xb[(NFFT - k) & (NFFT - 1)];
+          const float x1r = 0.5f * (zk.x + zn.x), x1i = 0.5f * (zk.y - zn.y);
+          const float x2r = 0.5f * (zk.y + zn.y), x2i = -0.5f * (zk.x - zn.x);
+          x[i] = make_float2(__builtin_amdgcn_sqrtf(x1r * x1r + x1i * x1i) * inv_norm,
+                             __builtin_amdgcn_sqrtf(x2r * x2r + x2i * x2i) * inv_norm);
         }
-      } else {
-        m0 = mag0[r];
-        m1 = mag1[r];
       }
-      tile[r * (FT + 1) + fp] = fmaf(aff_a, 20.0f * log10f(fmaxf(m0, floor_lin)), aff_b);
-      if (has2) tile[r * (FT + 1) + fp + 1] = fmaf(aff_a, 20.0f * log10f(fmaxf(m1, floor_lin)), aff_b);
     }
-    __syncthreads();
+    wave_sync();
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int k = lane + 64 * i;
+        if (k < NBIN) xb[k] = x[i];
+      }
+    }
+    wave_sync();
+    // ---- mel projection (or the linear bins), dB, affine -> tile[row][fp], tile[row][fp+1]
+    if (valid) {
+      for (int r = lane; r < n_rows; r += 64) {
+        float m0, m1;
+        if (use_mel) {
+          m0 = 0.f;
+          m1 = 0.f;
+          if (csr_lds) {
+            // four taps per trip, loads first: the (row pointer -> tap -> magnitude) chain is LDS latency three deep
+            const int e0 = rowp[r], e1 = rowp[r + 1];
+            for (int e = e0; e < e1; e += 4) {
+              float2 cv[4], mg[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) cv[u] = csr[min(e + u, e1 - 1)];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) mg[u] = xb[__float_as_int(cv[u].x)];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float v = e + u < e1 ? cv[u].y : 0.f;
+                m0 = fmaf(v, mg[u].x, m0);
+                m1 = fmaf(v, mg[u].y, m1);
+              }
+            }
+          } else {
+            for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
+              const float v = val[e];
+              const float2 mg = xb[col[e]];
+              m0 = fmaf(v, mg.x, m0);
+              m1 = fmaf(v, mg.y, m1);
+            }
+          }
+        } else {
+          const float2 mg = xb[r];
+          m0 = mg.x;
+          m1 = mg.y;
+        }
+        tile[r * (FT + 1) + fp] = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
+        if (has2)
+          tile[r * (FT + 1) + fp + 1] =
+              fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
+      }
+    }
+    wave_sync();
   }
+  __syncthreads();
   // write the [n_rows][nf] tile: lanes run along frames inside a row segment
   float* o = out + (int64_t)b * n_rows * n_frames;
   for (int i = tid; i < n_rows * FT; i += 256) {
@@ -150,9 +268,18 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
   if (B == 0) return PGV_OK;
   const int n_rows = n_mels > 0 ? n_mels : NBIN;
   const int sig_len = (FT - 1) * hop + NFFT;
-  const size_t lds_bytes = sizeof(float2) * 3 * NFFT + sizeof(float) * (2 * (NBIN + 3) + NFFT) +
-                           sizeof(float) * ((size_t)n_rows * (FT + 1) + sig_len);
-  PGV_CHECK_ARG(lds_bytes <= 160 * 1024, "pgv_stft_mel: %d output rows need %zu B of LDS", n_rows, lds_bytes);
+  const size_t fixed_floats = 2 * (size_t)NWAVE * XBUF + ((sig_len + 3) & ~3) + (((size_t)n_rows * (FT + 1) + 3) & ~(size_t)3) +
+                              (size_t)n_rows + 1 + 3;
+  PGV_CHECK_ARG(sizeof(float) * fixed_floats <= 160 * 1024, "pgv_stft_mel: %d output rows need %zu B of LDS", n_rows,
+                sizeof(float) * fixed_floats);
+  // the filterbank's CSR is staged in LDS when it fits beside two workgroups per CU (else read through the caches)
+  int csr_cap = 0;
+  if (n_mels > 0) {
+    const size_t budget = 80 * 1024 / sizeof(float);
+    const size_t room = budget > fixed_floats ? budget - fixed_floats : 0;
+    csr_cap = (int)min((size_t)16 * n_rows, room / 2);
+  }
+  const size_t lds_bytes = sizeof(float) * (fixed_floats + 2 * (size_t)csr_cap);
   static bool attr_set = false;  // idempotent; only widens the dynamic-LDS cap of this kernel
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -161,7 +288,7 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
   dim3 grid((unsigned)pgv_cdiv(n_frames, FT), (unsigned)B);
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(256), lds_bytes, pgv_stream(stream), wav, n_samples, hop, n_frames,
                      window, 1.0f / norm, mel_row_ptr, mel_col, mel_val, n_rows, n_mels > 0 ? 1 : 0, floor_lin,
-                     affine_a, affine_b, out, sig_len);
+                     affine_a, affine_b, out, sig_len, csr_cap);
   PGV_CHECK_LAUNCH("stft_mel");
   return PGV_OK;
 }
