@@ -80,8 +80,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
-  const int f0 = blockIdx.x * FT;
-  const int nf = min(FT, n_frames - f0);
   const float* w = wav + (int64_t)b * n_samples;
   float2* xb = xall + wave * XBUF;
 
@@ -90,11 +88,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     float s, c;
     sincospif(-2.0f * (float)i / (float)NFFT, &s, &c);
     xall[i] = make_float2(c, s);
-  }
-  const int64_t s0 = (int64_t)f0 * hop - NFFT / 2;
-  for (int i = tid; i < sig_len; i += 256) {
-    const int64_t g = s0 + i;
-    sig[i] = (g >= 0 && g < n_samples) ? w[g] : 0.f;
   }
   bool csr_lds = false;
   if (use_mel) {
@@ -119,6 +112,15 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
   }
   __syncthreads();
 
+  // a workgroup keeps its tables and walks over the frame groups blockIdx.x, blockIdx.x + gridDim.x, ... of its waveform
+  for (int f0 = blockIdx.x * FT; f0 < n_frames; f0 += gridDim.x * FT) {
+  const int nf = min(FT, n_frames - f0);
+  const int64_t s0 = (int64_t)f0 * hop - NFFT / 2;
+  for (int i = tid; i < sig_len; i += 256) {
+    const int64_t g = s0 + i;
+    sig[i] = (g >= 0 && g < n_samples) ? w[g] : 0.f;
+  }
+  __syncthreads();
   for (int round = 0; round < FT / 2 / NWAVE; ++round) {
     const int fp = 2 * (round * NWAVE + wave);
     const bool valid = fp < nf, has2 = fp + 1 < nf;
@@ -250,6 +252,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     const int r = i / FT, f = i % FT;
     if (f < nf) o[(int64_t)r * n_frames + f0 + f] = tile[r * (FT + 1) + f];
   }
+  __syncthreads();  // the tile and the signal window are rewritten by the next group
+  }
 }
 
 }  // namespace
@@ -285,7 +289,10 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
     (void)hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid((unsigned)pgv_cdiv(n_frames, FT), (unsigned)B);
+  // persistent workgroups: two resident per CU (512 on the chip), each walking over the frame groups of one waveform
+  const int groups = (int)pgv_cdiv(n_frames, FT);
+  const int per_wave = (int)max((int64_t)1, min((int64_t)groups, pgv_cdiv(512, B)));
+  dim3 grid((unsigned)per_wave, (unsigned)B);
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(256), lds_bytes, pgv_stream(stream), wav, n_samples, hop, n_frames,
                      window, 1.0f / norm, mel_row_ptr, mel_col, mel_val, n_rows, n_mels > 0 ? 1 : 0, floor_lin,
                      affine_a, affine_b, out, sig_len, csr_cap);
