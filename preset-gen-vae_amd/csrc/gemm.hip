@@ -106,6 +106,159 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path for the shapes the VAE actually runs (all extents multiples of the tile, 16-byte aligned rows): 16-byte
+// global loads along whichever index is contiguous, K slabs of 32 double-buffered in LDS with register prefetch (one
+// barrier per slab), v_mfma_f32_16x16x4_f32 with 4 column tiles per wave (64x64 tile per workgroup).  The MFMA k index
+// is laid out so that lane group j = lane>>4 owns k = 16g + 4j .. +3: a k-contiguous operand row is one ds_read_b128
+// per 16 k, an m/n-contiguous operand is staged k-major and read 4 bytes at a time.
+//   A_K: A(m,k) k-contiguous (sak == 1), else m-contiguous (sam == 1);  B_K: B(k,n) k-contiguous (sbk == 1), else
+//   n-contiguous (sbn == 1).  nn.Linear forward = (A_K, B_K), input gradient = (A_K, B_N), weight gradient = (A_M, B_N).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pack4(f32x4 v) {
+  const bf16x2_t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+  const unsigned u[2] = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, u);
+}
+
+constexpr int FK = 32;                 // K slab
+constexpr int KROW = FK + 4;           // row stride of a k-contiguous tile [64][KROW]
+constexpr int MROW_A = 64 + 16;        // row stride of an m-contiguous A tile [FK][MROW_A]
+constexpr int NROW_B = 64 + 4;         // row stride of an n-contiguous B tile [FK][NROW_B]
+
+template <bool A_K, bool B_K, bool BF16>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(int M, int N, int K, const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ Bm, int64_t ldb,
+                                                        float* __restrict__ C, int64_t ldc,
+                                                        const float* __restrict__ bias_n, int k_per_split, int atomic) {
+  constexpr int A_FLOATS = A_K ? 64 * KROW : FK * MROW_A;
+  constexpr int B_FLOATS = B_K ? 64 * KROW : FK * NROW_B;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+
+  // loaders: 512 float4 per operand per slab, two per thread
+  int64_t a_src[2], b_src[2];
+  int a_dst[2], b_dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 256 * i;
+    if (A_K) {  // A[m0 + r][k + 4f]: 8 float4 per row
+      const int r = q >> 3, f = q & 7;
+      a_src[i] = (int64_t)(m0 + r) * lda + 4 * f;
+      a_dst[i] = r * KROW + 4 * f;
+    } else {    // A stored [k][m]: A(m,k) = A[k*lda + m]; 16 float4 per k row
+      const int r = q >> 4, f = q & 15;
+      a_src[i] = (int64_t)r * lda + m0 + 4 * f;
+      a_dst[i] = r * MROW_A + 4 * f;
+    }
+    if (B_K) {  // B(k,n) = B[n*ldb + k]
+      const int r = q >> 3, f = q & 7;
+      b_src[i] = (int64_t)(n0 + r) * ldb + 4 * f;
+      b_dst[i] = r * KROW + 4 * f;
+    } else {    // B[k*ldb + n]
+      const int r = q >> 4, f = q & 15;
+      b_src[i] = (int64_t)r * ldb + n0 + 4 * f;
+      b_dst[i] = r * NROW_B + 4 * f;
+    }
+  }
+  f32x4 ra[2], rb[2];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + (A_K ? (int64_t)k0 : (int64_t)k0 * lda));
+      rb[i] = *reinterpret_cast<const f32x4*>(Bm + b_src[i] + (B_K ? (int64_t)k0 : (int64_t)k0 * ldb));
+    }
+  };
+  auto commit = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
+      *reinterpret_cast<f32x4*>(st + A_FLOATS + b_dst[i]) = rb[i];
+    }
+  };
+  const int a_frag = A_K ? (wave * 16 + m) * KROW + 4 * j : 4 * j * MROW_A + wave * 16 + m;
+  const int b_frag = B_K ? m * KROW + 4 * j : 4 * j * NROW_B + m;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kbeg < kend) {
+    issue(kbeg);
+    commit(lds);
+    __syncthreads();
+    int stage = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += FK, stage ^= 1) {
+      const float* st = lds + stage * STAGE;
+      const bool more = k0 + FK < kend;
+      if (more) issue(k0 + FK);
+      const float* ap = st + a_frag;
+      const float* bp = st + A_FLOATS + b_frag;
+#pragma unroll
+      for (int g = 0; g < FK / 16; ++g) {
+        f32x4 a;
+        if (A_K) {
+          a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = ap[(16 * g + e) * MROW_A];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 b;
+          if (B_K) {
+            b = *reinterpret_cast<const f32x4*>(bp + 16 * t * KROW + 16 * g);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = bp[(16 * g + e) * NROW_B + 16 * t];
+          }
+          if constexpr (BF16) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(a), pack4(b), acc[t], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[t], 0, 0, 0);
+          }
+        }
+      }
+      if (more) commit(lds + (stage ^ 1) * STAGE);
+      __syncthreads();
+    }
+  }
+  // acc[t][i]: row m0 + wave*16 + 4j + i, column n0 + 16t + m
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + m;
+    const float bias = (!atomic && bias_n) ? bias_n[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* c = C + (int64_t)(m0 + wave * 16 + 4 * j + i) * ldc + n;
+      if (atomic)
+        atomicAdd(c, acc[t][i]);
+      else
+        *c = acc[t][i] + bias;
+    }
+  }
+}
+
+template <bool A_K, bool B_K>
+void launch_fast(dim3 grid, hipStream_t st, int bf16, int M, int N, int K, const float* A, int64_t lda, const float* B,
+                 int64_t ldb, float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
+  if (bf16)
+    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n,
+                       k_per_split, atomic);
+  else
+    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                       bias_n, k_per_split, atomic);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 }  // namespace
 
 extern "C" {
@@ -118,6 +271,36 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
   PGV_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && A && B && C && ldc >= N, "pgv_gemm: bad argument");
   if (M == 0) return PGV_OK;
   hipStream_t st = pgv_stream(stream);
+  // ---- fast path: tile-aligned extents, one unit stride per operand, 16-byte aligned rows
+  {
+    const bool a_k = sak == 1, a_m = sam == 1 && !a_k, b_k = sbk == 1, b_n = sbn == 1 && !b_k;
+    const int64_t lda = a_k ? sam : sak, ldb = b_k ? sbn : sbk;
+    if (pgv_kernel_policy() == 0 && (a_k || a_m) && (b_k || b_n) && M % 64 == 0 && N % 64 == 0 && K % FK == 0 && K > 0 && lda % 4 == 0 &&
+        ldb % 4 == 0 && aligned16(A) && aligned16(B)) {
+      const int tiles = (M / 64) * (N / 64);
+      int splits = (int)max((int64_t)1, min(pgv_cdiv(768, tiles), (int64_t)K / (FK * 4)));
+      const int k_per_split = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
+      splits = (int)pgv_cdiv(K, k_per_split);
+      const int atomic = splits > 1;
+      if (atomic) {
+        hipLaunchKernelGGL(init_c_kernel, dim3((unsigned)min((int64_t)1024, pgv_cdiv((int64_t)M * N, 256))), dim3(256),
+                           0, st, C, M, N, ldc, bias_n);
+        PGV_CHECK_LAUNCH("gemm_init_c");
+      }
+      dim3 grid((unsigned)(N / 64), (unsigned)(M / 64), (unsigned)splits);
+      const int bf16 = (flags & PGV_COMPUTE_BF16) ? 1 : 0;
+      if (a_k && b_k)
+        launch_fast<true, true>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+      else if (a_k)
+        launch_fast<true, false>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+      else if (b_k)
+        launch_fast<false, true>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+      else
+        launch_fast<false, false>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+      PGV_CHECK_LAUNCH("gemm_fast");
+      return PGV_OK;
+    }
+  }
   const int tiles = (int)(pgv_cdiv(M, BM) * pgv_cdiv(N, BN));
   // Split K until the grid holds ~2 workgroups per CU, keeping >= 8 slabs per split.
   int splits = 1;

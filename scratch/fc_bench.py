@@ -1,0 +1,18 @@
+"""Standalone timing of the six nn.Linear products of the step (graph-differential, cold cache)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from preset_gen_vae_amd import ops, _lib
+B = 256
+for dz in (64, 512):
+    x = torch.randn(B, 24576, device='cuda'); We = torch.randn(2 * dz, 24576, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
+    gye = torch.randn(B, 2 * dz, device='cuda'); gWe = torch.empty_like(We)
+    z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(24576, dz, device='cuda') * 0.01; bd = torch.zeros(24576, device='cuda')
+    gyd = torch.randn(B, 24576, device='cuda'); gWd = torch.empty_like(Wd)
+    for pol in (0, 1):
+        _lib.load().pgv_set_kernel_policy(pol)
+        ts = [bench.time_kernel(f, iters=5) * 1e3 for f in (
+            lambda: ops.linear_fwd(x, We, be), lambda: ops.linear_dgrad(gye, We), lambda: ops.linear_wgrad(gye, x, gWe),
+            lambda: ops.linear_fwd(z, Wd, bd), lambda: ops.linear_dgrad(gyd, Wd), lambda: ops.linear_wgrad(gyd, z, gWd))]
+        print(f"dz={dz} policy {pol}: enc fwd/dgrad/wgrad {ts[0]:.1f} {ts[1]:.1f} {ts[2]:.1f} | dec {ts[3]:.1f} {ts[4]:.1f} {ts[5]:.1f} | sum {sum(ts):.1f} us")
+    _lib.load().pgv_set_kernel_policy(0)
