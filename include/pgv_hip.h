@@ -146,8 +146,9 @@ int64_t pgv_gemm_workspace(int M, int N, int K);
 int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
              int64_t sbn, float* C, int64_t ldc, const float* bias_n, int flags, void* workspace,
              int64_t workspace_bytes, void* stream);
-/* out[n] = sum_m x[m*ld + n]  (bias gradient of Linear). */
-int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, void* stream);
+/* out[n] (+)= sum_m x[m*ld + n]  (bias gradient of Linear).  flags: PGV_PREZEROED = out already holds zeros (or a
+ * partial sum to add to); 0 = the call clears it first. */
+int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, int flags, void* stream);
 
 /* ---- dropout / reparameterisation / losses -------------------------------------------------------- */
 /* Counter-based RNG (Philox4x32-10). rng_state: device uint64[2] = {seed, offset}; kernels only read it. */

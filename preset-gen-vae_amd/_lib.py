@@ -53,7 +53,7 @@ SIGNATURES = {
     "pgv_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "pgv_gemm": (c_int, [c_int, c_int, c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int,
                          _P, c_int64, _P]),
-    "pgv_colsum": (c_int, [_P, c_int, c_int, c_int64, _P, _P]),
+    "pgv_colsum": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, _P]),
     "pgv_dropout_mask": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P]),
     "pgv_normal": (c_int, [_P, c_uint64, c_int64, _P, _P]),
     "pgv_rng_advance": (c_int, [_P, c_uint64, _P]),

@@ -351,11 +351,13 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
   return PGV_OK;
 }
 
-int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, void* stream) {
+int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, int flags, void* stream) {
   PGV_CHECK_ARG(x && out && M >= 0 && N > 0 && ld >= N, "pgv_colsum: bad argument");
   hipStream_t st = pgv_stream(stream);
-  int rc = zero_async(out, sizeof(float) * N, st, "pgv_colsum");
-  if (rc) return rc;
+  if (!(flags & PGV_PREZEROED)) {
+    int rc = zero_async(out, sizeof(float) * N, st, "pgv_colsum");
+    if (rc) return rc;
+  }
   if (M == 0) return PGV_OK;
   const int gy = (int)max((int64_t)1, min((int64_t)pgv_cdiv(M, 32), pgv_cdiv(1024, pgv_cdiv(N, 64))));
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)pgv_cdiv(N, 64), gy), dim3(256), 0, st, x, M, N, ld, out);

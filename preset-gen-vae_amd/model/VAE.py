@@ -28,6 +28,40 @@ class _ReparamFn(torch.autograd.Function):
         return ops.reparam_kl_bwd(ml, eps, g_z.contiguous(), None, 0.0), None
 
 
+class _ReparamKlFn(torch.autograd.Function):
+    """z = mu + sigma * eps AND the Dkl term from one launch (the kernel reads mu / logvar once for both); backward takes
+    whichever of the two output gradients exist, again in one launch."""
+
+    @staticmethod
+    def forward(ctx, ml, eps, kl_scale):
+        ml = ml.contiguous()
+        ctx.save_for_backward(ml, eps)
+        ctx.kl_scale = kl_scale
+        ctx.set_materialize_grads(False)
+        return ops.reparam_kl_fwd(ml, eps, kl_scale, want_z=True)
+
+    @staticmethod
+    def backward(ctx, g_z, g_kl):
+        ml, eps = ctx.saved_tensors
+        if g_z is None and g_kl is None:
+            return None, None, None
+        return ops.reparam_kl_bwd(ml, eps, None if g_z is None else g_z.contiguous(),
+                                  None if g_kl is None else g_kl.contiguous(), ctx.kl_scale), None, None
+
+
+_NO_FLOW_LADJ = {}
+
+
+def _zero_log_abs_det_jac(n, device):
+    """The flow placeholder of the 5-tuple (VAE.py:60: no flow, log|det J| = 0): one constant tensor per (device, n)
+    instead of a fill launch per forward.  Read-only by contract (the reference only feeds it to latent_loss)."""
+    key = (str(device), n)
+    t = _NO_FLOW_LADJ.get(key)
+    if t is None:
+        t = _NO_FLOW_LADJ[key] = torch.zeros((n, 1), device=device)
+    return t
+
+
 class BasicVAE(nn.Module):
     """A standard VAE over given encoder/decoder networks; dim_z independent Gaussians (reference VAE.py:19-66)."""
 
@@ -53,12 +87,19 @@ class BasicVAE(nn.Module):
             if eps is None:
                 from ..rng import device_rng
                 eps = device_rng(self, z_mu_logvar.device).normal((n_minibatch, self.dim_z))
-            z_sampled = _ReparamFn.apply(z_mu_logvar, eps.contiguous())
+            # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
+            # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
+            kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
+            z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)
+            z_mu_logvar._pgv_kl = (kl_scale, kl)
         else:  # eval mode: no random sampling (VAE.py:57-58)
             z_sampled = _ReparamFn.apply(z_mu_logvar, None)
         x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
-        return z_mu_logvar, z_sampled, z_sampled, torch.zeros((n_minibatch, 1), device=x.device), x_out
+        return z_mu_logvar, z_sampled, z_sampled, _zero_log_abs_det_jac(n_minibatch, x.device), x_out
 
     def latent_loss(self, z_0_mu_logvar, z_0_sampled=None, z_K_sampled=None, log_abs_det_jac=None, **kwargs):
         """Dkl vs. zero-mean unit-variance Gaussian (reference VAE.py:63-66); extra args exist for flow compatibility."""
+        cached = getattr(z_0_mu_logvar, '_pgv_kl', None)
+        if cached is not None and cached[0] == self.latent_criterion.kl_scale(z_0_mu_logvar):
+            return cached[1]
         return self.latent_criterion.from_mu_logvar(z_0_mu_logvar)

@@ -102,6 +102,17 @@ def _grad_dest(param, accumulated=False):
     return (t, t, False) if accumulated else (t, t)
 
 
+def _step_zeros(param, n, dtype, tag, device):
+    """``n`` zeroed accumulators for one application of a stack: from the optimizer's step scratch (cleared by the fill of
+    ``zero_grad()``) when there is one and this is its first use in the step, else a fresh ``torch.zeros``."""
+    flat = getattr(param, '_pgv_flat', None)
+    if flat is not None and not getattr(param, '_pgv_shared', False):
+        t = flat.step_scratch((id(param), tag), n, dtype)
+        if t is not None:
+            return t
+    return torch.zeros(n, device=device, dtype=dtype)
+
+
 # Set by parallel.GradAllReduce: called with a parameter right after the kernel writing its gradient was launched on
 # the current stream (gradient-ready notification for bucketed all-reduce overlap).
 GRAD_READY_HOOK = None
@@ -128,7 +139,7 @@ class ConvStackFn(torch.autograd.Function):
         # BatchNorm statistics of all blocks in one arena cleared by ONE fill (PGV_PREZEROED): a memset node per block
         # costs ~5 us of dependent-launch latency each
         n_stats = sum(2 * blk.c_out for blk in blocks if blk.bn is not None) if training else 0
-        arena = torch.zeros(n_stats, device=dev, dtype=torch.float64) if n_stats else None
+        arena = _step_zeros(params[0], n_stats, torch.float64, 'stats', dev) if n_stats else None
         a_off = 0
         for blk in blocks:
             w, b = params[pi], params[pi + 1]
@@ -178,7 +189,7 @@ class ConvStackFn(torch.autograd.Function):
         grads = [None] * len(params)
         pi = len(params)
         n_red = sum(2 * blk.c_out for blk, sv in zip(blocks, saved) if blk.bn is not None and sv[5] is not None)
-        arena = torch.zeros(n_red, device=dev, dtype=torch.float64) if n_red else None  # BN-backward projections
+        arena = _step_zeros(params[0], n_red, torch.float64, 'red', dev) if n_red else None  # BN-backward projections
         a_off = 0
         # arena slice of every train-mode BatchNorm block; the projections of block li-1 are accumulated by the
         # input-gradient kernel of block li while it writes g (pgv_bn_fuse), only the top block needs its own pass
@@ -310,8 +321,8 @@ class LinearFn(torch.autograd.Function):
         ops.linear_wgrad(gy, x, gw)
         gb_ret = None
         if bp is not None:
-            gb, gb_ret = _grad_dest(bp)
-            ops.colsum(gy, gb)
+            gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
+            ops.colsum(gy, gb, prezeroed=gb_zero)
         _grad_done(wp, bp)
         return gx, gw_ret, gb_ret
 

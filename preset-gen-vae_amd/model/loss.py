@@ -85,10 +85,10 @@ class GaussianDkl:
             raise NotImplementedError("General Dkl not implemented yet...")
         return self.from_mu_logvar(torch.stack((mu1, logvar1), dim=1))
 
+    def kl_scale(self, z_mu_logvar):
+        B, _, D = z_mu_logvar.shape
+        return (1.0 / B) / D if self.normalize else 1.0 / B
+
     def from_mu_logvar(self, z_mu_logvar):
         """Same value from the packed [B,2,D] encoder output (no re-packing copy)."""
-        B, _, D = z_mu_logvar.shape
-        kl_scale = 1.0 / B
-        if self.normalize:
-            kl_scale /= D
-        return _DklFn.apply(z_mu_logvar, kl_scale)
+        return _DklFn.apply(z_mu_logvar, self.kl_scale(z_mu_logvar))

@@ -236,10 +236,11 @@ def linear_wgrad(gy, x, gw):
     return gemm(N, K, M, gy, 1, N, x, K, 1, gw, K)
 
 
-def colsum(x, out):
+def colsum(x, out, prezeroed=False):
     M, N = x.shape
     _chk(x, out)
-    _lib.check(_lib.load().pgv_colsum(_p(x), M, N, N, _p(out), _stream()), "pgv_colsum")
+    _lib.check(_lib.load().pgv_colsum(_p(x), M, N, N, _p(out), PGV_PREZEROED if prezeroed else 0, _stream()),
+               "pgv_colsum")
     return out
 
 

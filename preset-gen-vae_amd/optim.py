@@ -15,6 +15,7 @@ from . import _lib, ops
 
 _ALIGN = 64  # floats (256 B): 16-byte streaming accesses, and gradient slices start on a cache-line boundary - the
 # weight-gradient kernels flush with float atomics, which run ~1.5x slower when their 64-byte segments straddle lines
+_SCRATCH = 1 << 16   # floats of step scratch behind the flat gradient (256 KB)
 
 
 class FlatParams:
@@ -38,7 +39,15 @@ class FlatParams:
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = off
         self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        # gradient buffer + "step scratch": small accumulators that must start a step at zero (BatchNorm statistics /
+        # backward projections of every conv stack) live behind the gradients, so the ONE fill of zero_grad() clears
+        # them too instead of one fill node (~5 us of dependent-launch latency) per arena
+        self._grad_and_scratch = torch.zeros(off + _SCRATCH, device=dev, dtype=torch.float32)
+        self.flat_grad = self._grad_and_scratch[:off]
+        self._scratch = self._grad_and_scratch[off:]
+        self._scratch_slots = {}   # key -> (offset, n_floats): fixed addresses (a captured step replays them)
+        self._scratch_used = 0
+        self._scratch_gen = {}     # key -> zero_gen of its last hand-out
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_param[o:o + n].copy_(p.data.reshape(-1))
@@ -51,6 +60,23 @@ class FlatParams:
         # then skip their own clearing pass (PGV_PREZEROED)
         self.grad_zeroed = False
         self.zero_gen = 0  # bumped by every zero_grad(): a slice is clean only for the first backward after it
+
+    def step_scratch(self, key, n, dtype):
+        """``n`` zeros of ``dtype`` that were cleared by this step's ``zero_grad()``, or None (no zero_grad since the last
+        optimizer step, ``key`` already served in this step, or the scratch is full): the caller then allocates."""
+        if not self.grad_zeroed or self._scratch_gen.get(key) == self.zero_gen:
+            return None
+        n_floats = n * (2 if dtype == torch.float64 else 1)
+        slot = self._scratch_slots.get(key)
+        if slot is None or slot[1] < n_floats:
+            need = (n_floats + _ALIGN - 1) // _ALIGN * _ALIGN
+            if self._scratch_used + need > self._scratch.numel():
+                return None
+            slot = (self._scratch_used, need)
+            self._scratch_slots[key] = slot
+            self._scratch_used += need
+        self._scratch_gen[key] = self.zero_gen
+        return self._scratch[slot[0]:slot[0] + n_floats].view(dtype)
 
     def bucket_ranges(self, n_buckets):
         """Split [0, numel) at parameter boundaries into ~equal contiguous ranges (gradient-ready order)."""
@@ -98,7 +124,7 @@ class FusedAdam(torch.optim.Optimizer):
         """``optimizer.zero_grad()`` of train.py:208: ONE fill of the flat gradient buffer.  The weight / bias gradient
         kernels accumulate with atomics; knowing the buffer is clean they skip their per-call memset nodes (~5 us of
         dependent-launch latency each, 16 per step)."""
-        self.flat.flat_grad.zero_()
+        self.flat._grad_and_scratch.zero_()
         self.flat.grad_zeroed = True
         self.flat.zero_gen += 1
         return None

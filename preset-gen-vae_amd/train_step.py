@@ -46,6 +46,7 @@ class VAETrainStep:
             self.recons_criterion = loss_mod.L2Loss()
         self.controls_criterion = loss_mod.MSELoss(reduction='mean')
         self.use_graph = use_graph
+        self._const = {}
         self._graph = None
         self._graph_update = None
         self._static_x = None
@@ -68,16 +69,30 @@ class VAETrainStep:
         z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
         recons = self.recons_criterion(x_out, x)
         lat = self.model.latent_loss(z_mu_logvar, z0, zK, ladj)
-        total = recons + lat * self.beta
+        # total = recons + lat * beta (+ controls); total.backward() (train.py:227,246-247).  The gradients of the
+        # terms are the constants (1, beta, 1): they are handed to autograd as constant tensors, so neither the sum
+        # nor its backward costs arithmetic launches on 0-d tensors (5 us of dependent-launch latency each);
+        # the reported total is one fused multiply-add
+        one, beta_t = self._constants(x.device)
+        roots, root_grads = [recons, lat], [one, beta_t]
+        total = torch.addcmul(recons.detach(), lat.detach(), beta_t)
         cont = None
         if self.reg_model is not None and v_in is not None:
             v_out = self.reg_model(zK)
             cont = self.controls_criterion(v_out, v_in)
-            total = total + cont
-        total.backward()
+            total = total + cont.detach()
+            roots.append(cont)
+            root_grads.append(one)
+        torch.autograd.backward(roots, root_grads)
         return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(),
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
                 'x_out': x_out.detach()}
+
+    def _constants(self, device):
+        c = self._const.get(str(device))
+        if c is None:
+            c = self._const[str(device)] = (torch.ones((), device=device), torch.full((), self.beta, device=device))
+        return c
 
     def step(self, x, v_in=None, inject=None):
         if not self.use_graph or inject:
