@@ -154,6 +154,10 @@ int pgv_colsum(const float* x, int M, int N, int64_t ld, float* out, int flags, 
 /* Counter-based RNG (Philox4x32-10). rng_state: device uint64[2] = {seed, offset}; kernels only read it. */
 /* mask[i] = (u_i >= p) ? 1/(1-p) : 0  (nn.Dropout train mode, encoder.py:85, decoder.py:65). */
 int pgv_dropout_mask(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, float* mask, void* stream);
+/* nn.Dropout forward in one pass: y = x * mask with the mask of pgv_dropout_mask (same state, stream and counters)
+ * drawn on the fly and stored for the backward product (encoder.py:85, decoder.py:65). */
+int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, const float* x, float* y,
+                      float* mask, void* stream);
 /* eps ~ N(0,1) i.i.d. (VAE.py:54-55). */
 int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream);
 /* rng_state[1] += inc (device side, keeps graph replays advancing). */

@@ -52,6 +52,34 @@ __global__ void dropout_mask_kernel(const uint64_t* __restrict__ rng, uint64_t s
   }
 }
 
+// nn.Dropout forward in one pass: the keep mask is drawn, applied and stored (backward multiplies by it) - same
+// stream / counters as dropout_mask_kernel, so the two paths draw identical masks from identical states.
+__global__ void dropout_apply_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
+                                     int64_t n, const float* __restrict__ x, float* __restrict__ y,
+                                     float* __restrict__ mask, int vec) {
+  const uint64_t seed = rng[0], off = rng[1];
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    const float m[4] = {u01(r.x) >= p ? keep_scale : 0.f, u01(r.y) >= p ? keep_scale : 0.f,
+                        u01(r.z) >= p ? keep_scale : 0.f, u01(r.w) >= p ? keep_scale : 0.f};
+    if (vec && q * 4 + 4 <= n) {
+      const float4 xv = reinterpret_cast<const float4*>(x)[q];
+      reinterpret_cast<float4*>(y)[q] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
+      reinterpret_cast<float4*>(mask)[q] = make_float4(m[0], m[1], m[2], m[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i < n) {
+          y[i] = x[i] * m[j];
+          mask[i] = m[j];
+        }
+      }
+    }
+  }
+}
+
 __global__ void normal_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, int64_t n,
                               float* __restrict__ out) {
   const uint64_t seed = rng[0], off = rng[1];
@@ -282,6 +310,16 @@ int pgv_dropout_mask(const uint64_t* rng_state, uint64_t stream_id, float p, int
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state,
                      stream_id, p, 1.0f / (1.0f - p), n, mask);
   PGV_CHECK_LAUNCH("dropout_mask");
+  return PGV_OK;
+}
+
+int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, const float* x, float* y,
+                      float* mask, void* stream) {
+  PGV_CHECK_ARG(rng_state && x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "pgv_dropout_apply: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state,
+                     stream_id, p, 1.0f / (1.0f - p), n, x, y, mask, aligned16(x, y, mask) ? 1 : 0);
+  PGV_CHECK_LAUNCH("dropout_apply");
   return PGV_OK;
 }
 

@@ -109,8 +109,9 @@ class SpectrogramDecoder(nn.Module):
         if self.training and self.fc_dropout > 0.0:
             if dropout_mask is None:
                 from ..rng import device_rng
-                dropout_mask = device_rng(self, mixed.device).dropout_mask(self.fc_dropout, mixed.shape)
-            mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
+                mixed = layer.DropoutFn.apply(mixed, device_rng(self, mixed.device), self.fc_dropout)
+            else:
+                mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
         mixed = mixed.view(-1, self.cnn_input_shape[0], self.cnn_input_shape[1], self.cnn_input_shape[2])
         if self.spectrogram_channels == 1:
             return layer.run_stack(mixed, self._all_blocks(), self.training)

@@ -155,8 +155,9 @@ class SpectrogramEncoder(nn.Module):
         if self.training and self.fc_dropout > 0.0:
             if dropout_mask is None:
                 from ..rng import device_rng
-                dropout_mask = device_rng(self, cnn_out.device).dropout_mask(self.fc_dropout, cnn_out.shape)
-            cnn_out = layer.MaskMulFn.apply(cnn_out, dropout_mask.reshape(-1))
+                cnn_out = layer.DropoutFn.apply(cnn_out, device_rng(self, cnn_out.device), self.fc_dropout)
+            else:
+                cnn_out = layer.MaskMulFn.apply(cnn_out, dropout_mask.reshape(-1))
         lin = self.mlp[1]
         z_mu_logvar = layer.LinearFn.apply(cnn_out, lin.weight, lin.bias)
         if self.output_bn:

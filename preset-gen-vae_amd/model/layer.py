@@ -341,6 +341,21 @@ class MaskMulFn(torch.autograd.Function):
         return ops.mul(gy.contiguous(), mask), None
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout (train mode) with the mask drawn from the on-device Philox stream inside the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, rng, p):
+        y, mask = rng.dropout(p, x.contiguous())
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (mask,) = ctx.saved_tensors
+        return ops.mul(gy.contiguous(), mask), None, None
+
+
 class BatchNorm1dFn(torch.autograd.Function):
     """nn.BatchNorm1d over [B, C] (encoder.py:86-87), same kernels as the 2-D case with HW = 1."""
 

@@ -251,6 +251,15 @@ def dropout_mask(rng_state, stream_id, p, n, device):
     return mask
 
 
+def dropout_apply(rng_state, stream_id, p, x):
+    """(x * mask, mask) with the keep mask drawn on the fly (one pass instead of mask generation + multiply)."""
+    _chk(x)
+    y, mask = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.load().pgv_dropout_apply(rng_state.data_ptr(), stream_id, p, x.numel(), _p(x), _p(y), _p(mask),
+                                             _stream()), "pgv_dropout_apply")
+    return y, mask
+
+
 def normal(rng_state, stream_id, shape, device):
     out = torch.empty(shape, device=device, dtype=torch.float32)
     _lib.check(_lib.load().pgv_normal(rng_state.data_ptr(), stream_id, out.numel(), _p(out), _stream()), "pgv_normal")

@@ -28,6 +28,12 @@ class DeviceRNG:
         self._advance(n)
         return mask.view(*shape)
 
+    def dropout(self, p, x):
+        """nn.Dropout forward on ``x`` in one pass: returns (x * mask, mask); the same draw as ``dropout_mask``."""
+        y, mask = ops.dropout_apply(self.state, 0, float(p), x)
+        self._advance(x.numel())
+        return y, mask
+
     def normal(self, shape):
         out = ops.normal(self.state, 1, tuple(int(s) for s in shape), self.state.device)
         self._advance(out.numel())

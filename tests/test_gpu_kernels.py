@@ -525,6 +525,16 @@ def test_rng_distributions(ops):
     assert abs((e ** 4).mean().item() - 3.0) < 0.1
     rng_b = DeviceRNG(torch.device('cuda'), seed=42)
     assert torch.equal(rng_b.dropout_mask(0.3, (256, 24576)), m1)   # reproducible from the seed
+    # the fused forward (mask drawn inside the multiply kernel) is the same draw from the same state
+    rng_c = DeviceRNG(torch.device('cuda'), seed=42)
+    for shape in ((256, 24576), (3, 1001)):
+        x = torch.randn(*shape, device='cuda')
+        y, m = rng_c.dropout(0.3, x)
+        ref = DeviceRNG(torch.device('cuda'), seed=42)
+        if shape != (256, 24576):
+            ref.dropout_mask(0.3, (256, 24576))                     # advance the reference stream the same way
+        mr = ref.dropout_mask(0.3, shape)
+        assert torch.equal(m.view(*shape), mr) and torch.equal(y, x * mr)
 
 
 @pytest.mark.parametrize("kind", ["conv", "tconv"])
