@@ -228,6 +228,49 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
   }
 }
 
+// Output block of a decoder under a squared-error criterion, backward in one pass: g = 2 scale g_loss (a - x) is never
+// written - it goes straight through the block's activation backward into g_y, with the bias gradient alongside
+// (replaces pgv_sqerr_bwd + pgv_act_bn_bwd of a block without BatchNorm: 3 passes over the tensor instead of 6).
+__global__ void sqerr_act_bwd_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                     const float* __restrict__ g_loss, float scale, int B, int C, int HW, int per,
+                                     int act, float slope, float* __restrict__ g_y, float* __restrict__ gbias) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float k = 2.0f * scale * g_loss[0];
+  float acc = 0.f;
+  auto one = [&](float av, float xv) -> float {
+    float g = k * (av - xv);
+    if (act == PGV_ACT_LEAKY_RELU)
+      g = av > 0.f ? g : slope * g;
+    else if (act == PGV_ACT_HARDTANH)
+      g = (av > -1.f && av < 1.f) ? g : 0.f;
+    return g;
+  };
+  for_each_in_channel(
+      b0, b1, C, c, HW,
+      [&](int64_t off) {
+        const f4u av = *reinterpret_cast<const f4u*>(a + off);
+        const f4u xv = *reinterpret_cast<const f4u*>(x + off);
+        f4u r;
+        r.x = one(av.x, xv.x);
+        r.y = one(av.y, xv.y);
+        r.z = one(av.z, xv.z);
+        r.w = one(av.w, xv.w);
+        *reinterpret_cast<f4u*>(g_y + off) = r;
+        acc += (r.x + r.y) + (r.z + r.w);
+      },
+      [&](int64_t off) {
+        const float r = one(a[off], x[off]);
+        g_y[off] = r;
+        acc += r;
+      });
+  if (gbias) {
+    const float s = pgv_block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&gbias[c], s);
+  }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ld, float* __restrict__ out) {
   // block: 64 columns x 4 row-groups; rows split over blockIdx.y.
   __shared__ float part[4][64];
@@ -348,6 +391,22 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
   hipLaunchKernelGGL(act_bn_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, scale, mean, rstd, red, inv_n,
                      B, C, HW, s.per, act, slope, g_y, gbias, ggamma, gbeta);
   PGV_CHECK_LAUNCH("act_bn_bwd");
+  return PGV_OK;
+}
+
+int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
+                      float slope, float* g_y, float* gbias, int flags, void* stream) {
+  PGV_CHECK_ARG(a && x && g_loss && g_y && B >= 0 && C > 0 && HW > 0, "pgv_sqerr_act_bwd: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (gbias && !(flags & PGV_PREZEROED)) {
+    int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_sqerr_act_bwd");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(sqerr_act_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, a, x, g_loss, scale, B, C, HW, s.per,
+                     act, slope, g_y, gbias);
+  PGV_CHECK_LAUNCH("sqerr_act_bwd");
   return PGV_OK;
 }
 

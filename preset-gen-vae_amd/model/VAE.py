@@ -71,6 +71,10 @@ class BasicVAE(nn.Module):
         self.dim_z = dim_z
         self.decoder = decoder
         self.is_profiled = False
+        # 'mse_mean' / 'l2_batch' / 'l2_batch_contents' / None: evaluate that reconstruction criterion against the
+        # input inside the decoder's output stack (train mode) and hand it to loss.MSELoss / loss.L2Loss through an
+        # attribute of x_out, so that the criterion's backward fuses with the output block's (set by VAETrainStep)
+        self.fuse_recons_criterion = None
         if latent_loss_type.lower() == 'dkl':
             self.latent_criterion = loss_mod.GaussianDkl(normalize=normalize_latent_loss)
         else:
@@ -94,7 +98,14 @@ class BasicVAE(nn.Module):
             z_mu_logvar._pgv_kl = (kl_scale, kl)
         else:  # eval mode: no random sampling (VAE.py:57-58)
             z_sampled = _ReparamFn.apply(z_mu_logvar, None)
-        x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
+        kind = self.fuse_recons_criterion
+        if self.training and kind is not None and x.shape[1] == 1:
+            scale = {'mse_mean': 1.0 / x.numel(), 'l2_batch': 1.0 / x.shape[0],
+                     'l2_batch_contents': 1.0 / x.numel()}[kind]
+            x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x, sq_scale=scale)
+            x_out._pgv_recons = (x.data_ptr(), scale, recons)
+        else:
+            x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
         return z_mu_logvar, z_sampled, z_sampled, _zero_log_abs_det_jac(n_minibatch, x.device), x_out
 
     def latent_loss(self, z_0_mu_logvar, z_0_sampled=None, z_K_sampled=None, log_abs_det_jac=None, **kwargs):

@@ -103,7 +103,9 @@ class SpectrogramDecoder(nn.Module):
             blocks += self.features_unmixer_cnn.pgv_blocks()
         return blocks + self.single_ch_cnn.pgv_blocks()
 
-    def forward(self, z_sampled, dropout_mask=None):
+    def forward(self, z_sampled, dropout_mask=None, sq_target=None, sq_scale=None):
+        """``sq_target`` / ``sq_scale`` (single-channel spectrograms only): also return the squared-error reconstruction
+        term, evaluated inside the output stack (layer.ConvStackFn)."""
         lin = self.mlp[0]
         mixed = layer.LinearFn.apply(z_sampled, lin.weight, lin.bias)
         if self.training and self.fc_dropout > 0.0:
@@ -114,7 +116,9 @@ class SpectrogramDecoder(nn.Module):
                 mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
         mixed = mixed.view(-1, self.cnn_input_shape[0], self.cnn_input_shape[1], self.cnn_input_shape[2])
         if self.spectrogram_channels == 1:
-            return layer.run_stack(mixed, self._all_blocks(), self.training)
+            return layer.run_stack(mixed, self._all_blocks(), self.training, sq_target, sq_scale)
+        if sq_target is not None:
+            raise NotImplementedError("fused reconstruction criterion: single-channel spectrograms only")
         # stacked spectrograms (decoder.py:85-92): un-mix, split along channels, the shared stack once per chunk
         unmixed = layer.run_stack(mixed, self.features_unmixer_cnn.pgv_blocks(), self.training)
         single = self.single_ch_cnn.pgv_blocks()

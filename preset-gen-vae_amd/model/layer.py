@@ -129,7 +129,10 @@ class ConvStackFn(torch.autograd.Function):
     """A chain of conv blocks evaluated with folded BatchNorm between consecutive blocks."""
 
     @staticmethod
-    def forward(ctx, x, blocks, training, *params):
+    def forward(ctx, x, blocks, training, sq_target, sq_scale, *params):
+        """``sq_target`` / ``sq_scale`` (optional): also return ``sq_scale * sum((out - sq_target)^2)`` - the
+        reconstruction criterion evaluated where the output is produced, so that its backward can be fused with the
+        output block's (``pgv_sqerr_act_bwd``)."""
         x = x.contiguous()
         B = x.shape[0]
         dev = x.device
@@ -179,13 +182,29 @@ class ConvStackFn(torch.autograd.Function):
             cur, cur_scale, cur_shift = a, scale, shift
         out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
         ctx.blocks, ctx.saved, ctx.params = blocks, saved, params
-        return out
+        ctx.sq = None
+        if sq_target is None:
+            return out
+        sq_target = sq_target.contiguous()
+        ctx.sq = (sq_target, float(sq_scale))
+        ctx.set_materialize_grads(False)
+        return out, ops.sqerr_fwd(out, sq_target, float(sq_scale))
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_loss=None):
         blocks, saved, params = ctx.blocks, ctx.saved, ctx.params
-        g_o = g_out.contiguous()
-        dev = g_o.device
+        fused_sq = False
+        if ctx.sq is not None:
+            last = blocks[-1]
+            if g_loss is not None and g_out is None and last.bn is None:
+                fused_sq = True          # criterion + output activation backward in one pass, g_out never exists
+            elif g_loss is not None:
+                g_sq = ops.sqerr_bwd(saved[-1][3], ctx.sq[0], g_loss.contiguous(), ctx.sq[1])
+                g_out = g_sq if g_out is None else g_out + g_sq
+            if g_out is None and not fused_sq:
+                return (None,) * (5 + len(params))
+        g_o = g_out.contiguous() if g_out is not None else None
+        dev = saved[-1][3].device
         grads = [None] * len(params)
         pi = len(params)
         n_red = sum(2 * blk.c_out for blk, sv in zip(blocks, saved) if blk.bn is not None and sv[5] is not None)
@@ -216,9 +235,14 @@ class ConvStackFn(torch.autograd.Function):
             # (eval-mode BN: gamma/beta gradients are not produced)
             gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
             # g_y overwrites g_o unless g_o is the caller's tensor (first iteration)
-            g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
-            ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
-                           ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
+            if fused_sq and li == len(blocks) - 1:
+                g_y = torch.empty_like(a)
+                ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,
+                                  prezeroed=gb_zero)
+            else:
+                g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
+                ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
+                               ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
             grads[pi + 1] = gb_ret
             if ggamma is not None:
                 _grad_done(params[pi + 2], params[pi + 3])
@@ -244,14 +268,15 @@ class ConvStackFn(torch.autograd.Function):
                     g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bn_fuse=fuse)
             else:
                 g_o = None
-        return (g_o, None, None) + tuple(grads)
+        return (g_o, None, None, None, None) + tuple(grads)
 
 
-def run_stack(x, blocks, training):
+def run_stack(x, blocks, training, sq_target=None, sq_scale=None):
+    """``sq_target`` given: returns (output, sq_scale * sum((output - sq_target)^2)), see ConvStackFn.forward."""
     params = []
     for blk in blocks:
         params += blk.params()
-    return ConvStackFn.apply(x, tuple(blocks), bool(training), *params)
+    return ConvStackFn.apply(x, tuple(blocks), bool(training), sq_target, sq_scale, *params)
 
 
 class _ConvBlockBase(nn.Sequential):

@@ -30,6 +30,15 @@ class _SqErrFn(torch.autograd.Function):
         return g_inf, g_tgt, None
 
 
+def _sq_err(inferred, target, scale):
+    """scale * sum((inferred - target)^2); taken from the model when it already evaluated exactly this term where
+    ``inferred`` was produced (BasicVAE.fuse_recons_criterion), else computed here."""
+    cached = getattr(inferred, '_pgv_recons', None)
+    if cached is not None and cached[0] == target.data_ptr() and abs(cached[1] - scale) <= 1e-12 * scale:
+        return cached[2]
+    return _SqErrFn.apply(inferred, target, scale)
+
+
 class L2Loss:
     """Sum of squared differences / batch size [/ elements per item] (reference loss.py:15-43)."""
 
@@ -43,7 +52,7 @@ class L2Loss:
             scale /= inferred.shape[0]
         if self.contents_average:
             scale /= inferred[0, :].numel()
-        return _SqErrFn.apply(inferred, target, scale)
+        return _sq_err(inferred, target, scale)
 
 
 class MSELoss:
@@ -56,7 +65,7 @@ class MSELoss:
 
     def __call__(self, inferred, target):
         scale = 1.0 / inferred.numel() if self.reduction == 'mean' else 1.0
-        return _SqErrFn.apply(inferred, target, scale)
+        return _sq_err(inferred, target, scale)
 
 
 class _DklFn(torch.autograd.Function):

@@ -44,6 +44,10 @@ class VAETrainStep:
             self.recons_criterion = loss_mod.MSELoss(reduction='mean')
         else:
             self.recons_criterion = loss_mod.L2Loss()
+        # let the model evaluate this criterion inside the decoder's output stack (fused backward, VAE.py)
+        vae = getattr(ae_model, 'ae_model', ae_model)
+        if hasattr(vae, 'fuse_recons_criterion'):
+            vae.fuse_recons_criterion = 'mse_mean' if normalize_losses else 'l2_batch'
         self.controls_criterion = loss_mod.MSELoss(reduction='mean')
         self.use_graph = use_graph
         self._const = {}

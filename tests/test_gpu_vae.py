@@ -64,11 +64,19 @@ def _record_activation_regions(run, arch):
             rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
         return orig(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, **kw)
 
+    orig_sq = ops.sqerr_act_bwd
+
+    def patched_sq(a, x, g_loss, scale, act, slope, g_y, gbias, **kw):   # output block with the fused criterion
+        rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
+        return orig_sq(a, x, g_loss, scale, act, slope, g_y, gbias, **kw)
+
     ops.act_bn_bwd = patched
+    ops.sqerr_act_bwd = patched_sq
     try:
         out = run()
     finally:
         ops.act_bn_bwd = orig
+        ops.sqerr_act_bwd = orig_sq
     names = _block_names(arch)
     assert len(rec) == len(names), (len(rec), names)
     masks = dict(zip(names, rec))
@@ -320,6 +328,39 @@ def test_two_graph_launch_mode_matches_single_graph():
         stable = dv.abs() > 0.9 * 5 * 1e-5
         if stable.float().mean().item() > 0.05:
             assert rel_l2(finals[1][1][k][stable], dv[stable]) < 2e-2, k
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_fused_reconstruction_criterion_matches_separate(normalize):
+    """VAETrainStep lets the model evaluate the reconstruction criterion inside the decoder's output stack
+    (pgv_sqerr_act_bwd: criterion + Hardtanh backward in one pass); same losses and gradients as the separate
+    criterion(x_out, x) + sqerr_bwd + act_bn_bwd path, for MSELoss('mean') and L2Loss (train.py:103-106)."""
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    arch, dim_z, B = 'speccnn4l1_bn', 64, 3
+    x = _cuda32(synth_input(B))
+    eps = _cuda32(torch.sin(torch.arange(B * dim_z, dtype=torch.float64) * 0.37 + 0.2).reshape(B, dim_z))
+    res = []
+    for fused in (True, False):
+        ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
+        _load_closed_form(ae, arch, dim_z, False, 77)
+        ae = ae.cuda().train()
+        step = VAETrainStep(ae, lr=1e-5, normalize_losses=normalize)
+        assert ae.fuse_recons_criterion == ('mse_mean' if normalize else 'l2_batch')
+        if not fused:
+            ae.fuse_recons_criterion = None
+        out = step.step(x, inject={'eps': eps})
+        torch.cuda.synchronize()
+        res.append((out, {k: v.grad.detach().clone() for k, v in ae.named_parameters()}))
+    (o1, g1), (o2, g2) = res
+    # two runs of the same binary already differ at the 1e-6 level (float atomics in the split-K GEMMs and weight
+    # gradients, amplified by BatchNorm over 3 samples): tolerances are a decade above that noise
+    for key in ('recons', 'latent', 'total'):
+        assert abs(o1[key].item() - o2[key].item()) <= 1e-5 * abs(o2[key].item()), key
+    assert rel_l2(o1['x_out'], o2['x_out']) < 1e-5
+    for k in g2:
+        if g2[k].abs().max().item() < 1e-9:
+            continue
+        assert rel_l2(g1[k], g2[k]) < 1e-4, k
 
 
 def test_train_step_stacked_channels_f3():
