@@ -139,9 +139,10 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
 /* Output block under a squared-error criterion, backward in one pass: with g = 2 * scale * g_loss[0] * (a - x) (the
  * gradient of scale * sum (a - x)^2, train.py:222 / loss.py:15-43, never materialised) it writes
  * g_y = act'(a) * g and accumulates gbias[c] += sum g_y - pgv_sqerr_bwd followed by pgv_act_bn_bwd without BatchNorm.
- * flags: PGV_PREZEROED refers to gbias. */
+ * loss_acc (optional): += scale * sum (a - x)^2, the criterion's value as a by-product of the same pass (the caller
+ * provides a zeroed scalar).  flags: PGV_PREZEROED refers to gbias. */
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
-                      float slope, float* g_y, float* gbias, int flags, void* stream);
+                      float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream);
 
 /* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */
 /* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.

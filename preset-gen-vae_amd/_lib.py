@@ -53,7 +53,7 @@ SIGNATURES = {
     "pgv_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "pgv_gemm": (c_int, [c_int, c_int, c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int,
                          _P, c_int64, _P]),
-    "pgv_sqerr_act_bwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
+    "pgv_sqerr_act_bwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P]),
     "pgv_colsum": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, _P]),
     "pgv_dropout_mask": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P]),
     "pgv_dropout_apply": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P, _P]),

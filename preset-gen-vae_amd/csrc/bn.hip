@@ -233,14 +233,17 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
 // (replaces pgv_sqerr_bwd + pgv_act_bn_bwd of a block without BatchNorm: 3 passes over the tensor instead of 6).
 __global__ void sqerr_act_bwd_kernel(const float* __restrict__ a, const float* __restrict__ x,
                                      const float* __restrict__ g_loss, float scale, int B, int C, int HW, int per,
-                                     int act, float slope, float* __restrict__ g_y, float* __restrict__ gbias) {
+                                     int act, float slope, float* __restrict__ g_y, float* __restrict__ gbias,
+                                     float* __restrict__ loss_acc) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   const float k = 2.0f * scale * g_loss[0];
-  float acc = 0.f;
+  float acc = 0.f, sq = 0.f;
   auto one = [&](float av, float xv) -> float {
-    float g = k * (av - xv);
+    const float d = av - xv;
+    sq = fmaf(d, d, sq);
+    float g = k * d;
     if (act == PGV_ACT_LEAKY_RELU)
       g = av > 0.f ? g : slope * g;
     else if (act == PGV_ACT_HARDTANH)
@@ -268,6 +271,10 @@ __global__ void sqerr_act_bwd_kernel(const float* __restrict__ a, const float* _
   if (gbias) {
     const float s = pgv_block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(&gbias[c], s);
+  }
+  if (loss_acc) {  // the criterion's value as a by-product: scale * sum (a - x)^2
+    const float s = pgv_block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, scale * s);
   }
 }
 
@@ -395,7 +402,7 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
 }
 
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
-                      float slope, float* g_y, float* gbias, int flags, void* stream) {
+                      float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream) {
   PGV_CHECK_ARG(a && x && g_loss && g_y && B >= 0 && C > 0 && HW > 0, "pgv_sqerr_act_bwd: bad argument");
   hipStream_t st = pgv_stream(stream);
   if (gbias && !(flags & PGV_PREZEROED)) {
@@ -405,7 +412,7 @@ int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float
   if (B == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
   hipLaunchKernelGGL(sqerr_act_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, a, x, g_loss, scale, B, C, HW, s.per,
-                     act, slope, g_y, gbias);
+                     act, slope, g_y, gbias, loss_acc);
   PGV_CHECK_LAUNCH("sqerr_act_bwd");
   return PGV_OK;
 }

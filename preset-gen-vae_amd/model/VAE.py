@@ -73,7 +73,8 @@ class BasicVAE(nn.Module):
         self.is_profiled = False
         # 'mse_mean' / 'l2_batch' / 'l2_batch_contents' / None: evaluate that reconstruction criterion against the
         # input inside the decoder's output stack (train mode) and hand it to loss.MSELoss / loss.L2Loss through an
-        # attribute of x_out, so that the criterion's backward fuses with the output block's (set by VAETrainStep)
+        # attribute of x_out, so that the criterion's backward fuses with the output block's (set by VAETrainStep).
+        # '+deferred' appended: the value is produced BY the backward kernel and reads zero before backward has run
         self.fuse_recons_criterion = None
         if latent_loss_type.lower() == 'dkl':
             self.latent_criterion = loss_mod.GaussianDkl(normalize=normalize_latent_loss)
@@ -100,9 +101,11 @@ class BasicVAE(nn.Module):
             z_sampled = _ReparamFn.apply(z_mu_logvar, None)
         kind = self.fuse_recons_criterion
         if self.training and kind is not None and x.shape[1] == 1:
+            deferred = kind.endswith('+deferred')    # value delivered by the backward kernel (layer.ConvStackFn)
             scale = {'mse_mean': 1.0 / x.numel(), 'l2_batch': 1.0 / x.shape[0],
-                     'l2_batch_contents': 1.0 / x.numel()}[kind]
-            x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x, sq_scale=scale)
+                     'l2_batch_contents': 1.0 / x.numel()}[kind.split('+')[0]]
+            x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x,
+                                         sq_scale=-scale if deferred else scale)
             x_out._pgv_recons = (x.data_ptr(), scale, recons)
         else:
             x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)

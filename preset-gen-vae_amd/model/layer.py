@@ -132,7 +132,10 @@ class ConvStackFn(torch.autograd.Function):
     def forward(ctx, x, blocks, training, sq_target, sq_scale, *params):
         """``sq_target`` / ``sq_scale`` (optional): also return ``sq_scale * sum((out - sq_target)^2)`` - the
         reconstruction criterion evaluated where the output is produced, so that its backward can be fused with the
-        output block's (``pgv_sqerr_act_bwd``)."""
+        output block's (``pgv_sqerr_act_bwd``).  A NEGATIVE ``sq_scale`` asks for the deferred form (scale = -sq_scale):
+        no forward pass over the tensors at all - the returned scalar starts at zero and receives its value from the
+        backward kernel, which reads both tensors anyway; only for callers that always run backward before they look
+        at the value (VAETrainStep)."""
         x = x.contiguous()
         B = x.shape[0]
         dev = x.device
@@ -186,8 +189,13 @@ class ConvStackFn(torch.autograd.Function):
         if sq_target is None:
             return out
         sq_target = sq_target.contiguous()
-        ctx.sq = (sq_target, float(sq_scale))
         ctx.set_materialize_grads(False)
+        if sq_scale < 0:
+            ctx.sq = (sq_target, -float(sq_scale))
+            ctx.sq_deferred = _step_zeros(params[0], 1, torch.float32, 'sqloss', dev)
+            return out, ctx.sq_deferred.reshape(())
+        ctx.sq = (sq_target, float(sq_scale))
+        ctx.sq_deferred = None
         return out, ops.sqerr_fwd(out, sq_target, float(sq_scale))
 
     @staticmethod
@@ -201,6 +209,8 @@ class ConvStackFn(torch.autograd.Function):
             elif g_loss is not None:
                 g_sq = ops.sqerr_bwd(saved[-1][3], ctx.sq[0], g_loss.contiguous(), ctx.sq[1])
                 g_out = g_sq if g_out is None else g_out + g_sq
+            if ctx.sq_deferred is not None and not fused_sq:   # the deferred value has no fused kernel to come from
+                ctx.sq_deferred.add_(ops.sqerr_fwd(saved[-1][3], ctx.sq[0], ctx.sq[1]))
             if g_out is None and not fused_sq:
                 return (None,) * (5 + len(params))
         g_o = g_out.contiguous() if g_out is not None else None
@@ -238,7 +248,7 @@ class ConvStackFn(torch.autograd.Function):
             if fused_sq and li == len(blocks) - 1:
                 g_y = torch.empty_like(a)
                 ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,
-                                  prezeroed=gb_zero)
+                                  prezeroed=gb_zero, loss_acc=ctx.sq_deferred)
             else:
                 g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
                 ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,

@@ -206,14 +206,15 @@ def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=No
                "pgv_act_bn_bwd")
 
 
-def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False):
+def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, loss_acc=None):
     """g_y = act'(a) * 2 scale g_loss (a - x), gbias += sum over (batch, pixels): squared-error criterion + output
-    activation of a block without BatchNorm, backward in one pass."""
+    activation of a block without BatchNorm, backward in one pass.  ``loss_acc`` (zeroed scalar) += the criterion."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(a, x, g_loss, g_y, gbias)
+    _chk(a, x, g_loss, g_y, gbias, loss_acc)
     _lib.check(_lib.load().pgv_sqerr_act_bwd(_p(a), _p(x), _p(g_loss), scale, B, C, HW, act, slope, _p(g_y), _p(gbias),
-                                             PGV_PREZEROED if prezeroed else 0, _stream()), "pgv_sqerr_act_bwd")
+                                             _p(loss_acc), PGV_PREZEROED if prezeroed else 0, _stream()),
+               "pgv_sqerr_act_bwd")
 
 
 def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None):

@@ -47,7 +47,8 @@ class VAETrainStep:
         # let the model evaluate this criterion inside the decoder's output stack (fused backward, VAE.py)
         vae = getattr(ae_model, 'ae_model', ae_model)
         if hasattr(vae, 'fuse_recons_criterion'):
-            vae.fuse_recons_criterion = 'mse_mean' if normalize_losses else 'l2_batch'
+            # (deferred: this class always runs backward before anybody reads the loss values)
+            vae.fuse_recons_criterion = ('mse_mean' if normalize_losses else 'l2_batch') + '+deferred'
         self.controls_criterion = loss_mod.MSELoss(reduction='mean')
         self.use_graph = use_graph
         self._const = {}
@@ -79,15 +80,16 @@ class VAETrainStep:
         # the reported total is one fused multiply-add
         one, beta_t = self._constants(x.device)
         roots, root_grads = [recons, lat], [one, beta_t]
-        total = torch.addcmul(recons.detach(), lat.detach(), beta_t)
         cont = None
         if self.reg_model is not None and v_in is not None:
             v_out = self.reg_model(zK)
             cont = self.controls_criterion(v_out, v_in)
-            total = total + cont.detach()
             roots.append(cont)
             root_grads.append(one)
         torch.autograd.backward(roots, root_grads)
+        total = torch.addcmul(recons.detach(), lat.detach(), beta_t)   # (after backward: recons may be deferred)
+        if cont is not None:
+            total = total + cont.detach()
         return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(),
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
                 'x_out': x_out.detach()}

@@ -345,7 +345,7 @@ def test_fused_reconstruction_criterion_matches_separate(normalize):
         _load_closed_form(ae, arch, dim_z, False, 77)
         ae = ae.cuda().train()
         step = VAETrainStep(ae, lr=1e-5, normalize_losses=normalize)
-        assert ae.fuse_recons_criterion == ('mse_mean' if normalize else 'l2_batch')
+        assert ae.fuse_recons_criterion == ('mse_mean' if normalize else 'l2_batch') + '+deferred'
         if not fused:
             ae.fuse_recons_criterion = None
         out = step.step(x, inject={'eps': eps})
