@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="operand precision of the conv / linear products (bf16 = BASELINE config 2's arithmetic: bf16 "
                          "matrix cores, fp32 accumulation and storage); the default line is fp32")
+    ap.add_argument("--input", default="spectrograms", choices=["spectrograms", "audio"],
+                    help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
+                         "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--dist-graph", action="store_true",
                     help="N > 1: replay [fwd+bwd] and [Adam] as two hipGraphs around an eager, non-overlapped all-reduce")
@@ -272,8 +275,23 @@ def main():
     step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
                         beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
 
+    frontend = None
+    if args.input == "audio":
+        from preset_gen_vae_amd.utils.audio import MelSpectrogram
+        frontend = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+        frontend.set_minmax_normalization(-120.0, 3.5)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234 + rank)
+        wav = 0.3 * torch.randn(args.batch, 88576, device=device, generator=gen)   # 173 render buffers of 512 samples
+        x = frontend.batch(wav)
+
+    def one_step(xin):
+        if frontend is not None:
+            frontend.batch(wav, out=xin)
+        return step.step(xin)
+
     for _ in range(args.warmup):
-        out = step.step(x)
+        out = one_step(x)
     if step.static_input is not None:
         # the minibatch lives in the captured step's input buffer (where the on-GPU front-end / the H2D copy of a real
         # loader would put it): inputs are resident in HBM when the timed region starts, no device-to-device copy
@@ -284,7 +302,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step.step(x)
+        out = one_step(x)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -315,7 +333,9 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == 'bf16' else "f32", "data": "synthetic",
             "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
-                                   f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel",
+                                   f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
+                                   + (" computed on the GPU from raw audio [B, 88576] inside the timed step"
+                                      if args.input == "audio" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": (("hipGraph" if world == 1 else "2 hipGraphs + eager all-reduce") if use_graph
                                   else "eager"),

@@ -329,11 +329,16 @@ def adam_step(p, g, m, v, hyper, beta1, beta2, eps, weight_decay):
                                          weight_decay, _stream()), "pgv_adam_step")
 
 
-def stft_mel(wav, hop, n_frames, window, norm, mel_csr, n_mels, floor_lin, affine_a, affine_b):
+def stft_mel(wav, hop, n_frames, window, norm, mel_csr, n_mels, floor_lin, affine_a, affine_b, out=None):
     B, n = wav.shape
     _chk(wav, window)
     rows = n_mels if n_mels > 0 else 513
-    out = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.float32)
+    else:
+        _chk(out)
+        if out.numel() != B * rows * n_frames:
+            raise ValueError(f"stft_mel: out has {out.numel()} elements, expected {B}x{rows}x{n_frames}")
     rp, col, val = mel_csr if mel_csr is not None else (None, None, None)
     _lib.check(_lib.load().pgv_stft_mel(_p(wav), B, n, 1024, hop, n_frames, _p(window), norm,
                                         None if rp is None else rp.data_ptr(), None if col is None else col.data_ptr(),

@@ -110,7 +110,7 @@ class Spectrogram:
             self._window_dev = self.window.to(x_wav.device)
         return x_wav.contiguous(), single
 
-    def _run(self, x_wav, log_scale=True):
+    def _run(self, x_wav, log_scale=True, out=None):
         x, single = self._prep(x_wav)
         floor = 10 ** (self.min_dB / 20.0)
         a, b = 1.0, 0.0
@@ -128,7 +128,7 @@ class Spectrogram:
                                  torch.tensor(val, device=x.device))
             csr = self._mel_csr
         out = ops.stft_mel(x, self.fft_hop, self.n_frames(x.shape[1]), self._window_dev,
-                           self.spectrogram_norm_factor, csr, self.n_mel_bins, floor, a, b)
+                           self.spectrogram_norm_factor, csr, self.n_mel_bins, floor, a, b, out=out)
         return out[0] if single else out
 
     def __call__(self, x_wav):
@@ -153,6 +153,9 @@ class MelSpectrogram(Spectrogram):
         # (audio.py:85-86); the reference's own Fs is 22050 (config.py:30), so both coincide.
         self.mel_basis = slaney_mel_basis(22050, n_fft, n_mel_bins)
 
-    def batch(self, wav):
-        """[B, n_samples] -> [B, 1, n_mels, T]: the tensor layout the encoder consumes."""
-        return self._run(wav).unsqueeze(1)
+    def batch(self, wav, out=None):
+        """[B, n_samples] -> [B, 1, n_mels, T]: the tensor layout the encoder consumes.  ``out`` (contiguous
+        [B, 1, n_mels, T]): write there - e.g. ``VAETrainStep.static_input``, so that the captured step consumes the
+        spectrograms where the front-end leaves them."""
+        res = self._run(wav, out=out)
+        return out if out is not None else res.unsqueeze(1)
