@@ -278,6 +278,52 @@ __global__ void sqerr_act_bwd_kernel(const float* __restrict__ a, const float* _
   }
 }
 
+// single-channel form of the above (the spectrogram output layer: C = 1): one flat grid-stride pass, so the launch is
+// as wide as the tensor is long instead of one workgroup per batch split
+__global__ void sqerr_act_bwd_flat_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                          const float* __restrict__ g_loss, float scale, int64_t n, int act,
+                                          float slope, float* __restrict__ g_y, float* __restrict__ gbias,
+                                          float* __restrict__ loss_acc) {
+  __shared__ float red[16];
+  const float k = 2.0f * scale * g_loss[0];
+  float acc = 0.f, sq = 0.f;
+  auto one = [&](float av, float xv) -> float {
+    const float d = av - xv;
+    sq = fmaf(d, d, sq);
+    float g = k * d;
+    if (act == PGV_ACT_LEAKY_RELU)
+      g = av > 0.f ? g : slope * g;
+    else if (act == PGV_ACT_HARDTANH)
+      g = (av > -1.f && av < 1.f) ? g : 0.f;
+    return g;
+  };
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f4u av = *reinterpret_cast<const f4u*>(a + 4 * i);
+    const f4u xv = *reinterpret_cast<const f4u*>(x + 4 * i);
+    f4u r;
+    r.x = one(av.x, xv.x);
+    r.y = one(av.y, xv.y);
+    r.z = one(av.z, xv.z);
+    r.w = one(av.w, xv.w);
+    *reinterpret_cast<f4u*>(g_y + 4 * i) = r;
+    acc += (r.x + r.y) + (r.z + r.w);
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float r = one(a[i], x[i]);
+    g_y[i] = r;
+    acc += r;
+  }
+  if (gbias) {
+    const float s = pgv_block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&gbias[0], s);
+  }
+  if (loss_acc) {
+    const float s = pgv_block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, scale * s);
+  }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ld, float* __restrict__ out) {
   // block: 64 columns x 4 row-groups; rows split over blockIdx.y.
   __shared__ float part[4][64];
@@ -410,6 +456,14 @@ int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float
     if (rc) return rc;
   }
   if (B == 0) return PGV_OK;
+  if (C == 1) {
+    const int64_t n = (int64_t)B * HW;
+    const unsigned blocks = (unsigned)max((int64_t)1, min((int64_t)2048, pgv_cdiv(n, 256 * 16)));
+    hipLaunchKernelGGL(sqerr_act_bwd_flat_kernel, dim3(blocks), dim3(256), 0, st, a, x, g_loss, scale, n, act, slope,
+                       g_y, gbias, loss_acc);
+    PGV_CHECK_LAUNCH("sqerr_act_bwd");
+    return PGV_OK;
+  }
   Split s = pick_split(B, C, HW);
   hipLaunchKernelGGL(sqerr_act_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, a, x, g_loss, scale, B, C, HW, s.per,
                      act, slope, g_y, gbias, loss_acc);
