@@ -1,0 +1,16 @@
+"""Timing of the BatchNorm backward passes on the deep-layer shapes (cold cache)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from preset_gen_vae_amd import ops
+B = 256
+tot = [0.0, 0.0]
+for C, HW in ((64, 391), (128, 108), (256, 35), (512, 12), (2048, 12)):
+    a = torch.randn(B, C, HW, device='cuda'); g = torch.randn(B, C, HW, device='cuda'); gy = torch.empty_like(g)
+    mean, rstd, scale = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.ones(C, device='cuda')
+    red = torch.zeros(2 * C, device='cuda', dtype=torch.float64); gb = torch.zeros(C, device='cuda')
+    t1 = bench.time_kernel(lambda: ops.bn_bwd_reduce(g, a, mean, rstd, red, prezeroed=True), iters=5) * 1e3
+    t2 = bench.time_kernel(lambda: ops.act_bn_bwd(g, a, scale, mean, rstd, red, 1, 0.1, gy, gb, prezeroed=True), iters=5) * 1e3
+    tot[0] += t1; tot[1] += t2
+    print(f"C={C:5d} HW={HW:4d}: reduce {t1:6.1f} us, act_bn_bwd {t2:6.1f} us   ({a.numel()*4/1e6:.1f} MB)")
+print(f"sum reduce {tot[0]:.1f}  act {tot[1]:.1f}")

@@ -354,7 +354,8 @@ def test_empty_batch(ops):
     assert out.shape == (0, 3, geom.Hs, geom.Ws)
 
 
-@pytest.mark.parametrize("shape", [(4, 16, 65 * 88), (3, 7, 33 * 45), (6, 2048, 12), (256, 128, 1), (2, 8, 129 * 174)])
+@pytest.mark.parametrize("shape", [(4, 16, 65 * 88), (3, 7, 33 * 45), (6, 2048, 12), (256, 128, 1), (2, 8, 129 * 174),
+                                   (19, 2048, 12), (9, 512, 35), (33, 128, 108), (12, 64, 391), (8, 130, 12)])
 def test_batchnorm_pieces(ops, shape):
     B, C, HW = shape
     a = synth_vec((B, C, HW), 0.831, 0.2) * 1.3 + 0.4 * synth_vec((1, C, 1), 1.9, 0.3)
