@@ -85,6 +85,7 @@ def layer_ops(ae):
 
 
 _FLUSH = None
+_SINK = None
 
 
 def _graph_of(body):
@@ -117,24 +118,30 @@ _FLUSH_MS = {}
 def time_kernel(fn, iters=5):
     """Average device time of one fn() launch (kernel + its memset node, as the train step issues it) in ms, measured
     the way the step runs it: as nodes of a replayed hipGraph, so no host launch latency sits between nodes.  Graph A =
-    iters x [rewrite a 512 MB buffer, fn()], graph B = iters x [rewrite the buffer]; HIP events around the replays on
-    the replay stream; the result is (A - B) / iters.  The rewrite puts every timed launch's operands back in HBM
-    (not L2 / the 256 MB Infinity Cache), as inside the train step, where ~1 GB of other tensors pass between two
-    uses of a tensor."""
-    global _FLUSH
+    iters x [stream through a 512 MB buffer, fn()], graph B = iters x [stream through the buffer]; HIP events around
+    the replays on the replay stream; the result is (A - B) / iters.  The streaming pass puts every timed launch's
+    operands back in HBM (not L2 / the 256 MB Infinity Cache), as inside the train step, where ~1 GB of other tensors
+    pass between two uses of a tensor.  It READS the buffer (a reduction): a rewrite would leave 256 MB of dirty lines
+    whose write-back competes with the timed kernel for HBM (measured: +15..30 % on the HBM-bound kernels, against
+    their in-step rocprofv3 durations)."""
+    global _FLUSH, _SINK
     if _FLUSH is None:
-        _FLUSH = torch.empty(128 << 20, device='cuda', dtype=torch.float32)
+        _FLUSH = torch.ones(128 << 20, device='cuda', dtype=torch.float32)
+        _SINK = torch.zeros((), device='cuda', dtype=torch.float32)
     fn()
     torch.cuda.synchronize()
 
+    def flush():
+        torch.sum(_FLUSH, dim=(0,), out=_SINK)
+
     def with_fn():
         for _ in range(iters):
-            _FLUSH.fill_(1.0)
+            flush()
             fn()
 
     def without_fn():
         for _ in range(iters):
-            _FLUSH.fill_(1.0)
+            flush()
 
     if iters not in _FLUSH_MS:
         _FLUSH_MS[iters] = _time_graph(_graph_of(without_fn))
