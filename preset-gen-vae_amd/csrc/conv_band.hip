@@ -413,7 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
 #ifdef PGV_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    if constexpr (!BF16) {
+    // ragged last band (e.g. 17 output rows = 8 + 8 + 1): a wave whose pixel tiles all lie beyond the band's rows has
+    // nothing to multiply - it leaves the matrix pipe of its SIMD to the co-resident workgroup
+    const bool wave_active = wave * NT * 16 < min(R, G::Hs - (u % BANDS) * R) * G::Ws;
+    if (!wave_active) {
+    } else if constexpr (!BF16) {
       constexpr int S = CK * KS;  // steps (c, kh); one MFMA per (step, m, t) consumes the 4 kw taps
       float a0[MT], a1[MT], b0[NT], b1[NT];
       auto load_step = [&](int st, float (&av)[MT], float (&bv)[NT]) {
@@ -1052,7 +1056,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
     BAND_ACC(3);
     __syncthreads();
     BAND_ACC(4);
-    if constexpr (!BF16) {
+    // ragged last band (e.g. 17 grid rows = 8 + 8 + 1): a wave whose pixel tiles all lie beyond the band's rows has
+    // nothing to multiply - it leaves the matrix pipe of its SIMD to the co-resident workgroup
+    const bool wave_active = wave * NT * 16 < min(R, Hg - (u % BANDS) * R) * Wg;
+    if (!wave_active) {
+    } else if constexpr (!BF16) {
       constexpr int S = CK;  // one k-group (th, tw) per input channel
       static_assert(S % 2 == 0, "step count must be even");
       float a0[MT], a1[MT], b0[NT], b1[NT];
