@@ -1292,7 +1292,7 @@ int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in
   if (d->Hb == 65 && d->Wb == 88 && d->Cs <= 32)
     return launch_down_band<2, 3, 8, 2, true, 4, 88, 65, true>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 33 && d->Wb == 45 && d->Cs <= 64)
-    return launch_down_band<4, 3, 8, 4, false, 8, 45, 33, false>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+    return launch_down_band<4, 4, 8, 4, false, 9, 45, 33, false>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   return 0;
 }
 
