@@ -1316,7 +1316,7 @@ int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float*
                      const pgv_bn_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->Hb == 129 && d->Wb == 174)
-    return launch_up_band<2, 6, 16, 1, true, 2, 4, 174, 129, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+    return launch_up_band<2, 7, 16, 1, true, 2, 5, 174, 129, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);  // 65 grid rows = 13 x 5
   if (d->Hb == 65 && d->Wb == 88)
     return launch_up_band<4, 3, 16, 2, true, 4, 4, 88, 65, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 33 && d->Wb == 45)
