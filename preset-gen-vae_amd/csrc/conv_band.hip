@@ -1320,6 +1320,6 @@ int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float*
   if (d->Hb == 65 && d->Wb == 88)
     return launch_up_band<4, 3, 16, 2, true, 4, 4, 88, 65, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 33 && d->Wb == 45)
-    return launch_up_band<8, 3, 16, 4, false, 2, 8, 45, 33, false>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+    return launch_up_band<8, 3, 16, 4, false, 4, 8, 45, 33, false>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);  // epilogue in 2 passes of 16 channels
   return 0;
 }
