@@ -1306,7 +1306,7 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
   if (d->kh != 4) return 0;
   if (d->Hb == 129 && d->Wb == 174) PGV_WGB(4, 1, 16, 8, 1, 1, 1, 174, 129);
   if (d->Hb == 65 && d->Wb == 88) PGV_WGB(4, 2, 32, 16, 1, 2, 1, 88, 65);
-  if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 16, 2, 4, 2, 45, 33);
+  if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 16, 2, 4, 3, 45, 33);
 #undef PGV_WGB
   return 0;
 }
