@@ -303,7 +303,8 @@ def test_conv_prezeroed_outputs_accumulate(ops, case):
 
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64), (32, 64, 4, 2, 2, 33, 45, 6),
                                   (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2), (1, 8, 5, 2, 2, 257, 347, 21),
-                                  (128, 256, 4, 2, 2, 9, 12, 7), (256, 512, 4, 2, 2, 5, 7, 9), (512, 2048, 1, 1, 0, 3, 4, 19)])
+                                  (128, 256, 4, 2, 2, 9, 12, 7), (256, 512, 4, 2, 2, 5, 7, 9), (512, 2048, 1, 1, 0, 3, 4, 19),
+                                  (1, 8, 5, 2, 2, 257, 347, 70)])   # > 1024 units: persistent direct kernel, 2 units per WG
 def test_conv_bn_fuse_matches_separate_reduce(ops, case):
     """pgv_bn_fuse: the BatchNorm-backward projections accumulated while an input-gradient kernel writes its output
     equal those of a separate pgv_bn_bwd_reduce pass over that output (fused band / deep-layer epilogues and the
