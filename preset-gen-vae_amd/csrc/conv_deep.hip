@@ -1043,9 +1043,9 @@ int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float*
     return launch_k1_fwd<12, 4, 32, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
                                           out, stats, st, "conv_up_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
-  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up<5, 7, 4, 4>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up<5, 7, 4, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
   return 0;
 }
 
