@@ -1040,7 +1040,7 @@ int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float*
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
                      hipStream_t st) {
   if (shape_k1_3x4(d))
-    return launch_k1_fwd<12, 4, 32, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
+    return launch_k1_fwd<12, 4, 64, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
                                           out, stats, st, "conv_up_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
