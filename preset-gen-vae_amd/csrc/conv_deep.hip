@@ -837,6 +837,179 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
   }
 }
 
+// 8-wave form of the 1x1 DOWN kernel: 128 output channels x (NS*P) columns per 512-thread workgroup (waves 4 (M) x
+// 2 (N)).  The 64-row form re-reads the input planes once per 64 output channels and is bound by the L2 -> LDS stream
+// (enc8: 32 x 25 MB + 16 x 4 MB per launch ~ 10 TB/s); doubling the rows per workgroup halves the dominant term at the
+// same two waves per SIMD.
+template <int P, int NS, int CK, bool BF16>
+__global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COUT, const float* __restrict__ in,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int act, float slope, float* __restrict__ out,
+                                                         double* __restrict__ stats, int groups) {
+  constexpr int N = NS * P, NT = (N + 15) / 16, NTW = (NT + 1) / 2;   // column tiles per wave (parity split)
+  constexpr int AS = CK + 4, A_FLOATS = 128 * AS, CH_STRIDE = NS * P, B_FLOATS = CK * CH_STRIDE;
+  constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+  constexpr int QA = 128 * CK / 4 / 512, QB_ITEMS = NS * CK * P / 4, QB = (QB_ITEMS + 511) / 512;
+  static_assert((128 * CK / 4) % 512 == 0 && CK % 16 == 0 && P % 4 == 0, "tile shapes");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, j = lane >> 4, wm = wave & 3, wn = wave >> 2;
+  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  const int co0 = mb * 128, b0 = grp * NS;
+
+  int a_src[QA], a_dst[QA];
+#pragma unroll
+  for (int i = 0; i < QA; ++i) {
+    const int q = tid + 512 * i, row = q / (CK / 4), f = q - row * (CK / 4);
+    a_src[i] = (co0 + row) * CIN + 4 * f;
+    a_dst[i] = row * AS + 4 * f;
+  }
+  int b_src[QB], b_dst[QB], b_ch[QB];
+  bool b_ok[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    const int q = min(tid + 512 * i, QB_ITEMS - 1);
+    b_ok[i] = tid + 512 * i < QB_ITEMS;
+    const int si = q / (CK * P / 4), qq = q - si * (CK * P / 4);
+    const int ch = (4 * qq) / P, pix = 4 * qq - ch * P;
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = bs * CIN * P + 4 * qq;
+    b_ch[i] = ch;
+    b_dst[i] = ch * CH_STRIDE + si * P + pix;
+  }
+  int bn[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) bn[t] = min((2 * t + wn) * 16 + m, N - 1) + 4 * j * CH_STRIDE;
+  const int a_frag = (wm * 32 + m) * AS + 4 * j;
+  f32x4 acc[2][NTW];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[QA], rb[QB];
+  auto issue = [&](int slab) {
+    const int ci0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + ci0);
+#pragma unroll
+    for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+  };
+  auto commit = [&](int slab, float* st) {
+    const int ci0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < QA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
+    float* bt = st + A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+      if (b_ok[i]) {
+        f32x4 v = rb[i];
+        if (in_scale) {
+          const float sc = in_scale[ci0 + b_ch[i]], sh = in_shift[ci0 + b_ch[i]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+        }
+        *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
+      }
+    }
+  };
+  const int nslab = CIN / CK;
+  issue(0);
+  commit(0, lds);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const float* st = lds + (s & 1) * STAGE;
+    if (s + 1 < nslab) issue(s + 1);
+    const float* ap = st + a_frag;
+    const float* bp = st + A_FLOATS;
+#pragma unroll
+    for (int g = 0; g < CK / 16; ++g) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + 16 * g);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 16 * AS + 16 * g);
+      if constexpr (BF16) {
+        const s16x4 av0 = pack_bf16x4(a0[0], a0[1], a0[2], a0[3]), av1 = pack_bf16x4(a1[0], a1[1], a1[2], a1[3]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const float* q = bp + bn[t] + 16 * g * CH_STRIDE;
+          const s16x4 bv = pack_bf16x4(q[0], q[CH_STRIDE], q[2 * CH_STRIDE], q[3 * CH_STRIDE]);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av0, bv, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av1, bv, acc[1][t], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float bvv = bp[bn[t] + (16 * g + e) * CH_STRIDE];
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], bvv, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], bvv, acc[1][t], 0, 0, 0);
+          }
+      }
+    }
+    if (s + 1 < nslab) commit(s + 1, lds + ((s + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  const pgv_act_params apar = pgv_act_setup(act, slope);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = co0 + wm * 32 + r * 16 + 4 * j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int n = (2 * t + wn) * 16 + m;
+      const int si = n / P, pix = n - si * P;
+      const bool ok = n < N && b0 + si < B;
+      float* o = out + ((int64_t)(b0 + si) * COUT + c0) * P + pix;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = pgv_act_apply(acc[r][t][i] + bv[i], apar);
+        if (ok) {
+          o[i * P] = v;
+          s1[i] += v;
+          s2[i] += v * v;
+        }
+      }
+    }
+    if (stats) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+        if (m == 0) {
+          atomicAdd(&stats[c0 + i], (double)a1);
+          atomicAdd(&stats[COUT + c0 + i], (double)a2);
+        }
+      }
+    }
+  }
+}
+
+template <int P, int NS, int CK>
+int launch_k1_down128(int B, int CIN, int COUT, int flags, const float* in, const float* in_scale, const float* in_shift,
+                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                      hipStream_t st, const char* who) {
+  if (COUT % 128 || CIN % CK) return 0;
+  constexpr int STAGE = (128 * (CK + 4) + CK * NS * P + 3) / 4 * 4;
+  const size_t bytes = sizeof(float) * 2 * (size_t)STAGE;
+  const bool bf16 = (flags & PGV_COMPUTE_BF16) != 0;
+  auto kern = bf16 ? k1_down128_kernel<P, NS, CK, true> : k1_down128_kernel<P, NS, CK, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[bf16], who);
+  if (rc) return rc;
+  if (stats && !(flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * COUT, st) != hipSuccess) {
+    pgv_set_error("%s: memset failed", who);
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (B + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (COUT / 128))), dim3(512), bytes, st, B, CIN, COUT, in, in_scale,
+                     in_shift, w, bias, act, slope, out, stats, groups);
+  PGV_CHECK_LAUNCH(who);
+  return 1;
+}
+
 template <int P, int NS, int CK, bool TRANSA>
 int launch_k1_fwd(int B, int CIN, int COUT, int flags, const float* in, const float* in_scale, const float* in_shift,
                   const float* w, const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
@@ -1026,6 +1199,9 @@ bool shape_k1_3x4(const pgv_conv_desc* d) {
 int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
                        hipStream_t st) {
+  if (shape_k1_3x4(d) && d->Cs % 128 == 0)
+    return launch_k1_down128<12, 16, 32>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
+                                         stats, st, "conv_down_deep");
   if (shape_k1_3x4(d))
     return launch_k1_fwd<12, 16, 32, false>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
                                            stats, st, "conv_down_deep");
