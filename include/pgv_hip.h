@@ -206,6 +206,20 @@ int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_fft, int hop,
                  const float* mel_val, int n_mels, float floor_lin, float affine_a, float affine_b, float* out,
                  void* stream);
 
+/* The same transform with a choice of output (Spectrogram surface of utils/audio.py:24-61):
+ *   PGV_STFT_DB       out[B][rows][n_frames] = affine_a * 20*log10(max(mag, floor_lin)) + affine_b   (= pgv_stft_mel;
+ *                     Spectrogram.__call__ with log_scale=True :42-54, MelSpectrogram.__call__ :80-87)
+ *   PGV_STFT_LINEAR   out[B][rows][n_frames] = mag = |STFT| / norm (mel-projected when n_mels > 0), no clamp, no
+ *                     affine (Spectrogram(log_scale=False).__call__, :42-50)
+ *   PGV_STFT_COMPLEX  out[B][n_fft/2+1][n_frames][2] = (re, im) of the un-normalised one-sided STFT
+ *                     (Spectrogram.get_stft :33-40 = torch.stft(center=True, pad_mode='constant')); n_mels must be 0. */
+#define PGV_STFT_DB 0
+#define PGV_STFT_LINEAR 1
+#define PGV_STFT_COMPLEX 2
+int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, int hop, int n_frames, const float* window,
+             float norm, const int32_t* mel_row_ptr, const int32_t* mel_col, const float* mel_val, int n_mels,
+             int out_mode, float floor_lin, float affine_a, float affine_b, float* out, void* stream);
+
 /* ---- misc -------------------------------------------------------------------------------------------- */
 int pgv_fill(float* p, int64_t n, float v, void* stream);
 /* y = a*x + y */

@@ -319,10 +319,17 @@ def is_parameter_key(k):
 
 
 def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, normalize_losses=True, lr=2e-4,
-               betas=(0.9, 0.999), weight_decay=1e-4, adam_state=None, step=1, taps=None, act_masks=None):
-    """One minibatch of train.py:203-248 without the regression network: forward, MSE + beta*Dkl, backward, Adam.
+               betas=(0.9, 0.999), weight_decay=1e-4, adam_state=None, step=1, taps=None, act_masks=None, reg=None):
+    """One minibatch of train.py:203-248: forward, MSE + beta*Dkl (+ controls loss), backward, Adam.
+
+    ``reg`` (optional) adds the preset-regression network of train.py:220,238-246: dict(sd={'reg_model...': tensor},
+    v_in=[B, L] targets, masks=[two keep/(1-p) dropout masks] or None); its parameters then appear in ``grads`` /
+    ``new_sd`` / ``adam_state`` under 'reg.<key>' and the result carries 'controls' and 'v_out'.
 
     Returns dict(losses, outputs, grads{key}, new_sd{key}, adam_state)."""
+    sd = dict(sd)
+    if reg is not None:
+        sd.update({'reg.' + k: v for k, v in reg['sd'].items()})
     params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_parameter_key(k)}
     full = dict(sd)
     full.update(params)
@@ -334,6 +341,14 @@ def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, 
         recons = l2_loss(x_out, x)                                      # train.py:105-106
     lat = gaussian_dkl(zml[:, 0, :], zml[:, 1, :], normalize=normalize_losses)   # train.py:225
     total = recons + lat * beta                                         # train.py:227,246
+    cont = v_out = None
+    if reg is not None:
+        rsd = {k[len('reg.'):]: v for k, v in full.items() if k.startswith('reg.')}
+        rbuf = {}
+        v_out = mlp_regression_forward(rsd, z, True, reg.get('masks'), rbuf)      # train.py:220
+        cont = numeric_params_loss(v_out, reg['v_in'])                           # train.py:238-239
+        total = total + cont                                                       # train.py:246
+        new_buffers.update({'reg.' + k: v for k, v in rbuf.items()})
     keys = list(params.keys())
     grads = torch.autograd.grad(total, [params[k] for k in keys])
     grads = dict(zip(keys, grads))
@@ -350,8 +365,11 @@ def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, 
         hits = [k for k in sd if k.endswith(k_suffix)]
         assert len(hits) == 1, (k_suffix, hits)
         new_sd[hits[0]] = val
-    return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(), 'z_mu_logvar': zml.detach(),
-            'z': z.detach(), 'x_out': x_out.detach(), 'grads': grads, 'new_sd': new_sd, 'adam_state': new_state}
+    res = {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(), 'z_mu_logvar': zml.detach(),
+           'z': z.detach(), 'x_out': x_out.detach(), 'grads': grads, 'new_sd': new_sd, 'adam_state': new_state}
+    if reg is not None:
+        res['controls'], res['v_out'] = cont.detach(), v_out.detach()
+    return res
 
 
 def closed_form_state_dict(template, seed=1234, dtype=torch.float32):

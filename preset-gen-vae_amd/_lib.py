@@ -68,6 +68,8 @@ SIGNATURES = {
     "pgv_adam_tick": (c_int, [_P, _P, c_float, c_float, _P]),
     "pgv_stft_mel": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_float,
                              c_float, c_float, _P, _P]),
+    "pgv_stft": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_int, c_float,
+                         c_float, c_float, _P, _P]),
     "pgv_fill": (c_int, [_P, c_int64, c_float, _P]),
     "pgv_axpy": (c_int, [c_int64, c_float, _P, _P, _P]),
     "pgv_copy": (c_int, [_P, _P, c_int64, _P]),

@@ -13,6 +13,9 @@ class _Config(object):
 
 model = _Config()
 model.name = "BasicVAE"
+model.run_name = '00_debug'                    # config.py:21
+model.logs_root_dir = "saved"                  # config.py:75
+model.increased_dataset_size = None            # config.py:41, see update_dynamic_config_params()
 model.encoder_architecture = 'speccnn8l1_bn'   # config.py:24 ; 'speccnn4l1_bn' = BASELINE "4-layer conv-VAE"
 model.params_regression_architecture = 'mlp_3l1024'   # config.py:26 (flow_* variants are out of scope)
 model.params_reg_softmax = False               # config.py:27
@@ -39,6 +42,14 @@ train.latent_loss = 'Dkl'                      # config.py:90
 train.latent_flow_input_regularization = 'bn'  # config.py:92 -> output_bn=True (build.py:25)
 train.normalize_losses = True                  # config.py:98
 train.optimizer = 'Adam'
+train.test_holdout_proportion = 0.2            # config.py:82
+train.lr_warmup_epochs = 6                     # config.py:107
+train.lr_warmup_start_factor = 0.1             # config.py:108
+train.scheduler_name = 'ReduceLROnPlateau'     # config.py:120
+train.scheduler_lr_factor = 0.2                # config.py:123
+train.scheduler_patience = 6                   # config.py:125
+train.scheduler_cooldown = 6                   # config.py:126
+train.scheduler_threshold = 1e-4               # config.py:127
 train.initial_learning_rate = 2e-4             # config.py:105
 train.adam_betas = (0.9, 0.999)                # config.py:109
 train.weight_decay = 1e-4                      # config.py:110
@@ -53,6 +64,7 @@ def update_dynamic_config_params():
     """Derived fields (reference config.py:148-202, the part the builders read)."""
     model.stack_spectrograms = model.stack_spectrograms and (len(model.midi_notes) > 1)
     model.concat_midi_to_z = (len(model.midi_notes) > 1) and not model.stack_spectrograms
+    model.increased_dataset_size = (len(model.midi_notes) > 1) and not model.stack_spectrograms   # config.py:157
     model.input_tensor_size = (train.minibatch_size, 1 if not model.stack_spectrograms else len(model.midi_notes),
                                model.spectrogram_size[0], model.spectrogram_size[1])
 

@@ -30,7 +30,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 5; }
+int pgv_abi_version(void) { return 6; }
 const char* pgv_last_error(void) { return g_err; }
 int pgv_set_kernel_policy(int policy) {
   g_policy = policy;

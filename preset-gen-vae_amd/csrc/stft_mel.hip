@@ -13,6 +13,7 @@
 //     the filterbank (<= 14 taps per row, staged in LDS), results are collected in an LDS [rows][FT] tile and written
 //     as FT-float row segments.
 #include "pgv_common.h"
+#include "../../include/pgv_hip.h"
 
 namespace {
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     const float* __restrict__ wav, int64_t n_samples, int hop, int n_frames, const float* __restrict__ window,
     float inv_norm, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, int n_rows, int use_mel, float floor_lin, float aff_a, float aff_b,
-    float* __restrict__ out, int sig_len, int csr_cap) {
+    float* __restrict__ out, int sig_len, int csr_cap, int mode) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* xall = reinterpret_cast<float2*>(lds);                   // [NWAVE][XBUF]
   float* sig = lds + 2 * NWAVE * XBUF;                             // [sig_len]
@@ -178,7 +179,22 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     // ---- split the packed pair and take magnitudes, in place: slot k <- (|Xa[k]|, |Xb[k]|) / norm.
     // Xa[k] = (Z[k] + conj(Z[N-k]))/2 ; Xb[k] = (Z[k] - conj(Z[N-k]))/(2i).  Slot k <= 512 is written by the lane that
     // read it; the partner slots N-k (>= 512) are never written, so no lane reads a slot another lane has overwritten.
-    if (valid) {
+    if (valid && mode == PGV_STFT_COMPLEX) {
+      // Spectrogram.get_stft (utils/audio.py:33-40): the complex, un-normalised one-sided STFT, straight to HBM as
+      // interleaved (re, im) of out[b][k][frame] (an API-completeness path: stores are frame-strided, not tuned)
+      float2* oc = reinterpret_cast<float2*>(out) + (int64_t)b * NBIN * n_frames + f0 + fp;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int k = lane + 64 * i;
+        if (k < NBIN) {
+          const float2 zk = xb[k];
+          const float2 zn = xb[(NFFT - k) & (NFFT - 1)];
+          oc[(int64_t)k * n_frames] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+          if (has2) oc[(int64_t)k * n_frames + 1] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+      }
+    }
+    if (valid && mode != PGV_STFT_COMPLEX) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int k = lane + 64 * i;
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
       }
     }
     wave_sync();
-    if (valid) {
+    if (valid && mode != PGV_STFT_COMPLEX) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int k = lane + 64 * i;
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     }
     wave_sync();
     // ---- mel projection (or the linear bins), dB, affine -> tile[row][fp], tile[row][fp+1]
-    if (valid) {
+    if (valid && mode != PGV_STFT_COMPLEX) {
       for (int r = lane; r < n_rows; r += 64) {
         float m0, m1;
         if (use_mel) {
@@ -237,20 +253,28 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
           m0 = mg.x;
           m1 = mg.y;
         }
-        tile[r * (FT + 1) + fp] = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
+        // PGV_STFT_LINEAR (Spectrogram(log_scale=False), utils/audio.py:42-50): the normalised amplitudes as they are
+        tile[r * (FT + 1) + fp] =
+            mode == PGV_STFT_LINEAR
+                ? m0
+                : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
         if (has2)
           tile[r * (FT + 1) + fp + 1] =
-              fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
+              mode == PGV_STFT_LINEAR
+                  ? m1
+                  : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
       }
     }
     wave_sync();
   }
   __syncthreads();
   // write the [n_rows][nf] tile: lanes run along frames inside a row segment
-  float* o = out + (int64_t)b * n_rows * n_frames;
-  for (int i = tid; i < n_rows * FT; i += 256) {
-    const int r = i / FT, f = i % FT;
-    if (f < nf) o[(int64_t)r * n_frames + f0 + f] = tile[r * (FT + 1) + f];
+  if (mode != PGV_STFT_COMPLEX) {
+    float* o = out + (int64_t)b * n_rows * n_frames;
+    for (int i = tid; i < n_rows * FT; i += 256) {
+      const int r = i / FT, f = i % FT;
+      if (f < nf) o[(int64_t)r * n_frames + f0 + f] = tile[r * (FT + 1) + f];
+    }
   }
   __syncthreads();  // the tile and the signal window are rewritten by the next group
   }
@@ -262,6 +286,17 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
                             const float* window, float norm, const int32_t* mel_row_ptr, const int32_t* mel_col,
                             const float* mel_val, int n_mels, float floor_lin, float affine_a, float affine_b,
                             float* out, void* stream) {
+  return pgv_stft(wav, B, n_samples, n_fft, hop, n_frames, window, norm, mel_row_ptr, mel_col, mel_val, n_mels,
+                  PGV_STFT_DB, floor_lin, affine_a, affine_b, out, stream);
+}
+
+extern "C" int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, int hop, int n_frames,
+                        const float* window, float norm, const int32_t* mel_row_ptr, const int32_t* mel_col,
+                        const float* mel_val, int n_mels, int out_mode, float floor_lin, float affine_a,
+                        float affine_b, float* out, void* stream) {
+  PGV_CHECK_ARG(out_mode == PGV_STFT_DB || out_mode == PGV_STFT_LINEAR || out_mode == PGV_STFT_COMPLEX,
+                "pgv_stft: unknown output mode %d", out_mode);
+  PGV_CHECK_ARG(out_mode != PGV_STFT_COMPLEX || n_mels == 0, "pgv_stft: the complex STFT has no mel projection");
   PGV_CHECK_ARG(n_fft == NFFT, "pgv_stft_mel: only n_fft=1024 is implemented (got %d)", n_fft);
   PGV_CHECK_ARG(wav && window && out && B >= 0 && n_samples >= 0 && hop > 0 && hop <= NFFT && n_frames > 0 &&
                     norm > 0.f,
@@ -295,7 +330,7 @@ extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_ff
   dim3 grid((unsigned)per_wave, (unsigned)B);
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(256), lds_bytes, pgv_stream(stream), wav, n_samples, hop, n_frames,
                      window, 1.0f / norm, mel_row_ptr, mel_col, mel_val, n_rows, n_mels > 0 ? 1 : 0, floor_lin,
-                     affine_a, affine_b, out, sig_len, csr_cap);
+                     affine_a, affine_b, out, sig_len, csr_cap, out_mode);
   PGV_CHECK_LAUNCH("stft_mel");
   return PGV_OK;
 }

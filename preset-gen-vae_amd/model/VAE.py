@@ -86,12 +86,20 @@ class BasicVAE(nn.Module):
 
         ``eps`` / ``*_dropout_mask`` inject the random draws (parity harness); by default they come from the on-device
         Philox stream (``rng.py``)."""
+        rng = None
+        if self.training:
+            # ONE generator for the three random draws of a step (two fc Dropout masks, eps), each on its own Philox
+            # stream id (independent masks, as the reference's torch generator gives), advanced once per forward
+            from ..rng import device_rng
+            rng = device_rng(self, x.device)
+            object.__setattr__(self.encoder, '_rng', rng)
+            object.__setattr__(self.decoder, '_rng', rng)
+            rng.begin()
         z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
         n_minibatch = z_mu_logvar.size()[0]
         if self.training:
             if eps is None:
-                from ..rng import device_rng
-                eps = device_rng(self, z_mu_logvar.device).normal((n_minibatch, self.dim_z))
+                eps = rng.normal((n_minibatch, self.dim_z))
             # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
             # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
             kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
@@ -109,6 +117,8 @@ class BasicVAE(nn.Module):
             x_out._pgv_recons = (x.data_ptr(), scale, recons)
         else:
             x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
+        if rng is not None:
+            rng.flush()
         return z_mu_logvar, z_sampled, z_sampled, _zero_log_abs_det_jac(n_minibatch, x.device), x_out
 
     def latent_loss(self, z_0_mu_logvar, z_0_sampled=None, z_K_sampled=None, log_abs_det_jac=None, **kwargs):

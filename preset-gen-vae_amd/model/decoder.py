@@ -69,6 +69,7 @@ class SpectrogramDecoder(nn.Module):
         self.mixer_1x1conv_ch = 2048
         self.last_4x4conv_ch = (512 if not force_bigger_network else 1800)
         self.fc_dropout = fc_dropout
+        self._rng = None   # dropout mask source: the enclosing VAE's generator, else a local one (rng.device_rng)
         if architecture not in ('speccnn8l1_bn', 'speccnn4l1_bn'):
             raise NotImplementedError("Only speccnn8l1_bn / speccnn4l1_bn are available")
         if self.spectrogram_channels != 1 and architecture != 'speccnn8l1_bn':
@@ -110,8 +111,9 @@ class SpectrogramDecoder(nn.Module):
         mixed = layer.LinearFn.apply(z_sampled, lin.weight, lin.bias)
         if self.training and self.fc_dropout > 0.0:
             if dropout_mask is None:
-                from ..rng import device_rng
-                mixed = layer.DropoutFn.apply(mixed, device_rng(self, mixed.device), self.fc_dropout)
+                from ..rng import STREAM_DEC_DROPOUT, device_rng
+                mixed = layer.DropoutFn.apply(mixed, device_rng(self, mixed.device), self.fc_dropout,
+                                              STREAM_DEC_DROPOUT)
             else:
                 mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
         mixed = mixed.view(-1, self.cnn_input_shape[0], self.cnn_input_shape[1], self.cnn_input_shape[2])

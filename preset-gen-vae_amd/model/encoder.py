@@ -154,8 +154,9 @@ class SpectrogramEncoder(nn.Module):
         cnn_out = self._forward_cnns(x_spectrograms).view(n_minibatch, -1)
         if self.training and self.fc_dropout > 0.0:
             if dropout_mask is None:
-                from ..rng import device_rng
-                cnn_out = layer.DropoutFn.apply(cnn_out, device_rng(self, cnn_out.device), self.fc_dropout)
+                from ..rng import STREAM_ENC_DROPOUT, device_rng
+                cnn_out = layer.DropoutFn.apply(cnn_out, device_rng(self, cnn_out.device), self.fc_dropout,
+                                                STREAM_ENC_DROPOUT)
             else:
                 cnn_out = layer.MaskMulFn.apply(cnn_out, dropout_mask.reshape(-1))
         lin = self.mlp[1]

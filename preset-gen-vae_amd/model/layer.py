@@ -119,9 +119,12 @@ GRAD_READY_HOOK = None
 
 
 def _grad_done(*params):
+    """Parameters of a stack that is applied several times per forward (``_pgv_shared``: stacked spectrogram channels)
+    are NOT announced: their gradient is the sum over the applications, accumulated by autograd after this kernel, so
+    their bucket is only complete when backward has returned - ``GradAllReduce.wait()`` flushes it then."""
     if GRAD_READY_HOOK is not None:
         for p in params:
-            if p is not None:
+            if p is not None and not getattr(p, '_pgv_shared', False):
                 GRAD_READY_HOOK(p)
 
 
@@ -380,15 +383,15 @@ class DropoutFn(torch.autograd.Function):
     """nn.Dropout (train mode) with the mask drawn from the on-device Philox stream inside the forward kernel."""
 
     @staticmethod
-    def forward(ctx, x, rng, p):
-        y, mask = rng.dropout(p, x.contiguous())
+    def forward(ctx, x, rng, p, stream_id=0):
+        y, mask = rng.dropout(p, x.contiguous(), stream_id)
         ctx.save_for_backward(mask)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (mask,) = ctx.saved_tensors
-        return ops.mul(gy.contiguous(), mask), None, None
+        return ops.mul(gy.contiguous(), mask), None, None, None
 
 
 class BatchNorm1dFn(torch.autograd.Function):

@@ -9,20 +9,29 @@ import torch.nn as nn
 
 
 class PresetActivation(nn.Module):
-    """Hardtanh(0,1) on every output neuron (reference regression.py:20-53 with ``cat_softmax_activation=False``,
-    the configuration train.py uses for numeric-only parity; the softmax-on-categorical branch is out of scope)."""
+    """Per-parameter output activations (reference regression.py:20-53): Hardtanh(0,1) on every output neuron, or - with
+    ``cat_softmax_activation`` - Hardtanh on the numerical columns and a softmax over every categorical (one-hot)
+    sub-vector.  Stock torch ops; the reference writes into its input in place, this module does not."""
 
     def __init__(self, idx_helper, numerical_activation=None, cat_softmax_activation=False):
         super().__init__()
-        if cat_softmax_activation:
-            raise NotImplementedError("softmax activation on categorical sub-vectors is out of scope (SURVEY §8 f4)")
         self.idx_helper = idx_helper
         self.numerical_act = nn.Hardtanh(min_val=0.0, max_val=1.0) if numerical_activation is None \
             else numerical_activation
-        self.cat_softmax_activation = False
+        self.cat_softmax_activation = cat_softmax_activation
+        if self.cat_softmax_activation:
+            self.categorical_act = nn.Softmax(dim=-1)
+            self.num_indexes = list(self.idx_helper.get_numerical_learnable_indexes())
+            self.cat_indexes = [list(g) for g in self.idx_helper.get_categorical_learnable_indexes()]
 
     def forward(self, x):
-        return self.numerical_act(x)
+        if not self.cat_softmax_activation:
+            return self.numerical_act(x)
+        out = x.clone()
+        out[:, self.num_indexes] = self.numerical_act(x[:, self.num_indexes])
+        for cat_learnable_indexes in self.cat_indexes:
+            out[:, cat_learnable_indexes] = self.categorical_act(x[:, cat_learnable_indexes])
+        return out
 
 
 class MLPRegression(nn.Module):

@@ -329,22 +329,33 @@ def adam_step(p, g, m, v, hyper, beta1, beta2, eps, weight_decay):
                                          weight_decay, _stream()), "pgv_adam_step")
 
 
-def stft_mel(wav, hop, n_frames, window, norm, mel_csr, n_mels, floor_lin, affine_a, affine_b, out=None):
+STFT_DB, STFT_LINEAR, STFT_COMPLEX = 0, 1, 2
+
+
+def stft_mel(wav, hop, n_frames, window, norm, mel_csr, n_mels, floor_lin, affine_a, affine_b, out=None, mode=STFT_DB):
+    """``mode``: STFT_DB (clamped dB + affine), STFT_LINEAR (normalised amplitudes), STFT_COMPLEX (complex64
+    [B, 513, n_frames] un-normalised one-sided STFT; no mel projection) - ``pgv_stft`` of include/pgv_hip.h."""
     B, n = wav.shape
     _chk(wav, window)
     rows = n_mels if n_mels > 0 else 513
-    if out is None:
-        out = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.float32)
+    if mode == STFT_COMPLEX:
+        if n_mels > 0 or out is not None:
+            raise ValueError("stft_mel: the complex STFT has no mel projection / caller-provided output")
+        res = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.complex64)
+        out = torch.view_as_real(res)
+    elif out is None:
+        res = out = torch.empty((B, rows, n_frames), device=wav.device, dtype=torch.float32)
     else:
         _chk(out)
         if out.numel() != B * rows * n_frames:
             raise ValueError(f"stft_mel: out has {out.numel()} elements, expected {B}x{rows}x{n_frames}")
+        res = out
     rp, col, val = mel_csr if mel_csr is not None else (None, None, None)
-    _lib.check(_lib.load().pgv_stft_mel(_p(wav), B, n, 1024, hop, n_frames, _p(window), norm,
-                                        None if rp is None else rp.data_ptr(), None if col is None else col.data_ptr(),
-                                        _p(val), n_mels, floor_lin, affine_a, affine_b, _p(out), _stream()),
-               "pgv_stft_mel")
-    return out
+    _lib.check(_lib.load().pgv_stft(_p(wav), B, n, 1024, hop, n_frames, _p(window), norm,
+                                    None if rp is None else rp.data_ptr(), None if col is None else col.data_ptr(),
+                                    _p(val), n_mels, mode, floor_lin, affine_a, affine_b, out.data_ptr(), _stream()),
+               "pgv_stft")
+    return res
 
 
 def fill(t, v):

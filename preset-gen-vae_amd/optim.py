@@ -26,6 +26,7 @@ class FlatParams:
             if id(p) not in seen:
                 seen.add(id(p))
                 uniq.append(p)
+        self.params_natural = list(uniq)        # registration order: the order torch.optim.Adam(model.parameters()) sees
         self.params = list(reversed(uniq))
         if not self.params:
             raise ValueError("no parameters")
@@ -104,21 +105,34 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, flat: FlatParams, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         self.flat = flat
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        super().__init__(flat.params, defaults)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
+        # parameters in REGISTRATION order, so that state_dict() indices mean what they mean in the reference's
+        # torch.optim.Adam(extended_ae_model.parameters()) (train.py:166-167): checkpoints are interchangeable
+        super().__init__(flat.params_natural, defaults)
         dev = flat.flat_param.device
         self.exp_avg = torch.zeros_like(flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
         self.hyper = torch.tensor([lr, 1.0, 1.0, grad_scale], device=dev, dtype=torch.float32)
         self.pows = torch.ones(2, device=dev, dtype=torch.float64)
         self._lr = lr
+        self._offset_of = {id(p): o for p, o in zip(flat.params, flat.offsets)}
 
     def set_lr(self, lr):
         """LR warm-up / ReduceLROnPlateau hook (train.py:195-197,296): writes the device-resident learning rate."""
         self._lr = float(lr)
         for g in self.param_groups:
             g['lr'] = float(lr)
-        ops.fill(self.hyper[0:1], float(lr))
+        if self.hyper.is_cuda:
+            ops.fill(self.hyper[0:1], float(lr))
+        else:
+            self.hyper[0] = float(lr)
+
+    def sync_lr(self):
+        """Pick up a learning rate that a torch scheduler (or train.py:195-197's warm-up loop) wrote into
+        ``param_groups``.  ``step()`` does it on every eager step; a captured step calls it before each replay."""
+        lr = self.param_groups[0]['lr']
+        if lr != self._lr:
+            self.set_lr(lr)
 
     def zero_grad(self, set_to_none=False):
         """``optimizer.zero_grad()`` of train.py:208: ONE fill of the flat gradient buffer.  The weight / bias gradient
@@ -132,8 +146,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        if g['lr'] != self._lr:  # a torch LR scheduler edited param_groups
-            self.set_lr(g['lr'])
+        self.sync_lr()
         b1, b2 = g['betas']
         lib = _lib.load()
         _lib.check(lib.pgv_adam_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2,
@@ -143,3 +156,73 @@ class FusedAdam(torch.optim.Optimizer):
                       g['weight_decay'])
         f.grad_zeroed = False
         return None
+
+    # -- checkpoints (logs/logger.py:199-202 saves optimizer.state_dict(), train.py:177-179 restores it) ----------
+    def step_count(self):
+        """Number of updates applied so far, recovered from the device-side beta1^t (the count advances on the device so
+        that captured steps replay correctly; reading it synchronises - checkpoint time only)."""
+        b1 = self.param_groups[0]['betas'][0]
+        p0 = float(self.pows[0].item())
+        if p0 >= 1.0 or not 0.0 < b1 < 1.0:
+            return 0
+        import math
+        return int(round(math.log(p0) / math.log(b1)))
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: ``state[i] = {'step', 'exp_avg', 'exp_avg_sq'}`` per parameter i of
+        ``model.parameters()`` order plus ``param_groups`` - loadable by ``torch.optim.Adam.load_state_dict`` (and so by
+        the reference), and what ``load_state_dict`` below accepts."""
+        sd = super().state_dict()
+        t = self.step_count()
+        state = {}
+        if t > 0:
+            for i, p in enumerate(self.flat.params_natural):
+                o, n = self._offset_of[id(p)], p.numel()
+                state[i] = {'step': torch.tensor(float(t)),
+                            'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        sd['state'] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.flat.params_natural):
+            raise ValueError("optimizer state_dict does not match this model: expected ONE parameter group of "
+                             f"{len(self.flat.params_natural)} parameters")
+        if groups[0].get('amsgrad', False):
+            raise ValueError("amsgrad state cannot be loaded (train.py:166-167 uses plain Adam)")
+        g = self.param_groups[0]
+        for k in ('betas', 'eps', 'weight_decay'):
+            if k in groups[0]:
+                g[k] = tuple(groups[0][k]) if k == 'betas' else groups[0][k]
+        state = state_dict['state']
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, p in enumerate(self.flat.params_natural):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            o, n = self._offset_of[id(p)], p.numel()
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(st['step']))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one fused step counter only")
+        t = steps.pop() if steps else 0
+        b1, b2 = g['betas']
+        self.pows.copy_(torch.tensor([b1 ** t, b2 ** t], dtype=torch.float64))
+        self.hyper[1:3].copy_(torch.tensor([1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32))
+        self.set_lr(groups[0]['lr'])
+
+    def snapshot(self):
+        """Copies of everything a step changes on the optimizer side (graph-capture warm-up, train_step.py)."""
+        return (self.flat.flat_param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.pows.clone(),
+                self.hyper.clone())
+
+    def restore(self, snap):
+        for dst, src in zip((self.flat.flat_param, self.exp_avg, self.exp_avg_sq, self.pows, self.hyper), snap):
+            dst.copy_(src)

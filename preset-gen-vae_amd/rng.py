@@ -10,38 +10,63 @@ import torch
 from . import ops
 
 
+# Philox stream ids of the consumers: one counter space each, so draws at the same offset are independent
+STREAM_DROPOUT, STREAM_EPS, STREAM_ENC_DROPOUT, STREAM_DEC_DROPOUT = 0, 1, 2, 3
+
+
 class DeviceRNG:
+    """{seed, offset} in device memory.  Every consumer draws on its own Philox stream id; the offset advances after a
+    draw - immediately, or, between ``begin()`` and ``flush()``, ONCE for all draws of a forward pass (one tiny
+    dependent launch per step instead of one per draw)."""
+
     def __init__(self, device, seed=None):
         if seed is None:
             seed = torch.initial_seed()
         self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
-        self._calls = 0
+        self._deferred = False
+        self._pending = 0
+
+    def begin(self):
+        self._deferred, self._pending = True, 0
+
+    def flush(self):
+        if self._pending:
+            ops.rng_advance(self.state, self._pending)
+        self._deferred, self._pending = False, 0
 
     def _advance(self, n):
-        ops.rng_advance(self.state, (n + 3) // 4)
+        inc = (n + 3) // 4
+        if self._deferred:
+            self._pending = max(self._pending, inc)
+        else:
+            ops.rng_advance(self.state, inc)
 
-    def dropout_mask(self, p, shape):
+    def dropout_mask(self, p, shape, stream_id=STREAM_DROPOUT):
         n = 1
         for s in shape:
             n *= int(s)
-        mask = ops.dropout_mask(self.state, 0, float(p), n, self.state.device)
+        mask = ops.dropout_mask(self.state, stream_id, float(p), n, self.state.device)
         self._advance(n)
         return mask.view(*shape)
 
-    def dropout(self, p, x):
+    def dropout(self, p, x, stream_id=STREAM_DROPOUT):
         """nn.Dropout forward on ``x`` in one pass: returns (x * mask, mask); the same draw as ``dropout_mask``."""
-        y, mask = ops.dropout_apply(self.state, 0, float(p), x)
+        y, mask = ops.dropout_apply(self.state, stream_id, float(p), x)
         self._advance(x.numel())
         return y, mask
 
-    def normal(self, shape):
-        out = ops.normal(self.state, 1, tuple(int(s) for s in shape), self.state.device)
+    def normal(self, shape, stream_id=STREAM_EPS):
+        out = ops.normal(self.state, stream_id, tuple(int(s) for s in shape), self.state.device)
         self._advance(out.numel())
         return out
 
 
 def device_rng(module, device):
-    """RNG attached to ``module`` (created lazily on ``device``; seeded from ``torch.initial_seed()``)."""
+    """RNG attached to ``module`` (created lazily on ``device``; seeded from ``torch.initial_seed()``).  A module whose
+    ``_rng`` attribute is set (encoder / decoder inside a VAE) draws from that shared generator instead."""
+    shared = getattr(module, '_rng', None)
+    if shared is not None and shared.state.device == device:
+        return shared
     rng = getattr(module, '_pgv_rng_obj', None)
     if rng is None or rng.state.device != device:
         rng = DeviceRNG(device)

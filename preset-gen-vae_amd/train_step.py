@@ -95,16 +95,39 @@ class VAETrainStep:
                 'x_out': x_out.detach()}
 
     def _constants(self, device):
+        """(1, beta) as device scalars.  beta is written IN PLACE when ``self.beta`` changed (``set_beta``, or a caller
+        assigning the attribute as train.py:227's ``Sched/beta`` ramp would): a captured step reads the same address."""
         c = self._const.get(str(device))
         if c is None:
-            c = self._const[str(device)] = (torch.ones((), device=device), torch.full((), self.beta, device=device))
-        return c
+            c = self._const[str(device)] = [torch.ones((), device=device), torch.full((), self.beta, device=device),
+                                            self.beta]
+        if c[2] != self.beta:
+            c[1].fill_(self.beta)
+            c[2] = self.beta
+        return c[0], c[1]
+
+    def set_beta(self, beta):
+        """KL weight schedule (config.py:114-117: beta ramps 0.1 -> 0.2 over 25 epochs, applied at train.py:227)."""
+        self.beta = float(beta)
+        for dev in list(self._const):
+            self._constants(torch.device(dev))
+
+    def set_lr(self, lr):
+        """Learning-rate schedule (warm-up train.py:195-197, ReduceLROnPlateau train.py:296).  Editing
+        ``optimizer.param_groups[...]['lr']`` as torch schedulers do works too: ``step`` syncs it before every launch."""
+        self.optimizer.set_lr(lr)
 
     def step(self, x, v_in=None, inject=None):
+        """One minibatch.  Returns the losses / outputs as device tensors; in graph mode they are the captured step's
+        static buffers: read them before the next ``step`` overwrites them."""
         if not self.use_graph or inject:
             return self._step_body(x, v_in, inject)
         if self._graph is None:
             self._capture(x, v_in)
+        # schedules: the captured kernels read lr / beta from device memory; refresh those words when the host-side
+        # values (param_groups['lr'] edited by a scheduler, self.beta) changed since the last launch
+        self.optimizer.sync_lr()
+        self._constants(self._static_x.device)
         # a loader that writes its minibatch straight into ``static_input`` (and passes that tensor) skips the copy
         if x.data_ptr() != self._static_x.data_ptr():
             self._static_x.copy_(x, non_blocking=True)
@@ -122,15 +145,41 @@ class VAETrainStep:
         output of ``MelSpectrogram.batch`` or the destination of the host-to-device copy - and pass it to ``step``."""
         return self._static_x
 
+    def _mutable_state(self):
+        """Every tensor a step changes besides the flat parameter / Adam buffers: BatchNorm running statistics and
+        counters, the device RNG states."""
+        mods = [self.model] + ([self.reg_model] if self.reg_model is not None else [])
+        ts = []
+        for m in mods:
+            ts += [b for b in m.buffers()]
+            for sub in m.modules():
+                rng = getattr(sub, '_pgv_rng_obj', None)
+                if rng is not None:
+                    ts.append(rng.state)
+        return ts
+
     def _capture(self, x, v_in):
         self._static_x = x.clone()
         self._static_v = None if v_in is None else v_in.clone()
-        # warm-up on a side stream (allocator pools, lazy module state), then capture
+        # warm-up on a side stream (allocator pools, lazy module state), then capture.  The warm-up runs REAL steps
+        # (on N ranks including the exchange); everything they changed - parameters, Adam moments and step count,
+        # BatchNorm running statistics, RNG offsets - is put back afterwards, so that the first replay is step 1 of
+        # the run exactly as in the eager mode and in the reference
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        from .rng import device_rng
+        vae = getattr(self.model, 'ae_model', self.model)
+        if hasattr(vae, 'encoder'):
+            device_rng(vae, self._static_x.device)        # the generator exists before its state is snapshotted
         with torch.cuda.stream(s):
+            snap_opt = self.optimizer.snapshot()
+            state = self._mutable_state()
+            snap_state = [t.clone() for t in state]
             for _ in range(2):
                 self._step_body(self._static_x, self._static_v)
+            self.optimizer.restore(snap_opt)
+            for t, c in zip(state, snap_state):
+                t.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()

@@ -110,13 +110,17 @@ class Spectrogram:
             self._window_dev = self.window.to(x_wav.device)
         return x_wav.contiguous(), single
 
-    def _run(self, x_wav, log_scale=True, out=None):
+    def _run(self, x_wav, log_scale=True, out=None, mode=None):
         x, single = self._prep(x_wav)
         floor = 10 ** (self.min_dB / 20.0)
         a, b = 1.0, 0.0
-        if not log_scale:
-            raise NotImplementedError("linear-amplitude output is not produced by the fused kernel")
-        if self.minmax is not None:
+        if mode is None:
+            mode = ops.STFT_DB if log_scale else ops.STFT_LINEAR
+        if mode == ops.STFT_COMPLEX:
+            res = ops.stft_mel(x, self.fft_hop, self.n_frames(x.shape[1]), self._window_dev,
+                               self.spectrogram_norm_factor, None, 0, floor, 1.0, 0.0, mode=mode)
+            return res[0] if single else res
+        if self.minmax is not None and mode == ops.STFT_DB:
             mn, mx = self.minmax
             a = 2.0 / (mx - mn)
             b = -1.0 - mn * a
@@ -128,15 +132,28 @@ class Spectrogram:
                                  torch.tensor(val, device=x.device))
             csr = self._mel_csr
         out = ops.stft_mel(x, self.fft_hop, self.n_frames(x.shape[1]), self._window_dev,
-                           self.spectrogram_norm_factor, csr, self.n_mel_bins, floor, a, b, out=out)
+                           self.spectrogram_norm_factor, csr, self.n_mel_bins, floor, a, b, out=out, mode=mode)
         return out[0] if single else out
 
+    def get_stft(self, x_wav):
+        """The complex, non-normalised STFT (reference audio.py:33-40: torch.stft(n_fft, hop, window, center=True,
+        pad_mode='constant', onesided=True)): complex64 ``[n_fft/2+1, T]`` (``[B, n_fft/2+1, T]`` for a batch)."""
+        return self._run(x_wav, mode=ops.STFT_COMPLEX)
+
     def __call__(self, x_wav):
+        """Log-scale spectrogram with the 'floor' dB value, or (``log_scale=False``) the normalised amplitudes
+        (audio.py:42-50)."""
         return self._run(x_wav, self.log_scale)
 
     def linear_to_log_scale(self, spectrogram):
         spectrogram = torch.clamp(spectrogram, min=10 ** (self.min_dB / 20.0))
         return 20.0 * torch.log10(spectrogram)
+
+    def linear_to_log_scale_with_dynamic_range(self, spectrogram):
+        """audio.py:63-69: log scale, then everything below (max - dynamic_range_dB) is raised to that level."""
+        assert self.dynamic_range_dB is not None  # (the reference asserts the same)
+        spectrogram = self.linear_to_log_scale(spectrogram)
+        return torch.maximum(spectrogram, torch.max(spectrogram) - self.dynamic_range_dB)
 
     def log_to_linear_scale(self, spectrogram):
         return torch.pow(10.0, spectrogram / 20.0) * self.spectrogram_norm_factor
@@ -152,6 +169,14 @@ class MelSpectrogram(Spectrogram):
         # librosa.feature.melspectrogram(S=..., n_mels=..., norm=None) ignores self.Fs and uses its default sr=22050
         # (audio.py:85-86); the reference's own Fs is 22050 (config.py:30), so both coincide.
         self.mel_basis = slaney_mel_basis(22050, n_fft, n_mel_bins)
+
+    def mel_dB_to_STFT(self, mel_spectrogram):
+        """Reference audio.py:89-92 inverts the filterbank with ``librosa.feature.inverse.mel_to_stft`` - an iterative
+        non-negative least-squares solve of an under-determined system (257 mel rows, 513 bins) inside librosa ~=0.8
+        (not vendored, not installed): its result depends on that solver's iteration, not on a closed form, so it has no
+        restatement here.  Off the train-step path (evaluation / audio export only)."""
+        raise NotImplementedError("mel_dB_to_STFT needs librosa's NNLS mel inversion (third-party, out of scope); use "
+                                  "log_to_linear_scale() for the mel-amplitude spectrogram")
 
     def batch(self, wav, out=None):
         """[B, n_samples] -> [B, 1, n_mels, T]: the tensor layout the encoder consumes.  ``out`` (contiguous

@@ -296,9 +296,18 @@ def run_stft_cases(out_dir):
         frames = [0, 1, 2, 100, 173, 344, 345, 346]
         out[f'wave{idx}/frames'] = np.array(frames)
         out[f'wave{idx}/mag'] = mag[:, frames].numpy()
+        out[f'wave{idx}/stft_re'] = stft.real[:, frames].numpy()      # get_stft: complex, un-normalised
+        out[f'wave{idx}/stft_im'] = stft.imag[:, frames].numpy()
         out[f'wave{idx}/db'] = db[:, frames].numpy()
         out[f'wave{idx}/db_checksum'] = np.array([db.double().sum().item(), db.double().abs().sum().item(),
                                                   db.max().item(), db.min().item()])
+    # log_scale=False and the dynamic-range variant of the log scale (utils/audio.py:42-50, :63-69)
+    wav = synth_wave(idx=1)
+    lin = ref_audio.Spectrogram(1024, 256, -120.0, log_scale=False)(wav.astype(np.float64))
+    out['linear/frames'] = np.array(frames)
+    out['linear/mag'] = lin[:, frames].numpy()
+    dyn = ref_audio.Spectrogram(1024, 256, -120.0, dynamic_range_dB=60.0)
+    out['dynrange/db'] = dyn.linear_to_log_scale_with_dynamic_range(lin)[:, frames].numpy()
     # short waveform: ragged/edge case (fewer samples than one FFT)
     short = synth_wave(n=700, idx=5)
     out['short/db'] = spec(short.astype(np.float64)).numpy()
@@ -351,6 +360,76 @@ def run_regression_case(out_dir):
     np.savez_compressed(path, **out)
     print('regression mse', loss.item(), '->', path, os.path.getsize(path) // 1024, 'KiB')
 
+
+def run_regstep_case(out_dir):
+    """The whole minibatch body of train.py:203-248 WITH the preset-regression network: ae_out = VAE(x), v_out =
+    reg_model(z_K) (train.py:220), recons + beta * lat + cont_loss (numeric SynthParamsLoss, train.py:238-246), one
+    backward through both networks (the controls gradient reaches the encoder through z_K), Adam over all parameters of
+    the extended model (train.py:166-167)."""
+    arch, dim_z, B = 'speccnn4l1_bn', 64, 4
+    vae = build_reference_vae(arch, dim_z, B, False).double()
+    template = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    sd = vo.closed_form_state_dict(template, seed=1234, dtype=torch.float64)
+    vae.load_state_dict(sd)
+    helper = _AllNumericalHelper()
+    reg = ref_regression.MLPRegression('3l1024', dim_z, helper, dropout_p=0.4, cat_softmax_activation=False).double()
+    rtemplate = {k: tuple(v.shape) for k, v in reg.state_dict().items()}
+    reg.load_state_dict(vo.closed_form_state_dict(rtemplate, seed=4321, dtype=torch.float64))
+    x = synth_input(B)
+    eps = synth_vec((B, dim_z), 1.2345, 0.4) * 1.3
+    v_in = 0.5 * (synth_vec((B, 144), 0.377, 0.6) + 1.0)
+    enc_mask = keep_mask((B, vae.encoder.mlp[1].in_features), 0.3, 0.7071, 0.1)
+    dec_mask = keep_mask((B, vae.decoder.mlp[0].out_features), 0.3, 0.5772, 0.9)
+    vae.encoder.mlp[0] = _MaskMul(enc_mask)
+    vae.decoder.mlp[1] = _MaskMul(dec_mask)
+    rmasks = [keep_mask((B, 1024), 0.4, 0.61 + 0.1 * i, 0.2 * i) for i in range(2)]
+    reg.reg_model.drp1 = _MaskMul(rmasks[0])
+    reg.reg_model.drp2 = _MaskMul(rmasks[1])
+    _FixedNormal.eps = eps
+    vae.train(), reg.train()
+    params = list(vae.parameters()) + list(reg.parameters())
+    opt = torch.optim.Adam(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    crit = ref_loss.SynthParamsLoss(helper, True, prevent_useless_params_loss=False, cat_bce=False, cat_softmax=True,
+                                    cat_softmax_t=0.2)
+    with mock.patch.object(ref_VAE, 'Normal', _FixedNormal):
+        opt.zero_grad()
+        zml, z0, zk, ladj, x_out = vae(x)
+        v_out = reg(zk)
+        recons = nn.MSELoss(reduction='mean')(x_out, x)
+        lat = vae.latent_loss(zml)
+        lat_b = lat * 0.2
+        cont = crit(v_out, v_in.clone())
+        (recons + lat_b + torch.tensor([0.0], dtype=torch.float64) + cont).backward()
+    out = {'meta/arch': np.array(arch), 'meta/dim_z': np.array(dim_z), 'meta/B': np.array(B),
+           'meta/seed': np.array(1234), 'meta/reg_seed': np.array(4321), 'meta/beta': np.array(0.2),
+           'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4),
+           'meta/reg_keys': np.array(list(rtemplate.keys())),
+           'meta/reg_shapes': np.array([' '.join(str(d) for d in v) for v in rtemplate.values()]),
+           'in/eps': eps.numpy(), 'in/v_in': v_in.numpy(),
+           'in/enc_mask_bits': np.packbits((enc_mask > 0).numpy()), 'in/dec_mask_bits': np.packbits((dec_mask > 0).numpy()),
+           'in/enc_mask_shape': np.array(enc_mask.shape), 'in/dec_mask_shape': np.array(dec_mask.shape),
+           'in/reg_mask0_bits': np.packbits((rmasks[0] > 0).numpy()),
+           'in/reg_mask1_bits': np.packbits((rmasks[1] > 0).numpy()),
+           'train/z_mu_logvar': zml.detach().numpy(), 'train/v_out': v_out.detach().numpy(),
+           'train/recons': np.array(recons.item()), 'train/latent': np.array(lat.item()),
+           'train/controls': np.array(cont.item()), 'train/total': np.array((recons + lat_b + cont).item())}
+    pack_big('train/x_out', x_out, out)
+    for k, p in vae.named_parameters():
+        pack_big('grad/' + k, p.grad, out)
+    for k, p in reg.named_parameters():
+        pack_big('grad_reg/' + k, p.grad, out)
+    opt.step()
+    for k, v in list(vae.state_dict().items()) + [('reg.' + k, v) for k, v in reg.state_dict().items()]:
+        if v.dtype == torch.long:
+            out['post/' + k] = v.numpy()
+        elif v.numel() <= 4096:
+            out['post_full/' + k] = v.detach().numpy()
+        else:
+            pack_big('post/' + k, v, out)
+    path = os.path.join(out_dir, 'regstep_4l_b4.npz')
+    np.savez_compressed(path, **out)
+    print('regstep recons', recons.item(), 'lat', lat.item(), 'cont', cont.item(), '->', path,
+          os.path.getsize(path) // 1024, 'KiB')
 
 
 def run_probability_case(out_dir):
@@ -414,6 +493,15 @@ def run_params_loss_case(out_dir):
     acc = ref_loss.CategoricalParamsAccuracy(helper, reduce=False, percentage_output=False)(raw, u_in)
     out['accuracy/keys'] = np.array(list(acc.keys()))
     out['accuracy/values'] = np.array(list(acc.values()))
+    # PresetActivation with the softmax on categorical sub-vectors (model/regression.py:35-51)
+    act = ref_regression.PresetActivation(helper, cat_softmax_activation=True)
+    xin = (synth_vec((B, L), 0.531, 0.9) * 2.0)
+    leaf = xin.clone().requires_grad_(True)
+    y = act(leaf * 1.0)                               # (the reference writes into its argument in place)
+    gy = synth_vec((B, L), 0.77, 0.4)
+    (y * gy).sum().backward()
+    out['act_softmax/in'], out['act_softmax/out'] = xin.numpy(), y.detach().numpy()
+    out['act_softmax/gy'], out['act_softmax/gx'] = gy.numpy(), leaf.grad.numpy()
     # the Dexed useless-parameter rule of data/preset.py:259-281 through the reference's own method
     from data import preset as ref_preset
     f2l = [None] * 155
@@ -511,6 +599,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'probability':
         run_probability_case(HERE)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'regstep':
+        run_regstep_case(HERE)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'b16':
+        run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)
+        run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'stacked':
         run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
         sys.exit(0)
@@ -521,6 +616,9 @@ if __name__ == '__main__':
     run_vae_case('speccnn8l1_bn', 64, 2, True, 'vae8l_b2_outbn', HERE)
     run_vae_case('speccnn4l1_bn', 64, 2, False, 'vae4l_b2', HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
+    run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)       # B = 16 capture
+    run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
+    run_regstep_case(HERE)
     run_dataset_seam_case(HERE)
     run_probability_case(HERE)
     run_params_loss_case(HERE)

@@ -141,3 +141,38 @@ def test_dataset_seam_f1_matches_oracle(tmp_path):
             assert torch.allclose(ds.normalize_spectrogram(back), spec, atol=1e-5)
     with pytest.raises(RuntimeError):
         BatchedPresetSpectrograms(waves, params, uids, midi_notes=notes).get_batch([0])
+
+
+def test_get_stft_linear_scale_and_dynamic_range_match_reference():
+    """SURVEY 8b front-end surface: Spectrogram.get_stft (complex), log_scale=False, linear_to_log_scale_with_dynamic_range
+    (utils/audio.py:33-50, :63-69) against the reference's own outputs (tests/golden/stft.npz) and the numpy oracle."""
+    _need_gpu()
+    from oracle import audio_oracle as ao
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram, Spectrogram
+    g = load_golden('stft.npz')
+    spec = Spectrogram(1024, 256, -120.0)
+    for idx in range(3):
+        wav = ao.synth_fm_wave(idx=idx)
+        z = spec.get_stft(wav.astype(np.float64))
+        assert z.dtype == torch.complex64 and tuple(z.shape) == (513, 347)
+        frames = g[f'wave{idx}/frames']
+        ref = g[f'wave{idx}/stft_re'] + 1j * g[f'wave{idx}/stft_im']
+        got = z.cpu().numpy()[:, frames]
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+        full = ao.stft_complex(wav)                                  # float64 oracle, every frame
+        assert np.abs(z.cpu().numpy() - full).max() <= 2e-5 * np.abs(full).max()
+    zb = spec.get_stft(torch.tensor(np.stack([ao.synth_fm_wave(idx=i) for i in range(3)])))
+    assert tuple(zb.shape) == (3, 513, 347)
+    assert np.abs(zb[2].cpu().numpy() - ao.stft_complex(ao.synth_fm_wave(idx=2))).max() < 2e-5 * 512
+    # log_scale=False: the normalised amplitudes
+    wav = ao.synth_fm_wave(idx=1)
+    lin = Spectrogram(1024, 256, -120.0, log_scale=False)(wav.astype(np.float64))
+    frames = g['linear/frames']
+    assert np.abs(lin.cpu().numpy()[:, frames] - g['linear/mag']).max() <= 2e-5 * g['linear/mag'].max()
+    assert np.abs(lin.cpu().numpy() - ao.spectrogram_mag(wav)).max() <= 2e-5 * g['linear/mag'].max()
+    dyn = Spectrogram(1024, 256, -120.0, dynamic_range_dB=60.0).linear_to_log_scale_with_dynamic_range(lin)
+    assert np.abs(dyn.cpu().numpy()[:, frames] - g['dynrange/db']).max() < 2e-2
+    with pytest.raises(AssertionError):
+        spec.linear_to_log_scale_with_dynamic_range(lin)             # no dynamic range given (reference asserts too)
+    with pytest.raises(NotImplementedError, match="librosa"):
+        MelSpectrogram(1024, 256, -120.0, 257, 22050).mel_dB_to_STFT(torch.zeros(257, 4))

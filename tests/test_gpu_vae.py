@@ -96,8 +96,12 @@ def _region_pairs(masks, sd64, x, arch, dim_z, eps, enc_mask, dec_mask):
             yield m, taps[n + '_act']
 
 
-@pytest.mark.parametrize("name", ["vae4l_b2.npz", "vae8l_b2.npz", "vae8l_b2_outbn.npz"])
+@pytest.mark.parametrize("name", ["vae4l_b2.npz", "vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b16.npz",
+                                  "vae8l_b16.npz"])
 def test_train_step_parity(name):
+    """B = 2 goldens: tolerance = max(SURVEY 8c, 4x the reference arithmetic's own float32 noise) - the deepest
+    BatchNorms see 24 values per channel there.  B = 16 goldens (SURVEY 8c's capture size): the SURVEY 8c tolerances
+    as they stand (activations 1e-5, losses 1e-5, gradients 5e-3), no noise escape."""
     from oracle import vae_oracle as vo
     from preset_gen_vae_amd.train_step import VAETrainStep
     g = load_golden(name)
@@ -145,7 +149,11 @@ def test_train_step_parity(name):
                           beta=float(g['meta/beta']), lr=float(g['meta/lr']),
                           weight_decay=float(g['meta/weight_decay']))
 
+    strict = B >= 16
+
     def tol(base, key=None, gkey=None):
+        if strict:
+            return base
         noise = rel_l2(ora32['grads'][gkey], ora['grads'][gkey]) if gkey else rel_l2(ora32[key], ora[key])
         return max(base, 4.0 * noise)
 
@@ -158,7 +166,7 @@ def test_train_step_parity(name):
     check_big('x_out', out['x_out'], g, 'train/x_out', 3 * tol(1e-5, 'x_out'), atol=1e-6)
     for key in ('recons', 'latent', 'total'):
         ref = float(g['train/' + key])
-        t = max(1e-5, 4 * abs(ora32[key].item() - ora[key].item()) / abs(ref))
+        t = 1e-5 if strict else max(1e-5, 4 * abs(ora32[key].item() - ora[key].item()) / abs(ref))
         assert abs(out[key].item() - ref) <= t * abs(ref), (key, out[key].item(), ref)
     params = dict(ae.named_parameters())
     worst = 0.0
@@ -173,7 +181,8 @@ def test_train_step_parity(name):
         worst = max(worst, r / tol(5e-3, gkey=k))
         assert r < tol(5e-3, gkey=k), (k, r, tol(5e-3, gkey=k))
         noise_abs = (ora32['grads'][k].double() - gr).abs().max().item()
-        assert (got.double().cpu() - gr).abs().max().item() <= max(5e-3 * gmax, 4 * noise_abs) + 1e-9, (k, gmax, noise_abs)
+        assert (got.double().cpu() - gr).abs().max().item() <= max(5e-3 * gmax, 0.0 if strict else 4 * noise_abs) + 1e-9, \
+            (k, gmax, noise_abs)
     print(f"{name}: worst gradient error / tolerance = {worst:.3f}")
     # post-Adam parameters and BN buffers
     sd_new = ae.state_dict()
@@ -298,7 +307,7 @@ def test_train_step_bf16_operand_mode_vs_oracle(arch, dim_z):
 def test_two_graph_launch_mode_matches_single_graph():
     """train_step's N-rank graph mode ([zero_grad + fwd + bwd] graph, eager exchange, [Adam] graph) against the
     one-graph mode, on one rank (the exchange is then a no-op, the two-graph sequencing is what is under test):
-    the parameter UPDATES of 5 steps (2 capture warm-ups + 3 replays) must agree."""
+    the parameter UPDATES of 3 steps (the capture warm-ups are rolled back) must agree."""
     from preset_gen_vae_amd import parallel
     from preset_gen_vae_amd.train_step import VAETrainStep
     arch, dim_z, B = 'speccnn4l1_bn', 64, 4
@@ -322,10 +331,10 @@ def test_two_graph_launch_mode_matches_single_graph():
                                               if not k.endswith('conv.bias')}))
     assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * abs(finals[0][0])
     for k, dv in finals[0][1].items():
-        assert dv.abs().max().item() > 1e-5             # five Adam steps of 1e-5 happened
+        assert dv.abs().max().item() > 1e-5             # three Adam steps of 1e-5 happened
         # Adam's first steps move every element by ~lr*sign(g): compare where the sign of the gradient was stable over
-        # the five steps (|update| ~ 5 lr); elements whose gradient hovers around zero flip with float-atomics noise
-        stable = dv.abs() > 0.9 * 5 * 1e-5
+        # the three steps (|update| ~ 3 lr); elements whose gradient hovers around zero flip with float-atomics noise
+        stable = dv.abs() > 0.9 * 3 * 1e-5
         if stable.float().mean().item() > 0.05:
             assert rel_l2(finals[1][1][k][stable], dv[stable]) < 2e-2, k
 
@@ -506,8 +515,9 @@ def test_graph_replay_equals_eager():
             ls.append(out['total'].item())
         losses.append(ls)
     eager, graph = losses
-    # the graph path runs 2 warm-up steps before capture: its k-th replay is step k+2 of an eager run
+    # the capture warm-up is rolled back (parameters, Adam state, BN statistics, RNG offset): replay k IS step k
     assert all(abs(a) < 1e4 for a in eager + graph)
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(eager, graph)), (eager, graph)
     assert len(set(round(v, 6) for v in graph)) > 1       # dropout/eps differ from replay to replay
     assert graph[-1] < graph[0] * 1.5
 
@@ -623,3 +633,306 @@ def test_params_losses_on_device_f4():
             nums += n
             cats += c
     assert nums == g['dexed/useless_num'].tolist() and cats == g['dexed/useless_cat'].tolist()
+
+
+def test_train_step_l2loss_unnormalized_vs_golden():
+    """normalize_losses=False (train.py:105-106: loss.L2Loss; Dkl / B): the golden's ``train/l2loss`` and
+    ``train/latent_unnormalized`` and the oracle's gradients for that configuration."""
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    g = load_golden('vae4l_b2.npz')
+    arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
+    import copy
+    from preset_gen_vae_amd import config
+    from preset_gen_vae_amd.model import build
+    mc, tc = copy.copy(config.model), copy.copy(config.train)
+    mc.encoder_architecture, mc.dim_z, mc.input_tensor_size = arch, dim_z, (B, 1, 257, 347)
+    tc.minibatch_size, tc.latent_flow_input_regularization, tc.normalize_losses = B, 'none', False
+    _, _, ae = build.build_ae_model(mc, tc)
+    sd64 = _load_closed_form(ae, arch, dim_z, False, int(g['meta/seed']))
+    ae = ae.cuda().train()
+    x, eps = synth_input(B), torch.tensor(g['in/eps'])
+    enc_mask, dec_mask = unpack_mask(g, 'enc'), unpack_mask(g, 'dec')
+    step = VAETrainStep(ae, lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+                        beta=float(g['meta/beta']), normalize_losses=False)
+    inject = {'eps': _cuda32(eps), 'enc_dropout_mask': _cuda32(enc_mask), 'dec_dropout_mask': _cuda32(dec_mask)}
+    masks = _record_activation_regions(lambda: step.step(_cuda32(x), inject=inject), arch)
+    out = masks.pop('__out__')
+    kw = dict(beta=float(g['meta/beta']), lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+              normalize_losses=False)
+    ora = vo.train_step(sd64, x, arch, dim_z, eps, enc_mask, dec_mask, act_masks=masks, **kw)
+    sd32 = {k: (v if v.dtype == torch.long else v.float()) for k, v in sd64.items()}
+    ora32 = vo.train_step(sd32, x.float(), arch, dim_z, eps.float(), enc_mask.float(), dec_mask.float(), **kw)
+    l2, lat = float(g['train/l2loss']), float(g['train/latent_unnormalized'])
+    assert abs(out['recons'].item() - l2) <= max(1e-5, 4 * abs(ora32['recons'].item() - l2) / l2) * l2
+    assert abs(out['latent'].item() - lat) <= max(1e-5, 4 * abs(ora32['latent'].item() - lat) / lat) * lat
+    tot = l2 + float(g['meta/beta']) * lat
+    assert abs(out['total'].item() - tot) <= 2e-5 * tot
+    params = dict(ae.named_parameters())
+    for k, gr in ora['grads'].items():
+        if gr.abs().max().item() < 1e-9:
+            continue
+        r, noise = rel_l2(params[k].grad, gr), rel_l2(ora32['grads'][k], gr)
+        assert r < max(5e-3, 4 * noise), (k, r, noise)
+
+
+def test_train_step_with_regression_network_vs_reference_golden():
+    """train.py:203-248 with the preset-regression network inside the step (``VAETrainStep(reg_model=..., v_in=...)``):
+    v_out, cont_loss, the summed loss, gradients of BOTH networks (the controls gradient reaches the encoder through
+    z_K) and the Adam update, against the golden produced by the reference's modules (regstep_4l_b4.npz)."""
+    import torch.nn as nn
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd.model import regression
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    from test_oracle_golden import regstep_inputs
+    g = load_golden('regstep_4l_b4.npz')
+    i = regstep_inputs(g)
+    arch, dim_z, B = i['arch'], i['dim_z'], i['B']
+
+    class Helper:
+        learnable_preset_size = 144
+
+    class MaskMul(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            return x * self.m if self.training else x
+
+    ae = _build(arch, dim_z, B, False)
+    ae.load_state_dict({k: (v if v.dtype == torch.long else v.float()) for k, v in i['sd'].items()})
+    reg = regression.MLPRegression('3l1024', dim_z, Helper(), 0.4, cat_softmax_activation=False)
+    assert list(reg.state_dict().keys()) == list(i['rtpl'].keys())
+    reg.load_state_dict({k: (v if v.dtype == torch.long else v.float()) for k, v in i['rsd'].items()})
+    reg.reg_model.drp1, reg.reg_model.drp2 = MaskMul(_cuda32(i['rmasks'][0])), MaskMul(_cuda32(i['rmasks'][1]))
+    ae, reg = ae.cuda().train(), reg.cuda().train()
+    step = VAETrainStep(ae, lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+                        beta=float(g['meta/beta']), normalize_losses=True, reg_model=reg)
+    inject = {'eps': _cuda32(i['eps']), 'enc_dropout_mask': _cuda32(i['enc_mask']),
+              'dec_dropout_mask': _cuda32(i['dec_mask'])}
+    masks = _record_activation_regions(lambda: step.step(_cuda32(i['x']), v_in=_cuda32(i['v_in']), inject=inject), arch)
+    out = masks.pop('__out__')
+    kw = dict(beta=float(g['meta/beta']), lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']))
+    regarg = dict(sd=i['rsd'], v_in=i['v_in'], masks=i['rmasks'])
+    ora = vo.train_step(i['sd'], i['x'], arch, dim_z, i['eps'], i['enc_mask'], i['dec_mask'], act_masks=masks,
+                        reg=regarg, **kw)
+    sd32 = {k: (v if v.dtype == torch.long else v.float()) for k, v in i['sd'].items()}
+    reg32 = dict(sd={k: (v if v.dtype == torch.long else v.float()) for k, v in i['rsd'].items()},
+                 v_in=i['v_in'].float(), masks=[m.float() for m in i['rmasks']])
+    ora32 = vo.train_step(sd32, i['x'].float(), arch, dim_z, i['eps'].float(), i['enc_mask'].float(),
+                          i['dec_mask'].float(), reg=reg32, **kw)
+    assert out['controls'] is not None
+    for key in ('recons', 'latent', 'controls', 'total'):
+        ref = float(g['train/' + key])
+        t = max(1e-5, 4 * abs(ora32[key].item() - ora[key].item()) / abs(ref))
+        assert abs(out[key].item() - ref) <= t * abs(ref), (key, out[key].item(), ref)
+    assert rel_l2(out['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < \
+        max(1e-5, 4 * rel_l2(ora32['z_mu_logvar'], ora['z_mu_logvar']))
+    params = {k: p for k, p in ae.named_parameters()}
+    params.update({'reg.' + k: p for k, p in reg.named_parameters()})
+    assert set(params) == set(ora['grads'])
+    n_reg = 0
+    for k, gr in ora['grads'].items():
+        if gr.abs().max().item() < 1e-9:
+            continue
+        r, noise = rel_l2(params[k].grad, gr), rel_l2(ora32['grads'][k], gr)
+        assert r < max(5e-3, 4 * noise), (k, r, noise)
+        n_reg += k.startswith('reg.')
+    assert n_reg >= 8
+    # the encoder's gradient contains the controls path: without it the fc gradient differs by far more than the noise
+    no_reg = vo.train_step(i['sd'], i['x'], arch, dim_z, i['eps'], i['enc_mask'], i['dec_mask'], act_masks=masks, **kw)
+    k = 'encoder.mlp.1.weight'
+    assert rel_l2(no_reg['grads'][k], ora['grads'][k]) > 20 * rel_l2(params[k].grad, ora['grads'][k])
+    # Adam over the extended model (train.py:166-167): regression parameters moved too
+    for k, p in reg.named_parameters():
+        before = i['rsd'][k].float()
+        assert (p.detach().cpu() - before).abs().max().item() > 1e-5, k
+        g_dev = p.grad.double().cpu()
+        p_exp, _, _ = vo.adam_update(before.double(), g_dev, torch.zeros_like(g_dev), torch.zeros_like(g_dev), 1,
+                                     float(g['meta/lr']), (0.9, 0.999), 1e-8, float(g['meta/weight_decay']))
+        assert (p.detach().double().cpu() - p_exp).abs().max().item() < 2e-5, k
+
+
+def test_fused_frontend_into_step():
+    """BASELINE configs[4]: raw audio -> fused STFT/mel/dB/min-max kernel writing the step's input buffer
+    (``MelSpectrogram.batch(out=...)``, bench.py --input audio) -> train step, against audio_oracle -> vae_oracle."""
+    from oracle import audio_oracle as ao
+    from oracle import vae_oracle as vo
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    arch, dim_z, B = 'speccnn4l1_bn', 64, 4
+    ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
+    sd64 = _load_closed_form(ae, arch, dim_z, False, 1234)
+    ae = ae.cuda().train()
+    waves = np.stack([ao.synth_fm_wave(idx=i) * (0.5 + 0.1 * i) for i in range(B)]).astype(np.float32)
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+    mel.set_minmax_normalization(-120.0, -5.0)
+    eps = torch.sin(torch.arange(B * dim_z, dtype=torch.float64) * 0.37 + 0.2).reshape(B, dim_z)
+    step = VAETrainStep(ae, lr=2e-4, weight_decay=1e-4, beta=0.2)
+    x_buf = torch.full((B, 1, 257, 347), float('nan'), device='cuda')
+    ret = mel.batch(torch.tensor(waves, device='cuda'), out=x_buf)
+    assert ret.data_ptr() == x_buf.data_ptr() and bool(torch.isfinite(x_buf).all())
+    out = step.step(x_buf, inject={'eps': _cuda32(eps)})
+    # (1) the buffer holds the oracle's spectrograms (front-end tolerance of tests/test_gpu_frontend.py)
+    x_ora = np.stack([ao.minmax_normalize(ao.mel_spectrogram_db(w.astype(np.float64)), -120.0, -5.0) for w in waves])
+    x_ora = torch.tensor(x_ora).unsqueeze(1)
+    x_dev = x_buf.double().cpu()
+    strong = x_ora > ao.minmax_normalize(-80.0, -120.0, -5.0)
+    assert (x_dev - x_ora)[strong].abs().max().item() < 2e-2 * 2.0 / 115.0          # 0.02 dB on the normalised scale
+    # (2) the step consumed exactly that buffer: oracle train step on the device's spectrograms
+    kw = dict(beta=0.2, lr=2e-4, weight_decay=1e-4)
+    ora = vo.train_step(sd64, x_dev, arch, dim_z, eps, None, None, **kw)
+    sd32 = {k: (v if v.dtype == torch.long else v.float()) for k, v in sd64.items()}
+    ora32 = vo.train_step(sd32, x_dev.float(), arch, dim_z, eps.float(), None, None, **kw)
+    for key in ('recons', 'latent', 'total'):
+        ref = ora[key].item()
+        assert abs(out[key].item() - ref) <= max(1e-5, 4 * abs(ora32[key].item() - ref) / abs(ref)) * abs(ref), key
+    assert rel_l2(out['x_out'], ora['x_out']) < max(1e-5, 4 * rel_l2(ora32['x_out'], ora['x_out']))
+    # (3) end to end against the all-oracle pipeline (oracle front-end -> oracle step): bounded by the front-end's
+    # float32 noise near the -120 dB floor
+    ora_e2e = vo.train_step(sd64, x_ora, arch, dim_z, eps, None, None, **kw)
+    for key in ('recons', 'latent', 'total'):
+        assert abs(out[key].item() - ora_e2e[key].item()) <= 2e-3 * abs(ora_e2e[key].item()), key
+    # graph mode: the captured step reads its input where the front-end writes it
+    step_g = VAETrainStep(ae, use_graph=True)
+    step_g.step(x_buf)
+    assert step_g.static_input is not None and step_g.static_input.shape == x_buf.shape
+    l0 = step_g.step(mel.batch(torch.tensor(waves, device='cuda'), out=step_g.static_input))['recons'].item()
+    l1 = step_g.step(mel.batch(torch.tensor(0.1 * waves, device='cuda'), out=step_g.static_input))['recons'].item()
+    assert np.isfinite(l0) and np.isfinite(l1) and abs(l0 - l1) > 1e-3 * abs(l0)
+
+
+def test_optimizer_state_resume():
+    """Checkpointed ``optimizer_state_dict`` (logs/logger.py:199-202, train.py:177-179): after 3 steps the state goes
+    into a fresh FusedAdam AND into torch.optim.Adam; all three take the same 4th step."""
+    from preset_gen_vae_amd import optim
+    torch.manual_seed(5)
+    shapes = [(300, 7), (64,), (3, 5, 4, 4), (1,)]
+    init = [torch.randn(s, device='cuda') for s in shapes]
+    grads = [[torch.randn(s, device='cuda') * 0.1 for s in shapes] for _ in range(4)]
+
+    def make():
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        flat = optim.FlatParams(ps)
+        return ps, flat, optim.FusedAdam(flat, lr=3e-4, weight_decay=1e-4)
+
+    def apply(ps, opt, gs):
+        opt.zero_grad()
+        for p, gg in zip(ps, gs):
+            p.grad.copy_(gg)
+        opt.step()
+
+    ps_a, flat_a, opt_a = make()
+    for t in range(3):
+        apply(ps_a, opt_a, grads[t])
+    sd = opt_a.state_dict()
+    assert opt_a.step_count() == 3 and len(sd['state']) == len(shapes)
+    snap = [p.detach().clone() for p in ps_a]
+    # fresh FusedAdam
+    ps_b, flat_b, opt_b = make()
+    for p, s in zip(ps_b, snap):
+        p.data.copy_(s)
+    opt_b.load_state_dict(sd)
+    # torch.optim.Adam (the reference's optimizer)
+    ps_c = [torch.nn.Parameter(s.clone()) for s in snap]
+    opt_c = torch.optim.Adam(ps_c, lr=1.0)
+    opt_c.load_state_dict(sd)
+    assert opt_c.param_groups[0]['lr'] == 3e-4 and opt_c.param_groups[0]['weight_decay'] == 1e-4
+    apply(ps_a, opt_a, grads[3])
+    apply(ps_b, opt_b, grads[3])
+    for p, gg in zip(ps_c, grads[3]):
+        p.grad = gg.clone()
+    opt_c.step()
+    torch.cuda.synchronize()
+    for a, b, c, s in zip(ps_a, ps_b, ps_c, snap):
+        assert (a - s).abs().max().item() > 1e-5                     # a real update happened
+        assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item())
+        assert (a - c).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    # a restarted Adam (what a resume without the state silently was) is clearly different
+    ps_d, _, opt_d = make()
+    for p, s in zip(ps_d, snap):
+        p.data.copy_(s)
+    apply(ps_d, opt_d, grads[3])
+    assert max((a - d).abs().max().item() for a, d in zip(ps_a, ps_d)) > 1e-5
+    assert opt_b.step_count() == 4 and float(opt_c.state_dict()['state'][0]['step']) == 4.0
+
+
+def test_dropout_masks_are_independent_and_advance():
+    """The encoder's and the decoder's fc Dropout masks of one step are different draws (own Philox stream ids on the
+    VAE's generator), and they change from step to step with ONE rng_advance launch per forward."""
+    from preset_gen_vae_amd import ops
+    ae = _build('speccnn4l1_bn', 64, 2, False).cuda().train()
+    rec, adv = [], []
+    orig, orig_adv = ops.dropout_apply, ops.rng_advance
+
+    def patched(state, stream_id, p, x):
+        y, m = orig(state, stream_id, p, x)
+        rec.append((stream_id, m.clone()))
+        return y, m
+
+    def patched_adv(state, inc):
+        adv.append(inc)
+        return orig_adv(state, inc)
+
+    ops.dropout_apply, ops.rng_advance = patched, patched_adv
+    try:
+        x = _cuda32(synth_input(2))
+        ae(x)
+        ae(x)
+    finally:
+        ops.dropout_apply, ops.rng_advance = orig, orig_adv
+    assert len(rec) == 4 and len(adv) == 2 and all(a >= 2 * 25024 // 4 for a in adv)
+    (s0, enc0), (s1, dec0), (_, enc1), (_, dec1) = rec
+    assert s0 != s1 and enc0.shape == dec0.shape
+    for a, b in ((enc0, dec0), (enc0, enc1), (dec0, dec1)):
+        assert 0.3 < ((a > 0) != (b > 0)).float().mean().item() < 0.55      # independent Bernoulli(0.7): 42 % differ
+    assert abs((enc0 > 0).float().mean().item() - 0.7) < 0.01
+
+
+def test_graph_mode_schedules_and_first_step():
+    """hipGraph mode: the warm-up leaves no trace (the first replay is Adam step 1, BatchNorm batch 1, same update as
+    the eager first step), and lr / beta schedules (train.py:195-197, 227) reach the captured kernels."""
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    B = 4
+    x = _cuda32(synth_input(B))
+    runs = []
+    for use_graph in (False, True):
+        ae = _build('speccnn4l1_bn', 64, B, True, fc_dropout=0.0)
+        _load_closed_form(ae, 'speccnn4l1_bn', 64, True, 31)
+        ae = ae.cuda().train()
+        torch.manual_seed(11)
+        before = {k: v.detach().clone() for k, v in ae.named_parameters()}
+        step = VAETrainStep(ae, lr=1e-4, use_graph=use_graph)
+        out = step.step(x)
+        torch.cuda.synchronize()
+        assert step.optimizer.step_count() == 1
+        assert all(int(v) == 1 for k, v in ae.state_dict().items() if k.endswith('num_batches_tracked'))
+        runs.append((step, ae, before, {k: out[k].item() for k in ('recons', 'latent', 'total')},
+                     {k: (v.detach() - before[k]).clone() for k, v in ae.named_parameters()}))
+    (_, _, _, l_e, d_e), (step, ae, _, l_g, d_g) = runs
+    for k in l_e:     # same eps stream (fresh generator, offset 0): the same first step
+        assert abs(l_e[k] - l_g[k]) <= 1e-4 * abs(l_e[k]), (k, l_e[k], l_g[k])
+    for k in d_e:
+        if k.endswith('conv.bias'):
+            continue   # zero-gradient biases in front of a BatchNorm: +-lr noise
+        agree = ((d_e[k] - d_g[k]).abs() < 0.2 * 1e-4).float().mean().item()
+        assert agree > 0.97, (k, agree)
+    # beta schedule: total = recons + beta * latent with the NEW beta after set_beta, on replay
+    step.set_beta(0.05)
+    out = step.step(x)
+    assert abs(out['total'].item() - (out['recons'].item() + 0.05 * out['latent'].item())) < 1e-5 * abs(out['total'].item())
+    step.beta = 0.4               # plain attribute assignment works too
+    out = step.step(x)
+    assert abs(out['total'].item() - (out['recons'].item() + 0.4 * out['latent'].item())) < 1e-5 * abs(out['total'].item())
+    # learning rate through param_groups (what torch schedulers / train.py:195-197 edit): lr = 0 freezes the parameters
+    for gpar in step.optimizer.param_groups:
+        gpar['lr'] = 0.0
+    frozen = {k: v.detach().clone() for k, v in ae.named_parameters()}
+    step.step(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(v.detach(), frozen[k]) for k, v in ae.named_parameters())
+    step.set_lr(1e-4)
+    step.step(x)
+    torch.cuda.synchronize()
+    assert any(not torch.equal(v.detach(), frozen[k]) for k, v in ae.named_parameters())

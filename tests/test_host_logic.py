@@ -140,3 +140,81 @@ def test_config_surface():
     assert config.model.input_tensor_size == (config.train.minibatch_size, 1, 257, 347)
     assert config.model.concat_midi_to_z is False and config.model.stft_args == (1024, 256)
     assert config.train.adam_betas == (0.9, 0.999) and config.train.weight_decay == 1e-4
+
+
+def test_fused_adam_state_dict_is_torch_adam_layout():
+    """optimizer_state_dict of the reference checkpoints (logs/logger.py:199-202, train.py:177-179): FusedAdam emits and
+    accepts torch.optim.Adam's per-parameter layout in model.parameters() order (the step itself needs the GPU:
+    tests/test_gpu_vae.py::test_optimizer_state_resume)."""
+    from preset_gen_vae_amd import optim
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    flat = optim.FlatParams(ps)
+    opt = optim.FusedAdam(flat, lr=1e-3, weight_decay=1e-4)
+    sd0 = opt.state_dict()
+    assert sd0['state'] == {} and sd0['param_groups'][0]['params'] == [0, 1, 2] and opt.step_count() == 0
+    # a torch Adam that has taken 3 steps on the same parameters -> into FusedAdam -> back out -> into torch Adam
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ta = torch.optim.Adam(ref, lr=5e-4, weight_decay=1e-4, betas=(0.8, 0.99))
+    for _ in range(3):
+        for r in ref:
+            r.grad = torch.randn_like(r)
+        ta.step()
+    opt.load_state_dict(ta.state_dict())
+    assert opt.step_count() == 3 and opt.param_groups[0]['lr'] == 5e-4 and opt.param_groups[0]['betas'] == (0.8, 0.99)
+    assert abs(opt.hyper[0].item() - 5e-4) < 1e-10
+    assert abs(opt.pows[0].item() - 0.8 ** 3) < 1e-15 and abs(opt.pows[1].item() - 0.99 ** 3) < 1e-15
+    sd = opt.state_dict()
+    tsd = ta.state_dict()
+    for i, p in enumerate(ps):
+        assert torch.equal(sd['state'][i]['exp_avg'], tsd['state'][i]['exp_avg'])
+        assert torch.equal(sd['state'][i]['exp_avg_sq'], tsd['state'][i]['exp_avg_sq'])
+        assert float(sd['state'][i]['step']) == 3.0 and sd['state'][i]['exp_avg'].shape == p.shape
+        o = [off for q, off in zip(flat.params, flat.offsets) if q is p][0]   # moments sit at the flat offset
+        assert torch.equal(opt.exp_avg[o:o + p.numel()].view(p.shape), tsd['state'][i]['exp_avg'])
+    tb = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1.0)
+    tb.load_state_dict(sd)
+    for r_a, r_b in zip(ref, tb.param_groups[0]['params']):
+        r_b.data.copy_(r_a.data)
+        r_a.grad = torch.randn_like(r_a)
+        r_b.grad = r_a.grad.clone()
+    ta.step(), tb.step()
+    for r_a, r_b in zip(ref, tb.param_groups[0]['params']):
+        assert torch.equal(r_a, r_b)                                # the reloaded optimizer continues identically
+    with pytest.raises(ValueError):
+        opt.load_state_dict({'state': {}, 'param_groups': [{'lr': 1e-3, 'params': [0, 1]}]})
+
+
+def test_check_configs_on_resume_from_checkpoint():
+    import copy
+    from preset_gen_vae_amd import config
+    from preset_gen_vae_amd.model import build
+    config.update_dynamic_config_params()
+    mc, tc = copy.copy(config.model), copy.copy(config.train)
+    saved = {'model': {k: (list(v) if isinstance(v, tuple) else v) for k, v in mc.__dict__.items()},
+             'train': dict(tc.__dict__)}
+    build.check_configs_on_resume_from_checkpoint(mc, tc, saved)        # json lists compare equal to tuples
+    mc2 = copy.copy(mc)
+    mc2.dim_z = mc.dim_z + 1
+    with pytest.raises(ValueError, match="Model attribute 'dim_z'"):
+        build.check_configs_on_resume_from_checkpoint(mc2, tc, saved)
+    tc2 = copy.copy(tc)
+    tc2.minibatch_size = 3
+    with pytest.raises(ValueError, match="Train attribute 'minibatch_size'"):
+        build.check_configs_on_resume_from_checkpoint(mc, tc2, saved)
+
+
+def test_preset_activation_softmax_branch_matches_reference():
+    """regression.py:35-51 with cat_softmax_activation=True (golden from the reference class, tests/golden/
+    params_loss.npz 'act_softmax')."""
+    from helpers import MiniPresetIndexesHelper, load_golden
+    from preset_gen_vae_amd.model import regression
+    g = load_golden('params_loss.npz')
+    x = torch.tensor(g['act_softmax/in'], requires_grad=True)
+    x_before = x.detach().clone()
+    act = regression.PresetActivation(MiniPresetIndexesHelper(), cat_softmax_activation=True)
+    y = act(x)
+    assert torch.equal(x.detach(), x_before)                            # no in-place write (the reference mutates)
+    assert (y.detach() - torch.tensor(g['act_softmax/out'])).abs().max().item() < 1e-12
+    (y * torch.tensor(g['act_softmax/gy'])).sum().backward()
+    assert (x.grad - torch.tensor(g['act_softmax/gx'])).abs().max().item() < 1e-12

@@ -31,7 +31,8 @@ def reference_template(g):
     return tpl
 
 
-@pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz", "vae8l_b2_c2.npz"])
+@pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz", "vae8l_b2_c2.npz",
+                                  "vae8l_b16.npz", "vae4l_b16.npz"])
 def test_train_step_matches_reference(name):
     g = load_golden(name)
     arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
@@ -66,6 +67,47 @@ def test_train_step_matches_reference(name):
             assert (v.double() - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item()), k
         elif 'post/' + k + '/checksum' in g.files:
             check_big('post ' + k, v, g, 'post/' + k, 1e-9)
+
+
+def regstep_inputs(g):
+    """Inputs of the regstep golden (VAE + preset-regression network, train.py:203-248) as the oracle takes them."""
+    from helpers import template_from_meta
+    arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
+    sd = vo.closed_form_state_dict(param_shapes(arch, dim_z, False), seed=int(g['meta/seed']), dtype=torch.float64)
+    rtpl = {str(k): (tuple(int(v) for v in str(sh).split()) if str(sh) else ())
+            for k, sh in zip(g['meta/reg_keys'], g['meta/reg_shapes'])}
+    rsd = vo.closed_form_state_dict(rtpl, seed=int(g['meta/reg_seed']), dtype=torch.float64)
+    rmasks = [torch.tensor(np.unpackbits(g[f'in/reg_mask{i}_bits'])[:B * 1024].reshape(B, 1024), dtype=torch.float64)
+              / 0.6 for i in range(2)]
+    return dict(arch=arch, dim_z=dim_z, B=B, sd=sd, rsd=rsd, rtpl=rtpl, x=synth_input(B), eps=torch.tensor(g['in/eps']),
+                enc_mask=unpack_mask(g, 'enc'), dec_mask=unpack_mask(g, 'dec'), v_in=torch.tensor(g['in/v_in']),
+                rmasks=rmasks)
+
+
+def test_train_step_with_regression_matches_reference():
+    """train.py:203-248 with the preset-regression network in the step (v_out = reg_model(z_K), cont_loss, one backward
+    through both networks, Adam over the extended model): golden from the reference's own modules."""
+    g = load_golden('regstep_4l_b4.npz')
+    i = regstep_inputs(g)
+    r = vo.train_step(i['sd'], i['x'], i['arch'], i['dim_z'], i['eps'], i['enc_mask'], i['dec_mask'],
+                      beta=float(g['meta/beta']), lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+                      reg=dict(sd=i['rsd'], v_in=i['v_in'], masks=i['rmasks']))
+    assert rel_l2(r['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < 1e-10
+    assert rel_l2(r['v_out'], torch.tensor(g['train/v_out'])) < 1e-10
+    for key in ('recons', 'latent', 'controls', 'total'):
+        assert abs(r[key].item() - float(g['train/' + key])) <= 1e-10 * abs(float(g['train/' + key])), key
+    for k, gr in r['grads'].items():
+        check_big('grad ' + k, gr, g, ('grad_reg/' + k[4:]) if k.startswith('reg.') else ('grad/' + k), 1e-8)
+    n = 0
+    for k, v in r['new_sd'].items():
+        if 'post_full/' + k in g.files:
+            ref = torch.tensor(g['post_full/' + k])
+            assert (v.double() - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item()), k
+            n += 1
+        elif 'post/' + k + '/checksum' in g.files:
+            check_big('post ' + k, v, g, 'post/' + k, 1e-9)
+            n += 1
+    assert n == len([k for k in r['new_sd'] if not k.endswith('num_batches_tracked')])
 
 
 def test_layer_blocks_match_reference():
@@ -254,3 +296,20 @@ def test_params_losses_match_reference():
     nums, cats = po.dexed_useless_learned_params_indexes(f2l, g['dexed/preset'])
     assert nums == g['dexed/useless_num'].tolist() and cats == g['dexed/useless_cat'].tolist()
     assert len(nums) > 0 and len(cats) > 0
+
+
+def test_stft_complex_linear_and_dynamic_range_match_reference():
+    """get_stft (complex, un-normalised), Spectrogram(log_scale=False) and the dynamic-range log scale
+    (utils/audio.py:33-50, :63-69) of the oracle against the reference's own outputs."""
+    g = load_golden('stft.npz')
+    for idx in range(3):
+        frames = g[f'wave{idx}/frames']
+        z = ao.stft_complex(ao.synth_fm_wave(idx=idx))[:, frames]
+        ref = g[f'wave{idx}/stft_re'] + 1j * g[f'wave{idx}/stft_im']      # reference: float32 torch.stft
+        assert np.abs(z - ref).max() <= 2e-5 * np.abs(ref).max()
+    mag = ao.spectrogram_mag(ao.synth_fm_wave(idx=1))
+    frames = g['linear/frames']
+    assert np.abs(mag[:, frames] - g['linear/mag']).max() <= 2e-5 * g['linear/mag'].max()
+    dyn = ao.linear_to_log_with_dynamic_range(mag, -120.0, 60.0)[:, frames]
+    assert np.abs(dyn - g['dynrange/db']).max() < 2e-2     # float32 reference near the -60 dB clamp level
+    assert dyn.min() >= dyn.max() - 60.0 - 1e-9

@@ -35,7 +35,7 @@ def _shard_grads(rank, world):
     return tpl, sd, r['grads']
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, shared=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -49,10 +49,25 @@ def _worker(rank, world, port, ret):
         sync = parallel.GradAllReduce(flat, n_buckets=3).install()
         assert sync.world_size == world and len(sync.ranges) == 3
         sync.start_step()
+        late = []
         for p in flat.params:                       # gradient-ready order
             k = [kk for kk, vv in params.items() if vv is p][0]
-            p.grad.copy_(grads[k].float())
-            layer._grad_done(p)
+            if shared and 'single_ch_cnn' in k:
+                # a stack applied twice per forward (stacked spectrogram channels): each application announces its
+                # kernel, but autograd adds the per-application gradients only AFTER the announcement - a bucket that
+                # launched on the announcement count would all-reduce partial sums
+                p._pgv_shared = True
+                p.grad.copy_(0.25 * grads[k].float())
+                layer._grad_done(p)
+                layer._grad_done(p)
+                late.append((p, 0.75 * grads[k].float()))
+            else:
+                p.grad.copy_(grads[k].float())
+                layer._grad_done(p)
+        if shared:
+            assert not all(sync._launched)          # buckets holding shared parameters are still waiting
+        for p, rest in late:
+            p.grad.add_(rest)
         sync.wait()
         sync.uninstall()
         out = {k: params[k].grad.clone() for k in params}
@@ -75,6 +90,16 @@ def test_bucketed_allreduce_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret['launched'] is True
+    assert ret['worst'] < 1e-6
+
+
+def test_shared_stack_parameters_are_reduced_after_backward_world2():
+    """Parameters of a stack applied once per spectrogram channel: their buckets must not launch from the hooks."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, True), nprocs=world, join=True)
     assert ret['launched'] is True
     assert ret['worst'] < 1e-6
 
