@@ -44,12 +44,23 @@ def parse():
                     help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
                          "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
-    ap.add_argument("--dist-graph", action="store_true",
-                    help="N > 1: replay [fwd+bwd] and [Adam] as two hipGraphs around an eager, non-overlapped all-reduce")
+    ap.add_argument("--dist-mode", default="eager", choices=["eager", "two-graph"],
+                    help="N > 1 launch mode: eager = every kernel launched from Python, bucketed all-reduce from "
+                         "gradient-ready hooks overlapped with backward; two-graph = [fwd+bwd] and [Adam] as two "
+                         "hipGraphs around an eagerly launched, non-overlapped all-reduce")
+    ap.add_argument("--dist-graph", action="store_true", help="alias of --dist-mode two-graph")
+    ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets (N > 1)")
+    ap.add_argument("--latent-reg", default="bn", choices=["bn", "none"],
+                    help="train.latent_flow_input_regularization (reference default 'bn', config.py:92)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="N = 1: skip the additional BASELINE.json configurations reported under 'extra'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.dist_graph:
+        args.dist_mode = 'two-graph'
+    return args
 
 
 def synth_spectrograms(B, device, seed):
@@ -148,11 +159,12 @@ def time_kernel(fn, iters=5):
     return max(_time_graph(_graph_of(with_fn)) - _FLUSH_MS[iters], 0.0) / iters
 
 
-def measure_roofline(ae, B, device, matrix_peak=F32_MATRIX_PEAK_TFLOPS):
-    """Time every conv-layer kernel (forward, input-gradient, weight-gradient) standalone at the bench shapes, pick
-    the one with the largest duration (the dominant kernel of the step) and price it against its roofline."""
+def launch_table(ae, B, device, frontend=None):
+    """Every distinct kind of launch the train step issues, as (label, fn, algorithmic bytes, algorithmic flops):
+    forward / input-gradient / weight-gradient of every conv block exactly as the step issues them, the BatchNorm /
+    activation backward passes, the output-block criterion backward, the fc GEMMs, Adam, and (``--input audio``) the
+    STFT->mel front-end.  Algorithmic bytes = every operand and result moved once."""
     from preset_gen_vae_amd import ops
-    worst = None
     table = []
     for name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up in layer_ops(ae):
         geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
@@ -166,53 +178,108 @@ def measure_roofline(ae, B, device, matrix_peak=F32_MATRIX_PEAK_TFLOPS):
         stats_b = torch.empty(2 * Cb, device=device, dtype=torch.float64)
         stats_s = torch.empty(2 * Cs, device=device, dtype=torch.float64)
         out_s, out_b = torch.empty_like(small), torch.empty_like(big)
-        macs = B * Cs * geom.Hs * geom.Ws * Cb * k * k
-        flops = 2.0 * macs
+        flops = 2.0 * B * Cs * geom.Hs * geom.Ws * Cb * k * k
         nb, ns, nw = big.numel() * 4, small.numel() * 4, w.numel() * 4
         # the launches exactly as the train step issues them: the layer's own direction carries bias + activation
         # (+ BN statistics when the block has a BatchNorm, + the producer's folded BN), the opposite direction is the
         # plain input-gradient product
         fwd_stats_s = stats_s if (has_bn and not is_up) else None
         fwd_stats_b = stats_b if (has_bn and is_up) else None
-        launches = {
-            'conv_down': ((lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b,
-                                                 stats=fwd_stats_s, out=out_s)) if not is_up else
-                          (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s)), nb + ns + nw),
-            'conv_up': ((lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s,
-                                             stats=fwd_stats_b, out=out_b)) if is_up else
-                        (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b)), nb + ns + nw),
-            'conv_wgrad': ((lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)) if not is_up
-                           else (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s)),
-                           nb + ns + nw),
-        }
-        for kname, (fn, bytes_) in launches.items():
-            if name == 'enc1' and kname == 'conv_up':
+
+        def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
+               bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up):
+            if kind == 'conv_down':
+                return (lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b, stats=fs,
+                                              out=out_s)) if not is_up else \
+                    (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s))
+            if kind == 'conv_up':
+                return (lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s, stats=fb,
+                                            out=out_b)) if is_up else \
+                    (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b))
+            return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)) if not is_up else \
+                (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s))
+
+        for kind in ('conv_down', 'conv_up', 'conv_wgrad'):
+            if name == 'enc1' and kind == 'conv_up':
                 continue  # the first block needs no input gradient: this launch is not part of the train step
-            ms = time_kernel(fn, iters=5)
-            t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (matrix_peak * 1e12)
-            rec = {'layer': name, 'kernel': kname, 'ms': ms, 'flops': flops, 'bytes': bytes_,
-                   'bound': 'hbm' if t_hbm >= t_mfma else 'mfma'}
-            table.append(rec)
-            if worst is None or ms > worst['ms']:
-                worst = rec
-        del big, small, out_b, out_s
+            table.append((f"{kind}[{name}]", mk(kind), nb + ns + nw, flops))
+        # BatchNorm / activation backward passes over this block's output tensor (layer.ConvStackFn.backward)
+        a = big if is_up else small
+        C = a.shape[1]
+        if has_bn:
+            g_o, g_y = torch.randn_like(a), torch.empty_like(a)
+            mean, rstd, scale = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
+            red = torch.zeros(2 * C, device=device, dtype=torch.float64)
+            gbias, gga, gbe = (torch.zeros(C, device=device) for _ in range(3))
+            table.append((f"act_bn_bwd[{name}]",
+                          (lambda g_o=g_o, a=a, scale=scale, mean=mean, rstd=rstd, red=red, g_y=g_y, gbias=gbias, gga=gga,
+                           gbe=gbe: ops.act_bn_bwd(g_o, a, scale, mean, rstd, red, 1, 0.1, g_y, gbias, ggamma=gga,
+                                                   gbeta=gbe)), 3 * a.numel() * 4, 0.0))
+            table.append((f"bn_bwd_reduce[{name}]",
+                          (lambda g_o=g_o, a=a, mean=mean, rstd=rstd, red=red: ops.bn_bwd_reduce(g_o, a, mean, rstd, red)),
+                          2 * a.numel() * 4, 0.0))
+    # output block: criterion + Hardtanh backward in one pass (pgv_sqerr_act_bwd)
+    xo, xt, gy = (torch.randn(B, 1, 257, 347, device=device) for _ in range(3))
+    gl, gb1 = torch.ones((), device=device), torch.zeros(1, device=device)
+    table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1),
+                  3 * xo.numel() * 4, 0.0))
+    # fc layers (encoder.mlp.1 / decoder.mlp.0): forward, input gradient, weight gradient
+    lin_e, lin_d = ae.encoder.mlp[1], ae.decoder.mlp[0]
+    for tag, lin in (('enc_fc', lin_e), ('dec_fc', lin_d)):
+        N, K = lin.weight.shape
+        xin, gyl = torch.randn(B, K, device=device), torch.randn(B, N, device=device)
+        wl, bl, gwl = lin.weight.detach(), lin.bias.detach(), torch.empty_like(lin.weight)
+        byt, fl = (B * K + B * N + N * K) * 4, 2.0 * B * N * K
+        table.append((f"linear_fwd[{tag}]", lambda xin=xin, wl=wl, bl=bl: ops.linear_fwd(xin, wl, bl), byt, fl))
+        table.append((f"linear_dgrad[{tag}]", lambda gyl=gyl, wl=wl: ops.linear_dgrad(gyl, wl), byt, fl))
+        table.append((f"linear_wgrad[{tag}]", lambda gyl=gyl, xin=xin, gwl=gwl: ops.linear_wgrad(gyl, xin, gwl), byt, fl))
+    # fused Adam over the flat parameter buffer: read p, g, m, v; write p, m, v
+    n = sum(p.numel() for p in ae.parameters())
+    fp, fg, fm, fv = (torch.zeros(n, device=device) for _ in range(4))
+    hyper = torch.tensor([2e-4, 0.1, 0.001, 1.0], device=device)
+    table.append(("adam", lambda: ops.adam_step(fp, fg, fm, fv, hyper, 0.9, 0.999, 1e-8, 1e-4), 7 * n * 4, 0.0))
+    if frontend is not None:
+        wav = 0.3 * torch.randn(B, 88576, device=device)
+        xo2 = torch.empty(B, 1, 257, 347, device=device)
+        table.append(("stft_mel", lambda: frontend.batch(wav, out=xo2), B * (88576 + 257 * 347) * 4, 0.0))
+    return table
+
+
+def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS, frontend=None, traffic_file=None):
+    """Time every kind of launch of the step standalone at the bench shapes and report the one FURTHEST BELOW ITS OWN
+    ROOFLINE among the launches that take at least 2 % of the step (the kernel to fix next); the table of all launches
+    goes to gpurun_out/bench_kernel_table.json."""
+    rows = []
+    for label, fn, bytes_, flops in launch_table(ae, B, device, frontend):
+        ms = time_kernel(fn, iters=5)
+        t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (matrix_peak * 1e12)
+        bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
+        frac = max(t_hbm, t_mfma) * 1e3 / ms if ms > 0 else 0.0
+        rows.append({'launch': label, 'ms': ms, 'flops': flops, 'bytes': bytes_, 'bound': bound, 'frac': frac,
+                     'share_of_step': ms / step_ms})
+    cands = [r for r in rows if r['share_of_step'] >= 0.02] or rows
+    worst = min(cands, key=lambda r: r['frac'])
     if worst['bound'] == 'hbm':
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
         achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, matrix_peak, 'TFLOP/s'
-    label = f"{worst['kernel']}[{worst['layer']}]"
-    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json), if any
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation, if any
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
-            entry = json.load(f).get(label)
-        if entry and B == 256 and matrix_peak == F32_MATRIX_PEAK_TFLOPS:
+        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+            entry = json.load(f).get(worst['launch'])
+        if entry and B == 256:
             traffic = entry['hbm_bytes_per_launch']
     except (OSError, ValueError):
         pass
+    conv = [r for r in rows if r['launch'].startswith('conv_')]
     roof = {'bound': worst['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
-            'frac': round(achieved / peak, 5), 'traffic': traffic, 'kernel': label,
-            'kernel_ms': round(worst['ms'], 4), 'algorithmic_bytes': worst['bytes'], 'algorithmic_flops': worst['flops']}
-    return roof, table
+            'frac': round(achieved / peak, 5), 'traffic': traffic, 'kernel': worst['launch'],
+            'kernel_ms': round(worst['ms'], 4), 'algorithmic_bytes': worst['bytes'],
+            'algorithmic_flops': worst['flops'],
+            'selection': 'lowest roofline fraction among launches >= 2 % of the step',
+            'conv_launches_sum_roofline_ms': round(sum(r['ms'] * r['frac'] for r in conv), 4),
+            'conv_launches_sum_ms': round(sum(r['ms'] for r in conv), 4)}
+    return roof, rows
 
 
 def cpu_baseline(arch, dim_z, B, max_seconds=25.0):
@@ -259,44 +326,31 @@ def cpu_baseline(arch, dim_z, B, max_seconds=25.0):
                       f'median {med * 1e3:.1f} ms/step'}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+def run_workload(args, rank, world, device, with_roofline, with_cpu):
+    """Build the model of ``args``, run ``args.warmup`` untimed + ``args.steps`` timed steps (barrier + synchronize on
+    both sides, MAX over ranks) and return the JSON line of that workload as a dict (rank 0; None elsewhere)."""
     import torch.distributed as dist
-    from preset_gen_vae_amd import _lib, config, ops, parallel
+    from preset_gen_vae_amd import config, ops, parallel
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.train_step import VAETrainStep
-    _lib.load()   # fails loudly if the HIP library is missing
     ops.set_compute_dtype(args.dtype)
-    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    # one rank per GPU; PGV_DIST_BACKEND=gloo + a single visible GPU lets the N>1 code path be exercised on a 1-GPU box
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = torch.device('cuda', dev_index)
-    if world > 1:
-        dist.init_process_group(os.environ.get('PGV_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
-
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture, mc.dim_z = args.arch, args.dim_z
     tc.minibatch_size = args.batch
     mc.input_tensor_size = (args.batch, 1, 257, 347)
-    tc.latent_flow_input_regularization = 'none'
+    # reference default (config.py:92): 'bn' -> BatchNorm1d on the encoder output (build.py:25)
+    tc.latent_flow_input_regularization = args.latent_reg
     torch.manual_seed(1234)            # identical replicas on every rank
     _, _, ae = mbuild.build_ae_model(mc, tc)
     ae = ae.to(device).train()
     torch.manual_seed(1234 + rank)     # per-rank eps / dropout streams
     x = synth_spectrograms(args.batch, device, seed=rank)
 
-    # N = 1: one hipGraph per step.  N > 1: eager launches with the bucketed all-reduce overlapped with backward (the
-    # step is GPU-bound either way: eager and graph replay measure the same at N = 1); --dist-graph selects the
-    # two-graphs-around-the-exchange mode of train_step.py instead
-    use_graph = (not args.no_graph) and (world == 1 or args.dist_graph)
-    sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=4)) if world > 1 else None
+    # N = 1: one hipGraph per step.  N > 1: see --dist-mode
+    use_graph = (not args.no_graph) and (world == 1 or args.dist_mode != 'eager')
+    sync = None
+    if world > 1:
+        sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=args.buckets))
     step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
                         beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
 
@@ -339,34 +393,93 @@ def main():
         elapsed = t.item()
     loss = out['total'].item()
     assert np.isfinite(loss), "non-finite loss in the timed region"
+    ms = elapsed / args.steps * 1e3
 
     roof, table, cpu = None, None, None
-    if rank == 0 and not args.no_roofline:
-        roof, table = measure_roofline(ae, args.batch, device, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
-                                       else F32_MATRIX_PEAK_TFLOPS)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and with_roofline:
+        roof, table = measure_roofline(ae, args.batch, device, ms, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
+                                       else F32_MATRIX_PEAK_TFLOPS, frontend=frontend)
+    if rank == 0 and world == 1 and with_cpu:
         cpu = cpu_baseline(args.arch, args.dim_z, args.cpu_batch)
     if world > 1:
         dist.barrier()
-
+    line = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
+        launch = "eager"
+        if use_graph:
+            launch = "hipGraph" if world == 1 else {'two-graph': "2 hipGraphs + eager all-reduce"}[args.dist_mode]
+        cfg = {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
+                           f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
+                           + (" computed on the GPU from raw audio [B, 88576] inside the timed step"
+                              if args.input == "audio" else ""),
+               "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": launch,
+               "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
+        if world > 1:
+            cfg["rccl_ranks"] = dist.get_world_size()
+            cfg["backend"] = dist.get_backend()
+            cfg["grad_buckets_bytes"] = [4 * (hi - lo) for lo, hi in step.grad_sync.ranges]
         line = {
             "metric": "spectrograms/sec per VAE train step (batch 256, 1x257x347)", "value": round(value, 2),
             "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == 'bf16' else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
-                                   f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
-                                   + (" computed on the GPU from raw audio [B, 88576] inside the timed step"
-                                      if args.input == "audio" else ""),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": (("hipGraph" if world == 1 else "2 hipGraphs + eager all-reduce") if use_graph
-                                  else "eager"),
-                       "final_loss": round(loss, 6)},
+            "dtype": "bf16" if args.dtype == 'bf16' else "f32", "data": "synthetic", "config": cfg,
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if table is not None:
+            line["_table"] = table
+    if step.grad_sync is not None:
+        step.grad_sync.uninstall()
+    del step, ae, x
+    ops.set_compute_dtype('fp32')
+    torch.cuda.empty_cache()
+    return line
+
+
+# the other BASELINE.json configurations measured inside the same invocation (N = 1): fewer steps, live roofline each
+EXTRA_CONFIGS = [
+    ("configs[1] on the reference-exact 8-layer stack", dict(arch='speccnn8l1_bn')),
+    ("configs[2]: 8-layer z=512 bf16", dict(arch='speccnn8l1_bn', dim_z=512, dtype='bf16')),
+    ("configs[4]: raw-audio minibatch, fused STFT->mel front-end", dict(input='audio')),
+]
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    from preset_gen_vae_amd import _lib
+    _lib.load()   # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    # one rank per GPU; PGV_DIST_BACKEND=gloo + a single visible GPU lets the N>1 code path be exercised on a 1-GPU box
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    if world > 1:
+        dist.init_process_group(os.environ.get('PGV_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+
+    line = run_workload(args, rank, world, device, not args.no_roofline, not args.no_cpu_baseline)
+    extras = []
+    if world == 1 and not args.no_extra:
+        for label, over in EXTRA_CONFIGS:
+            a2 = copy.copy(args)
+            for k, v in over.items():
+                setattr(a2, k, v)
+            a2.steps, a2.warmup = min(args.steps, 10), min(args.warmup, 3)
+            e = run_workload(a2, rank, world, device, not args.no_roofline, False)
+            e.pop("_table", None)
+            e.pop("cpu_baseline", None)
+            e["label"] = label
+            extras.append(e)
+    if rank == 0:
+        table = line.pop("_table", None)
+        if extras:
+            line["extra"] = extras
         if table is not None:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', 'bench_kernel_table.json'), 'w') as f:
