@@ -32,8 +32,11 @@ extern "C" {
 
 int pgv_abi_version(void) { return 6; }
 const char* pgv_last_error(void) { return g_err; }
+static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {
-  g_policy = policy;
+  // 3 = policy 0 without the second-generation kernels of conv_v2.hip (A/B timing and cross-checks)
+  g_no_v2 = policy == 3;
+  g_policy = policy == 3 ? 0 : policy;
   return PGV_OK;
 }
 
@@ -56,6 +59,11 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
   rc = 0;
   if (g_policy != 1) {
     rc = pgv_conv_down_direct(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    if (rc == 0 && g_policy == 0 && !g_no_v2) {
+      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      rc = pgv_conv_down_v2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
+      fused = rc == 1 && f != nullptr;
+    }
     if (rc == 0 && g_policy == 0) {
       const pgv_bn_fuse* f = stats ? nullptr : fuse;  // the band epilogue has one reduction slot
       rc = pgv_conv_down_band(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);

@@ -37,6 +37,11 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st);
 
+// Second-generation kernels (conv_v2.hip): one workgroup per CU, waves split M, weights from registers; tried first.
+int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
+                     const pgv_bn_fuse* fuse, hipStream_t st);
+
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                          const float* w, const float* bias, int act, float slope, float* out, double* stats,

@@ -1,0 +1,522 @@
+// Second-generation implicit-GEMM kernels for the stride-2 k=4 layers at the reference sizes (model/encoder.py:241-255,
+// model/decoder.py:205-218): ONE 256-thread workgroup per CU (one wave per SIMD, 512-register budget) running a
+// software pipeline, instead of two co-resident workgroups that take turns on the matrix pipe (conv_band.hip).
+//
+//   * waves split M (output channels) first: every wave multiplies ALL pixel tiles of a unit against its own 16-channel
+//     slice, so a ragged pixel count costs < 1 tile in 25 instead of whole idle waves (33x45 planes: 28 -> 25 tiles per
+//     sample), and the per-wave work is identical;
+//   * the weights never touch LDS: a lane's A fragment of step (c, kh) is ONE dword of the weight tensor
+//     (w[cs = m][c][kh][kw = lane>>4]), loaded straight from global memory (L2-resident: every workgroup reads the same
+//     <= 128 KB) one channel chunk ahead of its use;
+//   * the input band is double-buffered in LDS by channel chunks: while chunk i is multiplied, chunk i+1 is committed
+//     from registers (producer's BatchNorm affine applied, zero padding stored as zeros) and the global loads of chunk
+//     i+2 are in flight - one barrier per chunk;
+//   * the MFMA stream is interleaved 1 : 1 with the ds_read_b32 of the next k-step (sched_group_barrier), so the matrix
+//     pipe is never drained by a burst of LDS reads;
+//   * the epilogue needs no LDS and no barrier: a 4x4 transpose inside each lane quad (DPP) turns the accumulator layout
+//     (4 channels x 1 pixel per lane) into 1 channel x 4 consecutive pixels, which leaves as one 16-byte store; in that
+//     layout a lane owns ONE channel for the whole kernel, so BatchNorm statistics / backward projections are two
+//     registers per M tile.
+#include "conv_tile.h"
+#include "band_prefetch.h"
+
+#ifdef PGV_V2_TIMING
+// per-wave accumulated phase durations in shader cycles (s_memtime): slot i = time before V2_ACC(i) since the previous
+// stamp, summed over the items of a persistent workgroup; slot 7 = number of items (scratch/v2_timing.py)
+__device__ unsigned long long* pgv_tlog_v2 = nullptr;
+extern "C" int pgv_dbg_set_tlog_v2(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(pgv_tlog_v2), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define V2_T0() unsigned long long v2_tp = clock64(), v2_sum[7] = {0, 0, 0, 0, 0, 0, 0}, v2_n = 0
+#define V2_ACC(i)                                 \
+  do {                                            \
+    const unsigned long long now = clock64();     \
+    v2_sum[i] += now - v2_tp;                     \
+    v2_tp = now;                                  \
+  } while (0)
+#define V2_ITEM() (++v2_n)
+#define V2_FLUSH()                                                                               \
+  do {                                                                                           \
+    if ((threadIdx.x & 63) == 0 && pgv_tlog_v2) {                                                \
+      unsigned long long* o = pgv_tlog_v2 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;  \
+      for (int i = 0; i < 7; ++i) o[i] = v2_sum[i];                                              \
+      o[7] = v2_n;                                                                               \
+    }                                                                                            \
+  } while (0)
+#else
+#define V2_T0()
+#define V2_ACC(i)
+#define V2_ITEM()
+#define V2_FLUSH()
+#endif
+
+namespace {
+
+#define PGV_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// 4x4 transpose inside every aligned lane quad: in: lane i holds x[r] = element (row r, column i); out: lane i holds
+// x[k] = element (row i, column k).
+__device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  {  // distance 1: (x0,x1) and (x2,x3)
+    const float s0 = odd ? x[0] : x[1], s1 = odd ? x[2] : x[3];
+    const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+    if (odd) {
+      x[0] = r0;
+      x[2] = r1;
+    } else {
+      x[1] = r0;
+      x[3] = r1;
+    }
+  }
+  {  // distance 2: (x0,x2) and (x1,x3)
+    const float s0 = hi ? x[0] : x[2], s1 = hi ? x[1] : x[3];
+    const float r0 = dpp_mov<0x4E>(s0), r1 = dpp_mov<0x4E>(s1);
+    if (hi) {
+      x[0] = r0;
+      x[1] = r1;
+    } else {
+      x[2] = r0;
+      x[3] = r1;
+    }
+  }
+}
+
+// sum over the 4 lanes that share (lane & 15)
+__device__ __forceinline__ float lanegroup_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Staging of one channel chunk of a band: CK channels x ROWS rows at LDS row stride WP (image columns 0..W-1, then >= 2
+// zero pad columns which double as the left padding of the next row), channels back to back.  The tile is a flat list of
+// 16-byte chunks; lane tid owns chunks tid + 256*j (slot j).  Slots are issued (global -> register) and committed
+// (register -> LDS, producer's BatchNorm affine on image data, exact zeros elsewhere) ONE AT A TIME, so that the kernel
+// can place them between the MFMAs of its k-steps; nothing here branches.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CK, int ROWS, int W, int WP, int H>
+struct StageV2 {
+  static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256, NP = W % 4;
+  static_assert(WP % 4 == 0 && WP >= W + 2 && NPF <= 32 && ROWS < 256 && CK <= 256 && QR < 4096, "stage geometry");
+  f32x4 v[NPF];
+  unsigned meta[NPF];  // rr | ncol << 8 | c << 12 | q << 20   (ncol = 0: pad chunk or idle lane)
+  int off0[NPF];       // byte offset of the slot's window inside the chunk's planes for a band that starts at row 0
+  unsigned live;       // bit j: slot j holds image data
+  float sc[NPF], sh[NPF];
+
+  __device__ __forceinline__ void init(int tid) {
+    live = 0;
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int e = tid + 256 * j;
+      const int ee = min(e, ITEMS - 1);
+      const int rowi = ee / QR, q = ee - rowi * QR;
+      const int c = rowi / ROWS, rr = rowi - c * ROWS;
+      const int nc = e < ITEMS ? min(max(W - 4 * q, 0), 4) : 0;
+      meta[j] = (unsigned)rr | ((unsigned)nc << 8) | ((unsigned)c << 12) | ((unsigned)q << 20);
+      const int col = 4 * q - ((NP != 0 && nc > 0 && nc < 4) ? 4 - NP : 0);
+      off0[j] = ((c * H + rr) * W + col) * 4;
+      sc[j] = 1.f;
+      sh[j] = 0.f;
+    }
+  }
+  // plane0 = first element of the first channel of the chunk in its sample; the partial chunk at the end of a row reads
+  // the LAST four floats of the row (rotated into place at commit); chunks without image data read offset 0.
+  template <int J>
+  __device__ __forceinline__ void issue_slot(const float* __restrict__ plane0, int ih0) {
+    const int rr = meta[J] & 255;
+    const bool ok = (unsigned)(ih0 + rr) < (unsigned)H && (meta[J] & 0xF00u) != 0;
+    const unsigned off = ok ? (unsigned)(off0[J] + ih0 * (W * 4)) : 0u;
+    live = ok ? (live | (1u << J)) : (live & ~(1u << J));
+    const f4u t = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(plane0) + off);
+    v[J] = f32x4{t.x, t.y, t.z, t.w};
+  }
+  // per-slot affine of the chunk that starts at channel c0 (LDS table [C] scales, [C] shifts)
+  __device__ __forceinline__ void load_affine(const float* __restrict__ aff, int C, int c0) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int cg = c0 + (int)((meta[j] >> 12) & 255);
+      sc[j] = aff[cg];
+      sh[j] = aff[C + cg];
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void commit_slot(float* __restrict__ tile, int tid, bool has_aff) {
+    if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
+      const f32x4 t = v[J];
+      const bool on = (live >> J) & 1u;
+      const float m = on ? (has_aff ? sc[J] : 1.f) : 0.f, a = (on && has_aff) ? sh[J] : 0.f;
+      f32x4 x;
+      if (NP == 0) {
+        x.x = fmaf(t.x, m, a);
+        x.y = fmaf(t.y, m, a);
+        x.z = fmaf(t.z, m, a);
+        x.w = fmaf(t.w, m, a);
+      } else {
+        const bool part = ((meta[J] >> 8) & 15) < 4;
+        const float e0 = part ? t[(4 - NP) & 3] : t.x;
+        const float e1 = part ? t[(5 - NP) & 3] : t.y;
+        const float e2 = part ? t[(6 - NP) & 3] : t.z;
+        const float m1 = (part && NP < 2) ? 0.f : m, a1 = (part && NP < 2) ? 0.f : a;
+        const float m2 = (part && NP < 3) ? 0.f : m, a2 = (part && NP < 3) ? 0.f : a;
+        const float m3 = part ? 0.f : m, a3 = part ? 0.f : a;
+        x.x = fmaf(e0, m, a);
+        x.y = fmaf(e1, m1, a1);
+        x.z = fmaf(e2, m2, a2);
+        x.w = fmaf(t.w, m3, a3);
+      }
+      *reinterpret_cast<f32x4*>(tile + 4 * tid + 1024 * J) = x;
+    }
+  }
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel symbol (not a stream operation: also fine while a
+// graph is being captured, but there is no point in repeating it on every launch)
+inline int raise_lds_once(const void* kern, const char* who) {
+  static const void* done[64];
+  static int n_done = 0;
+  for (int i = 0; i < n_done; ++i)
+    if (done[i] == kern) return PGV_OK;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+  if (e != hipSuccess) {
+    pgv_set_error("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
+    return PGV_E_LAUNCH;
+  }
+  if (n_done < 64) done[n_done++] = kern;
+  return PGV_OK;
+}
+
+// compile-time loop helper: f(integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN (Conv2d forward / ConvTranspose2d input-gradient), k = 4, stride 2, pad 2:
+//   D[cs][pixel] = sum_{c,kh,kw} W[cs][c][kh][kw] * X[c][2r+kh-2][2col+kw-2]
+// Unit = R output rows of one sample; waves = MW (M groups of MTW tiles) x NW (pixel-tile groups of NT tiles); CK input
+// channels per LDS chunk; work items (unit, chunk) of a workgroup form ONE pipeline:
+//   step loop of item i  ||  commit of item i+1 (first half of the steps)  ||  global loads of item i+2 (second half)
+// Every k-step is one scheduling region: NT x MTW MFMAs interleaved 1 : 1 with the ds_read_b32 of step + 2 (three
+// rotating operand sets; measured 34.5 clk per MFMA against 53.7 for the compiler's own order, scratch/ubench/v2_loop.hip).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CB, int CS, int W, int H, int R, int MW, int CK>
+struct DownV2Cfg {
+  static constexpr int KS = 4;
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;
+  static constexpr int BANDS = (Hs + R - 1) / R;
+  static constexpr int NW = 4 / MW;
+  static constexpr int MTT = CS / 16, MTW = MTT / MW;
+  static constexpr int P = R * Ws;
+  static constexpr int NTT = (P + 15) / 16, NT = (NTT + NW - 1) / NW;
+  static constexpr int ROWS = 2 * (R - 1) + KS;
+  static constexpr int WP = (W + 2 + 3) / 4 * 4;
+  static constexpr int PLANE = ROWS * WP;
+  static constexpr int NCH = CB / CK;
+  static constexpr int S = CK * KS;
+  static constexpr int FRONT = 4;
+  static constexpr int BUF = CK * PLANE;
+  static constexpr size_t LDS_FLOATS = FRONT + 2 * (size_t)BUF + 2 * CB;
+  static_assert(CS % 16 == 0 && MTT % MW == 0 && CB % CK == 0 && 4 % MW == 0, "tiling");
+  static_assert(2 * (Ws - 1) + KS - 3 < WP, "row stride");
+  static_assert(S % 2 == 0 && S >= 4, "k-steps");
+};
+
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT>
+__global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float* __restrict__ big,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int act, float slope, float* __restrict__ out,
+                                                            double* __restrict__ stats, pgv_bn_fuse fuse) {
+  using G = DownV2Cfg<CB, CS, W, H, R, MW, CK>;
+  constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, NW = G::NW, MTW = G::MTW, P = G::P, NT = G::NT;
+  constexpr int WP = G::WP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
+  using Stage = StageV2<CK, G::ROWS, W, WP, H>;
+  constexpr int NPF = Stage::NPF;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile0 = lds + G::FRONT;
+  float* aff = tile0 + 2 * BUF;  // [2][CB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NW, wn = wave - wm * NW;
+  const int units = B * BANDS;
+
+  // per-lane B base of every pixel tile: pixel (r, c), tap kw = lane>>4: (2r)*WP + 2c - 2 + kw
+  int offB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = (wn * NT + t) * 16 + (lane & 15);
+    const int pv = p < P ? p : 0;
+    const int r = pv / Ws, c = pv - r * Ws;
+    offB[t] = 2 * r * WP + 2 * c - 2 + (lane >> 4);
+  }
+  // per-lane A address: w[cs = mt*16 + (lane&15)][c][kh][kw = lane>>4]
+  const float* wl[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) wl[m] = w + (size_t)((wm * MTW + m) * 16 + (lane & 15)) * CB * 16 + (lane >> 4);
+
+  Stage stg;
+  stg.init(tid);
+  if (tid < G::FRONT) lds[tid] = 0.f;
+  for (int i = tid; i < CB; i += 256) {
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[CB + i] = in_shift ? in_shift[i] : 0.f;
+  }
+  const pgv_act_params actp = pgv_act_setup(act, slope);
+
+  // The MFMA is issued as D^T = X^T W^T (pixels are the M rows, channels the N columns): the accumulator of a lane is
+  // then 4 CONSECUTIVE PIXELS (rows (lane>>4)*4 + reg) of ONE channel (column lane & 15) - the layout of a 16-byte NCHW
+  // store, and one channel per lane for the whole kernel (statistics are two registers per M tile)
+  const int ech = lane & 15, epx = 4 * (lane >> 4);
+  float bias_r[MTW], mean_r[MTW], rstd_r[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int cl = (wm * MTW + m) * 16 + ech;
+    bias_r[m] = bias ? bias[cl] : 0.f;
+    mean_r[m] = FUSE ? fuse.mean[cl] : 0.f;
+    rstd_r[m] = FUSE ? fuse.rstd[cl] : 0.f;
+  }
+  float st_s[MTW], st_q[MTW];  // statistics (forward) or BatchNorm-backward projections (FUSE) of this lane's channel
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) st_s[m] = st_q[m] = 0.f;
+
+  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int my_items = my_units * NCH;
+  if (my_items == 0) return;
+  // global source of local item `it` (clamped to the last one: the pipeline loads / commits unconditionally)
+  auto item_src = [&](int it, const float*& plane0, int& ih0) {
+    it = min(it, my_items - 1);
+    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
+    const int b = u / BANDS, band = u - b * BANDS;
+    plane0 = big + ((int64_t)b * CB + ch * CK) * (H * W);
+    ih0 = band * R * 2 - 2;
+  };
+  float a_cur[MTW][S], a_next[NCH > 1 ? MTW : 1][NCH > 1 ? S : 1];
+
+  // ---- prologue: item 0 into buffer 0, item 1 in flight, weights of chunk 0
+  {
+    const float* p0;
+    int ih0;
+    item_src(0, p0, ih0);
+    static_for<0, NPF>([&](auto j) { stg.template issue_slot<decltype(j)::value>(p0, ih0); });
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        a_cur[m][st] = wl[m][st * 4];
+        if constexpr (NCH > 1) a_next[m][st] = a_cur[m][st];
+      }
+    __syncthreads();  // affine table visible
+    if constexpr (HAS_AFF) stg.load_affine(aff, CB, 0);
+    static_for<0, NPF>([&](auto j) { stg.template commit_slot<decltype(j)::value>(tile0, tid, HAS_AFF); });
+    item_src(1, p0, ih0);
+    static_for<0, NPF>([&](auto j) { stg.template issue_slot<decltype(j)::value>(p0, ih0); });
+  }
+
+  f32x4 acc[MTW][NT];
+  V2_T0();
+#pragma unroll 1
+  for (int it = 0; it < my_items; ++it) {
+    const int ch = it % NCH;
+    const float* cur = tile0 + (it & 1) * BUF;
+    float* nxt = tile0 + ((it + 1) & 1) * BUF;
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (NCH > 1) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int st = 0; st < S; ++st) a_cur[m][st] = a_next[m][st];
+    }
+    V2_ACC(1);
+    __syncthreads();  // buffer (it & 1) committed by everybody; buffer (it+1) & 1 no longer read by anybody
+    V2_ACC(2);
+    if constexpr (HAS_AFF) stg.load_affine(aff, CB, ((it + 1) % NCH) * CK);  // (chunk committed during this loop)
+    const float* p2;
+    int ih2;
+    item_src(it + 2, p2, ih2);
+    const float* wn_[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) wn_[m] = wl[m] + ((it + 1) % NCH) * CK * 16;
+    // ---- k-steps of this chunk: step st = (c, kh) consumes the 4 kw taps
+    float bq[3][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[0][t] = cur[offB[t]];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[1][t] = cur[WP + offB[t]];
+    V2_ACC(3);
+    static_for<0, S>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      constexpr int sn = st + 2, cn = sn / 4, khn = sn - cn * 4;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (sn < S) bq[sn % 3][t] = cur[cn * PLANE + khn * WP + offB[t]];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(bq[st % 3][t], a_cur[m][st], acc[m][t]);
+      }
+      // auxiliary work riding along: the slots of item it+1 are committed one by one, each immediately re-issued for
+      // item it+2; one weight dword of the next chunk per step
+      static_for<0, NPF>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        if constexpr (j * S / NPF == st) {
+          stg.template commit_slot<j>(nxt, tid, HAS_AFF);
+          stg.template issue_slot<j>(p2, ih2);  // same registers, one full chunk ahead of their commit
+        }
+      });
+      if constexpr (NCH > 1) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) a_next[m][st] = wn_[m][st * 4];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);            // MFMA
+        if (sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    V2_ACC(4);
+    V2_ITEM();
+    if (ch == NCH - 1) {
+      // ---- epilogue of the unit: bias + activation, quad transpose, 16-byte stores, statistics / projections
+      const int u = blockIdx.x + (it / NCH) * gridDim.x;
+      const int b = u / BANDS, band = u - b * BANDS;
+      const int oh0 = band * R;
+      const int Pb = min(R, Hs - oh0) * Ws;  // valid pixels of this band
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int cl = (wm * MTW + m) * 16 + ech;
+        float* orow = out + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws;
+        const float* arow = FUSE ? fuse.a + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int tp0 = (wn * NT + t) * 16;  // first pixel of the tile (wave-uniform)
+          if (tp0 >= Pb) continue;             // tile entirely beyond the band
+          const int p0 = tp0 + epx;
+          float x[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y = acc[m][t][k] + bias_r[m];
+            // ACT 1: LeakyReLU with 0 <= slope <= 1 is max(y, slope*y) - bit-identical to the select form, 2 ops
+            x[k] = ACT == 0 ? y : (ACT == 1 ? fmaxf(y, slope * y) : pgv_act_apply(y, actp));
+          }
+          if (tp0 + 16 <= Pb) {  // (wave-uniform) whole tile inside the band: one 16-byte store per lane
+            f4u o;
+            o.x = x[0], o.y = x[1], o.z = x[2], o.w = x[3];
+            *reinterpret_cast<f4u*>(orow + p0) = o;
+            st_s[m] += (x[0] + x[1]) + (x[2] + x[3]);
+            if constexpr (FUSE) {
+              const f4u av = *reinterpret_cast<const f4u*>(arow + p0);
+              st_q[m] = fmaf(x[0], (av.x - mean_r[m]) * rstd_r[m], st_q[m]);
+              st_q[m] = fmaf(x[1], (av.y - mean_r[m]) * rstd_r[m], st_q[m]);
+              st_q[m] = fmaf(x[2], (av.z - mean_r[m]) * rstd_r[m], st_q[m]);
+              st_q[m] = fmaf(x[3], (av.w - mean_r[m]) * rstd_r[m], st_q[m]);
+            } else {
+              st_q[m] = fmaf(x[0], x[0], st_q[m]);
+              st_q[m] = fmaf(x[1], x[1], st_q[m]);
+              st_q[m] = fmaf(x[2], x[2], st_q[m]);
+              st_q[m] = fmaf(x[3], x[3], st_q[m]);
+            }
+          } else {  // ragged last tile of the band
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (p0 + k < Pb) {
+                orow[p0 + k] = x[k];
+                st_s[m] += x[k];
+                if constexpr (FUSE)
+                  st_q[m] = fmaf(x[k], (arow[p0 + k] - mean_r[m]) * rstd_r[m], st_q[m]);
+                else
+                  st_q[m] = fmaf(x[k], x[k], st_q[m]);
+              }
+            }
+          }
+        }
+      }
+    }
+    V2_ACC(5);
+  }
+  V2_FLUSH();
+  // ---- statistics / projections: lanes that share a channel (4 per wave), then one float64 atomic per (wave, channel)
+  double* dst = FUSE ? fuse.red : stats;
+  if (dst) {
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const float ss = lanegroup_sum(st_s[m]), qq = lanegroup_sum(st_q[m]);
+      if (lane < 16) {
+        const int cl = (wm * MTW + m) * 16 + ech;
+        atomicAdd(&dst[cl], (double)ss);
+        atomicAdd(&dst[CS + cl], (double)qq);
+      }
+    }
+  }
+}
+
+template <int CB, int CS, int W, int H, int R, int MW, int CK>
+int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                   const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                   const pgv_bn_fuse* fuse, hipStream_t st) {
+  using G = DownV2Cfg<CB, CS, W, H, R, MW, CK>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cb != CB || d->Cs != CS) return 0;
+  if (stats && fuse) return 0;  // one reduction slot
+  // the two ways the train step calls it: forward of a Conv2D block (producer's BatchNorm folded or not, LeakyReLU,
+  // statistics) and input gradient of a TConv2D block (plain product, optional BatchNorm-backward projections)
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
+                         double*, pgv_bn_fuse);
+  kern_t kern;
+  const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
+  const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+  if (fuse)
+    kern = in_scale ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, true, 2>
+                    : (actk == 0 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, false, 0>
+                                 : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, false, 2>);
+  else if (in_scale)
+    kern = actk == 1 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, true, 1>
+                     : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, true, 2>;
+  else
+    kern = actk == 0 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 0>
+                     : (actk == 1 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 1>
+                                  : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 2>);
+  if (int rc = raise_lds_once((const void*)kern, "conv_down_v2")) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_v2: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int units = d->B * G::BANDS;
+  const int grid = min(units, 256);
+  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, big, in_scale, in_shift, w, bias, act, slope, out,
+                     stats, fuse ? *fuse : fz);
+  PGV_CHECK_LAUNCH("conv_down_v2");
+  return 1;
+}
+
+}  // namespace
+
+// Returns 1 when handled, 0 when the shape / mode is not covered (the caller falls back to conv_band.hip), < 0 on error.
+int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
+                     const pgv_bn_fuse* fuse, hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  if (d->flags & PGV_COMPUTE_BF16) return 0;
+  if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
+    return launch_down_v2<32, 64, 45, 33, 17, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+  if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)
+    return launch_down_v2<16, 32, 88, 65, 11, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+  if (d->Hb == 129 && d->Wb == 174)  // 8 -> 16 channels, 65x88 outputs: 13 bands of 5 rows, waves split the pixels
+    return launch_down_v2<8, 16, 174, 129, 5, 1, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+  return 0;
+}

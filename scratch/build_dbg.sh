@@ -1,5 +1,9 @@
 #!/bin/bash
-# debug library with in-kernel phase stamps (never shipped): scratch/libpgv_hip_dbg.so
-cd "$(dirname "$0")/.." || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -Wno-unused-value -DPGV_PHASE_TIMING $PGV_DBG_FLAGS \
-  preset-gen-vae_amd/csrc/*.hip -o scratch/libpgv_hip_dbg.so
+# debug library: conv_v2.hip with in-kernel phase stamps (PGV_V2_TIMING), every other object from the regular build
+set -e
+cd "$(dirname "$0")/.."
+P=preset-gen-vae_amd
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DPGV_V2_TIMING ${PGV_DBG_DEFS} -c $P/csrc/conv_v2.hip -o scratch/conv_v2_dbg.o
+objs=$(ls $P/build/*.hip.o | grep -v conv_v2)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libpgv_hip_dbg.so $objs scratch/conv_v2_dbg.o
+echo built scratch/libpgv_hip_dbg.so
