@@ -38,7 +38,7 @@ extern "C" int pgv_dbg_set_tlog_v2(void* p) {
 #define V2_FLUSH()                                                                               \
   do {                                                                                           \
     if ((threadIdx.x & 63) == 0 && pgv_tlog_v2) {                                                \
-      unsigned long long* o = pgv_tlog_v2 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;  \
+      unsigned long long* o = pgv_tlog_v2 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;  \
       for (int i = 0; i < 7; ++i) o[i] = v2_sum[i];                                              \
       o[7] = v2_n;                                                                               \
     }                                                                                            \
@@ -48,6 +48,14 @@ extern "C" int pgv_dbg_set_tlog_v2(void* p) {
 #define V2_ACC(i)
 #define V2_ITEM()
 #define V2_FLUSH()
+#endif
+
+#ifndef PGV_V2_PRIO_MFMA
+#define PGV_V2_PRIO_MFMA 0
+#define PGV_V2_PRIO_LOADER 2
+#endif
+#ifndef PGV_V2_LOADER_SLEEP
+#define PGV_V2_LOADER_SLEEP 3  // x 64 clocks
 #endif
 
 namespace {
@@ -93,61 +101,74 @@ __device__ __forceinline__ float lanegroup_sum(float v) {
 // Staging of one channel chunk of a band: CK channels x ROWS rows at LDS row stride WP (image columns 0..W-1, then >= 2
 // zero pad columns which double as the left padding of the next row), channels back to back.  The tile is a flat list of
 // 16-byte chunks; lane tid owns chunks tid + 256*j (slot j).  Slots are issued (global -> register) and committed
-// (register -> LDS, producer's BatchNorm affine on image data, exact zeros elsewhere) ONE AT A TIME, so that the kernel
-// can place them between the MFMAs of its k-steps; nothing here branches.
+// (register -> LDS, producer's BatchNorm affine on image data, exact zeros elsewhere) by the loader waves; the per-lane
+// slot geometry is computed once, the data registers exist twice (two items in flight).
 // ---------------------------------------------------------------------------------------------------------------
 template <int CK, int ROWS, int W, int WP, int H>
 struct StageV2 {
   static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256, NP = W % 4;
   static_assert(WP % 4 == 0 && WP >= W + 2 && NPF <= 32 && ROWS < 256 && CK <= 256 && QR < 4096, "stage geometry");
-  f32x4 v[NPF];
-  unsigned meta[NPF];  // rr | ncol << 8 | c << 12 | q << 20   (ncol = 0: pad chunk or idle lane)
-  int off0[NPF];       // byte offset of the slot's window inside the chunk's planes for a band that starts at row 0
-  unsigned live;       // bit j: slot j holds image data
-  float sc[NPF], sh[NPF];
-
-  __device__ __forceinline__ void init(int tid) {
-    live = 0;
+  // per-lane constants of the slots (one copy, shared by the register sets)
+  struct Geo {
+    unsigned meta[NPF];  // rr | ncol << 8 | c << 12   (ncol = 0: pad chunk or idle lane)
+    int off0[NPF];       // byte offset of the slot's window inside the chunk's planes for a band that starts at row 0
+    __device__ __forceinline__ void init(int tid) {
 #pragma unroll
-    for (int j = 0; j < NPF; ++j) {
-      const int e = tid + 256 * j;
-      const int ee = min(e, ITEMS - 1);
-      const int rowi = ee / QR, q = ee - rowi * QR;
-      const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      const int nc = e < ITEMS ? min(max(W - 4 * q, 0), 4) : 0;
-      meta[j] = (unsigned)rr | ((unsigned)nc << 8) | ((unsigned)c << 12) | ((unsigned)q << 20);
-      const int col = 4 * q - ((NP != 0 && nc > 0 && nc < 4) ? 4 - NP : 0);
-      off0[j] = ((c * H + rr) * W + col) * 4;
-      sc[j] = 1.f;
-      sh[j] = 0.f;
+      for (int j = 0; j < NPF; ++j) {
+        const int e = tid + 256 * j;
+        const int ee = min(e, ITEMS - 1);
+        const int rowi = ee / QR, q = ee - rowi * QR;
+        const int c = rowi / ROWS, rr = rowi - c * ROWS;
+        const int nc = e < ITEMS ? min(max(W - 4 * q, 0), 4) : 0;
+        meta[j] = (unsigned)rr | ((unsigned)nc << 8) | ((unsigned)c << 12);
+        // the partial chunk at the end of a row reads the LAST four floats of the row (rotated into place at commit)
+        const int col = 4 * q - ((NP != 0 && nc > 0 && nc < 4) ? 4 - NP : 0);
+        off0[j] = ((c * H + rr) * W + col) * 4;
+      }
     }
-  }
-  // plane0 = first element of the first channel of the chunk in its sample; the partial chunk at the end of a row reads
-  // the LAST four floats of the row (rotated into place at commit); chunks without image data read offset 0.
+  };
+  // one item in flight
+  struct Set {
+    f32x4 v[NPF];
+    unsigned live;  // bit j: slot j holds image data
+  };
+  // plane0 = first element of the first channel of the chunk in its sample; chunks without image data read offset 0
   template <int J>
-  __device__ __forceinline__ void issue_slot(const float* __restrict__ plane0, int ih0) {
-    const int rr = meta[J] & 255;
-    const bool ok = (unsigned)(ih0 + rr) < (unsigned)H && (meta[J] & 0xF00u) != 0;
-    const unsigned off = ok ? (unsigned)(off0[J] + ih0 * (W * 4)) : 0u;
-    live = ok ? (live | (1u << J)) : (live & ~(1u << J));
-    const f4u t = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(plane0) + off);
-    v[J] = f32x4{t.x, t.y, t.z, t.w};
+  static __device__ __forceinline__ void issue_slot(const Geo& g, Set& s, const float* __restrict__ plane0, int ih0) {
+    const int rr = g.meta[J] & 255;
+    const bool ok = (unsigned)(ih0 + rr) < (unsigned)H && (g.meta[J] & 0xF00u) != 0;
+    const unsigned off = ok ? (unsigned)(g.off0[J] + ih0 * (W * 4)) : 0u;
+    s.live = ok ? (s.live | (1u << J)) : (s.live & ~(1u << J));
+    // The load is inline asm ON PURPOSE: with two register sets in flight across the loop back-edge the compiler's
+    // s_waitcnt bookkeeping drains BOTH sets at every commit (vmcnt(0) at the loop header), which collapses the
+    // prefetch to less than one item.  The asm load is invisible to that bookkeeping; the loader waits by hand
+    // (wait_set) - loads of a wave complete in issue order and this wave issues nothing else on the vector memory path.
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(s.v[J]) : "v"(off), "s"(plane0) : "memory");
   }
-  // per-slot affine of the chunk that starts at channel c0 (LDS table [C] scales, [C] shifts)
-  __device__ __forceinline__ void load_affine(const float* __restrict__ aff, int C, int c0) {
+  // Block until the OLDER of the two sets in flight has landed (the NPF loads of the newer one may stay outstanding).
+  static __device__ __forceinline__ void wait_set() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing that reads the registers may be scheduled above the wait
+  }
+  // aff = LDS table ([C] scales, [C] shifts) or null; c0 = first channel of the chunk
+  // per-slot affine of the chunk that starts at channel c0, from the LDS table ([C] scales, [C] shifts): all reads
+  // issued back to back (one LDS latency per chunk, not one per slot)
+  static __device__ __forceinline__ void load_affine(const Geo& g, const float* __restrict__ aff, int C, int c0,
+                                                     float (&sc)[NPF], float (&sh)[NPF]) {
 #pragma unroll
     for (int j = 0; j < NPF; ++j) {
-      const int cg = c0 + (int)((meta[j] >> 12) & 255);
+      const int cg = c0 + (int)((g.meta[j] >> 12) & 255);
       sc[j] = aff[cg];
       sh[j] = aff[C + cg];
     }
   }
   template <int J>
-  __device__ __forceinline__ void commit_slot(float* __restrict__ tile, int tid, bool has_aff) {
+  static __device__ __forceinline__ void commit_slot(const Geo& g, const Set& s, float* __restrict__ tile, int tid,
+                                                     bool has_aff, float scj, float shj) {
     if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
-      const f32x4 t = v[J];
-      const bool on = (live >> J) & 1u;
-      const float m = on ? (has_aff ? sc[J] : 1.f) : 0.f, a = (on && has_aff) ? sh[J] : 0.f;
+      const f32x4 t = s.v[J];
+      const bool on = (s.live >> J) & 1u;
+      const float m = on ? (has_aff ? scj : 1.f) : 0.f, a = (on && has_aff) ? shj : 0.f;
       f32x4 x;
       if (NP == 0) {
         x.x = fmaf(t.x, m, a);
@@ -155,7 +176,7 @@ struct StageV2 {
         x.z = fmaf(t.z, m, a);
         x.w = fmaf(t.w, m, a);
       } else {
-        const bool part = ((meta[J] >> 8) & 15) < 4;
+        const bool part = ((g.meta[J] >> 8) & 15) < 4;
         const float e0 = part ? t[(4 - NP) & 3] : t.x;
         const float e1 = part ? t[(5 - NP) & 3] : t.y;
         const float e2 = part ? t[(6 - NP) & 3] : t.z;
@@ -187,6 +208,11 @@ inline int raise_lds_once(const void* kern, const char* who) {
   if (n_done < 64) done[n_done++] = kern;
   return PGV_OK;
 }
+
+// Workgroup barrier of the wave-specialised kernels: LDS traffic of this wave complete, then s_barrier.  Unlike
+// __syncthreads() it carries no fence, so the compiler does not drain the global loads that are in flight across it
+// (the loader's prefetch, the MFMA waves' weight loads); the "memory" clobber keeps LDS accesses on their side.
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // compile-time loop helper: f(integral_constant<int, I>) for I in [0, N)
 template <int I, int N, typename F>
@@ -228,8 +254,17 @@ struct DownV2Cfg {
   static_assert(S % 2 == 0 && S >= 4, "k-steps");
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN, wave-specialised form: 512 threads = 4 MFMA waves (one per SIMD) + 4 loader waves (their SIMD partners).
+//   MFMA waves:   k-steps (ds_read_b32 + MFMA only, pinned 1 : 1), weights from global memory, epilogue.
+//   loader waves: global -> registers -> LDS staging of the channel chunks, TWO items ahead of the multiplication (two
+//                 register sets), producer's BatchNorm affine applied on the way.
+// One workgroup barrier per item joins the two roles (LDS double buffer).  The MFMA stream carries no staging
+// instructions (the sliced single-role kernel above spends 38-44 clk per MFMA in its k-steps, the bare loop 34.5), and
+// the loader is ordinary code - loops, branches, no scheduling pragmas.
+// ---------------------------------------------------------------------------------------------------------------
 template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT>
-__global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float* __restrict__ big,
+__global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float* __restrict__ big,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
@@ -246,9 +281,92 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NW, wn = wave - wm * NW;
   const int units = B * BANDS;
+  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int my_items = my_units * NCH;
+  if (my_items == 0) return;
+  if (tid < G::FRONT) lds[tid] = 0.f;
+  for (int i = tid; i < CB; i += 512) {
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[CB + i] = in_shift ? in_shift[i] : 0.f;
+  }
+  __syncthreads();
+  // global source of local item `it` (clamped to the last one: the loader runs ahead unconditionally)
+  auto item_src = [&](int it, const float*& plane0, int& ih0) {
+    it = min(it, my_items - 1);
+    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
+    const int b = u / BANDS, band = u - b * BANDS;
+    const uint64_t p = (uint64_t)(big + ((int64_t)b * CB + ch * CK) * (H * W));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    plane0 = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);  // provably wave-uniform: an SGPR pair
+    ih0 = band * R * 2 - 2;
+  };
 
+  if (wave >= 4) {
+    // ================================================= loader waves =================================================
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    typename Stage::Geo geo;
+    typename Stage::Set sA, sB;
+    geo.init(ltid);
+    sA.live = sB.live = 0;
+    auto issue_all = [&](typename Stage::Set& sx, int it) {
+      const float* p0;
+      int ih0;
+      item_src(it, p0, ih0);
+      static_for<0, NPF>([&](auto j) { Stage::template issue_slot<decltype(j)::value>(geo, sx, p0, ih0); });
+    };
+    float sc[NPF], sh[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) sc[j] = 1.f, sh[j] = 0.f;
+    if constexpr (HAS_AFF && NCH == 1) Stage::load_affine(geo, aff, CB, 0, sc, sh);  // one chunk: constant per slot
+    auto commit_all = [&](const typename Stage::Set& sx, int it, float* dst) {
+      if constexpr (HAS_AFF && NCH > 1) Stage::load_affine(geo, aff, CB, (min(it, my_items - 1) % NCH) * CK, sc, sh);
+      Stage::wait_set();
+      static_for<0, NPF>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J]);
+      });
+    };
+    // Pipeline: item n lives in register set n & 1 and LDS buffer n & 1; loads are issued two items ahead of their
+    // commit; ALWAYS exactly one older and one newer set are in flight when a commit starts (wait_set).
+    issue_all(sA, 0);
+    issue_all(sB, 1);
+    commit_all(sA, 0, tile0);
+    issue_all(sA, 2);
+    V2_T0();
+    ws_barrier();  // item 0 committed; the MFMA waves start
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+      V2_ACC(2);
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);  // let the MFMA waves' first operand reads of the item go first
+      V2_ACC(3);
+      commit_all(sB, it + 1, tile0 + BUF);  // item it+1 -> buffer 1 while item it is multiplied from buffer 0
+      V2_ACC(0);
+      issue_all(sB, it + 3);
+      V2_ACC(1);
+      V2_ITEM();
+      ws_barrier();
+      if (it + 1 < my_items) {
+        V2_ACC(2);
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        V2_ACC(3);
+        commit_all(sA, it + 2, tile0);       // item it+2 -> buffer 0 while item it+1 is multiplied from buffer 1
+        V2_ACC(0);
+        issue_all(sA, it + 4);
+        V2_ACC(1);
+        V2_ITEM();
+        ws_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in registers at wave exit
+    V2_FLUSH();
+    return;
+  }
+  // ==================================================== MFMA waves ===================================================
+  const int wm = wave / NW, wn = wave - wm * NW;
+  __builtin_amdgcn_s_setprio(PGV_V2_PRIO_MFMA);
+  V2_T0();
   // per-lane B base of every pixel tile: pixel (r, c), tap kw = lane>>4: (2r)*WP + 2c - 2 + kw
   int offB[NT];
 #pragma unroll
@@ -258,23 +376,12 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
     const int r = pv / Ws, c = pv - r * Ws;
     offB[t] = 2 * r * WP + 2 * c - 2 + (lane >> 4);
   }
-  // per-lane A address: w[cs = mt*16 + (lane&15)][c][kh][kw = lane>>4]
+  // per-lane weight address: w[cs = mt*16 + (lane&15)][c][kh][kw = lane>>4]
   const float* wl[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) wl[m] = w + (size_t)((wm * MTW + m) * 16 + (lane & 15)) * CB * 16 + (lane >> 4);
-
-  Stage stg;
-  stg.init(tid);
-  if (tid < G::FRONT) lds[tid] = 0.f;
-  for (int i = tid; i < CB; i += 256) {
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[CB + i] = in_shift ? in_shift[i] : 0.f;
-  }
   const pgv_act_params actp = pgv_act_setup(act, slope);
-
-  // The MFMA is issued as D^T = X^T W^T (pixels are the M rows, channels the N columns): the accumulator of a lane is
-  // then 4 CONSECUTIVE PIXELS (rows (lane>>4)*4 + reg) of ONE channel (column lane & 15) - the layout of a 16-byte NCHW
-  // store, and one channel per lane for the whole kernel (statistics are two registers per M tile)
+  // D^T = X^T W^T: the accumulator of a lane is 4 consecutive pixels (rows (lane>>4)*4 + reg) of one channel (lane & 15)
   const int ech = lane & 15, epx = 4 * (lane >> 4);
   float bias_r[MTW], mean_r[MTW], rstd_r[MTW];
 #pragma unroll
@@ -284,50 +391,30 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
     mean_r[m] = FUSE ? fuse.mean[cl] : 0.f;
     rstd_r[m] = FUSE ? fuse.rstd[cl] : 0.f;
   }
-  float st_s[MTW], st_q[MTW];  // statistics (forward) or BatchNorm-backward projections (FUSE) of this lane's channel
+  float st_s[MTW], st_q[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) st_s[m] = st_q[m] = 0.f;
-
-  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int my_items = my_units * NCH;
-  if (my_items == 0) return;
-  // global source of local item `it` (clamped to the last one: the pipeline loads / commits unconditionally)
-  auto item_src = [&](int it, const float*& plane0, int& ih0) {
-    it = min(it, my_items - 1);
-    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
-    const int b = u / BANDS, band = u - b * BANDS;
-    plane0 = big + ((int64_t)b * CB + ch * CK) * (H * W);
-    ih0 = band * R * 2 - 2;
-  };
   float a_cur[MTW][S], a_next[NCH > 1 ? MTW : 1][NCH > 1 ? S : 1];
-
-  // ---- prologue: item 0 into buffer 0, item 1 in flight, weights of chunk 0
-  {
-    const float* p0;
-    int ih0;
-    item_src(0, p0, ih0);
-    static_for<0, NPF>([&](auto j) { stg.template issue_slot<decltype(j)::value>(p0, ih0); });
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
-      for (int st = 0; st < S; ++st) {
-        a_cur[m][st] = wl[m][st * 4];
-        if constexpr (NCH > 1) a_next[m][st] = a_cur[m][st];
-      }
-    __syncthreads();  // affine table visible
-    if constexpr (HAS_AFF) stg.load_affine(aff, CB, 0);
-    static_for<0, NPF>([&](auto j) { stg.template commit_slot<decltype(j)::value>(tile0, tid, HAS_AFF); });
-    item_src(1, p0, ih0);
-    static_for<0, NPF>([&](auto j) { stg.template issue_slot<decltype(j)::value>(p0, ih0); });
-  }
-
+    for (int st = 0; st < S; ++st) {
+      a_cur[m][st] = wl[m][st * 4];
+      if constexpr (NCH > 1) a_next[m][st] = a_cur[m][st];
+    }
   f32x4 acc[MTW][NT];
-  V2_T0();
+  ws_barrier();  // item 0 committed
+  V2_ACC(0);
 #pragma unroll 1
   for (int it = 0; it < my_items; ++it) {
     const int ch = it % NCH;
     const float* cur = tile0 + (it & 1) * BUF;
-    float* nxt = tile0 + ((it + 1) & 1) * BUF;
+    // the operands of the first two k-steps first (LDS latency), the per-item bookkeeping behind them
+    float bq[3][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[0][t] = cur[offB[t]];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[1][t] = cur[WP + offB[t]];
     if (ch == 0) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
@@ -340,23 +427,11 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
 #pragma unroll
         for (int st = 0; st < S; ++st) a_cur[m][st] = a_next[m][st];
     }
-    V2_ACC(1);
-    __syncthreads();  // buffer (it & 1) committed by everybody; buffer (it+1) & 1 no longer read by anybody
-    V2_ACC(2);
-    if constexpr (HAS_AFF) stg.load_affine(aff, CB, ((it + 1) % NCH) * CK);  // (chunk committed during this loop)
-    const float* p2;
-    int ih2;
-    item_src(it + 2, p2, ih2);
     const float* wn_[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) wn_[m] = wl[m] + ((it + 1) % NCH) * CK * 16;
-    // ---- k-steps of this chunk: step st = (c, kh) consumes the 4 kw taps
-    float bq[3][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bq[0][t] = cur[offB[t]];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bq[1][t] = cur[WP + offB[t]];
     V2_ACC(3);
+#ifndef PGV_V2_NO_MFMA
     static_for<0, S>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
       constexpr int sn = st + 2, cn = sn / 4, khn = sn - cn * 4;
@@ -367,15 +442,6 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
 #pragma unroll
         for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(bq[st % 3][t], a_cur[m][st], acc[m][t]);
       }
-      // auxiliary work riding along: the slots of item it+1 are committed one by one, each immediately re-issued for
-      // item it+2; one weight dword of the next chunk per step
-      static_for<0, NPF>([&](auto j_c) {
-        constexpr int j = decltype(j_c)::value;
-        if constexpr (j * S / NPF == st) {
-          stg.template commit_slot<j>(nxt, tid, HAS_AFF);
-          stg.template issue_slot<j>(p2, ih2);  // same registers, one full chunk ahead of their commit
-        }
-      });
       if constexpr (NCH > 1) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) a_next[m][st] = wn_[m][st * 4];
@@ -386,11 +452,15 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
         if (sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
       }
     });
+#endif
     __builtin_amdgcn_sched_barrier(0);
     V2_ACC(4);
     V2_ITEM();
+#ifdef PGV_V2_NO_EPI
+    if (false) {
+#else
     if (ch == NCH - 1) {
-      // ---- epilogue of the unit: bias + activation, quad transpose, 16-byte stores, statistics / projections
+#endif
       const int u = blockIdx.x + (it / NCH) * gridDim.x;
       const int b = u / BANDS, band = u - b * BANDS;
       const int oh0 = band * R;
@@ -409,7 +479,6 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float y = acc[m][t][k] + bias_r[m];
-            // ACT 1: LeakyReLU with 0 <= slope <= 1 is max(y, slope*y) - bit-identical to the select form, 2 ops
             x[k] = ACT == 0 ? y : (ACT == 1 ? fmaxf(y, slope * y) : pgv_act_apply(y, actp));
           }
           if (tp0 + 16 <= Pb) {  // (wave-uniform) whole tile inside the band: one 16-byte store per lane
@@ -446,18 +515,53 @@ __global__ __launch_bounds__(256, 1) void conv_down_v2_kernel(int B, const float
       }
     }
     V2_ACC(5);
+    ws_barrier();  // everybody is done with buffer (it & 1); buffer (it+1) & 1 is committed
+    V2_ACC(2);
   }
   V2_FLUSH();
-  // ---- statistics / projections: lanes that share a channel (4 per wave), then one float64 atomic per (wave, channel)
+  // statistics / projections: ONE float64 atomic per channel per workgroup (256 workgroups finishing together on 2*CS
+  // addresses: the atomics serialise at the memory side, ~25 ns each - with one per wave they cost 10-25 us per launch).
+  // Waves that share channels (NW > 1) are added up through LDS first; the loader waves have left, so this part uses
+  // named waits on an LDS flag instead of a workgroup barrier.
   double* dst = FUSE ? fuse.red : stats;
   if (dst) {
+    float* red = tile0;  // [NW][MTW*MW*16][2] floats; the input buffers are dead (the last barrier is behind us)
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
       const float ss = lanegroup_sum(st_s[m]), qq = lanegroup_sum(st_q[m]);
       if (lane < 16) {
         const int cl = (wm * MTW + m) * 16 + ech;
-        atomicAdd(&dst[cl], (double)ss);
-        atomicAdd(&dst[CS + cl], (double)qq);
+        if constexpr (NW == 1) {
+          atomicAdd(&dst[cl], (double)ss);
+          atomicAdd(&dst[CS + cl], (double)qq);
+        } else {
+          red[(wn * CS + cl) * 2 + 0] = ss;
+          red[(wn * CS + cl) * 2 + 1] = qq;
+        }
+      }
+    }
+    if constexpr (NW > 1) {
+      // the 4 MFMA waves rendezvous on an LDS counter (the 4 loader waves never arrive at a barrier again)
+      int* flag = reinterpret_cast<int*>(lds);  // FRONT slack word 0 (re-zeroed below is not needed: kernel ends)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wn == 0) {
+        while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          if (lane < 16) {
+            const int cl = (wm * MTW + m) * 16 + ech;
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+              ss += (double)red[(k * CS + cl) * 2 + 0];
+              qq += (double)red[(k * CS + cl) * 2 + 1];
+            }
+            atomicAdd(&dst[cl], ss);
+            atomicAdd(&dst[CS + cl], qq);
+          }
+        }
       }
     }
   }
@@ -479,17 +583,20 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+#define PGV_DK(F, A, C) (kern_t) conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
+#ifdef PGV_V2_EXPERIMENT
+  // tuning builds (scratch/build_dbg.sh): only the forward-call instantiation
+  if (fuse || !in_scale || actk != 1) return 0;
+  kern = PGV_DK(false, true, 1);
+#else
   if (fuse)
-    kern = in_scale ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, true, 2>
-                    : (actk == 0 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, false, 0>
-                                 : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, true, false, 2>);
+    kern = in_scale ? PGV_DK(true, true, 2) : (actk == 0 ? PGV_DK(true, false, 0) : PGV_DK(true, false, 2));
   else if (in_scale)
-    kern = actk == 1 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, true, 1>
-                     : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, true, 2>;
+    kern = actk == 1 ? PGV_DK(false, true, 1) : PGV_DK(false, true, 2);
   else
-    kern = actk == 0 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 0>
-                     : (actk == 1 ? (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 1>
-                                  : (kern_t)conv_down_v2_kernel<CB, CS, W, H, R, MW, CK, false, false, 2>);
+    kern = actk == 0 ? PGV_DK(false, false, 0) : (actk == 1 ? PGV_DK(false, false, 1) : PGV_DK(false, false, 2));
+#endif
+#undef PGV_DK
   if (int rc = raise_lds_once((const void*)kern, "conv_down_v2")) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_v2: memset failed");
@@ -498,8 +605,8 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   const int units = d->B * G::BANDS;
   const int grid = min(units, 256);
   const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, big, in_scale, in_shift, w, bias, act, slope, out,
-                     stats, fuse ? *fuse : fz);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, in_scale, in_shift, w, bias, act,
+                     slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_down_v2");
   return 1;
 }

@@ -7,12 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import preset_gen_vae_amd  # noqa
 from preset_gen_vae_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'scratch', 'libpgv_hip_dbg.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'scratch', 'libpgv_hip_dbg' + os.environ.get('PGV_DBG_SFX', '') + '.so')
 from preset_gen_vae_amd import ops
 lib = _lib.load()
 lib.pgv_dbg_set_tlog_v2.argtypes = [ctypes.c_void_p]
 LAYERS = {'enc2': (8, 16, 4, 129, 174), 'enc3': (16, 32, 4, 65, 88), 'enc4': (32, 64, 4, 33, 45)}
 NAMES = ['prologue', 'pre-barrier', 'barrier wait', 'pre-loop', 'k-steps', 'epilogue', '-']
+if len(sys.argv) > 4:
+    lib.pgv_set_kernel_policy(int(sys.argv[4]))
 
 
 def main():
@@ -38,7 +40,7 @@ def main():
             if mode == 'fwd' else (lambda: ops.conv_up(g, small, w, None, 0, 0.0, out=out_b))
     else:
         fn = lambda: ops.conv_wgrad(g, big, small, gw, big_scale=sc_b, big_shift=sh_b)
-    tlog = torch.zeros(1 << 12, 4, 8, dtype=torch.int64, device='cuda')
+    tlog = torch.zeros(1 << 12, 8, 8, dtype=torch.int64, device='cuda')
     flush = torch.ones(64 << 20, device='cuda')
     for _ in range(3):
         fn()
@@ -58,6 +60,10 @@ def main():
         print(f"   {nm:14s} " + ' '.join(f"{d[:, wv, i].mean():9.0f}" for wv in range(4)) +
               f"   per item {d[:, 0, i].sum() / n[:, 0].sum():8.0f}")
     print(f"   sum            " + ' '.join(f"{d[:, wv, :6].sum(1).mean():9.0f}" for wv in range(4)))
+    if d[:, 4, :6].sum() > 0:
+        print("   loader waves 4..7 (cycles per workgroup):")
+        for i, nm in ((0, 'commit'), (1, 'issue'), (2, 'barrier wait'), (3, 'sleep')):
+            print(f"   {nm:14s} " + ' '.join(f"{d[:, wv, i].mean():9.0f}" for wv in range(4, 8)))
 
 
 main()
