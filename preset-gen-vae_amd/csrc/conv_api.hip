@@ -108,6 +108,11 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
   rc = 0;
   if (g_policy != 1) {
     rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
+    if (rc == 0 && g_policy == 0 && !g_no_v2) {
+      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      rc = pgv_conv_up_v2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, f, st);
+      fused = rc == 1 && f != nullptr;
+    }
     if (rc == 0 && g_policy == 0) {
       const pgv_bn_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_up_band(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, f, st);

@@ -42,6 +42,10 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                      const pgv_bn_fuse* fuse, hipStream_t st);
 
+int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                   const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
+                   const pgv_bn_fuse* fuse, hipStream_t st);
+
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                          const float* w, const float* bias, int act, float slope, float* out, double* stats,

@@ -104,10 +104,10 @@ __device__ __forceinline__ float lanegroup_sum(float v) {
 // (register -> LDS, producer's BatchNorm affine on image data, exact zeros elsewhere) by the loader waves; the per-lane
 // slot geometry is computed once, the data registers exist twice (two items in flight).
 // ---------------------------------------------------------------------------------------------------------------
-template <int CK, int ROWS, int W, int WP, int H>
+template <int CK, int ROWS, int W, int WP, int H, int MINPAD = 2>
 struct StageV2 {
   static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256, NP = W % 4;
-  static_assert(WP % 4 == 0 && WP >= W + 2 && NPF <= 32 && ROWS < 256 && CK <= 256 && QR < 4096, "stage geometry");
+  static_assert(WP % 4 == 0 && WP >= W + MINPAD && NPF <= 32 && ROWS < 256 && CK <= 256 && QR < 4096, "stage geometry");
   // per-lane constants of the slots (one copy, shared by the register sets)
   struct Geo {
     unsigned meta[NPF];  // rr | ncol << 8 | c << 12   (ncol = 0: pad chunk or idle lane)
@@ -377,9 +377,12 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
     offB[t] = 2 * r * WP + 2 * c - 2 + (lane >> 4);
   }
   // per-lane weight address: w[cs = mt*16 + (lane&15)][c][kh][kw = lane>>4]
-  const float* wl[MTW];
+  // (uniform base + 32-bit per-lane byte offset: the loads take the scalar-base form, no 64-bit pointers in VGPRs)
+  const char* wb = reinterpret_cast<const char*>(w);
+  unsigned wl[MTW];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m) wl[m] = w + (size_t)((wm * MTW + m) * 16 + (lane & 15)) * CB * 16 + (lane >> 4);
+  for (int m = 0; m < MTW; ++m) wl[m] = (unsigned)((((wm * MTW + m) * 16 + (lane & 15)) * CB * 16 + (lane >> 4)) * 4);
+  auto wload = [&](int m, int elem) { return *reinterpret_cast<const float*>(wb + (size_t)elem * 4 + wl[m]); };
   const pgv_act_params actp = pgv_act_setup(act, slope);
   // D^T = X^T W^T: the accumulator of a lane is 4 consecutive pixels (rows (lane>>4)*4 + reg) of one channel (lane & 15)
   const int ech = lane & 15, epx = 4 * (lane >> 4);
@@ -394,14 +397,15 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   float st_s[MTW], st_q[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) st_s[m] = st_q[m] = 0.f;
-  float a_cur[MTW][S], a_next[NCH > 1 ? MTW : 1][NCH > 1 ? S : 1];
+  // weights: a lane's A operand of k-step st is ONE dword; they are prefetched HS steps ahead into the other half of a
+  // two-halves register ring (an even number of halves per item keeps every index a compile-time constant)
+  constexpr int HS = (S % 16 == 0) ? 8 : S / 2;
+  static_assert(S % (2 * HS) == 0, "weight ring");
+  float aw[2][MTW][HS];
 #pragma unroll
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int st = 0; st < S; ++st) {
-      a_cur[m][st] = wl[m][st * 4];
-      if constexpr (NCH > 1) a_next[m][st] = a_cur[m][st];
-    }
+    for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i * 4);
   f32x4 acc[MTW][NT];
   ws_barrier();  // item 0 committed
   V2_ACC(0);
@@ -421,15 +425,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (NCH > 1) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int st = 0; st < S; ++st) a_cur[m][st] = a_next[m][st];
-    }
-    const float* wn_[MTW];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) wn_[m] = wl[m] + ((it + 1) % NCH) * CK * 16;
+    const int wc_ = ch * CK * 16, wn_ = ((it + 1) % NCH) * CK * 16;  // element offsets of this / the next item's chunk
     V2_ACC(3);
 #ifndef PGV_V2_NO_MFMA
     static_for<0, S>([&](auto st_c) {
@@ -440,11 +436,13 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       for (int t = 0; t < NT; ++t) {
         if (sn < S) bq[sn % 3][t] = cur[cn * PLANE + khn * WP + offB[t]];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(bq[st % 3][t], a_cur[m][st], acc[m][t]);
+        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(bq[st % 3][t], aw[(st / HS) & 1][m][st % HS], acc[m][t]);
       }
-      if constexpr (NCH > 1) {
+      {  // the weight of step st + HS (same item, or the first half of the next one) into the other half of the ring
+        constexpr int sp = st + HS;
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) a_next[m][st] = wn_[m][st * 4];
+        for (int m = 0; m < MTW; ++m)
+          aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp * 4) : wload(m, wn_ + (sp - S) * 4);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -611,6 +609,382 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// UP (ConvTranspose2d forward / Conv2d input-gradient), k = 4, stride 2, pad 2, by sub-pixel phases:
+//   out[cb][2u+ph][2v+pw] = sum_{cs,th,tw} w[cs][cb][ph+2th][pw+2tw] * X[cs][u+1-th][v+1-tw]
+// GEMM rows m = (cb, ph, pw) (M tile = 4 output channels x 4 phases), columns = grid positions (u, v) of the
+// Hg x Wg = ceil(H/2) x ceil(W/2) sub-pixel grid (rows padded to an even width Wgp), one k-step per input channel
+// (k lane = (th, tw)).  Same wave-specialised pipeline as conv_down_ws_kernel.  A lane's accumulator holds the 2x2 output
+// block of one channel at one grid position; one exchange with the neighbouring lane (DPP) turns it into 4 consecutive
+// pixels of one output row: a 16-byte store.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CB, int CS, int W, int H, int R, int MW, int CK>
+struct UpV2Cfg {
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;      // input (small) size
+  static constexpr int Wg = (W + 1) / 2, Hg = (H + 1) / 2;  // sub-pixel grid
+  static constexpr int Wgp = (Wg + 1) / 2 * 2;
+  static constexpr int BANDS = (Hg + R - 1) / R;
+  static constexpr int NW = 4 / MW;
+  static constexpr int MTT = CB / 4, MTW = MTT / MW;
+  static constexpr int P = R * Wgp;
+  static constexpr int NTT = (P + 15) / 16, NT = (NTT + NW - 1) / NW;
+  static constexpr int ROWS = R + 1;
+  static constexpr int WsP = (Ws + 1 + 3) / 4 * 4;
+  static constexpr int PLANE = ROWS * WsP;
+  static constexpr int NCH = CS / CK;
+  static constexpr int S = CK;
+  static constexpr int FRONT = 4;
+  static constexpr int BUF = CK * PLANE;
+  static constexpr size_t LDS_FLOATS = FRONT + 2 * (size_t)BUF + 2 * CS;
+  static_assert(CB % 4 == 0 && MTT % MW == 0 && CS % CK == 0 && 4 % MW == 0 && S >= 4, "tiling");
+};
+
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT>
+__global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* __restrict__ small_in,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          int act, float slope, float* __restrict__ out,
+                                                          double* __restrict__ stats, pgv_bn_fuse fuse) {
+  using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
+  constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, Wgp = G::Wgp, BANDS = G::BANDS, NW = G::NW;
+  constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
+  using Stage = StageV2<CK, G::ROWS, Ws, WsP, Hs, 1>;
+  constexpr int NPF = Stage::NPF;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile0 = lds + G::FRONT;
+  float* aff = tile0 + 2 * BUF;  // [2][CS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int units = B * BANDS;
+  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int my_items = my_units * NCH;
+  if (my_items == 0) return;
+  if (tid < G::FRONT) lds[tid] = 0.f;
+  for (int i = tid; i < CS; i += 512) {
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[CS + i] = in_shift ? in_shift[i] : 0.f;
+  }
+  __syncthreads();
+  auto item_src = [&](int it, const float*& plane0, int& ih0) {
+    it = min(it, my_items - 1);
+    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
+    const int b = u / BANDS, band = u - b * BANDS;
+    const uint64_t p = (uint64_t)(small_in + ((int64_t)b * CS + ch * CK) * (Hs * Ws));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    plane0 = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    ih0 = band * R;
+  };
+
+  if (wave >= 4) {
+    // ================================================= loader waves =================================================
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    typename Stage::Geo geo;
+    typename Stage::Set sA, sB;
+    geo.init(ltid);
+    sA.live = sB.live = 0;
+    auto issue_all = [&](typename Stage::Set& sx, int it) {
+      const float* p0;
+      int ih0;
+      item_src(it, p0, ih0);
+      static_for<0, NPF>([&](auto j) { Stage::template issue_slot<decltype(j)::value>(geo, sx, p0, ih0); });
+    };
+    float sc[NPF], sh[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) sc[j] = 1.f, sh[j] = 0.f;
+    if constexpr (HAS_AFF && NCH == 1) Stage::load_affine(geo, aff, CS, 0, sc, sh);
+    auto commit_all = [&](const typename Stage::Set& sx, int it, float* dst) {
+      if constexpr (HAS_AFF && NCH > 1) Stage::load_affine(geo, aff, CS, (min(it, my_items - 1) % NCH) * CK, sc, sh);
+      Stage::wait_set();
+      static_for<0, NPF>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J]);
+      });
+    };
+    issue_all(sA, 0);
+    issue_all(sB, 1);
+    commit_all(sA, 0, tile0);
+    issue_all(sA, 2);
+    ws_barrier();
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+      commit_all(sB, it + 1, tile0 + BUF);
+      issue_all(sB, it + 3);
+      ws_barrier();
+      if (it + 1 < my_items) {
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        commit_all(sA, it + 2, tile0);
+        issue_all(sA, it + 4);
+        ws_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // ==================================================== MFMA waves ===================================================
+  const int wm = wave / NW, wn = wave - wm * NW;
+  __builtin_amdgcn_s_setprio(PGV_V2_PRIO_MFMA);
+  // per-lane B base of every position tile: position (u, v), tap (th, tw) = lane>>4: (u+1-th)*WsP + (v+1-tw)
+  int offB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = (wn * NT + t) * 16 + (lane & 15);
+    const int pv = p < P ? p : 0;
+    const int u = pv / Wgp, v = min(pv - u * Wgp, Wg - 1);
+    offB[t] = (u + 1 - (lane >> 5)) * WsP + (v + 1 - ((lane >> 4) & 1));
+  }
+  // per-lane weight address: row (lane&15) = (cb = mt*4 + (row>>2), ph, pw), k = lane>>4 = (th, tw):
+  // w[cs][cb][ph + 2 th][pw + 2 tw]
+  const char* wb = reinterpret_cast<const char*>(w);
+  unsigned wl[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int row = lane & 15, k = lane >> 4;
+    const int cb = (wm * MTW + m) * 4 + (row >> 2), kh = ((row >> 1) & 1) + 2 * (k >> 1), kw = (row & 1) + 2 * (k & 1);
+    wl[m] = (unsigned)((cb * 16 + kh * 4 + kw) * 4);
+  }
+  // weight of input channel cs (uniform base + 32-bit per-lane byte offset: scalar-base loads)
+  auto wload = [&](int m, int cs) { return *reinterpret_cast<const float*>(wb + (size_t)cs * (CB * 16 * 4) + wl[m]); };
+  const pgv_act_params actp = pgv_act_setup(act, slope);
+  // accumulator layout: column (lane&15) = grid position, rows (lane>>4)*4 + reg = (channel lane>>4 of the M tile,
+  // phase reg = ph*2 + pw); after the lane-pair exchange a lane holds 4 consecutive pixels of output row 2u + (lane&1)
+  const int ech = lane >> 4, odd = lane & 1;
+  float bias_r[MTW], mean_r[MTW], rstd_r[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int cl = (wm * MTW + m) * 4 + ech;
+    bias_r[m] = bias ? bias[cl] : 0.f;
+    mean_r[m] = FUSE ? fuse.mean[cl] : 0.f;
+    rstd_r[m] = FUSE ? fuse.rstd[cl] : 0.f;
+  }
+  float st_s[MTW], st_q[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) st_s[m] = st_q[m] = 0.f;
+  // weight ring (see conv_down_ws_kernel); 4-step halves where the accumulators leave no room for 8-step ones
+  constexpr int HS = (S % 16 == 0 && MTW * NT < 28) ? 8 : (S % 8 == 0 ? 4 : S / 2);
+  static_assert(S % (2 * HS) == 0, "weight ring");
+  float aw[2][MTW][HS];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i);
+  f32x4 acc[MTW][NT];
+  V2_T0();
+  ws_barrier();  // item 0 committed
+  V2_ACC(0);
+#pragma unroll 1
+  for (int it = 0; it < my_items; ++it) {
+    const int ch = it % NCH;
+    const float* cur = tile0 + (it & 1) * BUF;
+    float bq[3][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[0][t] = cur[offB[t]];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[1][t] = cur[PLANE + offB[t]];
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int wc_ = ch * CK, wn_ = ((it + 1) % NCH) * CK;  // first input channel of this / the next item's chunk
+    V2_ACC(3);
+    static_for<0, S>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      constexpr int sn = st + 2;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (sn < S) bq[sn % 3][t] = cur[sn * PLANE + offB[t]];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(aw[(st / HS) & 1][m][st % HS], bq[st % 3][t], acc[m][t]);
+      }
+      {
+        constexpr int sp = st + HS;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+          aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp) : wload(m, wn_ + sp - S);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);            // MFMA
+        if (sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    V2_ACC(4);
+    V2_ITEM();
+    if (ch == NCH - 1) {
+      // ---- epilogue of the unit
+      const int un = blockIdx.x + (it / NCH) * gridDim.x;
+      const int b = un / BANDS, band = un - b * BANDS;
+      const int u0 = band * R;
+      const int Rb = min(R, Hg - u0);     // grid rows of this band
+      const int Hb = min(2 * Rb, H - 2 * u0);  // output rows of this band
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int cl = (wm * MTW + m) * 4 + ech;
+        float* obase = out + (((int64_t)b * CB + cl) * H + 2 * u0) * W;
+        const float* abase = FUSE ? fuse.a + (((int64_t)b * CB + cl) * H + 2 * u0) * W : nullptr;
+        // grid position of this lane in the wave's first tile, advanced by 16 positions per tile (Wgp > 16: at most one
+        // row wrap per step)
+        int pu, pv;
+        {
+          const int p = wn * NT * 16 + (lane & 15);
+          pu = p / Wgp;
+          pv = p - pu * Wgp;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int tp0 = (wn * NT + t) * 16;
+          if (tp0 < Rb * Wgp) {  // (wave-uniform) else: tile entirely beyond the band
+            float x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float y = acc[m][t][k] + bias_r[m];
+              x[k] = ACT == 0 ? y : (ACT == 1 ? fmaxf(y, slope * y) : pgv_act_apply(y, actp));
+            }
+            // exchange with the neighbouring grid column: even lanes end up with output row 2u, odd lanes with row 2u+1
+            const float s0 = odd ? x[0] : x[2], s1 = odd ? x[1] : x[3];
+            const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+            const float o0 = odd ? r0 : x[0], o1 = odd ? r1 : x[1], o2 = odd ? x[2] : r0, o3 = odd ? x[3] : r1;
+            const int orow = 2 * pu + odd, ocol = 2 * (pv & ~1);
+            const int off = orow * W + ocol;
+            const bool full = orow < Hb && ocol + 4 <= W;
+            if (__builtin_amdgcn_ballot_w64(full) == ~0ull) {  // (wave-uniform) every lane stores 4 valid pixels
+              f4u o;
+              o.x = o0, o.y = o1, o.z = o2, o.w = o3;
+              *reinterpret_cast<f4u*>(obase + off) = o;
+              st_s[m] += (o0 + o1) + (o2 + o3);
+              if constexpr (FUSE) {
+                const f4u av = *reinterpret_cast<const f4u*>(abase + off);
+                st_q[m] = fmaf(o0, (av.x - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o1, (av.y - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o2, (av.z - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o3, (av.w - mean_r[m]) * rstd_r[m], st_q[m]);
+              } else {
+                st_q[m] = fmaf(o0, o0, st_q[m]);
+                st_q[m] = fmaf(o1, o1, st_q[m]);
+                st_q[m] = fmaf(o2, o2, st_q[m]);
+                st_q[m] = fmaf(o3, o3, st_q[m]);
+              }
+            } else {  // row ends of odd-width images, last row of odd-height images, padded grid column
+              const int nv = (orow < Hb) ? min(W - ocol, 4) : 0;
+              const float ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (k < nv) {
+                  obase[off + k] = ov[k];
+                  st_s[m] += ov[k];
+                  if constexpr (FUSE)
+                    st_q[m] = fmaf(ov[k], (abase[off + k] - mean_r[m]) * rstd_r[m], st_q[m]);
+                  else
+                    st_q[m] = fmaf(ov[k], ov[k], st_q[m]);
+                }
+              }
+            }
+          }
+          pv += 16;
+          if (pv >= Wgp) {
+            pv -= Wgp;
+            ++pu;
+          }
+        }
+      }
+    }
+    V2_ACC(5);
+    ws_barrier();
+    V2_ACC(2);
+  }
+  V2_FLUSH();
+  // statistics / projections: one float64 atomic per channel per workgroup (see conv_down_ws_kernel)
+  double* dst = FUSE ? fuse.red : stats;
+  if (dst) {
+    float* red = tile0;  // [NW][CB][2]
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const float ss = group16_sum(st_s[m]), qq = group16_sum(st_q[m]);
+      if ((lane & 15) == 0) {
+        const int cl = (wm * MTW + m) * 4 + ech;
+        if constexpr (NW == 1) {
+          atomicAdd(&dst[cl], (double)ss);
+          atomicAdd(&dst[CB + cl], (double)qq);
+        } else {
+          red[(wn * CB + cl) * 2 + 0] = ss;
+          red[(wn * CB + cl) * 2 + 1] = qq;
+        }
+      }
+    }
+    if constexpr (NW > 1) {
+      int* flag = reinterpret_cast<int*>(lds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wn == 0) {
+        while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          if ((lane & 15) == 0) {
+            const int cl = (wm * MTW + m) * 4 + ech;
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+              ss += (double)red[(k * CB + cl) * 2 + 0];
+              qq += (double)red[(k * CB + cl) * 2 + 1];
+            }
+            atomicAdd(&dst[cl], ss);
+            atomicAdd(&dst[CB + cl], qq);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CB, int CS, int W, int H, int R, int MW, int CK>
+int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                 const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                 const pgv_bn_fuse* fuse, hipStream_t st) {
+  using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cb != CB || d->Cs != CS) return 0;
+  if (stats && fuse) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
+                         double*, pgv_bn_fuse);
+  kern_t kern;
+  const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
+  const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+#define PGV_UK(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
+#ifdef PGV_V2_EXPERIMENT
+  if (fuse || !in_scale || actk != 1) return 0;
+  kern = PGV_UK(false, true, 1);
+#else
+  if (fuse)
+    kern = in_scale ? PGV_UK(true, true, 2) : (actk == 0 ? PGV_UK(true, false, 0) : PGV_UK(true, false, 2));
+  else if (in_scale)
+    kern = actk == 1 ? PGV_UK(false, true, 1) : PGV_UK(false, true, 2);
+  else
+    kern = actk == 0 ? PGV_UK(false, false, 0) : (actk == 1 ? PGV_UK(false, false, 1) : PGV_UK(false, false, 2));
+#endif
+#undef PGV_UK
+  if (int rc = raise_lds_once((const void*)kern, "conv_up_v2")) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_v2: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int units = d->B * G::BANDS;
+  const int grid = min(units, 256);
+  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, small_in, in_scale, in_shift, w, bias, act, slope,
+                     out, stats, fuse ? *fuse : fz);
+  PGV_CHECK_LAUNCH("conv_up_v2");
+  return 1;
+}
+
 }  // namespace
 
 // Returns 1 when handled, 0 when the shape / mode is not covered (the caller falls back to conv_band.hip), < 0 on error.
@@ -620,10 +994,29 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->flags & PGV_COMPUTE_BF16) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
-    return launch_down_v2<32, 64, 45, 33, 17, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+    return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)
     return launch_down_v2<16, 32, 88, 65, 11, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 129 && d->Wb == 174)  // 8 -> 16 channels, 65x88 outputs: 13 bands of 5 rows, waves split the pixels
     return launch_down_v2<8, 16, 174, 129, 5, 1, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+  return 0;
+}
+
+int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                   const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
+                   const pgv_bn_fuse* fuse, hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  if (d->flags & PGV_COMPUTE_BF16) return 0;
+  if (d->Hb == 33 && d->Wb == 45)   // 64 -> 32 channels onto 33x45: 2 bands of 9 / 8 grid rows, M split 4 ways
+    return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+  if (d->Hb == 65 && d->Wb == 88)   // 32 -> 16 channels onto 65x88: 3 bands of 11 grid rows, waves split the positions
+    return launch_up_v2<16, 32, 88, 65, 11, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+#ifdef PGV_V2_UP_L2
+  // 16 -> 8 channels onto 129x174 (13 bands of 5 grid rows, waves split the positions): correct, but this layer is bound
+  // by the CU's store path (56 KB of output per unit leave in one burst while the matrix pipe idles); the band kernel's
+  // two co-resident workgroups overlap that burst and are 5-7 us faster, so the dispatch leaves the layer to them
+  if (d->Hb == 129 && d->Wb == 174)
+    return launch_up_v2<8, 16, 174, 129, 5, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+#endif
   return 0;
 }
