@@ -58,7 +58,12 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
   bool fused = false;
   rc = 0;
   if (g_policy != 1) {
-    rc = pgv_conv_down_direct(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
+    if (g_policy == 0 && !g_no_v2) {
+      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      rc = pgv_conv_down_direct2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
+      fused = rc == 1 && f != nullptr;
+    }
+    if (rc == 0) rc = pgv_conv_down_direct(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0 && g_policy == 0 && !g_no_v2) {
       const pgv_bn_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_down_v2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
@@ -107,11 +112,14 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
   bool fused = false;
   rc = 0;
   if (g_policy != 1) {
-    rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
+    if (g_policy == 0 && !g_no_v2)
+      rc = pgv_conv_up_direct2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
+    if (rc == 0) rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0 && g_policy == 0 && !g_no_v2) {
       const pgv_bn_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_up_v2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, f, st);
       fused = rc == 1 && f != nullptr;
+      if (rc == 2) rc = 1;  // handled, projections left to the reduce pass below
     }
     if (rc == 0 && g_policy == 0) {
       const pgv_bn_fuse* f = stats ? nullptr : fuse;

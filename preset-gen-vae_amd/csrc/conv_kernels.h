@@ -46,6 +46,14 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                    const pgv_bn_fuse* fuse, hipStream_t st);
 
+// Second-generation direct kernels (conv_direct2.hip): four pixels per lane, 16-byte LDS reads and stores.
+int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                        hipStream_t st);
+int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                          const float* w, const float* bias, int act, float slope, float* out, double* stats,
+                          const pgv_bn_fuse* fuse, hipStream_t st);
+
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                          const float* w, const float* bias, int act, float slope, float* out, double* stats,

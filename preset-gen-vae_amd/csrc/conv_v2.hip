@@ -468,44 +468,59 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
         const int cl = (wm * MTW + m) * 16 + ech;
         float* orow = out + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws;
         const float* arow = FUSE ? fuse.a + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws : nullptr;
+        // tiles in groups of 8: the saved-activation loads of a group (FUSE) are all issued before the first one is
+        // used - one memory latency per group, not one per tile
+        constexpr int TG = 8;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int tp0 = (wn * NT + t) * 16;  // first pixel of the tile (wave-uniform)
-          if (tp0 >= Pb) continue;             // tile entirely beyond the band
-          const int p0 = tp0 + epx;
-          float x[4];
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+          f4u av[TG];
+          if constexpr (FUSE) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float y = acc[m][t][k] + bias_r[m];
-            x[k] = ACT == 0 ? y : (ACT == 1 ? fmaxf(y, slope * y) : pgv_act_apply(y, actp));
-          }
-          if (tp0 + 16 <= Pb) {  // (wave-uniform) whole tile inside the band: one 16-byte store per lane
-            f4u o;
-            o.x = x[0], o.y = x[1], o.z = x[2], o.w = x[3];
-            *reinterpret_cast<f4u*>(orow + p0) = o;
-            st_s[m] += (x[0] + x[1]) + (x[2] + x[3]);
-            if constexpr (FUSE) {
-              const f4u av = *reinterpret_cast<const f4u*>(arow + p0);
-              st_q[m] = fmaf(x[0], (av.x - mean_r[m]) * rstd_r[m], st_q[m]);
-              st_q[m] = fmaf(x[1], (av.y - mean_r[m]) * rstd_r[m], st_q[m]);
-              st_q[m] = fmaf(x[2], (av.z - mean_r[m]) * rstd_r[m], st_q[m]);
-              st_q[m] = fmaf(x[3], (av.w - mean_r[m]) * rstd_r[m], st_q[m]);
-            } else {
-              st_q[m] = fmaf(x[0], x[0], st_q[m]);
-              st_q[m] = fmaf(x[1], x[1], st_q[m]);
-              st_q[m] = fmaf(x[2], x[2], st_q[m]);
-              st_q[m] = fmaf(x[3], x[3], st_q[m]);
+            for (int g = 0; g < TG; ++g) {
+              const int tp0 = (wn * NT + t0 + g) * 16;
+              if (t0 + g < NT && tp0 + 16 <= Pb) av[g] = *reinterpret_cast<const f4u*>(arow + tp0 + epx);
             }
-          } else {  // ragged last tile of the band
+          }
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            const int t = t0 + g;
+            if (t >= NT) continue;
+            const int tp0 = (wn * NT + t) * 16;  // first pixel of the tile (wave-uniform)
+            if (tp0 >= Pb) continue;             // tile entirely beyond the band
+            const int p0 = tp0 + epx;
+            float x[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              if (p0 + k < Pb) {
-                orow[p0 + k] = x[k];
-                st_s[m] += x[k];
-                if constexpr (FUSE)
-                  st_q[m] = fmaf(x[k], (arow[p0 + k] - mean_r[m]) * rstd_r[m], st_q[m]);
-                else
-                  st_q[m] = fmaf(x[k], x[k], st_q[m]);
+              const float y = acc[m][t][k] + bias_r[m];
+              x[k] = ACT == 0 ? y : (ACT == 1 ? fmaxf(y, slope * y) : pgv_act_apply(y, actp));
+            }
+            if (tp0 + 16 <= Pb) {  // (wave-uniform) whole tile inside the band: one 16-byte store per lane
+              f4u o;
+              o.x = x[0], o.y = x[1], o.z = x[2], o.w = x[3];
+              *reinterpret_cast<f4u*>(orow + p0) = o;
+              st_s[m] += (x[0] + x[1]) + (x[2] + x[3]);
+              if constexpr (FUSE) {
+                st_q[m] = fmaf(x[0], (av[g].x - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(x[1], (av[g].y - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(x[2], (av[g].z - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(x[3], (av[g].w - mean_r[m]) * rstd_r[m], st_q[m]);
+              } else {
+                st_q[m] = fmaf(x[0], x[0], st_q[m]);
+                st_q[m] = fmaf(x[1], x[1], st_q[m]);
+                st_q[m] = fmaf(x[2], x[2], st_q[m]);
+                st_q[m] = fmaf(x[3], x[3], st_q[m]);
+              }
+            } else {  // ragged last tile of the band
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (p0 + k < Pb) {
+                  orow[p0 + k] = x[k];
+                  st_s[m] += x[k];
+                  if constexpr (FUSE)
+                    st_q[m] = fmaf(x[k], (arow[p0 + k] - mean_r[m]) * rstd_r[m], st_q[m]);
+                  else
+                    st_q[m] = fmaf(x[k], x[k], st_q[m]);
+                }
               }
             }
           }
@@ -837,10 +852,35 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
           pu = p / Wgp;
           pv = p - pu * Wgp;
         }
+        constexpr int TG = 8;  // tiles per group: saved-activation loads of a group issued together (FUSE)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int tp0 = (wn * NT + t) * 16;
-          if (tp0 < Rb * Wgp) {  // (wave-uniform) else: tile entirely beyond the band
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+          int offs[TG];
+          bool fulls[TG];
+          f4u av[TG];
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            const int orow = 2 * pu + odd, ocol = 2 * (pv & ~1);
+            offs[g] = orow * W + ocol;
+            const bool full = orow < Hb && ocol + 4 <= W;
+            const int tp0 = (wn * NT + t0 + g) * 16;
+            fulls[g] = t0 + g < NT && tp0 < Rb * Wgp && __builtin_amdgcn_ballot_w64(full) == ~0ull;
+            if constexpr (FUSE) {
+              if (fulls[g]) av[g] = *reinterpret_cast<const f4u*>(abase + offs[g]);
+            }
+            if (!fulls[g]) offs[g] = (orow < Hb) ? offs[g] | (min(max(W - ocol, 0), 4) << 28) : offs[g];  // nv in the top bits
+            pv += 16;
+            if (pv >= Wgp) {
+              pv -= Wgp;
+              ++pu;
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            const int t = t0 + g;
+            if (t >= NT) continue;
+            const int tp0 = (wn * NT + t) * 16;
+            if (tp0 >= Rb * Wgp) continue;  // (wave-uniform) tile entirely beyond the band
             float x[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -851,20 +891,17 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
             const float s0 = odd ? x[0] : x[2], s1 = odd ? x[1] : x[3];
             const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
             const float o0 = odd ? r0 : x[0], o1 = odd ? r1 : x[1], o2 = odd ? x[2] : r0, o3 = odd ? x[3] : r1;
-            const int orow = 2 * pu + odd, ocol = 2 * (pv & ~1);
-            const int off = orow * W + ocol;
-            const bool full = orow < Hb && ocol + 4 <= W;
-            if (__builtin_amdgcn_ballot_w64(full) == ~0ull) {  // (wave-uniform) every lane stores 4 valid pixels
+            if (fulls[g]) {  // (wave-uniform) every lane stores 4 valid pixels
+              const int off = offs[g];
               f4u o;
               o.x = o0, o.y = o1, o.z = o2, o.w = o3;
               *reinterpret_cast<f4u*>(obase + off) = o;
               st_s[m] += (o0 + o1) + (o2 + o3);
               if constexpr (FUSE) {
-                const f4u av = *reinterpret_cast<const f4u*>(abase + off);
-                st_q[m] = fmaf(o0, (av.x - mean_r[m]) * rstd_r[m], st_q[m]);
-                st_q[m] = fmaf(o1, (av.y - mean_r[m]) * rstd_r[m], st_q[m]);
-                st_q[m] = fmaf(o2, (av.z - mean_r[m]) * rstd_r[m], st_q[m]);
-                st_q[m] = fmaf(o3, (av.w - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o0, (av[g].x - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o1, (av[g].y - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o2, (av[g].z - mean_r[m]) * rstd_r[m], st_q[m]);
+                st_q[m] = fmaf(o3, (av[g].w - mean_r[m]) * rstd_r[m], st_q[m]);
               } else {
                 st_q[m] = fmaf(o0, o0, st_q[m]);
                 st_q[m] = fmaf(o1, o1, st_q[m]);
@@ -872,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
                 st_q[m] = fmaf(o3, o3, st_q[m]);
               }
             } else {  // row ends of odd-width images, last row of odd-height images, padded grid column
-              const int nv = (orow < Hb) ? min(W - ocol, 4) : 0;
+              const int off = offs[g] & 0x0FFFFFFF, nv = (unsigned)offs[g] >> 28;
               const float ov[4] = {o0, o1, o2, o3};
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
@@ -886,11 +923,6 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
                 }
               }
             }
-          }
-          pv += 16;
-          if (pv >= Wgp) {
-            pv -= Wgp;
-            ++pu;
           }
         }
       }
@@ -988,11 +1020,17 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
 }  // namespace
 
 // Returns 1 when handled, 0 when the shape / mode is not covered (the caller falls back to conv_band.hip), < 0 on error.
+// Fused BatchNorm-backward projections (pgv_bn_fuse) in the wave-specialised kernels: the saved-activation loads sit in
+// the epilogue burst next to the stores and are not overlapped with matrix work (one workgroup per CU), so the fused
+// form only pays where the alternative is worse (measured inside the train step, us, fused v2 / fused band / unfused v2
+// + separate reduce pass):  down 129x174: 115 / 102 / 130 -> band;  down 65x88: 85 / 83 / 107 -> v2 fused;
+// up 65x88: 154 / 89 / 138 -> band;  up 33x45: 133 / (no fused band kernel: 140) / 125 -> v2 unfused + reduce pass.
 int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                      const pgv_bn_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->flags & PGV_COMPUTE_BF16) return 0;
+  if (fuse && d->Hb == 129 && d->Wb == 174) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
     return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)
@@ -1002,11 +1040,17 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
   return 0;
 }
 
+// (returns 2 when it handled the call but left the requested projections to a separate reduce pass)
 int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                    const pgv_bn_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->flags & PGV_COMPUTE_BF16) return 0;
+  if (fuse && d->Hb == 65 && d->Wb == 88) return 0;
+  if (fuse && d->Hb == 33 && d->Wb == 45) {
+    const int rc = launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, nullptr, st);
+    return rc == 1 ? 2 : rc;
+  }
   if (d->Hb == 33 && d->Wb == 45)   // 64 -> 32 channels onto 33x45: 2 bands of 9 / 8 grid rows, M split 4 ways
     return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 32 -> 16 channels onto 65x88: 3 bands of 11 grid rows, waves split the positions

@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pmcsq_${tag}_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'conv_' not in n and '_c1_kernel' not in n and 'deep_' not in n:
+        if 'conv_' not in n and '_c1_' not in n and 'deep_' not in n:
             continue
         acc[n[:90]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, c in acc.items():
