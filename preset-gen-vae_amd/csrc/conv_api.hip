@@ -153,7 +153,8 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_s
 
 int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d) {
   if (!d) return 0;
-  return pgv_conv_wgrad_tuned_workspace(d);
+  const int64_t a = pgv_conv_wgrad_tuned_workspace(d), b = pgv_conv_wgrad_v2_workspace(d);
+  return a > b ? a : b;
 }
 
 int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
@@ -168,7 +169,10 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
   hipStream_t st = pgv_stream(stream);
   if (g_policy != 1) {
     rc = 0;
-    if (g_policy == 0)
+    if (g_policy == 0 && !g_no_v2)
+      rc = pgv_conv_wgrad_v2(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
+                             workspace_bytes, st);
+    if (rc == 0 && g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0 && g_policy == 0)
       rc = pgv_conv_wgrad_deep(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);

@@ -62,7 +62,7 @@ def main():
     print(f"   sum            " + ' '.join(f"{d[:, wv, :6].sum(1).mean():9.0f}" for wv in range(4)))
     if d[:, 4, :6].sum() > 0:
         print("   loader waves 4..7 (cycles per workgroup):")
-        for i, nm in ((0, 'commit'), (1, 'issue'), (2, 'barrier wait'), (3, 'sleep')):
+        for i, nm in ((0, 'commit'), (1, 'issue'), (2, 'barrier wait'), (3, 'sleep'), (5, 'load wait')):
             print(f"   {nm:14s} " + ' '.join(f"{d[:, wv, i].mean():9.0f}" for wv in range(4, 8)))
 
 
