@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets (N > 1)")
     ap.add_argument("--latent-reg", default="bn", choices=["bn", "none"],
                     help="train.latent_flow_input_regularization (reference default 'bn', config.py:92)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: run the N > 1 code path (gradient all-reduce over a 1-rank RCCL communicator, "
+                         "launch mode of --dist-mode) - readiness evidence for the multi-GPU path on a 1-GPU box")
     ap.add_argument("--no-extra", action="store_true",
                     help="N = 1: skip the additional BASELINE.json configurations reported under 'extra'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -347,9 +350,10 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     x = synth_spectrograms(args.batch, device, seed=rank)
 
     # N = 1: one hipGraph per step.  N > 1: see --dist-mode
-    use_graph = (not args.no_graph) and (world == 1 or args.dist_mode != 'eager')
+    dist_on = world > 1 or getattr(args, 'force_dist', False)
+    use_graph = (not args.no_graph) and (not dist_on or args.dist_mode != 'eager')
     sync = None
-    if world > 1:
+    if dist_on:
         sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=args.buckets))
     step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
                         beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
@@ -408,14 +412,14 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         value = args.batch * world * args.steps / elapsed
         launch = "eager"
         if use_graph:
-            launch = "hipGraph" if world == 1 else {'two-graph': "2 hipGraphs + eager all-reduce"}[args.dist_mode]
+            launch = "hipGraph" if not dist_on else {'two-graph': "2 hipGraphs + eager all-reduce"}[args.dist_mode]
         cfg = {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
                            f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
                            + (" computed on the GPU from raw audio [B, 88576] inside the timed step"
                               if args.input == "audio" else ""),
                "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": launch,
                "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
-        if world > 1:
+        if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
             cfg["grad_buckets_bytes"] = [4 * (hi - lo) for lo, hi in step.grad_sync.ranges]
@@ -462,10 +466,14 @@ def main():
     device = torch.device('cuda', dev_index)
     if world > 1:
         dist.init_process_group(os.environ.get('PGV_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+    elif args.force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(os.environ.get('PGV_DIST_BACKEND', 'nccl'), rank=0, world_size=1)
 
     line = run_workload(args, rank, world, device, not args.no_roofline, not args.no_cpu_baseline)
     extras = []
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and not args.force_dist:
         for label, over in EXTRA_CONFIGS:
             a2 = copy.copy(args)
             for k, v in over.items():
@@ -485,7 +493,7 @@ def main():
             with open(os.path.join(ROOT, 'gpurun_out', 'bench_kernel_table.json'), 'w') as f:
                 json.dump(table, f, indent=1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 
