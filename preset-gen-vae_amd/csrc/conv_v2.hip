@@ -1,22 +1,23 @@
 // Second-generation implicit-GEMM kernels for the stride-2 k=4 layers at the reference sizes (model/encoder.py:241-255,
-// model/decoder.py:205-218): ONE 256-thread workgroup per CU (one wave per SIMD, 512-register budget) running a
-// software pipeline, instead of two co-resident workgroups that take turns on the matrix pipe (conv_band.hip).
+// model/decoder.py:205-218): ONE 512-thread workgroup per CU with fixed wave roles - waves 0-3 (one per SIMD) multiply,
+// waves 4-7 (their SIMD partners) stage - instead of two co-resident workgroups that take turns on the matrix pipe
+// (conv_band.hip).  DESIGN.md section 3.4 has the measurements behind every choice.
 //
-//   * waves split M (output channels) first: every wave multiplies ALL pixel tiles of a unit against its own 16-channel
-//     slice, so a ragged pixel count costs < 1 tile in 25 instead of whole idle waves (33x45 planes: 28 -> 25 tiles per
-//     sample), and the per-wave work is identical;
-//   * the weights never touch LDS: a lane's A fragment of step (c, kh) is ONE dword of the weight tensor
-//     (w[cs = m][c][kh][kw = lane>>4]), loaded straight from global memory (L2-resident: every workgroup reads the same
-//     <= 128 KB) one channel chunk ahead of its use;
-//   * the input band is double-buffered in LDS by channel chunks: while chunk i is multiplied, chunk i+1 is committed
-//     from registers (producer's BatchNorm affine applied, zero padding stored as zeros) and the global loads of chunk
-//     i+2 are in flight - one barrier per chunk;
-//   * the MFMA stream is interleaved 1 : 1 with the ds_read_b32 of the next k-step (sched_group_barrier), so the matrix
-//     pipe is never drained by a burst of LDS reads;
-//   * the epilogue needs no LDS and no barrier: a 4x4 transpose inside each lane quad (DPP) turns the accumulator layout
-//     (4 channels x 1 pixel per lane) into 1 channel x 4 consecutive pixels, which leaves as one 16-byte store; in that
-//     layout a lane owns ONE channel for the whole kernel, so BatchNorm statistics / backward projections are two
-//     registers per M tile.
+//   * waves split M (output channels) first: every MFMA wave multiplies ALL pixel tiles of a unit against its own
+//     channel slice, so a ragged pixel count costs < 1 tile in 25 instead of whole idle waves;
+//   * the weights never touch LDS: a lane's weight operand of k-step (c, kh) is ONE dword of the weight tensor, loaded
+//     straight from global memory (L2-resident) into a two-halves register ring, half an item ahead of its use;
+//   * the input band is double-buffered in LDS by channel chunks: while chunk i is multiplied, the loader waves commit
+//     chunk i+1 from registers (producer's BatchNorm affine applied, zero padding stored as zeros) and the global loads
+//     of chunk i+2 are in flight in a second register set - one workgroup barrier per chunk;
+//   * every k-step is one scheduling region in which the MFMAs are pinned 1 : 1 with the ds_reads two steps ahead
+//     (sched_group_barrier): 34.5 clk per MFMA against 53.7 for the compiler's own order;
+//   * D^T orientation (pixels = M rows, channels = N columns): a lane's accumulator is 4 consecutive pixels of ONE
+//     channel, so the epilogue stores 16 bytes of NCHW per lane without a transpose, and BatchNorm statistics /
+//     backward projections are two registers per tile column;
+//   * the weight-gradient kernel (conv_wgrad_ws_kernel) uses a leaner stage (StageLean: buffer loads with the hardware
+//     range check, 2-4 instructions per 16-byte slot): an instruction of a loader wave gets an issue slot only every
+//     ~70 clocks while its SIMD partner streams MFMAs.
 #include "conv_tile.h"
 #include "band_prefetch.h"
 
