@@ -62,6 +62,8 @@ extern "C" int pgv_dbg_set_tlog_v2(void* p) {
 namespace {
 
 #define PGV_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 4x4 transpose inside every aligned lane quad: in: lane i holds x[r] = element (row r, column i); out: lane i holds
 // x[k] = element (row i, column k).
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
         const int cl = (wm * MTW + m) * 16 + ech;
         float* orow = out + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws;
         const float* arow = FUSE ? fuse.a + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws : nullptr;
+        if constexpr (FUSE) {
         // tiles in groups of 8: the saved-activation loads of a group (FUSE) are all issued before the first one is
         // used - one memory latency per group, not one per tile
         constexpr int TG = 8;
@@ -525,6 +528,69 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
               }
             }
           }
+        }
+        } else {
+        // No wave-uniform per-tile branches (each costs more than the tile's arithmetic): a lane whose 4 pixels lie inside
+        // the band stores 16 bytes, the lane that straddles the end of the band stores its 1-3 pixels one by one, lanes
+        // beyond it do nothing - all by exec mask.  Tiles in groups of 8: the saved-activation loads of a group (FUSE) are
+        // all issued before the first one is used - one memory latency per group, not one per tile.
+        constexpr int TG = NT > 16 ? 4 : 8;
+        const f32x2 bias2 = {bias_r[m], bias_r[m]}, slope2 = {slope, slope};
+        f32x2 ss = {0.f, 0.f}, qq = {0.f, 0.f};
+        const int pl = wn * NT * 16 + epx;  // first pixel of this lane in tile 0 of the wave
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+          f4u av[TG];
+          if constexpr (FUSE) {
+#pragma unroll
+            for (int g = 0; g < TG; ++g)
+              if (t0 + g < NT && pl + (t0 + g) * 16 + 4 <= Pb) av[g] = *reinterpret_cast<const f4u*>(arow + pl + (t0 + g) * 16);
+          }
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            const int t = t0 + g;
+            if (t >= NT) continue;
+            const int p0 = pl + t * 16;
+            f32x2 y0 = f32x2{acc[m][t][0], acc[m][t][1]} + bias2, y1 = f32x2{acc[m][t][2], acc[m][t][3]} + bias2;
+            if (ACT == 1) {
+              const f32x2 z0 = y0 * slope2, z1 = y1 * slope2;
+              y0 = f32x2{fmaxf(y0.x, z0.x), fmaxf(y0.y, z0.y)};
+              y1 = f32x2{fmaxf(y1.x, z1.x), fmaxf(y1.y, z1.y)};
+            } else if (ACT != 0) {
+              y0 = f32x2{pgv_act_apply(y0.x, actp), pgv_act_apply(y0.y, actp)};
+              y1 = f32x2{pgv_act_apply(y1.x, actp), pgv_act_apply(y1.y, actp)};
+            }
+            if (p0 + 4 <= Pb) {
+              f4u o;
+              o.x = y0.x, o.y = y0.y, o.z = y1.x, o.w = y1.y;
+              *reinterpret_cast<f4u*>(orow + p0) = o;
+              ss += y0 + y1;
+              if constexpr (FUSE) {
+                const f32x2 mu2 = {mean_r[m], mean_r[m]}, rs2 = {rstd_r[m], rstd_r[m]};
+                qq = __builtin_elementwise_fma(y0, (f32x2{av[g].x, av[g].y} - mu2) * rs2, qq);
+                qq = __builtin_elementwise_fma(y1, (f32x2{av[g].z, av[g].w} - mu2) * rs2, qq);
+              } else {
+                qq = __builtin_elementwise_fma(y0, y0, qq);
+                qq = __builtin_elementwise_fma(y1, y1, qq);
+              }
+            } else if (p0 < Pb) {  // the lane at the ragged end of the band
+              const float x[4] = {y0.x, y0.y, y1.x, y1.y};
+#pragma unroll
+              for (int e = 0; e < 3; ++e) {
+                if (p0 + e < Pb) {
+                  orow[p0 + e] = x[e];
+                  ss.x += x[e];
+                  if constexpr (FUSE)
+                    qq.x = fmaf(x[e], (arow[p0 + e] - mean_r[m]) * rstd_r[m], qq.x);
+                  else
+                    qq.x = fmaf(x[e], x[e], qq.x);
+                }
+              }
+            }
+          }
+        }
+        st_s[m] += ss.x + ss.y;
+        st_q[m] += qq.x + qq.y;
         }
       }
     }
@@ -651,7 +717,8 @@ struct UpV2Cfg {
   static constexpr int S = CK;
   static constexpr int FRONT = 4;
   static constexpr int BUF = CK * PLANE;
-  static constexpr size_t LDS_FLOATS = FRONT + 2 * (size_t)BUF + 2 * CS;
+  // + the epilogue's per-lane store geometry, [2][NT][256] ints (kept in LDS: the accumulators leave no registers for it)
+  static constexpr size_t LDS_FLOATS = FRONT + 2 * (size_t)BUF + 2 * CS + 2 * (size_t)NT * 256;
   static_assert(CB % 4 == 0 && MTT % MW == 0 && CS % CK == 0 && 4 % MW == 0 && S >= 4, "tiling");
 };
 
@@ -788,6 +855,21 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
 #pragma unroll
     for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i);
   f32x4 acc[MTW][NT];
+  // Epilogue geometry of a FULL band (R grid rows, 2R output rows), per pixel tile of this lane: byte-less offset of the
+  // lane's 4 output pixels inside the band of one channel and the number of them that exist (0: tile position beyond the
+  // band / padded grid column), packed as offset | count << 28.  Loop-invariant: computed once.
+  // table 0: a full band (R grid rows, 2R output rows); table 1: the last band of a sample (fewer rows)
+  int* tofl = reinterpret_cast<int*>(tile0 + 2 * BUF + 2 * CS) + tid;  // [2][NT][256], this lane's column
+  constexpr int RB_LAST = Hg - (BANDS - 1) * R, HB_LAST = H - 2 * (BANDS - 1) * R < 2 * RB_LAST ? H - 2 * (BANDS - 1) * R : 2 * RB_LAST;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = (wn * NT + t) * 16 + (lane & 15);
+    const int pu = p / Wgp, pv = p - pu * Wgp;
+    const int orow = 2 * pu + odd, ocol = 2 * (pv & ~1);
+    const int nv = min(max(W - ocol, 0), 4);
+    tofl[t * 256] = (orow * W + ocol) | ((pu < R ? nv : 0) << 28);
+    tofl[(NT + t) * 256] = (orow * W + ocol) | ((pu < RB_LAST && orow < HB_LAST ? nv : 0) << 28);
+  }
   V2_T0();
   ws_barrier();  // item 0 committed
   V2_ACC(0);
@@ -840,6 +922,61 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       const int u0 = band * R;
       const int Rb = min(R, Hg - u0);     // grid rows of this band
       const int Hb = min(2 * Rb, H - 2 * u0);  // output rows of this band
+      if (!FUSE && ACT != 2) {
+        const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
+        // No wave-uniform per-tile branches and no address arithmetic (a uniform branch per tile costs more than the
+        // tile's arithmetic: the general path below spends ~480 clocks per tile): the geometry of the two kinds of band
+        // comes from the tables computed at kernel start.  Lanes whose 4 pixels exist store 16 bytes; the lane at a row end of an odd-width image
+        // stores its 1-3 pixels one by one; statistics ride in the same exec-masked blocks.
+        const f32x2 slope2 = {slope, slope};
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const int cl = (wm * MTW + m) * 4 + ech;
+          float* obase = out + (((int64_t)b * CB + cl) * H + 2 * u0) * W;
+          const f32x2 bias2 = {bias_r[m], bias_r[m]};
+          f32x2 ss = {0.f, 0.f}, qq = {0.f, 0.f};
+          int tvn = tof[0];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int tv = tvn;
+            if (t + 1 < NT) tvn = tof[(t + 1) * 256];  // one tile ahead: the LDS latency hides under this tile's arithmetic
+            f32x2 y0 = f32x2{acc[m][t][0], acc[m][t][1]} + bias2, y1 = f32x2{acc[m][t][2], acc[m][t][3]} + bias2;
+            if (ACT == 1) {
+              const f32x2 z0 = y0 * slope2, z1 = y1 * slope2;
+              y0 = f32x2{fmaxf(y0.x, z0.x), fmaxf(y0.y, z0.y)};
+              y1 = f32x2{fmaxf(y1.x, z1.x), fmaxf(y1.y, z1.y)};
+            }
+            // exchange with the neighbouring grid column: even lanes end up with output row 2u, odd lanes with row 2u+1
+            const float s0 = odd ? y0.x : y1.x, s1 = odd ? y0.y : y1.y;
+            const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+            const f32x2 rr = {r0, r1};
+            const f32x2 o01 = odd ? rr : y0, o23 = odd ? y1 : rr;
+            const int off = tv & 0x0FFFFFFF;
+            const unsigned nv = (unsigned)tv >> 28;
+            if (nv == 4) {
+              f4u o;
+              o.x = o01.x, o.y = o01.y, o.z = o23.x, o.w = o23.y;
+#ifndef PGV_V2_NO_STORE
+              *reinterpret_cast<f4u*>(obase + off) = o;
+#endif
+              ss += o01 + o23;
+              qq = __builtin_elementwise_fma(o01, o01, qq);
+              qq = __builtin_elementwise_fma(o23, o23, qq);
+            } else if ((W % 4 != 0 || Wg != Wgp) && nv != 0) {
+              const float ov[4] = {o01.x, o01.y, o23.x, o23.y};
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (e < (int)nv) {
+                  obase[off + e] = ov[e];
+                  ss.x += ov[e];
+                  qq.x = fmaf(ov[e], ov[e], qq.x);
+                }
+            }
+          }
+          st_s[m] += ss.x + ss.y;
+          st_q[m] += qq.x + qq.y;
+        }
+      } else
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         const int cl = (wm * MTW + m) * 4 + ech;
@@ -896,7 +1033,9 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
               const int off = offs[g];
               f4u o;
               o.x = o0, o.y = o1, o.z = o2, o.w = o3;
+#ifndef PGV_V2_NO_STORE
               *reinterpret_cast<f4u*>(obase + off) = o;
+#endif
               st_s[m] += (o0 + o1) + (o2 + o3);
               if constexpr (FUSE) {
                 st_q[m] = fmaf(o0, (av[g].x - mean_r[m]) * rstd_r[m], st_q[m]);
@@ -1059,8 +1198,6 @@ struct WgradV2Cfg {
 //    end are the next row's) and the CONSUMER zeroes the operand lanes that would read them (last k-step of a row);
 //  * the per-channel affine comes pre-masked per slot (pad chunks 0,0); rows outside the image exist only in the first
 //    and the last band of a sample: those items take a slow path that masks offset and shift per slot.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int CK, int ROWS, int W, int WP, int H>
 struct StageLean {
