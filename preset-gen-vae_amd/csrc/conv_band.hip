@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
   for (int m = 0; m < (kRegStats ? MT : 1); ++m)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) st_s[m][reg] = st_q[m][reg] = 0.f;
-  int u = blockIdx.x;
+  int u = pgv_xcd_block();
   if (u >= units) return;
   BAND_T0();
 #ifdef PGV_SETPRIO
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   };
 
   const int ustep = gridDim.x / NSPLIT;  // the launcher makes the grid a multiple of NSPLIT
-  int u = blockIdx.x / NSPLIT;
+  int u = NSPLIT == 1 ? pgv_xcd_block() : blockIdx.x / NSPLIT;  // consecutive units on one XCD (conv_tile.h)
   BAND_T0();
   if (u < units) issue_unit(u);
 #pragma unroll 1
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
   float st_s[kRegStats ? MT : 1], st_q[kRegStats ? MT : 1];
 #pragma unroll
   for (int m = 0; m < (kRegStats ? MT : 1); ++m) st_s[m] = st_q[m] = 0.f;
-  int u = blockIdx.x;
+  int u = pgv_xcd_block();
   if (u >= units) return;
   BAND_T0();
   issue_item(u, 0);

@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
     const int b = un / BANDS, band = un - b * BANDS;
     pf.issue(small_in + (int64_t)b * CS * Hs * Ws, band * R - 1, CS);
   };
-  if ((int)blockIdx.x < units) issue_unit(blockIdx.x);
-  for (int un = blockIdx.x; un < units; un += gridDim.x) {
+  const int bid = pgv_xcd_block();
+  if (bid < units) issue_unit(bid);
+  for (int un = bid; un < units; un += gridDim.x) {
     const int b = un / BANDS, band = un - b * BANDS;
     const int u0 = band * R, Rb = min(R, Hg - u0);
     __syncthreads();  // the previous unit's reads are complete (first pass: the tables are visible)
@@ -213,8 +214,9 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
     const int b = un / BANDS, band = un - b * BANDS;
     pf.issue(big + (int64_t)b * H * W, 2 * band * R - 2, 1);
   };
-  if ((int)blockIdx.x < units) issue_unit(blockIdx.x);
-  for (int un = blockIdx.x; un < units; un += gridDim.x) {
+  const int bid = pgv_xcd_block();
+  if (bid < units) issue_unit(bid);
+  for (int un = bid; un < units; un += gridDim.x) {
     const int b = un / BANDS, band = un - b * BANDS;
     const int oh0 = band * R, Rb = min(R, Hs - oh0);
     __syncthreads();

@@ -36,6 +36,15 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // Exact n / d for 0 <= n < 2^20, 1 <= d < 2^12 (tile sizes here), via one float multiply.
+// Persistent kernels walk the units  bid, bid + grid, bid + 2 grid, ...  Blocks b and b + 8 share an XCD and its L2
+// (round-robin placement, MI355X_MICROARCH.md; a speed matter only), so the blocks of one XCD are given CONSECUTIVE
+// units - neighbouring bands of a sample, processed at about the same time: the halo rows that two neighbouring bands
+// both stage then come out of that L2 instead of being fetched from HBM once per band.
+__device__ __forceinline__ int pgv_xcd_block() {
+  const int g = (int)gridDim.x, b = (int)blockIdx.x;
+  return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
+
 __device__ __forceinline__ int fast_div(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 
 // Copy a [nch][rows][Wt] window of one sample's [C][H][W] tensor into LDS: element (c, rr, cc) <-> global

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int units = B * BANDS;
-  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int bid = pgv_xcd_block();  // first unit of this workgroup
+  const int my_units = bid < units ? (units - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int my_items = my_units * NCH;
   if (my_items == 0) return;
   if (tid < G::FRONT) lds[tid] = 0.f;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   // global source of local item `it` (clamped to the last one: the loader runs ahead unconditionally)
   auto item_src = [&](int it, const float*& plane0, int& ih0) {
     it = min(it, my_items - 1);
-    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
+    const int u = bid + (it / NCH) * gridDim.x, ch = it % NCH;
     const int b = u / BANDS, band = u - b * BANDS;
     const uint64_t p = (uint64_t)(big + ((int64_t)b * CB + ch * CK) * (H * W));
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
 #else
     if (ch == NCH - 1) {
 #endif
-      const int u = blockIdx.x + (it / NCH) * gridDim.x;
+      const int u = bid + (it / NCH) * gridDim.x;
       const int b = u / BANDS, band = u - b * BANDS;
       const int oh0 = band * R;
       const int Pb = min(R, Hs - oh0) * Ws;  // valid pixels of this band
@@ -741,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int units = B * BANDS;
-  const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int bid = pgv_xcd_block();  // first unit of this workgroup
+  const int my_units = bid < units ? (units - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int my_items = my_units * NCH;
   if (my_items == 0) return;
   if (tid < G::FRONT) lds[tid] = 0.f;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   __syncthreads();
   auto item_src = [&](int it, const float*& plane0, int& ih0) {
     it = min(it, my_items - 1);
-    const int u = blockIdx.x + (it / NCH) * gridDim.x, ch = it % NCH;
+    const int u = bid + (it / NCH) * gridDim.x, ch = it % NCH;
     const int b = u / BANDS, band = u - b * BANDS;
     const uint64_t p = (uint64_t)(small_in + ((int64_t)b * CS + ch * CK) * (Hs * Ws));
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     V2_ITEM();
     if (ch == NCH - 1) {
       // ---- epilogue of the unit
-      const int un = blockIdx.x + (it / NCH) * gridDim.x;
+      const int un = bid + (it / NCH) * gridDim.x;
       const int b = un / BANDS, band = un - b * BANDS;
       const int u0 = band * R;
       const int Rb = min(R, Hg - u0);     // grid rows of this band
@@ -1292,7 +1294,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int units = B * BANDS;
-  const int my_items = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int bid = pgv_xcd_block();  // first unit of this workgroup
+  const int my_items = bid < units ? (units - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   if (tid < 2 * G::FRONT) lds[(tid / G::FRONT) * BUF + tid % G::FRONT] = 0.f;
   if (AFF_B)
     for (int i = tid; i < CB; i += 512) aff_b[i] = big_scale[i], aff_b[CB + i] = big_shift[i];
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
     static_assert(BANDS >= 3 && (BANDS - 2) * 2 * R - 2 + G::ROWS_B <= H && (BANDS - 1) * R <= Hs, "edge bands");
     auto first_item = [&](auto stage_is_big, auto jc) {  // the loads of item 0, slot by slot out of the set-up
       constexpr int J = decltype(jc)::value;
-      const int u = blockIdx.x, b = u / BANDS, band = u - b * BANDS;
+      const int u = bid, b = u / BANDS, band = u - b * BANDS;
       if constexpr (decltype(stage_is_big)::value) {
         const i32x4 rb = StageB::band_rsrc(big, (int64_t)B * CB * (H * W) * 4, ((int64_t)b * CB * H + band * 2 * R - 2) * W);
         StageB::template issue_slot<J, true>(geoB, bA, rb, band == 0 ? geoB.top_bad : (band == BANDS - 1 ? geoB.bot_bad : 0u));
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
     const int64_t bytes_b = (int64_t)B * CB * (H * W) * 4, bytes_s = (int64_t)B * CS * (Hs * Ws) * 4;
     auto band_of = [&](int it, int& b, int& band) {
       it = min(it, my_items - 1);
-      const int u = blockIdx.x + it * gridDim.x;
+      const int u = bid + it * gridDim.x;
       b = u / BANDS;
       band = u - b * BANDS;
     };
@@ -1427,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
     for (int it = 0; it < my_items; ++it) {
       V2_ACC(2);
       const float* cur = tile0 + (it & 1) * BUF;
-      const int u = blockIdx.x + it * gridDim.x;
+      const int u = bid + it * gridDim.x;
       const int nrows = min(R, Hs - (u % BANDS) * R);  // the last band of a sample may be short
       // k-steps go in pairs (two consecutive 4-pixel groups of a row): the two operand values of a lane lie 4 (A) / 8 (B)
       // floats apart and come from ONE ds_read2_b32 - an LDS instruction of the MFMA wave costs MFMA issue time
