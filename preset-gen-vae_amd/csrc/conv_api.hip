@@ -1,6 +1,7 @@
 // extern "C" convolution entry points: validate, pick a tuned gfx950 kernel, fall back to the generic one.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "conv_kernels.h"
 
 static thread_local char g_err[512] = "";
@@ -59,7 +60,8 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
   rc = 0;
   if (g_policy != 1) {
     if (g_policy == 0 && !g_no_v2) {
-      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      static const int fuse_c1 = getenv("PGV_FUSE_C1") ? atoi(getenv("PGV_FUSE_C1")) : 1;
+      const pgv_bn_fuse* f = (stats || !fuse_c1) ? nullptr : fuse;
       rc = pgv_conv_down_direct2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
       fused = rc == 1 && f != nullptr;
     }
