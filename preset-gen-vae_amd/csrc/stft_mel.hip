@@ -24,11 +24,32 @@ constexpr int NWAVE = 4;    // waves per workgroup: one frame pair each per roun
 constexpr int XROW = 68;    // exchange-buffer row stride (float2): 64 + 4 keeps both transposes bank-conflict free
 constexpr int XBUF = 16 * XROW;  // float2 per wave (>= 1024: the natural-order spectrum reuses it)
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex arithmetic on register pairs with the swizzles folded into the packed instructions' operand selects
+// (op_sel / neg modifiers): left to the compiler, the float2 code below spent as many v_mov / v_pk_mov instructions on
+// swapping and negating halves as it spent on arithmetic (742 + 92 moves against 854 packed operations).
+typedef float c32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c32 mk(float x, float y) { return c32{x, y}; }
+// (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
+  c32 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                       // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"               // + (-a.y b.y, a.y b.x)
+      : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return a - b; }
+// a - i b = (a.x + b.y, a.y - b.x);  a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ c32 sub_i(c32 a, c32 b) {
+  c32 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ c32 add_i(c32 a, c32 b) {
+  c32 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // The exchange buffer of a wave is private to it: LDS operations of one wave are issued and completed in order, so a
 // transpose needs no hardware barrier - only the compiler must keep the order of the accesses.
@@ -38,31 +59,31 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
-__device__ __forceinline__ void bfly4(float2& a, float2& b, float2& c, float2& d) {
-  const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
-  a = cadd(t0, t2);
-  c = csub(t0, t2);
-  b = make_float2(t1.x + t3.y, t1.y - t3.x);  // t1 - i t3
-  d = make_float2(t1.x - t3.y, t1.y + t3.x);  // t1 + i t3
+__device__ __forceinline__ void bfly4(c32& a, c32& b, c32& c, c32& d) {
+  const c32 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+  a = t0 + t2;
+  c = t0 - t2;
+  b = sub_i(t1, t3);  // t1 - i t3
+  d = add_i(t1, t3);  // t1 + i t3
 }
 
 // forward 16-point DFT in registers (4 x 4 Cooley-Tukey).  Input x[n] natural; output X[k] is left in slot
 // 4*(k&3) + (k>>2)  (see P16).
 __device__ __forceinline__ constexpr int P16(int k) { return ((k & 3) << 2) | (k >> 2); }
-__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+__device__ __forceinline__ void dft16(c32 (&x)[16]) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) bfly4(x[b], x[4 + b], x[8 + b], x[12 + b]);  // over a (n = 4a + b): slot 4c+b = u[b][c]
   // twiddles W16^(b c), W16 = exp(-2 pi i / 16)
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
-  x[4 * 1 + 1] = cmul(x[4 * 1 + 1], make_float2(C1, -S1));   // e = 1
-  x[4 * 1 + 2] = cmul(x[4 * 1 + 2], make_float2(R, -R));     // e = 2
-  x[4 * 1 + 3] = cmul(x[4 * 1 + 3], make_float2(S1, -C1));   // e = 3
-  x[4 * 2 + 1] = cmul(x[4 * 2 + 1], make_float2(R, -R));     // e = 2
-  x[4 * 2 + 2] = make_float2(x[4 * 2 + 2].y, -x[4 * 2 + 2].x);  // e = 4: -i
-  x[4 * 2 + 3] = cmul(x[4 * 2 + 3], make_float2(-R, -R));    // e = 6
-  x[4 * 3 + 1] = cmul(x[4 * 3 + 1], make_float2(S1, -C1));   // e = 3
-  x[4 * 3 + 2] = cmul(x[4 * 3 + 2], make_float2(-R, -R));    // e = 6
-  x[4 * 3 + 3] = cmul(x[4 * 3 + 3], make_float2(-C1, S1));   // e = 9
+  x[4 * 1 + 1] = cmul(x[4 * 1 + 1], mk(C1, -S1));   // e = 1
+  x[4 * 1 + 2] = cmul(x[4 * 1 + 2], mk(R, -R));     // e = 2
+  x[4 * 1 + 3] = cmul(x[4 * 1 + 3], mk(S1, -C1));   // e = 3
+  x[4 * 2 + 1] = cmul(x[4 * 2 + 1], mk(R, -R));     // e = 2
+  x[4 * 2 + 2] = sub_i(mk(0.f, 0.f), x[4 * 2 + 2]);  // e = 4: -i x = (x.y, -x.x)
+  x[4 * 2 + 3] = cmul(x[4 * 2 + 3], mk(-R, -R));    // e = 6
+  x[4 * 3 + 1] = cmul(x[4 * 3 + 1], mk(S1, -C1));   // e = 3
+  x[4 * 3 + 2] = cmul(x[4 * 3 + 2], mk(-R, -R));    // e = 6
+  x[4 * 3 + 3] = cmul(x[4 * 3 + 3], mk(-C1, S1));   // e = 9
 #pragma unroll
   for (int c = 0; c < 4; ++c) bfly4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);  // over b: slot 4c+d = X[c+4d]
 }
@@ -73,29 +94,29 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     const float* __restrict__ val, int n_rows, int use_mel, float floor_lin, float aff_a, float aff_b,
     float* __restrict__ out, int sig_len, int csr_cap, int mode) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2* xall = reinterpret_cast<float2*>(lds);                   // [NWAVE][XBUF]
+  c32* xall = reinterpret_cast<c32*>(lds);                   // [NWAVE][XBUF]
   float* sig = lds + 2 * NWAVE * XBUF;                             // [sig_len]
   float* tile = sig + ((sig_len + 3) & ~3);                        // [n_rows][FT+1]
-  float2* csr = reinterpret_cast<float2*>(tile + (((size_t)n_rows * (FT + 1) + 3) & ~(size_t)3));  // [csr_cap]
+  c32* csr = reinterpret_cast<c32*>(tile + (((size_t)n_rows * (FT + 1) + 3) & ~(size_t)3));  // [csr_cap]
   int* rowp = reinterpret_cast<int*>(csr + csr_cap);               // [n_rows + 1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const float* w = wav + (int64_t)b * n_samples;
-  float2* xb = xall + wave * XBUF;
+  c32* xb = xall + wave * XBUF;
 
   // ---- one-time setup: W_1024 table (in the exchange buffers), signal window, CSR
   for (int i = tid; i < NFFT; i += 256) {
     float s, c;
     sincospif(-2.0f * (float)i / (float)NFFT, &s, &c);
-    xall[i] = make_float2(c, s);
+    xall[i] = mk(c, s);
   }
   bool csr_lds = false;
   if (use_mel) {
     const int nnz = row_ptr[n_rows];
     csr_lds = nnz <= csr_cap;
     if (csr_lds) {
-      for (int i = tid; i < nnz; i += 256) csr[i] = make_float2(__int_as_float(col[i]), val[i]);
+      for (int i = tid; i < nnz; i += 256) csr[i] = mk(__int_as_float(col[i]), val[i]);
       for (int i = tid; i <= n_rows; i += 256) rowp[i] = row_ptr[i];
     }
   }
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
   __syncthreads();
   // lane-dependent twiddles: pass A multiplies A[k1] by W_1024^(lane k1); pass B (lane = 4 k1 + m2) multiplies C[j1] by
   // W_64^(m2 j1) = W_1024^(16 m2 j1)
-  float2 twA[16], twB[16];
+  c32 twA[16], twB[16];
 #pragma unroll
   for (int k = 1; k < 16; ++k) {
     twA[k] = xall[(lane * k) & (NFFT - 1)];
@@ -114,45 +135,65 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
   __syncthreads();
 
   // a workgroup keeps its tables and walks over the frame groups blockIdx.x, blockIdx.x + gridDim.x, ... of its waveform
+  // The samples of the NEXT frame group are fetched into registers while this group is transformed (one memory latency
+  // per group was exposed before: the waves of a workgroup all wait for the same window).  NPRE covers hop <= 256.
+  constexpr int NPRE = 19;
+  const bool pre_ok = sig_len <= NPRE * 256;
+  float pre[NPRE];
+  auto fetch = [&](int f0n, auto&& put) {
+    const int64_t s0 = (int64_t)f0n * hop - NFFT / 2;
+    for (int i = tid; i < sig_len; i += 256) {
+      const int64_t g = s0 + i;
+      put(i, (g >= 0 && g < n_samples) ? w[g] : 0.f);
+    }
+  };
+  if ((int)blockIdx.x * FT < n_frames) fetch(blockIdx.x * FT, [&](int i, float v) { sig[i] = v; });
   for (int f0 = blockIdx.x * FT; f0 < n_frames; f0 += gridDim.x * FT) {
   const int nf = min(FT, n_frames - f0);
-  const int64_t s0 = (int64_t)f0 * hop - NFFT / 2;
-  for (int i = tid; i < sig_len; i += 256) {
-    const int64_t g = s0 + i;
-    sig[i] = (g >= 0 && g < n_samples) ? w[g] : 0.f;
-  }
+  const int f0n = f0 + gridDim.x * FT;
   __syncthreads();
+  if (pre_ok && f0n < n_frames) {
+    const int64_t s0 = (int64_t)f0n * hop - NFFT / 2;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int i = tid + 256 * j;
+      const int64_t g = s0 + i;
+      pre[j] = (i < sig_len && g >= 0 && g < n_samples) ? w[g] : 0.f;
+    }
+  }
   for (int round = 0; round < FT / 2 / NWAVE; ++round) {
     const int fp = 2 * (round * NWAVE + wave);
-    const bool valid = fp < nf, has2 = fp + 1 < nf;
-    float2 x[16];
+    // every wave transforms its frame pair unconditionally (the pair always lies inside the staged signal window: no
+    // exec-mask branches around the passes); a pair / second frame beyond the spectrogram is simply not stored
+    const bool valid_out = fp < nf, has2 = fp + 1 < nf;
+    constexpr bool valid = true;
+    c32 x[16];
     // ---- pass A: x[n1] = z[64 n1 + lane]; 16-point DFT over n1; twiddle; transpose
     if (valid) {
       const float* sa = sig + fp * hop + lane;
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) {
-        const float re = sa[64 * n1] * wreg[n1];
-        const float im = has2 ? sa[hop + 64 * n1] * wreg[n1] : 0.f;
-        x[n1] = make_float2(re, im);
+        // (frame fp + 1 always lies inside the staged window; when it does not exist its spectrum is not stored)
+        x[n1] = c32{sa[64 * n1], sa[hop + 64 * n1]} * c32{wreg[n1], wreg[n1]};
       }
       dft16(x);
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) {
-        const float2 v = k1 ? cmul(x[P16(k1)], twA[k1]) : x[P16(0)];
+        const c32 v = k1 ? cmul(x[P16(k1)], twA[k1]) : x[P16(0)];
         xb[k1 * XROW + lane] = v;
       }
     }
     wave_sync();
     // ---- pass B: lane = 4 k1 + m2 takes B[k1][4 m1 + m2], m1 = 0..15; 16-point DFT over m1; twiddle; transpose
     if (valid) {
-      const float2* src = xb + (lane >> 2) * XROW + (lane & 3);
+      const c32* src = xb + (lane >> 2) * XROW + (lane & 3);
 #pragma unroll
       for (int m1 = 0; m1 < 16; ++m1) x[m1] = src[4 * m1];
     }
     wave_sync();
     if (valid) {
       dft16(x);
-      float2* dst = xb + (lane >> 2) * XROW + (lane & 3);  // [(k1*17 + j1)*4 + m2]
+      c32* dst = xb + (lane >> 2) * XROW + (lane & 3);  // [(k1*17 + j1)*4 + m2]
 #pragma unroll
       for (int j1 = 0; j1 < 16; ++j1) dst[4 * j1] = j1 ? cmul(x[P16(j1)], twB[j1]) : x[P16(0)];
     }
@@ -161,7 +202,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     if (valid) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float2* src = xb + (lane & 15) * XROW + ((lane >> 4) + 4 * r) * 4;
+        const c32* src = xb + (lane & 15) * XROW + ((lane >> 4) + 4 * r) * 4;
 #pragma unroll
         for (int m2 = 0; m2 < 4; ++m2) x[4 * r + m2] = src[m2];
       }
@@ -179,18 +220,18 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     // ---- split the packed pair and take magnitudes, in place: slot k <- (|Xa[k]|, |Xb[k]|) / norm.
     // Xa[k] = (Z[k] + conj(Z[N-k]))/2 ; Xb[k] = (Z[k] - conj(Z[N-k]))/(2i).  Slot k <= 512 is written by the lane that
     // read it; the partner slots N-k (>= 512) are never written, so no lane reads a slot another lane has overwritten.
-    if (valid && mode == PGV_STFT_COMPLEX) {
+    if (valid_out && mode == PGV_STFT_COMPLEX) {
       // Spectrogram.get_stft (utils/audio.py:33-40): the complex, un-normalised one-sided STFT, straight to HBM as
       // interleaved (re, im) of out[b][k][frame] (an API-completeness path: stores are frame-strided, not tuned)
-      float2* oc = reinterpret_cast<float2*>(out) + (int64_t)b * NBIN * n_frames + f0 + fp;
+      c32* oc = reinterpret_cast<c32*>(out) + (int64_t)b * NBIN * n_frames + f0 + fp;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int k = lane + 64 * i;
         if (k < NBIN) {
-          const float2 zk = xb[k];
-          const float2 zn = xb[(NFFT - k) & (NFFT - 1)];
-          oc[(int64_t)k * n_frames] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-          if (has2) oc[(int64_t)k * n_frames + 1] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+          const c32 zk = xb[k];
+          const c32 zn = xb[(NFFT - k) & (NFFT - 1)];
+          oc[(int64_t)k * n_frames] = mk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+          if (has2) oc[(int64_t)k * n_frames + 1] = mk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
         }
       }
     }
@@ -199,11 +240,11 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
       for (int i = 0; i < 9; ++i) {
         const int k = lane + 64 * i;
         if (k < NBIN) {
-          const float2 zk = xb[k];
-          const float2 zn = xb[(NFFT - k) & (NFFT - 1)];
+          const c32 zk = xb[k];
+          const c32 zn = xb[(NFFT - k) & (NFFT - 1)];
           const float x1r = 0.5f * (zk.x + zn.x), x1i = 0.5f * (zk.y - zn.y);
           const float x2r = 0.5f * (zk.y + zn.y), x2i = -0.5f * (zk.x - zn.x);
-          x[i] = make_float2(__builtin_amdgcn_sqrtf(x1r * x1r + x1i * x1i) * inv_norm,
+          x[i] = mk(__builtin_amdgcn_sqrtf(x1r * x1r + x1i * x1i) * inv_norm,
                              __builtin_amdgcn_sqrtf(x2r * x2r + x2i * x2i) * inv_norm);
         }
       }
@@ -228,7 +269,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
             // four taps per trip, loads first: the (row pointer -> tap -> magnitude) chain is LDS latency three deep
             const int e0 = rowp[r], e1 = rowp[r + 1];
             for (int e = e0; e < e1; e += 4) {
-              float2 cv[4], mg[4];
+              c32 cv[4], mg[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u) cv[u] = csr[min(e + u, e1 - 1)];
 #pragma unroll
@@ -243,18 +284,19 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
           } else {
             for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
               const float v = val[e];
-              const float2 mg = xb[col[e]];
+              const c32 mg = xb[col[e]];
               m0 = fmaf(v, mg.x, m0);
               m1 = fmaf(v, mg.y, m1);
             }
           }
         } else {
-          const float2 mg = xb[r];
+          const c32 mg = xb[r];
           m0 = mg.x;
           m1 = mg.y;
         }
         // PGV_STFT_LINEAR (Spectrogram(log_scale=False), utils/audio.py:42-50): the normalised amplitudes as they are
-        tile[r * (FT + 1) + fp] =
+        if (valid_out)
+          tile[r * (FT + 1) + fp] =
             mode == PGV_STFT_LINEAR
                 ? m0
                 : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
@@ -277,6 +319,15 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
     }
   }
   __syncthreads();  // the tile and the signal window are rewritten by the next group
+  if (f0n < n_frames) {
+    if (pre_ok) {
+#pragma unroll
+      for (int j = 0; j < NPRE; ++j)
+        if (tid + 256 * j < sig_len) sig[tid + 256 * j] = pre[j];
+    } else {
+      fetch(f0n, [&](int i, float v) { sig[i] = v; });
+    }
+  }
   }
 }
 
