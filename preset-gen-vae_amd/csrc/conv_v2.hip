@@ -226,6 +226,86 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// Loader stage of the wgrad kernel.  Measured on gfx950 (scratch/ubench/ws_share.hip): while one wave of a SIMD streams
+// MFMAs back to back, every instruction of the SIMD's other wave (VALU or LDS, any s_setprio) gets an issue slot only
+// about every 70 clocks.  The StageV2 loader (20 instructions per 16-byte slot) then needs 1.3x the time the MFMA waves
+// need for the item.  This stage spends 2-4 instructions per slot instead:
+//  * buffer_load_dwordx4 with the hardware range check: pad lanes carry offset 0xFFFFFFFF and read as zero - no select,
+//    no live mask; the per-item address lives in the resource descriptor (scalar ALU), the lane offset is a constant;
+//  * no rotation of the partial chunk at the end of a row: the chunk is loaded as it lies (the floats behind the row
+//    end are the next row's) and the CONSUMER zeroes the operand lanes that would read them (last k-step of a row);
+//  * the per-channel affine comes pre-masked per slot (pad chunks 0,0); rows outside the image exist only in the first
+//    and the last band of a sample: those items take a slow path that masks offset and shift per slot.
+
+template <int CK, int ROWS, int W, int WP, int H>
+struct StageLean {
+  static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256;
+  static_assert(WP % 4 == 0 && WP >= W && NPF <= 32, "stage geometry");
+  struct Geo {
+    unsigned voff[NPF];  // byte offset from the band's first row in channel 0, 0xFFFFFFFF for pad chunks / idle lanes
+    f32x2 ma[NPF];       // (scale, shift) of the slot's channel; (0, 0) for pad chunks
+    unsigned top_bad, bot_bad;  // bit j: slot j lies in a row outside the image in the first / the last band of a sample
+    // top_rows: rows of the first band above the image; bot_row: first row of the last band below the image
+    // after_slot(integral_constant<j>) runs when slot j's constants are ready (the caller issues the first item's load
+    // of the slot there: the rest of the set-up then overlaps the memory latency)
+    template <class F>
+    __device__ __forceinline__ void init(int tid, const float* __restrict__ aff, int C, bool has_aff, int top_rows,
+                                         int bot_row, F&& after_slot) {
+      top_bad = bot_bad = 0;
+      static_for<0, NPF>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int e = min(tid + 256 * j, ITEMS - 1);
+        const int rowi = e / QR, q = e - rowi * QR;
+        const int c = rowi / ROWS, rr = rowi - c * ROWS;
+        const bool data = tid + 256 * j < ITEMS && 4 * q < W;
+        voff[j] = data ? (unsigned)(((c * H + rr) * W + 4 * q) * 4) : 0xFFFFFFFFu;
+        top_bad |= rr < top_rows ? 1u << j : 0u;
+        bot_bad |= rr >= bot_row ? 1u << j : 0u;
+        after_slot(jc);
+        ma[j] = f32x2{data ? (has_aff ? aff[c] : 1.f) : 0.f, (data && has_aff) ? aff[C + c] : 0.f};
+      });
+    }
+  };
+  struct Set {
+    f32x4 v[NPF];
+  };
+  // descriptor of "everything from the band's first row (row ih0 of channel 0 of sample b) to the end of the tensor"
+  static __device__ __forceinline__ i32x4 band_rsrc(const float* __restrict__ base, int64_t total_bytes, int64_t elem0) {
+    const uint64_t p = (uint64_t)base + (uint64_t)(elem0 * 4);
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32) & 0xFFFF);
+    r.z = __builtin_amdgcn_readfirstlane((int)(uint32_t)(total_bytes - elem0 * 4));
+    r.w = 0x00020000;  // raw buffer, 32-bit data format (gfx9 family)
+    return r;
+  }
+  // bad = top_bad / bot_bad of the item (EDGE) - unused otherwise
+  template <int J, bool EDGE>
+  static __device__ __forceinline__ void issue_slot(const Geo& g, Set& s, i32x4 rsrc, unsigned bad) {
+    unsigned off = g.voff[J];
+    if (EDGE) off |= (unsigned)__builtin_amdgcn_sbfe(bad, J, 1);
+    // inline asm: see StageV2::issue_slot (the compiler's s_waitcnt bookkeeping would drain both sets in flight)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(s.v[J]) : "v"(off), "s"(rsrc) : "memory");
+  }
+  template <int J, bool EDGE, bool AFF>
+  static __device__ __forceinline__ void commit_slot(const Geo& g, const Set& s, float* __restrict__ tile, int tid,
+                                                     unsigned bad) {
+    if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
+      f32x4 x = s.v[J];
+      if (AFF) {
+        f32x2 ma = g.ma[J];
+        if (EDGE) ma.y = ((bad >> J) & 1u) ? 0.f : ma.y;  // the data of such a row was read as zero already
+        // x = x * scale + shift on both halves, scale / shift broadcast out of the (scale, shift) pair by op_sel
+        f32x2 lo = {x.x, x.y}, hi = {x.z, x.w};
+        asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(lo), "v"(ma));
+        asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(hi), "v"(ma));
+        x = f32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      *reinterpret_cast<f32x4*>(tile + 4 * tid + 1024 * J) = x;
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN (Conv2d forward / ConvTranspose2d input-gradient), k = 4, stride 2, pad 2:
 //   D[cs][pixel] = sum_{c,kh,kw} W[cs][c][kh][kw] * X[c][2r+kh-2][2col+kw-2]
@@ -723,7 +803,14 @@ struct UpV2Cfg {
   static_assert(CB % 4 == 0 && MTT % MW == 0 && CS % CK == 0 && 4 % MW == 0 && S >= 4, "tiling");
 };
 
-template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT>
+// STG ("deferred stores"): the epilogue leaves the finished band in REGISTERS and the stores go out one tile per k-step
+// of the NEXT unit, from the MFMA waves themselves.  For the 129x174 layer the output of a unit (56 KB) leaving in one
+// burst while the matrix pipe idles was 35 % of the kernel (the store path of a CU moves ~10 bytes per clock).  Handing
+// the band to the loader waves through LDS does not work: their ~100 instruction slots per unit are used up by the input
+// stage.  The stores are buffer stores with the hardware range check, so they need no branch inside the pinned k-step
+// regions: lanes without (4 / 2) valid pixels carry an out-of-range offset, and a descriptor of zero bytes drops the
+// stores of the first unit, which has nothing pending.  Needs NCH == 1 and an even image width; uses the lean loader.
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false>
 __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* __restrict__ small_in,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift,
@@ -735,6 +822,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
   using Stage = StageV2<CK, G::ROWS, Ws, WsP, Hs, 1>;
   constexpr int NPF = Stage::NPF;
+  static_assert(!STG || (NCH == 1 && !FUSE && ACT != 2 && W % 2 == 0 && S >= MTW * NT), "deferred stores");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile0 = lds + G::FRONT;
   float* aff = tile0 + 2 * BUF;  // [2][CS]
@@ -762,6 +850,65 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     ih0 = band * R;
   };
 
+  if (STG && wave >= 4) {
+    // ======================================= loader waves, lean form (see StageLean) =====================================
+    // (an instruction of these waves gets an issue slot every ~70 clocks while the SIMD partner streams MFMAs: the
+    // StageV2 loader needs ~180 of them per item of this layer, the budget is ~100)
+    using Lean = StageLean<CK, G::ROWS, Ws, WsP, Hs>;
+    constexpr int NL = Lean::NPF;
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    typename Lean::Geo geo;
+    typename Lean::Set sA, sB;
+    static_assert(!STG || (BANDS >= 2 && (BANDS - 1) * R <= Hs), "edge bands");
+    const int64_t bytes_in = (int64_t)B * CS * (Hs * Ws) * 4;
+    auto item_geo = [&](int it, i32x4& rs, unsigned& bad) {
+      it = min(it, my_items - 1);
+      const int u = bid + it * gridDim.x;
+      const int b = u / BANDS, band = u - b * BANDS;
+      rs = Lean::band_rsrc(small_in, bytes_in, ((int64_t)b * CS * Hs + band * R) * Ws);
+      bad = band == BANDS - 1 ? geo.bot_bad : 0u;  // rows below the input plane exist only in the last band
+    };
+    geo.init(ltid, aff, CS, HAS_AFF, 0, Hs - (BANDS - 1) * R, [&](auto jc) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(0, rs, bad);
+      Lean::template issue_slot<decltype(jc)::value, true>(geo, sA, rs, bad);
+    });
+    auto issue_all = [&](typename Lean::Set& sx, int it) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(it, rs, bad);
+      static_for<0, NL>([&](auto j) { Lean::template issue_slot<decltype(j)::value, true>(geo, sx, rs, bad); });
+    };
+    auto commit_all = [&](const typename Lean::Set& sx, int it, float* dst) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(it, rs, bad);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // the older set has landed
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF>(geo, sx, dst, ltid, bad); });
+    };
+    issue_all(sB, 1);  // (item 0 went out during the set-up)
+    commit_all(sA, 0, tile0);
+    issue_all(sA, 2);
+    ws_barrier();
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+      commit_all(sB, it + 1, tile0 + BUF);
+      issue_all(sB, it + 3);
+      ws_barrier();
+      if (it + 1 < my_items) {
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        commit_all(sA, it + 2, tile0);
+        issue_all(sA, it + 4);
+        ws_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   if (wave >= 4) {
     // ================================================= loader waves =================================================
     const int ltid = tid - 256;
@@ -857,6 +1004,27 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
 #pragma unroll
     for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i);
   f32x4 acc[MTW][NT];
+  // deferred stores (STG): the previous unit's output tiles, their byte offsets inside the unit (or an out-of-range mark)
+  // for the lanes that store 16 / 8 bytes, this lane's channel offsets, and the unit's buffer descriptor
+  constexpr unsigned OOR = 0x80000000u;  // stays out of range after the channel offset is added
+  f32x4 pend[STG ? MTW : 1][STG ? NT : 1];
+  unsigned p4[STG ? NT : 1], p2[STG ? NT : 1], choff[STG ? MTW : 1];
+  i32x4 prs = {0, 0, 0, 0x00020000};  // zero bytes: nothing pending yet, every store is dropped
+  if constexpr (STG) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p4[t] = p2[t] = OOR;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) choff[m] = (unsigned)(((wm * MTW + m) * 4 + (lane >> 4)) * (H * W) * 4);
+  }
+  auto store_pending = [&](auto qc) {  // tile q = m * NT + t of the pending unit
+    constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
+    const unsigned o4 = p4[t] + choff[m], o2 = p2[t] + choff[m];
+    const f32x2 lo = {pend[m][t].x, pend[m][t].y};
+    const f32x4 all = pend[m][t];
+    const i32x4 rs = prs;
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(all), "v"(o4), "s"(rs) : "memory");
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" ::"v"(lo), "v"(o2), "s"(rs) : "memory");
+  };
   // Epilogue geometry of a FULL band (R grid rows, 2R output rows), per pixel tile of this lane: byte-less offset of the
   // lane's 4 output pixels inside the band of one channel and the number of them that exist (0: tile position beyond the
   // band / padded grid column), packed as offset | count << 28.  Loop-invariant: computed once.
@@ -896,6 +1064,10 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       constexpr int st = decltype(st_c)::value;
       constexpr int sn = st + 2;
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (STG && st < MTW * NT) {
+        store_pending(st_c);  // one tile of the previous unit leaves per k-step
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (sn < S) bq[sn % 3][t] = cur[sn * PLANE + offB[t]];
@@ -931,6 +1103,9 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
         // comes from the tables computed at kernel start.  Lanes whose 4 pixels exist store 16 bytes; the lane at a row end of an odd-width image
         // stores its 1-3 pixels one by one; statistics ride in the same exec-masked blocks.
         const f32x2 slope2 = {slope, slope};
+        if constexpr (STG)  // descriptor of [this band of channel 0 of the sample .. end of the tensor)
+          prs = StageLean<CK, G::ROWS, Ws, WsP, Hs>::band_rsrc(out, (int64_t)B * CB * (H * W) * 4,
+                                                                ((int64_t)b * CB * H + 2 * u0) * W);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
           const int cl = (wm * MTW + m) * 4 + ech;
@@ -955,12 +1130,22 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
             const f32x2 o01 = odd ? rr : y0, o23 = odd ? y1 : rr;
             const int off = tv & 0x0FFFFFFF;
             const unsigned nv = (unsigned)tv >> 28;
+            if constexpr (STG) {
+              if (m == 0) {
+                p4[t] = nv == 4 ? (unsigned)off * 4u : OOR;
+                p2[t] = nv == 2 ? (unsigned)off * 4u : OOR;
+              }
+            }
             if (nv == 4) {
               f4u o;
               o.x = o01.x, o.y = o01.y, o.z = o23.x, o.w = o23.y;
+              if constexpr (STG) {
+                pend[m][t] = f32x4{o.x, o.y, o.z, o.w};
+              } else {
 #ifndef PGV_V2_NO_STORE
-              *reinterpret_cast<f4u*>(obase + off) = o;
+                *reinterpret_cast<f4u*>(obase + off) = o;
 #endif
+              }
               ss += o01 + o23;
               qq = __builtin_elementwise_fma(o01, o01, qq);
               qq = __builtin_elementwise_fma(o23, o23, qq);
@@ -969,7 +1154,10 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
 #pragma unroll
               for (int e = 0; e < 3; ++e)
                 if (e < (int)nv) {
-                  obase[off + e] = ov[e];
+                  if constexpr (STG)
+                    pend[m][t] = f32x4{ov[0], ov[1], ov[2], ov[3]};  // (even width: 2 valid pixels, stored as 8 bytes)
+                  else
+                    obase[off + e] = ov[e];
                   ss.x += ov[e];
                   qq.x = fmaf(ov[e], ov[e], qq.x);
                 }
@@ -1073,6 +1261,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     ws_barrier();
     V2_ACC(2);
   }
+  if constexpr (STG) static_for<0, MTW * NT>([&](auto qc) { store_pending(qc); });  // the last unit
   V2_FLUSH();
   // statistics / projections: one float64 atomic per channel per workgroup (see conv_down_ws_kernel)
   double* dst = FUSE ? fuse.red : stats;
@@ -1123,6 +1312,8 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
                  const float* w, const float* bias, int act, float slope, float* out, double* stats,
                  const pgv_bn_fuse* fuse, hipStream_t st) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
+  // deferred stores for the layer whose output bursts bound it (129x174: 56 KB per unit), where the variant exists
+  constexpr bool STG = W == 174 && G::NCH == 1;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
   if (d->Cb != CB || d->Cs != CS) return 0;
@@ -1145,6 +1336,15 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
     kern = actk == 0 ? PGV_UK(false, false, 0) : (actk == 1 ? PGV_UK(false, false, 1) : PGV_UK(false, false, 2));
 #endif
 #undef PGV_UK
+  if constexpr (STG) {  // (only the non-fused LeakyReLU / linear forms exist with deferred stores)
+    if (fuse || actk == 2) return 0;
+    if (in_scale)
+      kern = actk == 1 ? (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 1, true>
+                       : (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 0, true>;
+    else
+      kern = actk == 1 ? (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 1, true>
+                       : (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 0, true>;
+  }
   if (int rc = raise_lds_once((const void*)kern, "conv_up_v2")) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_v2: memset failed");
@@ -1188,86 +1388,6 @@ struct WgradV2Cfg {
   static constexpr int BUF = FRONT + CB * PLANE_B + CS * PLANE_S;
   static constexpr size_t LDS_FLOATS = 2 * (size_t)BUF + 2 * (CB + CS);
   static_assert(CS % 16 == 0 && CB % 4 == 0 && WP >= W + 2 && WP % 4 == 0 && 2 * WsP <= WP, "tiling");
-};
-
-// Loader stage of the wgrad kernel.  Measured on gfx950 (scratch/ubench/ws_share.hip): while one wave of a SIMD streams
-// MFMAs back to back, every instruction of the SIMD's other wave (VALU or LDS, any s_setprio) gets an issue slot only
-// about every 70 clocks.  The StageV2 loader (20 instructions per 16-byte slot) then needs 1.3x the time the MFMA waves
-// need for the item.  This stage spends 2-4 instructions per slot instead:
-//  * buffer_load_dwordx4 with the hardware range check: pad lanes carry offset 0xFFFFFFFF and read as zero - no select,
-//    no live mask; the per-item address lives in the resource descriptor (scalar ALU), the lane offset is a constant;
-//  * no rotation of the partial chunk at the end of a row: the chunk is loaded as it lies (the floats behind the row
-//    end are the next row's) and the CONSUMER zeroes the operand lanes that would read them (last k-step of a row);
-//  * the per-channel affine comes pre-masked per slot (pad chunks 0,0); rows outside the image exist only in the first
-//    and the last band of a sample: those items take a slow path that masks offset and shift per slot.
-
-template <int CK, int ROWS, int W, int WP, int H>
-struct StageLean {
-  static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256;
-  static_assert(WP % 4 == 0 && WP >= W && NPF <= 32, "stage geometry");
-  struct Geo {
-    unsigned voff[NPF];  // byte offset from the band's first row in channel 0, 0xFFFFFFFF for pad chunks / idle lanes
-    f32x2 ma[NPF];       // (scale, shift) of the slot's channel; (0, 0) for pad chunks
-    unsigned top_bad, bot_bad;  // bit j: slot j lies in a row outside the image in the first / the last band of a sample
-    // top_rows: rows of the first band above the image; bot_row: first row of the last band below the image
-    // after_slot(integral_constant<j>) runs when slot j's constants are ready (the caller issues the first item's load
-    // of the slot there: the rest of the set-up then overlaps the memory latency)
-    template <class F>
-    __device__ __forceinline__ void init(int tid, const float* __restrict__ aff, int C, bool has_aff, int top_rows,
-                                         int bot_row, F&& after_slot) {
-      top_bad = bot_bad = 0;
-      static_for<0, NPF>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int e = min(tid + 256 * j, ITEMS - 1);
-        const int rowi = e / QR, q = e - rowi * QR;
-        const int c = rowi / ROWS, rr = rowi - c * ROWS;
-        const bool data = tid + 256 * j < ITEMS && 4 * q < W;
-        voff[j] = data ? (unsigned)(((c * H + rr) * W + 4 * q) * 4) : 0xFFFFFFFFu;
-        top_bad |= rr < top_rows ? 1u << j : 0u;
-        bot_bad |= rr >= bot_row ? 1u << j : 0u;
-        after_slot(jc);
-        ma[j] = f32x2{data ? (has_aff ? aff[c] : 1.f) : 0.f, (data && has_aff) ? aff[C + c] : 0.f};
-      });
-    }
-  };
-  struct Set {
-    f32x4 v[NPF];
-  };
-  // descriptor of "everything from the band's first row (row ih0 of channel 0 of sample b) to the end of the tensor"
-  static __device__ __forceinline__ i32x4 band_rsrc(const float* __restrict__ base, int64_t total_bytes, int64_t elem0) {
-    const uint64_t p = (uint64_t)base + (uint64_t)(elem0 * 4);
-    i32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
-    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32) & 0xFFFF);
-    r.z = __builtin_amdgcn_readfirstlane((int)(uint32_t)(total_bytes - elem0 * 4));
-    r.w = 0x00020000;  // raw buffer, 32-bit data format (gfx9 family)
-    return r;
-  }
-  // bad = top_bad / bot_bad of the item (EDGE) - unused otherwise
-  template <int J, bool EDGE>
-  static __device__ __forceinline__ void issue_slot(const Geo& g, Set& s, i32x4 rsrc, unsigned bad) {
-    unsigned off = g.voff[J];
-    if (EDGE) off |= (unsigned)__builtin_amdgcn_sbfe(bad, J, 1);
-    // inline asm: see StageV2::issue_slot (the compiler's s_waitcnt bookkeeping would drain both sets in flight)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(s.v[J]) : "v"(off), "s"(rsrc) : "memory");
-  }
-  template <int J, bool EDGE, bool AFF>
-  static __device__ __forceinline__ void commit_slot(const Geo& g, const Set& s, float* __restrict__ tile, int tid,
-                                                     unsigned bad) {
-    if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
-      f32x4 x = s.v[J];
-      if (AFF) {
-        f32x2 ma = g.ma[J];
-        if (EDGE) ma.y = ((bad >> J) & 1u) ? 0.f : ma.y;  // the data of such a row was read as zero already
-        // x = x * scale + shift on both halves, scale / shift broadcast out of the (scale, shift) pair by op_sel
-        f32x2 lo = {x.x, x.y}, hi = {x.z, x.w};
-        asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(lo), "v"(ma));
-        asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(hi), "v"(ma));
-        x = f32x4{lo.x, lo.y, hi.x, hi.y};
-      }
-      *reinterpret_cast<f32x4*>(tile + 4 * tid + 1024 * J) = x;
-    }
-  }
 };
 
 template <int CB, int CS, int W, int H, int R, bool AFF_B, bool AFF_S>
@@ -1603,10 +1723,11 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
     return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 32 -> 16 channels onto 65x88: 3 bands of 11 grid rows, waves split the positions
     return launch_up_v2<16, 32, 88, 65, 11, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
-#ifdef PGV_V2_UP_L2
-  // 16 -> 8 channels onto 129x174 (13 bands of 5 grid rows, waves split the positions): correct, but this layer is bound
-  // by the CU's store path (56 KB of output per unit leave in one burst while the matrix pipe idles); the band kernel's
-  // two co-resident workgroups overlap that burst and are 5-7 us faster, so the dispatch leaves the layer to them
+#ifndef PGV_V2_NO_UP_L2
+  // 16 -> 8 channels onto 129x174 (13 bands of 5 grid rows, waves split the positions).  This layer is bound by the CU's
+  // store path (56 KB of output per unit): with direct stores from the epilogue the matrix pipe idled 35 % of the time
+  // and the band kernel's two co-resident workgroups were faster; with the output staged through LDS and moved out by
+  // the loader waves during the next unit's k-steps (STG) this form wins.  Fused projections stay on the band kernel.
   if (d->Hb == 129 && d->Wb == 174)
     return launch_up_v2<8, 16, 174, 129, 5, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
 #endif
