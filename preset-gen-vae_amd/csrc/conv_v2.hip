@@ -237,14 +237,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 //  * the per-channel affine comes pre-masked per slot (pad chunks 0,0); rows outside the image exist only in the first
 //    and the last band of a sample: those items take a slow path that masks offset and shift per slot.
 
-template <int CK, int ROWS, int W, int WP, int H>
+// ZTAIL: the loader itself clears the floats behind the end of a row in the row's last chunk (W % 4 != 0), for consumers
+// that read them as zero padding in every k-step (conv_down): 1 + (4 - W % 4) more instructions per slot.
+template <int CK, int ROWS, int W, int WP, int H, bool ZTAIL = false>
 struct StageLean {
-  static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256;
+  static constexpr int QR = WP / 4, PC = ROWS * QR, ITEMS = CK * PC, NPF = (ITEMS + 255) / 256, NP = W % 4;
   static_assert(WP % 4 == 0 && WP >= W && NPF <= 32, "stage geometry");
   struct Geo {
     unsigned voff[NPF];  // byte offset from the band's first row in channel 0, 0xFFFFFFFF for pad chunks / idle lanes
     f32x2 ma[NPF];       // (scale, shift) of the slot's channel; (0, 0) for pad chunks
     unsigned top_bad, bot_bad;  // bit j: slot j lies in a row outside the image in the first / the last band of a sample
+    unsigned whole;             // bit j: all 4 floats of slot j lie inside their row (ZTAIL)
     // top_rows: rows of the first band above the image; bot_row: first row of the last band below the image
     // after_slot(integral_constant<j>) runs when slot j's constants are ready (the caller issues the first item's load
     // of the slot there: the rest of the set-up then overlaps the memory latency)
@@ -252,12 +255,14 @@ struct StageLean {
     __device__ __forceinline__ void init(int tid, const float* __restrict__ aff, int C, bool has_aff, int top_rows,
                                          int bot_row, F&& after_slot) {
       top_bad = bot_bad = 0;
+      whole = 0;
       static_for<0, NPF>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int e = min(tid + 256 * j, ITEMS - 1);
         const int rowi = e / QR, q = e - rowi * QR;
         const int c = rowi / ROWS, rr = rowi - c * ROWS;
         const bool data = tid + 256 * j < ITEMS && 4 * q < W;
+        whole |= 4 * q + 4 <= W ? 1u << j : 0u;
         voff[j] = data ? (unsigned)(((c * H + rr) * W + 4 * q) * 4) : 0xFFFFFFFFu;
         top_bad |= rr < top_rows ? 1u << j : 0u;
         bot_bad |= rr >= bot_row ? 1u << j : 0u;
@@ -300,6 +305,11 @@ struct StageLean {
         asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(lo), "v"(ma));
         asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(hi), "v"(ma));
         x = f32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      if (ZTAIL && NP != 0) {
+        const int km = __builtin_amdgcn_sbfe((int)g.whole, J, 1);  // -1: keep, 0: the row ends inside this chunk
+#pragma unroll
+        for (int c = NP; c < 4; ++c) x[c] = __int_as_float(__float_as_int(x[c]) & km);
       }
       *reinterpret_cast<f32x4*>(tile + 4 * tid + 1024 * J) = x;
     }
@@ -346,7 +356,9 @@ struct DownV2Cfg {
 // instructions (the sliced single-role kernel above spends 38-44 clk per MFMA in its k-steps, the bare loop 34.5), and
 // the loader is ordinary code - loops, branches, no scheduling pragmas.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT>
+// STG: lean loader (StageLean, row tails cleared by the loader) + deferred stores, as in conv_up_ws_kernel: for the
+// 129x174 layer, whose StageV2 loader co-limits it and whose output leaves in bursts.
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false>
 __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float* __restrict__ big,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   constexpr int WP = G::WP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
   using Stage = StageV2<CK, G::ROWS, W, WP, H>;
   constexpr int NPF = Stage::NPF;
+  static_assert(!STG || (NCH == 1 && !FUSE && ACT != 2 && Ws % 4 == 0 && S >= MTW * NT), "deferred stores");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile0 = lds + G::FRONT;
   float* aff = tile0 + 2 * BUF;  // [2][CB]
@@ -386,6 +399,63 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
     ih0 = band * R * 2 - 2;
   };
 
+  if (STG && wave >= 4) {
+    // ======================================= loader waves, lean form (see StageLean) =====================================
+    using Lean = StageLean<CK, G::ROWS, W, WP, H, true>;
+    constexpr int NL = Lean::NPF;
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    typename Lean::Geo geo;
+    typename Lean::Set sA, sB;
+    static_assert(!STG || (BANDS >= 3 && (BANDS - 2) * 2 * R - 2 + G::ROWS <= H), "edge bands");
+    const int64_t bytes_in = (int64_t)B * CB * (H * W) * 4;
+    auto item_geo = [&](int it, i32x4& rs, unsigned& bad) {
+      it = min(it, my_items - 1);
+      const int u = bid + it * gridDim.x;
+      const int b = u / BANDS, band = u - b * BANDS;
+      rs = Lean::band_rsrc(big, bytes_in, ((int64_t)b * CB * H + band * 2 * R - 2) * W);
+      bad = band == 0 ? geo.top_bad : (band == BANDS - 1 ? geo.bot_bad : 0u);
+    };
+    geo.init(ltid, aff, CB, HAS_AFF, 2, H - ((BANDS - 1) * 2 * R - 2), [&](auto jc) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(0, rs, bad);
+      Lean::template issue_slot<decltype(jc)::value, true>(geo, sA, rs, bad);
+    });
+    auto issue_all = [&](typename Lean::Set& sx, int it) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(it, rs, bad);
+      static_for<0, NL>([&](auto j) { Lean::template issue_slot<decltype(j)::value, true>(geo, sx, rs, bad); });
+    };
+    auto commit_all = [&](const typename Lean::Set& sx, int it, float* dst) {
+      i32x4 rs;
+      unsigned bad;
+      item_geo(it, rs, bad);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // the older set has landed
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF>(geo, sx, dst, ltid, bad); });
+    };
+    issue_all(sB, 1);  // (item 0 went out during the set-up)
+    commit_all(sA, 0, tile0);
+    issue_all(sA, 2);
+    ws_barrier();
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+      commit_all(sB, it + 1, tile0 + BUF);
+      issue_all(sB, it + 3);
+      ws_barrier();
+      if (it + 1 < my_items) {
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        commit_all(sA, it + 2, tile0);
+        issue_all(sA, it + 4);
+        ws_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   if (wave >= 4) {
     // ================================================= loader waves =================================================
     const int ltid = tid - 256;
@@ -485,12 +555,45 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   // two-halves register ring (an even number of halves per item keeps every index a compile-time constant)
   constexpr int HS = (S % 16 == 0) ? 8 : S / 2;
   static_assert(S % (2 * HS) == 0, "weight ring");
-  float aw[2][MTW][HS];
+  // STG (one channel chunk per unit): the S weights of a lane are the same for every item - they are loaded ONCE and the
+  // loop holds no vector-memory loads at all.  That matters beyond the loads saved: gfx9 counts loads and stores in one
+  // counter (vmcnt), so every wait for a weight load issued after a deferred store also waits for that store to
+  // complete (10.7 k instead of 7.3 k clocks per item with the ring).
+  constexpr bool WRES = STG && NCH == 1;
+  float aw[2][MTW][WRES ? 1 : HS];
+  float awr[WRES ? MTW : 1][WRES ? S : 1];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
+  for (int m = 0; m < MTW; ++m) {
+    if constexpr (WRES) {
 #pragma unroll
-    for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i * 4);
+      for (int i = 0; i < S; ++i) awr[m][i] = wload(m, i * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i * 4);
+    }
+  }
   f32x4 acc[MTW][NT];
+  // deferred stores (STG), see conv_up_ws_kernel: the previous unit's tiles, their byte offsets inside the unit (or the
+  // out-of-range mark), this lane's channel offsets, the unit's buffer descriptor (zero bytes: nothing pending)
+  constexpr unsigned OOR = 0x80000000u;
+  f32x4 pend[STG ? MTW : 1][STG ? NT : 1];
+  unsigned p4[STG ? NT : 1], choff[STG ? MTW : 1];
+  i32x4 prs = {0, 0, 0, 0x00020000};
+  if constexpr (STG) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p4[t] = OOR;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) choff[m] = (unsigned)(((wm * MTW + m) * 16 + (lane & 15)) * (Hs * Ws) * 4);
+  }
+  auto store_pending = [&](auto qc) {  // tile q = m * NT + t of the pending unit
+    constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
+    const unsigned o4 = p4[t] + choff[m];
+    const f32x4 all = pend[m][t];
+    const i32x4 rs = prs;
+    // (s_nop: a VALU write to the data registers of a > 8-byte store needs a wait state on gfx9; the compiler's hazard
+    // recognizer cannot see into inline asm - without it some lanes stored the next instruction's result)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(all), "v"(o4), "s"(rs) : "memory");
+  };
   ws_barrier();  // item 0 committed
   V2_ACC(0);
 #pragma unroll 1
@@ -516,17 +619,24 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       constexpr int st = decltype(st_c)::value;
       constexpr int sn = st + 2, cn = sn / 4, khn = sn - cn * 4;
       __builtin_amdgcn_sched_barrier(0);
+      constexpr int SPREAD = S / (MTW * NT);  // the pending tiles leave evenly spread over the k-steps of the item
+      if constexpr (STG && st % SPREAD == 0 && st / SPREAD < MTW * NT) {
+        store_pending(std::integral_constant<int, st / SPREAD>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (sn < S) bq[sn % 3][t] = cur[cn * PLANE + khn * WP + offB[t]];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(bq[st % 3][t], aw[(st / HS) & 1][m][st % HS], acc[m][t]);
+        for (int m = 0; m < MTW; ++m)
+          acc[m][t] = PGV_MFMA4(bq[st % 3][t], WRES ? awr[m][WRES ? st : 0] : aw[(st / HS) & 1][m][WRES ? 0 : st % HS], acc[m][t]);
       }
       {  // the weight of step st + HS (same item, or the first half of the next one) into the other half of the ring
         constexpr int sp = st + HS;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
-          aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp * 4) : wload(m, wn_ + (sp - S) * 4);
+          if constexpr (!WRES)
+            aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp * 4) : wload(m, wn_ + (sp - S) * 4);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -547,6 +657,9 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       const int b = u / BANDS, band = u - b * BANDS;
       const int oh0 = band * R;
       const int Pb = min(R, Hs - oh0) * Ws;  // valid pixels of this band
+      if constexpr (STG)  // [this band of channel 0 of the sample .. end of the tensor)
+        prs = StageLean<CK, G::ROWS, W, WP, H, true>::band_rsrc(out, (int64_t)B * CS * (Hs * Ws) * 4,
+                                                                  ((int64_t)b * CS * Hs + oh0) * Ws);
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         const int cl = (wm * MTW + m) * 16 + ech;
@@ -641,10 +754,14 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
               y0 = f32x2{pgv_act_apply(y0.x, actp), pgv_act_apply(y0.y, actp)};
               y1 = f32x2{pgv_act_apply(y1.x, actp), pgv_act_apply(y1.y, actp)};
             }
+            if constexpr (STG) {
+              pend[m][t] = f32x4{y0.x, y0.y, y1.x, y1.y};
+              if (m == 0) p4[t] = p0 + 4 <= Pb ? (unsigned)p0 * 4u : OOR;
+            }
             if (p0 + 4 <= Pb) {
               f4u o;
               o.x = y0.x, o.y = y0.y, o.z = y1.x, o.w = y1.y;
-              *reinterpret_cast<f4u*>(orow + p0) = o;
+              if constexpr (!STG) *reinterpret_cast<f4u*>(orow + p0) = o;
               ss += y0 + y1;
               if constexpr (FUSE) {
                 const f32x2 mu2 = {mean_r[m], mean_r[m]}, rs2 = {rstd_r[m], rstd_r[m]};
@@ -679,6 +796,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
     ws_barrier();  // everybody is done with buffer (it & 1); buffer (it+1) & 1 is committed
     V2_ACC(2);
   }
+  if constexpr (STG) static_for<0, MTW * NT>([&](auto qc) { store_pending(qc); });  // the last unit
   V2_FLUSH();
   // statistics / projections: ONE float64 atomic per channel per workgroup (256 workgroups finishing together on 2*CS
   // addresses: the atomics serialise at the memory side, ~25 ns each - with one per wave they cost 10-25 us per launch).
@@ -758,6 +876,17 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
     kern = actk == 0 ? PGV_DK(false, false, 0) : (actk == 1 ? PGV_DK(false, false, 1) : PGV_DK(false, false, 2));
 #endif
 #undef PGV_DK
+  // lean loader + deferred stores for the layer where they pay (129x174, one channel chunk); plain / LeakyReLU forms
+  if constexpr (W == 174 && G::NCH == 1) {
+    if (!fuse && actk != 2) {
+      if (in_scale)
+        kern = actk == 1 ? (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 1, true>
+                         : (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 0, true>;
+      else
+        kern = actk == 1 ? (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 1, true>
+                         : (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 0, true>;
+    }
+  }
   if (int rc = raise_lds_once((const void*)kern, "conv_down_v2")) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_v2: memset failed");
@@ -998,11 +1127,19 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   // weight ring (see conv_down_ws_kernel); 4-step halves where the accumulators leave no room for 8-step ones
   constexpr int HS = (S % 16 == 0 && MTW * NT < 28) ? 8 : (S % 8 == 0 ? 4 : S / 2);
   static_assert(S % (2 * HS) == 0, "weight ring");
-  float aw[2][MTW][HS];
+  constexpr bool WRES = STG && NCH == 1;  // weights resident for the whole kernel (see conv_down_ws_kernel)
+  float aw[2][MTW][WRES ? 1 : HS];
+  float awr[WRES ? MTW : 1][WRES ? S : 1];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
+  for (int m = 0; m < MTW; ++m) {
+    if constexpr (WRES) {
 #pragma unroll
-    for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i);
+      for (int i = 0; i < S; ++i) awr[m][i] = wload(m, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < HS; ++i) aw[0][m][i] = wload(m, i);
+    }
+  }
   f32x4 acc[MTW][NT];
   // deferred stores (STG): the previous unit's output tiles, their byte offsets inside the unit (or an out-of-range mark)
   // for the lanes that store 16 / 8 bytes, this lane's channel offsets, and the unit's buffer descriptor
@@ -1022,8 +1159,10 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     const f32x2 lo = {pend[m][t].x, pend[m][t].y};
     const f32x4 all = pend[m][t];
     const i32x4 rs = prs;
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(all), "v"(o4), "s"(rs) : "memory");
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" ::"v"(lo), "v"(o2), "s"(rs) : "memory");
+    // (s_nop: a VALU write to the data registers of a > 8-byte store needs a wait state on gfx9; the compiler's hazard
+    // recognizer cannot see into inline asm - without it some lanes stored the next instruction's result)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(all), "v"(o4), "s"(rs) : "memory");
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(lo), "v"(o2), "s"(rs) : "memory");
   };
   // Epilogue geometry of a FULL band (R grid rows, 2R output rows), per pixel tile of this lane: byte-less offset of the
   // lane's 4 output pixels inside the band of one channel and the number of them that exist (0: tile position beyond the
@@ -1072,13 +1211,14 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       for (int t = 0; t < NT; ++t) {
         if (sn < S) bq[sn % 3][t] = cur[sn * PLANE + offB[t]];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[m][t] = PGV_MFMA4(aw[(st / HS) & 1][m][st % HS], bq[st % 3][t], acc[m][t]);
+        for (int m = 0; m < MTW; ++m)
+          acc[m][t] = PGV_MFMA4(WRES ? awr[m][WRES ? st : 0] : aw[(st / HS) & 1][m][WRES ? 0 : st % HS], bq[st % 3][t], acc[m][t]);
       }
       {
         constexpr int sp = st + HS;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
-          aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp) : wload(m, wn_ + sp - S);
+          if constexpr (!WRES) aw[((st / HS) + 1) & 1][m][st % HS] = sp < S ? wload(m, wc_ + sp) : wload(m, wn_ + sp - S);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
