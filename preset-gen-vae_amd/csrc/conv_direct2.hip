@@ -380,7 +380,9 @@ int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const flo
                         hipStream_t st) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
   if (d->Hb != 257 || d->Wb != 347 || (d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
-  static const int r_env = getenv("PGV_C1_R") ? atoi(getenv("PGV_C1_R")) : 5;
+  // 11 grid rows per unit: since the units of neighbouring bands share an XCD's L2 (pgv_xcd_block) the larger unit no
+  // longer pays for its halo and its longer multiply phase hides more of the next unit's loads (88 -> 83 us)
+  static const int r_env = getenv("PGV_C1_R") ? atoi(getenv("PGV_C1_R")) : 11;
   if (r_env == 5) return launch_up_c1<5>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
   return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
 }
