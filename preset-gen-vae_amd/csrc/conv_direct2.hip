@@ -234,6 +234,22 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
       rq[ps] = qq / QW;
       vqq[ps] = qq - rq[ps] * QW;
     }
+    // FUSE: the saved activation of the quad's CS channels is fetched NOW, ahead of the multiply phase - issued in the
+    // epilogue (as it first was) every unit exposed one memory latency to the whole workgroup: 150 us against 59 us for
+    // the plain kernel, slower than the separate reduce pass the fusion replaces
+    const int64_t cstride = (int64_t)Hs * Ws;
+    f4u avv[FUSE ? NPASS : 1][FUSE ? CS : 1];
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int ow0 = 4 * vqq[ps];
+        const int64_t off = (int64_t)b * CS * cstride + (int64_t)(oh0 + rq[ps]) * Ws + ow0;
+        if (okq[ps] && Ws - ow0 >= 4) {
+#pragma unroll
+          for (int cs = 0; cs < CS; ++cs) avv[ps][cs] = *reinterpret_cast<const f4u*>(fuse.a + off + cs * cstride);
+        }
+      }
+    }
     // accumulators as channel pairs: one v_pk_fma_f32 per input value, tap and channel pair
     f32x2 acc[NPASS][4][CS / 2];
 #pragma unroll
@@ -275,20 +291,12 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
           }
       }
     }
-    const int64_t cstride = (int64_t)Hs * Ws;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       if (!okq[ps]) continue;
       const int ow0 = 4 * vqq[ps];
       const int n = Ws - ow0;  // valid pixels from ow0 on
       const int64_t off = (int64_t)b * CS * cstride + (int64_t)(oh0 + rq[ps]) * Ws + ow0;
-      f4u avv[CS];  // saved activation of all channels first: one memory latency per quad, not one per channel
-      if constexpr (FUSE) {
-        if (n >= 4) {
-#pragma unroll
-          for (int cs = 0; cs < CS; ++cs) avv[cs] = *reinterpret_cast<const f4u*>(fuse.a + off + cs * cstride);
-        }
-      }
 #pragma unroll
       for (int cs = 0; cs < CS; ++cs) {
         float y[4];
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
           t.x = y[0], t.y = y[1], t.z = y[2], t.w = y[3];
           *reinterpret_cast<f4u*>(o) = t;
           if constexpr (FUSE) {
-            const f4u av = avv[cs];
+            const f4u av = avv[ps][cs];
             s1[cs] += (y[0] + y[1]) + (y[2] + y[3]);
             s2[cs] = fmaf(y[0], (av.x - mean_r[cs]) * rstd_r[cs], s2[cs]);
             s2[cs] = fmaf(y[1], (av.y - mean_r[cs]) * rstd_r[cs], s2[cs]);
