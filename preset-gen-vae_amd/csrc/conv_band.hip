@@ -292,6 +292,13 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
       float* out_tile = in_tile;
 #pragma unroll
       for (int m0 = 0; m0 < MT; m0 += EM) {
+        constexpr int BN_IT = (16 * NT * EM * 16 + 255) / 256;
+        f4u bn_av[FUSE ? BN_IT : 1];
+        if constexpr (FUSE) {  // saved activation of this channel group: in flight while the band goes through LDS
+          const int nchf = min(Cs - m0 * 16, EM * 16);
+          const int64_t offf = ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws;
+          bnred_fetch<EM * 16, BN_IT>(fuse.a + offf, (int64_t)Hs * Ws, nchf, Pb, tid, bn_av);
+        }
         __syncthreads();
 #pragma unroll
         for (int mm = 0; mm < EM; ++mm) {
@@ -336,10 +343,8 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
         if (nchn > 0) {
           const int64_t off = ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws;
           if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
-            store_rows_bnred<EM * 16, (16 * NT * EM * 16 + 255) / 256>(out_tile, PS, out + off, fuse.a + off,
-                                                                      (int64_t)Hs * Ws, nchn, Pb, tid,
-                                                                      fuse.mean + m0 * 16, fuse.rstd + m0 * 16,
-                                                                      st_tile + 2 * m0 * 16);
+            store_rows_bnred<EM * 16, BN_IT>(out_tile, PS, out + off, fuse.a + off, (int64_t)Hs * Ws, nchn, Pb, tid,
+                                             fuse.mean + m0 * 16, fuse.rstd + m0 * 16, st_tile + 2 * m0 * 16, bn_av);
           else
             store_rows_contig(out_tile, PS, out + off, (int64_t)Hs * Ws, nchn, Pb, tid);
         }
@@ -935,6 +940,13 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
       float* out_tile = in_tile;
 #pragma unroll
       for (int m0 = 0; m0 < MT; m0 += EM) {
+        constexpr int BN_IT = (OPS / 4 * EM * 4 + 255) / 256;
+        f4u bn_av[FUSE ? BN_IT : 1];
+        if constexpr (FUSE) {  // saved activation of this channel group: in flight while the band goes through LDS
+          const int nchf = min(Cb - m0 * 4, EM * 4);
+          const int64_t offf = (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W;
+          bnred_fetch<EM * 4, BN_IT>(fuse.a + offf, (int64_t)H * W, nchf, rows_o * W, tid, bn_av);
+        }
         __syncthreads();
 #pragma unroll
         for (int mm = 0; mm < EM; ++mm) {
@@ -989,10 +1001,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
         if (nchn > 0) {
           const int64_t off = (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W;
           if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
-            store_rows_bnred<EM * 4, (OPS / 4 * EM * 4 + 255) / 256>(out_tile, OPS, out + off, fuse.a + off,
-                                                                    (int64_t)H * W, nchn, rows_o * W, tid,
-                                                                    fuse.mean + m0 * 4, fuse.rstd + m0 * 4,
-                                                                    st_tile + 2 * m0 * 4);
+            store_rows_bnred<EM * 4, BN_IT>(out_tile, OPS, out + off, fuse.a + off, (int64_t)H * W, nchn, rows_o * W, tid,
+                                            fuse.mean + m0 * 4, fuse.rstd + m0 * 4, st_tile + 2 * m0 * 4, bn_av);
           else
             store_rows_contig(out_tile, OPS, out + off, (int64_t)H * W, nchn, rows_o * W, tid);
         }

@@ -183,11 +183,30 @@ __device__ __forceinline__ void store_rows_contig(const float* __restrict__ tile
 // lanes own one channel row each, read the saved activation `a` at the offsets they store to (all loads issued before
 // the copy loop), and add  sum g  and  sum g*(a-mean)*rstd  of the row into acc[2*c], acc[2*c+1] (LDS, one owner lane
 // per channel: accumulated over all units of a persistent workgroup, flushed once with float64 atomics).
+// The loads of the saved activation, split off so that the caller can issue them BEFORE the band is transposed through
+// LDS (bnred_fetch ... LDS writes ... barrier ... store_rows_bnred): issued inside the store pass every unit exposed one
+// memory latency.
+template <int NCHP, int MAXIT>
+__device__ __forceinline__ void bnred_fetch(const float* __restrict__ a, int64_t cstride, int nch, int len, int tid,
+                                            f4u (&av)[MAXIT]) {
+  constexpr int TPC = 256 / NCHP;
+  const int c = tid / TPC, j = tid - c * TPC;
+  const int Q = len >> 2;
+  const bool cok = c < nch;
+  const float* ap = a + c * cstride;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int q = j + i * TPC;
+    av[i] = (cok && q < Q) ? *reinterpret_cast<const f4u*>(ap + 4 * q) : f4u{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 template <int NCHP, int MAXIT>
 __device__ __forceinline__ void store_rows_bnred(const float* __restrict__ tile, int row_stride, float* __restrict__ dst,
                                                  const float* __restrict__ a, int64_t cstride, int nch, int len,
                                                  int tid, const float* __restrict__ mean,
-                                                 const float* __restrict__ rstd, float* __restrict__ acc) {
+                                                 const float* __restrict__ rstd, float* __restrict__ acc,
+                                                 const f4u (&av)[MAXIT]) {
   constexpr int TPC = 256 / NCHP;
   static_assert(TPC == 8 || TPC == 16 || TPC == 32, "lanes per channel");
   const int c = tid / TPC, j = tid - c * TPC;
@@ -197,12 +216,6 @@ __device__ __forceinline__ void store_rows_bnred(const float* __restrict__ tile,
   const float* ap = a + c * cstride;
   float* dp = dst + c * cstride;
   const float* tp = tile + c * row_stride;
-  f4u av[MAXIT];
-#pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {
-    const int q = j + i * TPC;
-    av[i] = (cok && q < Q) ? *reinterpret_cast<const f4u*>(ap + 4 * q) : f4u{0.f, 0.f, 0.f, 0.f};
-  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXIT; ++i) {
