@@ -143,6 +143,49 @@ def test_band_kernels_many_units(ops, case):
     assert rel_l2(gw2, gw) < 1e-5       # float atomics: run-to-run differences stay at rounding level
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 4, 129, 174), (16, 32, 4, 65, 88), (32, 64, 4, 33, 45), (1, 8, 5, 257, 347)])
+@pytest.mark.parametrize("B", [1, 19, 257])
+def test_conv_products_odd_batches(ops, shape, B):
+    """The persistent kernels (wave-specialised / direct, XCD-aware unit order, deferred stores, per-workgroup partial
+    gradients) at batch sizes that leave workgroups with 0, 1 or an odd number of units, against MIOpen fp32."""
+    Cb, Cs, k, Hb, Wb = shape
+    torch.manual_seed(B)
+    g = ops.ConvGeom(Cb, Cs, k, 2, 2, Hb, Wb)
+    big, small = torch.randn(B, Cb, Hb, Wb, device='cuda'), torch.randn(B, Cs, g.Hs, g.Ws, device='cuda')
+    w = torch.randn(Cs, Cb, k, k, device='cuda') * 0.1
+    bs, bb = torch.randn(Cs, device='cuda'), torch.randn(Cb, device='cuda')
+    sc_b, sh_b = torch.rand(Cb, device='cuda') + 0.5, torch.randn(Cb, device='cuda') * 0.1
+    sc_s, sh_s = torch.rand(Cs, device='cuda') + 0.5, torch.randn(Cs, device='cuda') * 0.1
+
+    def aff(t, sc, sh):
+        return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+
+    st = torch.zeros(2 * Cs, device='cuda', dtype=torch.float64)
+    ref = F.leaky_relu(F.conv2d(aff(big, sc_b, sh_b), w, bs, stride=2, padding=2), 0.1)
+    got = ops.conv_down(g, big, w, bs, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=sc_b, in_shift=sh_b, stats=st)
+    assert rel_l2(got, ref) < 1e-5
+    assert rel_l2(st, torch.cat([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])) < 2e-5
+    assert rel_l2(ops.conv_down(g, big, w, None, ops.PGV_ACT_NONE, 0.0), F.conv2d(big, w, None, stride=2, padding=2)) < 1e-5
+    oph, opw = Hb - ((g.Hs - 1) * 2 - 4 + k), Wb - ((g.Ws - 1) * 2 - 4 + k)
+    ref = F.leaky_relu(F.conv_transpose2d(aff(small, sc_s, sh_s), w, bb, stride=2, padding=2,
+                                          output_padding=(oph, opw)), 0.1)
+    stb = torch.zeros(2 * Cb, device='cuda', dtype=torch.float64)
+    got = ops.conv_up(g, small, w, bb, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=sc_s, in_shift=sh_s, stats=stb)
+    assert rel_l2(got, ref) < 1e-5
+    assert rel_l2(stb, torch.cat([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])) < 2e-5
+    ref = F.conv_transpose2d(small, w, None, stride=2, padding=2, output_padding=(oph, opw))
+    assert rel_l2(ops.conv_up(g, small, w, None, ops.PGV_ACT_NONE, 0.0), ref) < 1e-5
+    gw = torch.empty_like(w)
+    wv = w.clone().requires_grad_(True)
+    F.conv2d(aff(big, sc_b, sh_b), wv, None, stride=2, padding=2).backward(small)
+    ops.conv_wgrad(g, big, small, gw, big_scale=sc_b, big_shift=sh_b)
+    assert rel_l2(gw, wv.grad) < 5e-5
+    wv = w.clone().requires_grad_(True)
+    F.conv2d(big, wv, None, stride=2, padding=2).backward(aff(small, sc_s, sh_s))
+    ops.conv_wgrad(g, big, small, gw, small_scale=sc_s, small_shift=sh_s)
+    assert rel_l2(gw, wv.grad) < 5e-5
+
+
 def _bf16(t):
     return t.float().bfloat16().double()
 
