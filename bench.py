@@ -169,7 +169,10 @@ def launch_table(ae, B, device, frontend=None):
     STFT->mel front-end.  Algorithmic bytes = every operand and result moved once."""
     from preset_gen_vae_amd import ops
     table = []
+    prev_bn = {False: False, True: False}   # does the producer block of the same stack end in a BatchNorm (folded here)?
     for name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up in layer_ops(ae):
+        fold = prev_bn[is_up]
+        prev_bn[is_up] = has_bn
         geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
         big = torch.randn(B, Cb, Hb, Wb, device=device)
         small = torch.randn(B, Cs, geom.Hs, geom.Ws, device=device)
@@ -188,6 +191,9 @@ def launch_table(ae, B, device, frontend=None):
         # plain input-gradient product
         fwd_stats_s = stats_s if (has_bn and not is_up) else None
         fwd_stats_b = stats_b if (has_bn and is_up) else None
+
+        if not fold:   # (first block of a stack, or a producer without BatchNorm: nothing to fold)
+            sc_b = sh_b = sc_s = sh_s = None
 
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
                bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up):
