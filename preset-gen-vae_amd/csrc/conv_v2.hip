@@ -1524,7 +1524,10 @@ struct WgradV2Cfg {
   // half) then fall on disjoint bank ranges of the 32 ds_read_b32 banks
   static constexpr int WP = (W + 2 - 8 + 15) / 16 * 16 + 8;
   static constexpr int WsP = (Ws + 3) / 4 * 4;
-  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP;
+  // small-tile plane stride = an odd number of 16-byte groups: the A fragment reads one pixel of 16 channels per 16
+  // lanes - with the planes back to back (72 / 144 / 264 floats: 8, 16, 8 mod 32) that is a 4- to 8-way bank conflict,
+  // with an odd group count the 16 channels fall on 8 different bank groups (2-way)
+  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP + ((R * WsP / 4) % 2 == 0 ? 4 : 0);
   static constexpr int SPR = WsP / 4;                         // k-steps per output row
   static constexpr int S = R * SPR;
   static constexpr int FRONT = 4;
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
   constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, MT = G::MT, NBW = G::NBW, WP = G::WP, WsP = G::WsP;
   constexpr int PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BUF = G::BUF;
   using StageB = StageLean<CB, G::ROWS_B, W, WP, H>;
-  using StageS = StageLean<CS, R, Ws, WsP, Hs>;
+  using StageS = StageLean<CS, R, Ws, WsP, Hs, false, PLANE_S>;
   constexpr int NPB = StageB::NPF, NPS = StageS::NPF;
   static_assert(NPB + NPS < 64, "vmcnt range");
   // columns >= W / >= Ws (what lies behind the end of a row in its last chunk) are only reached in the last k-step of a row
