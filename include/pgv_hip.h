@@ -100,7 +100,10 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small, const float* i
 
 /* gw[cs][cb][kh][kw] = sum_{b,oh,ow} small'[b,cs,oh,ow] * big'[b,cb,oh*s-p+kh,ow*s-p+kw]
  * (autograd of both layer kinds).  Either operand may carry a folded BN affine.
- * gw is overwritten.  workspace: pgv_conv_wgrad_workspace() bytes. */
+ * gw is overwritten (with PGV_PREZEROED in d->flags: added to).  workspace: pgv_conv_wgrad_workspace() bytes, 16-byte
+ * aligned, private to the call until it has completed on `stream` (the wave-specialised kernels keep one partial
+ * gradient per workgroup / wave there and a second launch adds them up); with a null or smaller workspace the call
+ * falls back to kernels that flush with float atomics. */
 int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d);
 int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                    const float* small, const float* small_scale, const float* small_shift, float* gw,
