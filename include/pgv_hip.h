@@ -12,7 +12,7 @@
  *     allocates (graph-capture safe); scratch comes from caller-provided workspaces;
  *   - return 0 on success, a negative PGV_E_* code otherwise (never throws across the ABI);
  *     pgv_last_error() returns a thread-local message for the last failure;
- *   - re-entrant, no hidden global state.
+ *   - re-entrant; the only process-wide state is the kernel-selection policy (pgv_set_kernel_policy, a test aid).
  *
  * "big"/"small" naming for convolutions: a stride-s convolution maps a big tensor [B,Cb,Hb,Wb] to a small
  * one [B,Cs,Hs,Ws]; its transpose maps small to big.  The weight buffer is always [Cs][Cb][kh][kw], which is
@@ -60,7 +60,8 @@ typedef struct pgv_conv_desc {
 int pgv_abi_version(void);
 const char* pgv_last_error(void);
 /* 0 = prefer tuned kernels (default), 1 = force the generic one-thread-per-output kernels, 2 = tuned kernels but
- * without the shape-specialised band kernels of the reference layer shapes (1 and 2 are test aids). */
+ * without the shape-specialised band kernels of the reference layer shapes, 3 = policy 0 without the wave-specialised
+ * second-generation kernels (1-3 are test / A-B timing aids; process-wide). */
 int pgv_set_kernel_policy(int policy);
 
 /* ---- convolutions (layer.Conv2D / layer.TConv2D bodies, model/layer.py:10-46) -------------------- */
@@ -80,23 +81,62 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scal
                 const float* w, const float* bias, int act, float slope, float* big, double* stats,
                 void* stream);
 
-/* Optional fusion for input-gradient calls: while the output tensor (a gradient g of the activations `a` saved by the
- * next-lower block) is written, also accumulate that block's BatchNorm-backward projections
- *   red[c] += sum g[:,c],   red[C+c] += sum g[:,c] * (a[:,c] - mean[c]) * rstd[c]
- * (what pgv_bn_bwd_reduce would compute in a separate pass over g and a).  red is accumulated into: the caller clears
- * it.  The band kernels do this in their epilogue, every other kernel family runs the reduce pass after the product. */
-typedef struct pgv_bn_fuse {
-  const float* a;    /* same shape as the output tensor */
-  const float* mean; /* [C] */
-  const float* rstd; /* [C] */
-  double* red;       /* [2C] */
-} pgv_bn_fuse;
+/* Optional fusion for input-gradient calls (backward of model/layer.py:21-26 under train.py:246).  The product of the
+ * call is g, the gradient w.r.t. the BatchNorm output o of the next-lower block; with a pgv_bwd_fuse it is never
+ * stored: the epilogue applies that block's BatchNorm + activation backward and writes the gradient w.r.t. its
+ * pre-activation convolution output instead,
+ *     out = g_y = act'(a) * (coef[c] * g + coef[C + c] * a + coef[2C + c]),
+ * and accumulates the block's bias gradient gbias[c] += sum g_y (float atomics; the caller clears gbias).
+ * coef ([3C] floats) comes from pgv_bn_bwd_coef (train-mode BatchNorm), or is (scale, 0, 0) for an eval-mode
+ * BatchNorm and (1, 0, 0) for a block without BatchNorm.  act' is recovered from the saved activated tensor a.
+ * Kernel families without the fused epilogue write g and run pgv_act_bwd_coef in place. */
+typedef struct pgv_bwd_fuse {
+  const float* a;    /* saved activated output of the lower block, same shape as the output tensor */
+  const float* coef; /* [3C] */
+  float* gbias;      /* [C], accumulated into; may be NULL */
+  int32_t act;       /* activation of the lower block (PGV_ACT_*) */
+  float slope;
+  float* cls;        /* optional [C][4]: g_y summed by (row parity, column parity) class, accumulated into - the class
+                        sums pgv_conv_tap_sums wants when g_y is the output gradient of a stride-2 ConvTranspose2d */
+} pgv_bwd_fuse;
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* small, double* stats,
-                        const pgv_bn_fuse* fuse, void* stream);
+                        const pgv_bwd_fuse* fuse, void* stream);
 int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small, const float* in_scale, const float* in_shift,
                       const float* w, const float* bias, int act, float slope, float* big, double* stats,
-                      const pgv_bn_fuse* fuse, void* stream);
+                      const pgv_bwd_fuse* fuse, void* stream);
+
+/* BatchNorm backward of block l WITHOUT a pass over the gradient g of its output o = a*scale + shift: both projections
+ * follow from what block l+1 (the consumer of o; descriptor d, weights w) has already produced.  Since g = W^T gy,
+ *     sum_p g[c,p] * o[c,p] = sum_{c',tap} w * gw        over the weight slice of channel c   (gw = pgv_conv_wgrad of block
+ *                                                          l+1, evaluated with the same folded affine on o), and
+ *     sum_p g[c,p]          = sum_{c',tap} w * T[c'][tap]  with T = pgv_conv_tap_sums of gy, the other wgrad operand.
+ * lower_is_big != 0: o is the big tensor of d (block l+1 is a Conv2d), else the small one (ConvTranspose2d).
+ * Outputs: coef[3C] for pgv_bwd_fuse / pgv_act_bwd_coef with n = B*H*W elements per channel,
+ *     coef[c] = scale, coef[C+c] = -scale*rstd*S2/n, coef[2C+c] = -scale*(S1 - mean*rstd*S2)/n,
+ *     S1 = sum g, S2 = sum g*a_hat = (sum g*o - beta*S1)/gamma  (beta = shift + mean*scale, gamma = scale/rstd),
+ * and the BatchNorm parameter gradients ggamma[c] = S2, gbeta[c] = S1 (either may be NULL).  A channel whose scale is
+ * exactly 0 gets S2 = 0.  flags: PGV_COMPUTE_BF16 = w is read rounded to bfloat16, as the products saw it. */
+int pgv_bn_bwd_coef(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T,
+                    const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
+                    float* coef, float* ggamma, float* gbeta, void* stream);
+/* T[c][kh][kw] = sum over the batch and over the positions of gy[:,c] that kernel tap (kh,kw) pairs with a position
+ * inside the OTHER tensor of d (what a channel of ones there would receive as weight gradient).  gy_is_big != 0: gy is
+ * the big tensor [B,Cb,Hb,Wb] (gradient of a ConvTranspose2d output), else the small one.  T: [C][kh*kw] doubles,
+ * overwritten (flags & PGV_PREZEROED: accumulated into).
+ * cls (may be NULL) = the class sums of gy (pgv_conv_class_sums, or the producer's own: for the small tensor simply the
+ * per-channel sum, i.e. the bias gradient of the block that owns gy): with them only the few border rows and columns of
+ * gy that some tap cannot pair are read, T = class sum - unpaired border positions; without them gy is read in full. */
+int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
+                      void* stream);
+/* cls[c][(r mod m)*m + (w mod m)] = sum over the batch of gy[:,c,r,w], m = stride when gy is the big tensor of d (a tap
+ * of a transposed convolution reaches one residue class of rows / columns), m = 1 (plain channel sums) when it is the
+ * small one.  cls: [C][m*m] floats, overwritten (flags & PGV_PREZEROED: accumulated into). */
+int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, float* cls, int flags, void* stream);
+/* g_y = act'(a) * (coef[c]*g + coef[C+c]*a + coef[2C+c]), gbias[c] += sum g_y: the unfused form of pgv_bwd_fuse
+ * (in place allowed).  gbias may be NULL; flags: PGV_PREZEROED refers to gbias. */
+int pgv_act_bwd_coef(const float* g, const float* a, const float* coef, int B, int C, int HW, int act, float slope,
+                     float* g_y, float* gbias, int flags, void* stream);
 
 /* gw[cs][cb][kh][kw] = sum_{b,oh,ow} small'[b,cs,oh,ow] * big'[b,cb,oh*s-p+kh,ow*s-p+kw]
  * (autograd of both layer kinds).  Either operand may carry a folded BN affine.
@@ -146,6 +186,11 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
  * provides a zeroed scalar).  flags: PGV_PREZEROED refers to gbias. */
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
                       float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream);
+/* The same with the class sums of g_y as a by-product (see pgv_bwd_fuse.cls): planes of W columns, cls [C][4] floats
+ * accumulated into (the caller clears them); single-channel tensors only (the spectrogram output layer). */
+int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int W,
+                          int act, float slope, float* g_y, float* gbias, float* loss_acc, float* cls, int flags,
+                          void* stream);
 
 /* ---- fully-connected (nn.Linear, encoder.py:85, decoder.py:64) ----------------------------------- */
 /* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.

@@ -25,12 +25,14 @@ _P = c_void_p  # device pointers travel as integers
 _DESC = POINTER(ConvDesc)
 
 
-class BnFuse(Structure):
-    """Mirror of ``pgv_bn_fuse``: BatchNorm-backward projections fused into an input-gradient call."""
-    _fields_ = [("a", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("red", c_void_p)]
+class BwdFuse(Structure):
+    """Mirror of ``pgv_bwd_fuse``: BatchNorm + activation backward of the next-lower block fused into an
+    input-gradient call."""
+    _fields_ = [("a", c_void_p), ("coef", c_void_p), ("gbias", c_void_p), ("act", c_int32), ("slope", c_float),
+                ("cls", c_void_p)]
 
 
-_FUSE = POINTER(BnFuse)
+_FUSE = POINTER(BwdFuse)
 
 # name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
@@ -47,6 +49,10 @@ SIGNATURES = {
     "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "pgv_affine_nchw": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pgv_bn_bwd_coef": (c_int, [_DESC, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "pgv_conv_tap_sums": (c_int, [_DESC, c_int, _P, _P, _P, c_int, _P]),
+    "pgv_conv_class_sums": (c_int, [_DESC, c_int, _P, _P, c_int, _P]),
+    "pgv_act_bwd_coef": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
     "pgv_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "pgv_act_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int,
                                _P]),
@@ -54,6 +60,8 @@ SIGNATURES = {
     "pgv_gemm": (c_int, [c_int, c_int, c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int,
                          _P, c_int64, _P]),
     "pgv_sqerr_act_bwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P]),
+    "pgv_sqerr_act_bwd_cls": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P,
+                                      c_int, _P]),
     "pgv_colsum": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, _P]),
     "pgv_dropout_mask": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P]),
     "pgv_dropout_apply": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P, _P]),

@@ -283,6 +283,416 @@ __global__ void act_bn_bwd_kernel(const float* __restrict__ g_o, const float* __
   }
 }
 
+// ---- BatchNorm backward without a pass over the gradient (pgv_bn_bwd_coef / pgv_conv_tap_sums / pgv_act_bwd_coef) -----
+// Does kernel tap k pair row (or column) r of gy with a position inside the other tensor (extent o_ext)?
+//   gy small: the big position is r*s - p + k;   gy big: the small position is (r + p - k) / s when that divides.
+__device__ __forceinline__ bool tap_hits(bool gy_is_big, int r, int k, int s, int p, int o_ext) {
+  if (!gy_is_big) {
+    const int rb = r * s - p + k;
+    return rb >= 0 && rb < o_ext;
+  }
+  const int t = r + p - k;
+  if (t < 0) return false;
+  const int q = t / s;
+  return q * s == t && q < o_ext;
+}
+
+// T[c][kh][kw] += sum over (b in this block's batch range, r, w) of gy[b,c,r,w] * hit(kh, r) * hit(kw, w).
+// A thread keeps a fixed column (W >= 256: columns tid + 256 j; narrower planes: 256 / W rows per pass, the thread's
+// row advances): per element K conditional adds (row masks), the column masks are applied once at the end.
+template <int K, int NJ>
+__global__ __launch_bounds__(256) void tap_sums_kernel(const float* __restrict__ gy, int B, int C, int H, int W, int per,
+                                                       int gy_is_big, int s, int p, int oH, int oW,
+                                                       double* __restrict__ T) {
+  __shared__ unsigned rowm[1024];
+  __shared__ float wsum[4][K * K];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int r = tid; r < H; r += 256) {
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) m |= tap_hits(gy_is_big, r, k, s, p, oH) ? 1u << k : 0u;
+    rowm[r] = m;
+  }
+  __syncthreads();
+  const int RP = NJ == 1 ? max(1, 256 / W) : 1;  // rows per pass
+  const int rs = NJ == 1 ? tid / W : 0;
+  const int w0 = NJ == 1 ? tid - rs * W : tid;
+  const bool active = NJ == 1 ? tid < RP * W : true;
+  unsigned cm[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int w = w0 + 256 * j;
+    cm[j] = 0;
+    if (active && w < W)
+#pragma unroll
+      for (int k = 0; k < K; ++k) cm[j] |= tap_hits(gy_is_big, w, k, s, p, oW) ? 1u << k : 0u;
+  }
+  float acc[NJ][K];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[j][k] = 0.f;
+  if (active) {
+    constexpr int U = 4;  // rows in flight per thread
+    for (int b = b0; b < b1; ++b) {
+      const float* pl = gy + ((int64_t)b * C + c) * H * W;
+      for (int r0 = rs; r0 < H; r0 += RP * U) {
+        float v[U][NJ];
+        unsigned rm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = r0 + u * RP;
+          rm[u] = r < H ? rowm[r] : 0u;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int w = w0 + 256 * j;
+            v[u][j] = (r < H && w < W) ? pl[(int64_t)r * W + w] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[j][k] += (rm[u] >> k) & 1u ? v[u][j] : 0.f;
+      }
+    }
+  }
+  // T[kh][kw] = sum over threads and columns of colmask(kw) * acc[kh]
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += (cm[j] >> kw) & 1u ? acc[j][kh] : 0.f;
+      t = pgv_wave_sum(t);
+      if (lane == 0) wsum[wave][kh * K + kw] = t;
+    }
+  __syncthreads();
+  if (tid < K * K)
+    atomicAdd(&T[(int64_t)c * K * K + tid], (double)wsum[0][tid] + (double)wsum[1][tid] + (double)wsum[2][tid] + (double)wsum[3][tid]);
+}
+
+// Is row (column) r of gy in the residue class that tap k can pair at all?  (gy big: r = q*s - p + k for an integer q;
+// gy small: every row.)  cls index of a position = (r mod s) * s + (w mod s) for gy big, 0 for gy small.
+__device__ __forceinline__ bool tap_in_class(bool gy_is_big, int r, int k, int s, int p) {
+  if (!gy_is_big) return true;
+  const int t = r + p - k;
+  return ((t % s) + s) % s == 0;
+}
+
+// cls[c][(r mod m) * m + (w mod m)] += sum of gy[:, c, r, w]  (m = M: 1 = plain channel sums).  Streaming pass, 16 bytes
+// per lane, one float atomic per class per workgroup.
+template <int M>
+__global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict__ gy, int B, int C, int H, int W, int per,
+                                                         float* __restrict__ cls) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const int nb = b1 - b0;
+  float acc[M * M];
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) acc[i] = 0.f;
+  if (M == 1) {
+    const int HW = H * W, HW4 = HW >> 2;
+    const float inv_hw4 = 1.0f / (float)max(HW4, 1);
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < nb * HW4; e0 += 256 * U) {
+      f4u v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256;
+        const int bi = (int)(((float)e + 0.5f) * inv_hw4), i = e - bi * HW4;   // exact for e < 2^20
+        v[u] = e < nb * HW4 ? *reinterpret_cast<const f4u*>(gy + ((int64_t)(b0 + bi) * C + c) * HW + 4 * i)
+                            : f4u{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[0] += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+    const int T4 = HW - (HW4 << 2);
+    for (int e = threadIdx.x; e < nb * T4; e += 256) {
+      const int bi = e / T4;
+      acc[0] += gy[((int64_t)(b0 + bi) * C + c) * HW + (HW4 << 2) + (e - bi * T4)];
+    }
+  } else {
+    // rows in 16-byte pieces (4-byte aligned): a piece starts at a column that is a multiple of 4, so its elements' column
+    // classes are compile-time; the row class selects the accumulator
+    const int QW = W >> 2, TW = W - (QW << 2);
+    const int rows = nb * H;
+    const float inv_qw = 1.0f / (float)max(QW, 1);
+    float part[M];   // this thread's sums by column class for the row in hand
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < rows * QW; e0 += 256 * U) {
+      f4u v[U];
+      int rr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256;
+        const int row = (int)(((float)e + 0.5f) * inv_qw), q = e - row * QW;   // exact for e < 2^20
+        const int bi = row / H, r = row - bi * H;
+        rr[u] = r % M;
+        v[u] = e < rows * QW ? *reinterpret_cast<const f4u*>(gy + (((int64_t)(b0 + bi) * C + c) * H + r) * W + 4 * q)
+                             : f4u{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < M; ++k) part[k] = 0.f;
+        if (M == 2) {
+          part[0] = vv[0] + vv[2], part[1] = vv[1] + vv[3];
+        } else {
+          // (columns 4q + j: class (4q + j) mod M depends on q - generic, slow path)
+          const int e = e0 + u * 256;
+          const int row = (int)(((float)e + 0.5f) * inv_qw), q = e - row * QW;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < M; ++k) part[k] += ((4 * q + j) % M) == k ? vv[j] : 0.f;
+        }
+#pragma unroll
+        for (int rc = 0; rc < M; ++rc)
+#pragma unroll
+          for (int k = 0; k < M; ++k) acc[rc * M + k] += rr[u] == rc ? part[k] : 0.f;
+      }
+    }
+    for (int e = threadIdx.x; e < rows * TW; e += 256) {   // the last W % 4 columns of every row
+      const int row = e / TW, j = e - row * TW;
+      const int bi = row / H, r = row - bi * H, w = (QW << 2) + j;
+      const float v = gy[(((int64_t)(b0 + bi) * C + c) * H + r) * W + w];
+#pragma unroll
+      for (int i = 0; i < M * M; ++i) acc[i] += ((r % M) * M + (w % M)) == i ? v : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) {
+    const float t = pgv_block_sum(acc[i], red);
+    if (threadIdx.x == 0) atomicAdd(&cls[c * M * M + i], t);
+  }
+}
+
+// T[c][kh][kw] = cls[c][class of the tap] - sum of gy over the positions of that class the tap does NOT pair with a
+// position inside the other tensor.  Those positions lie in a few border rows and columns (the partner index is monotone
+// in the row / column: strips [0, ra) and [H - rb, H), likewise for columns): only they are read.  The strips and their
+// per-tap masks are worked out on the host (TapBorder, a kernel argument).
+// A thread owns border POSITIONS (fixed row / column) and sums them over the planes of its batch range with all loads in
+// flight; the per-position sums go to LDS, and thread (tap, slice) adds up the positions of its slice that its tap cannot
+// pair - no cross-lane reductions (K*K wave reductions through ds_bpermute cost more than everything else here).
+constexpr int kTapStrip = 8;      // border rows / columns per side the fast form handles
+constexpr int kTapChunk = 512;    // border positions per workgroup (grid.z walks the chunks)
+struct TapBorder {
+  int ra, rb, ca, cb;                                     // leading / trailing border rows and columns
+  unsigned short rm[2 * kTapStrip], cm[2 * kTapStrip];   // low byte: in-class bits per tap, high byte: "in class, no partner"
+};
+template <int K>
+__global__ __launch_bounds__(256) void tap_border_kernel(const float* __restrict__ gy, int B, int C, int H, int W, int per,
+                                                         int gy_is_big, int s, int p, TapBorder tb,
+                                                         const float* __restrict__ cls, double* __restrict__ T) {
+  __shared__ float psum[kTapChunk];
+  __shared__ unsigned pmask[kTapChunk];   // row mask | column mask << 16 of the position
+  __shared__ unsigned short rm[2 * kTapStrip], cm[2 * kTapStrip];
+  constexpr int KK = K * K, NSL = 256 / KK;             // slices of positions per tap
+  __shared__ float part[NSL][KK];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  if (tid < 2 * kTapStrip) rm[tid] = tb.rm[tid], cm[tid] = tb.cm[tid];
+  const int ra = tb.ra, ca = tb.ca, nBR = tb.ra + tb.rb, nNR = H - nBR, nBC = tb.ca + tb.cb;
+  const int n1 = nBR * W, NE = n1 + nNR * nBC;
+  const int nb = b1 - b0;
+  const int64_t pstride = (int64_t)C * H * W;
+  const int tap = tid % KK, slice = tid / KK, kh = tap / K, kw = tap - kh * K;
+  // in-class bits of an interior row / column (not in a strip): every tap of the class finds its partner there
+  unsigned ic_all = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) ic_all |= 1u << k;
+  __syncthreads();
+  float tacc = 0.f;   // this thread's tap over its slices of all chunks
+  {
+    const int base = blockIdx.z * kTapChunk;
+    const int n = min(kTapChunk, NE - base);
+    for (int li = tid; li < n; li += 256) {
+      const int i = base + li;
+      int r, w;
+      unsigned mr, mc;
+      if (i < n1) {   // a border row, all columns
+        const int ri = i / W;
+        r = ri < ra ? ri : H - nBR + ri, w = i - ri * W;
+        mr = rm[ri < ra ? ri : kTapStrip + (ri - ra)];
+        const int wi = w < ca ? w : (w >= W - tb.cb ? kTapStrip + (w - (W - tb.cb)) : -1);
+        // interior column: in class for the taps whose residue it has, never unpaired
+        unsigned icc = 0;
+        if (wi < 0) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) icc |= tap_in_class(gy_is_big, w, k, s, p) ? 1u << k : 0u;
+        }
+        mc = wi >= 0 ? cm[wi] : icc;
+      } else {        // a border column of an interior row
+        const int j = i - n1, ri = j / nBC, ci = j - ri * nBC;
+        r = ra + ri, w = ci < ca ? ci : W - nBC + ci;
+        mc = cm[ci < ca ? ci : kTapStrip + (ci - ca)];
+        unsigned icr = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) icr |= tap_in_class(gy_is_big, r, k, s, p) ? 1u << k : 0u;
+        mr = icr;
+      }
+      const float* src = gy + ((int64_t)b0 * C + c) * H * W + (int64_t)r * W + w;
+      float sv = 0.f;
+      int b = 0;
+      for (; b + 8 <= nb; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(b + u) * pstride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv += v[u];
+      }
+      for (; b < nb; ++b) sv += src[b * pstride];
+      psum[li] = sv;
+      pmask[li] = mr | (mc << 16);
+    }
+    __syncthreads();
+    if (slice < NSL) {
+      for (int li = slice; li < n; li += NSL) {
+        const unsigned m = pmask[li];
+        const unsigned icr = m & 255u, bdr = (m >> 8) & 255u, icc = (m >> 16) & 255u, bdc = m >> 24;
+        const bool on = ((icr >> kh) & (icc >> kw) & ((bdr >> kh) | (bdc >> kw)) & 1u) != 0;
+        tacc += on ? psum[li] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  (void)ic_all;
+  if (slice < NSL) part[slice][tap] = tacc;
+  __syncthreads();
+  if (tid < KK) {
+    double t = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) t -= (double)part[sl][tid];
+    if (blockIdx.y == 0 && blockIdx.z == 0) {   // the class total enters once per channel
+      const int m = gy_is_big ? s : 1;
+      const int rho = gy_is_big ? (((kh - p) % s) + s) % s : 0, kap = gy_is_big ? (((kw - p) % s) + s) % s : 0;
+      t += (double)cls[c * m * m + rho * m + kap];
+    }
+    atomicAdd(&T[(int64_t)c * KK + tid], t);
+  }
+}
+
+// host side of TapBorder: masks of one axis; false when a strip is longer than kTapStrip (the caller reads gy in full)
+static bool host_tap_hits(bool gy_is_big, int r, int k, int s, int p, int o_ext) {
+  if (!gy_is_big) {
+    const int rb = r * s - p + k;
+    return rb >= 0 && rb < o_ext;
+  }
+  const int t = r + p - k;
+  if (t < 0) return false;
+  const int q = t / s;
+  return q * s == t && q < o_ext;
+}
+static bool host_tap_in_class(bool gy_is_big, int r, int k, int s, int p) {
+  if (!gy_is_big) return true;
+  const int t = r + p - k;
+  return ((t % s) + s) % s == 0;
+}
+static bool tap_axis(bool gy_is_big, int n, int K, int s, int p, int o_ext, int* lead, int* trail, unsigned short* m) {
+  auto mask = [&](int r) {
+    unsigned ic = 0, bd = 0;
+    for (int k = 0; k < K; ++k) {
+      const bool in = host_tap_in_class(gy_is_big, r, k, s, p);
+      ic |= in ? 1u << k : 0u;
+      bd |= (in && !host_tap_hits(gy_is_big, r, k, s, p, o_ext)) ? 1u << k : 0u;
+    }
+    return (unsigned short)(ic | (bd << 8));
+  };
+  int a = 0;
+  while (a < n && (mask(a) >> 8)) ++a;
+  int b = 0;
+  while (b < n - a && (mask(n - 1 - b) >> 8)) ++b;
+  if (a > kTapStrip || b > kTapStrip) return false;
+  for (int r = a; r < n - b; ++r)
+    if (mask(r) >> 8) return false;   // (cannot happen: the partner index is monotone)
+  for (int i = 0; i < 2 * kTapStrip; ++i) m[i] = 0;
+  for (int i = 0; i < a; ++i) m[i] = mask(i);
+  for (int i = 0; i < b; ++i) m[kTapStrip + i] = mask(n - b + i);
+  *lead = a, *trail = b;
+  return true;
+}
+
+// One workgroup per channel c of the lower block: S_o = sum w*gw and S_1 = sum w*T over the weight slice of c.
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ w, const float* __restrict__ gw,
+                                                          const double* __restrict__ T, int Cb, int Cs, int KK,
+                                                          int lower_is_big, int bf16, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, double inv_n, int C,
+                                                          float* __restrict__ coef, float* __restrict__ ggamma,
+                                                          float* __restrict__ gbeta) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  const int n_other = lower_is_big ? Cs : Cb;
+  const int total = n_other * KK;
+  double so = 0.0, s1 = 0.0;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int co = e / KK, tap = e - co * KK;
+    const int64_t idx = lower_is_big ? ((int64_t)co * Cb + c) * KK + tap : ((int64_t)c * Cb + co) * KK + tap;
+    const double wv = (double)pgv_opnd(w[idx], bf16 != 0);
+    so = fma(wv, (double)gw[idx], so);
+    s1 = fma(wv, T[(int64_t)co * KK + tap], s1);
+  }
+  so = pgv_block_sum_d(so, red);
+  s1 = pgv_block_sum_d(s1, red);
+  if (threadIdx.x == 0) {
+    const double sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    // o = gamma*a_hat + beta:  sum g*a_hat = (sum g*o - beta * sum g) / gamma
+    const double gamma = sc / rs, beta = sh + mu * sc;
+    const double s2 = sc != 0.0 ? (so - beta * s1) / gamma : 0.0;
+    coef[c] = (float)sc;
+    coef[C + c] = (float)(-sc * rs * s2 * inv_n);
+    coef[2 * C + c] = (float)(-sc * (s1 - mu * rs * s2) * inv_n);
+    if (ggamma) ggamma[c] = (float)s2;
+    if (gbeta) gbeta[c] = (float)s1;
+  }
+}
+
+// g_y = act'(a) * (A*g + Bc*a + Cc), gbias += sum g_y: the separate-pass form of pgv_bwd_fuse
+template <int ACT>
+__global__ void act_bwd_coef_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                    const float* __restrict__ coef, int B, int C, int HW, int per, float slope,
+                                    float* __restrict__ g_y, float* __restrict__ gbias) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float ka = coef[c], kb = coef[C + c], kc = coef[2 * C + c];
+  float acc = 0.f;
+  auto one = [&](float gv, float av) -> float {
+    float t = fmaf(gv, ka, fmaf(av, kb, kc));
+    if (ACT == PGV_ACT_LEAKY_RELU)
+      t = av > 0.f ? t : slope * t;
+    else if (ACT == PGV_ACT_HARDTANH)
+      t = (av > -1.f && av < 1.f) ? t : 0.f;
+    return t;
+  };
+  for_each_in_channel2<4>(
+      b0, b1, C, c, HW, g, a,
+      [&](int64_t off, const f4u& gv, const f4u& v) {
+        f4u r;
+        r.x = one(gv.x, v.x);
+        r.y = one(gv.y, v.y);
+        r.z = one(gv.z, v.z);
+        r.w = one(gv.w, v.w);
+        *reinterpret_cast<f4u*>(g_y + off) = r;
+        acc += (r.x + r.y) + (r.z + r.w);
+      },
+      [&](int64_t off) {
+        const float r = one(g[off], a[off]);
+        g_y[off] = r;
+        acc += r;
+      });
+  if (gbias) {
+    const float s = pgv_block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&gbias[c], s);
+  }
+}
+
 // Output block of a decoder under a squared-error criterion, backward in one pass: g = 2 scale g_loss (a - x) is never
 // written - it goes straight through the block's activation backward into g_y, with the bias gradient alongside
 // (replaces pgv_sqerr_bwd + pgv_act_bn_bwd of a block without BatchNorm: 3 passes over the tensor instead of 6).
@@ -391,6 +801,88 @@ __global__ void sqerr_act_bwd_flat_kernel(const float* __restrict__ a, const flo
   }
 }
 
+// The single-channel form with the class sums of g_y as a by-product (pgv_sqerr_act_bwd_cls): the tensor is walked row
+// by row in 16-byte pieces that start at columns 4q, so a piece's column parities are fixed (even, odd, even, odd) and
+// its row parity is one bit; a workgroup owns RPB consecutive rows of the flat [B*H][W] matrix.
+constexpr int kSqRows = 24;
+__global__ __launch_bounds__(256) void sqerr_act_bwd_rows_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                                const float* __restrict__ g_loss, float scale,
+                                                                int nrows, int H, int W, int act, float slope,
+                                                                float* __restrict__ g_y, float* __restrict__ gbias,
+                                                                float* __restrict__ loss_acc, float* __restrict__ cls) {
+  __shared__ float red[16];
+  const float k = 2.0f * scale * g_loss[0];
+  float sq = 0.f, c4[4] = {0.f, 0.f, 0.f, 0.f};   // [2 * row parity + column parity]
+  auto one = [&](float av, float xv) -> float {
+    const float d = av - xv;
+    sq = fmaf(d, d, sq);
+    float g = k * d;
+    if (act == PGV_ACT_LEAKY_RELU)
+      g = av > 0.f ? g : slope * g;
+    else if (act == PGV_ACT_HARDTANH)
+      g = (av > -1.f && av < 1.f) ? g : 0.f;
+    return g;
+  };
+  const int QW = W >> 2, TW = W - (QW << 2);
+  const int row0 = blockIdx.x * kSqRows, rows = min(kSqRows, nrows - row0);
+  const float inv_qw = 1.0f / (float)max(QW, 1), inv_h = 1.0f / (float)H;
+  constexpr int U = 4;
+  for (int e0 = threadIdx.x; e0 < rows * QW; e0 += 256 * U) {
+    f4u av[U], xv[U];
+    int64_t off[U];
+    bool rodd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * 256;
+      const int rl = (int)(((float)e + 0.5f) * inv_qw), q = e - rl * QW;   // exact: e < 2^20
+      const int grow = row0 + rl;
+      const int b = (int)(((float)grow + 0.5f) * inv_h);                   // exact: B*H < 2^20 (checked by the launcher)
+      rodd[u] = (grow - b * H) & 1;
+      off[u] = (int64_t)grow * W + 4 * q;
+      if (e < rows * QW) {
+        av[u] = *reinterpret_cast<const f4u*>(a + off[u]);
+        xv[u] = *reinterpret_cast<const f4u*>(x + off[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * 256 < rows * QW) {
+        f4u r;
+        r.x = one(av[u].x, xv[u].x);
+        r.y = one(av[u].y, xv[u].y);
+        r.z = one(av[u].z, xv[u].z);
+        r.w = one(av[u].w, xv[u].w);
+        *reinterpret_cast<f4u*>(g_y + off[u]) = r;
+        const float ev = r.x + r.z, od = r.y + r.w;
+        c4[0] += rodd[u] ? 0.f : ev, c4[1] += rodd[u] ? 0.f : od, c4[2] += rodd[u] ? ev : 0.f, c4[3] += rodd[u] ? od : 0.f;
+      }
+    }
+  }
+  for (int e = threadIdx.x; e < rows * TW; e += 256) {   // the last W % 4 columns of every row
+    const int rl = e / TW, j = e - rl * TW;
+    const int grow = row0 + rl, w = (QW << 2) + j;
+    const int b = grow / H;
+    const int64_t off = (int64_t)grow * W + w;
+    const float r = one(a[off], x[off]);
+    g_y[off] = r;
+    const int kc = ((grow - b * H) & 1) * 2 + (w & 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c4[q] += kc == q ? r : 0.f;
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float s = pgv_block_sum(c4[q], red);
+    if (threadIdx.x == 0) atomicAdd(&cls[q], s);
+    tot += s;
+  }
+  if (gbias && threadIdx.x == 0) atomicAdd(&gbias[0], tot);
+  if (loss_acc) {
+    const float s = pgv_block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, scale * s);
+  }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ld, float* __restrict__ out) {
   // block: 64 columns x 4 row-groups; rows split over blockIdx.y.
   __shared__ float part[4][64];
@@ -428,13 +920,25 @@ int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipSt
   return PGV_OK;
 }
 
-int pgv_bn_bwd_reduce_impl(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
-                           double* red, hipStream_t st) {
+int pgv_act_bwd_coef_impl(const float* g, const float* a, const float* coef, int B, int C, int HW, int act, float slope,
+                          float* g_y, float* gbias, hipStream_t st) {
   if (B == 0) return PGV_OK;
   Split s = pick_split(B, C, HW);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, mean, rstd, B, C, HW, s.per,
-                     red);
-  PGV_CHECK_LAUNCH("bn_bwd_reduce");
+  typedef void (*kern_t)(const float*, const float*, const float*, int, int, int, int, float, float*, float*);
+  kern_t kern = act == PGV_ACT_LEAKY_RELU ? (kern_t)act_bwd_coef_kernel<PGV_ACT_LEAKY_RELU>
+                                          : (act == PGV_ACT_HARDTANH ? (kern_t)act_bwd_coef_kernel<PGV_ACT_HARDTANH>
+                                                                     : (kern_t)act_bwd_coef_kernel<PGV_ACT_NONE>);
+  hipLaunchKernelGGL(kern, dim3(C, s.nsplit), dim3(256), 0, st, g, a, coef, B, C, HW, s.per, slope, g_y, gbias);
+  PGV_CHECK_LAUNCH("act_bwd_coef");
+  return PGV_OK;
+}
+
+// class sums of a tensor written by a kernel family without that by-product (accumulates into cls[C][4])
+int pgv_class_sums2_impl(const float* gy, int B, int C, int H, int W, float* cls, hipStream_t st) {
+  if (B == 0) return PGV_OK;
+  Split sp = pick_split(B, C, H * W);
+  hipLaunchKernelGGL(class_sums_kernel<2>, dim3(C, sp.nsplit), dim3(256), 0, st, gy, B, C, H, W, sp.per, cls);
+  PGV_CHECK_LAUNCH("conv_class_sums");
   return PGV_OK;
 }
 
@@ -525,6 +1029,106 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
   return PGV_OK;
 }
 
+int pgv_act_bwd_coef(const float* g, const float* a, const float* coef, int B, int C, int HW, int act, float slope,
+                     float* g_y, float* gbias, int flags, void* stream) {
+  PGV_CHECK_ARG(g && a && coef && g_y && B >= 0 && C > 0 && HW > 0, "pgv_act_bwd_coef: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (gbias && !(flags & PGV_PREZEROED)) {
+    int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_act_bwd_coef");
+    if (rc) return rc;
+  }
+  return pgv_act_bwd_coef_impl(g, a, coef, B, C, HW, act, slope, g_y, gbias, st);
+}
+
+int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, float* cls, int flags, void* stream) {
+  PGV_CHECK_ARG(d && gy && cls, "pgv_conv_class_sums: null argument");
+  const int C = gy_is_big ? d->Cb : d->Cs, H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
+  const int m = gy_is_big ? d->stride : 1;
+  PGV_CHECK_ARG(m >= 1 && m <= 3, "pgv_conv_class_sums: stride %d not supported", m);
+  hipStream_t st = pgv_stream(stream);
+  if (!(flags & PGV_PREZEROED)) {
+    int rc = zero_async(cls, sizeof(float) * C * m * m, st, "pgv_conv_class_sums");
+    if (rc) return rc;
+  }
+  if (d->B == 0) return PGV_OK;
+  Split sp = pick_split(d->B, C, H * W);
+  typedef void (*kern_t)(const float*, int, int, int, int, int, float*);
+  kern_t kern = m == 1 ? (kern_t)class_sums_kernel<1> : (m == 2 ? (kern_t)class_sums_kernel<2> : (kern_t)class_sums_kernel<3>);
+  hipLaunchKernelGGL(kern, dim3(C, sp.nsplit), dim3(256), 0, st, gy, d->B, C, H, W, sp.per, cls);
+  PGV_CHECK_LAUNCH("conv_class_sums");
+  return PGV_OK;
+}
+
+int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
+                      void* stream) {
+  PGV_CHECK_ARG(d && gy && T, "pgv_conv_tap_sums: null argument");
+  PGV_CHECK_ARG(d->kh == d->kw && d->kh >= 1 && d->kh <= 5, "pgv_conv_tap_sums: kernel %dx%d not supported", d->kh, d->kw);
+  const int C = gy_is_big ? d->Cb : d->Cs, H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
+  const int oH = gy_is_big ? d->Hs : d->Hb, oW = gy_is_big ? d->Ws : d->Wb;
+  PGV_CHECK_ARG(H <= 1024 && W <= 1024, "pgv_conv_tap_sums: plane %dx%d too large", H, W);
+  hipStream_t st = pgv_stream(stream);
+  const int K = d->kh;
+  if (!(flags & PGV_PREZEROED)) {
+    int rc = zero_async(T, sizeof(double) * C * K * K, st, "pgv_conv_tap_sums");
+    if (rc) return rc;
+  }
+  if (d->B == 0) return PGV_OK;
+  TapBorder tb;
+  if (cls && tap_axis(gy_is_big != 0, H, K, d->stride, d->pad, oH, &tb.ra, &tb.rb, tb.rm) &&
+      tap_axis(gy_is_big != 0, W, K, d->stride, d->pad, oW, &tb.ca, &tb.cb, tb.cm)) {
+    // border form: ~512 workgroups of up to 16 planes x 512 border positions each
+    const int NE = (tb.ra + tb.rb) * W + (H - tb.ra - tb.rb) * (tb.ca + tb.cb);
+    const int nz = (int)max((int64_t)1, pgv_cdiv(NE, kTapChunk));
+    const int per = (int)max((int64_t)1, min((int64_t)16, pgv_cdiv((int64_t)d->B * C * nz, 512)));
+    const int nsplit = (int)pgv_cdiv(d->B, per);
+    typedef void (*kern_t)(const float*, int, int, int, int, int, int, int, int, TapBorder, const float*, double*);
+    kern_t kern = nullptr;
+    switch (K) {
+      case 1: kern = (kern_t)tap_border_kernel<1>; break;
+      case 2: kern = (kern_t)tap_border_kernel<2>; break;
+      case 3: kern = (kern_t)tap_border_kernel<3>; break;
+      case 4: kern = (kern_t)tap_border_kernel<4>; break;
+      default: kern = (kern_t)tap_border_kernel<5>; break;
+    }
+    hipLaunchKernelGGL(kern, dim3(C, nsplit, nz), dim3(256), 0, st, gy, d->B, C, H, W, per, gy_is_big, d->stride, d->pad,
+                       tb, cls, T);
+    PGV_CHECK_LAUNCH("conv_tap_sums (border)");
+    return PGV_OK;
+  }
+  // ~2048 workgroups, at least 64 K elements each (the K*K-value tail reduction is amortised over them)
+  const int64_t want = pgv_cdiv(2048, C), by_work = pgv_cdiv((int64_t)d->B * H * W, 65536);
+  const int ns = (int)max((int64_t)1, min((int64_t)d->B, min(want, by_work)));
+  const int per = (int)pgv_cdiv(d->B, ns), nsplit = (int)pgv_cdiv(d->B, per);
+  const int NJ = (int)pgv_cdiv(W, 256);
+  typedef void (*kern_t)(const float*, int, int, int, int, int, int, int, int, int, int, double*);
+  kern_t kern = nullptr;
+#define PGV_TS(KV)                                                                                      \
+  case KV:                                                                                              \
+    kern = NJ == 1 ? (kern_t)tap_sums_kernel<KV, 1>                                                     \
+                   : (NJ == 2 ? (kern_t)tap_sums_kernel<KV, 2> : (kern_t)tap_sums_kernel<KV, 4>);       \
+    break;
+  switch (K) {
+    PGV_TS(1) PGV_TS(2) PGV_TS(3) PGV_TS(4) PGV_TS(5)
+  }
+#undef PGV_TS
+  hipLaunchKernelGGL(kern, dim3(C, nsplit), dim3(256), 0, st, gy, d->B, C, H, W, per, gy_is_big, d->stride, d->pad, oH,
+                     oW, T);
+  PGV_CHECK_LAUNCH("conv_tap_sums");
+  return PGV_OK;
+}
+
+int pgv_bn_bwd_coef(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T,
+                    const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
+                    float* coef, float* ggamma, float* gbeta, void* stream) {
+  PGV_CHECK_ARG(d && w && gw && T && scale && shift && mean && rstd && coef && n > 0, "pgv_bn_bwd_coef: bad argument");
+  const int C = lower_is_big ? d->Cb : d->Cs;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, pgv_stream(stream), w, gw, T, d->Cb, d->Cs,
+                     d->kh * d->kw, lower_is_big, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0, scale, shift, mean, rstd,
+                     1.0 / (double)n, C, coef, ggamma, gbeta);
+  PGV_CHECK_LAUNCH("bn_bwd_coef");
+  return PGV_OK;
+}
+
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
                       float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream) {
   PGV_CHECK_ARG(a && x && g_loss && g_y && B >= 0 && C > 0 && HW > 0, "pgv_sqerr_act_bwd: bad argument");
@@ -546,6 +1150,25 @@ int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float
   hipLaunchKernelGGL(sqerr_act_bwd_kernel, dim3(C, s.nsplit), dim3(256), 0, st, a, x, g_loss, scale, B, C, HW, s.per,
                      act, slope, g_y, gbias, loss_acc);
   PGV_CHECK_LAUNCH("sqerr_act_bwd");
+  return PGV_OK;
+}
+
+int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int W,
+                          int act, float slope, float* g_y, float* gbias, float* loss_acc, float* cls, int flags,
+                          void* stream) {
+  PGV_CHECK_ARG(a && x && g_loss && g_y && cls && B >= 0 && C == 1 && HW > 0 && W > 0 && HW % W == 0 && HW < (1 << 20),
+                "pgv_sqerr_act_bwd_cls: bad argument (single-channel planes of fewer than 2^20 elements only)");
+  hipStream_t st = pgv_stream(stream);
+  if (gbias && !(flags & PGV_PREZEROED)) {
+    int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_sqerr_act_bwd_cls");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  const int H = HW / W, nrows = B * H;
+  PGV_CHECK_ARG((int64_t)B * H < (1 << 20) && kSqRows * (W / 4 + 1) < (1 << 20), "pgv_sqerr_act_bwd_cls: tensor too large");
+  hipLaunchKernelGGL(sqerr_act_bwd_rows_kernel, dim3((unsigned)pgv_cdiv(nrows, kSqRows)), dim3(256), 0, st, a, x, g_loss,
+                     scale, nrows, H, W, act, slope, g_y, gbias, loss_acc, cls);
+  PGV_CHECK_LAUNCH("sqerr_act_bwd_cls");
   return PGV_OK;
 }
 

@@ -31,7 +31,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 6; }
+int pgv_abi_version(void) { return 7; }
 const char* pgv_last_error(void) { return g_err; }
 static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {
@@ -41,14 +41,15 @@ int pgv_set_kernel_policy(int policy) {
   return PGV_OK;
 }
 
-static int check_fuse(const pgv_bn_fuse* f, const char* who) {
-  PGV_CHECK_ARG(f == nullptr || (f->a && f->mean && f->rstd && f->red), "%s: incomplete pgv_bn_fuse", who);
+static int check_fuse(const pgv_bwd_fuse* f, const char* who) {
+  PGV_CHECK_ARG(f == nullptr || (f->a && f->coef), "%s: incomplete pgv_bwd_fuse", who);
+  PGV_CHECK_ARG(f == nullptr || (f->act >= PGV_ACT_NONE && f->act <= PGV_ACT_HARDTANH), "%s: pgv_bwd_fuse: bad activation", who);
   return PGV_OK;
 }
 
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                        const pgv_bn_fuse* fuse, void* stream) {
+                        const pgv_bwd_fuse* fuse, void* stream) {
   int rc = check_desc(d, "pgv_conv_down");
   if (rc) return rc;
   if ((rc = check_fuse(fuse, "pgv_conv_down"))) return rc;
@@ -56,25 +57,26 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
   PGV_CHECK_ARG(big && w && small_out, "pgv_conv_down: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_down: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
-  bool fused = false;
+  bool fused = false, cls_done = false;
   rc = 0;
   if (g_policy != 1) {
     if (g_policy == 0 && !g_no_v2) {
-      static const int fuse_c1 = getenv("PGV_FUSE_C1") ? atoi(getenv("PGV_FUSE_C1")) : 1;
-      const pgv_bn_fuse* f = (stats || !fuse_c1) ? nullptr : fuse;
+      const pgv_bwd_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_down_direct2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
-      fused = rc == 1 && f != nullptr;
+      fused = rc >= 1 && f != nullptr;
+      if (rc == 3) cls_done = true, rc = 1;
     }
     if (rc == 0) rc = pgv_conv_down_direct(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, st);
     if (rc == 0 && g_policy == 0 && !g_no_v2) {
-      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      const pgv_bwd_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_down_v2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
       fused = rc == 1 && f != nullptr;
     }
     if (rc == 0 && g_policy == 0) {
-      const pgv_bn_fuse* f = stats ? nullptr : fuse;  // the band epilogue has one reduction slot
+      const pgv_bwd_fuse* f = stats ? nullptr : fuse;  // the band epilogue has one reduction slot
       rc = pgv_conv_down_band(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
-      fused = rc == 1 && f != nullptr;
+      fused = rc >= 1 && f != nullptr;
+      if (rc == 3) cls_done = true, rc = 1;
       if (rc == 0 && f)  // shape covered, fused epilogue not instantiated for it: plain band kernel + reduce pass
         rc = pgv_conv_down_band(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, nullptr, st);
     }
@@ -90,8 +92,11 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
     if (rc) return rc;
     if (stats && (rc = pgv_bn_stats_impl(small_out, d->B, d->Cs, d->Hs * d->Ws, stats, st))) return rc;
   }
-  if (fuse && !fused)
-    return pgv_bn_bwd_reduce_impl(small_out, fuse->a, fuse->mean, fuse->rstd, d->B, d->Cs, d->Hs * d->Ws, fuse->red, st);
+  if (fuse && !fused &&
+      (rc = pgv_act_bwd_coef_impl(small_out, fuse->a, fuse->coef, d->B, d->Cs, d->Hs * d->Ws, fuse->act, fuse->slope,
+                                  small_out, fuse->gbias, st)))
+    return rc;
+  if (fuse && fuse->cls && !cls_done) return pgv_class_sums2_impl(small_out, d->B, d->Cs, d->Hs, d->Ws, fuse->cls, st);
   return PGV_OK;
 }
 
@@ -103,7 +108,7 @@ int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scal
 
 int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                       const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                      const pgv_bn_fuse* fuse, void* stream) {
+                      const pgv_bwd_fuse* fuse, void* stream) {
   int rc = check_desc(d, "pgv_conv_up");
   if (rc) return rc;
   if ((rc = check_fuse(fuse, "pgv_conv_up"))) return rc;
@@ -111,20 +116,20 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
   PGV_CHECK_ARG(small_in && w && big_out, "pgv_conv_up: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
-  bool fused = false;
+  bool fused = false, cls_done = false;
   rc = 0;
   if (g_policy != 1) {
     if (g_policy == 0 && !g_no_v2)
       rc = pgv_conv_up_direct2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0) rc = pgv_conv_up_direct(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, st);
     if (rc == 0 && g_policy == 0 && !g_no_v2) {
-      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      const pgv_bwd_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_up_v2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, f, st);
       fused = rc == 1 && f != nullptr;
       if (rc == 2) rc = 1;  // handled, projections left to the reduce pass below
     }
     if (rc == 0 && g_policy == 0) {
-      const pgv_bn_fuse* f = stats ? nullptr : fuse;
+      const pgv_bwd_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_up_band(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, f, st);
       fused = rc == 1 && f != nullptr;
       if (rc == 0 && f)
@@ -142,8 +147,11 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
     if (rc) return rc;
     if (stats && (rc = pgv_bn_stats_impl(big_out, d->B, d->Cb, d->Hb * d->Wb, stats, st))) return rc;
   }
-  if (fuse && !fused)
-    return pgv_bn_bwd_reduce_impl(big_out, fuse->a, fuse->mean, fuse->rstd, d->B, d->Cb, d->Hb * d->Wb, fuse->red, st);
+  if (fuse && !fused &&
+      (rc = pgv_act_bwd_coef_impl(big_out, fuse->a, fuse->coef, d->B, d->Cb, d->Hb * d->Wb, fuse->act, fuse->slope,
+                                  big_out, fuse->gbias, st)))
+    return rc;
+  if (fuse && fuse->cls && !cls_done) return pgv_class_sums2_impl(big_out, d->B, d->Cb, d->Hb, d->Wb, fuse->cls, st);
   return PGV_OK;
 }
 

@@ -80,14 +80,14 @@ struct DownCfg {
   static_assert((KC * MT * 16) % 1024 == 0, "weight chunk must split into whole 16-byte loads per lane");
 };
 
-template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool FUSE, bool BF16>
+template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool FUSE, bool BF16, bool CLS = false>
 __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, int Cs, const float* __restrict__ big,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift,
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ bias, int act, float slope,
                                                               float* __restrict__ out, double* __restrict__ stats,
-                                                              pgv_bn_fuse fuse) {
+                                                              pgv_bwd_fuse fuse) {
   using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
   constexpr int KS = 4, Ws = G::Ws, Hs = G::Hs, WP = G::WP, PLANE = G::PLANE, CSP = G::CSP, KC = G::KC;
   constexpr int PS = G::PS, EM = G::EM, BANDS = G::BANDS;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
   for (int i = tid; i < 4 * MT * 16 * 2; i += 256) st_tile[i] = 0.f;
   stage_affine(aff, in_scale, in_shift, Cb, tid);  // visible after the first barrier of the item loop
   const pgv_act_params actp = pgv_act_setup(act, slope);
+  const pgv_actd_params actd = pgv_actd_setup(FUSE ? fuse.act : 0, FUSE ? fuse.slope : 0.f);
 
   // weights: 16-byte loads of 4 consecutive k = (c, kh, kw0..3) of one output channel, transposed to [k][cs] in LDS.
   // WRES: every chunk is staged once per workgroup; otherwise the chunk of the next item is prefetched into
@@ -342,9 +343,10 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
         const int nchn = min(Cs - m0 * 16, EM * 16);
         if (nchn > 0) {
           const int64_t off = ((int64_t)b * Cs + m0 * 16) * Hs * Ws + (int64_t)oh0 * Ws;
-          if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
-            store_rows_bnred<EM * 16, BN_IT>(out_tile, PS, out + off, fuse.a + off, (int64_t)Hs * Ws, nchn, Pb, tid,
-                                             fuse.mean + m0 * 16, fuse.rstd + m0 * 16, st_tile + 2 * m0 * 16, bn_av);
+          if constexpr (FUSE)  // BatchNorm + activation backward of the lower block on the way out (pgv_bwd_fuse)
+            store_rows_bwd<EM * 16, BN_IT, CLS ? Ws : 0>(out_tile, PS, out + off, fuse.a + off, (int64_t)Hs * Ws, nchn, Pb, tid,
+                                                         fuse.coef + m0 * 16, Cs, actd, st_tile + (CLS ? 4 : 1) * m0 * 16,
+                                                         bn_av, oh0);
           else
             store_rows_contig(out_tile, PS, out + off, (int64_t)Hs * Ws, nchn, Pb, tid);
         }
@@ -383,11 +385,22 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
       atomicAdd(&stats[Cs + tid], qq);
     }
   }
-  if constexpr (FUSE) {  // (never together with stats: the launcher falls back to a separate reduce pass then)
+  if constexpr (FUSE) {  // (never together with stats: the launcher falls back to a separate pass then)
     __syncthreads();
-    if (tid < MT * 16 && tid < Cs) {
-      atomicAdd(&fuse.red[tid], (double)st_tile[2 * tid]);
-      atomicAdd(&fuse.red[Cs + tid], (double)st_tile[2 * tid + 1]);
+    if constexpr (CLS) {   // class sums (pgv_bwd_fuse.cls) and, from them, the bias gradient
+      static_assert(Ws % 4 == 0, "class sums");
+      if (tid < MT * 16 && tid < Cs) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = st_tile[4 * tid + k];
+          atomicAdd(&fuse.cls[4 * tid + k], v);
+          t += v;
+        }
+        if (fuse.gbias) atomicAdd(&fuse.gbias[tid], t);
+      }
+    } else {
+      if (fuse.gbias && tid < MT * 16 && tid < Cs) atomicAdd(&fuse.gbias[tid], st_tile[tid]);
     }
   }
   BAND_FLUSH();
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
 template <int MT, int NT, int CK, int NCH, bool WRES, int R, int W, int H, bool CANFUSE>
 int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                     const pgv_bn_fuse* fuse, hipStream_t st) {
+                     const pgv_bwd_fuse* fuse, hipStream_t st) {
   using G = DownCfg<MT, NT, CK, NCH, WRES, R, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -432,7 +445,19 @@ int launch_down_band(const pgv_conv_desc* d, const float* big, const float* in_s
   if (getenv("PGV_WG_PER_CU")) per_cu = atoi(getenv("PGV_WG_PER_CU"));
 #endif
   const int grid = min(units, 256 * per_cu);
-  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
+  // class sums of the written tensor (pgv_bwd_fuse.cls) ride in the store pass where its rows are whole 16-byte pieces
+  if constexpr (CANFUSE && G::Ws % 4 == 0) {
+    if (fuse && fuse->cls && !bf16) {
+      auto kernc = conv_down_band_kernel<MT, NT, CK, NCH, WRES, R, W, H, CANFUSE, false, true>;
+      static bool attr_done_c = false;
+      if ((rc = raise_lds_limit(kernc, &attr_done_c, "conv_down_band"))) return rc;
+      hipLaunchKernelGGL(kernc, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, in_scale, in_shift, w, bias,
+                         act, slope, out, stats, *fuse);
+      PGV_CHECK_LAUNCH("conv_down_band");
+      return 3;   // handled, class sums included
+    }
+  }
   hipLaunchKernelGGL(bf16 ? (fuse ? kernfb : kernb) : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B,
                      d->Cb, d->Cs, big,
                      in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
@@ -745,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias, int act, float slope,
                                                             float* __restrict__ out, double* __restrict__ stats,
-                                                            pgv_bn_fuse fuse) {
+                                                            pgv_bwd_fuse fuse) {
   using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, WsP = G::WsP, PLANE = G::PLANE, MSP = G::MSP;
   constexpr int KC = G::KC, OPS = G::OPS, BANDS = G::BANDS;
@@ -776,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
   for (int i = tid; i < 4 * MT * 4 * 2; i += 256) st_tile[i] = 0.f;
   stage_affine(aff, in_scale, in_shift, Cs, tid);  // visible after the first barrier of the item loop
   const pgv_act_params actp = pgv_act_setup(act, slope);
+  const pgv_actd_params actd = pgv_actd_setup(FUSE ? fuse.act : 0, FUSE ? fuse.slope : 0.f);
 
   // weights: 16-byte loads of one kernel row (cs, cb, kh, kw0..3), scattered to [k = (c, th, tw)][m = (cb, ph, pw)]
   constexpr int NWQ = G::NWQ;
@@ -1000,9 +1026,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
         const int nchn = min(Cb - m0 * 4, EM * 4);
         if (nchn > 0) {
           const int64_t off = (((int64_t)b * Cb + m0 * 4) * H + 2 * u0) * W;
-          if constexpr (FUSE)  // BatchNorm-backward projections of this band against the saved activation
-            store_rows_bnred<EM * 4, BN_IT>(out_tile, OPS, out + off, fuse.a + off, (int64_t)H * W, nchn, rows_o * W, tid,
-                                            fuse.mean + m0 * 4, fuse.rstd + m0 * 4, st_tile + 2 * m0 * 4, bn_av);
+          if constexpr (FUSE)  // BatchNorm + activation backward of the lower block on the way out (pgv_bwd_fuse)
+            store_rows_bwd<EM * 4, BN_IT>(out_tile, OPS, out + off, fuse.a + off, (int64_t)H * W, nchn, rows_o * W, tid,
+                                          fuse.coef + m0 * 4, Cb, actd, st_tile + m0 * 4, bn_av);
           else
             store_rows_contig(out_tile, OPS, out + off, (int64_t)H * W, nchn, rows_o * W, tid);
         }
@@ -1038,10 +1064,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
   }
   if constexpr (FUSE) {
     __syncthreads();
-    if (tid < MT * 4 && tid < Cb) {
-      atomicAdd(&fuse.red[tid], (double)st_tile[2 * tid]);
-      atomicAdd(&fuse.red[Cb + tid], (double)st_tile[2 * tid + 1]);
-    }
+    if (fuse.gbias && tid < MT * 4 && tid < Cb) atomicAdd(&fuse.gbias[tid], st_tile[tid]);
   }
   BAND_FLUSH();
 }
@@ -1049,7 +1072,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
 template <int MT, int NT, int CK, int NCH, bool WRES, int EM, int R, int W, int H, bool CANFUSE>
 int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                   const pgv_bn_fuse* fuse, hipStream_t st) {
+                   const pgv_bwd_fuse* fuse, hipStream_t st) {
   using G = UpCfg<MT, NT, CK, NCH, WRES, EM, R, W, H>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -1080,7 +1103,7 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
   const int units = d->B * G::BANDS;
   int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
   const int grid = min(units, 256 * per_cu);
-  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(bf16 ? (fuse ? kernfb : kernb) : (fuse ? kernf : kern), dim3(grid), dim3(256), bytes, st, d->B,
                      d->Cb, d->Cs, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_up_band");
@@ -1091,7 +1114,7 @@ int launch_up_band(const pgv_conv_desc* d, const float* small_in, const float* i
 
 int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                       const pgv_bn_fuse* fuse, hipStream_t st) {
+                       const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || d->Cb > 64) return 0;
   if (d->Hb == 129 && d->Wb == 174 && d->Cs <= 16)
     return launch_down_band<1, 6, 8, 1, true, 4, 174, 129, true>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
@@ -1119,7 +1142,7 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
 
 int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                     const pgv_bn_fuse* fuse, hipStream_t st) {
+                     const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->Hb == 129 && d->Wb == 174)
     return launch_up_band<2, 7, 16, 1, true, 2, 5, 174, 129, true>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);  // 65 grid rows = 13 x 5

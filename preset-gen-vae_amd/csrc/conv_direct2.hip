@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
 
 // ---- DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{kh,kw} x'[b,0,2oh-2+kh,2ow-2+kw] * w[cs,0,kh,kw]) ------------------
 // A lane owns output pixels ow0 .. ow0+3 of one output row, all CS channels.  FUSE: BatchNorm-backward projections of
-// the written tensor against the saved activation `a` (pgv_bn_fuse), one float64 atomic per channel per workgroup.
+// the written tensor against the saved activation `a` (pgv_bwd_fuse), one float64 atomic per channel per workgroup.
 template <int CS, int H, int W, int R>
 struct DownC1Cfg {
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1;
   static constexpr int WP = (W + 2 + 3) / 4 * 4, ROWS = 2 * (R - 1) + K5;
   static constexpr int QW = (Ws + 3) / 4, BANDS = (Hs + R - 1) / R;
   static constexpr int FRONT = 4;
-  static constexpr size_t LDS_FLOATS = FRONT + (size_t)ROWS * WP + 16 + 4 + 4 * 2 * CS + 8 + K5 * CS * 8;
+  static constexpr size_t LDS_FLOATS = FRONT + (size_t)ROWS * WP + 16 + 4 + 4 * 4 * CS + 8 + K5 * CS * 8;
 };
 
 template <int CS, int H, int W, int R, bool FUSE>
@@ -179,14 +179,14 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          pgv_bn_fuse fuse) {
+                                                          pgv_bwd_fuse fuse) {
   using G = DownC1Cfg<CS, H, W, R>;
   constexpr int Hs = G::Hs, Ws = G::Ws, WP = G::WP, QW = G::QW, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile = lds + G::FRONT;
   float* aff = tile + G::ROWS * WP + 16;  // [2] (+2 pad)
-  float* red = aff + 4;                   // [4 waves][2*CS]
-  float* wl = lds + ((red + 4 * 2 * CS - lds) + 3) / 4 * 4;  // [kh][kw][cs], 16-byte aligned
+  float* red = aff + 4;                   // [4 waves][4*CS]
+  float* wl = lds + ((red + 4 * 4 * CS - lds) + 3) / 4 * 4;  // [kh][kw][cs], 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < G::FRONT) lds[tid] = 0.f;
   if (tid < 16) tile[G::ROWS * WP + tid] = 0.f;
@@ -199,13 +199,18 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
     aff[1] = in_shift[0];
   }
   const pgv_act_params actp = pgv_act_setup(act, slope);
-  float bias_r[CS], mean_r[CS], rstd_r[CS], s1[CS], s2[CS];
+  // FUSE (pgv_bwd_fuse): the lower block's BatchNorm + activation backward, g_y = act'(a) * (ka*g + kb*a + kc)
+  const pgv_actd_params actd = pgv_actd_setup(FUSE ? fuse.act : 0, FUSE ? fuse.slope : 0.f);
+  // s1: sums of g_y over this lane's even / odd output columns (its row parity is a constant of the kernel, see below);
+  // by (row parity, column parity) class they are pgv_bwd_fuse.cls, their total is the bias gradient
+  float bias_r[CS], ka_r[CS], kb_r[CS], kc_r[CS], s1[CS][2];
 #pragma unroll
   for (int cs = 0; cs < CS; ++cs) {
     bias_r[cs] = bias ? bias[cs] : 0.f;
-    mean_r[cs] = FUSE ? fuse.mean[cs] : 0.f;
-    rstd_r[cs] = FUSE ? fuse.rstd[cs] : 0.f;
-    s1[cs] = s2[cs] = 0.f;
+    ka_r[cs] = FUSE ? fuse.coef[cs] : 0.f;
+    kb_r[cs] = FUSE ? fuse.coef[CS + cs] : 0.f;
+    kc_r[cs] = FUSE ? fuse.coef[2 * CS + cs] : 0.f;
+    s1[cs][0] = s1[cs][1] = 0.f;
   }
   const int units = B * BANDS;
   typename PickPrefetch<1, G::ROWS, W, WP, H>::type pf;  // (see up_c1_v2_kernel)
@@ -304,47 +309,56 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
         for (int j = 0; j < 4; ++j) y[j] = pgv_act_apply(acc[ps][j][cs >> 1][cs & 1], actp);
         float* o = out + off + cs * cstride;
         if (n >= 4) {
+          if constexpr (FUSE) {
+            const f4u av = avv[ps][cs];
+            y[0] = pgv_bwd_apply(y[0], av.x, ka_r[cs], kb_r[cs], kc_r[cs], actd);
+            y[1] = pgv_bwd_apply(y[1], av.y, ka_r[cs], kb_r[cs], kc_r[cs], actd);
+            y[2] = pgv_bwd_apply(y[2], av.z, ka_r[cs], kb_r[cs], kc_r[cs], actd);
+            y[3] = pgv_bwd_apply(y[3], av.w, ka_r[cs], kb_r[cs], kc_r[cs], actd);
+            s1[cs][0] += y[0] + y[2], s1[cs][1] += y[1] + y[3];   // ow0 is a multiple of 4: even / odd columns
+          }
           f4u t;
           t.x = y[0], t.y = y[1], t.z = y[2], t.w = y[3];
           *reinterpret_cast<f4u*>(o) = t;
-          if constexpr (FUSE) {
-            const f4u av = avv[ps][cs];
-            s1[cs] += (y[0] + y[1]) + (y[2] + y[3]);
-            s2[cs] = fmaf(y[0], (av.x - mean_r[cs]) * rstd_r[cs], s2[cs]);
-            s2[cs] = fmaf(y[1], (av.y - mean_r[cs]) * rstd_r[cs], s2[cs]);
-            s2[cs] = fmaf(y[2], (av.z - mean_r[cs]) * rstd_r[cs], s2[cs]);
-            s2[cs] = fmaf(y[3], (av.w - mean_r[cs]) * rstd_r[cs], s2[cs]);
-          }
         } else {
 #pragma unroll
           for (int j = 0; j < 3; ++j)
             if (j < n) {
-              o[j] = y[j];
+              float yy = y[j];
               if constexpr (FUSE) {
-                s1[cs] += y[j];
-                s2[cs] = fmaf(y[j], (fuse.a[off + cs * cstride + j] - mean_r[cs]) * rstd_r[cs], s2[cs]);
+                yy = pgv_bwd_apply(yy, fuse.a[off + cs * cstride + j], ka_r[cs], kb_r[cs], kc_r[cs], actd);
+                s1[cs][j & 1] += yy;
               }
+              o[j] = yy;
             }
         }
       }
     }
   }
-  if constexpr (FUSE) {
+  if constexpr (FUSE) {  // class sums / bias gradient of the lower block: one float atomic per value per workgroup
     __syncthreads();
+    // Row parity of this lane's output row: a unit is R rows of a sample, units are walked bid, bid + grid, ...; with an
+    // even number of bands per sample and an even grid (or one unit per workgroup) the parity of the band index is the
+    // parity of bid, and the lane's row inside the band (rq = tid / QW) never changes - one quad per lane (NPASS = 1).
+    static_assert(R * QW <= 256 && BANDS % 2 == 0, "constant row parity per lane");
+    const bool rodd = ((R & 1 ? bid : 0) + tid / QW) & 1;
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
-      const float a = pgv_wave_sum(s1[cs]), c = pgv_wave_sum(s2[cs]);
-      if (lane == 0) {
-        red[wave * 2 * CS + cs] = a;
-        red[wave * 2 * CS + CS + cs] = c;
+    for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = pgv_wave_sum(((k >> 1) != 0) == rodd ? s1[cs][k & 1] : 0.f);
+        if (lane == 0) red[wave * 4 * CS + 4 * cs + k] = a;
       }
-    }
     __syncthreads();
-    if (tid < 2 * CS) {
-      double t = 0.0;
+    if (tid < 4 * CS) {
+      float t = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) t += (double)red[wv * 2 * CS + tid];
-      atomicAdd(&fuse.red[tid], t);
+      for (int wv = 0; wv < 4; ++wv) t += red[wv * 4 * CS + tid];
+      if (fuse.cls) atomicAdd(&fuse.cls[tid], t);
+      // bias gradient = the four classes of a channel added up (lanes 4cs .. 4cs+3)
+      t += dpp_mov<0xB1>(t);
+      t += dpp_mov<0x4E>(t);
+      if (fuse.gbias && (tid & 3) == 0) atomicAdd(&fuse.gbias[tid >> 2], t);
     }
   }
 }
@@ -390,14 +404,12 @@ int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const flo
   if (d->Hb != 257 || d->Wb != 347 || (d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
   // 11 grid rows per unit: since the units of neighbouring bands share an XCD's L2 (pgv_xcd_block) the larger unit no
   // longer pays for its halo and its longer multiply phase hides more of the next unit's loads (88 -> 83 us)
-  static const int r_env = getenv("PGV_C1_R") ? atoi(getenv("PGV_C1_R")) : 11;
-  if (r_env == 5) return launch_up_c1<5>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
   return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
 }
 
 template <int R>
 static int launch_down_c1(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
-                          const float* w, const float* bias, int act, float slope, float* out, const pgv_bn_fuse* fuse,
+                          const float* w, const float* bias, int act, float slope, float* out, const pgv_bwd_fuse* fuse,
                           hipStream_t st) {
   using G = DownC1Cfg<8, 257, 347, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
@@ -405,12 +417,14 @@ static int launch_down_c1(const pgv_conv_desc* d, const float* big, const float*
   const int units = d->B * G::BANDS;
   const int per_cu = (int)min((size_t)4, (size_t)kMaxLds / bytes);
   const int grid = min(units, 256 * per_cu);
-  const pgv_bn_fuse fz = {nullptr, nullptr, nullptr, nullptr};
+  const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   if (fuse) {
     auto kern = down_c1_v2_kernel<8, 257, 347, R, true>;
     if (int rc = raise_lds(kern, "conv_down_direct2")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, big, in_scale, in_shift, w, bias, act, slope, out,
                        *fuse);
+    PGV_CHECK_LAUNCH("conv_down_direct2");
+    return fuse->cls ? 3 : 1;   // (3: handled, class sums included)
   } else {
     auto kern = down_c1_v2_kernel<8, 257, 347, R, false>;
     if (int rc = raise_lds(kern, "conv_down_direct2")) return rc;
@@ -423,10 +437,8 @@ static int launch_down_c1(const pgv_conv_desc* d, const float* big, const float*
 
 int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                           const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                          const pgv_bn_fuse* fuse, hipStream_t st) {
+                          const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
   if (d->Hb != 257 || d->Wb != 347 || (d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
-  static const int r_env = getenv("PGV_C1_R") ? atoi(getenv("PGV_C1_R")) : 5;
-  if (r_env == 5) return launch_down_c1<5>(d, big, in_scale, in_shift, w, bias, act, slope, out, fuse, st);
-  return launch_down_c1<11>(d, big, in_scale, in_shift, w, bias, act, slope, out, fuse, st);
+  return launch_down_c1<5>(d, big, in_scale, in_shift, w, bias, act, slope, out, fuse, st);
 }

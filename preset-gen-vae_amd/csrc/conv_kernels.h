@@ -28,11 +28,11 @@ int64_t pgv_conv_wgrad_tuned_workspace(const pgv_conv_desc* d);
 // Shape-specialised band kernels (conv_band.hip): compile-time tile geometry for the reference layer shapes.
 int pgv_conv_down_band(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                       const pgv_bn_fuse* fuse, hipStream_t st);
+                       const pgv_bwd_fuse* fuse, hipStream_t st);
 
 int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                     const pgv_bn_fuse* fuse, hipStream_t st);
+                     const pgv_bwd_fuse* fuse, hipStream_t st);
 int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st);
@@ -40,11 +40,11 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
 // Second-generation kernels (conv_v2.hip): one workgroup per CU, waves split M, weights from registers; tried first.
 int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                     const pgv_bn_fuse* fuse, hipStream_t st);
+                     const pgv_bwd_fuse* fuse, hipStream_t st);
 
 int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                   const pgv_bn_fuse* fuse, hipStream_t st);
+                   const pgv_bwd_fuse* fuse, hipStream_t st);
 
 // Second-generation direct kernels (conv_direct2.hip): four pixels per lane, 16-byte LDS reads and stores.
 int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
@@ -52,7 +52,7 @@ int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const flo
                         hipStream_t st);
 int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                           const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                          const pgv_bn_fuse* fuse, hipStream_t st);
+                          const pgv_bwd_fuse* fuse, hipStream_t st);
 
 int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d);
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
@@ -95,6 +95,9 @@ int pgv_conv_wgrad_deep(const pgv_conv_desc* d, const float* big, const float* b
                         hipStream_t st);
 
 int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st);
-// red += projections (no clearing): the fallback of pgv_bn_fuse for kernels without the fused epilogue
-int pgv_bn_bwd_reduce_impl(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C, int HW,
-                           double* red, hipStream_t st);
+// g_y = act'(a) * (coef[c]*g + coef[C+c]*a + coef[2C+c]), gbias += sum g_y (no clearing): the separate-pass fallback of
+// pgv_bwd_fuse for kernel families without the fused epilogue (in place: g_y == g)
+int pgv_act_bwd_coef_impl(const float* g, const float* a, const float* coef, int B, int C, int HW, int act, float slope,
+                          float* g_y, float* gbias, hipStream_t st);
+// cls[C][4] += sums of gy[B,C,H,W] by (row parity, column parity): pgv_bwd_fuse.cls for kernels without that by-product
+int pgv_class_sums2_impl(const float* gy, int B, int C, int H, int W, float* cls, hipStream_t st);

@@ -179,12 +179,32 @@ __device__ __forceinline__ void store_rows_contig(const float* __restrict__ tile
   }
 }
 
-// store_rows_contig with the BatchNorm-backward projections of the stored band fused in (pgv_bn_fuse): TPC = 256/NCHP
-// lanes own one channel row each, read the saved activation `a` at the offsets they store to (all loads issued before
-// the copy loop), and add  sum g  and  sum g*(a-mean)*rstd  of the row into acc[2*c], acc[2*c+1] (LDS, one owner lane
-// per channel: accumulated over all units of a persistent workgroup, flushed once with float64 atomics).
+// Derivative of the block activation recovered from the saved ACTIVATED tensor (pgv_bwd_fuse): LeakyReLU keeps the sign
+// (slope >= 0), Hardtanh passes no gradient at / beyond the bounds (torch semantics).
+struct pgv_actd_params {
+  float ns, lo, hi;
+};
+__device__ __forceinline__ pgv_actd_params pgv_actd_setup(int act, float slope) {
+  pgv_actd_params p;
+  p.ns = act == PGV_ACT_LEAKY_RELU ? slope : 1.0f;
+  p.lo = act == PGV_ACT_HARDTANH ? -1.0f : -__builtin_inff();
+  p.hi = act == PGV_ACT_HARDTANH ? 1.0f : __builtin_inff();
+  return p;
+}
+// g_y = act'(a) * (ka*g + kb*a + kc)
+__device__ __forceinline__ float pgv_bwd_apply(float g, float a, float ka, float kb, float kc, const pgv_actd_params& p) {
+  const float t = fmaf(g, ka, fmaf(a, kb, kc));
+  const float d = a > 0.f ? t : p.ns * t;
+  return (a > p.lo && a < p.hi) ? d : 0.f;
+}
+
+// store_rows_contig with the BatchNorm + activation backward of the next-lower block fused in (pgv_bwd_fuse): TPC =
+// 256/NCHP lanes own one channel row each, read the saved activation `a` at the offsets they store to (all loads issued
+// before the copy loop), store g_y = act'(a) * (ka*g + kb*a + kc) instead of g and add the row's sum of g_y (the bias
+// gradient) into acc[c] (LDS, one owner lane per channel: accumulated over all units of a persistent workgroup,
+// flushed once with float atomics).
 // The loads of the saved activation, split off so that the caller can issue them BEFORE the band is transposed through
-// LDS (bnred_fetch ... LDS writes ... barrier ... store_rows_bnred): issued inside the store pass every unit exposed one
+// LDS (bnred_fetch ... LDS writes ... barrier ... store_rows_bwd): issued inside the store pass every unit exposed one
 // memory latency.
 template <int NCHP, int MAXIT>
 __device__ __forceinline__ void bnred_fetch(const float* __restrict__ a, int64_t cstride, int nch, int len, int tid,
@@ -201,54 +221,66 @@ __device__ __forceinline__ void bnred_fetch(const float* __restrict__ a, int64_t
   }
 }
 
-template <int NCHP, int MAXIT>
-__device__ __forceinline__ void store_rows_bnred(const float* __restrict__ tile, int row_stride, float* __restrict__ dst,
-                                                 const float* __restrict__ a, int64_t cstride, int nch, int len,
-                                                 int tid, const float* __restrict__ mean,
-                                                 const float* __restrict__ rstd, float* __restrict__ acc,
-                                                 const f4u (&av)[MAXIT]) {
+// coef: [3][Ctot] table of the output tensor's channels, already offset to the first channel of this group.
+// CLSW != 0: rows of the band are CLSW (a multiple of 4) floats wide and start at image row `row0`; the sums are kept by
+// (row parity, column parity) class in acc[4*c + 2*rp + cp] (pgv_bwd_fuse.cls), else one sum per channel in acc[c].
+template <int NCHP, int MAXIT, int CLSW = 0>
+__device__ __forceinline__ void store_rows_bwd(const float* __restrict__ tile, int row_stride, float* __restrict__ dst,
+                                               const float* __restrict__ a, int64_t cstride, int nch, int len,
+                                               int tid, const float* __restrict__ coef, int Ctot,
+                                               const pgv_actd_params& actd, float* __restrict__ acc,
+                                               const f4u (&av)[MAXIT], int row0 = 0) {
   constexpr int TPC = 256 / NCHP;
   static_assert(TPC == 8 || TPC == 16 || TPC == 32, "lanes per channel");
+  static_assert(CLSW % 4 == 0, "class sums need rows of whole 16-byte pieces");
   const int c = tid / TPC, j = tid - c * TPC;
   const int Q = len >> 2, rem = len & 3;
   const bool cok = c < nch;
-  const float mu = cok ? mean[c] : 0.f, rs = cok ? rstd[c] : 0.f;
+  const float ka = cok ? coef[c] : 0.f, kb = cok ? coef[Ctot + c] : 0.f, kc = cok ? coef[2 * Ctot + c] : 0.f;
   const float* ap = a + c * cstride;
   float* dp = dst + c * cstride;
   const float* tp = tile + c * row_stride;
-  float s1 = 0.f, s2 = 0.f;
+  constexpr int NS = CLSW ? 4 : 1;
+  float s1[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) s1[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXIT; ++i) {
     const int q = j + i * TPC;
     if (cok && q < Q) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(tp + 4 * q);
       f4u o;
-      o.x = v.x, o.y = v.y, o.z = v.z, o.w = v.w;
+      o.x = pgv_bwd_apply(v.x, av[i].x, ka, kb, kc, actd);
+      o.y = pgv_bwd_apply(v.y, av[i].y, ka, kb, kc, actd);
+      o.z = pgv_bwd_apply(v.z, av[i].z, ka, kb, kc, actd);
+      o.w = pgv_bwd_apply(v.w, av[i].w, ka, kb, kc, actd);
       *reinterpret_cast<f4u*>(dp + 4 * q) = o;
-      s1 += (v.x + v.y) + (v.z + v.w);
-      s2 = fmaf(v.x, (av[i].x - mu) * rs, s2);
-      s2 = fmaf(v.y, (av[i].y - mu) * rs, s2);
-      s2 = fmaf(v.z, (av[i].z - mu) * rs, s2);
-      s2 = fmaf(v.w, (av[i].w - mu) * rs, s2);
+      if (CLSW) {
+        const bool rodd = (row0 + (4 * q) / (CLSW ? CLSW : 1)) & 1;
+        const float ev = o.x + o.z, od = o.y + o.w;   // the piece starts at an even column
+        s1[0] += rodd ? 0.f : ev, s1[1 % NS] += rodd ? 0.f : od, s1[2 % NS] += rodd ? ev : 0.f, s1[3 % NS] += rodd ? od : 0.f;
+      } else {
+        s1[0] += (o.x + o.y) + (o.z + o.w);
+      }
     }
   }
-  if (rem && cok && j == 0) {
+  if (rem && cok && j == 0) {   // (CLSW: len is a multiple of 4, no remainder)
     for (int i = 0; i < rem; ++i) {
-      const float v = tp[4 * Q + i];
-      dp[4 * Q + i] = v;
-      s1 += v;
-      s2 = fmaf(v, (ap[4 * Q + i] - mu) * rs, s2);
+      const float o = pgv_bwd_apply(tp[4 * Q + i], ap[4 * Q + i], ka, kb, kc, actd);
+      dp[4 * Q + i] = o;
+      s1[0] += o;
     }
   }
   // sum over the TPC consecutive lanes of the channel
-  s1 += dpp_mov<0xB1>(s1), s2 += dpp_mov<0xB1>(s2);
-  s1 += dpp_mov<0x4E>(s1), s2 += dpp_mov<0x4E>(s2);
-  s1 += dpp_mov<0x141>(s1), s2 += dpp_mov<0x141>(s2);  // 8 lanes
-  if (TPC >= 16) s1 += dpp_mov<0x140>(s1), s2 += dpp_mov<0x140>(s2);
-  if (TPC >= 32) s1 += __shfl_xor(s1, 16, 64), s2 += __shfl_xor(s2, 16, 64);
-  if (cok && j == 0) {
-    acc[2 * c] += s1;
-    acc[2 * c + 1] += s2;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    float t = s1[k];
+    t += dpp_mov<0xB1>(t);
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0x141>(t);  // 8 lanes
+    if (TPC >= 16) t += dpp_mov<0x140>(t);
+    if (TPC >= 32) t += __shfl_xor(t, 16, 64);
+    if (cok && j == 0) acc[NS * c + k] += t;
   }
 }
 

@@ -1,0 +1,613 @@
+// Wave-specialised weight-gradient kernels (k=4 layers and the 5x5 layers of the 1 <-> 8 channel pair) and the
+// partial-gradient reduce pass; structure and measurements: conv_v2_common.h, DESIGN.md section 3.4.
+#define PGV_V2_TU wgrad
+#include "conv_v2_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD, k = 4, stride 2, pad 2:  gw[cs][cb][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,cb,2oh-2+kh,2ow-2+kw]
+// GEMM with M = cs (16 per tile), N = (cb, 16 taps) = one N tile per big channel, K = output pixels (4 consecutive ow per
+// MFMA).  A[cs][pixel] from the small tile, B[pixel][tap] straight from the raw big tile.  Every MFMA wave holds ALL M
+// tiles for CB/4 big channels (MT + CB/4 operand reads per MT*CB/4 MFMAs: the LDS is idle most of the time, bank
+// conflicts of the A reads do not matter); the accumulators live in registers over all units of the persistent
+// workgroup.  Work item = R output rows of one sample (both tiles double-buffered in LDS, two items in flight in the
+// loader's registers).  Flush: per-workgroup partial sums go to a workspace with plain stores and a second kernel adds
+// them up (256 workgroups x the whole gradient as float atomics cost 26 us on the 64x32-channel layer: the atomics
+// execute at the memory side at 1.3 TB/s).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CB, int CS, int W, int H, int R>
+struct WgradV2Cfg {
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;
+  static constexpr int BANDS = (Hs + R - 1) / R;
+  static constexpr int MT = CS / 16, NBW = CB / 4;            // M tiles per wave (all), big channels per wave
+  static constexpr int ROWS_B = 2 * (R - 1) + 4;
+  // row stride of the big tile = 8 mod 16: the four kernel rows of a B fragment (6 consecutive floats each per 32-lane
+  // half) then fall on disjoint bank ranges of the 32 ds_read_b32 banks
+  static constexpr int WP = (W + 2 - 8 + 15) / 16 * 16 + 8;
+  static constexpr int WsP = (Ws + 3) / 4 * 4;
+  // small-tile plane stride = an odd number of 16-byte groups: the A fragment reads one pixel of 16 channels per 16
+  // lanes - with the planes back to back (72 / 144 / 264 floats: 8, 16, 8 mod 32) that is a 4- to 8-way bank conflict,
+  // with an odd group count the 16 channels fall on 8 different bank groups (2-way)
+  static constexpr int PLANE_B = ROWS_B * WP, PLANE_S = R * WsP + ((R * WsP / 4) % 2 == 0 ? 4 : 0);
+  static constexpr int SPR = WsP / 4;                         // k-steps per output row
+  static constexpr int S = R * SPR;
+  static constexpr int FRONT = 4;
+  // one item: FRONT zero floats (what column -2 of the first row of the first plane reads), big tile, small tile
+  static constexpr int BUF = FRONT + CB * PLANE_B + CS * PLANE_S;
+  static constexpr size_t LDS_FLOATS = 2 * (size_t)BUF + 2 * (CB + CS);
+  static_assert(CS % 16 == 0 && CB % 4 == 0 && WP >= W + 2 && WP % 4 == 0 && 2 * WsP <= WP, "tiling");
+};
+
+template <int CB, int CS, int W, int H, int R, bool AFF_B, bool AFF_S>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const float* __restrict__ big,
+                                                             const float* __restrict__ big_scale,
+                                                             const float* __restrict__ big_shift,
+                                                             const float* __restrict__ small_in,
+                                                             const float* __restrict__ small_scale,
+                                                             const float* __restrict__ small_shift,
+                                                             float* __restrict__ partial) {
+  using G = WgradV2Cfg<CB, CS, W, H, R>;
+  constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, MT = G::MT, NBW = G::NBW, WP = G::WP, WsP = G::WsP;
+  constexpr int PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BUF = G::BUF;
+  using StageB = StageLean<CB, G::ROWS_B, W, WP, H>;
+  using StageS = StageLean<CS, R, Ws, WsP, Hs, false, PLANE_S>;
+  constexpr int NPB = StageB::NPF, NPS = StageS::NPF;
+  static_assert(NPB + NPS < 64, "vmcnt range");
+  // columns >= W / >= Ws (what lies behind the end of a row in its last chunk) are only reached in the last k-step of a row
+  static_assert(SPR >= 2 && SPR % 2 == 0 && 8 * (SPR - 2) + 7 < W && 4 * (SPR - 1) <= Ws, "tail masking");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile0 = lds + G::FRONT;
+  float* aff_b = tile0 + 2 * BUF;  // [2][CB]
+  float* aff_s = aff_b + 2 * CB;   // [2][CS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int units = B * BANDS;
+  const int bid = pgv_xcd_block();  // first unit of this workgroup
+  const int my_items = bid < units ? (units - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (tid < 2 * G::FRONT) lds[(tid / G::FRONT) * BUF + tid % G::FRONT] = 0.f;
+  if (AFF_B)
+    for (int i = tid; i < CB; i += 512) aff_b[i] = big_scale[i], aff_b[CB + i] = big_shift[i];
+  if (AFF_S)
+    for (int i = tid; i < CS; i += 512) aff_s[i] = small_scale[i], aff_s[CS + i] = small_shift[i];
+  __syncthreads();
+  if (wave >= 4) {
+    // ================================================= loader waves =================================================
+    if (my_items == 0) return;
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    V2_T0();
+    typename StageB::Geo geoB;
+    typename StageS::Geo geoS;
+    typename StageB::Set bA, bB;
+    typename StageS::Set sA, sB;
+    // only the first and the last band of a sample touch rows outside the image
+    static_assert(BANDS >= 3 && (BANDS - 2) * 2 * R - 2 + G::ROWS_B <= H && (BANDS - 1) * R <= Hs, "edge bands");
+    auto first_item = [&](auto stage_is_big, auto jc) {  // the loads of item 0, slot by slot out of the set-up
+      constexpr int J = decltype(jc)::value;
+      const int u = bid, b = u / BANDS, band = u - b * BANDS;
+      if constexpr (decltype(stage_is_big)::value) {
+        const i32x4 rb = StageB::band_rsrc(big, (int64_t)B * CB * (H * W) * 4, ((int64_t)b * CB * H + band * 2 * R - 2) * W);
+        StageB::template issue_slot<J, true>(geoB, bA, rb, band == 0 ? geoB.top_bad : (band == BANDS - 1 ? geoB.bot_bad : 0u));
+      } else {
+        const i32x4 rs = StageS::band_rsrc(small_in, (int64_t)B * CS * (Hs * Ws) * 4, ((int64_t)b * CS * Hs + band * R) * Ws);
+        StageS::template issue_slot<J, true>(geoS, sA, rs, band == 0 ? geoS.top_bad : (band == BANDS - 1 ? geoS.bot_bad : 0u));
+      }
+    };
+    geoB.init(ltid, aff_b, CB, AFF_B, 2, H - ((BANDS - 1) * 2 * R - 2), [&](auto jc) { first_item(std::true_type{}, jc); });
+    geoS.init(ltid, aff_s, CS, AFF_S, 0, Hs - (BANDS - 1) * R, [&](auto jc) { first_item(std::false_type{}, jc); });
+    const int64_t bytes_b = (int64_t)B * CB * (H * W) * 4, bytes_s = (int64_t)B * CS * (Hs * Ws) * 4;
+    auto band_of = [&](int it, int& b, int& band) {
+      it = min(it, my_items - 1);
+      const int u = bid + it * gridDim.x;
+      b = u / BANDS;
+      band = u - b * BANDS;
+    };
+    auto is_edge = [&](int band) { return band == 0 || band == BANDS - 1; };
+    auto issue_all = [&](typename StageB::Set& bx, typename StageS::Set& sx, int it) {
+      int b, band;
+      band_of(it, b, band);
+      const int ihb = band * 2 * R - 2, ihs = band * R;
+      const i32x4 rb = StageB::band_rsrc(big, bytes_b, ((int64_t)b * CB * H + ihb) * W);
+      const i32x4 rs = StageS::band_rsrc(small_in, bytes_s, ((int64_t)b * CS * Hs + ihs) * Ws);
+      if (is_edge(band)) {
+        const unsigned badb = band == 0 ? geoB.top_bad : geoB.bot_bad, bads = band == 0 ? geoS.top_bad : geoS.bot_bad;
+        static_for<0, NPB>([&](auto j) { StageB::template issue_slot<decltype(j)::value, true>(geoB, bx, rb, badb); });
+        static_for<0, NPS>([&](auto j) { StageS::template issue_slot<decltype(j)::value, true>(geoS, sx, rs, bads); });
+      } else {
+        static_for<0, NPB>([&](auto j) { StageB::template issue_slot<decltype(j)::value, false>(geoB, bx, rb, 0u); });
+        static_for<0, NPS>([&](auto j) { StageS::template issue_slot<decltype(j)::value, false>(geoS, sx, rs, 0u); });
+      }
+    };
+    auto commit_all = [&](const typename StageB::Set& bx, const typename StageS::Set& sx, int it, float* dst) {
+      int b, band;
+      band_of(it, b, band);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NPS) : "memory");  // the older item has landed
+      __builtin_amdgcn_sched_barrier(0);
+      V2_ACC(5);
+      if ((AFF_B || AFF_S) && is_edge(band)) {
+        const unsigned badb = band == 0 ? geoB.top_bad : geoB.bot_bad, bads = band == 0 ? geoS.top_bad : geoS.bot_bad;
+        static_for<0, NPB>([&](auto j) { StageB::template commit_slot<decltype(j)::value, true, AFF_B>(geoB, bx, dst, ltid, badb); });
+        static_for<0, NPS>([&](auto j) {
+          StageS::template commit_slot<decltype(j)::value, true, AFF_S>(geoS, sx, dst + CB * PLANE_B, ltid, bads);
+        });
+      } else {
+        static_for<0, NPB>([&](auto j) { StageB::template commit_slot<decltype(j)::value, false, AFF_B>(geoB, bx, dst, ltid, 0u); });
+        static_for<0, NPS>([&](auto j) {
+          StageS::template commit_slot<decltype(j)::value, false, AFF_S>(geoS, sx, dst + CB * PLANE_B, ltid, 0u);
+        });
+      }
+    };
+    issue_all(bB, sB, 1);  // (item 0 went out during the set-up)
+    commit_all(bA, sA, 0, tile0);
+    issue_all(bA, sA, 2);
+    V2_ACC(6);
+    ws_barrier();
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+      V2_ACC(2);
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+      V2_ACC(3);
+      commit_all(bB, sB, it + 1, tile0 + BUF);
+      V2_ACC(0);
+      issue_all(bB, sB, it + 3);
+      V2_ACC(1);
+      V2_ITEM();
+      ws_barrier();
+      if (it + 1 < my_items) {
+        V2_ACC(2);
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        V2_ACC(3);
+        commit_all(bA, sA, it + 2, tile0);
+        V2_ACC(0);
+        issue_all(bA, sA, it + 4);
+        V2_ACC(1);
+        V2_ITEM();
+        ws_barrier();
+      }
+    }
+    V2_ACC(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V2_FLUSH();
+    return;
+  }
+  // ==================================================== MFMA waves ===================================================
+  __builtin_amdgcn_s_setprio(PGV_V2_PRIO_MFMA);
+  V2_T0();
+  // A: lane (m = cs = lane&15, k = pixel lane>>4) reads small[cs][r][4i + k]; B: lane (n = tap = lane&15, k) reads
+  // big[cb][2r + kh][2(4i + k) + kw - 2]  (column -2 of a row = the zero tail of the row before / the zero front)
+  int offA[MT], offB[NBW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) offA[m] = CB * PLANE_B + (m * 16 + (lane & 15)) * PLANE_S + (lane >> 4);
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) {
+    const int tap = lane & 15;
+    offB[n] = (wave * NBW + n) * PLANE_B + (tap >> 2) * WP + (tap & 3) - 2 + 2 * (lane >> 4);
+  }
+  // operand lanes of the last k-step of a row that lie behind the end of the row (the loader does not clean them)
+  const bool keepA = 4 * (SPR - 1) + (lane >> 4) < Ws;
+  const bool keepB = 8 * (SPR - 1) + 2 * (lane >> 4) + (lane & 3) - 2 < W;
+  f32x4 acc[MT][NBW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V2_ACC(0);
+  if (my_items > 0) {
+    ws_barrier();  // item 0 committed
+#pragma unroll 1
+    for (int it = 0; it < my_items; ++it) {
+      V2_ACC(2);
+      const float* cur = tile0 + (it & 1) * BUF;
+      const int u = bid + it * gridDim.x;
+      const int nrows = min(R, Hs - (u % BANDS) * R);  // the last band of a sample may be short
+      // k-steps go in pairs (two consecutive 4-pixel groups of a row): the two operand values of a lane lie 4 (A) / 8 (B)
+      // floats apart and come from ONE ds_read2_b32 - an LDS instruction of the MFMA wave costs MFMA issue time
+      // (3-7 clocks each, they do not hide under the 32 clocks of an MFMA), so there should be few of them
+      constexpr int NSET = MT * NBW >= 32 ? 2 : 3;  // operand pairs in flight + 1 (the big tile has no registers for 3)
+      float av[NSET][2][MT], bv[NSET][2][NBW];
+      auto load_pair = [&](int ps, float (&a)[2][MT], float (&b)[2][NBW]) {
+        const int r = ps / (SPR / 2), i = 2 * (ps - r * (SPR / 2));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[h][m] = cur[offA[m] + r * WsP + 4 * (i + h)];
+#pragma unroll
+          for (int n = 0; n < NBW; ++n) b[h][n] = cur[offB[n] + 2 * r * WP + 8 * (i + h)];
+        }
+        if (i + 1 == SPR - 1) {
+          if (Ws % 4 != 0)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[1][m] = keepA ? a[1][m] : 0.f;
+          if (W % 4 != 0)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) b[1][n] = keepB ? b[1][n] : 0.f;
+        }
+      };
+      constexpr int PPR = SPR / 2, PS = R * PPR;  // pairs per row, per item
+      load_pair(0, av[0], bv[0]);
+      if (NSET == 3) load_pair(1, av[1], bv[1]);
+      static_for<0, R>([&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        if (Hs % R == 0 || r < nrows) {
+          static_for<0, PPR>([&](auto i_c) {
+            constexpr int ps = r * PPR + decltype(i_c)::value;
+            constexpr int pn = ps + NSET - 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (pn < PS) load_pair(pn, av[pn % NSET], bv[pn % NSET]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = PGV_MFMA4(av[ps % NSET][h][m], bv[ps % NSET][h][n], acc[m][n]);
+            // MT + NBW reads under 2 * MT * NBW MFMAs: one read behind each of the first MFMAs
+            static_for<0, 2 * MT * NBW>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if constexpr (pn < PS && k < MT + NBW)
+                __builtin_amdgcn_sched_group_barrier(0x100, k + 1 == 2 * MT * NBW ? MT + NBW - k : 1, 0);
+            });
+          });
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      V2_ACC(4);
+      V2_ITEM();
+      ws_barrier();
+    }
+  }
+  V2_ACC(2);
+  // ---- this workgroup's partial gradient: D column = lane&15 = tap, rows (lane>>4)*4 + reg = cs within the M tile
+  float* pw = partial + (size_t)blockIdx.x * (CS * CB * 16);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cs = m * 16 + (lane >> 4) * 4 + reg, cb = wave * NBW + n;
+        pw[(cs * CB + cb) * 16 + (lane & 15)] = acc[m][n][reg];
+      }
+  V2_ACC(5);
+  V2_FLUSH();
+}
+
+// gw[e] (+)= sum over the workgroups' partial gradients.  A block = 8 float4 elements x 32 slices of the partials: with
+// 256 partials every thread has its 8 loads in flight at once - the pass costs about one memory round trip (a thread
+// that walks 32 partials one after the other made this kernel take 10 us).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int n4,
+                                                           float* __restrict__ gw, int accumulate) {
+  __shared__ f32x4 red[32][8];
+  const int el = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int e = blockIdx.x * 8 + el;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + e;
+    int k = sl;
+    for (; k + 7 * 32 < nparts; k += 8 * 32) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 32 * u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nparts; k += 32) s += p[(size_t)k * n4];
+  }
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && e < n4) {
+#pragma unroll
+    for (int k = 1; k < 32; ++k) s += red[k][el];
+    f32x4* o = reinterpret_cast<f32x4*>(gw) + e;
+    if (accumulate) s += *o;
+    *o = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD of the 1 <-> 8 channel 5x5 layers (enc1 / dec8: big = [B,1,257,347], small = [B,8,129,174]), same structure as
+// conv_wgrad_ws_kernel:  gw[cs][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,0,2oh-2+kh,2ow-2+kw].
+// M = cs (8 of the tile's 16 rows; lanes 8-15 duplicate 0-7 and are not stored), N = 25 taps in two tiles (lanes past
+// tap 24 duplicate it), K = output pixels.  There are only two (M, N) tiles, so the four MFMA waves split K: wave w
+// multiplies output row w of the unit (R = 4 rows) and keeps its own accumulators; every wave's partial sum goes to the
+// workspace (4 per workgroup) and the reduce pass adds them.  The band kernel this replaces spends 37 % of a
+// workgroup's time in its MFMA phase (commit 1.4 us + issue 1.0 us against 1.6 us of MFMAs per item).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CS, int W, int H, int R>
+struct Wgrad5Cfg {
+  static constexpr int KS = 5, NTAP = 25;
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1;
+  static constexpr int BANDS = (Hs + R - 1) / R;
+  static constexpr int ROWS_B = 2 * (R - 1) + KS;
+  // big-tile row stride = 8 mod 32 floats: the kernel rows of a B fragment (7 consecutive floats each per 32-lane half)
+  // fall on disjoint bank ranges
+  static constexpr int WP = (W + 2 - 8 + 31) / 32 * 32 + 8;
+  static constexpr int WsP = (Ws + 3) / 4 * 4;
+  // plane stride of the small tile = 4 mod 32 floats: the A fragment reads the same pixel of all 8 channels at once -
+  // with the planes back to back (704 floats) that is an 8-way bank conflict on every read, and this kernel has only
+  // 3 operand reads per 4 MFMAs to hide it behind (MFMA-side time 74 us instead of ~40)
+  static constexpr int PLANE_S = R * WsP + 4;
+  static_assert(PLANE_S % 32 == 4, "bank spreading");
+  static constexpr int SPR = WsP / 4, PPR = SPR / 2;  // k-steps / pairs of k-steps per output row
+  static constexpr int FRONT = 4;
+  static constexpr int BUF = FRONT + ROWS_B * WP + CS * PLANE_S;
+  static constexpr size_t LDS_FLOATS = 2 * (size_t)BUF + 2 * (1 + CS) + 8;
+  static_assert(R == 4 && CS == 8 && SPR % 2 == 0 && WP >= W + 2 && 2 * WsP <= WP, "tiling");
+};
+
+template <int CS, int W, int H, int R, bool AFF_S>
+__global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const float* __restrict__ big,
+                                                              const float* __restrict__ small_in,
+                                                              const float* __restrict__ small_scale,
+                                                              const float* __restrict__ small_shift,
+                                                              float* __restrict__ partial) {
+  using G = Wgrad5Cfg<CS, W, H, R>;
+  constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, WP = G::WP, WsP = G::WsP, PLANE_S = G::PLANE_S;
+  constexpr int SPR = G::SPR, PPR = G::PPR, BUF = G::BUF, PLANE_B = G::ROWS_B * WP;
+  using StageB = StageLean<1, G::ROWS_B, W, WP, H>;
+  using StageS = StageLean<CS, R, Ws, WsP, Hs, false, PLANE_S>;
+  constexpr int NPB = StageB::NPF, NPS = StageS::NPF;
+  static_assert(NPB + NPS < 64, "vmcnt range");
+  static_assert(8 * (SPR - 2) + 7 + 4 < W + 2 && 4 * (SPR - 1) <= Ws, "tail masking");
+  static_assert(BANDS >= 3 && (BANDS - 2) * 2 * R - 2 + G::ROWS_B <= H && (BANDS - 1) * R <= Hs, "edge bands");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile0 = lds + G::FRONT;
+  float* aff_s = lds + 2 * BUF;  // [2][CS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int units = B * BANDS;
+  const int bid = pgv_xcd_block();
+  const int my_items = bid < units ? (units - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (tid < 2 * G::FRONT) lds[(tid / G::FRONT) * BUF + tid % G::FRONT] = 0.f;
+  if (AFF_S)
+    for (int i = tid; i < CS; i += 512) aff_s[i] = small_scale[i], aff_s[CS + i] = small_shift[i];
+  __syncthreads();
+  if (wave >= 4) {
+    // ================================================= loader waves =================================================
+    if (my_items == 0) return;
+    const int ltid = tid - 256;
+    __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
+    typename StageB::Geo geoB;
+    typename StageS::Geo geoS;
+    typename StageB::Set bA, bB;
+    typename StageS::Set sA, sB;
+    const int64_t bytes_b = (int64_t)B * (H * W) * 4, bytes_s = (int64_t)B * CS * (Hs * Ws) * 4;
+    auto band_of = [&](int it, int& b, int& band) {
+      it = min(it, my_items - 1);
+      const int u = bid + it * gridDim.x;
+      b = u / BANDS;
+      band = u - b * BANDS;
+    };
+    auto is_edge = [&](int band) { return band == 0 || band == BANDS - 1; };
+    auto first_item = [&](auto stage_is_big, auto jc) {  // the loads of item 0, slot by slot out of the set-up
+      constexpr int J = decltype(jc)::value;
+      int b, band;
+      band_of(0, b, band);
+      if constexpr (decltype(stage_is_big)::value) {
+        const i32x4 rb = StageB::band_rsrc(big, bytes_b, ((int64_t)b * H + band * 2 * R - 2) * W);
+        StageB::template issue_slot<J, true>(geoB, bA, rb, band == 0 ? geoB.top_bad : (band == BANDS - 1 ? geoB.bot_bad : 0u));
+      } else {
+        const i32x4 rs = StageS::band_rsrc(small_in, bytes_s, ((int64_t)b * CS * Hs + band * R) * Ws);
+        StageS::template issue_slot<J, true>(geoS, sA, rs, band == BANDS - 1 ? geoS.bot_bad : 0u);
+      }
+    };
+    geoB.init(ltid, nullptr, 1, false, 2, H - ((BANDS - 1) * 2 * R - 2), [&](auto jc) { first_item(std::true_type{}, jc); });
+    geoS.init(ltid, aff_s, CS, AFF_S, 0, Hs - (BANDS - 1) * R, [&](auto jc) { first_item(std::false_type{}, jc); });
+    auto issue_all = [&](typename StageB::Set& bx, typename StageS::Set& sx, int it) {
+      int b, band;
+      band_of(it, b, band);
+      const i32x4 rb = StageB::band_rsrc(big, bytes_b, ((int64_t)b * H + band * 2 * R - 2) * W);
+      const i32x4 rs = StageS::band_rsrc(small_in, bytes_s, ((int64_t)b * CS * Hs + band * R) * Ws);
+      if (is_edge(band)) {
+        const unsigned badb = band == 0 ? geoB.top_bad : geoB.bot_bad, bads = band == 0 ? 0u : geoS.bot_bad;
+        static_for<0, NPB>([&](auto j) { StageB::template issue_slot<decltype(j)::value, true>(geoB, bx, rb, badb); });
+        static_for<0, NPS>([&](auto j) { StageS::template issue_slot<decltype(j)::value, true>(geoS, sx, rs, bads); });
+      } else {
+        static_for<0, NPB>([&](auto j) { StageB::template issue_slot<decltype(j)::value, false>(geoB, bx, rb, 0u); });
+        static_for<0, NPS>([&](auto j) { StageS::template issue_slot<decltype(j)::value, false>(geoS, sx, rs, 0u); });
+      }
+    };
+    auto commit_all = [&](const typename StageB::Set& bx, const typename StageS::Set& sx, int it, float* dst) {
+      int b, band;
+      band_of(it, b, band);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NPS) : "memory");  // the older item has landed
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NPB>([&](auto j) { StageB::template commit_slot<decltype(j)::value, false, false>(geoB, bx, dst, ltid, 0u); });
+      if (AFF_S && band == BANDS - 1) {
+        static_for<0, NPS>([&](auto j) {
+          StageS::template commit_slot<decltype(j)::value, true, AFF_S>(geoS, sx, dst + PLANE_B, ltid, geoS.bot_bad);
+        });
+      } else {
+        static_for<0, NPS>([&](auto j) {
+          StageS::template commit_slot<decltype(j)::value, false, AFF_S>(geoS, sx, dst + PLANE_B, ltid, 0u);
+        });
+      }
+    };
+    issue_all(bB, sB, 1);  // (item 0 went out during the set-up)
+    commit_all(bA, sA, 0, tile0);
+    issue_all(bA, sA, 2);
+    ws_barrier();
+#pragma unroll 1
+    for (int it = 0; it < my_items; it += 2) {
+#ifndef PGV_W5_NO_LOAD
+      __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+      commit_all(bB, sB, it + 1, tile0 + BUF);
+      issue_all(bB, sB, it + 3);
+#endif
+      ws_barrier();
+      if (it + 1 < my_items) {
+#ifndef PGV_W5_NO_LOAD
+        __builtin_amdgcn_s_sleep(PGV_V2_LOADER_SLEEP);
+        commit_all(bA, sA, it + 2, tile0);
+        issue_all(bA, sA, it + 4);
+#endif
+        ws_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // ==================================================== MFMA waves ===================================================
+  __builtin_amdgcn_s_setprio(PGV_V2_PRIO_MFMA);
+  // wave w multiplies output row w of the unit.  A: lane (m = cs = lane & 7, k = pixel lane>>4) reads
+  // small[cs][w][4i + k]; B: lane (tap = 16 n + (lane & 15), k) reads big[2w + kh][2(4i + k) + kw - 2]
+  const int offA = PLANE_B + (lane & 7) * PLANE_S + wave * WsP + (lane >> 4);
+  int offB[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int tap = min(16 * n + (lane & 15), G::NTAP - 1);
+    offB[n] = (2 * wave + tap / G::KS) * WP + tap % G::KS - 2 + 2 * (lane >> 4);
+  }
+  // operand lanes of the last k-step of a row that lie behind the end of the row (the loader does not clean them)
+  const bool keepA = 4 * (SPR - 1) + (lane >> 4) < Ws;
+  bool keepB[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) keepB[n] = 8 * (SPR - 1) + 2 * (lane >> 4) + min(16 * n + (lane & 15), G::NTAP - 1) % G::KS - 2 < W;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (my_items > 0) {
+    ws_barrier();  // item 0 committed
+#pragma unroll 1
+    for (int it = 0; it < my_items; ++it) {
+      const float* cur = tile0 + (it & 1) * BUF;
+      const int u = bid + it * gridDim.x;
+      const int nrows = min(R, Hs - (u % BANDS) * R);  // the last band of a sample is short
+#ifdef PGV_W5_NO_MFMA
+      if (false) {
+#else
+      if (wave < nrows) {
+#endif
+        float av[3][2], bv[3][2][2];
+        auto load_pair = [&](int ps, float (&a)[2], float (&b)[2][2]) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            a[h] = cur[offA + 4 * (2 * ps + h)];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[h][n] = cur[offB[n] + 8 * (2 * ps + h)];
+          }
+          if (2 * ps + 1 == SPR - 1) {
+            if (Ws % 4 != 0) a[1] = keepA ? a[1] : 0.f;
+            if (W % 4 != 0)
+#pragma unroll
+              for (int n = 0; n < 2; ++n) b[1][n] = keepB[n] ? b[1][n] : 0.f;
+          }
+        };
+        load_pair(0, av[0], bv[0]);
+        load_pair(1, av[1], bv[1]);
+        static_for<0, PPR>([&](auto pc) {
+          constexpr int ps = decltype(pc)::value, pn = ps + 2;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (pn < PPR) load_pair(pn, av[pn % 3], bv[pn % 3]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[n] = PGV_MFMA4(av[ps % 3][h], bv[ps % 3][h][n], acc[n]);
+          // 3 operand reads (one per operand: the two k-steps of a pair come from one ds_read2) under 4 MFMAs
+          static_for<0, 4>([&](auto kc) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (pn < PPR && decltype(kc)::value < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ws_barrier();
+    }
+  }
+  // ---- this wave's partial gradient: D column = lane & 15 = tap - 16 n, rows (lane>>4)*4 + reg = cs (0..7 are real)
+  float* pw = partial + ((size_t)blockIdx.x * 4 + wave) * (CS * G::NTAP);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int cs = (lane >> 4) * 4 + reg, tap = 16 * n + (lane & 15);
+      if (cs < CS && tap < G::NTAP) pw[cs * G::NTAP + tap] = acc[n][reg];
+    }
+}
+
+template <int R>
+int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* small_in, const float* small_scale,
+                     const float* small_shift, float* gw, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  using G = Wgrad5Cfg<8, 347, 257, R>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  const int units = d->B * G::BANDS;
+  const int grid = min(units, 256);
+  const int nparts = 4 * grid;
+  const int64_t need = (int64_t)nparts * 8 * G::NTAP * sizeof(float);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, float*);
+  kern_t kern = small_scale ? (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, true>
+                            : (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, false>;
+  if (int rc = raise_lds_once((const void*)kern, "conv_wgrad5_v2")) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, small_in, small_scale, small_shift, (float*)workspace);
+  PGV_CHECK_LAUNCH("conv_wgrad5_v2");
+  const int n4 = 8 * G::NTAP / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, nparts, n4, gw,
+                     (d->flags & PGV_PREZEROED) ? 1 : 0);
+  PGV_CHECK_LAUNCH("conv_wgrad5_v2 reduce");
+  return 1;
+}
+
+template <int CB, int CS, int W, int H, int R>
+int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                    const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                    void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  using G = WgradV2Cfg<CB, CS, W, H, R>;
+  constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
+  if (d->Cb != CB || d->Cs != CS) return 0;
+  const int units = d->B * G::BANDS;
+  const int grid = min(units, 256);
+  const int64_t need = (int64_t)grid * CS * CB * 16 * sizeof(float);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
+  if (big_scale && small_scale) return 0;  // not a case of the train step (the loader would spill registers)
+  kern_t kern = big_scale ? (kern_t)conv_wgrad_ws_kernel<CB, CS, W, H, R, true, false>
+                          : (small_scale ? (kern_t)conv_wgrad_ws_kernel<CB, CS, W, H, R, false, true>
+                                         : (kern_t)conv_wgrad_ws_kernel<CB, CS, W, H, R, false, false>);
+  if (int rc = raise_lds_once((const void*)kern, "conv_wgrad_v2")) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, big_scale, big_shift, small_in, small_scale,
+                     small_shift, (float*)workspace);
+  PGV_CHECK_LAUNCH("conv_wgrad_v2");
+  const int n4 = CS * CB * 16 / 4;
+  // PGV_PREZEROED: gw holds zeros or an earlier partial sum to add to; otherwise it is overwritten
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, grid, n4, gw,
+                     (d->flags & PGV_PREZEROED) ? 1 : 0);
+  PGV_CHECK_LAUNCH("conv_wgrad_v2 reduce");
+  return 1;
+}
+
+}  // namespace
+
+// workspace: one partial gradient per workgroup
+int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d) {
+  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->Cb == 1 &&
+      d->Cs == 8 && d->Hb == 257 && d->Wb == 347)
+    return (int64_t)4 * 256 * 8 * 25 * sizeof(float);  // one partial gradient per MFMA wave
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || (d->flags & PGV_COMPUTE_BF16)) return 0;
+  if ((d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) ||
+      (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
+      (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16))
+    return (int64_t)256 * d->Cs * d->Cb * 16 * sizeof(float);
+  return 0;
+}
+
+int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                      void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->B > 0 &&
+      d->Cb == 1 && d->Cs == 8 && d->Hb == 257 && d->Wb == 347 && !big_scale)
+    return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, st);
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  if ((d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
+  if (d->Hb == 33 && d->Wb == 45)
+    return launch_wgrad_v2<32, 64, 45, 33, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                              workspace, workspace_bytes, st);
+  if (d->Hb == 65 && d->Wb == 88)
+    return launch_wgrad_v2<16, 32, 88, 65, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                              workspace, workspace_bytes, st);
+  if (d->Hb == 129 && d->Wb == 174)
+    return launch_wgrad_v2<8, 16, 174, 129, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
+                                               workspace, workspace_bytes, st);
+  return 0;
+}

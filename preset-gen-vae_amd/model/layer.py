@@ -113,6 +113,18 @@ def _step_zeros(param, n, dtype, tag, device):
     return torch.zeros(n, device=device, dtype=dtype)
 
 
+# 'fused': BatchNorm + activation backward of every block that has a consumer inside its stack rides in that consumer's
+# input-gradient epilogue (no pass over the gradient); 'passes': the reduce + apply passes for every block (A/B aid).
+BN_BACKWARD_MODE = 'fused'
+
+
+def set_bn_backward_mode(mode):
+    global BN_BACKWARD_MODE
+    if mode not in ('fused', 'passes'):
+        raise ValueError(f"unknown BatchNorm backward mode {mode!r}")
+    BN_BACKWARD_MODE = mode
+
+
 # Set by parallel.GradAllReduce: called with a parameter right after the kernel writing its gradient was launched on
 # the current stream (gradient-ready notification for bucketed all-reduce overlap).
 GRAD_READY_HOOK = None
@@ -218,67 +230,144 @@ class ConvStackFn(torch.autograd.Function):
                 return (None,) * (5 + len(params))
         g_o = g_out.contiguous() if g_out is not None else None
         dev = saved[-1][3].device
+        nb = len(blocks)
+        B = saved[-1][3].shape[0]
         grads = [None] * len(params)
-        pi = len(params)
-        n_red = sum(2 * blk.c_out for blk, sv in zip(blocks, saved) if blk.bn is not None and sv[5] is not None)
+        # Block li < nb-1 normally gets the pass-free backward: the input-gradient kernel of block li+1 applies block
+        # li's BatchNorm + activation backward in its epilogue (pgv_bwd_fuse) with coefficients derived from block
+        # li+1's weight gradient (pgv_bn_bwd_coef) - the gradient of block li's BatchNorm output is never stored.
+        # Only the top block of a stack (its gradient arrives from outside) runs the reduce + apply passes.
+        # (fp32 products only: in bf16 operand mode the identity yields sum g*bf16(o) instead of sum g*o - a coherent
+        # error of relative size 2^-9/sqrt(n) in every element of g_y that the next weight gradient, a heavily cancelling
+        # sum, amplifies; measured 6x the bf16 oracle's self-distance on enc2conv.weight at B = 3)
+        passfree = [False] * nb
+        if BN_BACKWARD_MODE == 'fused' and ops.compute_dtype() == 'fp32':
+            for li in range(nb - 1):
+                up = blocks[li + 1]
+                gsz = saved[li + 1][7]
+                hy, wy = (gsz.Hb, gsz.Wb) if up.up else (gsz.Hs, gsz.Ws)
+                passfree[li] = up.k <= 5 and hy <= 1024 and wy <= 1024
+        n_red = sum(2 * blk.c_out for li, (blk, sv) in enumerate(zip(blocks, saved))
+                    if blk.bn is not None and sv[5] is not None and not passfree[li])
         arena = _step_zeros(params[0], n_red, torch.float64, 'red', dev) if n_red else None  # BN-backward projections
-        a_off = 0
-        # arena slice of every train-mode BatchNorm block; the projections of block li-1 are accumulated by the
-        # input-gradient kernel of block li while it writes g (pgv_bn_fuse), only the top block needs its own pass
-        reds = [None] * len(blocks)
-        for li in range(len(blocks)):
-            if blocks[li].bn is not None and saved[li][5] is not None:
-                reds[li] = arena[a_off:a_off + 2 * blocks[li].c_out]
-                a_off += 2 * blocks[li].c_out
-        red_done = False
-        for li in range(len(blocks) - 1, -1, -1):
+        n_tap = sum(blocks[li + 1].c_out * blocks[li + 1].k ** 2 for li in range(nb - 1)
+                    if passfree[li] and blocks[li].bn is not None and saved[li][5] is not None)
+        tap_arena = _step_zeros(params[0], n_tap, torch.float64, 'tap', dev) if n_tap else None
+        a_off = t_off = 0
+        pis = []   # index of every block's first parameter
+        pi = 0
+        for blk in blocks:
+            pis.append(pi)
+            pi += 4 if blk.bn is not None else 2
+        g_y_fused = None   # g_y of the current block when the block above produced it in its input-gradient epilogue
+        gb_cur = None      # the current block's bias gradient (complete when g_y is)
+        cls_cur = None     # sums of the current block's g_y by (row, column) parity class, when its producer kept them
+
+        def wants_cls(i):
+            """Will block i's g_y be the output gradient of a stride-2 ConvTranspose2d whose tap sums are needed?"""
+            return (i > 0 and passfree[i - 1] and blocks[i].up and blocks[i].stride == 2 and
+                    blocks[i - 1].bn is not None and saved[i - 1][5] is not None)
+
+        n_cls = sum(4 * blocks[i].c_out for i in range(nb) if wants_cls(i))
+        cls_arena = _step_zeros(params[0], n_cls, torch.float32, 'cls', dev) if n_cls else None
+        c_off = 0
+        for li in range(nb - 1, -1, -1):
             blk = blocks[li]
             inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
             has_bn = blk.bn is not None
-            pi -= 4 if has_bn else 2
+            pi = pis[li]
             w = params[pi]
             C = blk.c_out
-            red = ggamma = gbeta = None
-            if has_bn and mean is not None:
-                red = reds[li]
-                if not red_done:
-                    ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
-                ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
-                gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
-            # (eval-mode BN: gamma/beta gradients are not produced)
-            gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
-            # g_y overwrites g_o unless g_o is the caller's tensor (first iteration)
-            if fused_sq and li == len(blocks) - 1:
-                g_y = torch.empty_like(a)
-                ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,
-                                  prezeroed=gb_zero, loss_acc=ctx.sq_deferred)
+            if g_y_fused is not None:
+                # bias / BatchNorm parameter gradients were written on the way (gb_cur: this block's bias gradient)
+                g_y, g_y_fused = g_y_fused, None
             else:
-                g_y = g_o if li != len(blocks) - 1 else torch.empty_like(g_o)
-                ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
-                               ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
-            grads[pi + 1] = gb_ret
-            if ggamma is not None:
-                _grad_done(params[pi + 2], params[pi + 3])
-            _grad_done(params[pi + 1])
+                red = ggamma = gbeta = None
+                if has_bn and mean is not None:
+                    red = arena[a_off:a_off + 2 * C]
+                    a_off += 2 * C
+                    ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
+                    ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
+                    gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
+                # (eval-mode BN: gamma/beta gradients are not produced)
+                gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
+                # g_y overwrites g_o unless g_o is the caller's tensor (top block)
+                cls_cur = None
+                if fused_sq and li == nb - 1:
+                    g_y = torch.empty_like(a)
+                    if wants_cls(li) and C == 1:
+                        cls_cur = cls_arena[c_off:c_off + 4]
+                        c_off += 4
+                    ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,
+                                      prezeroed=gb_zero, loss_acc=ctx.sq_deferred, cls=cls_cur)
+                else:
+                    g_y = g_o if li != nb - 1 else torch.empty_like(g_o)
+                    ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
+                                   ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
+                grads[pi + 1] = gb_ret
+                gb_cur = gb
+                if ggamma is not None:
+                    _grad_done(params[pi + 2], params[pi + 3])
             gw, gw_ret, gw_zero = _grad_dest(w, accumulated=True)
             if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
                 ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero)
             else:        # Conv2d: big = block input, small = g_y
                 ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift, prezeroed=gw_zero)
             grads[pi] = gw_ret
-            _grad_done(w)
             need_dx = li > 0 or ctx.needs_input_grad[0]
-            red_done = False
-            if need_dx:
-                fuse = None
-                if li > 0 and reds[li - 1] is not None:
-                    _, _, _, a_prev, _, mean_prev, rstd_prev, _ = saved[li - 1]
-                    fuse = (a_prev, mean_prev, rstd_prev, reds[li - 1])
-                    red_done = True
-                if blk.up:
-                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bn_fuse=fuse)
+            fuse = None
+            if need_dx and li > 0 and passfree[li - 1]:
+                low = blocks[li - 1]
+                _, _, _, a_low, _, mean_low, rstd_low, _ = saved[li - 1]
+                pl = pis[li - 1]
+                Cl = low.c_out
+                if low.bn is not None and mean_low is not None:
+                    # train-mode BatchNorm: coefficients from W * gW of this block and the tap sums of g_y (must be
+                    # launched before this block's weight gradient is announced: a gradient exchange rewrites it)
+                    T = tap_arena[t_off:t_off + C * blk.k ** 2]
+                    t_off += C * blk.k ** 2
+                    # class sums of g_y: for a Conv2d consumer simply this block's bias gradient; for a ConvTranspose2d
+                    # one the sums by row / column parity class
+                    if not blk.up:
+                        cls = gb_cur.reshape(-1)
+                    elif cls_cur is not None:
+                        cls = cls_cur
+                    else:
+                        cls = ops.conv_class_sums(geom, g_y, True)
+                    ops.conv_tap_sums(geom, g_y, blk.up, T, prezeroed=True, cls=cls)
+                    coef = torch.empty(3 * Cl, device=dev, dtype=torch.float32)
+                    gg_low, grads[pl + 2] = _grad_dest(params[pl + 2])
+                    gbt_low, grads[pl + 3] = _grad_dest(params[pl + 3])
+                    ops.bn_bwd_coef(geom, B, not blk.up, w, gw, T, in_scale, in_shift, mean_low, rstd_low,
+                                    a_low.numel() // Cl, coef, gg_low, gbt_low)
+                elif low.bn is not None:   # eval-mode BatchNorm: g_a = scale * g
+                    coef = torch.cat([in_scale, torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
                 else:
-                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bn_fuse=fuse)
+                    coef = torch.cat([torch.ones(Cl, device=dev, dtype=torch.float32),
+                                      torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
+                gb_low, grads[pl + 1], gb_zero = _grad_dest(params[pl + 1], accumulated=True)
+                if not gb_zero:
+                    gb_low.zero_()
+                cls_low = None
+                if wants_cls(li - 1):
+                    cls_low = cls_arena[c_off:c_off + 4 * Cl]
+                    c_off += 4 * Cl
+                fuse = (a_low, coef, gb_low, low.act, low.slope, cls_low)
+            # (announced only now: the coefficient kernels above read this block's bias and weight gradients, which a
+            # gradient exchange rewrites in place)
+            _grad_done(params[pi + 1], w)
+            if need_dx:
+                if blk.up:
+                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+                else:
+                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+                if fuse is not None:
+                    g_y_fused, g_o = g_o, None
+                    gb_cur, cls_cur = fuse[2], fuse[5]
+                    low = blocks[li - 1]
+                    pl = pis[li - 1]
+                    if low.bn is not None and saved[li - 1][5] is not None:
+                        _grad_done(params[pl + 2], params[pl + 3])
             else:
                 g_o = None
         return (g_o, None, None, None, None) + tuple(grads)

@@ -77,21 +77,27 @@ class ConvGeom:
         return d
 
 
-def _fuse_arg(bn_fuse, out):
-    """``bn_fuse`` = (a, mean, rstd, red): accumulate the BatchNorm-backward projections of ``out`` against the saved
-    activation ``a`` into ``red`` (float64, caller-cleared) in the same call (``pgv_bn_fuse``)."""
-    if bn_fuse is None:
+def _fuse_arg(bwd_fuse, out):
+    """``bwd_fuse`` = (a, coef, gbias, act, slope[, cls]): the call's product is the gradient of the BatchNorm output of
+    the next-lower block; its BatchNorm + activation backward ``act'(a) * (coef[0]*g + coef[1]*a + coef[2])`` is applied
+    before the store, ``gbias`` (caller-cleared, may be None) receives the bias gradient and ``cls`` (optional,
+    caller-cleared [C*4]) the sums of the result by (row parity, column parity) class (``pgv_bwd_fuse``)."""
+    if bwd_fuse is None:
         return None
-    a, mean, rstd, red = bn_fuse
-    _chk(a, mean, rstd)
-    _chk64(red)
+    a, coef, gbias, act, slope = bwd_fuse[:5]
+    cls = bwd_fuse[5] if len(bwd_fuse) > 5 else None
+    _chk(a, coef, gbias, cls)
     if a.shape != out.shape:
-        raise ValueError("bn_fuse: saved activation and output shapes differ")
-    return _lib.BnFuse(_p(a), _p(mean), _p(rstd), _p(red))
+        raise ValueError("bwd_fuse: saved activation and output shapes differ")
+    if coef.numel() != 3 * a.shape[1] or (gbias is not None and gbias.numel() != a.shape[1]):
+        raise ValueError("bwd_fuse: coef must hold 3*C floats and gbias C floats")
+    if cls is not None and cls.numel() != 4 * a.shape[1]:
+        raise ValueError("bwd_fuse: cls must hold 4*C floats")
+    return _lib.BwdFuse(_p(a), _p(coef), _p(gbias), int(act), float(slope), _p(cls))
 
 
 def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-              bn_fuse=None):
+              bwd_fuse=None):
     """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it."""
     B = big.shape[0]
     if out is None:
@@ -99,7 +105,7 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
     _chk(big, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    f = _fuse_arg(bn_fuse, out)
+    f = _fuse_arg(bwd_fuse, out)
     _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale),
                                        _p(in_shift), _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                        None if f is None else ctypes.byref(f), _stream()), "pgv_conv_down")
@@ -107,14 +113,14 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
 
 
 def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-            bn_fuse=None):
+            bwd_fuse=None):
     B = small.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
     _chk(small, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
-    f = _fuse_arg(bn_fuse, out)
+    f = _fuse_arg(bwd_fuse, out)
     _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift),
                                      _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                      None if f is None else ctypes.byref(f), _stream()), "pgv_conv_up")
@@ -186,6 +192,60 @@ def affine_nchw(a, scale, shift, out=None):
     return out
 
 
+def conv_tap_sums(geom, gy, gy_is_big, T=None, prezeroed=False, cls=None):
+    """T[c][kh][kw] (float64) = sums of ``gy`` over the positions each kernel tap pairs with the inside of the other
+    tensor of ``geom`` (``pgv_conv_tap_sums``).  ``cls``: class sums of ``gy`` (``conv_class_sums`` or the bias gradient
+    of the block that owns a small-side ``gy``): only the border rows / columns of ``gy`` are read then."""
+    B = gy.shape[0]
+    C = geom.Cb if gy_is_big else geom.Cs
+    if T is None:
+        T = torch.empty(C * geom.k * geom.k, device=gy.device, dtype=torch.float64)
+        prezeroed = False
+    _chk(gy, cls)
+    _chk64(T)
+    m = geom.stride if gy_is_big else 1
+    if cls is not None and cls.numel() != C * m * m:
+        raise ValueError("conv_tap_sums: cls must hold C * m * m floats")
+    _lib.check(_lib.load().pgv_conv_tap_sums(ctypes.byref(geom.desc(B)), int(gy_is_big), _p(gy), _p(cls), _p(T),
+                                             PGV_PREZEROED if prezeroed else 0, _stream()), "pgv_conv_tap_sums")
+    return T
+
+
+def conv_class_sums(geom, gy, gy_is_big, cls=None, prezeroed=False):
+    """Per-channel sums of ``gy`` by (row mod m, column mod m) class, m = stride for the big tensor, 1 for the small one
+    (``pgv_conv_class_sums``)."""
+    B = gy.shape[0]
+    C = geom.Cb if gy_is_big else geom.Cs
+    m = geom.stride if gy_is_big else 1
+    if cls is None:
+        cls = torch.empty(C * m * m, device=gy.device, dtype=torch.float32)
+        prezeroed = False
+    _chk(gy, cls)
+    _lib.check(_lib.load().pgv_conv_class_sums(ctypes.byref(geom.desc(B)), int(gy_is_big), _p(gy), _p(cls),
+                                               PGV_PREZEROED if prezeroed else 0, _stream()), "pgv_conv_class_sums")
+    return cls
+
+
+def bn_bwd_coef(geom, B, lower_is_big, w, gw, T, scale, shift, mean, rstd, n, coef, ggamma=None, gbeta=None):
+    """BatchNorm-backward coefficients of the block below ``geom``'s block from that block's weights, weight gradient
+    and tap sums (``pgv_bn_bwd_coef``); also writes the BatchNorm parameter gradients."""
+    _chk(w, gw, scale, shift, mean, rstd, coef, ggamma, gbeta)
+    _chk64(T)
+    _lib.check(_lib.load().pgv_bn_bwd_coef(ctypes.byref(geom.desc(B)), int(lower_is_big), _p(w), _p(gw), _p(T),
+                                           _p(scale), _p(shift), _p(mean), _p(rstd), int(n), _p(coef), _p(ggamma),
+                                           _p(gbeta), _stream()), "pgv_bn_bwd_coef")
+    return coef
+
+
+def act_bwd_coef(g, a, coef, act, slope, g_y, gbias, prezeroed=False):
+    """g_y = act'(a) * (coef[0]*g + coef[1]*a + coef[2]), gbias (+)= sum g_y (``pgv_act_bwd_coef``)."""
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(g, a, coef, g_y, gbias)
+    _lib.check(_lib.load().pgv_act_bwd_coef(_p(g), _p(a), _p(coef), B, C, HW, act, slope, _p(g_y), _p(gbias),
+                                            PGV_PREZEROED if prezeroed else 0, _stream()), "pgv_act_bwd_coef")
+
+
 def bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=False):
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
@@ -206,12 +266,19 @@ def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=No
                "pgv_act_bn_bwd")
 
 
-def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, loss_acc=None):
+def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, loss_acc=None, cls=None):
     """g_y = act'(a) * 2 scale g_loss (a - x), gbias += sum over (batch, pixels): squared-error criterion + output
-    activation of a block without BatchNorm, backward in one pass.  ``loss_acc`` (zeroed scalar) += the criterion."""
+    activation of a block without BatchNorm, backward in one pass.  ``loss_acc`` (zeroed scalar) += the criterion.
+    ``cls`` (zeroed [4], single-channel tensors): += the sums of g_y by (row parity, column parity) class."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
-    _chk(a, x, g_loss, g_y, gbias, loss_acc)
+    _chk(a, x, g_loss, g_y, gbias, loss_acc, cls)
+    if cls is not None:
+        _lib.check(_lib.load().pgv_sqerr_act_bwd_cls(_p(a), _p(x), _p(g_loss), scale, B, C, HW, a.shape[-1], act, slope,
+                                                     _p(g_y), _p(gbias), _p(loss_acc), _p(cls),
+                                                     PGV_PREZEROED if prezeroed else 0, _stream()),
+                   "pgv_sqerr_act_bwd_cls")
+        return
     _lib.check(_lib.load().pgv_sqerr_act_bwd(_p(a), _p(x), _p(g_loss), scale, B, C, HW, act, slope, _p(g_y), _p(gbias),
                                              _p(loss_acc), PGV_PREZEROED if prezeroed else 0, _stream()),
                "pgv_sqerr_act_bwd")

@@ -344,37 +344,176 @@ def test_conv_prezeroed_outputs_accumulate(ops, case):
     assert rel_l2(gw2, 2 * gw1) < 1e-5
 
 
-@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64), (32, 64, 4, 2, 2, 33, 45, 6),
-                                  (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2), (1, 8, 5, 2, 2, 257, 347, 21),
-                                  (128, 256, 4, 2, 2, 9, 12, 7), (256, 512, 4, 2, 2, 5, 7, 9), (512, 2048, 1, 1, 0, 3, 4, 19),
-                                  (1, 8, 5, 2, 2, 257, 347, 70)])   # > 1024 units: persistent direct kernel, 2 units per WG
-def test_conv_bn_fuse_matches_separate_reduce(ops, case):
-    """pgv_bn_fuse: the BatchNorm-backward projections accumulated while an input-gradient kernel writes its output
-    equal those of a separate pgv_bn_bwd_reduce pass over that output (fused band / deep-layer epilogues and the
-    fallback)."""
+BWD_FUSE_CASES = [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 64), (32, 64, 4, 2, 2, 33, 45, 6),
+                  (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2), (1, 8, 5, 2, 2, 257, 347, 21),
+                  (128, 256, 4, 2, 2, 9, 12, 7), (256, 512, 4, 2, 2, 5, 7, 9), (512, 2048, 1, 1, 0, 3, 4, 19),
+                  (1, 8, 5, 2, 2, 257, 347, 70)]   # > 1024 units: persistent direct kernel, 2 units per WG
+
+
+def _bwd_apply_ref(g, a, coef, act, slope):
+    C = a.shape[1]
+    ka, kb, kc = [coef[i * C:(i + 1) * C].double().view(1, -1, 1, 1) for i in range(3)]
+    t = g.double() * ka + a.double() * kb + kc
+    if act == 1:
+        t = torch.where(a > 0, t, slope * t)
+    elif act == 2:
+        t = torch.where((a > -1) & (a < 1), t, torch.zeros_like(t))
+    return t
+
+
+@pytest.mark.parametrize("policy", [0, 3, 2, 1])
+@pytest.mark.parametrize("case", BWD_FUSE_CASES)
+def test_conv_bwd_fuse_matches_separate_pass(ops, case, policy):
+    """pgv_bwd_fuse: an input-gradient call that applies the lower block's BatchNorm + activation backward in its
+    epilogue (fused band / wave-specialised / direct epilogues, and the in-place pass every other kernel family falls
+    back to) equals the plain product followed by act'(a) * (ka*g + kb*a + kc) in float64; the bias gradient is the
+    per-channel sum of the result.  All kernel policies, all three activations."""
+    from preset_gen_vae_amd import _lib
     Cb, Cs, k, s, p, Hb, Wb, B = case
     big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = [dev(t) if torch.is_tensor(t) else t
                                                                      for t in _conv_inputs(case)]
     geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
-    for out_is_big in (True, False):
-        C = Cb if out_is_big else Cs
-        a = (big if out_is_big else small) * 0.7 + 0.1           # "saved activation" of the block below
-        mean = a.mean(dim=(0, 2, 3)).contiguous()
-        rstd = (1.0 / torch.sqrt(a.var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
-        red_f = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
-        if out_is_big:
-            out = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bn_fuse=(a, mean, rstd, red_f))
-            ref_out = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0)
-        else:
-            out = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bn_fuse=(a, mean, rstd, red_f))
-            ref_out = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0)
-        assert torch.equal(out, ref_out)
-        red_s = torch.empty(2 * C, device='cuda', dtype=torch.float64)
-        ops.bn_bwd_reduce(ref_out, a, mean, rstd, red_s)
-        # the fused path adds in float32 inside a workgroup (<= ~12k terms per slot) and in float64 across workgroups:
-        # error bound relative to the sum of |terms| (these synthetic sums cancel to ~1e-6 of it)
-        l1 = ref_out.abs().sum(dim=(0, 2, 3)).max().item() * 4.0      # |a_hat| <= ~4
-        assert (red_f - red_s).abs().max().item() <= 1e-6 * l1, (out_is_big, (red_f - red_s).abs().max().item(), l1)
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    try:
+        for out_is_big in (True, False):
+            C = Cb if out_is_big else Cs
+            a = ((big if out_is_big else small) * 1.3 + 0.1).contiguous()    # "saved activation" of the block below
+            coef = dev(torch.cat([1.0 + 0.3 * synth_vec((C,), 4.1, 0.2), 0.05 * synth_vec((C,), 4.7, 0.3),
+                                  0.02 * synth_vec((C,), 5.3, 0.8)]))
+            for act, slope in ((ops.PGV_ACT_LEAKY_RELU, 0.1), (ops.PGV_ACT_HARDTANH, 0.0), (ops.PGV_ACT_NONE, 0.0)):
+                gb = torch.zeros(C, device='cuda')
+                if out_is_big:
+                    out = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=(a, coef, gb, act, slope))
+                    g = ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0)
+                else:
+                    out = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=(a, coef, gb, act, slope))
+                    g = ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0)
+                ref = _bwd_apply_ref(g, a, coef, act, slope)
+                assert rel_l2(out, ref) < 2e-6, (out_is_big, act, rel_l2(out, ref))
+                l1 = ref.abs().sum(dim=(0, 2, 3))
+                err = (gb.double() - ref.sum(dim=(0, 2, 3))).abs()
+                assert (err <= 2e-6 * l1 + 1e-12).all(), (out_is_big, act, (err / l1).max().item())
+                # class sums of the result as a by-product (kept in the epilogue where the kernel can, else a pass)
+                gb3, cls = torch.zeros(C, device='cuda'), torch.zeros(4 * C, device='cuda')
+                fz = (a, coef, gb3, act, slope, cls)
+                out3 = (ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz) if out_is_big else
+                        ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz))
+                assert rel_l2(out3, ref) < 2e-6
+                ref_cls = torch.stack([ref[:, :, r::2, c::2].sum(dim=(0, 2, 3)) for r in range(2) for c in range(2)], dim=1)
+                assert ((cls.double().view(C, 4) - ref_cls).abs() <= 2e-6 * l1.view(C, 1) + 1e-12).all()
+                assert ((gb3.double() - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+                # the unfused entry point gives the same (in place)
+                gb2 = torch.empty(C, device='cuda')
+                g2 = g.clone()
+                ops.act_bwd_coef(g2, a, coef, act, slope, g2, gb2)
+                assert rel_l2(g2, ref) < 2e-6
+                assert ((gb2.double() - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+    finally:
+        lib.pgv_set_kernel_policy(0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(8, 16, 4, 2, 2, 129, 174, 24), (16, 32, 4, 2, 2, 64, 87, 5),
+                                               (1, 8, 5, 2, 2, 257, 347, 9), (2, 3, 2, 2, 0, 8, 10, 3)])
+def test_conv_tap_sums(ops, case):
+    """pgv_conv_tap_sums = the weight gradient a channel of ones in the OTHER tensor would receive (autograd of
+    conv2d / conv_transpose2d over a ones input), both directions."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    Hs, Ws = geom.Hs, geom.Ws
+    gy_s = synth_vec((B, Cs, Hs, Ws), 0.7719, 1.1) + 0.05
+    gy_b = synth_vec((B, Cb, Hb, Wb), 0.9137, 0.3) + 0.05
+    # gy small: T[cs][kh][kw] = d/dw <conv2d(ones_big, w[Cs,1,k,k]), gy>
+    wv = torch.zeros((Cs, 1, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.ones((B, 1, Hb, Wb), dtype=torch.float64), wv, None, stride=s, padding=p).backward(gy_s)
+    T = ops.conv_tap_sums(geom, dev(gy_s), False)
+    l1 = gy_s.abs().sum().item() / Cs
+    assert (T.cpu().view(Cs, k, k) - wv.grad[:, 0]).abs().max().item() <= 1e-6 * l1
+    # border form: class sums (here the plain channel sums) minus the positions a tap cannot pair
+    cls = ops.conv_class_sums(geom, dev(gy_s), False)
+    assert (cls.cpu().double() - gy_s.sum(dim=(0, 2, 3))).abs().max().item() <= 1e-6 * l1
+    Tb = ops.conv_tap_sums(geom, dev(gy_s), False, cls=cls)
+    assert (Tb.cpu().view(Cs, k, k) - wv.grad[:, 0]).abs().max().item() <= 2e-6 * l1
+    # gy big: T[cb][kh][kw] = d/dw <conv_transpose2d(ones_small, w[1,Cb,k,k]), gy>
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    wv = torch.zeros((1, Cb, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(torch.ones((B, 1, Hs, Ws), dtype=torch.float64), wv, None, stride=s, padding=p,
+                       output_padding=(oph, opw)).backward(gy_b)
+    T = torch.zeros(Cb * k * k, device='cuda', dtype=torch.float64)
+    ops.conv_tap_sums(geom, dev(gy_b), True, T, prezeroed=True)
+    l1 = gy_b.abs().sum().item() / Cb
+    assert (T.cpu().view(Cb, k, k) - wv.grad[0]).abs().max().item() <= 1e-6 * l1
+    if s <= 3:
+        cls = ops.conv_class_sums(geom, dev(gy_b), True)
+        ref_cls = torch.stack([gy_b[:, :, r::s, c::s].sum(dim=(0, 2, 3)) for r in range(s) for c in range(s)], dim=1)
+        assert (cls.cpu().double().view(Cb, s * s) - ref_cls).abs().max().item() <= 1e-6 * l1
+        Tb = ops.conv_tap_sums(geom, dev(gy_b), True, cls=cls)
+        assert (Tb.cpu().view(Cb, k, k) - wv.grad[0]).abs().max().item() <= 2e-6 * l1
+
+
+@pytest.mark.parametrize("policy", [0, 3])
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 6), (16, 32, 4, 2, 2, 65, 88, 9), (32, 64, 4, 2, 2, 33, 45, 12),
+                                  (64, 128, 4, 2, 2, 17, 23, 5), (1, 8, 5, 2, 2, 257, 347, 3), (3, 5, 4, 2, 2, 10, 13, 4),
+                                  (256, 512, 4, 2, 2, 5, 7, 6), (512, 2048, 1, 1, 0, 3, 4, 8)])
+def test_bn_backward_without_a_pass(ops, case, policy):
+    """The pass-free backward of [conv -> LeakyReLU -> BatchNorm] under a consumer block (model/layer.py:21-26): tap
+    sums + weight gradient of the consumer -> pgv_bn_bwd_coef -> consumer's input gradient with pgv_bwd_fuse, against
+    float64 autograd of the reference arithmetic (LeakyReLU, train-mode batch_norm, conv2d / conv_transpose2d): the
+    gradient of the pre-activation tensor, of the bias (its sum), of gamma and beta."""
+    from preset_gen_vae_amd import _lib
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    Hs, Ws = geom.Hs, geom.Ws
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    w = synth_vec((Cs, Cb, k, k), 0.6180, 0.7) * (1.0 / np.sqrt(Cb * k * k / (s * s)))
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    try:
+        for lower_is_big in (True, False):
+            C, H, W = (Cb, Hb, Wb) if lower_is_big else (Cs, Hs, Ws)
+            Co, Ho, Wo = (Cs, Hs, Ws) if lower_is_big else (Cb, Hb, Wb)
+            y = (synth_vec((B, C, H, W), 0.9137, 0.3) * 1.5 + 0.2).requires_grad_(True)   # pre-activation of block l
+            gamma = (1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)).requires_grad_(True)
+            beta = (0.3 * synth_vec((C,), 2.9, 0.6)).requires_grad_(True)
+            gy = synth_vec((B, Co, Ho, Wo), 0.7719, 1.1) + 0.03                        # gradient of block l+1's output
+            a = F.leaky_relu(y, 0.1)
+            o = F.batch_norm(a, None, None, gamma, beta, training=True, eps=1e-5)
+            if lower_is_big:
+                z = F.conv2d(o, w, None, stride=s, padding=p)
+            else:
+                z = F.conv_transpose2d(o, w, None, stride=s, padding=p, output_padding=(oph, opw))
+            z.backward(gy)
+            # device side: what the forward saved
+            ad = a.detach()
+            mean = ad.mean(dim=(0, 2, 3))
+            rstd = 1.0 / torch.sqrt(ad.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+            scale, shift = gamma.detach() * rstd, beta.detach() - mean * gamma.detach() * rstd
+            a_d, gy_d, w_d = dev(ad), dev(gy), dev(w)
+            sc_d, sh_d, mu_d, rs_d = dev(scale), dev(shift), dev(mean), dev(rstd)
+            gw = torch.empty((Cs, Cb, k, k), device='cuda')
+            if lower_is_big:
+                ops.conv_wgrad(geom, a_d, gy_d, gw, big_scale=sc_d, big_shift=sh_d)
+            else:
+                ops.conv_wgrad(geom, gy_d, a_d, gw, small_scale=sc_d, small_shift=sh_d)
+            T = ops.conv_tap_sums(geom, gy_d, not lower_is_big)
+            coef = torch.empty(3 * C, device='cuda')
+            gg, gbt = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+            ops.bn_bwd_coef(geom, B, lower_is_big, w_d, gw, T, sc_d, sh_d, mu_d, rs_d, B * H * W, coef, gg, gbt)
+            gb = torch.zeros(C, device='cuda')
+            fuse = (a_d, coef, gb, ops.PGV_ACT_LEAKY_RELU, 0.1)
+            if lower_is_big:
+                g_y = ops.conv_up(geom, gy_d, w_d, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+            else:
+                g_y = ops.conv_down(geom, gy_d, w_d, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+            # the projections are sums of n = B*H*W products g*o that cancel: error bounds relative to the sum of |g*o|
+            assert rel_l2(g_y, y.grad) < 2e-5, (lower_is_big, rel_l2(g_y, y.grad))
+            n = B * H * W
+            gscale = y.grad.abs().mean().item() * n          # ~ sum |g| per channel
+            assert (gbt.cpu().double() - beta.grad).abs().max().item() <= 2e-6 * gscale * 4
+            assert (gg.cpu().double() - gamma.grad).abs().max().item() <= 2e-6 * gscale * 16
+            assert (gb.cpu().double() - y.grad.sum(dim=(0, 2, 3))).abs().max().item() <= 2e-6 * gscale * 4
+    finally:
+        lib.pgv_set_kernel_policy(0)
 
 
 def test_conv_desc_validation(ops):
@@ -387,7 +526,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 6
+    assert _lib.load().pgv_abi_version() == 7
 
 
 def test_empty_batch(ops):

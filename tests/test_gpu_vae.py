@@ -70,13 +70,27 @@ def _record_activation_regions(run, arch):
         rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
         return orig_sq(a, x, g_loss, scale, act, slope, g_y, gbias, **kw)
 
+    # blocks whose BatchNorm + activation backward rides in the consumer's input-gradient epilogue (pgv_bwd_fuse)
+    orig_down, orig_up = ops.conv_down, ops.conv_up
+
+    def fused(orig_fn):
+        def f(*args, **kw):
+            fz = kw.get('bwd_fuse')
+            if fz is not None:
+                a, act = fz[0], fz[3]
+                rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
+            return orig_fn(*args, **kw)
+        return f
+
     ops.act_bn_bwd = patched
     ops.sqerr_act_bwd = patched_sq
+    ops.conv_down, ops.conv_up = fused(orig_down), fused(orig_up)
     try:
         out = run()
     finally:
         ops.act_bn_bwd = orig
         ops.sqerr_act_bwd = orig_sq
+        ops.conv_down, ops.conv_up = orig_down, orig_up
     names = _block_names(arch)
     assert len(rec) == len(names), (len(rec), names)
     masks = dict(zip(names, rec))
