@@ -187,7 +187,8 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
                       float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream);
 /* The same with the class sums of g_y as a by-product (see pgv_bwd_fuse.cls): planes of W columns, cls [C][4] floats
- * accumulated into (the caller clears them); single-channel tensors only (the spectrogram output layer). */
+ * accumulated into (the caller clears them); single-channel tensors with planes of >= 16384 elements only (the
+ * spectrogram output layer). */
 int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int W,
                           int act, float slope, float* g_y, float* gbias, float* loss_acc, float* cls, int flags,
                           void* stream);

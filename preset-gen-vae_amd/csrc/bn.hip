@@ -801,15 +801,16 @@ __global__ void sqerr_act_bwd_flat_kernel(const float* __restrict__ a, const flo
   }
 }
 
-// The single-channel form with the class sums of g_y as a by-product (pgv_sqerr_act_bwd_cls): the tensor is walked row
-// by row in 16-byte pieces that start at columns 4q, so a piece's column parities are fixed (even, odd, even, odd) and
-// its row parity is one bit; a workgroup owns RPB consecutive rows of the flat [B*H][W] matrix.
-constexpr int kSqRows = 24;
-__global__ __launch_bounds__(256) void sqerr_act_bwd_rows_kernel(const float* __restrict__ a, const float* __restrict__ x,
-                                                                const float* __restrict__ g_loss, float scale,
-                                                                int nrows, int H, int W, int act, float slope,
-                                                                float* __restrict__ g_y, float* __restrict__ gbias,
-                                                                float* __restrict__ loss_acc, float* __restrict__ cls) {
+// The single-channel form with the class sums of g_y as a by-product (pgv_sqerr_act_bwd_cls).  Same aligned 16-byte walk
+// over the flat tensor as above (rows of odd width start at 4-byte aligned addresses: row-wise 16-byte accesses would be
+// split by the memory pipeline and run at a third of the rate); a workgroup owns kSqChunk consecutive floats, works out
+// the (row, column) of its first element once, and every element's position from its distance to it.
+constexpr int kSqChunk = 16384;
+__global__ __launch_bounds__(256) void sqerr_act_bwd_cls_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                               const float* __restrict__ g_loss, float scale, int64_t n,
+                                                               int H, int W, int act, float slope,
+                                                               float* __restrict__ g_y, float* __restrict__ gbias,
+                                                               float* __restrict__ loss_acc, float* __restrict__ cls) {
   __shared__ float red[16];
   const float k = 2.0f * scale * g_loss[0];
   float sq = 0.f, c4[4] = {0.f, 0.f, 0.f, 0.f};   // [2 * row parity + column parity]
@@ -823,51 +824,65 @@ __global__ __launch_bounds__(256) void sqerr_act_bwd_rows_kernel(const float* __
       g = (av > -1.f && av < 1.f) ? g : 0.f;
     return g;
   };
-  const int QW = W >> 2, TW = W - (QW << 2);
-  const int row0 = blockIdx.x * kSqRows, rows = min(kSqRows, nrows - row0);
-  const float inv_qw = 1.0f / (float)max(QW, 1), inv_h = 1.0f / (float)H;
+  const int64_t start = (int64_t)blockIdx.x * kSqChunk;
+  const int len = (int)min((int64_t)kSqChunk, n - start);
+  const int HW = H * W;
+  const int pos0 = (int)(start % HW), r_start = pos0 / W, w_start = pos0 - r_start * W;
+  const float inv_w = 1.0f / (float)W;
+  auto add = [&](int rel, float v) {   // element start + rel (rel + W < 2^20; at most one plane boundary inside a chunk)
+    const int t = w_start + rel;
+    const int dr = (int)(((float)t + 0.5f) * inv_w), w = t - dr * W;
+    int r = r_start + dr;
+    r = r >= H ? r - H : r;
+    const int kc = (r & 1) * 2 + (w & 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c4[q] += kc == q ? v : 0.f;
+  };
+  const int len4 = len >> 2;
   constexpr int U = 4;
-  for (int e0 = threadIdx.x; e0 < rows * QW; e0 += 256 * U) {
+  for (int i0 = threadIdx.x; i0 < len4; i0 += 256 * U) {
     f4u av[U], xv[U];
-    int64_t off[U];
-    bool rodd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * 256;
-      const int rl = (int)(((float)e + 0.5f) * inv_qw), q = e - rl * QW;   // exact: e < 2^20
-      const int grow = row0 + rl;
-      const int b = (int)(((float)grow + 0.5f) * inv_h);                   // exact: B*H < 2^20 (checked by the launcher)
-      rodd[u] = (grow - b * H) & 1;
-      off[u] = (int64_t)grow * W + 4 * q;
-      if (e < rows * QW) {
-        av[u] = *reinterpret_cast<const f4u*>(a + off[u]);
-        xv[u] = *reinterpret_cast<const f4u*>(x + off[u]);
+      const int i = i0 + u * 256;
+      if (i < len4) {
+        av[u] = *reinterpret_cast<const f4u*>(a + start + 4 * i);
+        xv[u] = *reinterpret_cast<const f4u*>(x + start + 4 * i);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (e0 + u * 256 < rows * QW) {
+      const int i = i0 + u * 256;
+      if (i < len4) {
         f4u r;
         r.x = one(av[u].x, xv[u].x);
         r.y = one(av[u].y, xv[u].y);
         r.z = one(av[u].z, xv[u].z);
         r.w = one(av[u].w, xv[u].w);
-        *reinterpret_cast<f4u*>(g_y + off[u]) = r;
-        const float ev = r.x + r.z, od = r.y + r.w;
-        c4[0] += rodd[u] ? 0.f : ev, c4[1] += rodd[u] ? 0.f : od, c4[2] += rodd[u] ? ev : 0.f, c4[3] += rodd[u] ? od : 0.f;
+        *reinterpret_cast<f4u*>(g_y + start + 4 * i) = r;
+        // position of the first element, the other three advance the column (and wrap into the next row / plane)
+        const int t = w_start + 4 * i;
+        const int dr = (int)(((float)t + 0.5f) * inv_w);
+        int w = t - dr * W, rr = r_start + dr;
+        rr = rr >= H ? rr - H : rr;
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kc = (rr & 1) * 2 + (w & 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) c4[q] += kc == q ? rv[j] : 0.f;
+          ++w;
+          const bool wrap = w == W;
+          w = wrap ? 0 : w;
+          rr = wrap ? (rr + 1 == H ? 0 : rr + 1) : rr;
+        }
       }
     }
   }
-  for (int e = threadIdx.x; e < rows * TW; e += 256) {   // the last W % 4 columns of every row
-    const int rl = e / TW, j = e - rl * TW;
-    const int grow = row0 + rl, w = (QW << 2) + j;
-    const int b = grow / H;
-    const int64_t off = (int64_t)grow * W + w;
-    const float r = one(a[off], x[off]);
-    g_y[off] = r;
-    const int kc = ((grow - b * H) & 1) * 2 + (w & 1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c4[q] += kc == q ? r : 0.f;
+  for (int i = (len4 << 2) + threadIdx.x; i < len; i += 256) {   // (only the last chunk has a tail)
+    const float r = one(a[start + i], x[start + i]);
+    g_y[start + i] = r;
+    add(i, r);
   }
   float tot = 0.f;
 #pragma unroll
@@ -1156,18 +1171,19 @@ int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float
 int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int W,
                           int act, float slope, float* g_y, float* gbias, float* loss_acc, float* cls, int flags,
                           void* stream) {
-  PGV_CHECK_ARG(a && x && g_loss && g_y && cls && B >= 0 && C == 1 && HW > 0 && W > 0 && HW % W == 0 && HW < (1 << 20),
-                "pgv_sqerr_act_bwd_cls: bad argument (single-channel planes of fewer than 2^20 elements only)");
+  PGV_CHECK_ARG(a && x && g_loss && g_y && cls && B >= 0 && C == 1 && HW > 0 && W > 0 && HW % W == 0,
+                "pgv_sqerr_act_bwd_cls: bad argument (single-channel tensors only)");
   hipStream_t st = pgv_stream(stream);
   if (gbias && !(flags & PGV_PREZEROED)) {
     int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_sqerr_act_bwd_cls");
     if (rc) return rc;
   }
   if (B == 0) return PGV_OK;
-  const int H = HW / W, nrows = B * H;
-  PGV_CHECK_ARG((int64_t)B * H < (1 << 20) && kSqRows * (W / 4 + 1) < (1 << 20), "pgv_sqerr_act_bwd_cls: tensor too large");
-  hipLaunchKernelGGL(sqerr_act_bwd_rows_kernel, dim3((unsigned)pgv_cdiv(nrows, kSqRows)), dim3(256), 0, st, a, x, g_loss,
-                     scale, nrows, H, W, act, slope, g_y, gbias, loss_acc, cls);
+  const int H = HW / W;
+  PGV_CHECK_ARG(HW >= kSqChunk && W + kSqChunk < (1 << 20), "pgv_sqerr_act_bwd_cls: planes of at least %d elements", kSqChunk);
+  const int64_t n = (int64_t)B * HW;
+  hipLaunchKernelGGL(sqerr_act_bwd_cls_kernel, dim3((unsigned)pgv_cdiv(n, kSqChunk)), dim3(256), 0, st, a, x, g_loss, scale,
+                     n, H, W, act, slope, g_y, gbias, loss_acc, cls);
   PGV_CHECK_LAUNCH("sqerr_act_bwd_cls");
   return PGV_OK;
 }

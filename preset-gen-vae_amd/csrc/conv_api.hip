@@ -70,7 +70,8 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
     if (rc == 0 && g_policy == 0 && !g_no_v2) {
       const pgv_bwd_fuse* f = stats ? nullptr : fuse;
       rc = pgv_conv_down_v2(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, f, st);
-      fused = rc == 1 && f != nullptr;
+      fused = rc >= 1 && f != nullptr;
+      if (rc == 3) cls_done = true, rc = 1;
     }
     if (rc == 0 && g_policy == 0) {
       const pgv_bwd_fuse* f = stats ? nullptr : fuse;  // the band epilogue has one reduction slot

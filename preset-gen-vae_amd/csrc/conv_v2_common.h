@@ -221,6 +221,12 @@ inline int raise_lds_once(const void* kern, const char* who) {
 // (the loader's prefetch, the MFMA waves' weight loads); the "memory" clobber keeps LDS accesses on their side.
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 16-byte buffer load with the hardware range check, invisible to the compiler's s_waitcnt bookkeeping (the caller waits
+// by hand before it reads dst); a free function because an asm output operand cannot name a lambda capture
+__device__ __forceinline__ void v2_buffer_load_x4(f32x4& dst, unsigned byte_off, i32x4 rsrc) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rsrc) : "memory");
+}
+
 // compile-time loop helper: f(integral_constant<int, I>) for I in [0, N)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

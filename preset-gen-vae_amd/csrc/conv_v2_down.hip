@@ -59,7 +59,12 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   constexpr int WP = G::WP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
   using Stage = StageV2<CK, G::ROWS, W, WP, H>;
   constexpr int NPF = Stage::NPF;
-  static_assert(!STG || (NCH == 1 && !FUSE && ACT != 2 && Ws % 4 == 0 && S >= MTW * NT), "deferred stores");
+  static_assert(!STG || (NCH == 1 && ACT != 2 && Ws % 4 == 0 && S >= MTW * NT), "deferred stores");
+  // STG + FUSE ("APRE"): the fused backward epilogue (pgv_bwd_fuse) with the unit's saved activation prefetched into
+  // registers by the MFMA waves, one tile per k-step next to the deferred stores of the previous unit (see
+  // conv_up_ws_kernel); the class sums of the result (pgv_bwd_fuse.cls) ride along.  Plain products only.
+  constexpr bool APRE = STG && FUSE;
+  static_assert(!APRE || (!HAS_AFF && ACT == 0), "fused backward epilogue: plain input-gradient products");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile0 = lds + G::FRONT;
   float* aff = tile0 + 2 * BUF;  // [2][CB]
@@ -277,6 +282,24 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
 #pragma unroll
     for (int m = 0; m < MTW; ++m) choff[m] = (unsigned)(((wm * MTW + m) * 16 + (lane & 15)) * (Hs * Ws) * 4);
   }
+  // APRE: the saved-activation tiles of the unit being multiplied, this lane's byte offsets inside its band (or OOR), the
+  // band's descriptor; row parity of the lane's 4 pixels in every tile relative to the band's first row (bit t); class
+  // sums of the results [2 * row parity + column parity]
+  f32x4 apre[APRE ? MTW : 1][APRE ? NT : 1];
+  unsigned a4[APRE ? NT : 1];
+  i32x4 ars = {0, 0, 0, 0x00020000};
+  unsigned rbits = 0;
+  float c4[APRE ? MTW : 1][4];
+  if constexpr (APRE) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rbits |= (unsigned)(((wn * NT * 16 + 4 * (lane >> 4) + t * 16) / Ws) & 1) << t;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) c4[m][0] = c4[m][1] = c4[m][2] = c4[m][3] = 0.f;
+  }
+  auto load_a = [&](auto qc) {
+    constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
+    v2_buffer_load_x4(apre[APRE ? m : 0][APRE ? t : 0], a4[APRE ? t : 0] + choff[m], ars);
+  };
   auto store_pending = [&](auto qc) {  // tile q = m * NT + t of the pending unit
     constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
     const unsigned o4 = p4[t] + choff[m];
@@ -305,6 +328,18 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int wc_ = ch * CK * 16, wn_ = ((it + 1) % NCH) * CK * 16;  // element offsets of this / the next item's chunk
+    if constexpr (APRE) {   // where this unit's saved activation lies (one channel chunk per unit: it = unit)
+      const int u = bid + it * gridDim.x;
+      const int b = u / BANDS, band = u - b * BANDS;
+      const int Pb = min(R, Hs - band * R) * Ws;
+      ars = StageLean<CK, G::ROWS, W, WP, H, true>::band_rsrc(fuse.a, (int64_t)B * CS * (Hs * Ws) * 4,
+                                                                ((int64_t)b * CS * Hs + band * R) * Ws);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int p0 = wn * NT * 16 + 4 * (lane >> 4) + t * 16;
+        a4[t] = p0 + 4 <= Pb ? (unsigned)p0 * 4u : OOR;
+      }
+    }
     V2_ACC(3);
 #ifndef PGV_V2_NO_MFMA
     static_for<0, S>([&](auto st_c) {
@@ -315,6 +350,10 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       if constexpr (STG && st % SPREAD == 0 && st / SPREAD < MTW * NT) {
         store_pending(std::integral_constant<int, st / SPREAD>{});
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (APRE) {
+          load_a(std::integral_constant<int, st / SPREAD>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -349,6 +388,10 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       const int b = u / BANDS, band = u - b * BANDS;
       const int oh0 = band * R;
       const int Pb = min(R, Hs - oh0) * Ws;  // valid pixels of this band
+      if constexpr (APRE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unit's activation tiles have landed
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (STG)  // [this band of channel 0 of the sample .. end of the tensor)
         prs = StageLean<CK, G::ROWS, W, WP, H, true>::band_rsrc(out, (int64_t)B * CS * (Hs * Ws) * 4,
                                                                   ((int64_t)b * CS * Hs + oh0) * Ws);
@@ -357,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
         const int cl = (wm * MTW + m) * 16 + ech;
         float* orow = out + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws;
         const float* arow = FUSE ? fuse.a + ((int64_t)b * CS + cl) * (Hs * Ws) + (int64_t)oh0 * Ws : nullptr;
-        if constexpr (FUSE) {
+        if constexpr (FUSE && !APRE) {
         // tiles in groups of 8: the saved-activation loads of a group (FUSE) are all issued before the first one is
         // used - one memory latency per group, not one per tile
         constexpr int TG = 8;
@@ -429,6 +472,18 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
               y0 = f32x2{pgv_act_apply(y0.x, actp), pgv_act_apply(y0.y, actp)};
               y1 = f32x2{pgv_act_apply(y1.x, actp), pgv_act_apply(y1.y, actp)};
             }
+            if constexpr (APRE) {   // the lower block's BatchNorm + activation backward against the prefetched tile
+              const f32x4 av = apre[m][t];
+              y0 = f32x2{pgv_bwd_apply(y0.x, av.x, ka_r[m], kb_r[m], kc_r[m], actd),
+                         pgv_bwd_apply(y0.y, av.y, ka_r[m], kb_r[m], kc_r[m], actd)};
+              y1 = f32x2{pgv_bwd_apply(y1.x, av.z, ka_r[m], kb_r[m], kc_r[m], actd),
+                         pgv_bwd_apply(y1.y, av.w, ka_r[m], kb_r[m], kc_r[m], actd)};
+              if (p0 + 4 <= Pb) {    // class sums: the lane's 4 pixels lie in one row and start at an even column
+                const bool rodd = (((rbits >> t) ^ (unsigned)oh0) & 1u) != 0;
+                const float ev = y0.x + y1.x, od = y0.y + y1.y;
+                c4[m][0] += rodd ? 0.f : ev, c4[m][1] += rodd ? 0.f : od, c4[m][2] += rodd ? ev : 0.f, c4[m][3] += rodd ? od : 0.f;
+              }
+            }
             if constexpr (STG) {
               pend[m][t] = f32x4{y0.x, y0.y, y1.x, y1.y};
               if (m == 0) p4[t] = p0 + 4 <= Pb ? (unsigned)p0 * 4u : OOR;
@@ -438,8 +493,10 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
               o.x = y0.x, o.y = y0.y, o.z = y1.x, o.w = y1.y;
               if constexpr (!STG) *reinterpret_cast<f4u*>(orow + p0) = o;
               ss += y0 + y1;
-              qq = __builtin_elementwise_fma(y0, y0, qq);
-              qq = __builtin_elementwise_fma(y1, y1, qq);
+              if constexpr (!FUSE) {
+                qq = __builtin_elementwise_fma(y0, y0, qq);
+                qq = __builtin_elementwise_fma(y1, y1, qq);
+              }
             } else if (p0 < Pb) {  // the lane at the ragged end of the band
               const float x[4] = {y0.x, y0.y, y1.x, y1.y};
 #pragma unroll
@@ -469,12 +526,63 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   // Waves that share channels (NW > 1) are added up through LDS first; the loader waves have left, so this part uses
   // named waits on an LDS flag instead of a workgroup barrier.
   double* dst = stats;
-  if constexpr (FUSE) {  // bias gradient of the lower block: one float atomic per channel per MFMA wave
-    if (fuse.gbias) {
+  if constexpr (FUSE) {
+    // bias gradient of the lower block (and the class sums of g_y, APRE): ONE float atomic per value per workgroup - the
+    // 256 workgroups finish together and their atomics serialise per address (4 per workgroup cost 25 us per launch,
+    // 20 per workgroup 75 us); waves that share channels are added up through LDS first
+    constexpr int NV = APRE ? 5 : 1;
+    float vals[MTW][NV];
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const float ss = lanegroup_sum(st_s[m]);
-        if (lane < 16) atomicAdd(&fuse.gbias[(wm * MTW + m) * 16 + ech], ss);
+    for (int m = 0; m < MTW; ++m) {
+      vals[m][0] = lanegroup_sum(st_s[m]);
+      if constexpr (APRE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vals[m][1 + k] = lanegroup_sum(c4[m][k]);
+      }
+    }
+    auto flush = [&](int cl, const float (&v)[NV]) {
+      if (fuse.gbias) atomicAdd(&fuse.gbias[cl], v[0]);
+      if constexpr (APRE) {
+        if (fuse.cls) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) atomicAdd(&fuse.cls[4 * cl + k], v[1 + k]);
+        }
+      }
+    };
+    if constexpr (NW == 1) {
+      if (lane < 16) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) flush((wm * MTW + m) * 16 + ech, vals[m]);
+      }
+    } else {
+      float* red = tile0;  // [NW][CS][NV]; the input buffers are dead (the last barrier is behind us)
+      if (lane < 16) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int k = 0; k < NV; ++k) red[(wn * CS + (wm * MTW + m) * 16 + ech) * NV + k] = vals[m][k];
+      }
+      // the 4 MFMA waves rendezvous on an LDS counter (the 4 loader waves never arrive at a barrier again)
+      int* flag = reinterpret_cast<int*>(lds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wn == 0) {
+        while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < 16) {
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            const int cl = (wm * MTW + m) * 16 + ech;
+            float v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+              v[k] = 0.f;
+#pragma unroll
+              for (int j = 0; j < NW; ++j) v[k] += red[(j * CS + cl) * NV + k];
+            }
+            flush(cl, v);
+          }
+        }
       }
     }
   } else if (dst) {
@@ -551,7 +659,12 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
 #endif
 #undef PGV_DK
   // lean loader + deferred stores for the layer where they pay (129x174, one channel chunk); plain / LeakyReLU forms
+  bool with_cls = false;
   if constexpr (W == 174 && G::NCH == 1) {
+    if (fuse && !in_scale && actk == 0) {   // fused backward epilogue with the saved activation prefetched (APRE)
+      kern = (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true>;
+      with_cls = fuse->cls != nullptr;
+    }
     if (!fuse && actk != 2) {
       if (in_scale)
         kern = actk == 1 ? (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 1, true>
@@ -572,7 +685,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, in_scale, in_shift, w, bias, act,
                      slope, out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_down_v2");
-  return 1;
+  return with_cls ? 3 : 1;   // (3: handled, class sums included)
 }
 
 }  // namespace
@@ -588,7 +701,6 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
                      const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->flags & PGV_COMPUTE_BF16) return 0;
-  if (fuse && d->Hb == 129 && d->Wb == 174) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
     return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)

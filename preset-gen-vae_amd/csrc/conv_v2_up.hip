@@ -55,7 +55,13 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
   using Stage = StageV2<CK, G::ROWS, Ws, WsP, Hs, 1>;
   constexpr int NPF = Stage::NPF;
-  static_assert(!STG || (NCH == 1 && !FUSE && ACT != 2 && W % 2 == 0 && S >= MTW * NT), "deferred stores");
+  static_assert(!STG || (NCH == 1 && ACT != 2 && W % 2 == 0 && S >= MTW * NT), "deferred stores");
+  // STG + FUSE ("APRE"): the fused backward epilogue (pgv_bwd_fuse) with the saved activation of the unit PREFETCHED into
+  // registers by the MFMA waves themselves, one tile per k-step (buffer loads with the hardware range check: no branch
+  // inside the pinned k-step regions), so the epilogue finds it in registers; the stores then leave from the epilogue
+  // (registers hold the activation tile instead of a pending output tile).  Plain products only (no bias-side affine).
+  constexpr bool APRE = STG && FUSE, DEFER = STG && !FUSE;
+  static_assert(!APRE || (!HAS_AFF && ACT == 0), "fused backward epilogue: plain input-gradient products");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile0 = lds + G::FRONT;
   float* aff = tile0 + 2 * BUF;  // [2][CS]
@@ -250,20 +256,30 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   // deferred stores (STG): the previous unit's output tiles, their byte offsets inside the unit (or an out-of-range mark)
   // for the lanes that store 16 / 8 bytes, this lane's channel offsets, and the unit's buffer descriptor
   constexpr unsigned OOR = 0x80000000u;  // stays out of range after the channel offset is added
-  f32x4 pend[STG ? MTW : 1][STG ? NT : 1];
-  unsigned p4[STG ? NT : 1], p2[STG ? NT : 1], choff[STG ? MTW : 1];
+  f32x4 pend[DEFER ? MTW : 1][DEFER ? NT : 1];
+  unsigned p4[STG ? NT : 1], p2[DEFER ? NT : 1], choff[STG ? MTW : 1];
   i32x4 prs = {0, 0, 0, 0x00020000};  // zero bytes: nothing pending yet, every store is dropped
+  // APRE: the unit's saved-activation tiles (p4 = this lane's byte offset inside the unit's band, OOR without >= 2 pixels)
+  f32x4 apre[APRE ? MTW : 1][APRE ? NT : 1];
   if constexpr (STG) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) p4[t] = p2[t] = OOR;
+    for (int t = 0; t < NT; ++t) {
+      p4[t] = OOR;
+      if constexpr (DEFER) p2[t] = OOR;
+    }
 #pragma unroll
     for (int m = 0; m < MTW; ++m) choff[m] = (unsigned)(((wm * MTW + m) * 4 + (lane >> 4)) * (H * W) * 4);
   }
+  auto load_a = [&](auto qc) {  // APRE: saved activation of tile q = m * NT + t of the unit being multiplied
+    constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
+    // (a lane with 2 valid pixels at the end of a row reads 2 floats of the next row along with them: in range or zero)
+    v2_buffer_load_x4(apre[APRE ? m : 0][APRE ? t : 0], p4[t] + choff[m], prs);
+  };
   auto store_pending = [&](auto qc) {  // tile q = m * NT + t of the pending unit
     constexpr int q = decltype(qc)::value, m = q / NT, t = q - m * NT;
-    const unsigned o4 = p4[t] + choff[m], o2 = p2[t] + choff[m];
-    const f32x2 lo = {pend[m][t].x, pend[m][t].y};
-    const f32x4 all = pend[m][t];
+    const unsigned o4 = p4[t] + choff[m], o2 = p2[DEFER ? t : 0] + choff[m];
+    const f32x2 lo = {pend[DEFER ? m : 0][DEFER ? t : 0].x, pend[DEFER ? m : 0][DEFER ? t : 0].y};
+    const f32x4 all = pend[DEFER ? m : 0][DEFER ? t : 0];
     const i32x4 rs = prs;
     // (s_nop: a VALU write to the data registers of a > 8-byte store needs a wait state on gfx9; the compiler's hazard
     // recognizer cannot see into inline asm - without it some lanes stored the next instruction's result)
@@ -304,13 +320,29 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int wc_ = ch * CK, wn_ = ((it + 1) % NCH) * CK;  // first input channel of this / the next item's chunk
+    if constexpr (APRE) {   // where this unit's saved activation lies (one channel chunk per unit: it = unit)
+      const int un = bid + it * gridDim.x;
+      const int b = un / BANDS, band = un - b * BANDS;
+      prs = StageLean<CK, G::ROWS, Ws, WsP, Hs>::band_rsrc(fuse.a, (int64_t)B * CB * (H * W) * 4,
+                                                            ((int64_t)b * CB * H + 2 * band * R) * W);
+      const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tv = tof[t * 256];
+        p4[t] = ((unsigned)tv >> 28) >= 2u ? (unsigned)(tv & 0x0FFFFFFF) * 4u : OOR;
+      }
+    }
     V2_ACC(3);
     static_for<0, S>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
       constexpr int sn = st + 2;
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (STG && st < MTW * NT) {
+      if constexpr (DEFER && st < MTW * NT) {
         store_pending(st_c);  // one tile of the previous unit leaves per k-step
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (APRE && st < MTW * NT) {
+        load_a(st_c);         // one tile of this unit's saved activation arrives per k-step
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -342,14 +374,54 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       const int u0 = band * R;
       const int Rb = min(R, Hg - u0);     // grid rows of this band
       const int Hb = min(2 * Rb, H - 2 * u0);  // output rows of this band
-      if (!FUSE && ACT != 2) {
+      if constexpr (APRE) {
+        // ---- fused backward epilogue, table-driven like the plain one below; the activation tiles are in registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const int cl = (wm * MTW + m) * 4 + ech;
+          float* obase = out + (((int64_t)b * CB + cl) * H + 2 * u0) * W;
+          const f32x2 bias2 = {bias_r[m], bias_r[m]};
+          float ss = 0.f;
+          int tvn = tof[0];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int tv = tvn;
+            if (t + 1 < NT) tvn = tof[(t + 1) * 256];
+            const f32x2 y0 = f32x2{acc[m][t][0], acc[m][t][1]} + bias2, y1 = f32x2{acc[m][t][2], acc[m][t][3]} + bias2;
+            const float s0 = odd ? y0.x : y1.x, s1 = odd ? y0.y : y1.y;
+            const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+            const f32x2 rr = {r0, r1};
+            const f32x2 o01 = odd ? rr : y0, o23 = odd ? y1 : rr;
+            const f32x4 av = apre[m][t];
+            const float g0 = pgv_bwd_apply(o01.x, av.x, ka_r[m], kb_r[m], kc_r[m], actd);
+            const float g1 = pgv_bwd_apply(o01.y, av.y, ka_r[m], kb_r[m], kc_r[m], actd);
+            const float g2 = pgv_bwd_apply(o23.x, av.z, ka_r[m], kb_r[m], kc_r[m], actd);
+            const float g3 = pgv_bwd_apply(o23.y, av.w, ka_r[m], kb_r[m], kc_r[m], actd);
+            const int off = tv & 0x0FFFFFFF;
+            const unsigned nv = (unsigned)tv >> 28;
+            if (nv == 4) {
+              f4u o;
+              o.x = g0, o.y = g1, o.z = g2, o.w = g3;
+              *reinterpret_cast<f4u*>(obase + off) = o;
+              ss += (g0 + g1) + (g2 + g3);
+            } else if (nv == 2) {   // (even width: the last two pixels of a row)
+              *reinterpret_cast<float2*>(obase + off) = float2{g0, g1};
+              ss += g0 + g1;
+            }
+          }
+          st_s[m] += ss;
+        }
+      } else if (!FUSE && ACT != 2) {
         const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
         // No wave-uniform per-tile branches and no address arithmetic (a uniform branch per tile costs more than the
         // tile's arithmetic: the general path below spends ~480 clocks per tile): the geometry of the two kinds of band
         // comes from the tables computed at kernel start.  Lanes whose 4 pixels exist store 16 bytes; the lane at a row end of an odd-width image
         // stores its 1-3 pixels one by one; statistics ride in the same exec-masked blocks.
         const f32x2 slope2 = {slope, slope};
-        if constexpr (STG)  // descriptor of [this band of channel 0 of the sample .. end of the tensor)
+        if constexpr (DEFER)  // descriptor of [this band of channel 0 of the sample .. end of the tensor)
           prs = StageLean<CK, G::ROWS, Ws, WsP, Hs>::band_rsrc(out, (int64_t)B * CB * (H * W) * 4,
                                                                 ((int64_t)b * CB * H + 2 * u0) * W);
 #pragma unroll
@@ -376,17 +448,17 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
             const f32x2 o01 = odd ? rr : y0, o23 = odd ? y1 : rr;
             const int off = tv & 0x0FFFFFFF;
             const unsigned nv = (unsigned)tv >> 28;
-            if constexpr (STG) {
+            if constexpr (DEFER) {
               if (m == 0) {
                 p4[t] = nv == 4 ? (unsigned)off * 4u : OOR;
-                p2[t] = nv == 2 ? (unsigned)off * 4u : OOR;
+                p2[DEFER ? t : 0] = nv == 2 ? (unsigned)off * 4u : OOR;
               }
             }
             if (nv == 4) {
               f4u o;
               o.x = o01.x, o.y = o01.y, o.z = o23.x, o.w = o23.y;
-              if constexpr (STG) {
-                pend[m][t] = f32x4{o.x, o.y, o.z, o.w};
+              if constexpr (DEFER) {
+                pend[DEFER ? m : 0][DEFER ? t : 0] = f32x4{o.x, o.y, o.z, o.w};
               } else {
 #ifndef PGV_V2_NO_STORE
                 *reinterpret_cast<f4u*>(obase + off) = o;
@@ -400,8 +472,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
 #pragma unroll
               for (int e = 0; e < 3; ++e)
                 if (e < (int)nv) {
-                  if constexpr (STG)
-                    pend[m][t] = f32x4{ov[0], ov[1], ov[2], ov[3]};  // (even width: 2 valid pixels, stored as 8 bytes)
+                  if constexpr (DEFER)
+                    pend[DEFER ? m : 0][DEFER ? t : 0] = f32x4{ov[0], ov[1], ov[2], ov[3]};  // (even width: 2 valid pixels, stored as 8 bytes)
                   else
                     obase[off + e] = ov[e];
                   ss.x += ov[e];
@@ -507,16 +579,45 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     ws_barrier();
     V2_ACC(2);
   }
-  if constexpr (STG) static_for<0, MTW * NT>([&](auto qc) { store_pending(qc); });  // the last unit
+  if constexpr (DEFER) static_for<0, MTW * NT>([&](auto qc) { store_pending(qc); });  // the last unit
   V2_FLUSH();
   // statistics / projections: one float64 atomic per channel per workgroup (see conv_down_ws_kernel)
   double* dst = stats;
-  if constexpr (FUSE) {  // bias gradient of the lower block: one float atomic per channel per MFMA wave
-    if (fuse.gbias) {
+  if constexpr (FUSE) {
+    // bias gradient of the lower block: ONE float atomic per channel per workgroup (see conv_down_ws_kernel); waves that
+    // share channels are added up through LDS first
+    float vals[MTW];
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const float ss = group16_sum(st_s[m]);
-        if ((lane & 15) == 0) atomicAdd(&fuse.gbias[(wm * MTW + m) * 4 + ech], ss);
+    for (int m = 0; m < MTW; ++m) vals[m] = group16_sum(st_s[m]);
+    if (fuse.gbias) {
+      if constexpr (NW == 1) {
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) atomicAdd(&fuse.gbias[(wm * MTW + m) * 4 + ech], vals[m]);
+        }
+      } else {
+        float* red = tile0;  // [NW][CB]
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) red[wn * CB + (wm * MTW + m) * 4 + ech] = vals[m];
+        }
+        int* flag = reinterpret_cast<int*>(lds);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wn == 0) {
+          while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if ((lane & 15) == 0) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+              const int cl = (wm * MTW + m) * 4 + ech;
+              float v = 0.f;
+#pragma unroll
+              for (int j = 0; j < NW; ++j) v += red[j * CB + cl];
+              atomicAdd(&fuse.gbias[cl], v);
+            }
+          }
+        }
       }
     }
   } else if (dst) {
@@ -590,9 +691,11 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
     kern = actk == 0 ? PGV_UK(false, false, 0) : (actk == 1 ? PGV_UK(false, false, 1) : PGV_UK(false, false, 2));
 #endif
 #undef PGV_UK
-  if constexpr (STG) {  // (only the non-fused LeakyReLU / linear forms exist with deferred stores)
-    if (fuse || actk == 2) return 0;
-    if (in_scale)
+  if constexpr (STG) {  // (the LeakyReLU / linear forms exist with deferred stores, the plain product with the fused epilogue)
+    if (actk == 2 || (fuse && (in_scale || actk != 0))) return 0;
+    if (fuse)
+      kern = (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true>;
+    else if (in_scale)
       kern = actk == 1 ? (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 1, true>
                        : (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, true, 0, true>;
     else
@@ -624,7 +727,8 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
   if (fuse && d->Hb == 65 && d->Wb == 88) return 0;
   // fused backward epilogue (pgv_bwd_fuse), measured (us, fused / plain + separate pass): 33x45 279 / 107; 129x174 (band
   // kernel) 238 / 204 -> both run the plain form here and leave the epilogue to the in-place pass (return 2)
-  if (fuse && ((d->Hb == 33 && d->Wb == 45) || (d->Hb == 129 && d->Wb == 174))) {
+  // (129x174 since got the prefetching form of conv_up_ws_kernel: APRE)
+  if (fuse && d->Hb == 33 && d->Wb == 45) {
     const int rc = pgv_conv_up_v2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, nullptr, st);
     return rc == 1 ? 2 : rc;
   }

@@ -295,7 +295,7 @@ class ConvStackFn(torch.autograd.Function):
                 cls_cur = None
                 if fused_sq and li == nb - 1:
                     g_y = torch.empty_like(a)
-                    if wants_cls(li) and C == 1:
+                    if wants_cls(li) and C == 1 and a.shape[2] * a.shape[3] >= 16384:
                         cls_cur = cls_arena[c_off:c_off + 4]
                         c_off += 4
                     ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,

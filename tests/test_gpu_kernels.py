@@ -516,6 +516,26 @@ def test_bn_backward_without_a_pass(ops, case, policy):
         lib.pgv_set_kernel_policy(0)
 
 
+@pytest.mark.parametrize("shape", [(3, 1, 257, 347), (5, 1, 129, 128), (2, 1, 131, 174)])
+def test_sqerr_act_bwd_with_class_sums(ops, shape):
+    """pgv_sqerr_act_bwd_cls = pgv_sqerr_act_bwd plus the sums of g_y by (row parity, column parity) class."""
+    B, C, H, W = shape
+    a = dev(torch.clamp(synth_vec(shape, 0.713, 0.2) * 1.4, -1.0, 1.0))
+    x = dev(synth_vec(shape, 0.377, 0.9))
+    gl = torch.tensor(0.7, device='cuda')
+    scale = 1.0 / a.numel()
+    g1, gb1, l1 = torch.empty_like(a), torch.zeros(1, device='cuda'), torch.zeros((), device='cuda')
+    ops.sqerr_act_bwd(a, x, gl, scale, ops.PGV_ACT_HARDTANH, 0.0, g1, gb1, prezeroed=True, loss_acc=l1)
+    g2, gb2, l2 = torch.empty_like(a), torch.zeros(1, device='cuda'), torch.zeros((), device='cuda')
+    cls = torch.zeros(4, device='cuda')
+    ops.sqerr_act_bwd(a, x, gl, scale, ops.PGV_ACT_HARDTANH, 0.0, g2, gb2, prezeroed=True, loss_acc=l2, cls=cls)
+    assert torch.equal(g1, g2)
+    ref = torch.stack([g1.double()[:, :, r::2, c::2].sum() for r in range(2) for c in range(2)])
+    tol = 2e-6 * g1.double().abs().sum().item() + 1e-12
+    assert (cls.double() - ref).abs().max().item() <= tol
+    assert abs(gb2.item() - g1.double().sum().item()) <= tol and abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+
+
 def test_conv_desc_validation(ops):
     from preset_gen_vae_amd import _lib
     geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
