@@ -168,11 +168,18 @@ def launch_table(ae, B, device, frontend=None):
     activation backward passes, the output-block criterion backward, the fc GEMMs, Adam, and (``--input audio``) the
     STFT->mel front-end.  Algorithmic bytes = every operand and result moved once."""
     from preset_gen_vae_amd import ops
+    from preset_gen_vae_amd.model import layer as layer_mod
     table = []
     prev_bn = {False: False, True: False}   # does the producer block of the same stack end in a BatchNorm (folded here)?
-    for name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up in layer_ops(ae):
+    layers = layer_ops(ae)
+    fused_bwd = ops.compute_dtype() == 'fp32'   # (layer.BN_BACKWARD_MODE 'fused' applies to fp32 products only)
+    for li, (name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up) in enumerate(layers):
         fold = prev_bn[is_up]
         prev_bn[is_up] = has_bn
+        # the block below in the same stack (its BatchNorm + activation backward rides in this block's input gradient)
+        lower = layers[li - 1] if li > 0 and layers[li - 1][3] == is_up else None
+        # is this block's g_y the output gradient of a stride-2 ConvTranspose2d whose class sums the step keeps?
+        upper = layers[li + 1] if li + 1 < len(layers) and layers[li + 1][3] == is_up else None
         geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
         big = torch.randn(B, Cb, Hb, Wb, device=device)
         small = torch.randn(B, Cs, geom.Hs, geom.Ws, device=device)
@@ -188,34 +195,73 @@ def launch_table(ae, B, device, frontend=None):
         nb, ns, nw = big.numel() * 4, small.numel() * 4, w.numel() * 4
         # the launches exactly as the train step issues them: the layer's own direction carries bias + activation
         # (+ BN statistics when the block has a BatchNorm, + the producer's folded BN), the opposite direction is the
-        # plain input-gradient product
+        # input-gradient product - with the lower block's BatchNorm + activation backward in its epilogue
+        # (pgv_bwd_fuse: the saved activation is one more operand read) when there is a lower block in the stack
         fwd_stats_s = stats_s if (has_bn and not is_up) else None
         fwd_stats_b = stats_b if (has_bn and is_up) else None
 
         if not fold:   # (first block of a stack, or a producer without BatchNorm: nothing to fold)
             sc_b = sh_b = sc_s = sh_s = None
+        fuse = None
+        lo = small if is_up else big                         # the lower block's output = this block's input
+        if lower is not None and fused_bwd and lo.shape[2] * lo.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
+            Cl = lo.shape[1]
+            a_lo = torch.randn_like(lo)
+            coef = torch.cat([torch.ones(Cl, device=device), 0.01 * torch.randn(2 * Cl, device=device)])
+            gb_lo = torch.zeros(Cl, device=device)
+            # (class sums are kept when the lower block is itself a stride-2 ConvTranspose2d with a block below it)
+            lower2 = layers[li - 2] if li > 1 and layers[li - 2][3] == is_up else None
+            if lower2 is not None:   # ... whose own output plane is large enough for the pass-free backward
+                lg = ops.ConvGeom(*lower[1])
+                if lg.Hs * lg.Ws < layer_mod.PASSFREE_MIN_PLANE:
+                    lower2 = None
+            cls_lo = torch.zeros(4 * Cl, device=device) if (is_up and lower2 is not None) else None
+            fuse = (a_lo, coef, gb_lo, 1, 0.1, cls_lo)
 
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
-               bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up):
+               bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up,
+               fuse=fuse):
             if kind == 'conv_down':
                 return (lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b, stats=fs,
                                               out=out_s)) if not is_up else \
-                    (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s))
+                    (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse))
             if kind == 'conv_up':
                 return (lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s, stats=fb,
                                             out=out_b)) if is_up else \
-                    (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b))
+                    (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse))
             return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)) if not is_up else \
                 (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s))
 
         for kind in ('conv_down', 'conv_up', 'conv_wgrad'):
             if name == 'enc1' and kind == 'conv_up':
                 continue  # the first block needs no input gradient: this launch is not part of the train step
-            table.append((f"{kind}[{name}]", mk(kind), nb + ns + nw, flops))
-        # BatchNorm / activation backward passes over this block's output tensor (layer.ConvStackFn.backward)
+            is_dgrad = kind == ('conv_down' if is_up else 'conv_up')
+            extra = (ns if is_up else nb) if (is_dgrad and fuse is not None) else 0   # the saved activation
+            label = f"{kind}[{name}]" + ("+bn_act_bwd" if (is_dgrad and fuse is not None) else "")
+            table.append((label, mk(kind), nb + ns + nw + extra, flops))
         a = big if is_up else small
         C = a.shape[1]
-        if has_bn:
+        if has_bn and fused_bwd and upper is not None and a.shape[2] * a.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
+            # pass-free BatchNorm backward of this block: tap sums of the consumer's g_y (border rows / columns only) and
+            # the coefficient kernel (pgv_conv_tap_sums, pgv_bn_bwd_coef) - launch-latency-sized
+            (uCb, uCs, uk, us, up_, uHb, uWb) = upper[1]
+            ug = ops.ConvGeom(uCb, uCs, uk, us, up_, uHb, uWb)
+            gy_u = torch.randn(B, uCb, uHb, uWb, device=device) if is_up else torch.randn(B, uCs, ug.Hs, ug.Ws, device=device)
+            m_ = 2 if is_up else 1
+            cls_u = torch.zeros(gy_u.shape[1] * m_ * m_, device=device)
+            T = torch.zeros(gy_u.shape[1] * uk * uk, device=device, dtype=torch.float64)
+            wu, gwu = torch.randn(uCs, uCb, uk, uk, device=device) * 0.05, torch.randn(uCs, uCb, uk, uk, device=device)
+            one4 = [torch.ones(C, device=device) for _ in range(4)]
+            coef_o, gga, gbe = torch.empty(3 * C, device=device), torch.empty(C, device=device), torch.empty(C, device=device)
+            table.append((f"tap_sums[{name}]", (lambda ug=ug, gy_u=gy_u, T=T, cls_u=cls_u, is_up=is_up:
+                                                 ops.conv_tap_sums(ug, gy_u, is_up, T, prezeroed=True, cls=cls_u)), 0, 0.0))
+            table.append((f"bn_bwd_coef[{name}]", (lambda ug=ug, wu=wu, gwu=gwu, T=T, one4=one4, coef_o=coef_o, gga=gga,
+                                                   gbe=gbe, a=a, C=C, is_up=is_up:
+                                                   ops.bn_bwd_coef(ug, B, not is_up, wu, gwu, T, one4[0], one4[1], one4[2],
+                                                                   one4[3], a.numel() // C, coef_o, gga, gbe)),
+                          2 * wu.numel() * 4, 0.0))
+        elif has_bn:
+            # top block of a stack (or bf16 operand mode): the reduce + apply passes over this block's output tensor
             g_o, g_y = torch.randn_like(a), torch.empty_like(a)
             mean, rstd, scale = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
             red = torch.zeros(2 * C, device=device, dtype=torch.float64)
@@ -230,7 +276,9 @@ def launch_table(ae, B, device, frontend=None):
     # output block: criterion + Hardtanh backward in one pass (pgv_sqerr_act_bwd)
     xo, xt, gy = (torch.randn(B, 1, 257, 347, device=device) for _ in range(3))
     gl, gb1 = torch.ones((), device=device), torch.zeros(1, device=device)
-    table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1),
+    cls8 = torch.zeros(4, device=device) if fused_bwd else None   # (class sums of g_y for the block below, as in the step)
+    table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1,
+                                                                    prezeroed=True, cls=cls8),
                   3 * xo.numel() * 4, 0.0))
     # fc layers (encoder.mlp.1 / decoder.mlp.0): forward, input gradient, weight gradient
     lin_e, lin_d = ae.encoder.mlp[1], ae.decoder.mlp[0]
@@ -254,7 +302,8 @@ def launch_table(ae, B, device, frontend=None):
     return table
 
 
-def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS, frontend=None, traffic_file=None):
+def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS, frontend=None, traffic_file=None,
+                     traffic_ok=False):
     """Time every kind of launch of the step standalone at the bench shapes and report the one FURTHEST BELOW ITS OWN
     ROOFLINE among the launches that take at least 2 % of the step (the kernel to fix next); the table of all launches
     goes to gpurun_out/bench_kernel_table.json."""
@@ -266,17 +315,22 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
         frac = max(t_hbm, t_mfma) * 1e3 / ms if ms > 0 else 0.0
         rows.append({'launch': label, 'ms': ms, 'flops': flops, 'bytes': bytes_, 'bound': bound, 'frac': frac,
                      'share_of_step': ms / step_ms})
-    cands = [r for r in rows if r['share_of_step'] >= 0.02] or rows
+    # (launch-latency-sized helpers with no algorithmic bytes / flops of their own have no roofline to stand against)
+    priced = [r for r in rows if r['bytes'] > 0 or r['flops'] > 0]
+    cands = [r for r in priced if r['share_of_step'] >= 0.02] or priced
     worst = min(cands, key=lambda r: r['frac'])
     if worst['bound'] == 'hbm':
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
         achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, matrix_peak, 'TFLOP/s'
-    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation, if any
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation: the file is measured on
+    # the fp32 4-layer model at batch 256, so it only speaks for launches of that configuration (same labels on the
+    # 8-layer / bf16 models are other kernels or other fusions)
+    traffic = None
     try:
-        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r3_traffic.json')) as f:
             entry = json.load(f).get(worst['launch'])
-        if entry and B == 256:
+        if entry and B == 256 and traffic_ok:
             traffic = entry['hbm_bytes_per_launch']
     except (OSError, ValueError):
         pass
@@ -289,6 +343,64 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
             'conv_launches_sum_roofline_ms': round(sum(r['ms'] * r['frac'] for r in conv), 4),
             'conv_launches_sum_ms': round(sum(r['ms'] for r in conv), 4)}
     return roof, rows
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def frontend_figures(device, B=256, iters=10, cpu_seconds=6.0):
+    """the STFT -> mel -> dB -> min-max front-end on its own - GPU waveforms/s (HIP events over replays
+    of the batched kernel, inputs resident) against its HBM roofline (0.711 MB per spectrogram), and the CPU restatement
+    (oracle/audio_oracle.py, numpy) in the reference's per-item loop (data/abstractbasedataset.py:126-134), bounded."""
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    from preset_gen_vae_amd.utils.synthetic import fm_voice
+    waves = np.stack([fm_voice(idx=i) for i in range(16)])
+    wav = torch.tensor(np.tile(waves, (B // 16 + 1, 1))[:B], device=device)
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050, device=device)
+    mel.set_minmax_normalization(-120.0, 0.0)
+    out = mel.batch(wav)
+    ms = time_kernel(lambda: mel.batch(wav, out=out), iters=5)
+    per = wav.shape[1] * 4 + 257 * out.shape[-1] * 4
+    from oracle import audio_oracle as ao   # CPU baseline leg only
+    t0, n = time.perf_counter(), 0
+    while n < 4 or (time.perf_counter() - t0 < cpu_seconds and n < 64):
+        ao.minmax_normalize(ao.mel_spectrogram_db(waves[n % 16], dtype=np.float32), -120.0, 0.0)
+        n += 1
+    cpu = n / (time.perf_counter() - t0)
+    gbs = per * B / (ms * 1e-3) / 1e9
+    return {'metric': 'waveforms/sec STFT->mel->dB front-end (88576 samples -> 1x257x347)',
+            'value': round(B / ms * 1e3, 1), 'unit': 'waveforms/s', 'batch': B, 'ms_per_batch': round(ms, 4),
+            'roofline': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(gbs / HBM_PEAK_GBS, 5)},
+            'cpu_baseline': {'value': round(cpu, 2), 'unit': 'waveforms/s', 'cores': 1, 'kind': 'port',
+                             'sample': f'{n} items, numpy float32, per-item loop as data/abstractbasedataset.py:126-134'}}
+
+
+def h2d_inclusive(step, x, steps=10):
+    """The PCIe-inclusive rate (never `value`): every step starts with a pinned host -> device copy of its minibatch
+    into the captured step's input buffer, not overlapped with the previous step."""
+    host = x.detach().cpu().pin_memory()
+    dst = step.static_input if step.static_input is not None else x
+    for _ in range(2):
+        dst.copy_(host, non_blocking=True)
+        step.step(dst)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dst.copy_(host, non_blocking=True)
+        step.step(dst)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'value': round(x.shape[0] / dt, 2), 'unit': 'spectrograms/s', 'ms_per_step': round(dt * 1e3, 4),
+            'note': 'pinned host -> device copy of the minibatch (91 MB) in front of every step, not overlapped'}
 
 
 def cpu_baseline(arch, dim_z, B, max_seconds=25.0):
@@ -327,9 +439,16 @@ def cpu_baseline(arch, dim_z, B, max_seconds=25.0):
             times.append(dt)
         if time.perf_counter() - t_start > max_seconds and len(times) >= 2:
             break
+    # one thread (SURVEY section 8d asks for it next to the all-cores figure): a single step, bounded
+    torch.set_num_threads(1)
+    one_thread = None
+    if time.perf_counter() - t_start < 1.6 * max_seconds:
+        _, dt1 = one(state, 0)
+        one_thread = round(B / dt1, 2)
     torch.set_num_threads(default_threads)
     med = float(np.median(times)) if times else dt
     return {'value': round(B / med, 2), 'unit': 'spectrograms/s', 'cores': best_threads, 'kind': 'port',
+            'host_logical_cpus': os.cpu_count(), 'host_cpu_model': _cpu_model(), 'one_thread_value': one_thread,
             'sample': f'{len(times)} timed train steps (after 3 warm-up) of {arch} dz={dim_z} fp32 at batch {B} '
                       f'on torch CPU ops with {best_threads} threads (fastest of 8..{default_threads}), '
                       f'median {med * 1e3:.1f} ms/step'}
@@ -405,10 +524,13 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     assert np.isfinite(loss), "non-finite loss in the timed region"
     ms = elapsed / args.steps * 1e3
 
-    roof, table, cpu = None, None, None
+    roof, table, cpu, h2d = None, None, None, None
+    if rank == 0 and world == 1 and with_cpu and frontend is None:
+        h2d = h2d_inclusive(step, x)
     if rank == 0 and with_roofline:
         roof, table = measure_roofline(ae, args.batch, device, ms, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
-                                       else F32_MATRIX_PEAK_TFLOPS, frontend=frontend)
+                                       else F32_MATRIX_PEAK_TFLOPS, frontend=frontend,
+                                       traffic_ok=(args.arch == 'speccnn4l1_bn' and args.dtype == 'fp32'))
     if rank == 0 and world == 1 and with_cpu:
         cpu = cpu_baseline(args.arch, args.dim_z, args.cpu_batch)
     if world > 1:
@@ -436,6 +558,8 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
             "dtype": "bf16" if args.dtype == 'bf16' else "f32", "data": "synthetic", "config": cfg,
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if h2d is not None:
+            line["h2d_inclusive"] = h2d
         if table is not None:
             line["_table"] = table
     if step.grad_sync is not None:
@@ -494,6 +618,8 @@ def main():
         table = line.pop("_table", None)
         if extras:
             line["extra"] = extras
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:
+            line["frontend"] = frontend_figures(device)
         if table is not None:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', 'bench_kernel_table.json'), 'w') as f:

@@ -242,7 +242,8 @@ int pgv_sqerr_bwd(const float* xhat, const float* x, const float* g_loss, int64_
 /* hyper: device float[4] = {lr, bias_correction1 = 1-b1^t, bias_correction2 = 1-b2^t, grad_scale}. */
 int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
                   float beta2, float eps, float weight_decay, void* stream);
-/* Device-side step counter: pows (device double[2], initialised to {1,1}) *= {beta1,beta2};
+/* Device-side step counter: pows (device double[3], initialised to {1,1,0}): pows[0] *= beta1, pows[1] *= beta2,
+ * pows[2] += 1 (the number of steps taken: the powers underflow - beta1^t after ~7000 steps - and cannot be inverted);
  * hyper[1] = 1-pows[0], hyper[2] = 1-pows[1].  Keeps the bias corrections advancing under hipGraph replay. */
 int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* stream);
 

@@ -258,6 +258,7 @@ __global__ void adam_tick_kernel(double* __restrict__ pows, float* __restrict__ 
     const double p1 = pows[0] * beta1, p2 = pows[1] * beta2;
     pows[0] = p1;
     pows[1] = p2;
+    pows[2] += 1.0;  // the step count itself: beta1^t underflows after ~7000 steps and cannot be inverted for it
     hyper[1] = (float)(1.0 - p1);
     hyper[2] = (float)(1.0 - p2);
   }

@@ -95,30 +95,34 @@ class BasicVAE(nn.Module):
             object.__setattr__(self.encoder, '_rng', rng)
             object.__setattr__(self.decoder, '_rng', rng)
             rng.begin()
-        z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
-        n_minibatch = z_mu_logvar.size()[0]
-        if self.training:
-            if eps is None:
-                eps = rng.normal((n_minibatch, self.dim_z))
-            # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
-            # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
-            kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
-            z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)
-            z_mu_logvar._pgv_kl = (kl_scale, kl)
-        else:  # eval mode: no random sampling (VAE.py:57-58)
-            z_sampled = _ReparamFn.apply(z_mu_logvar, None)
-        kind = self.fuse_recons_criterion
-        if self.training and kind is not None and x.shape[1] == 1:
-            deferred = kind.endswith('+deferred')    # value delivered by the backward kernel (layer.ConvStackFn)
-            scale = {'mse_mean': 1.0 / x.numel(), 'l2_batch': 1.0 / x.shape[0],
-                     'l2_batch_contents': 1.0 / x.numel()}[kind.split('+')[0]]
-            x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x,
-                                         sq_scale=-scale if deferred else scale)
-            x_out._pgv_recons = (x.data_ptr(), scale, recons)
-        else:
-            x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
-        if rng is not None:
-            rng.flush()
+        try:
+            z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
+            n_minibatch = z_mu_logvar.size()[0]
+            if self.training:
+                if eps is None:
+                    eps = rng.normal((n_minibatch, self.dim_z))
+                # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
+                # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
+                kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
+                z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)
+                z_mu_logvar._pgv_kl = (kl_scale, kl)
+            else:  # eval mode: no random sampling (VAE.py:57-58)
+                z_sampled = _ReparamFn.apply(z_mu_logvar, None)
+            kind = self.fuse_recons_criterion
+            if self.training and kind is not None and x.shape[1] == 1:
+                deferred = kind.endswith('+deferred')    # value delivered by the backward kernel (layer.ConvStackFn)
+                scale = {'mse_mean': 1.0 / x.numel(), 'l2_batch': 1.0 / x.shape[0],
+                         'l2_batch_contents': 1.0 / x.numel()}[kind.split('+')[0]]
+                x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x,
+                                             sq_scale=-scale if deferred else scale)
+                x_out._pgv_recons = (x.data_ptr(), scale, recons)
+            else:
+                x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)
+        finally:
+            # also when the encoder / decoder raises: a generator left in deferred mode would hand every later
+            # stand-alone training-mode call the same Dropout masks (its offset would never advance)
+            if rng is not None:
+                rng.flush()
         return z_mu_logvar, z_sampled, z_sampled, _zero_log_abs_det_jac(n_minibatch, x.device), x_out
 
     def latent_loss(self, z_0_mu_logvar, z_0_sampled=None, z_K_sampled=None, log_abs_det_jac=None, **kwargs):

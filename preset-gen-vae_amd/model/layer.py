@@ -116,6 +116,7 @@ def _step_zeros(param, n, dtype, tag, device):
 # 'fused': BatchNorm + activation backward of every block that has a consumer inside its stack rides in that consumer's
 # input-gradient epilogue (no pass over the gradient); 'passes': the reduce + apply passes for every block (A/B aid).
 BN_BACKWARD_MODE = 'fused'
+PASSFREE_MIN_PLANE = 1024   # H*W of the block's output from which the pass-free backward is used
 
 
 def set_bn_backward_mode(mode):
@@ -246,7 +247,10 @@ class ConvStackFn(torch.autograd.Function):
                 up = blocks[li + 1]
                 gsz = saved[li + 1][7]
                 hy, wy = (gsz.Hb, gsz.Wb) if up.up else (gsz.Hs, gsz.Ws)
-                passfree[li] = up.k <= 5 and hy <= 1024 and wy <= 1024
+                # (only where the consumer's input-gradient kernel has the fused epilogue to gain from - the large planes:
+                # on the deep layers' small planes the coefficient / tap-sum launches cost what the reduce pass did)
+                passfree[li] = (up.k <= 5 and hy <= 1024 and wy <= 1024 and
+                                saved[li][3].shape[2] * saved[li][3].shape[3] >= PASSFREE_MIN_PLANE)
         n_red = sum(2 * blk.c_out for li, (blk, sv) in enumerate(zip(blocks, saved))
                     if blk.bn is not None and sv[5] is not None and not passfree[li])
         arena = _step_zeros(params[0], n_red, torch.float64, 'red', dev) if n_red else None  # BN-backward projections

@@ -128,14 +128,20 @@ def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stat
 
 
 _ws_cache = {}
+_ws_retired = []   # superseded workspaces: a captured hipGraph may still write its partial gradients into them
 
 
 def _workspace(device, nbytes):
+    """Weight-gradient workspace of the CURRENT stream on ``device`` (pgv_hip.h: private to a call until it has completed
+    on its stream - calls on different streams must not share one).  A buffer that is outgrown is kept alive instead of
+    being returned to the allocator: graphs captured earlier replay into its address."""
     if nbytes <= 0:
         return None
-    key = (device.index,)
+    key = (device.index, _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
         ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
         _ws_cache[key] = ws
     return ws

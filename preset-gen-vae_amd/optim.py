@@ -113,7 +113,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
         self.hyper = torch.tensor([lr, 1.0, 1.0, grad_scale], device=dev, dtype=torch.float32)
-        self.pows = torch.ones(2, device=dev, dtype=torch.float64)
+        self.pows = torch.tensor([1.0, 1.0, 0.0], device=dev, dtype=torch.float64)   # beta1^t, beta2^t, t
         self._lr = lr
         self._offset_of = {id(p): o for p, o in zip(flat.params, flat.offsets)}
 
@@ -159,14 +159,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     # -- checkpoints (logs/logger.py:199-202 saves optimizer.state_dict(), train.py:177-179 restores it) ----------
     def step_count(self):
-        """Number of updates applied so far, recovered from the device-side beta1^t (the count advances on the device so
-        that captured steps replay correctly; reading it synchronises - checkpoint time only)."""
-        b1 = self.param_groups[0]['betas'][0]
-        p0 = float(self.pows[0].item())
-        if p0 >= 1.0 or not 0.0 < b1 < 1.0:
-            return 0
-        import math
-        return int(round(math.log(p0) / math.log(b1)))
+        """Number of updates applied so far: an explicit device-side counter next to the powers of beta (it advances on
+        the device so that captured steps replay correctly; reading it synchronises - checkpoint time only).  The count
+        is NOT recovered from beta1^t, which underflows to zero after ~7000 steps."""
+        return int(round(float(self.pows[2].item())))
 
     def state_dict(self):
         """torch.optim.Adam's layout: ``state[i] = {'step', 'exp_avg', 'exp_avg_sq'}`` per parameter i of
@@ -214,7 +210,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one fused step counter only")
         t = steps.pop() if steps else 0
         b1, b2 = g['betas']
-        self.pows.copy_(torch.tensor([b1 ** t, b2 ** t], dtype=torch.float64))
+        self.pows.copy_(torch.tensor([b1 ** t, b2 ** t, float(t)], dtype=torch.float64))
         self.hyper[1:3].copy_(torch.tensor([1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32))
         self.set_lr(groups[0]['lr'])
 

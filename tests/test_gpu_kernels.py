@@ -58,7 +58,10 @@ def _affine(t, sc, sh):
     return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
+# kernel policies (pgv_set_kernel_policy): 0 = tuned (wave-specialised, then band kernels), 3 = the same without the
+# wave-specialised generation (band kernels at the reference shapes: the no-workspace wgrad fallback and the bf16 path),
+# 2 = runtime-stride MFMA kernels, 1 = generic
+@pytest.mark.parametrize("policy", [0, 3, 2, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_down_up_wgrad(ops, case, policy):
     from preset_gen_vae_amd import _lib
@@ -195,7 +198,7 @@ def _affine_fma(t, sc, sh):
     return (t.float().double() * sc.float().double().view(1, -1, 1, 1) + sh.float().double().view(1, -1, 1, 1)).float()
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
+@pytest.mark.parametrize("policy", [0, 3, 2, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_bf16_operand_mode(ops, case, policy):
     """PGV_COMPUTE_BF16 (BASELINE config 2): both operands of every product rounded to bfloat16 (after the lazy
@@ -534,6 +537,35 @@ def test_sqerr_act_bwd_with_class_sums(ops, shape):
     tol = 2e-6 * g1.double().abs().sum().item() + 1e-12
     assert (cls.double() - ref).abs().max().item() <= tol
     assert abs(gb2.item() - g1.double().sum().item()) <= tol and abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+
+
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 5), (16, 32, 4, 2, 2, 65, 88, 7), (32, 64, 4, 2, 2, 33, 45, 9),
+                                  (1, 8, 5, 2, 2, 257, 347, 3), (3, 5, 4, 2, 2, 10, 13, 2)])
+def test_conv_wgrad_without_workspace(ops, case):
+    """pgv_conv_wgrad with a NULL (or too small) workspace: the wave-specialised kernels need one partial gradient per
+    workgroup there, so the call must fall back to the kernels that flush with float atomics (pgv_hip.h) - same result,
+    overwrite and PGV_PREZEROED accumulate semantics."""
+    import ctypes
+    from preset_gen_vae_amd import _lib
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    wv = w.clone().requires_grad_(True)
+    F.conv2d(_affine(big, sc_b, sh_b), wv, None, stride=s, padding=p).backward(small)
+    lib = _lib.load()
+    bd, sd, scd, shd = dev(big), dev(small), dev(sc_b), dev(sh_b)
+    st = torch.cuda.current_stream().cuda_stream
+    for ws_bytes in (0, 64):
+        ws = torch.empty(16, device='cuda') if ws_bytes else None
+        gw = torch.full((Cs, Cb, k, k), 7.0, device='cuda')
+        _lib.check(lib.pgv_conv_wgrad(ctypes.byref(geom.desc(B)), bd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                      sd.data_ptr(), None, None, gw.data_ptr(), None if ws is None else ws.data_ptr(),
+                                      ws_bytes, st), "pgv_conv_wgrad")
+        assert rel_l2(gw, wv.grad) < 5e-5          # overwritten
+        _lib.check(lib.pgv_conv_wgrad(ctypes.byref(geom.desc(B, ops.PGV_PREZEROED)), bd.data_ptr(), scd.data_ptr(),
+                                      shd.data_ptr(), sd.data_ptr(), None, None, gw.data_ptr(),
+                                      None if ws is None else ws.data_ptr(), ws_bytes, st), "pgv_conv_wgrad")
+        assert rel_l2(gw, 2 * wv.grad) < 5e-5      # accumulated into
 
 
 def test_conv_desc_validation(ops):

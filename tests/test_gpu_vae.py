@@ -817,6 +817,51 @@ def test_fused_frontend_into_step():
     assert np.isfinite(l0) and np.isfinite(l1) and abs(l0 - l1) > 1e-3 * abs(l0)
 
 
+def test_optimizer_step_count_survives_underflow_of_beta1_power():
+    """A reference-length run takes ~37 k steps; beta1^t (0.9^t, float64) is denormal from t ~ 7040 and exactly 0 from
+    t ~ 7070, so the step count must be an explicit counter: a checkpoint at t = 12 345 loads, reports the same count,
+    saves again, takes a step (bias corrections = 1 - 0 = 1 exactly as torch.optim.Adam computes them) and reports
+    t + 1; a state_dict saved after many real device-side ticks carries the tick count."""
+    from preset_gen_vae_amd import _lib, optim
+    torch.manual_seed(7)
+    shapes = [(33, 5), (17,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    flat = optim.FlatParams(ps)
+    opt = optim.FusedAdam(flat, lr=1e-3, weight_decay=1e-4)
+    t0 = 12345
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(ref_ps, lr=1e-3, weight_decay=1e-4)
+    m = [torch.randn(s, device='cuda') * 0.01 for s in shapes]
+    v = [torch.rand(s, device='cuda') * 1e-4 for s in shapes]
+    sd = {'state': {i: {'step': torch.tensor(float(t0)), 'exp_avg': m[i].clone(), 'exp_avg_sq': v[i].clone()}
+                    for i in range(len(shapes))},
+          'param_groups': [dict(ref.state_dict()['param_groups'][0])]}
+    opt.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    assert opt.step_count() == t0
+    sd2 = opt.state_dict()                      # (used to raise: log(0.0))
+    assert int(sd2['state'][0]['step']) == t0
+    g = [torch.randn(s, device='cuda') * 0.1 for s in shapes]
+    opt.zero_grad()
+    for p, gg in zip(ps, g):
+        p.grad.copy_(gg)
+    opt.step()
+    for p, gg in zip(ref_ps, g):
+        p.grad = gg.clone()
+    ref.step()
+    assert opt.step_count() == t0 + 1
+    for a, b in zip(ps, ref_ps):
+        assert (a.detach() - b.detach()).abs().max().item() <= 1e-6 * b.detach().abs().max().item()
+    # many device-side ticks (what graph replays do): the counter follows, the powers underflow quietly
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(8000):
+        _lib.check(lib.pgv_adam_tick(opt.pows.data_ptr(), opt.hyper.data_ptr(), 0.9, 0.999, st), "pgv_adam_tick")
+    assert opt.step_count() == t0 + 1 + 8000
+    assert opt.pows[0].item() == 0.0 and opt.hyper[1].item() == 1.0
+    assert int(opt.state_dict()['state'][1]['step']) == t0 + 1 + 8000
+
+
 def test_optimizer_state_resume():
     """Checkpointed ``optimizer_state_dict`` (logs/logger.py:199-202, train.py:177-179): after 3 steps the state goes
     into a fresh FusedAdam AND into torch.optim.Adam; all three take the same 4th step."""
