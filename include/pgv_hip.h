@@ -120,6 +120,15 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small, const float* i
 int pgv_bn_bwd_coef(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T,
                     const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
                     float* coef, float* ggamma, float* gbeta, void* stream);
+/* pgv_conv_tap_sums (border form when cls is given) followed by pgv_bn_bwd_coef, as one call: gy is the other operand
+ * of the consumer's weight gradient (its output gradient).  T: [C_gy * kh*kw + 1] doubles of scratch holding zeros
+ * (flags & PGV_PREZEROED) or cleared by the call.  (A single-launch form - the last workgroup of the tap-sum kernel
+ * computing the coefficients - was measured at 43-164 us against 5 + 5: one workgroup streaming the whole weight
+ * gradient is far slower than a launch.) */
+int pgv_bn_bwd_coef_from_gy(const pgv_conv_desc* d, int lower_is_big, const float* gy, const float* cls, double* T,
+                            const float* w, const float* gw, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int64_t n, float* coef, float* ggamma, float* gbeta, int flags,
+                            void* stream);
 /* T[c][kh][kw] = sum over the batch and over the positions of gy[:,c] that kernel tap (kh,kw) pairs with a position
  * inside the OTHER tensor of d (what a channel of ones there would receive as weight gradient).  gy_is_big != 0: gy is
  * the big tensor [B,Cb,Hb,Wb] (gradient of a ConvTranspose2d output), else the small one.  T: [C][kh*kw] doubles,
@@ -167,6 +176,16 @@ int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 /* o = a*scale[c]+shift[c]  (materialised BN output; in place allowed). */
 int pgv_affine_nchw(const float* a, const float* scale, const float* shift, int B, int C, int HW, float* o,
                     void* stream);
+/* nn.BatchNorm1d over x[B][C] (encoder.py:86-87: the 'bn' latent regularisation), train mode, one launch per direction
+ * (the tensor is [256][128]: statistics / finalize / apply as separate launches cost more in launch latency than in
+ * work).  Forward: batch statistics in float64, y = x*scale + shift, saves scale / mean / rstd for the backward,
+ * momentum update of the running statistics with the unbiased variance, num_batches_tracked += 1 (any of those
+ * pointers may be NULL).  Backward: gx = scale*(g - mean(g) - x_hat*mean(g*x_hat)), ggamma = sum g*x_hat, gbeta = sum g. */
+int pgv_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta, float eps, float momentum,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* scale,
+                 float* mean, float* rstd, void* stream);
+int pgv_bn1d_bwd(const float* g, const float* x, const float* scale, const float* mean, const float* rstd, int B, int C,
+                 float* gx, float* ggamma, float* gbeta, void* stream);
 /* red[0:C] = sum g_o, red[C:2C] = sum g_o * a_hat, a_hat=(a-mean)*rstd. Overwrites red (flags: PGV_PREZEROED). */
 int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const float* rstd, int B, int C,
                       int HW, double* red, int flags, void* stream);

@@ -49,7 +49,11 @@ SIGNATURES = {
     "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "pgv_affine_nchw": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pgv_bn1d_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pgv_bn1d_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "pgv_bn_bwd_coef": (c_int, [_DESC, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "pgv_bn_bwd_coef_from_gy": (c_int, [_DESC, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int,
+                                        _P]),
     "pgv_conv_tap_sums": (c_int, [_DESC, c_int, _P, _P, _P, c_int, _P]),
     "pgv_conv_class_sums": (c_int, [_DESC, c_int, _P, _P, c_int, _P]),
     "pgv_act_bwd_coef": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),

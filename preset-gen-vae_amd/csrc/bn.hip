@@ -167,6 +167,90 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, doub
   if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
 }
 
+// nn.BatchNorm1d over x[B][C] (model/encoder.py:86-87), train mode, each direction in ONE launch: the tensor is tiny
+// ([256][128]), the separate statistics / finalize / apply launches cost a dependent-launch latency each.
+// A workgroup owns 32 consecutive channels (one 128-byte row segment), 8 row groups of threads walk the batch.
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float momentum, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var,
+                                                       int64_t* __restrict__ num_batches_tracked, float* __restrict__ y,
+                                                       float* __restrict__ scale_out, float* __restrict__ mean_out,
+                                                       float* __restrict__ rstd_out) {
+  __shared__ double ps[8][32], pq[8][32];
+  __shared__ float sc_s[32], sh_s[32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int b = rg; b < B; b += 8) {
+      const double v = x[(int64_t)b * C + c];
+      s += v;
+      q = fma(v, v, q);
+    }
+  ps[rg][cl] = s, pq[rg][cl] = q;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += ps[k][cl], q += pq[k][cl];
+    const double inv_n = 1.0 / (double)B, mean = s * inv_n;
+    double var = q * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+    const float sc = (float)(g * rstd), sh = (float)(bt - mean * g * rstd);
+    sc_s[cl] = sc, sh_s[cl] = sh;
+    if (scale_out) scale_out[c] = sc;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (rstd_out) rstd_out[c] = (float)rstd;
+    const double unbias = B > 1 ? (double)B / (double)(B - 1) : 1.0;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
+  }
+  __syncthreads();
+  if (c < C) {
+    const float sc = sc_s[cl], sh = sh_s[cl];
+    for (int b = rg; b < B; b += 8) y[(int64_t)b * C + c] = fmaf(x[(int64_t)b * C + c], sc, sh);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                       const float* __restrict__ scale, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int B, int C,
+                                                       float* __restrict__ gx, float* __restrict__ ggamma,
+                                                       float* __restrict__ gbeta) {
+  __shared__ double ps[8][32], pq[8][32];
+  __shared__ float c1_s[32], c2_s[32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const float mu = c < C ? mean[c] : 0.f, rs = c < C ? rstd[c] : 0.f, sc = c < C ? scale[c] : 0.f;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int b = rg; b < B; b += 8) {
+      const float gv = g[(int64_t)b * C + c], xh = (x[(int64_t)b * C + c] - mu) * rs;
+      s += (double)gv;
+      q += (double)(gv * xh);
+    }
+  ps[rg][cl] = s, pq[rg][cl] = q;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += ps[k][cl], q += pq[k][cl];
+    if (ggamma) ggamma[c] = (float)q;
+    if (gbeta) gbeta[c] = (float)s;
+    c1_s[cl] = (float)(s / (double)B), c2_s[cl] = (float)(q / (double)B);
+  }
+  __syncthreads();
+  if (c < C) {
+    const float c1 = c1_s[cl], c2 = c2_s[cl];
+    for (int b = rg; b < B; b += 8) {
+      const int64_t i = (int64_t)b * C + c;
+      gx[i] = sc * (g[i] - c1 - (x[i] - mu) * rs * c2);
+    }
+  }
+}
+
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
                                       float* __restrict__ scale, float* __restrict__ shift) {
@@ -442,7 +526,7 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < M; ++k) part[k] = 0.f;
         if (M == 2) {
-          part[0] = vv[0] + vv[2], part[1] = vv[1] + vv[3];
+          part[0] = vv[0] + vv[2], part[M > 1 ? 1 : 0] = vv[1] + vv[3];
         } else {
           // (columns 4q + j: class (4q + j) mod M depends on q - generic, slow path)
           const int e = e0 + u * 256;
@@ -471,6 +555,47 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict
     const float t = pgv_block_sum(acc[i], red);
     if (threadIdx.x == 0) atomicAdd(&cls[c * M * M + i], t);
   }
+}
+
+// Coefficients of channel c of the lower block from S_o = sum w*gw and S_1 = sum w*T over the weight slice of c
+// (block-wide: every thread of a 256-thread workgroup calls it; T_of(i) reads tap sum i).
+struct CoefArgs {
+  const float *w, *gw, *scale, *shift, *mean, *rstd;
+  float *coef, *ggamma, *gbeta;
+  double inv_n;
+  int Cb, Cs, KK, lower_is_big, bf16, C;   // C = channels of the lower block
+};
+template <typename TF>
+__device__ __forceinline__ void bn_bwd_coef_channel(const CoefArgs& ca, int c, TF T_of, double* red /* >= 16 doubles */) {
+  const int n_other = ca.lower_is_big ? ca.Cs : ca.Cb;
+  const int total = n_other * ca.KK;
+  double so = 0.0, s1 = 0.0;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int co = e / ca.KK, tap = e - co * ca.KK;
+    const int64_t idx = ca.lower_is_big ? ((int64_t)co * ca.Cb + c) * ca.KK + tap : ((int64_t)c * ca.Cb + co) * ca.KK + tap;
+    const double wv = (double)pgv_opnd(ca.w[idx], ca.bf16 != 0);
+    so = fma(wv, (double)ca.gw[idx], so);
+    s1 = fma(wv, T_of(co * ca.KK + tap), s1);
+  }
+  so = pgv_block_sum_d(so, red);
+  s1 = pgv_block_sum_d(s1, red);
+  if (threadIdx.x == 0) {
+    const double sc = ca.scale[c], sh = ca.shift[c], mu = ca.mean[c], rs = ca.rstd[c];
+    // o = gamma*a_hat + beta:  sum g*a_hat = (sum g*o - beta * sum g) / gamma
+    const double gamma = sc / rs, beta = sh + mu * sc;
+    const double s2 = sc != 0.0 ? (so - beta * s1) / gamma : 0.0;
+    ca.coef[c] = (float)sc;
+    ca.coef[ca.C + c] = (float)(-sc * rs * s2 * ca.inv_n);
+    ca.coef[2 * ca.C + c] = (float)(-sc * (s1 - mu * rs * s2) * ca.inv_n);
+    if (ca.ggamma) ca.ggamma[c] = (float)s2;
+    if (ca.gbeta) ca.gbeta[c] = (float)s1;
+  }
+}
+
+// One workgroup per channel c of the lower block.
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(CoefArgs ca, const double* __restrict__ T) {
+  __shared__ double red[16];
+  bn_bwd_coef_channel(ca, blockIdx.x, [&](int i) { return T[i]; }, red);
 }
 
 // T[c][kh][kw] = cls[c][class of the tap] - sum of gy over the positions of that class the tap does NOT pair with a
@@ -616,41 +741,6 @@ static bool tap_axis(bool gy_is_big, int n, int K, int s, int p, int o_ext, int*
   for (int i = 0; i < b; ++i) m[kTapStrip + i] = mask(n - b + i);
   *lead = a, *trail = b;
   return true;
-}
-
-// One workgroup per channel c of the lower block: S_o = sum w*gw and S_1 = sum w*T over the weight slice of c.
-__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ w, const float* __restrict__ gw,
-                                                          const double* __restrict__ T, int Cb, int Cs, int KK,
-                                                          int lower_is_big, int bf16, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, double inv_n, int C,
-                                                          float* __restrict__ coef, float* __restrict__ ggamma,
-                                                          float* __restrict__ gbeta) {
-  __shared__ double red[16];
-  const int c = blockIdx.x;
-  const int n_other = lower_is_big ? Cs : Cb;
-  const int total = n_other * KK;
-  double so = 0.0, s1 = 0.0;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int co = e / KK, tap = e - co * KK;
-    const int64_t idx = lower_is_big ? ((int64_t)co * Cb + c) * KK + tap : ((int64_t)c * Cb + co) * KK + tap;
-    const double wv = (double)pgv_opnd(w[idx], bf16 != 0);
-    so = fma(wv, (double)gw[idx], so);
-    s1 = fma(wv, T[(int64_t)co * KK + tap], s1);
-  }
-  so = pgv_block_sum_d(so, red);
-  s1 = pgv_block_sum_d(s1, red);
-  if (threadIdx.x == 0) {
-    const double sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
-    // o = gamma*a_hat + beta:  sum g*a_hat = (sum g*o - beta * sum g) / gamma
-    const double gamma = sc / rs, beta = sh + mu * sc;
-    const double s2 = sc != 0.0 ? (so - beta * s1) / gamma : 0.0;
-    coef[c] = (float)sc;
-    coef[C + c] = (float)(-sc * rs * s2 * inv_n);
-    coef[2 * C + c] = (float)(-sc * (s1 - mu * rs * s2) * inv_n);
-    if (ggamma) ggamma[c] = (float)s2;
-    if (gbeta) gbeta[c] = (float)s1;
-  }
 }
 
 // g_y = act'(a) * (A*g + Bc*a + Cc), gbias += sum g_y: the separate-pass form of pgv_bwd_fuse
@@ -977,6 +1067,25 @@ int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, c
   return PGV_OK;
 }
 
+int pgv_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta, float eps, float momentum,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* scale,
+                 float* mean, float* rstd, void* stream) {
+  PGV_CHECK_ARG(x && y && B > 0 && C > 0, "pgv_bn1d_fwd: bad argument");
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)pgv_cdiv(C, 32)), dim3(256), 0, pgv_stream(stream), x, B, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches_tracked, y, scale, mean, rstd);
+  PGV_CHECK_LAUNCH("bn1d_fwd");
+  return PGV_OK;
+}
+
+int pgv_bn1d_bwd(const float* g, const float* x, const float* scale, const float* mean, const float* rstd, int B, int C,
+                 float* gx, float* ggamma, float* gbeta, void* stream) {
+  PGV_CHECK_ARG(g && x && scale && mean && rstd && gx && B > 0 && C > 0, "pgv_bn1d_bwd: bad argument");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)pgv_cdiv(C, 32)), dim3(256), 0, pgv_stream(stream), g, x, scale,
+                     mean, rstd, B, C, gx, ggamma, gbeta);
+  PGV_CHECK_LAUNCH("bn1d_bwd");
+  return PGV_OK;
+}
+
 int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, int C, float* scale, float* shift, void* stream) {
   PGV_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "pgv_bn_eval_affine: bad argument");
@@ -1074,14 +1183,10 @@ int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, 
   return PGV_OK;
 }
 
-int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
-                      void* stream) {
-  PGV_CHECK_ARG(d && gy && T, "pgv_conv_tap_sums: null argument");
-  PGV_CHECK_ARG(d->kh == d->kw && d->kh >= 1 && d->kh <= 5, "pgv_conv_tap_sums: kernel %dx%d not supported", d->kh, d->kw);
+static int tap_sums_launch(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
+                           hipStream_t st) {
   const int C = gy_is_big ? d->Cb : d->Cs, H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
   const int oH = gy_is_big ? d->Hs : d->Hb, oW = gy_is_big ? d->Ws : d->Wb;
-  PGV_CHECK_ARG(H <= 1024 && W <= 1024, "pgv_conv_tap_sums: plane %dx%d too large", H, W);
-  hipStream_t st = pgv_stream(stream);
   const int K = d->kh;
   if (!(flags & PGV_PREZEROED)) {
     int rc = zero_async(T, sizeof(double) * C * K * K, st, "pgv_conv_tap_sums");
@@ -1132,14 +1237,53 @@ int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, co
   return PGV_OK;
 }
 
+int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
+                      void* stream) {
+  PGV_CHECK_ARG(d && gy && T, "pgv_conv_tap_sums: null argument");
+  PGV_CHECK_ARG(d->kh == d->kw && d->kh >= 1 && d->kh <= 5, "pgv_conv_tap_sums: kernel %dx%d not supported", d->kh, d->kw);
+  const int H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
+  PGV_CHECK_ARG(H <= 1024 && W <= 1024, "pgv_conv_tap_sums: plane %dx%d too large", H, W);
+  return tap_sums_launch(d, gy_is_big, gy, cls, T, flags, pgv_stream(stream));
+}
+
+static CoefArgs coef_args(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, int64_t n, float* coef, float* ggamma,
+                          float* gbeta) {
+  CoefArgs ca;
+  ca.w = w, ca.gw = gw, ca.scale = scale, ca.shift = shift, ca.mean = mean, ca.rstd = rstd;
+  ca.coef = coef, ca.ggamma = ggamma, ca.gbeta = gbeta;
+  ca.inv_n = 1.0 / (double)n;
+  ca.Cb = d->Cb, ca.Cs = d->Cs, ca.KK = d->kh * d->kw, ca.lower_is_big = lower_is_big;
+  ca.bf16 = (d->flags & PGV_COMPUTE_BF16) ? 1 : 0;
+  ca.C = lower_is_big ? d->Cb : d->Cs;
+  return ca;
+}
+
+int pgv_bn_bwd_coef_from_gy(const pgv_conv_desc* d, int lower_is_big, const float* gy, const float* cls, double* T,
+                            const float* w, const float* gw, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int64_t n, float* coef, float* ggamma, float* gbeta, int flags,
+                            void* stream) {
+  PGV_CHECK_ARG(d && gy && T && w && gw && scale && shift && mean && rstd && coef && n > 0,
+                "pgv_bn_bwd_coef_from_gy: bad argument");
+  PGV_CHECK_ARG(d->kh == d->kw && d->kh >= 1 && d->kh <= 5, "pgv_bn_bwd_coef_from_gy: kernel %dx%d not supported", d->kh, d->kw);
+  const int gy_is_big = !lower_is_big;
+  const int H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
+  PGV_CHECK_ARG(H <= 1024 && W <= 1024, "pgv_bn_bwd_coef_from_gy: plane %dx%d too large", H, W);
+  hipStream_t st = pgv_stream(stream);
+  const CoefArgs ca = coef_args(d, lower_is_big, w, gw, scale, shift, mean, rstd, n, coef, ggamma, gbeta);
+  int rc = tap_sums_launch(d, gy_is_big, gy, cls, T, flags, st);
+  if (rc || d->B == 0) return rc;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ca.C), dim3(256), 0, st, ca, (const double*)T);
+  PGV_CHECK_LAUNCH("bn_bwd_coef");
+  return PGV_OK;
+}
+
 int pgv_bn_bwd_coef(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T,
                     const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
                     float* coef, float* ggamma, float* gbeta, void* stream) {
   PGV_CHECK_ARG(d && w && gw && T && scale && shift && mean && rstd && coef && n > 0, "pgv_bn_bwd_coef: bad argument");
-  const int C = lower_is_big ? d->Cb : d->Cs;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, pgv_stream(stream), w, gw, T, d->Cb, d->Cs,
-                     d->kh * d->kw, lower_is_big, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0, scale, shift, mean, rstd,
-                     1.0 / (double)n, C, coef, ggamma, gbeta);
+  const CoefArgs ca = coef_args(d, lower_is_big, w, gw, scale, shift, mean, rstd, n, coef, ggamma, gbeta);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ca.C), dim3(256), 0, pgv_stream(stream), ca, T);
   PGV_CHECK_LAUNCH("bn_bwd_coef");
   return PGV_OK;
 }

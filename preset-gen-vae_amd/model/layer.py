@@ -126,6 +126,19 @@ def set_bn_backward_mode(mode):
     BN_BACKWARD_MODE = mode
 
 
+_IDENTITY_COEF = {}
+
+
+def _identity_coef(C, device):
+    """(1, 0, 0) coefficients of pgv_bwd_fuse for a block without BatchNorm: one constant tensor per (device, C) instead
+    of two fills and a concatenation per step.  Read-only by contract."""
+    key = (str(device), C)
+    t = _IDENTITY_COEF.get(key)
+    if t is None:
+        t = _IDENTITY_COEF[key] = torch.cat([torch.ones(C, device=device), torch.zeros(2 * C, device=device)])
+    return t
+
+
 # Set by parallel.GradAllReduce: called with a parameter right after the kernel writing its gradient was launched on
 # the current stream (gradient-ready notification for bucketed all-reduce overlap).
 GRAD_READY_HOOK = None
@@ -254,7 +267,7 @@ class ConvStackFn(torch.autograd.Function):
         n_red = sum(2 * blk.c_out for li, (blk, sv) in enumerate(zip(blocks, saved))
                     if blk.bn is not None and sv[5] is not None and not passfree[li])
         arena = _step_zeros(params[0], n_red, torch.float64, 'red', dev) if n_red else None  # BN-backward projections
-        n_tap = sum(blocks[li + 1].c_out * blocks[li + 1].k ** 2 for li in range(nb - 1)
+        n_tap = sum(blocks[li + 1].c_out * blocks[li + 1].k ** 2 + 1 for li in range(nb - 1)
                     if passfree[li] and blocks[li].bn is not None and saved[li][5] is not None)
         tap_arena = _step_zeros(params[0], n_tap, torch.float64, 'tap', dev) if n_tap else None
         a_off = t_off = 0
@@ -328,8 +341,8 @@ class ConvStackFn(torch.autograd.Function):
                 if low.bn is not None and mean_low is not None:
                     # train-mode BatchNorm: coefficients from W * gW of this block and the tap sums of g_y (must be
                     # launched before this block's weight gradient is announced: a gradient exchange rewrites it)
-                    T = tap_arena[t_off:t_off + C * blk.k ** 2]
-                    t_off += C * blk.k ** 2
+                    T = tap_arena[t_off:t_off + C * blk.k ** 2 + 1]   # (+ the arrival ticket of the fused launch)
+                    t_off += C * blk.k ** 2 + 1
                     # class sums of g_y: for a Conv2d consumer simply this block's bias gradient; for a ConvTranspose2d
                     # one the sums by row / column parity class
                     if not blk.up:
@@ -338,17 +351,15 @@ class ConvStackFn(torch.autograd.Function):
                         cls = cls_cur
                     else:
                         cls = ops.conv_class_sums(geom, g_y, True)
-                    ops.conv_tap_sums(geom, g_y, blk.up, T, prezeroed=True, cls=cls)
                     coef = torch.empty(3 * Cl, device=dev, dtype=torch.float32)
                     gg_low, grads[pl + 2] = _grad_dest(params[pl + 2])
                     gbt_low, grads[pl + 3] = _grad_dest(params[pl + 3])
-                    ops.bn_bwd_coef(geom, B, not blk.up, w, gw, T, in_scale, in_shift, mean_low, rstd_low,
-                                    a_low.numel() // Cl, coef, gg_low, gbt_low)
+                    ops.bn_bwd_coef_from_gy(geom, not blk.up, g_y, cls, T, w, gw, in_scale, in_shift, mean_low, rstd_low,
+                                            a_low.numel() // Cl, coef, gg_low, gbt_low, prezeroed=True)
                 elif low.bn is not None:   # eval-mode BatchNorm: g_a = scale * g
                     coef = torch.cat([in_scale, torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
-                else:
-                    coef = torch.cat([torch.ones(Cl, device=dev, dtype=torch.float32),
-                                      torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
+                else:                      # no BatchNorm (the first encoder block): activation backward only
+                    coef = _identity_coef(Cl, dev)
                 gb_low, grads[pl + 1], gb_zero = _grad_dest(params[pl + 1], accumulated=True)
                 if not gb_zero:
                     gb_low.zero_()
@@ -488,31 +499,33 @@ class DropoutFn(torch.autograd.Function):
 
 
 class BatchNorm1dFn(torch.autograd.Function):
-    """nn.BatchNorm1d over [B, C] (encoder.py:86-87), same kernels as the 2-D case with HW = 1."""
+    """nn.BatchNorm1d over [B, C] (encoder.py:86-87).  Train mode: one launch per direction (``pgv_bn1d_fwd`` /
+    ``pgv_bn1d_bwd``); eval mode: the folded running-statistics affine."""
 
     @staticmethod
     def forward(ctx, x, bn, training, gamma, beta):
         x = x.contiguous()
         B, C = x.shape
         dev = x.device
-        vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
-        scale, shift, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
+        vec = torch.empty(3 * C, device=dev, dtype=torch.float32)
+        scale, mean, rstd = vec[:C], vec[C:2 * C], vec[2 * C:]
+        ctx.params = (gamma, beta)
         if training:
             if B <= 1:
                 raise ValueError("Expected more than 1 value per channel when training")
-            stats = torch.empty(2 * C, device=dev, dtype=torch.float64)
-            x3 = x.view(B, C, 1)
-            ops.bn_stats(x3, stats)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = bn.momentum if bn.momentum is not None else 0.1
-            ops.bn_finalize(stats, B, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
-                            bn.running_var if track else None, scale, shift, mean, rstd,
-                            num_batches_tracked=bn.num_batches_tracked if track else None)
-        else:
-            ops.bn_eval_affine(gamma, beta, bn.running_mean, bn.running_var, bn.eps, scale, shift)
-            mean = rstd = None
-        ctx.saved = (x, scale, mean, rstd)
-        ctx.params = (gamma, beta)
+            y = torch.empty_like(x)
+            if track and (bn.num_batches_tracked.dtype != torch.int64 or not bn.num_batches_tracked.is_cuda):
+                raise ValueError("num_batches_tracked must be an int64 device tensor")
+            ops.bn1d_fwd(x, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
+                         bn.running_var if track else None, bn.num_batches_tracked if track else None, y, scale, mean,
+                         rstd)
+            ctx.saved = (x, scale, mean, rstd)
+            return y
+        shift = torch.empty(C, device=dev, dtype=torch.float32)
+        ops.bn_eval_affine(gamma, beta, bn.running_mean, bn.running_var, bn.eps, scale, shift)
+        ctx.saved = (x, scale, None, None)
         return ops.affine_nchw(x.view(B, C, 1), scale, shift).view(B, C)
 
     @staticmethod
@@ -520,17 +533,15 @@ class BatchNorm1dFn(torch.autograd.Function):
         x, scale, mean, rstd = ctx.saved
         gamma, beta = ctx.params
         B, C = x.shape
-        g = g.contiguous().view(B, C, 1)
-        x3 = x.view(B, C, 1)
-        red = ggamma = gbeta = None
-        gg_ret = gb_ret = None
+        g = g.contiguous()
+        gx = torch.empty_like(x)
         if mean is not None:
-            red = torch.empty(2 * C, device=x.device, dtype=torch.float64)
-            ops.bn_bwd_reduce(g, x3, mean, rstd, red)
             ggamma, gg_ret = _grad_dest(gamma)
             gbeta, gb_ret = _grad_dest(beta)
-        gx = torch.empty_like(x3)
-        ops.act_bn_bwd(g, x3, scale, mean, rstd, red, PGV_ACT_NONE, 0.0, gx, None, ggamma=ggamma, gbeta=gbeta)
-        if ggamma is not None:
+            ops.bn1d_bwd(g, x, scale, mean, rstd, gx, ggamma, gbeta)
             _grad_done(gamma, beta)
-        return gx.view(B, C), None, None, gg_ret, gb_ret
+            return gx, None, None, gg_ret, gb_ret
+        # eval mode: g_x = scale * g
+        x3, g3 = x.view(B, C, 1), g.view(B, C, 1)
+        ops.act_bn_bwd(g3, x3, scale, None, None, None, PGV_ACT_NONE, 0.0, gx.view(B, C, 1), None)
+        return gx, None, None, None, None

@@ -180,6 +180,25 @@ def bn_finalize(stats, n, gamma, beta, eps, momentum, running_mean, running_var,
                                            _p(rstd), _stream()), "pgv_bn_finalize")
 
 
+def bn1d_fwd(x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, y, scale, mean, rstd):
+    """Train-mode nn.BatchNorm1d forward over x[B, C] in one launch (``pgv_bn1d_fwd``)."""
+    B, C = x.shape
+    _chk(x, gamma, beta, running_mean, running_var, y, scale, mean, rstd)
+    _lib.check(_lib.load().pgv_bn1d_fwd(_p(x), B, C, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+                                        _p(running_var), _p(num_batches_tracked), _p(y), _p(scale), _p(mean), _p(rstd),
+                                        _stream()), "pgv_bn1d_fwd")
+    return y
+
+
+def bn1d_bwd(g, x, scale, mean, rstd, gx, ggamma, gbeta):
+    """Train-mode nn.BatchNorm1d backward over [B, C] in one launch (``pgv_bn1d_bwd``)."""
+    B, C = x.shape
+    _chk(g, x, scale, mean, rstd, gx, ggamma, gbeta)
+    _lib.check(_lib.load().pgv_bn1d_bwd(_p(g), _p(x), _p(scale), _p(mean), _p(rstd), B, C, _p(gx), _p(ggamma),
+                                        _p(gbeta), _stream()), "pgv_bn1d_bwd")
+    return gx
+
+
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
     C = running_mean.numel()
     _chk(gamma, beta, running_mean, running_var, scale, shift)
@@ -240,6 +259,23 @@ def bn_bwd_coef(geom, B, lower_is_big, w, gw, T, scale, shift, mean, rstd, n, co
     _lib.check(_lib.load().pgv_bn_bwd_coef(ctypes.byref(geom.desc(B)), int(lower_is_big), _p(w), _p(gw), _p(T),
                                            _p(scale), _p(shift), _p(mean), _p(rstd), int(n), _p(coef), _p(ggamma),
                                            _p(gbeta), _stream()), "pgv_bn_bwd_coef")
+    return coef
+
+
+def bn_bwd_coef_from_gy(geom, lower_is_big, gy, cls, T, w, gw, scale, shift, mean, rstd, n, coef, ggamma=None, gbeta=None,
+                        prezeroed=False):
+    """Tap sums of ``gy`` (border form, from its class sums ``cls``) + BatchNorm-backward coefficients in one launch
+    where possible (``pgv_bn_bwd_coef_from_gy``).  ``T``: float64 scratch of C_gy*k*k + 1 elements."""
+    B = gy.shape[0]
+    _chk(gy, cls, w, gw, scale, shift, mean, rstd, coef, ggamma, gbeta)
+    _chk64(T)
+    C = geom.Cs if lower_is_big else geom.Cb
+    if T.numel() < C * geom.k * geom.k + 1:
+        raise ValueError("bn_bwd_coef_from_gy: T needs C*k*k + 1 doubles")
+    _lib.check(_lib.load().pgv_bn_bwd_coef_from_gy(ctypes.byref(geom.desc(B)), int(lower_is_big), _p(gy), _p(cls), _p(T),
+                                                   _p(w), _p(gw), _p(scale), _p(shift), _p(mean), _p(rstd), int(n),
+                                                   _p(coef), _p(ggamma), _p(gbeta), PGV_PREZEROED if prezeroed else 0,
+                                                   _stream()), "pgv_bn_bwd_coef_from_gy")
     return coef
 
 

@@ -502,6 +502,15 @@ def test_bn_backward_without_a_pass(ops, case, policy):
             coef = torch.empty(3 * C, device='cuda')
             gg, gbt = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
             ops.bn_bwd_coef(geom, B, lower_is_big, w_d, gw, T, sc_d, sh_d, mu_d, rs_d, B * H * W, coef, gg, gbt)
+            # the same in one launch from the class sums of gy (border form of the tap sums + coefficient tail)
+            cls = ops.conv_class_sums(geom, gy_d, not lower_is_big)
+            T2 = torch.zeros(T.numel() + 1, device='cuda', dtype=torch.float64)
+            coef2, gg2, gbt2 = torch.empty_like(coef), torch.empty_like(gg), torch.empty_like(gbt)
+            ops.bn_bwd_coef_from_gy(geom, lower_is_big, gy_d, cls, T2, w_d, gw, sc_d, sh_d, mu_d, rs_d, B * H * W, coef2,
+                                    gg2, gbt2, prezeroed=True)
+            cscale = coef.abs().max().item()
+            assert (coef2 - coef).abs().max().item() <= 2e-5 * cscale, (lower_is_big, (coef2 - coef).abs().max().item())
+            assert rel_l2(gg2, gg) < 1e-4 and rel_l2(gbt2, gbt) < 1e-4
             gb = torch.zeros(C, device='cuda')
             fuse = (a_d, coef, gb, ops.PGV_ACT_LEAKY_RELU, 0.1)
             if lower_is_big:
@@ -566,6 +575,33 @@ def test_conv_wgrad_without_workspace(ops, case):
                                       shd.data_ptr(), sd.data_ptr(), None, None, gw.data_ptr(),
                                       None if ws is None else ws.data_ptr(), ws_bytes, st), "pgv_conv_wgrad")
         assert rel_l2(gw, 2 * wv.grad) < 5e-5      # accumulated into
+
+
+@pytest.mark.parametrize("shape", [(256, 128), (7, 33), (2, 1024), (19, 64)])
+def test_batchnorm1d_one_launch_per_direction(ops, shape):
+    """pgv_bn1d_fwd / pgv_bn1d_bwd (nn.BatchNorm1d, encoder.py:86-87, train mode) against float64 torch: output, saved
+    statistics, running-statistics update, all gradients."""
+    B, C = shape
+    x = (synth_vec(shape, 0.713, 0.2) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)).requires_grad_(True)
+    beta = (0.2 * synth_vec((C,), 2.9, 0.6)).requires_grad_(True)
+    rm, rv = 0.1 * synth_vec((C,), 1.3, 0.4), 1.0 + 0.2 * synth_vec((C,), 1.9, 0.8)
+    g = synth_vec(shape, 0.377, 0.9)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    y.backward(g)
+    xd, gd = dev(x.detach()), dev(g)
+    rmd, rvd = dev(rm), dev(rv)
+    nbt = torch.zeros((), device='cuda', dtype=torch.int64)
+    yd = torch.empty_like(xd)
+    sc, mu, rs = (torch.empty(C, device='cuda') for _ in range(3))
+    ops.bn1d_fwd(xd, dev(gamma.detach()), dev(beta.detach()), 1e-5, 0.1, rmd, rvd, nbt, yd, sc, mu, rs)
+    assert rel_l2(yd, y) < 1e-5 and int(nbt.item()) == 1
+    assert rel_l2(rmd, rm_ref) < 1e-6 and rel_l2(rvd, rv_ref) < 1e-6
+    gx, gg, gb = torch.empty_like(xd), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ops.bn1d_bwd(gd, xd, sc, mu, rs, gx, gg, gb)
+    assert rel_l2(gx, x.grad) < 2e-5
+    assert rel_l2(gg, gamma.grad) < 1e-5 and rel_l2(gb, beta.grad) < 1e-5
 
 
 def test_conv_desc_validation(ops):
