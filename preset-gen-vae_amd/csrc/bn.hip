@@ -169,7 +169,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, doub
 
 // nn.BatchNorm1d over x[B][C] (model/encoder.py:86-87), train mode, each direction in ONE launch: the tensor is tiny
 // ([256][128]), the separate statistics / finalize / apply launches cost a dependent-launch latency each.
-// A workgroup owns 32 consecutive channels (one 128-byte row segment), 8 row groups of threads walk the batch.
+// A workgroup owns 16 consecutive channels, 16 row groups of threads walk the batch 8 rows at a time (all loads of a
+// batch of rows in flight: the kernel is pure latency).
+constexpr int kB1C = 16, kB1R = 16, kB1U = 8;
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float momentum, float* __restrict__ running_mean,
@@ -177,23 +179,31 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
                                                        int64_t* __restrict__ num_batches_tracked, float* __restrict__ y,
                                                        float* __restrict__ scale_out, float* __restrict__ mean_out,
                                                        float* __restrict__ rstd_out) {
-  __shared__ double ps[8][32], pq[8][32];
-  __shared__ float sc_s[32], sh_s[32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double ps[kB1R][kB1C], pq[kB1R][kB1C];
+  __shared__ float sc_s[kB1C], sh_s[kB1C];
+  const int cl = threadIdx.x % kB1C, rg = threadIdx.x / kB1C;
+  const int c = blockIdx.x * kB1C + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int b = rg; b < B; b += 8) {
-      const double v = x[(int64_t)b * C + c];
-      s += v;
-      q = fma(v, v, q);
+    for (int b0 = rg; b0 < B; b0 += kB1R * kB1U) {
+      float v[kB1U];
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        v[u] = b < B ? x[(int64_t)b * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        s += (double)v[u];
+        q = fma((double)v[u], (double)v[u], q);
+      }
     }
   ps[rg][cl] = s, pq[rg][cl] = q;
   __syncthreads();
   if (rg == 0 && c < C) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) s += ps[k][cl], q += pq[k][cl];
+    for (int k = 1; k < kB1R; ++k) s += ps[k][cl], q += pq[k][cl];
     const double inv_n = 1.0 / (double)B, mean = s * inv_n;
     double var = q * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -211,7 +221,19 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
   __syncthreads();
   if (c < C) {
     const float sc = sc_s[cl], sh = sh_s[cl];
-    for (int b = rg; b < B; b += 8) y[(int64_t)b * C + c] = fmaf(x[(int64_t)b * C + c], sc, sh);
+    for (int b0 = rg; b0 < B; b0 += kB1R * kB1U) {
+      float v[kB1U];
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        v[u] = b < B ? x[(int64_t)b * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        if (b < B) y[(int64_t)b * C + c] = fmaf(v[u], sc, sh);
+      }
+    }
   }
 }
 
@@ -220,23 +242,32 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd, int B, int C,
                                                        float* __restrict__ gx, float* __restrict__ ggamma,
                                                        float* __restrict__ gbeta) {
-  __shared__ double ps[8][32], pq[8][32];
-  __shared__ float c1_s[32], c2_s[32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double ps[kB1R][kB1C], pq[kB1R][kB1C];
+  __shared__ float c1_s[kB1C], c2_s[kB1C];
+  const int cl = threadIdx.x % kB1C, rg = threadIdx.x / kB1C;
+  const int c = blockIdx.x * kB1C + cl;
   const float mu = c < C ? mean[c] : 0.f, rs = c < C ? rstd[c] : 0.f, sc = c < C ? scale[c] : 0.f;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int b = rg; b < B; b += 8) {
-      const float gv = g[(int64_t)b * C + c], xh = (x[(int64_t)b * C + c] - mu) * rs;
-      s += (double)gv;
-      q += (double)(gv * xh);
+    for (int b0 = rg; b0 < B; b0 += kB1R * kB1U) {
+      float gv[kB1U], xv[kB1U];
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        gv[u] = b < B ? g[(int64_t)b * C + c] : 0.f;
+        xv[u] = b < B ? x[(int64_t)b * C + c] : mu;
+      }
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        s += (double)gv[u];
+        q += (double)(gv[u] * ((xv[u] - mu) * rs));
+      }
     }
   ps[rg][cl] = s, pq[rg][cl] = q;
   __syncthreads();
   if (rg == 0 && c < C) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) s += ps[k][cl], q += pq[k][cl];
+    for (int k = 1; k < kB1R; ++k) s += ps[k][cl], q += pq[k][cl];
     if (ggamma) ggamma[c] = (float)q;
     if (gbeta) gbeta[c] = (float)s;
     c1_s[cl] = (float)(s / (double)B), c2_s[cl] = (float)(q / (double)B);
@@ -244,9 +275,19 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
   __syncthreads();
   if (c < C) {
     const float c1 = c1_s[cl], c2 = c2_s[cl];
-    for (int b = rg; b < B; b += 8) {
-      const int64_t i = (int64_t)b * C + c;
-      gx[i] = sc * (g[i] - c1 - (x[i] - mu) * rs * c2);
+    for (int b0 = rg; b0 < B; b0 += kB1R * kB1U) {
+      float gv[kB1U], xv[kB1U];
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        gv[u] = b < B ? g[(int64_t)b * C + c] : 0.f;
+        xv[u] = b < B ? x[(int64_t)b * C + c] : mu;
+      }
+#pragma unroll
+      for (int u = 0; u < kB1U; ++u) {
+        const int b = b0 + u * kB1R;
+        if (b < B) gx[(int64_t)b * C + c] = sc * (gv[u] - c1 - (xv[u] - mu) * rs * c2);
+      }
     }
   }
 }
@@ -974,17 +1015,16 @@ __global__ __launch_bounds__(256) void sqerr_act_bwd_cls_kernel(const float* __r
     g_y[start + i] = r;
     add(i, r);
   }
-  float tot = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float s = pgv_block_sum(c4[q], red);
-    if (threadIdx.x == 0) atomicAdd(&cls[q], s);
-    tot += s;
-  }
-  if (gbias && threadIdx.x == 0) atomicAdd(&gbias[0], tot);
-  if (loss_acc) {
-    const float s = pgv_block_sum(sq, red);
-    if (threadIdx.x == 0) atomicAdd(loss_acc, scale * s);
+  // the six sums of the workgroup in one pass (4 classes, their total = the bias gradient, the squared error)
+  __shared__ float red6[4 * 6];
+  const float v6[6] = {c4[0], c4[1], c4[2], c4[3], (c4[0] + c4[1]) + (c4[2] + c4[3]), sq};
+  const float r = pgv_block_sums<6>(v6, red6);
+  if (threadIdx.x < 4)
+    atomicAdd(&cls[threadIdx.x], r);
+  else if (threadIdx.x == 4) {
+    if (gbias) atomicAdd(&gbias[0], r);
+  } else if (threadIdx.x == 5) {
+    if (loss_acc) atomicAdd(loss_acc, scale * r);
   }
 }
 
@@ -1071,7 +1111,7 @@ int pgv_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* 
                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* scale,
                  float* mean, float* rstd, void* stream) {
   PGV_CHECK_ARG(x && y && B > 0 && C > 0, "pgv_bn1d_fwd: bad argument");
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)pgv_cdiv(C, 32)), dim3(256), 0, pgv_stream(stream), x, B, C, gamma,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)pgv_cdiv(C, kB1C)), dim3(256), 0, pgv_stream(stream), x, B, C, gamma,
                      beta, eps, momentum, running_mean, running_var, num_batches_tracked, y, scale, mean, rstd);
   PGV_CHECK_LAUNCH("bn1d_fwd");
   return PGV_OK;
@@ -1080,7 +1120,7 @@ int pgv_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* 
 int pgv_bn1d_bwd(const float* g, const float* x, const float* scale, const float* mean, const float* rstd, int B, int C,
                  float* gx, float* ggamma, float* gbeta, void* stream) {
   PGV_CHECK_ARG(g && x && scale && mean && rstd && gx && B > 0 && C > 0, "pgv_bn1d_bwd: bad argument");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)pgv_cdiv(C, 32)), dim3(256), 0, pgv_stream(stream), g, x, scale,
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)pgv_cdiv(C, kB1C)), dim3(256), 0, pgv_stream(stream), g, x, scale,
                      mean, rstd, B, C, gx, ggamma, gbeta);
   PGV_CHECK_LAUNCH("bn1d_bwd");
   return PGV_OK;

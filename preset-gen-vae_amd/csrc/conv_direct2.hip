@@ -342,18 +342,14 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
     // parity of bid, and the lane's row inside the band (rq = tid / QW) never changes - one quad per lane (NPASS = 1).
     static_assert(R * QW <= 256 && BANDS % 2 == 0, "constant row parity per lane");
     const bool rodd = ((R & 1 ? bid : 0) + tid / QW) & 1;
+    float v32[4 * CS];
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float a = pgv_wave_sum(((k >> 1) != 0) == rodd ? s1[cs][k & 1] : 0.f);
-        if (lane == 0) red[wave * 4 * CS + 4 * cs + k] = a;
-      }
-    __syncthreads();
+      for (int k = 0; k < 4; ++k) v32[4 * cs + k] = ((k >> 1) != 0) == rodd ? s1[cs][k & 1] : 0.f;
+    // (DPP row reductions + one barrier: 4*CS wave reductions through ds_bpermute took ~10 us at the end of every workgroup)
+    float t = pgv_block_sums<4 * CS>(v32, red);
     if (tid < 4 * CS) {
-      float t = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < 4; ++wv) t += red[wv * 4 * CS + tid];
       if (fuse.cls) atomicAdd(&fuse.cls[tid], t);
       // bias gradient = the four classes of a channel added up (lanes 4cs .. 4cs+3)
       t += dpp_mov<0xB1>(t);

@@ -74,6 +74,35 @@ __device__ __forceinline__ double pgv_block_sum_d(double v, double* smem /* >= 1
   return r;
 }
 
+// N block-wide sums at once for blockDim.x == 256: DPP row reductions (no ds_bpermute), v_readlane across the four rows of
+// a wave, ONE barrier across the waves.  pgv_block_sum costs two barriers and six LDS-latency shuffles per value - for
+// kernels that end with several reductions (class sums, loss, bias gradient) that tail was longer than the streaming
+// loop.  Results valid in threads 0..N-1: thread i holds sum i.  smem: >= 4*N floats.
+template <int CTRL>
+__device__ __forceinline__ float pgv_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float pgv_block_sums(const float (&v)[N], float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float t = v[i];
+    t += pgv_dpp<0xB1>(t);   // quad_perm [1,0,3,2]
+    t += pgv_dpp<0x4E>(t);   // quad_perm [2,3,0,1]
+    t += pgv_dpp<0x141>(t);  // row_half_mirror
+    t += pgv_dpp<0x140>(t);  // row_mirror: every lane of a 16-lane row holds the row's sum
+    const int ti = __float_as_int(t);   // (v_readlane is an integer builtin: no value conversion)
+    const float w = (__int_as_float(__builtin_amdgcn_readlane(ti, 0)) + __int_as_float(__builtin_amdgcn_readlane(ti, 16))) +
+                    (__int_as_float(__builtin_amdgcn_readlane(ti, 32)) + __int_as_float(__builtin_amdgcn_readlane(ti, 48)));
+    if (lane == 0) smem[wave * N + i] = w;
+  }
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < N) r = smem[threadIdx.x] + smem[N + threadIdx.x] + smem[2 * N + threadIdx.x] + smem[3 * N + threadIdx.x];
+  return r;
+}
+
 // Branch-free form of pgv_act for unrolled epilogues: bit-identical results, parameters derived once from (act, slope).
 struct pgv_act_params {
   float ns, lo, hi;
