@@ -20,6 +20,27 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// XCD-aware (channel block, sample group) of a workgroup.  Workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2: with blockIdx = mb * groups + grp every XCD works on ALL channel blocks at once and streams the whole
+// weight tensor (up to 8 MB against a 4 MB L2) again and again.  Here the workgroups of one XCD share a channel block
+// whenever the block count divides 8 (its weight slice, 1 MB or less, then stays in that XCD's L2 for all sample
+// groups); a speed matter only.
+__device__ __forceinline__ void deep_block(int nmb, int groups, int& mb, int& grp) {
+  const int b = (int)blockIdx.x;
+  if (nmb <= 8 && 8 % nmb == 0 && (nmb * groups) % 8 == 0) {
+    const int x = b & 7, q = b >> 3, per = 8 / nmb;   // per = XCDs per channel block
+    mb = x % nmb;
+    grp = q * per + x / nmb;
+  } else if (nmb % 8 == 0) {   // more channel blocks than XCDs: nmb / 8 of them per XCD, one after the other
+    const int x = b & 7, q = b >> 3;
+    mb = x * (nmb / 8) + q / groups;
+    grp = q % groups;
+  } else {
+    mb = b / groups;
+    grp = b - mb * groups;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
 // GEMM: M = cs (64 per workgroup, 16 per wave), N = the NS*Hs*Ws output pixels of NS samples, K = (cb, 16 taps).
@@ -52,7 +73,8 @@ __global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, c
   float* aff = lds + 2 * G::STAGE;  // [2*CB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
-  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  int mb, grp;
+  deep_block(CS / 64, groups, mb, grp);
   const int cs0 = mb * 64, b0 = grp * NS;
 
   // zero both stages' planes once (the data cells are rewritten every slab, the padding never)
@@ -257,7 +279,8 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
   float* aff = lds + 2 * G::STAGE;  // [2*CS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
-  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  int mb, grp;
+  deep_block(CB / 64, groups, mb, grp);
   const int cb0 = mb * 64, b0 = grp * NS;
 
   for (int i = tid; i < G::B_FLOATS; i += 256) {
@@ -695,7 +718,8 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
-  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  int mb, grp;
+  deep_block(COUT / 64, groups, mb, grp);
   const int co0 = mb * 64, b0 = grp * NS;
 
   // ---- loaders.  Weights: !TRANSA w[co0+row][ci0 + 4f ..] (row-major [COUT][CIN]);
@@ -856,7 +880,8 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4, wm = wave & 3, wn = wave >> 2;
-  const int mb = blockIdx.x / groups, grp = blockIdx.x - mb * groups;
+  int mb, grp;
+  deep_block(COUT / 128, groups, mb, grp);
   const int co0 = mb * 128, b0 = grp * NS;
 
   int a_src[QA], a_dst[QA];
