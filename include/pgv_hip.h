@@ -216,7 +216,9 @@ int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, f
 /* C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N] + beta_bias: generic strided fp32 GEMM on f32 MFMA.
  * A element (m,k) at A[m*sam + k*sak]; B element (k,n) at B[k*sbk + n*sbn]; C row-major ldc.
  * bias_n (len N) optional (NULL).  Overwrites C.  flags: PGV_COMPUTE_BF16 rounds both operands to bfloat16 (fp32
- * accumulation), 0 = fp32.  workspace is reserved (split-K accumulates in C). */
+ * accumulation), 0 = fp32; PGV_PREZEROED: C holds zeros on entry (e.g. a slice of the zero_grad'ed gradient / scratch
+ * buffer) - a split-K product then accumulates straight into it without a clearing launch.  workspace is reserved
+ * (split-K accumulates in C). */
 int64_t pgv_gemm_workspace(int M, int N, int K);
 int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
              int64_t sbn, float* C, int64_t ldc, const float* bias_n, int flags, void* workspace,

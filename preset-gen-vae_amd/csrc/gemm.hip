@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
   // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int n = n0 + wn + (lane & 31);
   if (n < N) {
-    const float bias = (!atomic && bias_n) ? bias_n[n] : 0.f;
+    const float bias = ((!atomic || (atomic == 2 && blockIdx.z == 0)) && bias_n) ? bias_n[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < M) {
         if (atomic)
-          atomicAdd(&C[(int64_t)m * ldc + n], acc[r]);
+          atomicAdd(&C[(int64_t)m * ldc + n], acc[r] + bias);
         else
           C[(int64_t)m * ldc + n] = acc[r] + bias;
       }
@@ -234,12 +234,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(int M, int N, int K, con
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int n = n0 + 16 * t + m;
-    const float bias = (!atomic && bias_n) ? bias_n[n] : 0.f;
+    // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
+    const float bias = ((!atomic || (atomic == 2 && blockIdx.z == 0)) && bias_n) ? bias_n[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float* c = C + (int64_t)(m0 + wave * 16 + 4 * j + i) * ldc + n;
       if (atomic)
-        atomicAdd(c, acc[t][i]);
+        atomicAdd(c, acc[t][i] + bias);
       else
         *c = acc[t][i] + bias;
     }
@@ -281,8 +282,8 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
       int splits = (int)max((int64_t)1, min(pgv_cdiv(768, tiles), (int64_t)K / (FK * 4)));
       const int k_per_split = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
       splits = (int)pgv_cdiv(K, k_per_split);
-      const int atomic = splits > 1;
-      if (atomic) {
+      const int atomic = splits > 1 ? ((flags & PGV_PREZEROED) ? 2 : 1) : 0;
+      if (atomic == 1) {
         hipLaunchKernelGGL(init_c_kernel, dim3((unsigned)min((int64_t)1024, pgv_cdiv((int64_t)M * N, 256))), dim3(256),
                            0, st, C, M, N, ldc, bias_n);
         PGV_CHECK_LAUNCH("gemm_init_c");
@@ -307,8 +308,8 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
   if (K > 0) splits = (int)max((int64_t)1, min(pgv_cdiv(512, tiles), pgv_cdiv(K, BK * 8)));
   int k_per_split = (int)(pgv_cdiv(pgv_cdiv(max(K, 1), splits), BK) * BK);
   splits = (int)pgv_cdiv(max(K, 1), k_per_split);
-  const int atomic = splits > 1;
-  if (atomic || K == 0) {
+  const int atomic = splits > 1 ? ((flags & PGV_PREZEROED) && K > 0 ? 2 : 1) : 0;
+  if (atomic == 1 || K == 0) {
     hipLaunchKernelGGL(init_c_kernel, dim3((unsigned)min((int64_t)1024, pgv_cdiv((int64_t)M * N, 256))), dim3(256), 0,
                        st, C, M, N, ldc, bias_n);
     PGV_CHECK_LAUNCH("gemm_init_c");

@@ -442,8 +442,25 @@ class TConv2D(_ConvBlockBase):
         self._finish('tconv', conv, activation, name_prefix, batch_norm)
 
 
+def _small_zeros(param, shape, tag):
+    """A zeroed [shape] activation buffer from the optimizer's step scratch (cleared by zero_grad's one fill) for a
+    split-K product to accumulate into, or None: small tensors only, first use in the step only."""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    flat = getattr(param, '_pgv_flat', None)
+    if flat is None or n > 1 << 15 or getattr(param, '_pgv_shared', False):
+        return None
+    t = flat.step_scratch((id(param), tag), n, torch.float32)
+    # (.data: same memory, but not a view of the scratch buffer as far as autograd is concerned - in-place torch ops on
+    # other slices of the scratch would otherwise invalidate every tensor saved from this one)
+    return None if t is None else t.view(*shape).data
+
+
 class LinearFn(torch.autograd.Function):
-    """nn.Linear on the f32-MFMA GEMM (encoder.py:85, decoder.py:64)."""
+    """nn.Linear on the f32-MFMA GEMM (encoder.py:85, decoder.py:64).  The long-K products (encoder forward, decoder
+    input gradient: K = 25 024) are split over K and accumulate with atomics: into a zeroed slice of the step scratch when
+    there is one (no clearing launch), as the weight gradient does into the zero_grad'ed flat gradient."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -451,16 +468,21 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.params = (w, b)
-        return ops.linear_fwd(x, w, b)
+        # (the output is handed to autograd consumers that keep it only until the end of the step)
+        out = _small_zeros(w, (x.shape[0], w.shape[0]), 'lin_y') if x.shape[1] >= 4096 else None
+        return ops.linear_fwd(x, w, b, out=out)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         wp, bp = ctx.params
         gy = gy.contiguous()
-        gx = ops.linear_dgrad(gy, w) if ctx.needs_input_grad[0] else None
-        gw, gw_ret = _grad_dest(wp)
-        ops.linear_wgrad(gy, x, gw)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            out = _small_zeros(wp, (gy.shape[0], w.shape[1]), 'lin_gx') if gy.shape[1] >= 4096 else None
+            gx = ops.linear_dgrad(gy, w, out=out)
+        gw, gw_ret, gw_zero = _grad_dest(wp, accumulated=True)
+        ops.linear_wgrad(gy, x, gw, prezeroed=gw_zero)
         gb_ret = None
         if bp is not None:
             gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)

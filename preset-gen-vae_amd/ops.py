@@ -326,34 +326,36 @@ def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, 
                "pgv_sqerr_act_bwd")
 
 
-def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None):
+def gemm(M, N, K, A, sam, sak, Bm, sbk, sbn, C, ldc, bias_n=None, prezeroed=False):
+    """``prezeroed``: C holds zeros (PGV_PREZEROED) - a split-K product accumulates into it without a clearing launch."""
     _chk(A, Bm, C, bias_n)
     _lib.check(_lib.load().pgv_gemm(M, N, K, _p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), ldc, _p(bias_n),
-                                    _COMPUTE_FLAGS, None, 0, _stream()), "pgv_gemm")
+                                    _COMPUTE_FLAGS | (PGV_PREZEROED if prezeroed else 0), None, 0, _stream()),
+               "pgv_gemm")
     return C
 
 
-def linear_fwd(x, w, bias):
-    """y[M,N] = x[M,K] @ w[N,K]^T + bias  (nn.Linear)."""
+def linear_fwd(x, w, bias, out=None):
+    """y[M,N] = x[M,K] @ w[N,K]^T + bias  (nn.Linear).  ``out``: a ZEROED [M,N] buffer to accumulate into."""
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    return gemm(M, N, K, x, K, 1, w, 1, K, y, N, bias)
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32) if out is None else out
+    return gemm(M, N, K, x, K, 1, w, 1, K, y, N, bias, prezeroed=out is not None)
 
 
-def linear_dgrad(gy, w):
-    """gx[M,K] = gy[M,N] @ w[N,K]."""
+def linear_dgrad(gy, w, out=None):
+    """gx[M,K] = gy[M,N] @ w[N,K].  ``out``: a ZEROED [M,K] buffer to accumulate into."""
     M, N = gy.shape
     K = w.shape[1]
-    gx = torch.empty((M, K), device=gy.device, dtype=torch.float32)
-    return gemm(M, K, N, gy, N, 1, w, K, 1, gx, K)
+    gx = torch.empty((M, K), device=gy.device, dtype=torch.float32) if out is None else out
+    return gemm(M, K, N, gy, N, 1, w, K, 1, gx, K, prezeroed=out is not None)
 
 
-def linear_wgrad(gy, x, gw):
+def linear_wgrad(gy, x, gw, prezeroed=False):
     """gw[N,K] = gy[M,N]^T @ x[M,K]."""
     M, N = gy.shape
     K = x.shape[1]
-    return gemm(N, K, M, gy, 1, N, x, K, 1, gw, K)
+    return gemm(N, K, M, gy, 1, N, x, K, 1, gw, K, prezeroed=prezeroed)
 
 
 def colsum(x, out, prezeroed=False):

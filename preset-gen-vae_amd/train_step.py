@@ -118,8 +118,10 @@ class VAETrainStep:
         self.optimizer.set_lr(lr)
 
     def step(self, x, v_in=None, inject=None):
-        """One minibatch.  Returns the losses / outputs as device tensors; in graph mode they are the captured step's
-        static buffers: read them before the next ``step`` overwrites them."""
+        """One minibatch.  Returns the losses / outputs as device tensors.  They are buffers of the step - in graph mode
+        the captured step's static buffers, in eager mode ``z_mu_logvar`` may live in the optimizer's step scratch (the
+        encoder's split-K linear layer accumulates into a slice cleared by ``zero_grad``): read them before the next
+        ``step`` overwrites them."""
         if not self.use_graph or inject:
             return self._step_body(x, v_in, inject)
         if self._graph is None:
