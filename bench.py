@@ -172,7 +172,7 @@ def launch_table(ae, B, device, frontend=None):
     table = []
     prev_bn = {False: False, True: False}   # does the producer block of the same stack end in a BatchNorm (folded here)?
     layers = layer_ops(ae)
-    fused_bwd = ops.compute_dtype() == 'fp32'   # (layer.BN_BACKWARD_MODE 'fused' applies to fp32 products only)
+    fused_bwd = True   # (layer.BN_BACKWARD_MODE 'fused'; bf16 operand mode: from B*H*W = 2^17 per channel on)
     for li, (name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up) in enumerate(layers):
         fold = prev_bn[is_up]
         prev_bn[is_up] = has_bn
@@ -204,7 +204,8 @@ def launch_table(ae, B, device, frontend=None):
             sc_b = sh_b = sc_s = sh_s = None
         fuse = None
         lo = small if is_up else big                         # the lower block's output = this block's input
-        if lower is not None and fused_bwd and lo.shape[2] * lo.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
+        big_n = ops.compute_dtype() == 'fp32' or B * lo.shape[2] * lo.shape[3] >= layer_mod.BF16_PASSFREE_MIN_N
+        if lower is not None and fused_bwd and big_n and lo.shape[2] * lo.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
             Cl = lo.shape[1]
             a_lo = torch.randn_like(lo)
             coef = torch.cat([torch.ones(Cl, device=device), 0.01 * torch.randn(2 * Cl, device=device)])
@@ -241,7 +242,8 @@ def launch_table(ae, B, device, frontend=None):
             table.append((label, mk(kind), nb + ns + nw + extra, flops))
         a = big if is_up else small
         C = a.shape[1]
-        if has_bn and fused_bwd and upper is not None and a.shape[2] * a.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
+        big_na = ops.compute_dtype() == 'fp32' or B * a.shape[2] * a.shape[3] >= layer_mod.BF16_PASSFREE_MIN_N
+        if has_bn and fused_bwd and big_na and upper is not None and a.shape[2] * a.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
             # pass-free BatchNorm backward of this block: tap sums of the consumer's g_y (border rows / columns only) and
             # the coefficient kernel (pgv_conv_tap_sums, pgv_bn_bwd_coef) - launch-latency-sized
             (uCb, uCs, uk, us, up_, uHb, uWb) = upper[1]

@@ -69,8 +69,9 @@ struct BandPrefetch {
   // aff = LDS copy of the producer's per-channel affine ([C] scales then [C] shifts, stage_affine) or null;
   // c0 = first channel of this chunk.  Chunks that hold no image data were loaded from a valid dummy address (finite
   // activations) and are multiplied by 0: they come out as exact zeros.
+  // bf16: round the committed operand to bfloat16 (PGV_COMPUTE_BF16 in kernels that keep multiplying on the fp32 pipe)
   __device__ __forceinline__ void commit(float* __restrict__ tile, const float* __restrict__ aff, int C, int c0,
-                                         int nch, int tid) {
+                                         int nch, int tid, bool bf16 = false) {
     float* lane_tile = tile + 4 * tid;
     float sc[CK], sh[CK];
 #pragma unroll
@@ -110,6 +111,7 @@ struct BandPrefetch {
             x.z = fmaf(e2, m2, a2);
             x.w = fmaf(t.w, m3, a3);
           }
+          if (bf16) x = f32x4{round_bf16(x.x), round_bf16(x.y), round_bf16(x.z), round_bf16(x.w)};
           *reinterpret_cast<f32x4*>(lane_tile + c * CSTRIDE + 1024 * k) = x;
         }
       }
@@ -161,7 +163,7 @@ struct FlatPrefetch {
     }
   }
   __device__ __forceinline__ void commit(float* __restrict__ tile, const float* __restrict__ aff, int C, int c0,
-                                         int /*nch*/, int tid) {
+                                         int /*nch*/, int tid, bool bf16 = false) {
     float* lane_tile = tile + 4 * tid;
     float sc[NPF], sh[NPF];
 #pragma unroll
@@ -195,6 +197,7 @@ struct FlatPrefetch {
           x.z = fmaf(e2, m2, a2);
           x.w = fmaf(t.w, m3, a3);
         }
+        if (bf16) x = f32x4{round_bf16(x.x), round_bf16(x.y), round_bf16(x.z), round_bf16(x.w)};
         *reinterpret_cast<f32x4*>(lane_tile + 1024 * j + (int)((meta[j] >> 12) & 255) * (CSTRIDE - PC * 4)) = x;
       }
     }

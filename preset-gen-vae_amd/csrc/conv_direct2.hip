@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int act, float slope,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int bf16) {
   using G = UpC1Cfg<CS, H, W, R>;
   constexpr int Hs = G::Hs, Ws = G::Ws, Hg = G::Hg, WsP = G::WsP, PLANE = G::PLANE, QW = G::QW, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
   }
   for (int i = tid; i < CS * G::WSTR; i += 256) {
     const int cs = i / G::WSTR, k = i - cs * G::WSTR;
-    wl[i] = k < KK5 ? w[cs * KK5 + k] : 0.f;
+    wl[i] = k < KK5 ? pgv_opnd(w[cs * KK5 + k], bf16 != 0) : 0.f;   // (PGV_COMPUTE_BF16: operands rounded, fp32 FMAs)
   }
   const pgv_act_params actp = pgv_act_setup(act, slope);
   const float bv = bias ? bias[0] : 0.f;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
     const int b = un / BANDS, band = un - b * BANDS;
     const int u0 = band * R, Rb = min(R, Hg - u0);
     __syncthreads();  // the previous unit's reads are complete (first pass: the tables are visible)
-    pf.commit(tile, in_scale ? aff : nullptr, CS, 0, CS, tid);
+    pf.commit(tile, in_scale ? aff : nullptr, CS, 0, CS, tid, bf16 != 0);
     if (un + (int)gridDim.x < units) issue_unit(un + gridDim.x);
     __syncthreads();
     float* ob = out + (int64_t)b * H * W;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          pgv_bwd_fuse fuse) {
+                                                          pgv_bwd_fuse fuse, int bf16) {
   using G = DownC1Cfg<CS, H, W, R>;
   constexpr int Hs = G::Hs, Ws = G::Ws, WP = G::WP, QW = G::QW, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
   if (tid < 16) tile[G::ROWS * WP + tid] = 0.f;
   for (int i = tid; i < KK5 * CS; i += 256) {
     const int k = i / CS, cs = i - k * CS;
-    wl[i] = w[cs * KK5 + k];
+    wl[i] = pgv_opnd(w[cs * KK5 + k], bf16 != 0);   // (PGV_COMPUTE_BF16: operands rounded, fp32 FMAs)
   }
   if (in_scale && tid == 0) {
     aff[0] = in_scale[0];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
     const int b = un / BANDS, band = un - b * BANDS;
     const int oh0 = band * R, Rb = min(R, Hs - oh0);
     __syncthreads();
-    pf.commit(tile, in_scale ? aff : nullptr, 1, 0, 1, tid);
+    pf.commit(tile, in_scale ? aff : nullptr, 1, 0, 1, tid, bf16 != 0);
     if (un + (int)gridDim.x < units) issue_unit(un + gridDim.x);
     __syncthreads();
     constexpr int NPASS = (R * QW + 255) / 256;
@@ -376,7 +376,8 @@ int raise_lds(K kern, const char* who) {
 
 }  // namespace
 
-// fp32, the reference size only (8 channels, 257x347 <-> 129x174); everything else stays with conv_direct.hip.
+// The reference size only (8 channels, 257x347 <-> 129x174), fp32 or bf16 operand mode (operands rounded where they are
+// committed to LDS, fp32 FMAs: products of bf16 values are exact in fp32); everything else stays with conv_direct.hip.
 template <int R>
 static int launch_up_c1(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* out, hipStream_t st) {
@@ -388,7 +389,7 @@ static int launch_up_c1(const pgv_conv_desc* d, const float* small_in, const flo
   const int units = d->B * G::BANDS;
   const int per_cu = (int)min((size_t)4, (size_t)kMaxLds / bytes);
   hipLaunchKernelGGL(kern, dim3(min(units, 256 * per_cu)), dim3(256), bytes, st, d->B, small_in, in_scale, in_shift, w,
-                     bias, act, slope, out);
+                     bias, act, slope, out, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0);
   PGV_CHECK_LAUNCH("conv_up_direct2");
   return 1;
 }
@@ -397,7 +398,7 @@ int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const flo
                         const float* w, const float* bias, int act, float slope, float* out, double* stats,
                         hipStream_t st) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
-  if (d->Hb != 257 || d->Wb != 347 || (d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
+  if (d->Hb != 257 || d->Wb != 347 || d->B <= 0) return 0;
   // 11 grid rows per unit: since the units of neighbouring bands share an XCD's L2 (pgv_xcd_block) the larger unit no
   // longer pays for its halo and its longer multiply phase hides more of the next unit's loads (88 -> 83 us)
   return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
@@ -418,14 +419,14 @@ static int launch_down_c1(const pgv_conv_desc* d, const float* big, const float*
     auto kern = down_c1_v2_kernel<8, 257, 347, R, true>;
     if (int rc = raise_lds(kern, "conv_down_direct2")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, big, in_scale, in_shift, w, bias, act, slope, out,
-                       *fuse);
+                       *fuse, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0);
     PGV_CHECK_LAUNCH("conv_down_direct2");
     return fuse->cls ? 3 : 1;   // (3: handled, class sums included)
   } else {
     auto kern = down_c1_v2_kernel<8, 257, 347, R, false>;
     if (int rc = raise_lds(kern, "conv_down_direct2")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, big, in_scale, in_shift, w, bias, act, slope, out,
-                       fz);
+                       fz, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0);
   }
   PGV_CHECK_LAUNCH("conv_down_direct2");
   return 1;
@@ -435,6 +436,6 @@ int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float*
                           const float* w, const float* bias, int act, float slope, float* out, double* stats,
                           const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
-  if (d->Hb != 257 || d->Wb != 347 || (d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
+  if (d->Hb != 257 || d->Wb != 347 || d->B <= 0) return 0;
   return launch_down_c1<5>(d, big, in_scale, in_shift, w, bias, act, slope, out, fuse, st);
 }

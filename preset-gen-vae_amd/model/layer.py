@@ -117,6 +117,7 @@ def _step_zeros(param, n, dtype, tag, device):
 # input-gradient epilogue (no pass over the gradient); 'passes': the reduce + apply passes for every block (A/B aid).
 BN_BACKWARD_MODE = 'fused'
 PASSFREE_MIN_PLANE = 1024   # H*W of the block's output from which the pass-free backward is used
+BF16_PASSFREE_MIN_N = 1 << 17   # ... and, in bf16 operand mode, B*H*W from which it is used (see ConvStackFn.backward)
 
 
 def set_bn_backward_mode(mode):
@@ -251,12 +252,17 @@ class ConvStackFn(torch.autograd.Function):
         # li's BatchNorm + activation backward in its epilogue (pgv_bwd_fuse) with coefficients derived from block
         # li+1's weight gradient (pgv_bn_bwd_coef) - the gradient of block li's BatchNorm output is never stored.
         # Only the top block of a stack (its gradient arrives from outside) runs the reduce + apply passes.
-        # (fp32 products only: in bf16 operand mode the identity yields sum g*bf16(o) instead of sum g*o - a coherent
-        # error of relative size 2^-9/sqrt(n) in every element of g_y that the next weight gradient, a heavily cancelling
-        # sum, amplifies; measured 6x the bf16 oracle's self-distance on enc2conv.weight at B = 3)
+        # (In bf16 operand mode the identity yields sum g*bf16(o) instead of sum g*o: a coherent error of relative size
+        # 2^-9/sqrt(n) in every element of g_y, n = elements per channel, that the next weight gradient - a heavily
+        # cancelling sum - amplifies; measured 6x the bf16 oracle's self-distance on enc2conv.weight at B = 3, n = 4455.
+        # The mode therefore uses the pass-free backward only from n = 2^17 on - training batches - where the term is at
+        # the fp32 rounding level.)
         passfree = [False] * nb
-        if BN_BACKWARD_MODE == 'fused' and ops.compute_dtype() == 'fp32':
+        if BN_BACKWARD_MODE == 'fused':
+            bf16 = ops.compute_dtype() != 'fp32'
             for li in range(nb - 1):
+                if bf16 and saved[li][3].numel() // saved[li][3].shape[1] < BF16_PASSFREE_MIN_N:
+                    continue
                 up = blocks[li + 1]
                 gsz = saved[li + 1][7]
                 hy, wy = (gsz.Hb, gsz.Wb) if up.up else (gsz.Hs, gsz.Ws)
