@@ -169,9 +169,10 @@ struct StageV2 {
       sh[j] = aff[C + cg];
     }
   }
+  // bf16: the committed operand is rounded to bfloat16 (PGV_COMPUTE_BF16: products of rounded operands on the fp32 MFMA)
   template <int J>
   static __device__ __forceinline__ void commit_slot(const Geo& g, const Set& s, float* __restrict__ tile, int tid,
-                                                     bool has_aff, float scj, float shj) {
+                                                     bool has_aff, float scj, float shj, bool bf16 = false) {
     if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
       const f32x4 t = s.v[J];
       const bool on = (s.live >> J) & 1u;
@@ -195,6 +196,7 @@ struct StageV2 {
         x.z = fmaf(e2, m2, a2);
         x.w = fmaf(t.w, m3, a3);
       }
+      if (bf16) x = f32x4{round_bf16(x.x), round_bf16(x.y), round_bf16(x.z), round_bf16(x.w)};
       *reinterpret_cast<f32x4*>(tile + 4 * tid + 1024 * J) = x;
     }
   }

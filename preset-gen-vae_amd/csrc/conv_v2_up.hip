@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          double* __restrict__ stats, pgv_bwd_fuse fuse) {
+                                                          double* __restrict__ stats, pgv_bwd_fuse fuse, int bf16) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, Wgp = G::Wgp, BANDS = G::BANDS, NW = G::NW;
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       Stage::wait_set();
       static_for<0, NPF>([&](auto j) {
         constexpr int J = decltype(j)::value;
-        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J]);
+        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J], bf16 != 0);
       });
     };
     issue_all(sA, 0);
@@ -218,7 +218,10 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     wl[m] = (unsigned)((cb * 16 + kh * 4 + kw) * 4);
   }
   // weight of input channel cs (uniform base + 32-bit per-lane byte offset: scalar-base loads)
-  auto wload = [&](int m, int cs) { return *reinterpret_cast<const float*>(wb + (size_t)cs * (CB * 16 * 4) + wl[m]); };
+  // (bf16 != 0: PGV_COMPUTE_BF16 - both operands rounded to bfloat16, the weights here, the input where it is committed)
+  auto wload = [&](int m, int cs) {
+    return pgv_opnd(*reinterpret_cast<const float*>(wb + (size_t)cs * (CB * 16 * 4) + wl[m]), bf16 != 0);
+  };
   const pgv_act_params actp = pgv_act_setup(act, slope);
   // accumulator layout: column (lane&15) = grid position, rows (lane>>4)*4 + reg = (channel lane>>4 of the M tile,
   // phase reg = ph*2 + pw); after the lane-pair exchange a lane holds 4 consecutive pixels of output row 2u + (lane&1)
@@ -674,10 +677,12 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   if (d->Cb != CB || d->Cs != CS) return 0;
   if (stats && fuse) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse);
+                         double*, pgv_bwd_fuse, int);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+  const int bf16 = (d->flags & PGV_COMPUTE_BF16) ? 1 : 0;
+  if (bf16 && STG) return 0;   // (the lean loader of the 129x174 form has no instruction slots for the rounding)
 #define PGV_UK(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
 #ifdef PGV_V2_EXPERIMENT
   if (fuse || !in_scale || actk != 1) return 0;
@@ -711,7 +716,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, small_in, in_scale, in_shift, w, bias, act, slope,
-                     out, stats, fuse ? *fuse : fz);
+                     out, stats, fuse ? *fuse : fz, bf16);
   PGV_CHECK_LAUNCH("conv_up_v2");
   return 1;
 }
@@ -723,7 +728,9 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                    const pgv_bwd_fuse* fuse, hipStream_t st) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
-  if (d->flags & PGV_COMPUTE_BF16) return 0;
+  // bf16 operand mode: only the 33x45 layer comes here (operands rounded at the LDS commit / weight load, fp32 MFMA: 95 us
+  // against 157 us for the band kernel's bf16 loop at this shape; the other shapes' band kernels are faster than this form)
+  if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 33 && d->Wb == 45)) return 0;
   if (fuse && d->Hb == 65 && d->Wb == 88) return 0;
   // fused backward epilogue (pgv_bwd_fuse), measured (us, fused / plain + separate pass): 33x45 279 / 107; 129x174 (band
   // kernel) 238 / 204 -> both run the plain form here and leave the epilogue to the in-place pass (return 2)
