@@ -1,4 +1,4 @@
-"""HBM traffic / counters per launch of the train step, keyed by the labels of bench.launch_table (round 2).
+"""HBM traffic / counters per launch of the train step, keyed by the labels of bench.launch_table (rounds 2-3).
 
 Every launch of the table is issued REPS times behind a sentinel kernel (torch erfinv_ on a 1-element tensor), so the
 dispatch stream of one process splits into one segment per label; all kernels of a segment (e.g. the wgrad kernel AND its
@@ -7,9 +7,10 @@ reduce pass) are added up and divided by REPS.  Counters are collected in separa
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 profiles/pmc_launches.py run
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 profiles/pmc_launches.py run
-    python3 profiles/pmc_launches.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r2_traffic.json
+    python3 profiles/pmc_launches.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r3_traffic.json
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_mfma ... run
-    python3 profiles/pmc_launches.py mfma gpurun_out/pmc_mfma > profiles/r2_mfma_util.json
+    python3 profiles/pmc_launches.py mfma gpurun_out/pmc_mfma > profiles/r3_mfma_util.json
+(scratch/profile_final.sh runs all of it)
 """
 import csv
 import re
