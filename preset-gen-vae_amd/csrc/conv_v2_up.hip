@@ -43,13 +43,17 @@ struct UpV2Cfg {
 // stage.  The stores are buffer stores with the hardware range check, so they need no branch inside the pinned k-step
 // regions: lanes without (4 / 2) valid pixels carry an out-of-range offset, and a descriptor of zero bytes drops the
 // stores of the first unit, which has nothing pending.  Needs NCH == 1 and an even image width; uses the lean loader.
-template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false>
+// BF16: PGV_COMPUTE_BF16 - both operands rounded to bfloat16 (the weights where they are loaded, the input where it is
+// committed to LDS), products on the fp32 MFMA.  Compile-time: as a run-time flag its test sat in the loader's commit
+// loop and cost the fp32 kernels 20-30 % (the loader waves have no instruction slots to spare).
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false,
+          bool BF16 = false>
 __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* __restrict__ small_in,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          double* __restrict__ stats, pgv_bwd_fuse fuse, int bf16) {
+                                                          double* __restrict__ stats, pgv_bwd_fuse fuse) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, Wgp = G::Wgp, BANDS = G::BANDS, NW = G::NW;
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       Stage::wait_set();
       static_for<0, NPF>([&](auto j) {
         constexpr int J = decltype(j)::value;
-        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J], bf16 != 0);
+        Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J], BF16);
       });
     };
     issue_all(sA, 0);
@@ -218,9 +222,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     wl[m] = (unsigned)((cb * 16 + kh * 4 + kw) * 4);
   }
   // weight of input channel cs (uniform base + 32-bit per-lane byte offset: scalar-base loads)
-  // (bf16 != 0: PGV_COMPUTE_BF16 - both operands rounded to bfloat16, the weights here, the input where it is committed)
   auto wload = [&](int m, int cs) {
-    return pgv_opnd(*reinterpret_cast<const float*>(wb + (size_t)cs * (CB * 16 * 4) + wl[m]), bf16 != 0);
+    return pgv_opnd(*reinterpret_cast<const float*>(wb + (size_t)cs * (CB * 16 * 4) + wl[m]), BF16);
   };
   const pgv_act_params actp = pgv_act_setup(act, slope);
   // accumulator layout: column (lane&15) = grid position, rows (lane>>4)*4 + reg = (channel lane>>4 of the M tile,
@@ -417,6 +420,74 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
           }
           st_s[m] += ss;
         }
+      } else if constexpr (FUSE && ACT == 0 && !HAS_AFF) {
+        // ---- fused backward epilogue of the multi-chunk layers ("WIN"): no registers are free during the k-steps to
+        // prefetch the saved activation (the accumulators alone are 112-128), so its tiles come in through a ring of
+        // D buffer loads that runs D tiles ahead of the arithmetic: compiler-visible raw buffer loads / stores with the
+        // hardware range check (no control flow: the s_waitcnt counts stay exact), geometry from the tables of the
+        // plain epilogue.  Only the first D loads of a unit expose their latency.
+        const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
+        constexpr int NPART = W % 4;             // pixels of the lane at the end of a row of an odd-width image
+        // (ring depth: what the accumulators leave of the 256 registers - deeper rings spill)
+        constexpr int QN = MTW * NT, DMAX = QN * 4 >= 128 ? 6 : (QN * 4 >= 112 ? 9 : 12), D = QN < DMAX ? QN : DMAX;
+        constexpr unsigned OOB = 0x80000000u;
+        const int64_t elem0 = ((int64_t)b * CB * H + 2 * u0) * W;
+        const unsigned left = (unsigned)min((int64_t)0x7FFFFFFF, ((int64_t)B * CB * (H * W) - elem0) * 4);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(fuse.a + elem0), 0, left, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + elem0), 0, left, 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 ar[D];
+        unsigned ap[D][NPART ? NPART : 1];
+        unsigned chb[MTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) chb[m] = (unsigned)(((wm * MTW + m) * 4 + ech) * (H * W) * 4);
+        auto fetch = [&](auto qc, auto slot) {   // saved activation of tile q = m * NT + t into ring slot
+          constexpr int q = decltype(qc)::value, sl = decltype(slot)::value, m = q / NT, t = q - m * NT;
+          const int tv = tof[t * 256];
+          const unsigned nv = (unsigned)tv >> 28, o4 = chb[m] + (unsigned)(tv & 0x0FFFFFFF) * 4u;
+          ar[sl] = __builtin_amdgcn_raw_buffer_load_b128(ra, nv == 4 ? o4 : OOB, 0, 0);
+#pragma unroll
+          for (int e = 0; e < NPART; ++e)
+            ap[sl][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (nv < 4 && (unsigned)e < nv) ? o4 + 4u * e : OOB, 0, 0);
+        };
+        static_for<0, D>([&](auto qc) { fetch(qc, qc); });
+        float ssm[MTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) ssm[m] = 0.f;
+        static_for<0, QN>([&](auto qc) {
+          constexpr int q = decltype(qc)::value, sl = q % D, m = q / NT, t = q - m * NT;
+          const int tv = tof[t * 256];
+          const unsigned nv = (unsigned)tv >> 28, o4 = chb[m] + (unsigned)(tv & 0x0FFFFFFF) * 4u;
+          const f32x2 bias2 = {bias_r[m], bias_r[m]};
+          const f32x2 y0 = f32x2{acc[m][t][0], acc[m][t][1]} + bias2, y1 = f32x2{acc[m][t][2], acc[m][t][3]} + bias2;
+          const float s0 = odd ? y0.x : y1.x, s1 = odd ? y0.y : y1.y;
+          const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+          const f32x2 rr = {r0, r1};
+          const f32x2 o01 = odd ? rr : y0, o23 = odd ? y1 : rr;
+          // (out-of-range loads return 0: the 16-byte and the per-pixel loads of a lane never both hit)
+          float av[4] = {__uint_as_float(ar[sl].x), __uint_as_float(ar[sl].y), __uint_as_float(ar[sl].z),
+                         __uint_as_float(ar[sl].w)};
+#pragma unroll
+          for (int e = 0; e < NPART; ++e) av[e] += __uint_as_float(ap[sl][e]);
+          const float g0 = pgv_bwd_apply(o01.x, av[0], ka_r[m], kb_r[m], kc_r[m], actd);
+          const float g1 = pgv_bwd_apply(o01.y, av[1], ka_r[m], kb_r[m], kc_r[m], actd);
+          const float g2 = pgv_bwd_apply(o23.x, av[2], ka_r[m], kb_r[m], kc_r[m], actd);
+          const float g3 = pgv_bwd_apply(o23.y, av[3], ka_r[m], kb_r[m], kc_r[m], actd);
+          const u32x4 gv = {__float_as_uint(g0), __float_as_uint(g1), __float_as_uint(g2), __float_as_uint(g3)};
+          __builtin_amdgcn_raw_buffer_store_b128(gv, ro, nv == 4 ? o4 : OOB, 0, 0);
+          const float ge[3] = {g0, g1, g2};
+          float part = 0.f;
+#pragma unroll
+          for (int e = 0; e < NPART; ++e) {
+            const bool on = nv < 4 && (unsigned)e < nv;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ge[e]), ro, on ? o4 + 4u * e : OOB, 0, 0);
+            part += on ? ge[e] : 0.f;
+          }
+          ssm[m] += nv == 4 ? (g0 + g1) + (g2 + g3) : part;
+          if constexpr (q + D < QN) fetch(std::integral_constant<int, q + D>{}, std::integral_constant<int, sl>{});
+        });
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) st_s[m] += ssm[m];
       } else if (!FUSE && ACT != 2) {
         const int* tof = tofl + (band == BANDS - 1 ? NT * 256 : 0);
         // No wave-uniform per-tile branches and no address arithmetic (a uniform branch per tile costs more than the
@@ -677,12 +748,11 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   if (d->Cb != CB || d->Cs != CS) return 0;
   if (stats && fuse) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse, int);
+                         double*, pgv_bwd_fuse);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
-  const int bf16 = (d->flags & PGV_COMPUTE_BF16) ? 1 : 0;
-  if (bf16 && STG) return 0;   // (the lean loader of the 129x174 form has no instruction slots for the rounding)
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
 #define PGV_UK(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
 #ifdef PGV_V2_EXPERIMENT
   if (fuse || !in_scale || actk != 1) return 0;
@@ -707,6 +777,24 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
       kern = actk == 1 ? (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 1, true>
                        : (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 0, true>;
   }
+  if (bf16) {   // operand-rounding instantiations exist for the 33x45 layer in the forms the train step issues
+    if constexpr (W == 45 && !STG) {
+#define PGV_UKB(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C, false, true>
+      if (fuse && !in_scale && actk == 0)
+        kern = PGV_UKB(true, false, 0);
+      else if (!fuse && !in_scale && actk == 0)
+        kern = PGV_UKB(false, false, 0);
+      else if (!fuse && !in_scale && actk == 1)
+        kern = PGV_UKB(false, false, 1);
+      else if (!fuse && in_scale && actk == 1)
+        kern = PGV_UKB(false, true, 1);
+      else
+        return 0;
+#undef PGV_UKB
+    } else {
+      return 0;
+    }
+  }
   if (int rc = raise_lds_once((const void*)kern, "conv_up_v2")) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
     pgv_set_error("conv_up_v2: memset failed");
@@ -716,7 +804,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, small_in, in_scale, in_shift, w, bias, act, slope,
-                     out, stats, fuse ? *fuse : fz, bf16);
+                     out, stats, fuse ? *fuse : fz);
   PGV_CHECK_LAUNCH("conv_up_v2");
   return 1;
 }
@@ -731,14 +819,10 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
   // bf16 operand mode: only the 33x45 layer comes here (operands rounded at the LDS commit / weight load, fp32 MFMA: 95 us
   // against 157 us for the band kernel's bf16 loop at this shape; the other shapes' band kernels are faster than this form)
   if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 33 && d->Wb == 45)) return 0;
+  // fused backward epilogue (pgv_bwd_fuse): 129x174 prefetches the saved activation during the k-steps (APRE), the
+  // multi-chunk layers run a ring of buffer loads through the epilogue (WIN); only plain input-gradient products
+  // (65x88: 128 accumulator registers leave no room for the ring - it spills; the band kernel's fused epilogue stays)
   if (fuse && d->Hb == 65 && d->Wb == 88) return 0;
-  // fused backward epilogue (pgv_bwd_fuse), measured (us, fused / plain + separate pass): 33x45 279 / 107; 129x174 (band
-  // kernel) 238 / 204 -> both run the plain form here and leave the epilogue to the in-place pass (return 2)
-  // (129x174 since got the prefetching form of conv_up_ws_kernel: APRE)
-  if (fuse && d->Hb == 33 && d->Wb == 45) {
-    const int rc = pgv_conv_up_v2(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, nullptr, st);
-    return rc == 1 ? 2 : rc;
-  }
   if (d->Hb == 33 && d->Wb == 45)   // 64 -> 32 channels onto 33x45: 2 bands of 9 / 8 grid rows, M split 4 ways
     return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
   if (d->Hb == 65 && d->Wb == 88)   // 32 -> 16 channels onto 65x88: 3 bands of 11 grid rows, waves split the positions
