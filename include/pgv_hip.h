@@ -235,6 +235,15 @@ int pgv_dropout_mask(const uint64_t* rng_state, uint64_t stream_id, float p, int
  * drawn on the fly and stored for the backward product (encoder.py:85, decoder.py:65). */
 int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, int64_t n, const float* x, float* y,
                       float* mask, void* stream);
+/* nn.Dropout (train mode) without a stored mask, the form the train step uses: y = x' * mask with the mask
+ * pgv_dropout_mask draws from the same state / stream; saved_state[2] receives a copy of the generator state it was drawn
+ * from, and pgv_dropout_bwd regenerates the mask from that copy (gx = gy * mask; in place allowed).  x is [B][C][HW];
+ * scale / shift (nullable, [C]): x' = x*scale[c] + shift[c] - the BatchNorm of the encoder's last conv block folded into
+ * this pass (encoder.py:85) - else x' = x. */
+int pgv_dropout_fwd(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
+                    const float* scale, const float* shift, float* y, uint64_t* saved_state, void* stream);
+int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, int64_t n, const float* gy, float* gx,
+                    void* stream);
 /* eps ~ N(0,1) i.i.d. (VAE.py:54-55). */
 int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream);
 /* rng_state[1] += inc (device side, keeps graph replays advancing). */

@@ -119,9 +119,16 @@ struct StageV2 {
   struct Geo {
     unsigned meta[NPF];  // rr | ncol << 8 | c << 12   (ncol = 0: pad chunk or idle lane)
     int off0[NPF];       // byte offset of the slot's window inside the chunk's planes for a band that starts at row 0
-    __device__ __forceinline__ void init(int tid) {
-#pragma unroll
-      for (int j = 0; j < NPF; ++j) {
+    // after_slot(integral_constant<j>) runs when slot j's constants are ready: the caller issues the first item's load of
+    // the slot there, so the rest of the set-up (two integer divisions per slot, up to 32 slots) overlaps its memory
+    // latency instead of preceding it (as in StageLean::Geo::init)
+    template <class F>
+    __device__ __forceinline__ void init(int tid, F&& after_slot) {
+      static_for_geo<0>(tid, after_slot);
+    }
+    template <int j, class F>
+    __device__ __forceinline__ void static_for_geo(int tid, F&& after_slot) {
+      if constexpr (j < NPF) {
         const int e = tid + 256 * j;
         const int ee = min(e, ITEMS - 1);
         const int rowi = ee / QR, q = ee - rowi * QR;
@@ -131,6 +138,8 @@ struct StageV2 {
         // the partial chunk at the end of a row reads the LAST four floats of the row (rotated into place at commit)
         const int col = 4 * q - ((NP != 0 && nc > 0 && nc < 4) ? 4 - NP : 0);
         off0[j] = ((c * H + rr) * W + col) * 4;
+        after_slot(std::integral_constant<int, j>{});
+        static_for_geo<j + 1>(tid, after_slot);
       }
     }
   };

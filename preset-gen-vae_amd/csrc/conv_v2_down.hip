@@ -156,8 +156,13 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
     __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
     typename Stage::Geo geo;
     typename Stage::Set sA, sB;
-    geo.init(ltid);
     sA.live = sB.live = 0;
+    {   // slot geometry, with item 0's loads going out slot by slot as their constants become ready
+      const float* p0;
+      int ih0;
+      item_src(0, p0, ih0);
+      geo.init(ltid, [&](auto jc) { Stage::template issue_slot<decltype(jc)::value>(geo, sA, p0, ih0); });
+    }
     auto issue_all = [&](typename Stage::Set& sx, int it) {
       const float* p0;
       int ih0;
@@ -178,8 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
     };
     // Pipeline: item n lives in register set n & 1 and LDS buffer n & 1; loads are issued two items ahead of their
     // commit; ALWAYS exactly one older and one newer set are in flight when a commit starts (wait_set).
-    issue_all(sA, 0);
-    issue_all(sB, 1);
+    issue_all(sB, 1);  // (item 0 went out during the set-up)
     commit_all(sA, 0, tile0);
     issue_all(sA, 2);
     V2_T0();

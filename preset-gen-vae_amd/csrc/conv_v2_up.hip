@@ -158,8 +158,13 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
     __builtin_amdgcn_s_setprio(PGV_V2_PRIO_LOADER);
     typename Stage::Geo geo;
     typename Stage::Set sA, sB;
-    geo.init(ltid);
     sA.live = sB.live = 0;
+    {   // slot geometry, with item 0's loads going out slot by slot as their constants become ready
+      const float* p0;
+      int ih0;
+      item_src(0, p0, ih0);
+      geo.init(ltid, [&](auto jc) { Stage::template issue_slot<decltype(jc)::value>(geo, sA, p0, ih0); });
+    }
     auto issue_all = [&](typename Stage::Set& sx, int it) {
       const float* p0;
       int ih0;
@@ -178,8 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
         Stage::template commit_slot<J>(geo, sx, dst, ltid, HAS_AFF, sc[J], sh[J], BF16);
       });
     };
-    issue_all(sA, 0);
-    issue_all(sB, 1);
+    issue_all(sB, 1);  // (item 0 went out during the set-up)
     commit_all(sA, 0, tile0);
     issue_all(sA, 2);
     ws_barrier();

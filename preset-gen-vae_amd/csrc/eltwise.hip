@@ -80,6 +80,78 @@ __global__ void dropout_apply_kernel(const uint64_t* __restrict__ rng, uint64_t 
   }
 }
 
+// nn.Dropout without a stored mask: Philox is counter-based, so backward regenerates the mask from a copy of the
+// generator state the forward drew from (two words) instead of reading back 4 bytes per element - 2 instead of 3 tensors
+// of traffic per pass.  Optional per-channel affine on the way in (x is [B][C][HW]): the BatchNorm of the encoder's last
+// conv block, which has no consumer kernel to fold it into (encoder.py:85: Dropout -> Linear).
+__global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
+                                   int64_t n, const float* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int C, int64_t HW, float* __restrict__ y,
+                                   uint64_t* __restrict__ saved, int vec) {
+  const uint64_t seed = rng[0], off = rng[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) saved[0] = seed, saved[1] = off;
+  const int64_t n4 = (n + 3) / 4;
+  // channel of the quad, kept incrementally along the grid-stride walk (a 64-bit division per quad cost more than the
+  // Philox rounds): position (ch, rem) of element 4q inside its sample, advanced by the stride's (channels, remainder)
+  const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  int ch = 0, rem = 0, d_ch = 0, d_rem = 0;
+  if (scale && vec) {
+    ch = (int)((q0 * 4 / HW) % C), rem = (int)(q0 * 4 % HW);
+    d_ch = (int)((stride * 4 / HW) % C), d_rem = (int)(stride * 4 % HW);
+  }
+  for (int64_t q = q0; q < n4; q += stride) {
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    const float m[4] = {u01(r.x) >= p ? keep_scale : 0.f, u01(r.y) >= p ? keep_scale : 0.f,
+                        u01(r.z) >= p ? keep_scale : 0.f, u01(r.w) >= p ? keep_scale : 0.f};
+    if (vec && q * 4 + 4 <= n) {   // (vec: 16-byte aligned, and HW % 4 == 0 when there is an affine: one channel per quad)
+      float4 xv = reinterpret_cast<const float4*>(x)[q];
+      if (scale) {
+        const int c = ch;
+        rem += d_rem, ch += d_ch;
+        if (rem >= (int)HW) rem -= (int)HW, ch += 1;
+        if (ch >= C) ch -= C;
+        const float sc = scale[c], sh = shift[c];
+        xv = make_float4(fmaf(xv.x, sc, sh), fmaf(xv.y, sc, sh), fmaf(xv.z, sc, sh), fmaf(xv.w, sc, sh));
+      }
+      reinterpret_cast<float4*>(y)[q] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i < n) {
+          float xv = x[i];
+          if (scale) {
+            const int c = (int)((i / HW) % C);
+            xv = fmaf(xv, scale[c], shift[c]);
+          }
+          y[i] = xv * m[j];
+        }
+      }
+    }
+  }
+}
+
+__global__ void dropout_bwd_kernel(const uint64_t* __restrict__ saved, uint64_t stream_id, float p, float keep_scale,
+                                   int64_t n, const float* __restrict__ gy, float* __restrict__ gx, int vec) {
+  const uint64_t seed = saved[0], off = saved[1];
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    const float m[4] = {u01(r.x) >= p ? keep_scale : 0.f, u01(r.y) >= p ? keep_scale : 0.f,
+                        u01(r.z) >= p ? keep_scale : 0.f, u01(r.w) >= p ? keep_scale : 0.f};
+    if (vec && q * 4 + 4 <= n) {
+      const float4 g = reinterpret_cast<const float4*>(gy)[q];
+      reinterpret_cast<float4*>(gx)[q] = make_float4(g.x * m[0], g.y * m[1], g.z * m[2], g.w * m[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i < n) gx[i] = gy[i] * m[j];
+      }
+    }
+  }
+}
+
 __global__ void normal_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, int64_t n,
                               float* __restrict__ out) {
   const uint64_t seed = rng[0], off = rng[1];
@@ -321,6 +393,30 @@ int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, in
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state,
                      stream_id, p, 1.0f / (1.0f - p), n, x, y, mask, aligned16(x, y, mask) ? 1 : 0);
   PGV_CHECK_LAUNCH("dropout_apply");
+  return PGV_OK;
+}
+
+int pgv_dropout_fwd(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
+                    const float* scale, const float* shift, float* y, uint64_t* saved_state, void* stream) {
+  PGV_CHECK_ARG(rng_state && x && y && saved_state && B >= 0 && C > 0 && HW > 0 && p >= 0.f && p < 1.f &&
+                    (scale == nullptr) == (shift == nullptr),
+                "pgv_dropout_fwd: bad argument");
+  const int64_t n = B * C * HW;
+  const int vec = aligned16(x, y, y) && (!scale || HW % 4 == 0) ? 1 : 0;
+  // (n == 0 still records the state: backward of an empty batch reads it)
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(max(n, (int64_t)1), 4)), dim3(kBlock), 0, pgv_stream(stream),
+                     rng_state, stream_id, p, 1.0f / (1.0f - p), n, x, scale, shift, C, HW, y, saved_state, vec);
+  PGV_CHECK_LAUNCH("dropout_fwd");
+  return PGV_OK;
+}
+
+int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, int64_t n, const float* gy, float* gx,
+                    void* stream) {
+  PGV_CHECK_ARG(saved_state && gy && gx && n >= 0 && p >= 0.f && p < 1.f, "pgv_dropout_bwd: bad argument");
+  if (n == 0) return PGV_OK;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, pgv_stream(stream), saved_state,
+                     stream_id, p, 1.0f / (1.0f - p), n, gy, gx, aligned16(gy, gx, gx) ? 1 : 0);
+  PGV_CHECK_LAUNCH("dropout_bwd");
   return PGV_OK;
 }
 

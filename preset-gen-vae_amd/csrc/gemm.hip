@@ -125,23 +125,44 @@ __device__ __forceinline__ s16x4 pack4(f32x4 v) {
 }
 
 constexpr int FK = 32;                 // K slab
+constexpr int kGemmDepth = 4;          // slabs in flight per workgroup
 constexpr int KROW = FK + 4;           // row stride of a k-contiguous tile [64][KROW]
 constexpr int MROW_A = 64 + 16;        // row stride of an m-contiguous A tile [FK][MROW_A]
 constexpr int NROW_B = 64 + 4;         // row stride of an n-contiguous B tile [FK][NROW_B]
 
-template <bool A_K, bool B_K, bool BF16>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(int M, int N, int K, const float* __restrict__ A, int64_t lda,
+template <bool A_K, bool B_K, bool BF16, int DEPTH>
+__global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ Bm, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc,
-                                                        const float* __restrict__ bias_n, int k_per_split, int atomic) {
+                                                        const float* __restrict__ bias_n, int k_per_split, int nsplit,
+                                                        int atomic) {
   constexpr int A_FLOATS = A_K ? 64 * KROW : FK * MROW_A;
   constexpr int B_FLOATS = B_K ? 64 * KROW : FK * NROW_B;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+  // Workgroup -> (m tile, n tile, K split).  Workgroups L, L + 8, L + 16, ... share an XCD and its L2 (round-robin
+  // placement): the ones that read the same slice of the LARGE operand - all tiles of a K split, or the m tiles of an n
+  // panel when K is not split - are given to one XCD, next to each other in time, so that slice is fetched from HBM once
+  // and not once per tile (with n tiles fastest, as a plain 3-D grid has them: 100 MB of fabric reads for the 38 MB of
+  // the encoder's Linear forward).
+  const int Mt = M >> 6, Nt = N >> 6;
+  int mt, nt, zs;
+  {
+    const int L = blockIdx.x, inner = nsplit > 1 ? Mt * Nt : Mt, outer = nsplit > 1 ? nsplit : Nt;
+    int in_i, out_i;
+    if ((outer & 7) == 0) {
+      const int idx = L >> 3;
+      in_i = idx % inner, out_i = (L & 7) + 8 * (idx / inner);
+    } else {
+      in_i = L % inner, out_i = L / inner;
+    }
+    if (nsplit > 1) mt = in_i / Nt, nt = in_i - mt * Nt, zs = out_i;
+    else mt = in_i, nt = out_i, zs = 0;
+  }
+  const int m0 = mt * 64, n0 = nt * 64;
+  const int kbeg = zs * k_per_split, kend = min(K, kbeg + k_per_split);
 
   // loaders: 512 float4 per operand per slab, two per thread
   int64_t a_src[2], b_src[2];
@@ -168,77 +189,97 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(int M, int N, int K, con
       b_dst[i] = r * NROW_B + 4 * f;
     }
   }
-  f32x4 ra[2], rb[2];
-  auto issue = [&](int k0) {
+  // DEPTH slabs in flight in registers ahead of the one being multiplied: these products are short-K or split-K with a
+  // few slabs per workgroup, and one slab ahead left every workgroup waiting a memory latency per slab (all six Linear
+  // products of the step took ~22 us whatever their size)
+  f32x4 ra[DEPTH][2], rb[DEPTH][2];
+  auto issue = [&](int slot, int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ra[i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + (A_K ? (int64_t)k0 : (int64_t)k0 * lda));
-      rb[i] = *reinterpret_cast<const f32x4*>(Bm + b_src[i] + (B_K ? (int64_t)k0 : (int64_t)k0 * ldb));
+      ra[slot][i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + (A_K ? (int64_t)k0 : (int64_t)k0 * lda));
+      rb[slot][i] = *reinterpret_cast<const f32x4*>(Bm + b_src[i] + (B_K ? (int64_t)k0 : (int64_t)k0 * ldb));
     }
   };
-  auto commit = [&](float* st) {
+  auto commit = [&](int slot, float* st) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
-      *reinterpret_cast<f32x4*>(st + A_FLOATS + b_dst[i]) = rb[i];
+      *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[slot][i];
+      *reinterpret_cast<f32x4*>(st + A_FLOATS + b_dst[i]) = rb[slot][i];
     }
   };
-  const int a_frag = A_K ? (wave * 16 + m) * KROW + 4 * j : 4 * j * MROW_A + wave * 16 + m;
-  const int b_frag = B_K ? m * KROW + 4 * j : 4 * j * NROW_B + m;
-  f32x4 acc[4];
+  // a wave owns a 32x32 quarter of the tile (2x2 MFMA tiles): 8 LDS fragment reads per 16 k against 20 for a 16x64
+  // strip - at 64x64 per workgroup the strip layout moved 80 KB of fragments per slab, 3/4 of the LDS rate at MFMA speed
+  const int wm = wave >> 1, wn = wave & 1;
+  const int a_frag = A_K ? (wm * 32 + m) * KROW + 4 * j : 4 * j * MROW_A + wm * 32 + m;
+  const int b_frag = B_K ? (wn * 32 + m) * KROW + 4 * j : 4 * j * NROW_B + wn * 32 + m;
+  f32x4 acc[4];   // [im][in]
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kbeg < kend) {
-    issue(kbeg);
-    commit(lds);
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+      if (kbeg + u * FK < kend) issue(u, kbeg + u * FK);
+    commit(0, lds);
     __syncthreads();
     int stage = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += FK, stage ^= 1) {
+    for (int kb = kbeg; kb < kend; kb += DEPTH * FK) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {   // slab kb + u*FK: its ring slot is u, free again once it sits in LDS
+      const int k0 = kb + u * FK;
+      if (k0 >= kend) break;
       const float* st = lds + stage * STAGE;
       const bool more = k0 + FK < kend;
-      if (more) issue(k0 + FK);
+      if (k0 + DEPTH * FK < kend) issue(u, k0 + DEPTH * FK);
       const float* ap = st + a_frag;
       const float* bp = st + A_FLOATS + b_frag;
 #pragma unroll
       for (int g = 0; g < FK / 16; ++g) {
-        f32x4 a;
-        if (A_K) {
-          a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
-        } else {
+        f32x4 a[2], b[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = ap[(16 * g + e) * MROW_A];
-        }
+        for (int h = 0; h < 2; ++h) {
+          if (A_K) {
+            a[h] = *reinterpret_cast<const f32x4*>(ap + 16 * h * KROW + 16 * g);
+          } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          f32x4 b;
+            for (int e = 0; e < 4; ++e) a[h][e] = ap[(16 * g + e) * MROW_A + 16 * h];
+          }
           if (B_K) {
-            b = *reinterpret_cast<const f32x4*>(bp + 16 * t * KROW + 16 * g);
+            b[h] = *reinterpret_cast<const f32x4*>(bp + 16 * h * KROW + 16 * g);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = bp[(16 * g + e) * NROW_B + 16 * t];
+            for (int e = 0; e < 4; ++e) b[h][e] = bp[(16 * g + e) * NROW_B + 16 * h];
           }
-          if constexpr (BF16) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(a), pack4(b), acc[t], 0, 0, 0);
-          } else {
+        }
+        if constexpr (BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[t], 0, 0, 0);
-          }
+          for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(a[t >> 1]), pack4(b[t & 1]), acc[t], 0, 0, 0);
+        } else {
+          // round-robin over the four accumulators: v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a
+          // dependent one only after 40
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t >> 1][e], b[t & 1][e], acc[t], 0, 0, 0);
         }
       }
-      if (more) commit(lds + (stage ^ 1) * STAGE);
+      if (more) commit((u + 1) % DEPTH, lds + (stage ^ 1) * STAGE);
       __syncthreads();
+      stage ^= 1;
+    }
     }
   }
-  // acc[t][i]: row m0 + wave*16 + 4j + i, column n0 + 16t + m
+  // acc[2 im + in][i]: row m0 + 32 wm + 16 im + 4j + i, column n0 + 32 wn + 16 in + m
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int n = n0 + 16 * t + m;
+    const int n = n0 + 32 * wn + 16 * (t & 1) + m;
     // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
-    const float bias = ((!atomic || (atomic == 2 && blockIdx.z == 0)) && bias_n) ? bias_n[n] : 0.f;
+    const float bias = ((!atomic || (atomic == 2 && zs == 0)) && bias_n) ? bias_n[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float* c = C + (int64_t)(m0 + wave * 16 + 4 * j + i) * ldc + n;
+      float* c = C + (int64_t)(m0 + 32 * wm + 16 * (t >> 1) + 4 * j + i) * ldc + n;
       if (atomic)
         atomicAdd(c, acc[t][i] + bias);
       else
@@ -248,14 +289,15 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(int M, int N, int K, con
 }
 
 template <bool A_K, bool B_K>
-void launch_fast(dim3 grid, hipStream_t st, int bf16, int M, int N, int K, const float* A, int64_t lda, const float* B,
+void launch_fast(int nsplit, hipStream_t st, int bf16, int M, int N, int K, const float* A, int64_t lda, const float* B,
                  int64_t ldb, float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
+  const dim3 grid((unsigned)((M / 64) * (N / 64) * nsplit));
   if (bf16)
-    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n,
-                       k_per_split, atomic);
+    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, true, kGemmDepth>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C,
+                       ldc, bias_n, k_per_split, nsplit, atomic);
   else
-    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,
-                       bias_n, k_per_split, atomic);
+    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, false, kGemmDepth>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C,
+                       ldc, bias_n, k_per_split, nsplit, atomic);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -280,24 +322,28 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
         ldb % 4 == 0 && aligned16(A) && aligned16(B)) {
       const int tiles = (M / 64) * (N / 64);
       int splits = (int)max((int64_t)1, min(pgv_cdiv(768, tiles), (int64_t)K / (FK * 4)));
-      const int k_per_split = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
-      splits = (int)pgv_cdiv(K, k_per_split);
+      int k_per_split_v = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
+      splits = (int)pgv_cdiv(K, k_per_split_v);
+      if (splits > 8 && (splits & 7)) {   // a multiple of 8 splits: one XCD per K slice (see the kernel)
+        const int s8 = splits & ~7, kp = (int)(pgv_cdiv(pgv_cdiv(K, s8), FK) * FK);
+        if (pgv_cdiv(K, kp) == s8) splits = s8, k_per_split_v = kp;
+      }
+      const int k_per_split = k_per_split_v;
       const int atomic = splits > 1 ? ((flags & PGV_PREZEROED) ? 2 : 1) : 0;
       if (atomic == 1) {
         hipLaunchKernelGGL(init_c_kernel, dim3((unsigned)min((int64_t)1024, pgv_cdiv((int64_t)M * N, 256))), dim3(256),
                            0, st, C, M, N, ldc, bias_n);
         PGV_CHECK_LAUNCH("gemm_init_c");
       }
-      dim3 grid((unsigned)(N / 64), (unsigned)(M / 64), (unsigned)splits);
       const int bf16 = (flags & PGV_COMPUTE_BF16) ? 1 : 0;
       if (a_k && b_k)
-        launch_fast<true, true>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        launch_fast<true, true>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else if (a_k)
-        launch_fast<true, false>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        launch_fast<true, false>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else if (b_k)
-        launch_fast<false, true>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        launch_fast<false, true>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else
-        launch_fast<false, false>(grid, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        launch_fast<false, false>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       PGV_CHECK_LAUNCH("gemm_fast");
       return PGV_OK;
     }

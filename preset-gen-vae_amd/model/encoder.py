@@ -137,27 +137,28 @@ class SpectrogramEncoder(nn.Module):
         """Single-channel input: per-channel stack and mixer run as ONE fused stack (BatchNorm folded across the seam)."""
         return self.single_ch_cnn.pgv_blocks() + self._mixer_blocks()
 
-    def _forward_cnns(self, x_spectrograms):
+    def _forward_cnns(self, x_spectrograms, out_dropout=None):
         if self.spectrogram_channels == 1:
-            return layer.run_stack(x_spectrograms, self._all_blocks(), self.training)
+            return layer.run_stack(x_spectrograms, self._all_blocks(), self.training, out_dropout=out_dropout)
         # stacked spectrograms (encoder.py:99-104): the shared per-channel stack once per input channel - each call has
         # its own BatchNorm batch statistics and running-stat update, as in the reference - then the features mixer
         single = self.single_ch_cnn.pgv_blocks()
         outs = [layer.run_stack(x_spectrograms[:, ch:ch + 1, :, :].contiguous(), single, self.training)
                 for ch in range(self.spectrogram_channels)]
-        return layer.run_stack(torch.cat(outs, dim=1), self._mixer_blocks(), self.training)
+        return layer.run_stack(torch.cat(outs, dim=1), self._mixer_blocks(), self.training, out_dropout=out_dropout)
 
     def forward(self, x_spectrograms, dropout_mask=None):
         """``dropout_mask`` (optional, [B, features], already scaled by 1/(1-p)) injects the Dropout mask for parity
         runs; by default it is drawn on device."""
         n_minibatch = x_spectrograms.size()[0]
-        cnn_out = self._forward_cnns(x_spectrograms).view(n_minibatch, -1)
-        if self.training and self.fc_dropout > 0.0:
-            if dropout_mask is None:
-                from ..rng import STREAM_ENC_DROPOUT, device_rng
-                cnn_out = layer.DropoutFn.apply(cnn_out, device_rng(self, cnn_out.device), self.fc_dropout,
-                                                STREAM_ENC_DROPOUT)
-            else:
+        if self.training and self.fc_dropout > 0.0 and dropout_mask is None:
+            # the Dropout mask is drawn and applied by the pass that applies the last conv block's BatchNorm
+            from ..rng import STREAM_ENC_DROPOUT, device_rng
+            drop = (device_rng(self, x_spectrograms.device), self.fc_dropout, STREAM_ENC_DROPOUT)
+            cnn_out = self._forward_cnns(x_spectrograms, out_dropout=drop).view(n_minibatch, -1)
+        else:
+            cnn_out = self._forward_cnns(x_spectrograms).view(n_minibatch, -1)
+            if self.training and self.fc_dropout > 0.0:
                 cnn_out = layer.MaskMulFn.apply(cnn_out, dropout_mask.reshape(-1))
         lin = self.mlp[1]
         z_mu_logvar = layer.LinearFn.apply(cnn_out, lin.weight, lin.bias)

@@ -159,13 +159,15 @@ class ConvStackFn(torch.autograd.Function):
     """A chain of conv blocks evaluated with folded BatchNorm between consecutive blocks."""
 
     @staticmethod
-    def forward(ctx, x, blocks, training, sq_target, sq_scale, *params):
+    def forward(ctx, x, blocks, training, sq_target, sq_scale, out_dropout, *params):
         """``sq_target`` / ``sq_scale`` (optional): also return ``sq_scale * sum((out - sq_target)^2)`` - the
         reconstruction criterion evaluated where the output is produced, so that its backward can be fused with the
         output block's (``pgv_sqerr_act_bwd``).  A NEGATIVE ``sq_scale`` asks for the deferred form (scale = -sq_scale):
         no forward pass over the tensors at all - the returned scalar starts at zero and receives its value from the
         backward kernel, which reads both tensors anyway; only for callers that always run backward before they look
-        at the value (VAETrainStep)."""
+        at the value (VAETrainStep).
+        ``out_dropout`` = (rng, p, stream_id) (optional): nn.Dropout on the output (encoder.py:85), in the pass that
+        applies the last block's BatchNorm; backward regenerates the mask (``pgv_dropout_fwd`` / ``_bwd``)."""
         x = x.contiguous()
         B = x.shape[0]
         dev = x.device
@@ -213,7 +215,13 @@ class ConvStackFn(torch.autograd.Function):
                     mean = rstd = None
             saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g))
             cur, cur_scale, cur_shift = a, scale, shift
-        out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
+        ctx.drop = None
+        if out_dropout is not None:
+            rng, p, stream_id = out_dropout
+            out, drop_state = rng.dropout_nomask(p, cur, stream_id, cur_scale, cur_shift)
+            ctx.drop = (drop_state, stream_id, float(p))
+        else:
+            out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
         ctx.blocks, ctx.saved, ctx.params = blocks, saved, params
         ctx.sq = None
         if sq_target is None:
@@ -242,8 +250,10 @@ class ConvStackFn(torch.autograd.Function):
             if ctx.sq_deferred is not None and not fused_sq:   # the deferred value has no fused kernel to come from
                 ctx.sq_deferred.add_(ops.sqerr_fwd(saved[-1][3], ctx.sq[0], ctx.sq[1]))
             if g_out is None and not fused_sq:
-                return (None,) * (5 + len(params))
+                return (None,) * (6 + len(params))
         g_o = g_out.contiguous() if g_out is not None else None
+        if ctx.drop is not None and g_o is not None:
+            g_o = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o)
         dev = saved[-1][3].device
         nb = len(blocks)
         B = saved[-1][3].shape[0]
@@ -391,15 +401,16 @@ class ConvStackFn(torch.autograd.Function):
                         _grad_done(params[pl + 2], params[pl + 3])
             else:
                 g_o = None
-        return (g_o, None, None, None, None) + tuple(grads)
+        return (g_o, None, None, None, None, None) + tuple(grads)
 
 
-def run_stack(x, blocks, training, sq_target=None, sq_scale=None):
-    """``sq_target`` given: returns (output, sq_scale * sum((output - sq_target)^2)), see ConvStackFn.forward."""
+def run_stack(x, blocks, training, sq_target=None, sq_scale=None, out_dropout=None):
+    """``sq_target`` given: returns (output, sq_scale * sum((output - sq_target)^2)); ``out_dropout`` = (rng, p,
+    stream_id): nn.Dropout on the output - see ConvStackFn.forward."""
     params = []
     for blk in blocks:
         params += blk.params()
-    return ConvStackFn.apply(x, tuple(blocks), bool(training), sq_target, sq_scale, *params)
+    return ConvStackFn.apply(x, tuple(blocks), bool(training), sq_target, sq_scale, out_dropout, *params)
 
 
 class _ConvBlockBase(nn.Sequential):
@@ -516,14 +527,15 @@ class DropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rng, p, stream_id=0):
-        y, mask = rng.dropout(p, x.contiguous(), stream_id)
-        ctx.save_for_backward(mask)
+        # no stored mask: backward regenerates it from the generator state of this draw (two words)
+        y, saved = rng.dropout_nomask(p, x.contiguous(), stream_id)
+        ctx.drop = (saved, stream_id, float(p))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (mask,) = ctx.saved_tensors
-        return ops.mul(gy.contiguous(), mask), None, None, None
+        saved, stream_id, p = ctx.drop
+        return ops.dropout_bwd(saved, stream_id, p, gy.contiguous()), None, None, None
 
 
 class BatchNorm1dFn(torch.autograd.Function):

@@ -382,6 +382,29 @@ def dropout_apply(rng_state, stream_id, p, x):
     return y, mask
 
 
+def dropout_fwd(rng_state, stream_id, p, x, scale=None, shift=None):
+    """nn.Dropout forward without a stored mask (``pgv_dropout_fwd``): returns (y, saved_state) - ``saved_state`` is the
+    copy of the generator state ``dropout_bwd`` regenerates the mask from.  ``scale`` / ``shift`` ([C], x is [B, C, ...]):
+    a per-channel affine applied on the way in."""
+    _chk(x, scale, shift)
+    B = x.shape[0]
+    C = x.shape[1] if scale is not None else 1
+    HW = x.numel() // max(1, B * C)
+    y = torch.empty_like(x)
+    saved = torch.empty(2, device=x.device, dtype=torch.int64)
+    _lib.check(_lib.load().pgv_dropout_fwd(rng_state.data_ptr(), stream_id, p, _p(x), B, C, max(1, HW), _p(scale),
+                                           _p(shift), _p(y), saved.data_ptr(), _stream()), "pgv_dropout_fwd")
+    return y, saved
+
+
+def dropout_bwd(saved_state, stream_id, p, gy):
+    _chk(gy)
+    gx = torch.empty_like(gy)
+    _lib.check(_lib.load().pgv_dropout_bwd(saved_state.data_ptr(), stream_id, p, gy.numel(), _p(gy), _p(gx), _stream()),
+               "pgv_dropout_bwd")
+    return gx
+
+
 def normal(rng_state, stream_id, shape, device):
     out = torch.empty(shape, device=device, dtype=torch.float32)
     _lib.check(_lib.load().pgv_normal(rng_state.data_ptr(), stream_id, out.numel(), _p(out), _stream()), "pgv_normal")

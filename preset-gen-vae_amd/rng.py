@@ -55,6 +55,13 @@ class DeviceRNG:
         self._advance(x.numel())
         return y, mask
 
+    def dropout_nomask(self, p, x, stream_id=STREAM_DROPOUT, scale=None, shift=None):
+        """nn.Dropout forward on ``x`` (after an optional per-channel affine) without a stored mask: returns
+        (y, saved_state) for ``ops.dropout_bwd``; the same draw as ``dropout_mask``."""
+        y, saved = ops.dropout_fwd(self.state, stream_id, float(p), x, scale, shift)
+        self._advance(x.numel())
+        return y, saved
+
     def normal(self, shape, stream_id=STREAM_EPS):
         out = ops.normal(self.state, stream_id, tuple(int(s) for s in shape), self.state.device)
         self._advance(out.numel())

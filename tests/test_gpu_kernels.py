@@ -809,6 +809,21 @@ def test_rng_distributions(ops):
             ref.dropout_mask(0.3, (256, 24576))                     # advance the reference stream the same way
         mr = ref.dropout_mask(0.3, shape)
         assert torch.equal(m.view(*shape), mr) and torch.equal(y, x * mr)
+    # ... and so is the mask-free form the train step uses: forward draws and applies, backward regenerates the mask from
+    # the saved copy of the state - also after the generator itself has moved on; optional per-channel affine on the way in
+    for shape in ((256, 64, 16, 24), (3, 5, 7, 11), (2, 1001)):
+        rng_d, ref = DeviceRNG(torch.device('cuda'), seed=7), DeviceRNG(torch.device('cuda'), seed=7)
+        x = torch.randn(*shape, device='cuda')
+        affine = len(shape) == 4
+        sc = torch.rand(shape[1], device='cuda') + 0.5 if affine else None
+        sh = torch.randn(shape[1], device='cuda') if affine else None
+        y, saved = rng_d.dropout_nomask(0.3, x, 2, sc, sh)
+        mr = ref.dropout_mask(0.3, shape, 2)
+        xa = _affine_fma(x.cpu(), sc.cpu(), sh.cpu()).cuda() if affine else x
+        assert torch.equal(y, xa * mr)
+        rng_d.dropout_mask(0.3, (1000,))                               # the generator moves on
+        g = torch.randn(*shape, device='cuda')
+        assert torch.equal(ops.dropout_bwd(saved, 2, 0.3, g), g * mr)
 
 
 @pytest.mark.parametrize("kind", ["conv", "tconv"])

@@ -923,24 +923,25 @@ def test_dropout_masks_are_independent_and_advance():
     from preset_gen_vae_amd import ops
     ae = _build('speccnn4l1_bn', 64, 2, False).cuda().train()
     rec, adv = [], []
-    orig, orig_adv = ops.dropout_apply, ops.rng_advance
+    orig, orig_adv = ops.dropout_fwd, ops.rng_advance
 
-    def patched(state, stream_id, p, x):
-        y, m = orig(state, stream_id, p, x)
-        rec.append((stream_id, m.clone()))
-        return y, m
+    def patched(state, stream_id, p, x, scale=None, shift=None):
+        y, saved = orig(state, stream_id, p, x, scale, shift)
+        # (no mask is stored: it is what backward regenerates from the saved generator state)
+        rec.append((stream_id, ops.dropout_bwd(saved, stream_id, p, torch.ones_like(x)).reshape(x.shape[0], -1)))
+        return y, saved
 
     def patched_adv(state, inc):
         adv.append(inc)
         return orig_adv(state, inc)
 
-    ops.dropout_apply, ops.rng_advance = patched, patched_adv
+    ops.dropout_fwd, ops.rng_advance = patched, patched_adv
     try:
         x = _cuda32(synth_input(2))
         ae(x)
         ae(x)
     finally:
-        ops.dropout_apply, ops.rng_advance = orig, orig_adv
+        ops.dropout_fwd, ops.rng_advance = orig, orig_adv
     assert len(rec) == 4 and len(adv) == 2 and all(a >= 2 * 25024 // 4 for a in adv)
     (s0, enc0), (s1, dec0), (_, enc1), (_, dec1) = rec
     assert s0 != s1 and enc0.shape == dec0.shape
