@@ -158,6 +158,26 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
                    const float* small, const float* small_scale, const float* small_shift, float* gw,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
+/* pgv_conv_wgrad and, behind it, the BatchNorm-backward coefficients of the block BELOW (pgv_bn_bwd_coef_from_gy with gy =
+ * the operand of this call that is the block's output gradient - `small` when lower_is_big, else `big` - and gw = this
+ * call's result), as one call.  With the wave-specialised weight-gradient kernels the partial-gradient reduce pass and
+ * the border tap sums (independent of each other) share ONE launch, followed by the coefficient kernel: two dependent
+ * launches behind the weight-gradient kernel instead of three; otherwise the pieces run one after the other.
+ * scratch: zeroed doubles, >= C_gy*kh*kw + 1, private to the call.  With PGV_PREZEROED gw must hold zeros (the
+ * coefficients are those of THIS call's gradient). */
+typedef struct pgv_coef_req {
+  int32_t lower_is_big;
+  const float* cls;   /* class sums of gy (see pgv_conv_tap_sums); required */
+  const float* w;     /* weights of this block, [Cs][Cb][kh][kw] */
+  const float *scale, *shift, *mean, *rstd; /* of the lower block's BatchNorm */
+  int64_t n;          /* elements per channel of the lower block's output */
+  float *coef, *ggamma, *gbeta;
+  double* scratch;    /* C_gy*kh*kw + 1 doubles, zeroed: receives the tap sums of gy */
+} pgv_coef_req;
+int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small, const float* small_scale, const float* small_shift, float* gw,
+                        void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, void* stream);
+
 /* ---- BatchNorm (nn.BatchNorm2d / BatchNorm1d train mode, layer.py:21-26, encoder.py:86-87) ------- */
 /* stats[0:C] = sum, stats[C:2C] = sum of squares over (B,HW) of a[B,C,HW]. Overwrites stats.
  * Cross-workgroup accumulation is in float64 (one double atomic per workgroup): the per-channel sums feed

@@ -34,6 +34,17 @@ class BwdFuse(Structure):
 
 _FUSE = POINTER(BwdFuse)
 
+
+class CoefReq(Structure):
+    """Mirror of ``pgv_coef_req``: the BatchNorm-backward coefficients of the block below, asked of a weight-gradient
+    call."""
+    _fields_ = [("lower_is_big", c_int32), ("cls", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("n", c_int64), ("coef", c_void_p), ("ggamma", c_void_p),
+                ("gbeta", c_void_p), ("scratch", c_void_p)]
+
+
+_COEF = POINTER(CoefReq)
+
 # name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
     "pgv_abi_version": (c_int, []),
@@ -45,6 +56,7 @@ SIGNATURES = {
     "pgv_conv_up_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),
     "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),

@@ -171,18 +171,39 @@ int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d) {
 int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                    const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                    void* workspace, int64_t workspace_bytes, void* stream) {
+  return pgv_conv_wgrad_coef(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
+                             workspace_bytes, nullptr, stream);
+}
+
+int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                        const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                        void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, void* stream) {
   int rc = check_desc(d, "pgv_conv_wgrad");
+  PGV_CHECK_ARG(req == nullptr || (req->cls && req->w && req->scale && req->shift && req->mean && req->rstd && req->coef &&
+                                   req->scratch && req->n > 0),
+                "pgv_conv_wgrad_coef: incomplete pgv_coef_req");
   if (rc) return rc;
   PGV_CHECK_ARG(gw && (d->B == 0 || (big && small_in)), "pgv_conv_wgrad: null tensor");
   PGV_CHECK_ARG((big_scale == nullptr) == (big_shift == nullptr), "pgv_conv_wgrad: scale/shift must come together");
   PGV_CHECK_ARG((small_scale == nullptr) == (small_shift == nullptr),
                 "pgv_conv_wgrad: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
+  // the coefficients of the block below when they did not come out of the weight-gradient launches themselves
+  auto coef_after = [&](int rc_w) -> int {
+    if (rc_w || !req || d->B == 0) return rc_w;
+    return pgv_bn_bwd_coef_from_gy(d, req->lower_is_big, req->lower_is_big ? small_in : big, req->cls, req->scratch, req->w,
+                                   gw, req->scale, req->shift, req->mean, req->rstd, req->n, req->coef, req->ggamma,
+                                   req->gbeta, PGV_PREZEROED, stream);
+  };
   if (g_policy != 1) {
     rc = 0;
-    if (g_policy == 0 && !g_no_v2)
+    if (g_policy == 0 && !g_no_v2) {
       rc = pgv_conv_wgrad_v2(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
-                             workspace_bytes, st);
+                             workspace_bytes, req, st);
+      if (rc == 3)   // weight gradient and tap sums done
+        return pgv_bn_bwd_coef(d, req->lower_is_big, req->w, gw, req->scratch, req->scale, req->shift, req->mean, req->rstd,
+                               req->n, req->coef, req->ggamma, req->gbeta, stream);
+    }
     if (rc == 0 && g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0 && g_policy == 0)
@@ -194,9 +215,9 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
     if (rc == 0)
       rc = pgv_conv_wgrad_gemm(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc < 0) return rc;
-    if (rc == 1) return PGV_OK;
+    if (rc == 1) return coef_after(PGV_OK);
   }
-  return pgv_conv_wgrad_generic(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
+  return coef_after(pgv_conv_wgrad_generic(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st));
 }
 
 }  // extern "C"

@@ -55,9 +55,10 @@ int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float*
                           const pgv_bwd_fuse* fuse, hipStream_t st);
 
 int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d);
+// (req != null: returns 3 when the tap sums of the output gradient - req->scratch - came out of the same launches)
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                      void* workspace, int64_t workspace_bytes, hipStream_t st);
+                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st);
 
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,

@@ -2,6 +2,7 @@
 // partial-gradient reduce pass; structure and measurements: conv_v2_common.h, DESIGN.md section 3.4.
 #define PGV_V2_TU wgrad
 #include "conv_v2_common.h"
+#include "bn_taps.h"
 
 namespace {
 
@@ -305,6 +306,105 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The reduce pass above and the border tap sums of the block's output gradient (bn_taps.h) in ONE launch - two roles
+// that share nothing but the launch (pgv_conv_wgrad_coef): each is a dependent launch of ~5 us otherwise, and the tap
+// sums only need gy, not the weight gradient.
+//   workgroups [0, nred): reduce role, as wgrad_reduce_kernel;
+//   workgroups [nred, ...): border role, as tap_border_kernel of bn.hip (T[c][tap] += class sum - unpaired border sum).
+// (Tried and dropped: also forming the coefficients here, S_o and S_1 accumulated with float64 atomics and finished by
+// the last workgroup to arrive.  Same-address atomics from a thousand workgroups retire one per ~90 ns, the arrival
+// counter alone cost 25 us, and a device-scope __threadfence() per workgroup - an L2 write-back on this chip - 100 us.)
+struct WgradTapsArgs {
+  const float* partial; int nparts, n4; float* gw; int accumulate, nred;
+  const float* gy; int B, Cgy, H, W, per, nsplit, gy_is_big, s, p; TapBorder tb; const float* cls; double* T;
+};
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a) {
+  constexpr int KK = K * K;
+  __shared__ f32x4 red[32][8];
+  __shared__ float res[KK];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < a.nred) {
+    const int el = tid & 7, sl = tid >> 3;
+    const int e = blockIdx.x * 8 + el;
+    f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+    if (e < a.n4) {
+      const f32x4* pp = reinterpret_cast<const f32x4*>(a.partial) + e;
+      int k = sl;
+      for (; k + 7 * 32 < a.nparts; k += 8 * 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(k + 32 * u) * a.n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv += v[u];
+      }
+      for (; k < a.nparts; k += 32) sv += pp[(size_t)k * a.n4];
+    }
+    red[sl][el] = sv;
+    __syncthreads();
+    if (sl == 0 && e < a.n4) {
+#pragma unroll
+      for (int k = 1; k < 32; ++k) sv += red[k][el];
+      f32x4* o = reinterpret_cast<f32x4*>(a.gw) + e;
+      if (a.accumulate) sv += *o;
+      *o = sv;
+    }
+  } else {
+    const int bid = blockIdx.x - a.nred;
+    const int c = bid % a.Cgy, r = bid / a.Cgy, by = r % a.nsplit, bz = r / a.nsplit;
+    tap_border_block<K>(a.gy, a.B, a.Cgy, a.H, a.W, a.per, a.gy_is_big, a.s, a.p, a.tb, c, by, bz, res);
+    if (tid < KK) {
+      const int kh = tid / K, kw = tid - kh * K;
+      double t = -(double)res[tid];
+      if (by == 0 && bz == 0) {   // the class total enters once per channel
+        const int m = a.gy_is_big ? a.s : 1;
+        const int rho = a.gy_is_big ? (((kh - a.p) % a.s) + a.s) % a.s : 0, kap = a.gy_is_big ? (((kw - a.p) % a.s) + a.s) % a.s : 0;
+        t += (double)a.cls[c * m * m + rho * m + kap];
+      }
+      atomicAdd(&a.T[(int64_t)c * KK + tid], t);
+    }
+  }
+}
+
+// arguments of the border role (as tap_sums_launch of bn.hip sizes them); false when the border form does not apply
+inline bool wgrad_taps_setup(const pgv_conv_desc* d, const pgv_coef_req* req, const float* big, const float* small_in,
+                             WgradTapsArgs* a, int* nblocks) {
+  const int gy_is_big = !req->lower_is_big;
+  const int C = gy_is_big ? d->Cb : d->Cs, H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
+  const int oH = gy_is_big ? d->Hs : d->Hb, oW = gy_is_big ? d->Ws : d->Wb;
+  const int K = d->kh;
+  if (!req->cls || d->kh != d->kw || (K != 4 && K != 5) || H > 1024 || W > 1024 || (gy_is_big && d->stride > 3)) return false;
+  if (!tap_axis(gy_is_big != 0, H, K, d->stride, d->pad, oH, &a->tb.ra, &a->tb.rb, a->tb.rm) ||
+      !tap_axis(gy_is_big != 0, W, K, d->stride, d->pad, oW, &a->tb.ca, &a->tb.cb, a->tb.cm))
+    return false;
+  const int NE = (a->tb.ra + a->tb.rb) * W + (H - a->tb.ra - a->tb.rb) * (a->tb.ca + a->tb.cb);
+  const int nz = (int)max((int64_t)1, pgv_cdiv(NE, kTapChunk));
+  a->per = (int)max((int64_t)1, min((int64_t)16, pgv_cdiv((int64_t)d->B * C * nz, 512)));
+  a->nsplit = (int)pgv_cdiv(d->B, a->per);
+  a->gy = gy_is_big ? big : small_in;
+  a->B = d->B, a->Cgy = C, a->H = H, a->W = W, a->gy_is_big = gy_is_big, a->s = d->stride, a->p = d->pad;
+  a->cls = req->cls, a->T = req->scratch;
+  *nblocks = a->nred + C * a->nsplit * nz;
+  return true;
+}
+
+// reduce + border launch; 1 when launched, 0 when the border form does not apply (the caller reduces on its own)
+inline int launch_wgrad_reduce_taps(const pgv_conv_desc* d, const pgv_coef_req* req, const float* big,
+                                    const float* small_in, const float* partial, int nparts, int n4, float* gw,
+                                    hipStream_t st) {
+  WgradTapsArgs a;
+  a.partial = partial, a.nparts = nparts, a.n4 = n4, a.gw = gw;
+  a.accumulate = (d->flags & PGV_PREZEROED) ? 1 : 0, a.nred = (n4 + 7) / 8;
+  int nblocks = 0;
+  if (!wgrad_taps_setup(d, req, big, small_in, &a, &nblocks)) return 0;
+  if (d->kh == 4)
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel<4>, dim3(nblocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel<5>, dim3(nblocks), dim3(256), 0, st, a);
+  PGV_CHECK_LAUNCH("conv_wgrad_v2 reduce + tap sums");
+  return 1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // WGRAD of the 1 <-> 8 channel 5x5 layers (enc1 / dec8: big = [B,1,257,347], small = [B,8,129,174]), same structure as
 // conv_wgrad_ws_kernel:  gw[cs][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,0,2oh-2+kh,2ow-2+kw].
@@ -526,7 +626,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
 
 template <int R>
 int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* small_in, const float* small_scale,
-                     const float* small_shift, float* gw, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+                     const float* small_shift, float* gw, void* workspace, int64_t workspace_bytes,
+                     const pgv_coef_req* req, hipStream_t st) {
   using G = Wgrad5Cfg<8, 347, 257, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -542,6 +643,10 @@ int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* smal
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, small_in, small_scale, small_shift, (float*)workspace);
   PGV_CHECK_LAUNCH("conv_wgrad5_v2");
   const int n4 = 8 * G::NTAP / 4;
+  if (req) {   // reduce + the tap sums of the output gradient in one launch (3: the caller goes on with the coefficients)
+    const int rc = launch_wgrad_reduce_taps(d, req, big, small_in, (const float*)workspace, nparts, n4, gw, st);
+    if (rc) return rc < 0 ? rc : 3;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, nparts, n4, gw,
                      (d->flags & PGV_PREZEROED) ? 1 : 0);
   PGV_CHECK_LAUNCH("conv_wgrad5_v2 reduce");
@@ -551,7 +656,7 @@ int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* smal
 template <int CB, int CS, int W, int H, int R>
 int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                     const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                    void* workspace, int64_t workspace_bytes, hipStream_t st) {
+                    void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st) {
   using G = WgradV2Cfg<CB, CS, W, H, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -570,6 +675,10 @@ int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_s
                      small_shift, (float*)workspace);
   PGV_CHECK_LAUNCH("conv_wgrad_v2");
   const int n4 = CS * CB * 16 / 4;
+  if (req) {   // reduce + the tap sums of the output gradient in one launch (3: the caller goes on with the coefficients)
+    const int rc = launch_wgrad_reduce_taps(d, req, big, small_in, (const float*)workspace, grid, n4, gw, st);
+    if (rc) return rc < 0 ? rc : 3;
+  }
   // PGV_PREZEROED: gw holds zeros or an earlier partial sum to add to; otherwise it is overwritten
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, grid, n4, gw,
                      (d->flags & PGV_PREZEROED) ? 1 : 0);
@@ -594,20 +703,20 @@ int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d) {
 
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                      void* workspace, int64_t workspace_bytes, hipStream_t st) {
+                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st) {
   if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->B > 0 &&
       d->Cb == 1 && d->Cs == 8 && d->Hb == 257 && d->Wb == 347 && !big_scale)
-    return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, st);
+    return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, st);
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if ((d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
   if (d->Hb == 33 && d->Wb == 45)
     return launch_wgrad_v2<32, 64, 45, 33, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                              workspace, workspace_bytes, st);
+                                              workspace, workspace_bytes, req, st);
   if (d->Hb == 65 && d->Wb == 88)
     return launch_wgrad_v2<16, 32, 88, 65, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                              workspace, workspace_bytes, st);
+                                              workspace, workspace_bytes, req, st);
   if (d->Hb == 129 && d->Wb == 174)
     return launch_wgrad_v2<8, 16, 174, 129, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                               workspace, workspace_bytes, st);
+                                               workspace, workspace_bytes, req, st);
   return 0;
 }

@@ -283,7 +283,9 @@ class ConvStackFn(torch.autograd.Function):
         n_red = sum(2 * blk.c_out for li, (blk, sv) in enumerate(zip(blocks, saved))
                     if blk.bn is not None and sv[5] is not None and not passfree[li])
         arena = _step_zeros(params[0], n_red, torch.float64, 'red', dev) if n_red else None  # BN-backward projections
-        n_tap = sum(blocks[li + 1].c_out * blocks[li + 1].k ** 2 + 1 for li in range(nb - 1)
+        def tap_slot(li):   # float64 scratch of the coefficient request of block li (ops.conv_wgrad, coef_req)
+            return ops.coef_scratch(saved[li + 1][7], not blocks[li + 1].up)
+        n_tap = sum(tap_slot(li) for li in range(nb - 1)
                     if passfree[li] and blocks[li].bn is not None and saved[li][5] is not None)
         tap_arena = _step_zeros(params[0], n_tap, torch.float64, 'tap', dev) if n_tap else None
         a_off = t_off = 0
@@ -342,23 +344,21 @@ class ConvStackFn(torch.autograd.Function):
                 if ggamma is not None:
                     _grad_done(params[pi + 2], params[pi + 3])
             gw, gw_ret, gw_zero = _grad_dest(w, accumulated=True)
-            if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
-                ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero)
-            else:        # Conv2d: big = block input, small = g_y
-                ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift, prezeroed=gw_zero)
             grads[pi] = gw_ret
             need_dx = li > 0 or ctx.needs_input_grad[0]
             fuse = None
+            coef_req = None
             if need_dx and li > 0 and passfree[li - 1]:
                 low = blocks[li - 1]
                 _, _, _, a_low, _, mean_low, rstd_low, _ = saved[li - 1]
                 pl = pis[li - 1]
                 Cl = low.c_out
                 if low.bn is not None and mean_low is not None:
-                    # train-mode BatchNorm: coefficients from W * gW of this block and the tap sums of g_y (must be
-                    # launched before this block's weight gradient is announced: a gradient exchange rewrites it)
-                    T = tap_arena[t_off:t_off + C * blk.k ** 2 + 1]   # (+ the arrival ticket of the fused launch)
-                    t_off += C * blk.k ** 2 + 1
+                    # train-mode BatchNorm: coefficients from W * gW of this block and the tap sums of g_y, computed by
+                    # this block's weight-gradient call (before the weight gradient is announced: a gradient exchange
+                    # rewrites it)
+                    T = tap_arena[t_off:t_off + tap_slot(li - 1)]
+                    t_off += tap_slot(li - 1)
                     # class sums of g_y: for a Conv2d consumer simply this block's bias gradient; for a ConvTranspose2d
                     # one the sums by row / column parity class
                     if not blk.up:
@@ -370,8 +370,9 @@ class ConvStackFn(torch.autograd.Function):
                     coef = torch.empty(3 * Cl, device=dev, dtype=torch.float32)
                     gg_low, grads[pl + 2] = _grad_dest(params[pl + 2])
                     gbt_low, grads[pl + 3] = _grad_dest(params[pl + 3])
-                    ops.bn_bwd_coef_from_gy(geom, not blk.up, g_y, cls, T, w, gw, in_scale, in_shift, mean_low, rstd_low,
-                                            a_low.numel() // Cl, coef, gg_low, gbt_low, prezeroed=True)
+                    coef_req = dict(lower_is_big=not blk.up, cls=cls, w=w, scale=in_scale, shift=in_shift, mean=mean_low,
+                                    rstd=rstd_low, n=a_low.numel() // Cl, coef=coef, ggamma=gg_low, gbeta=gbt_low,
+                                    scratch=T)
                 elif low.bn is not None:   # eval-mode BatchNorm: g_a = scale * g
                     coef = torch.cat([in_scale, torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
                 else:                      # no BatchNorm (the first encoder block): activation backward only
@@ -384,7 +385,13 @@ class ConvStackFn(torch.autograd.Function):
                     cls_low = cls_arena[c_off:c_off + 4 * Cl]
                     c_off += 4 * Cl
                 fuse = (a_low, coef, gb_low, low.act, low.slope, cls_low)
-            # (announced only now: the coefficient kernels above read this block's bias and weight gradients, which a
+            if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
+                ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero,
+                               coef_req=coef_req)
+            else:        # Conv2d: big = block input, small = g_y
+                ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift, prezeroed=gw_zero,
+                               coef_req=coef_req)
+            # (announced only now: the coefficient arithmetic reads this block's bias and weight gradients, which a
             # gradient exchange rewrites in place)
             _grad_done(params[pi + 1], w)
             if need_dx:

@@ -147,17 +147,43 @@ def _workspace(device, nbytes):
     return ws
 
 
+def coef_scratch(geom, lower_is_big):
+    """float64 elements of a ``coef_req`` scratch (``pgv_coef_req.scratch``): the tap sums of the output gradient + 1."""
+    c_gy = geom.Cs if lower_is_big else geom.Cb
+    return c_gy * geom.k * geom.k + 1
+
+
 def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None,
-               prezeroed=False):
-    """``prezeroed``: ``gw`` already holds zeros (e.g. a slice of the zero_grad'ed flat gradient buffer)."""
+               prezeroed=False, coef_req=None):
+    """``prezeroed``: ``gw`` already holds zeros (e.g. a slice of the zero_grad'ed flat gradient buffer).
+    ``coef_req``: also the BatchNorm-backward coefficients of the block below (``pgv_conv_wgrad_coef``) - a dict with the
+    fields of ``pgv_coef_req``; ``scratch`` is zeroed float64 of ``coef_scratch(geom, lower_is_big)`` elements."""
     B = big.shape[0]
     _chk(big, small, gw, big_scale, big_shift, small_scale, small_shift)
     lib = _lib.load()
     d = geom.desc(B, int(prezeroed))
     nbytes = lib.pgv_conv_wgrad_workspace(ctypes.byref(d))
     ws = _workspace(big.device, nbytes)
-    _lib.check(lib.pgv_conv_wgrad(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small), _p(small_scale),
-                                  _p(small_shift), _p(gw), _p(ws), nbytes, _stream()), "pgv_conv_wgrad")
+    if coef_req is None:
+        _lib.check(lib.pgv_conv_wgrad(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small),
+                                      _p(small_scale), _p(small_shift), _p(gw), _p(ws), nbytes, _stream()),
+                   "pgv_conv_wgrad")
+        return gw
+    r = coef_req
+    lower_is_big = bool(r['lower_is_big'])
+    _chk(r['cls'], r['w'], r['scale'], r['shift'], r['mean'], r['rstd'], r['coef'], r.get('ggamma'), r.get('gbeta'))
+    _chk64(r['scratch'])
+    c_low, c_gy = (geom.Cb, geom.Cs) if lower_is_big else (geom.Cs, geom.Cb)
+    if r['scratch'].numel() < coef_scratch(geom, lower_is_big):
+        raise ValueError("conv_wgrad: coef_req scratch needs coef_scratch(geom, lower_is_big) doubles")
+    if r['coef'].numel() < 3 * c_low:
+        raise ValueError("conv_wgrad: coef_req coef needs 3*C_lower floats")
+    req = _lib.CoefReq(int(lower_is_big), _p(r['cls']), _p(r['w']), _p(r['scale']), _p(r['shift']), _p(r['mean']),
+                       _p(r['rstd']), int(r['n']), _p(r['coef']), _p(r.get('ggamma')), _p(r.get('gbeta')),
+                       _p(r['scratch']))
+    _lib.check(lib.pgv_conv_wgrad_coef(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small),
+                                       _p(small_scale), _p(small_shift), _p(gw), _p(ws), nbytes, ctypes.byref(req),
+                                       _stream()), "pgv_conv_wgrad_coef")
     return gw
 
 

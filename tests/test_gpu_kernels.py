@@ -511,6 +511,23 @@ def test_bn_backward_without_a_pass(ops, case, policy):
             cscale = coef.abs().max().item()
             assert (coef2 - coef).abs().max().item() <= 2e-5 * cscale, (lower_is_big, (coef2 - coef).abs().max().item())
             assert rel_l2(gg2, gg) < 1e-4 and rel_l2(gbt2, gbt) < 1e-4
+            # and as part of the consumer's weight-gradient call (pgv_conv_wgrad_coef), into an uninitialised gradient and
+            # into a zeroed one (PGV_PREZEROED)
+            for prior in (None, 0.0):
+                gw3 = torch.full_like(gw, float('nan')) if prior is None else torch.zeros_like(gw)
+                T3 = torch.zeros(ops.coef_scratch(geom, lower_is_big), device='cuda', dtype=torch.float64)
+                coef3, gg3, gbt3 = torch.empty_like(coef), torch.empty_like(gg), torch.empty_like(gbt)
+                req = dict(lower_is_big=lower_is_big, cls=cls, w=w_d, scale=sc_d, shift=sh_d, mean=mu_d, rstd=rs_d,
+                           n=B * H * W, coef=coef3, ggamma=gg3, gbeta=gbt3, scratch=T3)
+                if lower_is_big:
+                    ops.conv_wgrad(geom, a_d, gy_d, gw3, big_scale=sc_d, big_shift=sh_d, prezeroed=prior is not None,
+                                   coef_req=req)
+                else:
+                    ops.conv_wgrad(geom, gy_d, a_d, gw3, small_scale=sc_d, small_shift=sh_d, prezeroed=prior is not None,
+                                   coef_req=req)
+                assert (gw3 - gw).abs().max().item() <= 1e-5 * gw.abs().max().item()
+                assert (coef3 - coef).abs().max().item() <= 2e-5 * cscale, (lower_is_big, prior)
+                assert rel_l2(gg3, gg) < 1e-4 and rel_l2(gbt3, gbt) < 1e-4
             gb = torch.zeros(C, device='cuda')
             fuse = (a_d, coef, gb, ops.PGV_ACT_LEAKY_RELU, 0.1)
             if lower_is_big:
