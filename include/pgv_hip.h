@@ -264,6 +264,10 @@ int pgv_dropout_fwd(const uint64_t* rng_state, uint64_t stream_id, float p, cons
                     const float* scale, const float* shift, float* y, uint64_t* saved_state, void* stream);
 int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, int64_t n, const float* gy, float* gx,
                     void* stream);
+/* pgv_dropout_bwd over a [M][N] gradient plus colsum[n] (+)= sum_m gx[m][n] in the same pass - the bias gradient of the
+ * nn.Linear whose output the Dropout follows (decoder.py:64-65).  PGV_PREZEROED: colsum already holds zeros. */
+int pgv_dropout_bwd_colsum(const uint64_t* saved_state, uint64_t stream_id, float p, int M, int N, const float* gy,
+                           float* gx, float* colsum, int flags, void* stream);
 /* eps ~ N(0,1) i.i.d. (VAE.py:54-55). */
 int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream);
 /* rng_state[1] += inc (device side, keeps graph replays advancing). */
@@ -277,6 +281,10 @@ int pgv_mul(const float* x, const float* m, int64_t n, float* y, void* stream);
 int pgv_reparam_kl_fwd(const float* ml, const float* eps, int B, int D, float kl_scale, float* z, float* kl,
                        void* stream);
 /* g_ml = d/d(ml) [ <g_z, z> + g_kl * kl ] ; g_z may be NULL, g_kl is a device scalar pointer (may be NULL). */
+/* The same with eps drawn inside: eps_out[i] = element i of what pgv_normal draws from the same state / stream (stored
+ * for pgv_reparam_kl_bwd).  PGV_PREZEROED: kl already holds zero (no clearing launch). */
+int pgv_reparam_kl_fwd_rng(const float* ml, const uint64_t* rng_state, uint64_t stream_id, int B, int D, float kl_scale,
+                           float* z, float* eps_out, float* kl, int flags, void* stream);
 int pgv_reparam_kl_bwd(const float* ml, const float* eps, const float* g_z, const float* g_kl, int B, int D,
                        float kl_scale, float* g_ml, void* stream);
 
@@ -296,6 +304,12 @@ int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
  * pows[2] += 1 (the number of steps taken: the powers underflow - beta1^t after ~7000 steps - and cannot be inverted);
  * hyper[1] = 1-pows[0], hyper[2] = 1-pows[1].  Keeps the bias corrections advancing under hipGraph replay. */
 int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* stream);
+/* pgv_adam_tick plus the rest of a train step's single-thread bookkeeping in the same launch: the generator offset
+ * rng_state[1] += rng_inc (pgv_rng_advance; rng_state nullable) and the reported loss total[0] = loss_a[0] +
+ * loss_b[0] * weight_b[0] (+ loss_c[0]) (train.py:227,246; total / loss_c nullable).  Placed in front of pgv_adam_step. */
+int pgv_step_tick(double* pows, float* hyper, float beta1, float beta2, uint64_t* rng_state, uint64_t rng_inc,
+                  const float* loss_a, const float* loss_b, const float* weight_b, const float* loss_c, float* total,
+                  void* stream);
 
 /* ---- STFT -> mel -> dB front-end (utils/audio.py:20-92, data/abstractbasedataset.py:129-131) -------- */
 /* wav[B][n_samples] fp32 -> out[B][n_mels][n_frames]; n_fft=1024 only, hop any, centre zero padding.

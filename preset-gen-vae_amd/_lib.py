@@ -83,15 +83,18 @@ SIGNATURES = {
     "pgv_dropout_apply": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P, _P]),
     "pgv_dropout_fwd": (c_int, [_P, c_uint64, c_float, _P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P]),
     "pgv_dropout_bwd": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P]),
+    "pgv_dropout_bwd_colsum": (c_int, [_P, c_uint64, c_float, c_int, c_int, _P, _P, _P, c_int, _P]),
     "pgv_normal": (c_int, [_P, c_uint64, c_int64, _P, _P]),
     "pgv_rng_advance": (c_int, [_P, c_uint64, _P]),
     "pgv_mul": (c_int, [_P, _P, c_int64, _P, _P]),
     "pgv_reparam_kl_fwd": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "pgv_reparam_kl_fwd_rng": (c_int, [_P, _P, c_uint64, c_int, c_int, c_float, _P, _P, _P, c_int, _P]),
     "pgv_reparam_kl_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "pgv_sqerr_fwd": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
     "pgv_sqerr_bwd": (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P, _P]),
     "pgv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, _P]),
     "pgv_adam_tick": (c_int, [_P, _P, c_float, c_float, _P]),
+    "pgv_step_tick": (c_int, [_P, _P, c_float, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
     "pgv_stft_mel": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_float,
                              c_float, c_float, _P, _P]),
     "pgv_stft": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_int, c_float,

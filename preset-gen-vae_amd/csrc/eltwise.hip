@@ -152,19 +152,56 @@ __global__ void dropout_bwd_kernel(const uint64_t* __restrict__ saved, uint64_t 
   }
 }
 
+// four standard normals from one Philox block: Box-Muller, two pairs; u in (0,1] for the log
+__device__ __forceinline__ void normal4(const U4 r, float (&v)[4]) {
+  const float u0 = 1.0f - u01(r.x), u1 = u01(r.y), u2 = 1.0f - u01(r.z), u3 = u01(r.w);
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  v[0] = r0 * c0, v[1] = r0 * s0, v[2] = r1 * c1, v[3] = r1 * s1;
+}
+
+// dropout_bwd_kernel over a [M][N] gradient with the column sums of the result on the way (the bias gradient of the
+// nn.Linear in front of the Dropout, decoder.py:64-65): a thread owns four columns and R rows, loads in flight per
+// thread = R, one float atomic per column and row group.  N % 4 == 0, 16-byte aligned rows.
+template <int R>
+__global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const uint64_t* __restrict__ saved, uint64_t stream_id,
+                                                                 float p, float keep_scale, int M, int N4,
+                                                                 const float4* __restrict__ gy, float4* __restrict__ gx,
+                                                                 float* __restrict__ colsum) {
+  const uint64_t seed = saved[0], off = saved[1];
+  const int qc = blockIdx.x * 256 + threadIdx.x;
+  if (qc >= N4) return;
+  const int r0 = blockIdx.y * R;
+  float4 g[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+    if (r0 + u < M) g[u] = gy[(int64_t)(r0 + u) * N4 + qc];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (r0 + u >= M) break;
+    const int64_t q = (int64_t)(r0 + u) * N4 + qc;
+    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+    const float4 o = make_float4(u01(r.x) >= p ? g[u].x * keep_scale : 0.f, u01(r.y) >= p ? g[u].y * keep_scale : 0.f,
+                                 u01(r.z) >= p ? g[u].z * keep_scale : 0.f, u01(r.w) >= p ? g[u].w * keep_scale : 0.f);
+    gx[q] = o;
+    acc.x += o.x, acc.y += o.y, acc.z += o.z, acc.w += o.w;
+  }
+  atomicAdd(&colsum[4 * qc], acc.x);
+  atomicAdd(&colsum[4 * qc + 1], acc.y);
+  atomicAdd(&colsum[4 * qc + 2], acc.z);
+  atomicAdd(&colsum[4 * qc + 3], acc.w);
+}
+
 __global__ void normal_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, int64_t n,
                               float* __restrict__ out) {
   const uint64_t seed = rng[0], off = rng[1];
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
-    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
-    // Box-Muller, two pairs. u in (0,1] for the log.
-    const float u0 = 1.0f - u01(r.x), u1 = u01(r.y), u2 = 1.0f - u01(r.z), u3 = u01(r.w);
-    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-    float s0, c0, s1, c1;
-    sincosf(6.283185307179586f * u1, &s0, &c0);
-    sincosf(6.283185307179586f * u3, &s1, &c1);
-    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+    float v[4];
+    normal4(philox4x32_10(off + (uint64_t)q, stream_id, seed), v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t i = q * 4 + j;
@@ -220,6 +257,32 @@ __global__ void reparam_kl_fwd_kernel(const float* __restrict__ ml, const float*
     const float var = expf(lv);
     acc += var + mu * mu - lv - 1.0f;
     if (z) z[i] = eps ? fmaf(expf(0.5f * lv), eps[i], mu) : mu;
+  }
+  const float s = pgv_block_sum(acc, red);
+  if (threadIdx.x == 0 && kl) atomicAdd(kl, 0.5f * kl_scale * s);
+}
+
+// The same with eps drawn here - element i of the draw pgv_normal makes from the same state and stream (one Philox block
+// per element instead of per four: B*D is 16 K values) - and stored for backward: one launch for the draw, the
+// reparameterisation and the Dkl term instead of three.
+__global__ void reparam_kl_fwd_rng_kernel(const float* __restrict__ ml, const uint64_t* __restrict__ rng,
+                                          uint64_t stream_id, int B, int D, float kl_scale, float* __restrict__ z,
+                                          float* __restrict__ eps_out, float* __restrict__ kl) {
+  __shared__ float red[16];
+  const uint64_t seed = rng[0], off = rng[1];
+  float acc = 0.f;
+  const int64_t n = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / D;
+    const int dd = (int)(i - b * D);
+    const float mu = ml[(b * 2) * D + dd], lv = ml[(b * 2 + 1) * D + dd];
+    float v[4];
+    normal4(philox4x32_10(off + (uint64_t)(i >> 2), stream_id, seed), v);
+    const int j = (int)(i & 3);
+    const float e = j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+    acc += expf(lv) + mu * mu - lv - 1.0f;
+    eps_out[i] = e;
+    z[i] = fmaf(expf(0.5f * lv), e, mu);
   }
   const float s = pgv_block_sum(acc, red);
   if (threadIdx.x == 0 && kl) atomicAdd(kl, 0.5f * kl_scale * s);
@@ -336,6 +399,27 @@ __global__ void adam_tick_kernel(double* __restrict__ pows, float* __restrict__ 
   }
 }
 
+// The single-thread bookkeeping of a train step as ONE launch in front of the Adam update (each was a dependent launch of
+// ~4.7 us): Adam's step counter, the generator offset (all draws of the step are behind it), the reported total loss.
+__global__ void step_tick_kernel(double* __restrict__ pows, float* __restrict__ hyper, double beta1, double beta2,
+                                 uint64_t* __restrict__ rng_state, uint64_t rng_inc, const float* __restrict__ la,
+                                 const float* __restrict__ lb, const float* __restrict__ wb,
+                                 const float* __restrict__ lc, float* __restrict__ total) {
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x == 0) {
+    const double p1 = pows[0] * beta1, p2 = pows[1] * beta2;
+    pows[0] = p1;
+    pows[1] = p2;
+    pows[2] += 1.0;
+    hyper[1] = (float)(1.0 - p1);
+    hyper[2] = (float)(1.0 - p2);
+  } else if (threadIdx.x == 1) {
+    if (rng_state) rng_state[1] += rng_inc;
+  } else if (threadIdx.x == 2) {
+    if (total) total[0] = fmaf(lb[0], wb[0], la[0]) + (lc ? lc[0] : 0.f);
+  }
+}
+
 __global__ void adam4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                              float4* __restrict__ v, int64_t n4, const float* __restrict__ hyper, float beta1, float beta2,
                              float eps, float wd) {
@@ -420,6 +504,32 @@ int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, in
   return PGV_OK;
 }
 
+int pgv_dropout_bwd_colsum(const uint64_t* saved_state, uint64_t stream_id, float p, int M, int N, const float* gy,
+                           float* gx, float* colsum, int flags, void* stream) {
+  PGV_CHECK_ARG(saved_state && gy && gx && colsum && M >= 0 && N > 0 && p >= 0.f && p < 1.f,
+                "pgv_dropout_bwd_colsum: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (N % 4 == 0 && aligned16(gy, gx, gx) && M > 0) {
+    if (!(flags & PGV_PREZEROED)) {
+      if (hipMemsetAsync(colsum, 0, sizeof(float) * N, st) != hipSuccess) {
+        pgv_set_error("pgv_dropout_bwd_colsum: hipMemsetAsync failed");
+        return PGV_E_LAUNCH;
+      }
+    }
+    constexpr int R = 8;
+    // (values whose mask is 0 are multiplied, not selected, in dropout_bwd_kernel; here they are selected - the same
+    // numbers unless gy holds infinities or NaNs under a dropped position)
+    hipLaunchKernelGGL(dropout_bwd_colsum_kernel<R>, dim3((unsigned)pgv_cdiv(N / 4, 256), (unsigned)pgv_cdiv(M, R)),
+                       dim3(256), 0, st, saved_state, stream_id, p, 1.0f / (1.0f - p), M, N / 4, (const float4*)gy,
+                       (float4*)gx, colsum);
+    PGV_CHECK_LAUNCH("dropout_bwd_colsum");
+    return PGV_OK;
+  }
+  int rc = pgv_dropout_bwd(saved_state, stream_id, p, (int64_t)M * N, gy, gx, stream);
+  if (rc) return rc;
+  return pgv_colsum(gx, M, N, N, colsum, flags, stream);
+}
+
 int pgv_normal(const uint64_t* rng_state, uint64_t stream_id, int64_t n, float* out, void* stream) {
   PGV_CHECK_ARG(rng_state && out && n >= 0, "pgv_normal: bad argument");
   if (n == 0) return PGV_OK;
@@ -464,6 +574,21 @@ int pgv_reparam_kl_fwd(const float* ml, const float* eps, int B, int D, float kl
   hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for((int64_t)B * D, 1)), dim3(kBlock), 0, st, ml, eps, B, D,
                      kl_scale, z, kl);
   PGV_CHECK_LAUNCH("reparam_kl_fwd");
+  return PGV_OK;
+}
+
+int pgv_reparam_kl_fwd_rng(const float* ml, const uint64_t* rng_state, uint64_t stream_id, int B, int D, float kl_scale,
+                           float* z, float* eps_out, float* kl, int flags, void* stream) {
+  PGV_CHECK_ARG(ml && rng_state && z && eps_out && B >= 0 && D > 0, "pgv_reparam_kl_fwd_rng: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (kl && !(flags & PGV_PREZEROED)) {
+    int rc = zero_scalar(kl, st, "pgv_reparam_kl_fwd_rng");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  hipLaunchKernelGGL(reparam_kl_fwd_rng_kernel, dim3(grid_for((int64_t)B * D, 1)), dim3(kBlock), 0, st, ml, rng_state,
+                     stream_id, B, D, kl_scale, z, eps_out, kl);
+  PGV_CHECK_LAUNCH("reparam_kl_fwd_rng");
   return PGV_OK;
 }
 
@@ -535,6 +660,16 @@ int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* st
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, pgv_stream(stream), pows, hyper, (double)beta1,
                      (double)beta2);
   PGV_CHECK_LAUNCH("adam_tick");
+  return PGV_OK;
+}
+
+int pgv_step_tick(double* pows, float* hyper, float beta1, float beta2, uint64_t* rng_state, uint64_t rng_inc,
+                  const float* loss_a, const float* loss_b, const float* weight_b, const float* loss_c, float* total,
+                  void* stream) {
+  PGV_CHECK_ARG(pows && hyper && (!total || (loss_a && loss_b && weight_b)), "pgv_step_tick: bad argument");
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, pgv_stream(stream), pows, hyper, (double)beta1,
+                     (double)beta2, rng_state, rng_inc, loss_a, loss_b, weight_b, loss_c, total);
+  PGV_CHECK_LAUNCH("step_tick");
   return PGV_OK;
 }
 

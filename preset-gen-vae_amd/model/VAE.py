@@ -33,20 +33,26 @@ class _ReparamKlFn(torch.autograd.Function):
     whichever of the two output gradients exist, again in one launch."""
 
     @staticmethod
-    def forward(ctx, ml, eps, kl_scale):
+    def forward(ctx, ml, eps, kl_scale, rng=None, kl_buf=None):
+        """``eps`` None: drawn from ``rng`` inside the kernel (one launch for draw, z and Dkl); ``kl_buf``: a zeroed
+        element of the step scratch for the Dkl term (no clearing launch)."""
         ml = ml.contiguous()
-        ctx.save_for_backward(ml, eps)
         ctx.kl_scale = kl_scale
         ctx.set_materialize_grads(False)
-        return ops.reparam_kl_fwd(ml, eps, kl_scale, want_z=True)
+        if eps is None:
+            z, kl, eps = rng.reparam_kl(ml, kl_scale, kl_buf)
+        else:
+            z, kl = ops.reparam_kl_fwd(ml, eps, kl_scale, want_z=True)
+        ctx.save_for_backward(ml, eps)
+        return z, kl
 
     @staticmethod
     def backward(ctx, g_z, g_kl):
         ml, eps = ctx.saved_tensors
         if g_z is None and g_kl is None:
-            return None, None, None
+            return None, None, None, None, None
         return ops.reparam_kl_bwd(ml, eps, None if g_z is None else g_z.contiguous(),
-                                  None if g_kl is None else g_kl.contiguous(), ctx.kl_scale), None, None
+                                  None if g_kl is None else g_kl.contiguous(), ctx.kl_scale), None, None, None, None
 
 
 _NO_FLOW_LADJ = {}
@@ -99,12 +105,15 @@ class BasicVAE(nn.Module):
             z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
             n_minibatch = z_mu_logvar.size()[0]
             if self.training:
-                if eps is None:
-                    eps = rng.normal((n_minibatch, self.dim_z))
                 # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
                 # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
                 kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
-                z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)
+                if eps is None:   # eps drawn inside the same launch, Dkl accumulated into a zeroed word of the step scratch
+                    from . import layer
+                    kl_buf = layer._small_zeros(next(self.parameters()), (1,), 'kl')   # (None: cleared by the call)
+                    z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, None, kl_scale, rng, kl_buf)
+                else:
+                    z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)
                 z_mu_logvar._pgv_kl = (kl_scale, kl)
             else:  # eval mode: no random sampling (VAE.py:57-58)
                 z_sampled = _ReparamFn.apply(z_mu_logvar, None)

@@ -108,13 +108,14 @@ class SpectrogramDecoder(nn.Module):
         """``sq_target`` / ``sq_scale`` (single-channel spectrograms only): also return the squared-error reconstruction
         term, evaluated inside the output stack (layer.ConvStackFn)."""
         lin = self.mlp[0]
-        mixed = layer.LinearFn.apply(z_sampled, lin.weight, lin.bias)
-        if self.training and self.fc_dropout > 0.0:
-            if dropout_mask is None:
-                from ..rng import STREAM_DEC_DROPOUT, device_rng
-                mixed = layer.DropoutFn.apply(mixed, device_rng(self, mixed.device), self.fc_dropout,
-                                              STREAM_DEC_DROPOUT)
-            else:
+        if self.training and self.fc_dropout > 0.0 and dropout_mask is None:
+            # Linear + Dropout as one function: the Dropout backward pass also sums the bias gradient
+            from ..rng import STREAM_DEC_DROPOUT, device_rng
+            mixed = layer.LinearFn.apply(z_sampled, lin.weight, lin.bias,
+                                         (device_rng(self, z_sampled.device), self.fc_dropout, STREAM_DEC_DROPOUT))
+        else:
+            mixed = layer.LinearFn.apply(z_sampled, lin.weight, lin.bias)
+            if self.training and self.fc_dropout > 0.0:
                 mixed = layer.MaskMulFn.apply(mixed, dropout_mask.reshape(-1))
         mixed = mixed.view(-1, self.cnn_input_shape[0], self.cnn_input_shape[1], self.cnn_input_shape[2])
         if self.spectrogram_channels == 1:

@@ -487,32 +487,47 @@ class LinearFn(torch.autograd.Function):
     there is one (no clearing launch), as the weight gradient does into the zero_grad'ed flat gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, out_dropout=None):
+        """``out_dropout`` = (rng, p, stream_id): nn.Dropout on the output (decoder.py:64-65) as part of this function -
+        its backward pass then also sums the columns of the gradient for the bias."""
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.params = (w, b)
+        ctx.drop = None
         # (the output is handed to autograd consumers that keep it only until the end of the step)
         out = _small_zeros(w, (x.shape[0], w.shape[0]), 'lin_y') if x.shape[1] >= 4096 else None
-        return ops.linear_fwd(x, w, b, out=out)
+        y = ops.linear_fwd(x, w, b, out=out)
+        if out_dropout is not None:
+            rng, p, stream_id = out_dropout
+            y, saved = rng.dropout_nomask(p, y, stream_id)
+            ctx.drop = (saved, stream_id, float(p))
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         wp, bp = ctx.params
         gy = gy.contiguous()
+        bias_done, gb_ret = False, None
+        if ctx.drop is not None:
+            gb = None
+            if bp is not None:
+                gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
+                bias_done = True
+            gy = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], gy, colsum=gb, prezeroed=bias_done and gb_zero)
         gx = None
         if ctx.needs_input_grad[0]:
             out = _small_zeros(wp, (gy.shape[0], w.shape[1]), 'lin_gx') if gy.shape[1] >= 4096 else None
             gx = ops.linear_dgrad(gy, w, out=out)
         gw, gw_ret, gw_zero = _grad_dest(wp, accumulated=True)
         ops.linear_wgrad(gy, x, gw, prezeroed=gw_zero)
-        gb_ret = None
-        if bp is not None:
-            gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
-            ops.colsum(gy, gb, prezeroed=gb_zero)
+        if not bias_done:
+            if bp is not None:
+                gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
+                ops.colsum(gy, gb, prezeroed=gb_zero)
         _grad_done(wp, bp)
-        return gx, gw_ret, gb_ret
+        return gx, gw_ret, gb_ret, None
 
 
 class MaskMulFn(torch.autograd.Function):

@@ -423,9 +423,17 @@ def dropout_fwd(rng_state, stream_id, p, x, scale=None, shift=None):
     return y, saved
 
 
-def dropout_bwd(saved_state, stream_id, p, gy):
-    _chk(gy)
+def dropout_bwd(saved_state, stream_id, p, gy, colsum=None, prezeroed=False):
+    """gx = gy * mask (regenerated); ``colsum`` ([N], gy is [M, N]): also colsum (+)= gx.sum(0) in the same pass
+    (``pgv_dropout_bwd_colsum``; ``prezeroed``: it already holds zeros)."""
+    _chk(gy, colsum)
     gx = torch.empty_like(gy)
+    if colsum is not None:
+        M, N = gy.shape
+        _lib.check(_lib.load().pgv_dropout_bwd_colsum(saved_state.data_ptr(), stream_id, p, M, N, _p(gy), _p(gx),
+                                                      _p(colsum), PGV_PREZEROED if prezeroed else 0, _stream()),
+                   "pgv_dropout_bwd_colsum")
+        return gx
     _lib.check(_lib.load().pgv_dropout_bwd(saved_state.data_ptr(), stream_id, p, gy.numel(), _p(gy), _p(gx), _stream()),
                "pgv_dropout_bwd")
     return gx
@@ -457,6 +465,20 @@ def reparam_kl_fwd(ml, eps, kl_scale, want_z=True):
     _lib.check(_lib.load().pgv_reparam_kl_fwd(_p(ml), _p(eps), B, D, kl_scale, _p(z), _p(kl), _stream()),
                "pgv_reparam_kl_fwd")
     return z, kl
+
+
+def reparam_kl_fwd_rng(ml, rng_state, stream_id, kl_scale, kl=None):
+    """``reparam_kl_fwd`` with eps drawn inside the kernel (``pgv_reparam_kl_fwd_rng``): returns (z, kl, eps).  ``kl``: a
+    ZEROED 0-d / 1-element buffer to accumulate the Dkl term into (else one is cleared here)."""
+    B, _, D = ml.shape
+    _chk(ml, kl)
+    z = torch.empty((B, D), device=ml.device, dtype=torch.float32)
+    eps = torch.empty((B, D), device=ml.device, dtype=torch.float32)
+    out = torch.empty((), device=ml.device, dtype=torch.float32) if kl is None else kl
+    _lib.check(_lib.load().pgv_reparam_kl_fwd_rng(_p(ml), rng_state.data_ptr(), stream_id, B, D, kl_scale, _p(z), _p(eps),
+                                                  _p(out), PGV_PREZEROED if kl is not None else 0, _stream()),
+               "pgv_reparam_kl_fwd_rng")
+    return z, out.reshape(()), eps
 
 
 def reparam_kl_bwd(ml, eps, g_z, g_kl, kl_scale):

@@ -144,13 +144,23 @@ class FusedAdam(torch.optim.Optimizer):
         return None
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, rng_advance=None, loss_total=None):
+        """``rng_advance`` = (state tensor, increment) and ``loss_total`` = (a, b, weight_b, c or None, total): bookkeeping
+        of the train step that rides in the step-counter launch (``pgv_step_tick``): the generator offset and the
+        reported total = a + b * weight_b (+ c)."""
         g = self.param_groups[0]
         self.sync_lr()
         b1, b2 = g['betas']
         lib = _lib.load()
-        _lib.check(lib.pgv_adam_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2,
-                                     torch.cuda.current_stream().cuda_stream), "pgv_adam_tick")
+        st = torch.cuda.current_stream().cuda_stream
+        if rng_advance is None and loss_total is None:
+            _lib.check(lib.pgv_adam_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2, st), "pgv_adam_tick")
+        else:
+            rs, inc = rng_advance if rng_advance is not None else (None, 0)
+            la, lb, wb, lc, tot = loss_total if loss_total is not None else (None,) * 5
+            ptr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+            _lib.check(lib.pgv_step_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2, ptr(rs), int(inc), ptr(la),
+                                         ptr(lb), ptr(wb), ptr(lc), ptr(tot), st), "pgv_step_tick")
         f = self.flat
         ops.adam_step(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, self.hyper, b1, b2, g['eps'],
                       g['weight_decay'])

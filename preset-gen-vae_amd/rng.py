@@ -25,13 +25,24 @@ class DeviceRNG:
         self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
         self._deferred = False
         self._pending = 0
+        # hand_over: flush() does not launch the advance but leaves the increment in ``owed`` for a caller that folds it
+        # into a launch of its own (VAETrainStep: the optimizer's step-counter launch) and collects it with take_owed()
+        self.hand_over = False
+        self.owed = 0
+
+    def take_owed(self):
+        inc, self.owed = self.owed, 0
+        return inc
 
     def begin(self):
         self._deferred, self._pending = True, 0
 
     def flush(self):
         if self._pending:
-            ops.rng_advance(self.state, self._pending)
+            if self.hand_over:
+                self.owed += self._pending
+            else:
+                ops.rng_advance(self.state, self._pending)
         self._deferred, self._pending = False, 0
 
     def _advance(self, n):
@@ -61,6 +72,13 @@ class DeviceRNG:
         y, saved = ops.dropout_fwd(self.state, stream_id, float(p), x, scale, shift)
         self._advance(x.numel())
         return y, saved
+
+    def reparam_kl(self, ml, kl_scale, kl=None, stream_id=STREAM_EPS):
+        """z = mu + sigma * eps with eps drawn in the same launch (the draw ``normal((B, D))`` makes), plus the Dkl term:
+        returns (z, kl, eps)."""
+        z, kl, eps = ops.reparam_kl_fwd_rng(ml, self.state, stream_id, kl_scale, kl)
+        self._advance(eps.numel())
+        return z, kl, eps
 
     def normal(self, shape, stream_id=STREAM_EPS):
         out = ops.normal(self.state, stream_id, tuple(int(s) for s in shape), self.state.device)

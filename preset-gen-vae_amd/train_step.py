@@ -63,15 +63,35 @@ class VAETrainStep:
         out = self._forward_backward(x, v_in, inject, hooks=True)
         if self.grad_sync is not None:
             self.grad_sync.wait()
-        self.optimizer.step()
+        self._optimizer_step(out)
         return out
+
+    def _optimizer_step(self, out):
+        """Adam, with the step's single-thread bookkeeping in its step-counter launch: the generator offset the forward
+        left to us (``DeviceRNG.hand_over``) and the reported total loss."""
+        rng = self._rng()
+        inc = rng.take_owed() if rng is not None else 0
+        self.optimizer.step(rng_advance=(rng.state, inc) if inc else None, loss_total=out.pop('_total_terms'))
+
+    def _rng(self):
+        vae = getattr(self.model, 'ae_model', self.model)
+        return getattr(vae, '_pgv_rng_obj', None)
 
     def _forward_backward(self, x, v_in=None, inject=None, hooks=False):
         inject = inject or {}
         self.optimizer.zero_grad()
         if self.grad_sync is not None and hooks:
             self.grad_sync.start_step()
-        z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
+        rng = None
+        if hasattr(getattr(self.model, 'ae_model', self.model), 'encoder'):
+            from .rng import device_rng
+            rng = device_rng(getattr(self.model, 'ae_model', self.model), x.device)
+            rng.hand_over = True     # its advance rides in the optimizer's step-counter launch (_optimizer_step)
+        try:
+            z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
+        finally:
+            if rng is not None:
+                rng.hand_over = False
         recons = self.recons_criterion(x_out, x)
         lat = self.model.latent_loss(z_mu_logvar, z0, zK, ladj)
         # total = recons + lat * beta (+ controls); total.backward() (train.py:227,246-247).  The gradients of the
@@ -87,10 +107,11 @@ class VAETrainStep:
             roots.append(cont)
             root_grads.append(one)
         torch.autograd.backward(roots, root_grads)
-        total = torch.addcmul(recons.detach(), lat.detach(), beta_t)   # (after backward: recons may be deferred)
-        if cont is not None:
-            total = total + cont.detach()
-        return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total.detach(),
+        # total = recons + lat * beta (+ controls), evaluated by the optimizer's step-counter launch (after backward:
+        # recons may be a deferred value that the backward kernels deliver)
+        total = torch.empty((), device=x.device, dtype=torch.float32)
+        terms = (recons.detach(), lat.detach(), beta_t, None if cont is None else cont.detach(), total)
+        return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total, '_total_terms': terms,
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
                 'x_out': x_out.detach()}
 
@@ -195,4 +216,4 @@ class VAETrainStep:
             self._out = self._forward_backward(self._static_x, self._static_v)
         self._graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_update):
-            self.optimizer.step()
+            self._optimizer_step(self._out)

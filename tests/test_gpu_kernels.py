@@ -826,6 +826,17 @@ def test_rng_distributions(ops):
             ref.dropout_mask(0.3, (256, 24576))                     # advance the reference stream the same way
         mr = ref.dropout_mask(0.3, shape)
         assert torch.equal(m.view(*shape), mr) and torch.equal(y, x * mr)
+    # eps drawn inside the reparameterisation kernel = the draw normal() makes from the same state
+    rng_e, ref = DeviceRNG(torch.device('cuda'), seed=11), DeviceRNG(torch.device('cuda'), seed=11)
+    ml = torch.randn(37, 2, 29, device='cuda') * 0.5
+    z, kl, eps = rng_e.reparam_kl(ml, 0.25)
+    eps_ref = ref.normal((37, 29))
+    assert torch.equal(eps, eps_ref)
+    z_ref, kl_ref = ops.reparam_kl_fwd(ml, eps_ref, 0.25)
+    assert torch.equal(z, z_ref) and abs(kl.item() - kl_ref.item()) <= 1e-6 * abs(kl_ref.item())
+    buf = torch.zeros(1, device='cuda')
+    _, kl2, _ = DeviceRNG(torch.device('cuda'), seed=11).reparam_kl(ml, 0.25, kl=buf)
+    assert kl2.data_ptr() == buf.data_ptr() and abs(kl2.item() - kl_ref.item()) <= 1e-6 * abs(kl_ref.item())
     # ... and so is the mask-free form the train step uses: forward draws and applies, backward regenerates the mask from
     # the saved copy of the state - also after the generator itself has moved on; optional per-channel affine on the way in
     for shape in ((256, 64, 16, 24), (3, 5, 7, 11), (2, 1001)):
@@ -841,6 +852,12 @@ def test_rng_distributions(ops):
         rng_d.dropout_mask(0.3, (1000,))                               # the generator moves on
         g = torch.randn(*shape, device='cuda')
         assert torch.equal(ops.dropout_bwd(saved, 2, 0.3, g), g * mr)
+        if len(shape) == 2 or shape[0] == 256:   # ... with the column sums of the result (the Linear bias gradient)
+            g2, m2 = g.reshape(shape[0], -1), mr.reshape(shape[0], -1)
+            cs = torch.full((g2.shape[1],), 0.5, device='cuda')
+            gx = ops.dropout_bwd(saved, 2, 0.3, g2, colsum=cs, prezeroed=True)
+            ref_cs = (g2 * m2).double().sum(0) + 0.5
+            assert torch.equal(gx, g2 * m2) and (cs.double() - ref_cs).abs().max().item() <= 1e-5 * ref_cs.abs().max().item()
 
 
 @pytest.mark.parametrize("kind", ["conv", "tconv"])
