@@ -189,6 +189,25 @@ int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, c
                     float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* (num_batches_tracked, may be NULL, is incremented by one: nn.BatchNorm's counter, same launch) */
+/* The arguments of pgv_bn_finalize as a value: the BatchNorm whose statistics a producer kernel has just accumulated and
+ * whose affine the NEXT kernel applies to its input.  pgv_conv_down_bn / pgv_conv_up_bn / pgv_dropout_fwd_bn =
+ * pgv_bn_finalize(src...) followed by the plain call with in_scale = src->scale, in_shift = src->shift - as ONE launch
+ * where the kernel that serves the shape evaluates the (per-channel, float64) finalize arithmetic in its prologue: every
+ * workgroup for itself, the first one also writing scale / shift / mean / rstd and the running statistics for the
+ * backward pass.  A ~5 us dependent launch less per BatchNorm layer. */
+typedef struct pgv_bn_src {
+  const double* stats; /* [2C] sums and sums of squares (pgv_bn_stats layout) */
+  int64_t n;           /* elements per channel */
+  const float *gamma, *beta; /* nullable */
+  float eps, momentum;
+  float *running_mean, *running_var; /* nullable */
+  int64_t* num_batches_tracked;      /* nullable */
+  float *scale, *shift, *mean, *rstd; /* [C] each, outputs; scale and shift required */
+} pgv_bn_src;
+int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src* in_bn, const float* w, const float* bias,
+                     int act, float slope, float* small_out, double* stats, void* stream);
+int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* w,
+                   const float* bias, int act, float slope, float* big_out, double* stats, void* stream);
 /* Eval-mode BN folded to an affine: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
  * (validation forward, train.py:261-291). */
 int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -262,6 +281,9 @@ int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, in
  * this pass (encoder.py:85) - else x' = x. */
 int pgv_dropout_fwd(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
                     const float* scale, const float* shift, float* y, uint64_t* saved_state, void* stream);
+/* pgv_dropout_fwd with the affine given as the BatchNorm it comes from (pgv_bn_src above: finalize in the same launch) */
+int pgv_dropout_fwd_bn(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
+                       const pgv_bn_src* bn, float* y, uint64_t* saved_state, void* stream);
 int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, int64_t n, const float* gy, float* gx,
                     void* stream);
 /* pgv_dropout_bwd over a [M][N] gradient plus colsum[n] (+)= sum_m gx[m][n] in the same pass - the bias gradient of the

@@ -35,6 +35,18 @@ class BwdFuse(Structure):
 _FUSE = POINTER(BwdFuse)
 
 
+class BnSrc(Structure):
+    """Mirror of ``pgv_bn_src``: the arguments of ``pgv_bn_finalize`` as a value, handed to the kernel that consumes the
+    BatchNorm so that it finalizes it in its own prologue."""
+    _fields_ = [("stats", c_void_p), ("n", c_int64), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+                ("momentum", c_float), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("num_batches_tracked", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("mean", c_void_p),
+                ("rstd", c_void_p)]
+
+
+_BN = POINTER(BnSrc)
+
+
 class CoefReq(Structure):
     """Mirror of ``pgv_coef_req``: the BatchNorm-backward coefficients of the block below, asked of a weight-gradient
     call."""
@@ -54,6 +66,8 @@ SIGNATURES = {
     "pgv_conv_up": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_down_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
     "pgv_conv_up_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
+    "pgv_conv_down_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_up_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),
@@ -82,6 +96,7 @@ SIGNATURES = {
     "pgv_dropout_mask": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P]),
     "pgv_dropout_apply": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P, _P]),
     "pgv_dropout_fwd": (c_int, [_P, c_uint64, c_float, _P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P]),
+    "pgv_dropout_fwd_bn": (c_int, [_P, c_uint64, c_float, _P, c_int64, c_int, c_int64, _BN, _P, _P, _P]),
     "pgv_dropout_bwd": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P]),
     "pgv_dropout_bwd_colsum": (c_int, [_P, c_uint64, c_float, c_int, c_int, _P, _P, _P, c_int, _P]),
     "pgv_normal": (c_int, [_P, c_uint64, c_int64, _P, _P]),

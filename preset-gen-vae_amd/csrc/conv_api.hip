@@ -107,6 +107,49 @@ int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scal
   return pgv_conv_down_fused(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, nullptr, stream);
 }
 
+// The BatchNorm of the input finalized by the kernel itself where the wave-specialised / direct kernels serve the call
+// (pgv_bn_src); otherwise pgv_bn_finalize as a launch of its own in front of the plain call.
+static int check_bn_src(const pgv_bn_src* bn, const char* who) {
+  PGV_CHECK_ARG(bn && bn->stats && bn->scale && bn->shift && bn->n > 0, "%s: incomplete pgv_bn_src", who);
+  return PGV_OK;
+}
+static int bn_src_finalize(const pgv_bn_src* bn, int C, void* stream) {
+  return pgv_bn_finalize(bn->stats, C, bn->n, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
+                         bn->num_batches_tracked, bn->scale, bn->shift, bn->mean, bn->rstd, stream);
+}
+
+int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src* in_bn, const float* w, const float* bias,
+                     int act, float slope, float* small_out, double* stats, void* stream) {
+  int rc = check_desc(d, "pgv_conv_down_bn");
+  if (rc) return rc;
+  if ((rc = check_bn_src(in_bn, "pgv_conv_down_bn"))) return rc;
+  if (g_policy == 0 && !g_no_v2 && d->B > 0 && big && w && small_out) {
+    rc = pgv_conv_down_v2(d, big, in_bn->scale, in_bn->shift, w, bias, act, slope, small_out, stats, nullptr,
+                          pgv_stream(stream), in_bn);
+    if (rc < 0) return rc;
+    if (rc >= 1) return PGV_OK;
+  }
+  if ((rc = bn_src_finalize(in_bn, d->Cb, stream))) return rc;
+  return pgv_conv_down(d, big, in_bn->scale, in_bn->shift, w, bias, act, slope, small_out, stats, stream);
+}
+
+int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* w,
+                   const float* bias, int act, float slope, float* big_out, double* stats, void* stream) {
+  int rc = check_desc(d, "pgv_conv_up_bn");
+  if (rc) return rc;
+  if ((rc = check_bn_src(in_bn, "pgv_conv_up_bn"))) return rc;
+  if (g_policy == 0 && !g_no_v2 && d->B > 0 && small_in && w && big_out) {
+    hipStream_t st = pgv_stream(stream);
+    rc = pgv_conv_up_direct2(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, st, in_bn);
+    if (rc == 0)
+      rc = pgv_conv_up_v2(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, nullptr, st, in_bn);
+    if (rc < 0) return rc;
+    if (rc >= 1) return PGV_OK;
+  }
+  if ((rc = bn_src_finalize(in_bn, d->Cs, stream))) return rc;
+  return pgv_conv_up(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, stream);
+}
+
 int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                       const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                       const pgv_bwd_fuse* fuse, void* stream) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int act, float slope,
-                                                        float* __restrict__ out, int bf16) {
+                                                        float* __restrict__ out, int bf16, pgv_bn_src bn) {
   using G = UpC1Cfg<CS, H, W, R>;
   constexpr int Hs = G::Hs, Ws = G::Ws, Hg = G::Hg, WsP = G::WsP, PLANE = G::PLANE, QW = G::QW, BANDS = G::BANDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -50,8 +50,14 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
   if (tid < G::FRONT) lds[tid] = 0.f;
   if (tid < 16) tile[CS * PLANE + tid] = 0.f;
   if (in_scale && tid < CS) {
-    aff[tid] = in_scale[tid];
-    aff[CS + tid] = in_shift[tid];
+    float sc, sh;
+    // (pgv_conv_up_bn: the producer's BatchNorm is finalized here, from its statistics, instead of by a launch of its own)
+    if (bn.stats)
+      pgv_bn_finalize_dev(bn, CS, tid, blockIdx.x == 0, sc, sh);
+    else
+      sc = in_scale[tid], sh = in_shift[tid];
+    aff[tid] = sc;
+    aff[CS + tid] = sh;
   }
   for (int i = tid; i < CS * G::WSTR; i += 256) {
     const int cs = i / G::WSTR, k = i - cs * G::WSTR;
@@ -380,7 +386,8 @@ int raise_lds(K kern, const char* who) {
 // committed to LDS, fp32 FMAs: products of bf16 values are exact in fp32); everything else stays with conv_direct.hip.
 template <int R>
 static int launch_up_c1(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
-                        const float* w, const float* bias, int act, float slope, float* out, hipStream_t st) {
+                        const float* w, const float* bias, int act, float slope, float* out, const pgv_bn_src* bn,
+                        hipStream_t st) {
   using G = UpC1Cfg<8, 257, 347, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds / 2, "two workgroups per CU");
@@ -389,19 +396,20 @@ static int launch_up_c1(const pgv_conv_desc* d, const float* small_in, const flo
   const int units = d->B * G::BANDS;
   const int per_cu = (int)min((size_t)4, (size_t)kMaxLds / bytes);
   hipLaunchKernelGGL(kern, dim3(min(units, 256 * per_cu)), dim3(256), bytes, st, d->B, small_in, in_scale, in_shift, w,
-                     bias, act, slope, out, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0);
+                     bias, act, slope, out, (d->flags & PGV_COMPUTE_BF16) ? 1 : 0, bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_up_direct2");
   return 1;
 }
 
 int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                        hipStream_t st) {
+                        hipStream_t st, const pgv_bn_src* bn) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
   if (d->Hb != 257 || d->Wb != 347 || d->B <= 0) return 0;
+  if (bn && !in_scale) return 0;
   // 11 grid rows per unit: since the units of neighbouring bands share an XCD's L2 (pgv_xcd_block) the larger unit no
   // longer pays for its halo and its longer multiply phase hides more of the next unit's loads (88 -> 83 us)
-  return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, st);
+  return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, bn, st);
 }
 
 template <int R>

@@ -38,18 +38,20 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
                         hipStream_t st);
 
 // Second-generation kernels (conv_v2.hip): one workgroup per CU, waves split M, weights from registers; tried first.
+// (bn != null: in_scale / in_shift are bn->scale / bn->shift, not yet computed - the kernel finalizes the BatchNorm in its
+// prologue, pgv_bn_src; 0 is returned, nothing launched, when the form that would serve the call cannot)
 int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                     const pgv_bwd_fuse* fuse, hipStream_t st);
+                     const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn = nullptr);
 
 int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                   const pgv_bwd_fuse* fuse, hipStream_t st);
+                   const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn = nullptr);
 
 // Second-generation direct kernels (conv_direct2.hip): four pixels per lane, 16-byte LDS reads and stores.
 int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                        hipStream_t st);
+                        hipStream_t st, const pgv_bn_src* bn = nullptr);
 int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                           const float* w, const float* bias, int act, float slope, float* out, double* stats,
                           const pgv_bwd_fuse* fuse, hipStream_t st);

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
                                                             const float* __restrict__ in_shift,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             int act, float slope, float* __restrict__ out,
-                                                            double* __restrict__ stats, pgv_bwd_fuse fuse) {
+                                                            double* __restrict__ stats, pgv_bwd_fuse fuse,
+                                                            pgv_bn_src bn) {
   using G = DownV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, NW = G::NW, MTW = G::MTW, P = G::P, NT = G::NT;
   constexpr int WP = G::WP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -78,8 +79,14 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   if (my_items == 0) return;
   if (tid < G::FRONT) lds[tid] = 0.f;
   for (int i = tid; i < CB; i += 512) {
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[CB + i] = in_shift ? in_shift[i] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    // (pgv_conv_down_bn: the producer's BatchNorm is finalized here, from its statistics, instead of by a launch of its own)
+    if (HAS_AFF && bn.stats)
+      pgv_bn_finalize_dev(bn, CB, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CB + i] = sh;
   }
   __syncthreads();
   // global source of local item `it` (clamped to the last one: the loader runs ahead unconditionally)
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
 template <int CB, int CS, int W, int H, int R, int MW, int CK>
 int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                   const pgv_bwd_fuse* fuse, hipStream_t st) {
+                   const pgv_bwd_fuse* fuse, const pgv_bn_src* bn, hipStream_t st) {
   using G = DownV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -644,10 +651,11 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   // the two ways the train step calls it: forward of a Conv2D block (producer's BatchNorm folded or not, LeakyReLU,
   // statistics) and input gradient of a TConv2D block (plain product, optional BatchNorm-backward projections)
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse);
+                         double*, pgv_bwd_fuse, pgv_bn_src);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+  if (bn && (!in_scale || fuse)) return 0;
 #define PGV_DK(F, A, C) (kern_t) conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
 #ifdef PGV_V2_EXPERIMENT
   // tuning builds (scratch/build_dbg.sh): only the forward-call instantiation
@@ -687,7 +695,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, in_scale, in_shift, w, bias, act,
-                     slope, out, stats, fuse ? *fuse : fz);
+                     slope, out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_down_v2");
   return with_cls ? 3 : 1;   // (3: handled, class sums included)
 }
@@ -702,14 +710,14 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
 // up 65x88: 154 / 89 / 138 -> band;  up 33x45: 133 / (no fused band kernel: 140) / 125 -> v2 unfused + reduce pass.
 int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
-                     const pgv_bwd_fuse* fuse, hipStream_t st) {
+                     const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->flags & PGV_COMPUTE_BF16) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
-    return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+    return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)
-    return launch_down_v2<16, 32, 88, 65, 11, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+    return launch_down_v2<16, 32, 88, 65, 11, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   if (d->Hb == 129 && d->Wb == 174)  // 8 -> 16 channels, 65x88 outputs: 13 bands of 5 rows, waves split the pixels
-    return launch_down_v2<8, 16, 174, 129, 5, 1, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, st);
+    return launch_down_v2<8, 16, 174, 129, 5, 1, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   return 0;
 }

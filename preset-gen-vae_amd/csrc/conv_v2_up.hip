@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          double* __restrict__ stats, pgv_bwd_fuse fuse) {
+                                                          double* __restrict__ stats, pgv_bwd_fuse fuse, pgv_bn_src bn) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, Wgp = G::Wgp, BANDS = G::BANDS, NW = G::NW;
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -79,8 +79,14 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   if (my_items == 0) return;
   if (tid < G::FRONT) lds[tid] = 0.f;
   for (int i = tid; i < CS; i += 512) {
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[CS + i] = in_shift ? in_shift[i] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    // (pgv_conv_up_bn: the producer's BatchNorm is finalized here, from its statistics, instead of by a launch of its own)
+    if (HAS_AFF && bn.stats)
+      pgv_bn_finalize_dev(bn, CS, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CS + i] = sh;
   }
   __syncthreads();
   auto item_src = [&](int it, const float*& plane0, int& ih0) {
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
 template <int CB, int CS, int W, int H, int R, int MW, int CK>
 int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                  const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                 const pgv_bwd_fuse* fuse, hipStream_t st) {
+                 const pgv_bwd_fuse* fuse, const pgv_bn_src* bn, hipStream_t st) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
   // deferred stores for the layer whose output bursts bound it (129x174: 56 KB per unit), where the variant exists
   constexpr bool STG = W == 174 && G::NCH == 1;
@@ -752,10 +758,11 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   if (d->Cb != CB || d->Cs != CS) return 0;
   if (stats && fuse) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse);
+                         double*, pgv_bwd_fuse, pgv_bn_src);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
+  if (bn && (!in_scale || fuse)) return 0;
   const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
 #define PGV_UK(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C>
 #ifdef PGV_V2_EXPERIMENT
@@ -808,7 +815,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, small_in, in_scale, in_shift, w, bias, act, slope,
-                     out, stats, fuse ? *fuse : fz);
+                     out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_up_v2");
   return 1;
 }
@@ -818,7 +825,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
 // (returns 2 when it handled the call but left the requested projections to a separate reduce pass)
 int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
-                   const pgv_bwd_fuse* fuse, hipStream_t st) {
+                   const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   // bf16 operand mode: only the 33x45 layer comes here (operands rounded at the LDS commit / weight load, fp32 MFMA: 95 us
   // against 157 us for the band kernel's bf16 loop at this shape; the other shapes' band kernels are faster than this form)
@@ -828,16 +835,16 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
   // (65x88: 128 accumulator registers leave no room for the ring - it spills; the band kernel's fused epilogue stays)
   if (fuse && d->Hb == 65 && d->Wb == 88) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 64 -> 32 channels onto 33x45: 2 bands of 9 / 8 grid rows, M split 4 ways
-    return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+    return launch_up_v2<32, 64, 45, 33, 9, 4, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, bn, st);
   if (d->Hb == 65 && d->Wb == 88)   // 32 -> 16 channels onto 65x88: 3 bands of 11 grid rows, waves split the positions
-    return launch_up_v2<16, 32, 88, 65, 11, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+    return launch_up_v2<16, 32, 88, 65, 11, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, bn, st);
 #ifndef PGV_V2_NO_UP_L2
   // 16 -> 8 channels onto 129x174 (13 bands of 5 grid rows, waves split the positions).  This layer is bound by the CU's
   // store path (56 KB of output per unit): with direct stores from the epilogue the matrix pipe idled 35 % of the time
   // and the band kernel's two co-resident workgroups were faster; with the output staged through LDS and moved out by
   // the loader waves during the next unit's k-steps (STG) this form wins.  Fused projections stay on the band kernel.
   if (d->Hb == 129 && d->Wb == 174)
-    return launch_up_v2<8, 16, 174, 129, 5, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, st);
+    return launch_up_v2<8, 16, 174, 129, 5, 1, 16>(d, small_in, in_scale, in_shift, w, bias, act, slope, big_out, stats, fuse, bn, st);
 #endif
   return 0;
 }

@@ -84,10 +84,23 @@ __global__ void dropout_apply_kernel(const uint64_t* __restrict__ rng, uint64_t 
 // generator state the forward drew from (two words) instead of reading back 4 bytes per element - 2 instead of 3 tensors
 // of traffic per pass.  Optional per-channel affine on the way in (x is [B][C][HW]): the BatchNorm of the encoder's last
 // conv block, which has no consumer kernel to fold it into (encoder.py:85: Dropout -> Linear).
+// (bn.stats != null, C <= kDropBnMaxC: the affine is the BatchNorm bn, finalized here into an LDS table by every workgroup
+// - pgv_bn_src - instead of by a launch of its own)
+constexpr int kDropBnMaxC = 512;
 __global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
                                    int64_t n, const float* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int C, int64_t HW, float* __restrict__ y,
-                                   uint64_t* __restrict__ saved, int vec) {
+                                   uint64_t* __restrict__ saved, int vec, pgv_bn_src bn) {
+  __shared__ float tab[2 * kDropBnMaxC];
+  if (bn.stats) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float sc, sh;
+      pgv_bn_finalize_dev(bn, C, c, blockIdx.x == 0, sc, sh);
+      tab[c] = sc, tab[kDropBnMaxC + c] = sh;
+    }
+    __syncthreads();
+    scale = tab, shift = tab + kDropBnMaxC;
+  }
   const uint64_t seed = rng[0], off = rng[1];
   if (blockIdx.x == 0 && threadIdx.x == 0) saved[0] = seed, saved[1] = off;
   const int64_t n4 = (n + 3) / 4;
@@ -480,18 +493,38 @@ int pgv_dropout_apply(const uint64_t* rng_state, uint64_t stream_id, float p, in
   return PGV_OK;
 }
 
+static int dropout_fwd_launch(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C,
+                              int64_t HW, const float* scale, const float* shift, const pgv_bn_src* bn, float* y,
+                              uint64_t* saved_state, void* stream) {
+  const int64_t n = B * C * HW;
+  const int vec = aligned16(x, y, y) && (!scale || HW % 4 == 0) ? 1 : 0;
+  // (n == 0 still records the state: backward of an empty batch reads it)
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(max(n, (int64_t)1), 4)), dim3(kBlock), 0, pgv_stream(stream),
+                     rng_state, stream_id, p, 1.0f / (1.0f - p), n, x, scale, shift, C, HW, y, saved_state, vec,
+                     bn ? *bn : pgv_no_bn());
+  PGV_CHECK_LAUNCH("dropout_fwd");
+  return PGV_OK;
+}
+
 int pgv_dropout_fwd(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
                     const float* scale, const float* shift, float* y, uint64_t* saved_state, void* stream) {
   PGV_CHECK_ARG(rng_state && x && y && saved_state && B >= 0 && C > 0 && HW > 0 && p >= 0.f && p < 1.f &&
                     (scale == nullptr) == (shift == nullptr),
                 "pgv_dropout_fwd: bad argument");
-  const int64_t n = B * C * HW;
-  const int vec = aligned16(x, y, y) && (!scale || HW % 4 == 0) ? 1 : 0;
-  // (n == 0 still records the state: backward of an empty batch reads it)
-  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(max(n, (int64_t)1), 4)), dim3(kBlock), 0, pgv_stream(stream),
-                     rng_state, stream_id, p, 1.0f / (1.0f - p), n, x, scale, shift, C, HW, y, saved_state, vec);
-  PGV_CHECK_LAUNCH("dropout_fwd");
-  return PGV_OK;
+  return dropout_fwd_launch(rng_state, stream_id, p, x, B, C, HW, scale, shift, nullptr, y, saved_state, stream);
+}
+
+int pgv_dropout_fwd_bn(const uint64_t* rng_state, uint64_t stream_id, float p, const float* x, int64_t B, int C, int64_t HW,
+                       const pgv_bn_src* bn, float* y, uint64_t* saved_state, void* stream) {
+  PGV_CHECK_ARG(rng_state && x && y && saved_state && B >= 0 && C > 0 && HW > 0 && p >= 0.f && p < 1.f && bn && bn->stats &&
+                    bn->scale && bn->shift && bn->n > 0,
+                "pgv_dropout_fwd_bn: bad argument");
+  if (C <= kDropBnMaxC)
+    return dropout_fwd_launch(rng_state, stream_id, p, x, B, C, HW, bn->scale, bn->shift, bn, y, saved_state, stream);
+  int rc = pgv_bn_finalize(bn->stats, C, bn->n, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean,
+                           bn->running_var, bn->num_batches_tracked, bn->scale, bn->shift, bn->mean, bn->rstd, stream);
+  if (rc) return rc;
+  return dropout_fwd_launch(rng_state, stream_id, p, x, B, C, HW, bn->scale, bn->shift, nullptr, y, saved_state, stream);
 }
 
 int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, int64_t n, const float* gy, float* gx,

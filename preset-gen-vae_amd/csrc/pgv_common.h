@@ -74,6 +74,34 @@ __device__ __forceinline__ double pgv_block_sum_d(double v, double* smem /* >= 1
   return r;
 }
 
+// pgv_bn_finalize's arithmetic for channel c, evaluated by the kernel that CONSUMES the BatchNorm (pgv_bn_src,
+// pgv_conv_*_bn): identical float64 expressions in every workgroup; `writer` (one workgroup) also stores the vectors the
+// backward pass reads and updates the running statistics.
+__device__ __forceinline__ void pgv_bn_finalize_dev(const pgv_bn_src& s, int C, int c, bool writer, float& sc, float& sh) {
+  const double inv_n = 1.0 / (double)s.n;
+  const double mean = s.stats[c] * inv_n;
+  double var = s.stats[C + c] * inv_n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)s.eps);
+  const double g = s.gamma ? (double)s.gamma[c] : 1.0, bt = s.beta ? (double)s.beta[c] : 0.0;
+  sc = (float)(g * rstd);
+  sh = (float)(bt - mean * g * rstd);
+  if (writer) {
+    const double unbias = s.n > 1 ? (double)s.n / (double)(s.n - 1) : 1.0;
+    s.scale[c] = sc;
+    s.shift[c] = sh;
+    if (s.mean) s.mean[c] = (float)mean;
+    if (s.rstd) s.rstd[c] = (float)rstd;
+    if (s.running_mean) s.running_mean[c] = (float)((1.0 - s.momentum) * s.running_mean[c] + s.momentum * mean);
+    if (s.running_var) s.running_var[c] = (float)((1.0 - s.momentum) * s.running_var[c] + s.momentum * var * unbias);
+    if (c == 0 && s.num_batches_tracked) *s.num_batches_tracked += 1;
+  }
+}
+inline pgv_bn_src pgv_no_bn() {
+  pgv_bn_src z = {};
+  return z;
+}
+
 // N block-wide sums at once for blockDim.x == 256: DPP row reductions (no ds_bpermute), v_readlane across the four rows of
 // a wave, ONE barrier across the waves.  pgv_block_sum costs two barriers and six LDS-latency shuffles per value - for
 // kernels that end with several reductions (class sums, loss, bias gradient) that tail was longer than the streaming

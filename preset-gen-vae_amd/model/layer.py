@@ -172,6 +172,7 @@ class ConvStackFn(torch.autograd.Function):
         B = x.shape[0]
         dev = x.device
         cur, cur_scale, cur_shift = x, None, None
+        pending = None
         saved = []
         pi = 0
         # BatchNorm statistics of all blocks in one arena cleared by ONE fill (PGV_PREZEROED): a memset node per block
@@ -194,8 +195,13 @@ class ConvStackFn(torch.autograd.Function):
                 stats = arena[a_off:a_off + 2 * C]
                 a_off += 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
-            a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats,
-                   prezeroed=stats is not None)
+            # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
+            if pending is not None:
+                a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending)
+                pending = None
+            else:
+                a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats,
+                       prezeroed=stats is not None)
             scale = shift = mean = rstd = None
             if has_bn:
                 vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
@@ -207,9 +213,11 @@ class ConvStackFn(torch.autograd.Function):
                     bn = blk.bn
                     mom = bn.momentum if bn.momentum is not None else 0.1
                     track = bn.track_running_stats and bn.running_mean is not None
-                    ops.bn_finalize(stats, n, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
-                                    bn.running_var if track else None, scale, shift, mean, rstd,
-                                    num_batches_tracked=bn.num_batches_tracked if track else None)
+                    # not a launch: the finalize arithmetic rides in the prologue of the kernel that applies this
+                    # BatchNorm - the next block's, or the output pass below
+                    pending = ops.bn_src(stats, n, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
+                                         bn.running_var if track else None,
+                                         bn.num_batches_tracked if track else None, scale, shift, mean, rstd)
                 else:
                     ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
                     mean = rstd = None
@@ -218,9 +226,14 @@ class ConvStackFn(torch.autograd.Function):
         ctx.drop = None
         if out_dropout is not None:
             rng, p, stream_id = out_dropout
-            out, drop_state = rng.dropout_nomask(p, cur, stream_id, cur_scale, cur_shift)
+            if pending is not None:
+                out, drop_state = rng.dropout_nomask(p, cur, stream_id, in_bn=pending)
+            else:
+                out, drop_state = rng.dropout_nomask(p, cur, stream_id, cur_scale, cur_shift)
             ctx.drop = (drop_state, stream_id, float(p))
         else:
+            if pending is not None:
+                ops.bn_src_finalize(pending)
             out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
         ctx.blocks, ctx.saved, ctx.params = blocks, saved, params
         ctx.sq = None

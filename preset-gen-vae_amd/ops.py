@@ -96,15 +96,44 @@ def _fuse_arg(bwd_fuse, out):
     return _lib.BwdFuse(_p(a), _p(coef), _p(gbias), int(act), float(slope), _p(cls))
 
 
+def bn_src(stats, n, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, mean,
+           rstd):
+    """``pgv_bn_src``: a BatchNorm whose statistics have been accumulated and whose finalize step (``bn_finalize`` with
+    these arguments) is left to the kernel that consumes it (``conv_down`` / ``conv_up`` / ``dropout_fwd`` with
+    ``in_bn=``).  Keeps the tensors alive; ``scale`` / ``shift`` / ``mean`` / ``rstd`` are outputs."""
+    _chk64(stats)
+    _chk(gamma, beta, running_mean, running_var, scale, shift, mean, rstd)
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise ValueError("num_batches_tracked must be an int64 device tensor")
+    s = _lib.BnSrc(_p(stats), int(n), _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                   _p(running_var), _p(num_batches_tracked), _p(scale), _p(shift), _p(mean), _p(rstd))
+    s._keep = (stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd)
+    return s
+
+
+def bn_src_finalize(src):
+    """The finalize step of a ``bn_src`` as a launch of its own (no consumer kernel to ride in)."""
+    stats, gamma, beta, rm, rv, nbt, scale, shift, mean, rstd = src._keep
+    bn_finalize(stats, src.n, gamma, beta, src.eps, src.momentum, rm, rv, scale, shift, mean, rstd,
+                num_batches_tracked=nbt)
+
+
 def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-              bwd_fuse=None):
-    """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it."""
+              bwd_fuse=None, in_bn=None):
+    """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it.
+    ``in_bn`` (a ``bn_src``): the input's BatchNorm, finalized by this call (``pgv_conv_down_bn``)."""
     B = big.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cs, geom.Hs, geom.Ws), device=big.device, dtype=torch.float32)
     _chk(big, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
+    if in_bn is not None:
+        if bwd_fuse is not None or in_scale is not None:
+            raise ValueError("conv_down: in_bn excludes in_scale / bwd_fuse")
+        _lib.check(lib.pgv_conv_down_bn(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), ctypes.byref(in_bn), _p(w),
+                                        _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_down_bn")
+        return out
     f = _fuse_arg(bwd_fuse, out)
     _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale),
                                        _p(in_shift), _p(w), _p(bias), act, slope, _p(out), _p(stats),
@@ -113,13 +142,19 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
 
 
 def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-            bwd_fuse=None):
+            bwd_fuse=None, in_bn=None):
     B = small.shape[0]
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
     _chk(small, w, bias, in_scale, in_shift, out)
     _chk64(stats)
     lib = _lib.load()
+    if in_bn is not None:
+        if bwd_fuse is not None or in_scale is not None:
+            raise ValueError("conv_up: in_bn excludes in_scale / bwd_fuse")
+        _lib.check(lib.pgv_conv_up_bn(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), ctypes.byref(in_bn), _p(w),
+                                      _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_up_bn")
+        return out
     f = _fuse_arg(bwd_fuse, out)
     _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift),
                                      _p(w), _p(bias), act, slope, _p(out), _p(stats),
@@ -408,16 +443,22 @@ def dropout_apply(rng_state, stream_id, p, x):
     return y, mask
 
 
-def dropout_fwd(rng_state, stream_id, p, x, scale=None, shift=None):
+def dropout_fwd(rng_state, stream_id, p, x, scale=None, shift=None, in_bn=None):
     """nn.Dropout forward without a stored mask (``pgv_dropout_fwd``): returns (y, saved_state) - ``saved_state`` is the
     copy of the generator state ``dropout_bwd`` regenerates the mask from.  ``scale`` / ``shift`` ([C], x is [B, C, ...]):
-    a per-channel affine applied on the way in."""
+    a per-channel affine applied on the way in; ``in_bn`` (a ``bn_src``) instead: the BatchNorm that affine comes from,
+    finalized by this call."""
     _chk(x, scale, shift)
     B = x.shape[0]
-    C = x.shape[1] if scale is not None else 1
+    C = x.shape[1] if (scale is not None or in_bn is not None) else 1
     HW = x.numel() // max(1, B * C)
     y = torch.empty_like(x)
     saved = torch.empty(2, device=x.device, dtype=torch.int64)
+    if in_bn is not None:
+        _lib.check(_lib.load().pgv_dropout_fwd_bn(rng_state.data_ptr(), stream_id, p, _p(x), B, C, max(1, HW),
+                                                  ctypes.byref(in_bn), _p(y), saved.data_ptr(), _stream()),
+                   "pgv_dropout_fwd_bn")
+        return y, saved
     _lib.check(_lib.load().pgv_dropout_fwd(rng_state.data_ptr(), stream_id, p, _p(x), B, C, max(1, HW), _p(scale),
                                            _p(shift), _p(y), saved.data_ptr(), _stream()), "pgv_dropout_fwd")
     return y, saved

@@ -66,10 +66,11 @@ class DeviceRNG:
         self._advance(x.numel())
         return y, mask
 
-    def dropout_nomask(self, p, x, stream_id=STREAM_DROPOUT, scale=None, shift=None):
-        """nn.Dropout forward on ``x`` (after an optional per-channel affine) without a stored mask: returns
-        (y, saved_state) for ``ops.dropout_bwd``; the same draw as ``dropout_mask``."""
-        y, saved = ops.dropout_fwd(self.state, stream_id, float(p), x, scale, shift)
+    def dropout_nomask(self, p, x, stream_id=STREAM_DROPOUT, scale=None, shift=None, in_bn=None):
+        """nn.Dropout forward on ``x`` (after an optional per-channel affine, given as vectors or as the BatchNorm to
+        finalize - ``ops.bn_src``) without a stored mask: returns (y, saved_state) for ``ops.dropout_bwd``; the same
+        draw as ``dropout_mask``."""
+        y, saved = ops.dropout_fwd(self.state, stream_id, float(p), x, scale, shift, in_bn)
         self._advance(x.numel())
         return y, saved
 

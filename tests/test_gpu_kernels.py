@@ -455,6 +455,69 @@ def test_conv_tap_sums(ops, case):
 
 
 @pytest.mark.parametrize("policy", [0, 3])
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 3), (16, 32, 4, 2, 2, 65, 88, 3), (32, 64, 4, 2, 2, 33, 45, 5),
+                                  (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2)])
+def test_conv_finalizes_the_input_batchnorm(ops, case, policy):
+    """pgv_conv_down_bn / pgv_conv_up_bn / pgv_dropout_fwd_bn (pgv_bn_src): the consumer kernel finalizes its input's
+    BatchNorm in its prologue - the same output, the same scale / shift / mean / rstd vectors, the same running
+    statistics and counter as pgv_bn_finalize followed by the plain call (bit for bit: the same float64 expressions)."""
+    from preset_gen_vae_amd import _lib
+    from preset_gen_vae_amd.rng import DeviceRNG
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    try:
+        for up in (False, True):
+            C, H, W = (Cs, geom.Hs, geom.Ws) if up else (Cb, Hb, Wb)        # the consumer's input
+            Co = Cb if up else Cs
+            x = dev(synth_vec((B, C, H, W), 0.371, 0.2) * 1.3 + 0.1)
+            w = dev(synth_vec((Cs, Cb, k, k), 0.6180, 0.7) * (1.0 / np.sqrt(C * k * k)))
+            bias = dev(synth_vec((Co,), 1.1, 0.3) * 0.1)
+            gamma, beta = dev(1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)), dev(0.3 * synth_vec((C,), 2.9, 0.6))
+            stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+            ops.bn_stats(x, stats)
+            fn = ops.conv_up if up else ops.conv_down
+            res = []
+            for fused in (False, True):
+                rm, rv = dev(synth_vec((C,), 0.5, 0.5)), dev(synth_vec((C,), 0.7, 0.1).abs() + 0.5)
+                nbt = torch.tensor(3, device='cuda', dtype=torch.int64)
+                vec = [torch.full((C,), float('nan'), device='cuda') for _ in range(4)]
+                src = ops.bn_src(stats, B * H * W, gamma, beta, 1e-5, 0.1, rm, rv, nbt, *vec)
+                if fused:
+                    y = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, in_bn=src)
+                else:
+                    ops.bn_src_finalize(src)
+                    y = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=vec[0], in_shift=vec[1])
+                res.append([y, rm, rv, nbt] + vec)
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+            assert res[1][3].item() == 4
+        # the Dropout in front of the encoder's Linear: same draw, same values
+        C, HW = Cb, 24
+        x = dev(synth_vec((B, C, 4, 6), 0.371, 0.2))
+        stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+        ops.bn_stats(x, stats)
+        gamma, beta = dev(1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)), dev(0.3 * synth_vec((C,), 2.9, 0.6))
+        res = []
+        for fused in (False, True):
+            rng = DeviceRNG(torch.device('cuda'), seed=5)
+            vec = [torch.full((C,), float('nan'), device='cuda') for _ in range(4)]
+            rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+            src = ops.bn_src(stats, B * HW, gamma, beta, 1e-5, 0.1, rm, rv, None, *vec)
+            if fused:
+                y, _ = rng.dropout_nomask(0.3, x, 2, in_bn=src)
+            else:
+                ops.bn_src_finalize(src)
+                y, _ = rng.dropout_nomask(0.3, x, 2, vec[0], vec[1])
+            res.append([y, rm, rv] + vec)
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    finally:
+        lib.pgv_set_kernel_policy(0)
+
+
+@pytest.mark.parametrize("policy", [0, 3])
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 6), (16, 32, 4, 2, 2, 65, 88, 9), (32, 64, 4, 2, 2, 33, 45, 12),
                                   (64, 128, 4, 2, 2, 17, 23, 5), (1, 8, 5, 2, 2, 257, 347, 3), (3, 5, 4, 2, 2, 10, 13, 4),
                                   (256, 512, 4, 2, 2, 5, 7, 6), (512, 2048, 1, 1, 0, 3, 4, 8)])

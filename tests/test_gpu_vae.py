@@ -925,8 +925,8 @@ def test_dropout_masks_are_independent_and_advance():
     rec, adv = [], []
     orig, orig_adv = ops.dropout_fwd, ops.rng_advance
 
-    def patched(state, stream_id, p, x, scale=None, shift=None):
-        y, saved = orig(state, stream_id, p, x, scale, shift)
+    def patched(state, stream_id, p, x, scale=None, shift=None, in_bn=None):
+        y, saved = orig(state, stream_id, p, x, scale, shift, in_bn)
         # (no mask is stored: it is what backward regenerates from the saved generator state)
         rec.append((stream_id, ops.dropout_bwd(saved, stream_id, p, torch.ones_like(x)).reshape(x.shape[0], -1)))
         return y, saved
