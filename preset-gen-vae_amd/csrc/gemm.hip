@@ -271,19 +271,42 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
     }
     }
   }
-  // acc[2 im + in][i]: row m0 + 32 wm + 16 im + 4j + i, column n0 + 32 wn + 16 in + m
+  // acc[2 im + in][i]: row 32 wm + 16 im + 4j + i, column 32 wn + 16 in + m of the tile.  Out through LDS (the staging
+  // buffers are free: the K loop ended with a barrier) so that a wave instruction covers whole 128-byte lines of C:
+  // 64 consecutive floats per atomic instruction (the split-K products spend a third of their time in these atomics:
+  // with 4 half-lines per instruction, as the accumulator layout gives them, ~8 us; laid out 16 quarter-lines wide 35 us),
+  // 16 bytes per lane for plain stores.
+  constexpr int TROW = 64 + 4;
+  static_assert(64 * TROW <= 2 * STAGE, "epilogue tile fits in the staging buffers");
+  float* tile = lds;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = n0 + 32 * wn + 16 * (t & 1) + m;
-    // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
-    const float bias = ((!atomic || (atomic == 2 && zs == 0)) && bias_n) ? bias_n[n] : 0.f;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* c = C + (int64_t)(m0 + 32 * wm + 16 * (t >> 1) + 4 * j + i) * ldc + n;
-      if (atomic)
-        atomicAdd(c, acc[t][i] + bias);
-      else
-        *c = acc[t][i] + bias;
+    for (int i = 0; i < 4; ++i)
+      tile[(32 * wm + 16 * (t >> 1) + 4 * j + i) * TROW + 32 * wn + 16 * (t & 1) + m] = acc[t][i];
+  __syncthreads();
+  // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
+  const bool with_bias = (!atomic || (atomic == 2 && zs == 0)) && bias_n;
+  if (atomic) {
+    const int col = tid & 63;
+    const float bias = with_bias ? bias_n[n0 + col] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = (tid >> 6) + 4 * k;
+      atomicAdd(C + (int64_t)(m0 + row) * ldc + n0 + col, tile[row * TROW + col] + bias);
+    }
+  } else {
+    const int c4 = (tid & 15) * 4;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (with_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bias[i] = bias_n[n0 + c4 + i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (tid >> 4) + 16 * k;
+      *reinterpret_cast<f32x4*>(C + (int64_t)(m0 + row) * ldc + n0 + c4) =
+          *reinterpret_cast<const f32x4*>(tile + row * TROW + c4) + bias;
     }
   }
 }
@@ -319,7 +342,7 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
     const bool a_k = sak == 1, a_m = sam == 1 && !a_k, b_k = sbk == 1, b_n = sbn == 1 && !b_k;
     const int64_t lda = a_k ? sam : sak, ldb = b_k ? sbn : sbk;
     if (pgv_kernel_policy() == 0 && (a_k || a_m) && (b_k || b_n) && M % 64 == 0 && N % 64 == 0 && K % FK == 0 && K > 0 && lda % 4 == 0 &&
-        ldb % 4 == 0 && aligned16(A) && aligned16(B)) {
+        ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C)) {
       const int tiles = (M / 64) * (N / 64);
       int splits = (int)max((int64_t)1, min(pgv_cdiv(768, tiles), (int64_t)K / (FK * 4)));
       int k_per_split_v = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
