@@ -307,6 +307,18 @@ int pgv_reparam_kl_fwd(const float* ml, const float* eps, int B, int D, float kl
  * for pgv_reparam_kl_bwd).  PGV_PREZEROED: kl already holds zero (no clearing launch). */
 int pgv_reparam_kl_fwd_rng(const float* ml, const uint64_t* rng_state, uint64_t stream_id, int B, int D, float kl_scale,
                            float* z, float* eps_out, float* kl, int flags, void* stream);
+/* The encoder head in one launch per direction: nn.BatchNorm1d (train mode, pgv_bn1d_fwd) over the Linear output
+ * x[B][2D], then pgv_reparam_kl_fwd_rng over y = [mu | log-variance]; backward: pgv_reparam_kl_bwd (+ g_y, a gradient that
+ * reaches y directly; g_z / g_kl / g_y nullable), pgv_bn1d_bwd over it, and colsum[c] = sum_b gx[b][c] (nullable; the bias
+ * gradient of the Linear in front; PGV_PREZEROED: added to what colsum holds).  Same values as the separate calls. */
+int pgv_bn1d_reparam_fwd(const float* x, int B, int D, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* scale,
+                         float* mean, float* rstd, const uint64_t* rng_state, uint64_t stream_id, float kl_scale,
+                         float* z, float* eps_out, float* kl, int flags, void* stream);
+int pgv_bn1d_reparam_bwd(const float* g_z, const float* g_kl, const float* g_y, const float* y, const float* eps,
+                         const float* x, const float* scale, const float* mean, const float* rstd, int B, int D,
+                         float kl_scale, float* gx, float* ggamma, float* gbeta, float* colsum, int flags,
+                         void* stream);
 int pgv_reparam_kl_bwd(const float* ml, const float* eps, const float* g_z, const float* g_kl, int B, int D,
                        float kl_scale, float* g_ml, void* stream);
 

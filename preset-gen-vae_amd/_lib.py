@@ -104,6 +104,10 @@ SIGNATURES = {
     "pgv_mul": (c_int, [_P, _P, c_int64, _P, _P]),
     "pgv_reparam_kl_fwd": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "pgv_reparam_kl_fwd_rng": (c_int, [_P, _P, c_uint64, c_int, c_int, c_float, _P, _P, _P, c_int, _P]),
+    "pgv_bn1d_reparam_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     c_uint64, c_float, _P, _P, _P, c_int, _P]),
+    "pgv_bn1d_reparam_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, c_int,
+                                     _P]),
     "pgv_reparam_kl_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "pgv_sqerr_fwd": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
     "pgv_sqerr_bwd": (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P, _P]),

@@ -176,36 +176,49 @@ __device__ __forceinline__ void normal4(const U4 r, float (&v)[4]) {
 }
 
 // dropout_bwd_kernel over a [M][N] gradient with the column sums of the result on the way (the bias gradient of the
-// nn.Linear in front of the Dropout, decoder.py:64-65): a thread owns four columns and R rows, loads in flight per
-// thread = R, one float atomic per column and row group.  N % 4 == 0, 16-byte aligned rows.
+// nn.Linear in front of the Dropout, decoder.py:64-65): a workgroup is 64 quad-columns x 4 row groups, a thread owns four
+// columns and R rows (loads in flight per thread = R), the four row groups are added up through LDS: one float atomic per
+// column per 4R rows.  N % 4 == 0, 16-byte aligned rows.
 template <int R>
 __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const uint64_t* __restrict__ saved, uint64_t stream_id,
                                                                  float p, float keep_scale, int M, int N4,
                                                                  const float4* __restrict__ gy, float4* __restrict__ gx,
                                                                  float* __restrict__ colsum) {
+  __shared__ float4 part[4][64];
   const uint64_t seed = saved[0], off = saved[1];
-  const int qc = blockIdx.x * 256 + threadIdx.x;
-  if (qc >= N4) return;
-  const int r0 = blockIdx.y * R;
-  float4 g[R];
-#pragma unroll
-  for (int u = 0; u < R; ++u)
-    if (r0 + u < M) g[u] = gy[(int64_t)(r0 + u) * N4 + qc];
+  const int ql = threadIdx.x & 63, rgp = threadIdx.x >> 6;
+  const int qc = blockIdx.x * 64 + ql;
+  const int r0 = (blockIdx.y * 4 + rgp) * R;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qc < N4) {
+    float4 g[R];
 #pragma unroll
-  for (int u = 0; u < R; ++u) {
-    if (r0 + u >= M) break;
-    const int64_t q = (int64_t)(r0 + u) * N4 + qc;
-    const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
-    const float4 o = make_float4(u01(r.x) >= p ? g[u].x * keep_scale : 0.f, u01(r.y) >= p ? g[u].y * keep_scale : 0.f,
-                                 u01(r.z) >= p ? g[u].z * keep_scale : 0.f, u01(r.w) >= p ? g[u].w * keep_scale : 0.f);
-    gx[q] = o;
-    acc.x += o.x, acc.y += o.y, acc.z += o.z, acc.w += o.w;
+    for (int u = 0; u < R; ++u)
+      if (r0 + u < M) g[u] = gy[(int64_t)(r0 + u) * N4 + qc];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (r0 + u >= M) break;
+      const int64_t q = (int64_t)(r0 + u) * N4 + qc;
+      const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+      const float4 o = make_float4(u01(r.x) >= p ? g[u].x * keep_scale : 0.f, u01(r.y) >= p ? g[u].y * keep_scale : 0.f,
+                                   u01(r.z) >= p ? g[u].z * keep_scale : 0.f, u01(r.w) >= p ? g[u].w * keep_scale : 0.f);
+      gx[q] = o;
+      acc.x += o.x, acc.y += o.y, acc.z += o.z, acc.w += o.w;
+    }
   }
-  atomicAdd(&colsum[4 * qc], acc.x);
-  atomicAdd(&colsum[4 * qc + 1], acc.y);
-  atomicAdd(&colsum[4 * qc + 2], acc.z);
-  atomicAdd(&colsum[4 * qc + 3], acc.w);
+  part[rgp][ql] = acc;
+  __syncthreads();
+  if (rgp == 0 && qc < N4) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 t = part[k][ql];
+      acc.x += t.x, acc.y += t.y, acc.z += t.z, acc.w += t.w;
+    }
+    atomicAdd(&colsum[4 * qc], acc.x);
+    atomicAdd(&colsum[4 * qc + 1], acc.y);
+    atomicAdd(&colsum[4 * qc + 2], acc.z);
+    atomicAdd(&colsum[4 * qc + 3], acc.w);
+  }
 }
 
 __global__ void normal_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, int64_t n,
@@ -299,6 +312,143 @@ __global__ void reparam_kl_fwd_rng_kernel(const float* __restrict__ ml, const ui
   }
   const float s = pgv_block_sum(acc, red);
   if (threadIdx.x == 0 && kl) atomicAdd(kl, 0.5f * kl_scale * s);
+}
+
+// ---- encoder head: nn.BatchNorm1d (train mode) + reparameterisation + Dkl in ONE launch per direction ------------
+// (encoder.py:86-87 -> VAE.py:49-56 -> loss.py:57-66).  x[B][2D] is the Linear output; a workgroup owns ONE latent
+// coordinate d = the channels {d, D + d} (mu and log-variance), a thread one row at a time: after the BatchNorm
+// statistics of its two channels (float64, block-wide) every thread has both operands of z = mu + exp(lv / 2) * eps for
+// its rows.  Two dependent launches of ~5-10 us per direction become one.  (A first form with 8 coordinates per
+// workgroup - the layout of bn1d_fwd_kernel - ran 24 / 37 us: 8 workgroups, and every thread walked 16 rows of Philox
+// rounds, logarithms and exponentials in sequence.)
+// sums of N doubles over the block, result in every thread (smem: N * 4 doubles)
+template <int N>
+__device__ __forceinline__ void head_block_sums(double (&v)[N], double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = pgv_wave_sum_d(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) smem[k * 4 + wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = (smem[k * 4] + smem[k * 4 + 1]) + (smem[k * 4 + 2] + smem[k * 4 + 3]);
+}
+
+__global__ __launch_bounds__(256) void bn1d_reparam_fwd_kernel(
+    const float* __restrict__ x, int B, int D, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+    int64_t* __restrict__ num_batches_tracked, float* __restrict__ y, float* __restrict__ scale_out,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint64_t* __restrict__ rng, uint64_t stream_id,
+    float kl_scale, float* __restrict__ z, float* __restrict__ eps_out, float* __restrict__ kl) {
+  __shared__ double smem[16];
+  __shared__ float red[16];
+  const int C = 2 * D, d = blockIdx.x, tid = threadIdx.x;
+  if (d == 0 && tid == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  double st[4] = {0.0, 0.0, 0.0, 0.0};   // sum, sum of squares of the mu channel; the same of the log-variance channel
+  for (int b = tid; b < B; b += 256) {
+    const float v0 = x[(int64_t)b * C + d], v1 = x[(int64_t)b * C + D + d];
+    st[0] += (double)v0, st[1] = fma((double)v0, (double)v0, st[1]);
+    st[2] += (double)v1, st[3] = fma((double)v1, (double)v1, st[3]);
+  }
+  head_block_sums<4>(st, smem);
+  float sc[2], sh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = h * D + d;
+    const double inv_n = 1.0 / (double)B, mean = st[2 * h] * inv_n;
+    double var = st[2 * h + 1] * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+    sc[h] = (float)(g * rstd), sh[h] = (float)(bt - mean * g * rstd);
+    if (tid == 0) {
+      if (scale_out) scale_out[c] = sc[h];
+      if (mean_out) mean_out[c] = (float)mean;
+      if (rstd_out) rstd_out[c] = (float)rstd;
+      const double unbias = B > 1 ? (double)B / (double)(B - 1) : 1.0;
+      if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
+    }
+  }
+  const uint64_t seed = rng[0], off = rng[1];
+  float acc = 0.f;
+  for (int b = tid; b < B; b += 256) {
+    const float mu = fmaf(x[(int64_t)b * C + d], sc[0], sh[0]), lv = fmaf(x[(int64_t)b * C + D + d], sc[1], sh[1]);
+    y[(int64_t)b * C + d] = mu;
+    y[(int64_t)b * C + D + d] = lv;
+    const int64_t i = (int64_t)b * D + d;
+    float nv[4];
+    normal4(philox4x32_10(off + (uint64_t)(i >> 2), stream_id, seed), nv);
+    const int j = (int)(i & 3);
+    const float e = j == 0 ? nv[0] : (j == 1 ? nv[1] : (j == 2 ? nv[2] : nv[3]));
+    acc += expf(lv) + mu * mu - lv - 1.0f;
+    eps_out[i] = e;
+    z[i] = fmaf(expf(0.5f * lv), e, mu);
+  }
+  const float tot = pgv_block_sum(acc, red);
+  if (tid == 0 && kl) atomicAdd(kl, 0.5f * kl_scale * tot);
+}
+
+// Backward of the same: the gradient of [mu, lv] from g_z / g_kl (pgv_reparam_kl_bwd; + g_y, a gradient arriving at the
+// BatchNorm output directly) formed on the fly, BatchNorm1d backward over it (pgv_bn1d_bwd), and the column sums of the
+// result - the bias gradient of the Linear in front (sums of a train-mode BatchNorm backward: rounding noise around 0,
+// which is what the reference's autograd hands Adam as well).
+__global__ __launch_bounds__(256) void bn1d_reparam_bwd_kernel(
+    const float* __restrict__ g_z, const float* __restrict__ g_kl, const float* __restrict__ g_y,
+    const float* __restrict__ y, const float* __restrict__ epsv, const float* __restrict__ x,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd, int B, int D,
+    float kl_scale, float* __restrict__ gx, float* __restrict__ ggamma, float* __restrict__ gbeta,
+    float* __restrict__ colsum, int colsum_accumulate) {
+  __shared__ double smem[16];
+  const int C = 2 * D, d = blockIdx.x, tid = threadIdx.x;
+  const float mu0 = mean[d], rs0 = rstd[d], sc0 = scale[d], mu1 = mean[D + d], rs1 = rstd[D + d], sc1 = scale[D + d];
+  const float gk = g_kl ? g_kl[0] * kl_scale : 0.f;
+  // gradients of y[b][d] (mu) and y[b][D + d] (log-variance)
+  auto grads = [&](int b, float& g0, float& g1) {
+    const float ym = y[(int64_t)b * C + d], yl = y[(int64_t)b * C + D + d];
+    g0 = gk * ym;
+    g1 = gk * 0.5f * (expf(yl) - 1.0f);
+    if (g_z) {
+      const float gz = g_z[(int64_t)b * D + d];
+      g0 += gz;
+      g1 = fmaf(gz * epsv[(int64_t)b * D + d], 0.5f * expf(0.5f * yl), g1);
+    }
+    if (g_y) g0 += g_y[(int64_t)b * C + d], g1 += g_y[(int64_t)b * C + D + d];
+  };
+  double st[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = tid; b < B; b += 256) {
+    float g0, g1;
+    grads(b, g0, g1);
+    st[0] += (double)g0, st[1] += (double)(g0 * ((x[(int64_t)b * C + d] - mu0) * rs0));
+    st[2] += (double)g1, st[3] += (double)(g1 * ((x[(int64_t)b * C + D + d] - mu1) * rs1));
+  }
+  head_block_sums<4>(st, smem);
+  if (tid == 0) {
+    if (ggamma) ggamma[d] = (float)st[1], ggamma[D + d] = (float)st[3];
+    if (gbeta) gbeta[d] = (float)st[0], gbeta[D + d] = (float)st[2];
+  }
+  const float c10 = (float)(st[0] / (double)B), c20 = (float)(st[1] / (double)B);
+  const float c11 = (float)(st[2] / (double)B), c21 = (float)(st[3] / (double)B);
+  double cs[2] = {0.0, 0.0};
+  for (int b = tid; b < B; b += 256) {
+    float g0, g1;
+    grads(b, g0, g1);
+    const float o0 = sc0 * (g0 - c10 - (x[(int64_t)b * C + d] - mu0) * rs0 * c20);
+    const float o1 = sc1 * (g1 - c11 - (x[(int64_t)b * C + D + d] - mu1) * rs1 * c21);
+    gx[(int64_t)b * C + d] = o0;
+    gx[(int64_t)b * C + D + d] = o1;
+    cs[0] += (double)o0, cs[1] += (double)o1;
+  }
+  if (colsum) {
+    head_block_sums<2>(cs, smem);
+    if (tid == 0) {
+      colsum[d] = (colsum_accumulate ? colsum[d] : 0.f) + (float)cs[0];
+      colsum[D + d] = (colsum_accumulate ? colsum[D + d] : 0.f) + (float)cs[1];
+    }
+  }
 }
 
 __global__ void reparam_kl_bwd_kernel(const float* __restrict__ ml, const float* __restrict__ eps,
@@ -552,7 +702,7 @@ int pgv_dropout_bwd_colsum(const uint64_t* saved_state, uint64_t stream_id, floa
     constexpr int R = 8;
     // (values whose mask is 0 are multiplied, not selected, in dropout_bwd_kernel; here they are selected - the same
     // numbers unless gy holds infinities or NaNs under a dropped position)
-    hipLaunchKernelGGL(dropout_bwd_colsum_kernel<R>, dim3((unsigned)pgv_cdiv(N / 4, 256), (unsigned)pgv_cdiv(M, R)),
+    hipLaunchKernelGGL(dropout_bwd_colsum_kernel<R>, dim3((unsigned)pgv_cdiv(N / 4, 64), (unsigned)pgv_cdiv(M, 4 * R)),
                        dim3(256), 0, st, saved_state, stream_id, p, 1.0f / (1.0f - p), M, N / 4, (const float4*)gy,
                        (float4*)gx, colsum);
     PGV_CHECK_LAUNCH("dropout_bwd_colsum");
@@ -622,6 +772,36 @@ int pgv_reparam_kl_fwd_rng(const float* ml, const uint64_t* rng_state, uint64_t 
   hipLaunchKernelGGL(reparam_kl_fwd_rng_kernel, dim3(grid_for((int64_t)B * D, 1)), dim3(kBlock), 0, st, ml, rng_state,
                      stream_id, B, D, kl_scale, z, eps_out, kl);
   PGV_CHECK_LAUNCH("reparam_kl_fwd_rng");
+  return PGV_OK;
+}
+
+int pgv_bn1d_reparam_fwd(const float* x, int B, int D, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* scale,
+                         float* mean, float* rstd, const uint64_t* rng_state, uint64_t stream_id, float kl_scale,
+                         float* z, float* eps_out, float* kl, int flags, void* stream) {
+  PGV_CHECK_ARG(x && y && rng_state && z && eps_out && B > 0 && D > 0, "pgv_bn1d_reparam_fwd: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (kl && !(flags & PGV_PREZEROED)) {
+    int rc = zero_scalar(kl, st, "pgv_bn1d_reparam_fwd");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(bn1d_reparam_fwd_kernel, dim3((unsigned)D), dim3(256), 0, st, x, B, D, gamma, beta, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, y, scale, mean, rstd, rng_state, stream_id,
+                     kl_scale, z, eps_out, kl);
+  PGV_CHECK_LAUNCH("bn1d_reparam_fwd");
+  return PGV_OK;
+}
+
+int pgv_bn1d_reparam_bwd(const float* g_z, const float* g_kl, const float* g_y, const float* y, const float* eps,
+                         const float* x, const float* scale, const float* mean, const float* rstd, int B, int D,
+                         float kl_scale, float* gx, float* ggamma, float* gbeta, float* colsum, int flags,
+                         void* stream) {
+  PGV_CHECK_ARG(y && x && scale && mean && rstd && gx && B > 0 && D > 0 && (!g_z || eps),
+                "pgv_bn1d_reparam_bwd: bad argument");
+  hipLaunchKernelGGL(bn1d_reparam_bwd_kernel, dim3((unsigned)D), dim3(256), 0, pgv_stream(stream), g_z, g_kl,
+                     g_y, y, eps, x, scale, mean, rstd, B, D, kl_scale, gx, ggamma, gbeta, colsum,
+                     (flags & PGV_PREZEROED) ? 1 : 0);
+  PGV_CHECK_LAUNCH("bn1d_reparam_bwd");
   return PGV_OK;
 }
 

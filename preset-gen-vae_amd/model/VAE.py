@@ -102,15 +102,28 @@ class BasicVAE(nn.Module):
             object.__setattr__(self.decoder, '_rng', rng)
             rng.begin()
         try:
-            z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
+            fused_head = None
+            if self.training and eps is None:
+                # eps is drawn inside the launch that uses it, Dkl accumulated into a zeroed word of the step scratch; an
+                # encoder that ends in BatchNorm1d evaluates all of it in that layer's launch (layer.EncoderHeadFn)
+                from . import layer
+                kl_buf = layer._small_zeros(next(self.parameters()), (1,), 'kl')   # (None: cleared by the call)
+                kl_scale = self.latent_criterion.kl_scale(torch.empty((x.shape[0], 2, self.dim_z), device='meta'))
+                enc_out = self.encoder(x, dropout_mask=enc_dropout_mask, reparam=(rng, kl_scale, kl_buf))
+                if isinstance(enc_out, tuple):
+                    z_mu_logvar, fused_head = enc_out[0], enc_out[1:]
+                else:
+                    z_mu_logvar = enc_out
+            else:
+                z_mu_logvar = self.encoder(x, dropout_mask=enc_dropout_mask)
             n_minibatch = z_mu_logvar.size()[0]
             if self.training:
                 # the Dkl term rides along (same kernel, same read of mu / logvar) and is handed to latent_loss() through an
                 # attribute of the returned tensor OBJECT; a caller that passes another tensor simply recomputes it
                 kl_scale = self.latent_criterion.kl_scale(z_mu_logvar)
-                if eps is None:   # eps drawn inside the same launch, Dkl accumulated into a zeroed word of the step scratch
-                    from . import layer
-                    kl_buf = layer._small_zeros(next(self.parameters()), (1,), 'kl')   # (None: cleared by the call)
+                if fused_head is not None:
+                    z_sampled, kl = fused_head
+                elif eps is None:
                     z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, None, kl_scale, rng, kl_buf)
                 else:
                     z_sampled, kl = _ReparamKlFn.apply(z_mu_logvar, eps.contiguous(), kl_scale)

@@ -147,9 +147,11 @@ class SpectrogramEncoder(nn.Module):
                 for ch in range(self.spectrogram_channels)]
         return layer.run_stack(torch.cat(outs, dim=1), self._mixer_blocks(), self.training, out_dropout=out_dropout)
 
-    def forward(self, x_spectrograms, dropout_mask=None):
+    def forward(self, x_spectrograms, dropout_mask=None, reparam=None):
         """``dropout_mask`` (optional, [B, features], already scaled by 1/(1-p)) injects the Dropout mask for parity
-        runs; by default it is drawn on device."""
+        runs; by default it is drawn on device.  ``reparam`` = (rng, kl_scale, kl_buf) (training, from BasicVAE.forward):
+        when this encoder ends in its BatchNorm1d, the reparameterisation and the Dkl term are evaluated by the same
+        launch and (z_mu_logvar, z_sampled, Dkl) is returned instead of z_mu_logvar alone."""
         n_minibatch = x_spectrograms.size()[0]
         if self.training and self.fc_dropout > 0.0 and dropout_mask is None:
             # the Dropout mask is drawn and applied by the pass that applies the last conv block's BatchNorm
@@ -161,6 +163,12 @@ class SpectrogramEncoder(nn.Module):
             if self.training and self.fc_dropout > 0.0:
                 cnn_out = layer.MaskMulFn.apply(cnn_out, dropout_mask.reshape(-1))
         lin = self.mlp[1]
+        if reparam is not None and self.output_bn and self.training:
+            bn = self.mlp.lat_in_regularization
+            rng, kl_scale, kl_buf = reparam
+            lin_out = layer.LinearFn.apply(cnn_out, lin.weight, lin.bias, None, True)
+            y, z, kl = layer.EncoderHeadFn.apply(lin_out, bn, bn.weight, bn.bias, rng, kl_scale, kl_buf, lin.bias)
+            return torch.reshape(y, (n_minibatch, 2, self.dim_z)), z, kl
         z_mu_logvar = layer.LinearFn.apply(cnn_out, lin.weight, lin.bias)
         if self.output_bn:
             bn = self.mlp.lat_in_regularization

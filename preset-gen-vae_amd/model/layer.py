@@ -500,13 +500,15 @@ class LinearFn(torch.autograd.Function):
     there is one (no clearing launch), as the weight gradient does into the zero_grad'ed flat gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, out_dropout=None):
+    def forward(ctx, x, w, b, out_dropout=None, bias_grad_elsewhere=False):
         """``out_dropout`` = (rng, p, stream_id): nn.Dropout on the output (decoder.py:64-65) as part of this function -
-        its backward pass then also sums the columns of the gradient for the bias."""
+        its backward pass then also sums the columns of the gradient for the bias.  ``bias_grad_elsewhere``: the
+        consumer's backward kernel writes the bias gradient (EncoderHeadFn)."""
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.params = (w, b)
+        ctx.bias_elsewhere = bool(bias_grad_elsewhere)
         ctx.drop = None
         # (the output is handed to autograd consumers that keep it only until the end of the step)
         out = _small_zeros(w, (x.shape[0], w.shape[0]), 'lin_y') if x.shape[1] >= 4096 else None
@@ -522,10 +524,10 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         wp, bp = ctx.params
         gy = gy.contiguous()
-        bias_done, gb_ret = False, None
+        bias_done, gb_ret = ctx.bias_elsewhere, None
         if ctx.drop is not None:
             gb = None
-            if bp is not None:
+            if bp is not None and not bias_done:
                 gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
                 bias_done = True
             gy = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], gy, colsum=gb, prezeroed=bias_done and gb_zero)
@@ -540,7 +542,50 @@ class LinearFn(torch.autograd.Function):
                 gb, gb_ret, gb_zero = _grad_dest(bp, accumulated=True)
                 ops.colsum(gy, gb, prezeroed=gb_zero)
         _grad_done(wp, bp)
-        return gx, gw_ret, gb_ret, None
+        return gx, gw_ret, gb_ret, None, None
+
+
+class EncoderHeadFn(torch.autograd.Function):
+    """The encoder's output BatchNorm1d (train mode, encoder.py:86-87) + reparameterisation + Dkl (VAE.py:49-56,
+    loss.py:57-66) as one launch per direction (``pgv_bn1d_reparam_fwd`` / ``_bwd``); the backward launch also writes
+    the bias gradient of the Linear in front (``lin_bias``: that layer is called with ``bias_grad_elsewhere``).
+    Returns (z_mu_logvar [B, 2D], z [B, D], Dkl)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, gamma, beta, rng, kl_scale, kl_buf, lin_bias):
+        x = x.contiguous()
+        B = x.shape[0]
+        if B <= 1:
+            raise ValueError("Expected more than 1 value per channel when training")
+        track = bn.track_running_stats and bn.running_mean is not None
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        if track and (bn.num_batches_tracked.dtype != torch.int64 or not bn.num_batches_tracked.is_cuda):
+            raise ValueError("num_batches_tracked must be an int64 device tensor")
+        y, scale, mean, rstd, z, kl, eps = rng.bn1d_reparam(
+            x, gamma, beta, bn.eps, mom, bn.running_mean if track else None, bn.running_var if track else None,
+            bn.num_batches_tracked if track else None, kl_scale, kl_buf)
+        ctx.saved = (x, y, eps, scale, mean, rstd)
+        ctx.params = (gamma, beta, lin_bias)
+        ctx.kl_scale = kl_scale
+        ctx.set_materialize_grads(False)
+        return y, z, kl
+
+    @staticmethod
+    def backward(ctx, g_y, g_z, g_kl):
+        x, y, eps, scale, mean, rstd = ctx.saved
+        gamma, beta, lin_bias = ctx.params
+        c = lambda t: None if t is None else t.contiguous()   # noqa: E731
+        gx = torch.empty_like(x)
+        ggamma, gg_ret = _grad_dest(gamma)
+        gbeta, gbt_ret = _grad_dest(beta)
+        gb = gb_ret = None
+        gb_zero = False
+        if lin_bias is not None:
+            gb, gb_ret, gb_zero = _grad_dest(lin_bias, accumulated=True)
+        ops.bn1d_reparam_bwd(c(g_z), c(g_kl), c(g_y), y, eps, x, scale, mean, rstd, ctx.kl_scale, gx, ggamma, gbeta,
+                             colsum=gb, colsum_accumulate=False)
+        _grad_done(gamma, beta)
+        return gx, None, gg_ret, gbt_ret, None, None, None, gb_ret
 
 
 class MaskMulFn(torch.autograd.Function):

@@ -522,6 +522,39 @@ def reparam_kl_fwd_rng(ml, rng_state, stream_id, kl_scale, kl=None):
     return z, out.reshape(()), eps
 
 
+def bn1d_reparam_fwd(x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, rng_state, stream_id,
+                     kl_scale, kl=None):
+    """Train-mode nn.BatchNorm1d over x[B, 2D] + reparameterisation + Dkl in one launch (``pgv_bn1d_reparam_fwd``):
+    returns (y, scale, mean, rstd, z, kl, eps)."""
+    B, C = x.shape
+    D = C // 2
+    _chk(x, gamma, beta, running_mean, running_var, kl)
+    dev = x.device
+    y = torch.empty_like(x)
+    vec = torch.empty(3 * C, device=dev, dtype=torch.float32)
+    z = torch.empty((B, D), device=dev, dtype=torch.float32)
+    e = torch.empty((B, D), device=dev, dtype=torch.float32)
+    out = torch.empty((), device=dev, dtype=torch.float32) if kl is None else kl
+    _lib.check(_lib.load().pgv_bn1d_reparam_fwd(_p(x), B, D, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+                                                _p(running_var), _p(num_batches_tracked), _p(y), _p(vec[:C]),
+                                                _p(vec[C:2 * C]), _p(vec[2 * C:]), rng_state.data_ptr(), stream_id,
+                                                kl_scale, _p(z), _p(e), _p(out),
+                                                PGV_PREZEROED if kl is not None else 0, _stream()),
+               "pgv_bn1d_reparam_fwd")
+    return y, vec[:C], vec[C:2 * C], vec[2 * C:], z, out.reshape(()), e
+
+
+def bn1d_reparam_bwd(g_z, g_kl, g_y, y, eps, x, scale, mean, rstd, kl_scale, gx, ggamma, gbeta, colsum=None,
+                     colsum_accumulate=False):
+    B, C = x.shape
+    _chk(g_z, g_kl, g_y, y, eps, x, scale, mean, rstd, gx, ggamma, gbeta, colsum)
+    _lib.check(_lib.load().pgv_bn1d_reparam_bwd(_p(g_z), _p(g_kl), _p(g_y), _p(y), _p(eps), _p(x), _p(scale), _p(mean),
+                                                _p(rstd), B, C // 2, kl_scale, _p(gx), _p(ggamma), _p(gbeta), _p(colsum),
+                                                PGV_PREZEROED if colsum_accumulate else 0, _stream()),
+               "pgv_bn1d_reparam_bwd")
+    return gx
+
+
 def reparam_kl_bwd(ml, eps, g_z, g_kl, kl_scale):
     B, _, D = ml.shape
     _chk(ml, eps, g_z, g_kl)

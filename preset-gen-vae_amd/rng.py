@@ -81,6 +81,15 @@ class DeviceRNG:
         self._advance(eps.numel())
         return z, kl, eps
 
+    def bn1d_reparam(self, x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, kl_scale, kl=None,
+                     stream_id=STREAM_EPS):
+        """Train-mode BatchNorm1d over x[B, 2D], then ``reparam_kl`` on the result, as one launch
+        (``ops.bn1d_reparam_fwd``): returns (y, scale, mean, rstd, z, kl, eps)."""
+        out = ops.bn1d_reparam_fwd(x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                                   self.state, stream_id, kl_scale, kl)
+        self._advance(out[-1].numel())
+        return out
+
     def normal(self, shape, stream_id=STREAM_EPS):
         out = ops.normal(self.state, stream_id, tuple(int(s) for s in shape), self.state.device)
         self._advance(out.numel())

@@ -684,6 +684,56 @@ def test_batchnorm1d_one_launch_per_direction(ops, shape):
     assert rel_l2(gg, gamma.grad) < 1e-5 and rel_l2(gb, beta.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(256, 64), (7, 5), (19, 20), (2, 64)])
+def test_encoder_head_in_one_launch(ops, shape):
+    """pgv_bn1d_reparam_fwd / _bwd = pgv_bn1d_fwd -> pgv_reparam_kl_fwd_rng and pgv_reparam_kl_bwd -> pgv_bn1d_bwd ->
+    column sums, each direction as one launch: the same values (outputs identical, sums to rounding)."""
+    from preset_gen_vae_amd.rng import DeviceRNG
+    B, D = shape
+    C = 2 * D
+    x = dev(synth_vec((B, C), 0.713, 0.2) * 1.7 + 0.3)
+    gamma, beta = dev(1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)), dev(0.2 * synth_vec((C,), 2.9, 0.6))
+    g_z, g_y = dev(synth_vec((B, D), 0.377, 0.9)), dev(0.1 * synth_vec((B, C), 0.177, 0.3))
+    g_kl = torch.tensor(0.7, device='cuda')
+    # separate launches
+    rng = DeviceRNG(torch.device('cuda'), seed=3)
+    rm, rv = dev(0.1 * synth_vec((C,), 1.3, 0.4)), dev(1.0 + 0.2 * synth_vec((C,), 1.9, 0.8))
+    nbt = torch.zeros((), device='cuda', dtype=torch.int64)
+    y = torch.empty_like(x)
+    sc, mu, rs = (torch.empty(C, device='cuda') for _ in range(3))
+    ops.bn1d_fwd(x, gamma, beta, 1e-5, 0.1, rm, rv, nbt, y, sc, mu, rs)
+    z, kl, eps = rng.reparam_kl(y.view(B, 2, D), 0.25)
+    g_ml = ops.reparam_kl_bwd(y.view(B, 2, D), eps, g_z, g_kl, 0.25).view(B, C) + g_y
+    gx, gg, gb = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ops.bn1d_bwd(g_ml, x, sc, mu, rs, gx, gg, gb)
+    # one launch each
+    rng2 = DeviceRNG(torch.device('cuda'), seed=3)
+    rm2, rv2 = dev(0.1 * synth_vec((C,), 1.3, 0.4)), dev(1.0 + 0.2 * synth_vec((C,), 1.9, 0.8))
+    nbt2 = torch.zeros((), device='cuda', dtype=torch.int64)
+    y2, sc2, mu2, rs2, z2, kl2, eps2 = rng2.bn1d_reparam(x, gamma, beta, 1e-5, 0.1, rm2, rv2, nbt2, 0.25)
+    assert torch.equal(eps2, eps) and torch.equal(nbt2, nbt)
+    for a, b in ((y2, y), (sc2, sc), (mu2, mu), (rs2, rs), (z2, z), (rm2, rm), (rv2, rv)):   # (sums in another order)
+        assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1.0)
+    assert torch.equal(rng2.state, rng.state)
+    assert abs(kl2.item() - kl.item()) <= 1e-5 * abs(kl.item())
+    gx2, gg2, gb2 = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    cs = torch.full((C,), float('nan'), device='cuda')
+    ops.bn1d_reparam_bwd(g_z, g_kl, g_y, y2, eps2, x, sc2, mu2, rs2, 0.25, gx2, gg2, gb2, colsum=cs)
+    scale_g = g_ml.abs().max().item()
+    assert (gx2 - gx).abs().max().item() <= 1e-5 * scale_g * sc.abs().max().item()
+    assert rel_l2(gg2, gg) < 1e-5 and rel_l2(gb2, gb) < 1e-5
+    assert (cs.double() - gx2.double().sum(0)).abs().max().item() <= 1e-5 * gx2.abs().max().item() * B
+    # without g_y / g_z (only the Dkl gradient), into an accumulating column sum
+    cs3 = torch.ones(C, device='cuda')
+    gx3 = torch.empty_like(x)
+    ops.bn1d_reparam_bwd(None, g_kl, None, y2, eps2, x, sc2, mu2, rs2, 0.25, gx3, None, None, colsum=cs3, colsum_accumulate=True)
+    g_ml3 = ops.reparam_kl_bwd(y.view(B, 2, D), eps, None, g_kl, 0.25).view(B, C)
+    gx_ref3 = torch.empty_like(x)
+    ops.bn1d_bwd(g_ml3, x, sc, mu, rs, gx_ref3, gg, gb)
+    assert (gx3 - gx_ref3).abs().max().item() <= 1e-5 * g_ml3.abs().max().item() * sc.abs().max().item()
+    assert (cs3.double() - 1.0 - gx3.double().sum(0)).abs().max().item() <= 1e-5 * max(gx3.abs().max().item() * B, 1.0)
+
+
 def test_conv_desc_validation(ops):
     from preset_gen_vae_amd import _lib
     geom = ops.ConvGeom(2, 3, 4, 2, 2, 9, 9)
