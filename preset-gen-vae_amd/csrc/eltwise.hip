@@ -87,30 +87,51 @@ __global__ void dropout_apply_kernel(const uint64_t* __restrict__ rng, uint64_t 
 // (bn.stats != null, C <= kDropBnMaxC: the affine is the BatchNorm bn, finalized here into an LDS table by every workgroup
 // - pgv_bn_src - instead of by a launch of its own)
 constexpr int kDropBnMaxC = 512;
+// AFF: 0 no affine, 1 scale / shift read from global memory, 2 from an LDS table (C <= kDropBnMaxC) that every workgroup
+// fills in its prologue - from the vectors, or from the BatchNorm's statistics (bn.stats).  Compile-time: with the table
+// chosen by a run-time pointer the per-quad reads became flat loads and the streaming loop lost its overlap (21 us
+// against 10 for the plain kernel).
+template <int AFF>
 __global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
                                    int64_t n, const float* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int C, int64_t HW, float* __restrict__ y,
                                    uint64_t* __restrict__ saved, int vec, pgv_bn_src bn) {
-  __shared__ float tab[2 * kDropBnMaxC];
-  if (bn.stats) {
+  __shared__ float tab[AFF == 2 ? 2 * kDropBnMaxC : 2];
+  if constexpr (AFF == 2) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float sc, sh;
-      pgv_bn_finalize_dev(bn, C, c, blockIdx.x == 0, sc, sh);
+      if (bn.stats)
+        pgv_bn_finalize_dev(bn, C, c, blockIdx.x == 0, sc, sh);
+      else
+        sc = scale[c], sh = shift[c];
       tab[c] = sc, tab[kDropBnMaxC + c] = sh;
     }
     __syncthreads();
-    scale = tab, shift = tab + kDropBnMaxC;
   }
+  auto aff_of = [&](int c, float& sc, float& sh) {
+    if constexpr (AFF == 2)
+      sc = tab[c], sh = tab[kDropBnMaxC + c];
+    else
+      sc = scale[c], sh = shift[c];
+  };
   const uint64_t seed = rng[0], off = rng[1];
   if (blockIdx.x == 0 && threadIdx.x == 0) saved[0] = seed, saved[1] = off;
   const int64_t n4 = (n + 3) / 4;
   // channel of the quad, kept incrementally along the grid-stride walk (a 64-bit division per quad cost more than the
   // Philox rounds): position (ch, rem) of element 4q inside its sample, advanced by the stride's (channels, remainder)
   const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  // (32-bit divisions: four 64-bit ones per thread - ~1000 instructions - were half of this kernel's 21 us)
   int ch = 0, rem = 0, d_ch = 0, d_rem = 0;
-  if (scale && vec) {
-    ch = (int)((q0 * 4 / HW) % C), rem = (int)(q0 * 4 % HW);
-    d_ch = (int)((stride * 4 / HW) % C), d_rem = (int)(stride * 4 % HW);
+  if (AFF != 0 && vec) {
+    if (n < ((int64_t)1 << 31)) {
+      const unsigned e0 = (unsigned)q0 * 4u, es = (unsigned)stride * 4u, hw = (unsigned)HW;
+      const unsigned p0 = e0 / hw, ps = es / hw;
+      ch = (int)(p0 % (unsigned)C), rem = (int)(e0 - p0 * hw);
+      d_ch = (int)(ps % (unsigned)C), d_rem = (int)(es - ps * hw);
+    } else {
+      ch = (int)((q0 * 4 / HW) % C), rem = (int)(q0 * 4 % HW);
+      d_ch = (int)((stride * 4 / HW) % C), d_rem = (int)(stride * 4 % HW);
+    }
   }
   for (int64_t q = q0; q < n4; q += stride) {
     const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
@@ -118,12 +139,13 @@ __global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t st
                         u01(r.z) >= p ? keep_scale : 0.f, u01(r.w) >= p ? keep_scale : 0.f};
     if (vec && q * 4 + 4 <= n) {   // (vec: 16-byte aligned, and HW % 4 == 0 when there is an affine: one channel per quad)
       float4 xv = reinterpret_cast<const float4*>(x)[q];
-      if (scale) {
+      if constexpr (AFF != 0) {
         const int c = ch;
         rem += d_rem, ch += d_ch;
         if (rem >= (int)HW) rem -= (int)HW, ch += 1;
         if (ch >= C) ch -= C;
-        const float sc = scale[c], sh = shift[c];
+        float sc, sh;
+        aff_of(c, sc, sh);
         xv = make_float4(fmaf(xv.x, sc, sh), fmaf(xv.y, sc, sh), fmaf(xv.z, sc, sh), fmaf(xv.w, sc, sh));
       }
       reinterpret_cast<float4*>(y)[q] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
@@ -133,9 +155,10 @@ __global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t st
         const int64_t i = q * 4 + j;
         if (i < n) {
           float xv = x[i];
-          if (scale) {
-            const int c = (int)((i / HW) % C);
-            xv = fmaf(xv, scale[c], shift[c]);
+          if constexpr (AFF != 0) {
+            float sc, sh;
+            aff_of((int)((i / HW) % C), sc, sh);
+            xv = fmaf(xv, sc, sh);
           }
           y[i] = xv * m[j];
         }
@@ -649,9 +672,11 @@ static int dropout_fwd_launch(const uint64_t* rng_state, uint64_t stream_id, flo
   const int64_t n = B * C * HW;
   const int vec = aligned16(x, y, y) && (!scale || HW % 4 == 0) ? 1 : 0;
   // (n == 0 still records the state: backward of an empty batch reads it)
-  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(max(n, (int64_t)1), 4)), dim3(kBlock), 0, pgv_stream(stream),
-                     rng_state, stream_id, p, 1.0f / (1.0f - p), n, x, scale, shift, C, HW, y, saved_state, vec,
-                     bn ? *bn : pgv_no_bn());
+  const int aff = !scale ? 0 : (C <= kDropBnMaxC ? 2 : 1);
+  auto kern = aff == 0 ? dropout_fwd_kernel<0> : (aff == 1 ? dropout_fwd_kernel<1> : dropout_fwd_kernel<2>);
+  hipLaunchKernelGGL(kern, dim3(grid_for(max(n, (int64_t)1), 4)), dim3(kBlock), 0, pgv_stream(stream), rng_state, stream_id,
+                     p, 1.0f / (1.0f - p), n, x, scale, shift, C, HW, y, saved_state, vec,
+                     (bn && aff == 2) ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("dropout_fwd");
   return PGV_OK;
 }
