@@ -219,19 +219,46 @@ def launch_table(ae, B, device, frontend=None):
             cls_lo = torch.zeros(4 * Cl, device=device) if (is_up and lower2 is not None) else None
             fuse = (a_lo, coef, gb_lo, 1, 0.1, cls_lo)
 
+        # the producer's train-mode BatchNorm is finalized in this block's forward kernel (ops.bn_src: statistics of a
+        # zero-mean unit-variance input stand in), no launch of its own
+        in_bn = None
+        if fold:
+            Ci, ni = lo.shape[1], B * lo.shape[2] * lo.shape[3]
+            st_in = torch.cat([torch.zeros(Ci, dtype=torch.float64), torch.full((Ci,), float(ni), dtype=torch.float64)]).to(device)
+            vec_in = [torch.empty(Ci, device=device) for _ in range(4)]
+            in_bn = ops.bn_src(st_in, ni, torch.ones(Ci, device=device), torch.zeros(Ci, device=device), 1e-5, 0.1,
+                               torch.zeros(Ci, device=device), torch.ones(Ci, device=device), None, *vec_in)
+        # the BatchNorm-backward coefficients of the lower block ride in this block's weight-gradient call
+        # (pgv_conv_wgrad_coef: partial-gradient reduce + border tap sums in one launch, then the coefficient kernel)
+        coef_req = None
+        if fuse is not None and lower[2]:
+            Cl, gy_t = lo.shape[1], (big if is_up else small)
+            m_ = s if is_up else 1
+            one4 = [torch.ones(Cl, device=device) for _ in range(4)]
+            coef_req = dict(lower_is_big=not is_up, cls=torch.zeros(gy_t.shape[1] * m_ * m_, device=device), w=w,
+                            scale=one4[0], shift=one4[1], mean=one4[2], rstd=one4[3], n=lo.numel() // Cl,
+                            coef=torch.empty(3 * Cl, device=device), ggamma=torch.empty(Cl, device=device),
+                            gbeta=torch.empty(Cl, device=device),
+                            scratch=torch.zeros(ops.coef_scratch(geom, not is_up), device=device, dtype=torch.float64))
+
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
                bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up,
-               fuse=fuse):
+               fuse=fuse, in_bn=in_bn, coef_req=coef_req):
             if kind == 'conv_down':
-                return (lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, in_scale=sc_b, in_shift=sh_b, stats=fs,
-                                              out=out_s)) if not is_up else \
-                    (lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse))
+                if is_up:
+                    return lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse)
+                if in_bn is not None:
+                    return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, in_bn=in_bn)
+                return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s)
             if kind == 'conv_up':
-                return (lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, in_scale=sc_s, in_shift=sh_s, stats=fb,
-                                            out=out_b)) if is_up else \
-                    (lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse))
-            return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b)) if not is_up else \
-                (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s))
+                if not is_up:
+                    return lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse)
+                if in_bn is not None:
+                    return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, in_bn=in_bn)
+                return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b)
+            return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b, coef_req=coef_req)) \
+                if not is_up else \
+                (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s, coef_req=coef_req))
 
         for kind in ('conv_down', 'conv_up', 'conv_wgrad'):
             if name == 'enc1' and kind == 'conv_up':
@@ -239,29 +266,16 @@ def launch_table(ae, B, device, frontend=None):
             is_dgrad = kind == ('conv_down' if is_up else 'conv_up')
             extra = (ns if is_up else nb) if (is_dgrad and fuse is not None) else 0   # the saved activation
             label = f"{kind}[{name}]" + ("+bn_act_bwd" if (is_dgrad and fuse is not None) else "")
+            if kind == 'conv_wgrad' and coef_req is not None:
+                label += "+bn_bwd_coef"
+            if not is_dgrad and kind != 'conv_wgrad' and in_bn is not None:
+                label += "+bn_finalize"
             table.append((label, mk(kind), nb + ns + nw + extra, flops))
         a = big if is_up else small
         C = a.shape[1]
         big_na = ops.compute_dtype() == 'fp32' or B * a.shape[2] * a.shape[3] >= layer_mod.BF16_PASSFREE_MIN_N
         if has_bn and fused_bwd and big_na and upper is not None and a.shape[2] * a.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
-            # pass-free BatchNorm backward of this block: tap sums of the consumer's g_y (border rows / columns only) and
-            # the coefficient kernel (pgv_conv_tap_sums, pgv_bn_bwd_coef) - launch-latency-sized
-            (uCb, uCs, uk, us, up_, uHb, uWb) = upper[1]
-            ug = ops.ConvGeom(uCb, uCs, uk, us, up_, uHb, uWb)
-            gy_u = torch.randn(B, uCb, uHb, uWb, device=device) if is_up else torch.randn(B, uCs, ug.Hs, ug.Ws, device=device)
-            m_ = 2 if is_up else 1
-            cls_u = torch.zeros(gy_u.shape[1] * m_ * m_, device=device)
-            T = torch.zeros(gy_u.shape[1] * uk * uk, device=device, dtype=torch.float64)
-            wu, gwu = torch.randn(uCs, uCb, uk, uk, device=device) * 0.05, torch.randn(uCs, uCb, uk, uk, device=device)
-            one4 = [torch.ones(C, device=device) for _ in range(4)]
-            coef_o, gga, gbe = torch.empty(3 * C, device=device), torch.empty(C, device=device), torch.empty(C, device=device)
-            table.append((f"tap_sums[{name}]", (lambda ug=ug, gy_u=gy_u, T=T, cls_u=cls_u, is_up=is_up:
-                                                 ops.conv_tap_sums(ug, gy_u, is_up, T, prezeroed=True, cls=cls_u)), 0, 0.0))
-            table.append((f"bn_bwd_coef[{name}]", (lambda ug=ug, wu=wu, gwu=gwu, T=T, one4=one4, coef_o=coef_o, gga=gga,
-                                                   gbe=gbe, a=a, C=C, is_up=is_up:
-                                                   ops.bn_bwd_coef(ug, B, not is_up, wu, gwu, T, one4[0], one4[1], one4[2],
-                                                                   one4[3], a.numel() // C, coef_o, gga, gbe)),
-                          2 * wu.numel() * 4, 0.0))
+            pass   # pass-free BatchNorm backward: its coefficients ride in the consumer block's weight-gradient entry
         elif has_bn:
             # top block of a stack (or bf16 operand mode): the reduce + apply passes over this block's output tensor
             g_o, g_y = torch.randn_like(a), torch.empty_like(a)
@@ -292,6 +306,29 @@ def launch_table(ae, B, device, frontend=None):
         table.append((f"linear_fwd[{tag}]", lambda xin=xin, wl=wl, bl=bl: ops.linear_fwd(xin, wl, bl), byt, fl))
         table.append((f"linear_dgrad[{tag}]", lambda gyl=gyl, wl=wl: ops.linear_dgrad(gyl, wl), byt, fl))
         table.append((f"linear_wgrad[{tag}]", lambda gyl=gyl, xin=xin, gwl=gwl: ops.linear_wgrad(gyl, xin, gwl), byt, fl))
+    # fc Dropout without a stored mask (forward draws and applies, backward regenerates), the encoder's with its last
+    # conv block's BatchNorm folded in, the decoder's backward with the Linear bias gradient on the way
+    from preset_gen_vae_amd.rng import DeviceRNG
+    rng = DeviceRNG(device, seed=1)
+    K = lin_e.weight.shape[1]
+    xd = torch.randn(B, K, device=device)
+    _, saved = ops.dropout_fwd(rng.state, 2, 0.3, xd)
+    cs = torch.zeros(K, device=device)
+    enc_last = [l for l in layers if not l[3]][-1]
+    if enc_last[2]:
+        g_l = ops.ConvGeom(*enc_last[1])
+        Ce, ne = enc_last[1][1], B * g_l.Hs * g_l.Ws
+        xe = torch.randn(B, Ce, g_l.Hs, g_l.Ws, device=device)
+        st_e = torch.cat([torch.zeros(Ce, dtype=torch.float64), torch.full((Ce,), float(ne), dtype=torch.float64)]).to(device)
+        bn_e = ops.bn_src(st_e, ne, torch.ones(Ce, device=device), torch.zeros(Ce, device=device), 1e-5, 0.1,
+                          torch.zeros(Ce, device=device), torch.ones(Ce, device=device), None,
+                          *[torch.empty(Ce, device=device) for _ in range(4)])
+        table.append(("dropout_fwd[enc_fc]+bn_finalize", lambda: ops.dropout_fwd(rng.state, 2, 0.3, xe, in_bn=bn_e),
+                      2 * xe.numel() * 4, 0.0))
+    table.append(("dropout_fwd[dec_fc]", lambda: ops.dropout_fwd(rng.state, 3, 0.3, xd), 2 * xd.numel() * 4, 0.0))
+    table.append(("dropout_bwd[enc_fc]", lambda: ops.dropout_bwd(saved, 2, 0.3, xd), 2 * xd.numel() * 4, 0.0))
+    table.append(("dropout_bwd+colsum[dec_fc]", lambda: ops.dropout_bwd(saved, 3, 0.3, xd, colsum=cs, prezeroed=True),
+                  2 * xd.numel() * 4, 0.0))
     # fused Adam over the flat parameter buffer: read p, g, m, v; write p, m, v
     n = sum(p.numel() for p in ae.parameters())
     fp, fg, fm, fv = (torch.zeros(n, device=device) for _ in range(4))

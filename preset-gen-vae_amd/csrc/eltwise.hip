@@ -137,16 +137,21 @@ __global__ void dropout_fwd_kernel(const uint64_t* __restrict__ rng, uint64_t st
     const U4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
     const float m[4] = {u01(r.x) >= p ? keep_scale : 0.f, u01(r.y) >= p ? keep_scale : 0.f,
                         u01(r.z) >= p ? keep_scale : 0.f, u01(r.w) >= p ? keep_scale : 0.f};
-    if (vec && q * 4 + 4 <= n) {   // (vec: 16-byte aligned, and HW % 4 == 0 when there is an affine: one channel per quad)
+    if (vec && q * 4 + 4 <= n) {   // (vec: 16-byte aligned; with an affine HW >= 4: a quad lies in at most two channels)
       float4 xv = reinterpret_cast<const float4*>(x)[q];
       if constexpr (AFF != 0) {
-        const int c = ch;
+        // (planes of 17x23 = 391 elements - the encoder's - are not multiples of 4: elements past the plane's end take
+        // the next channel's pair)
+        const int c = ch, left = (int)HW - rem;   // elements of this quad that still belong to channel c
         rem += d_rem, ch += d_ch;
         if (rem >= (int)HW) rem -= (int)HW, ch += 1;
         if (ch >= C) ch -= C;
-        float sc, sh;
+        float sc, sh, sc2, sh2;
         aff_of(c, sc, sh);
-        xv = make_float4(fmaf(xv.x, sc, sh), fmaf(xv.y, sc, sh), fmaf(xv.z, sc, sh), fmaf(xv.w, sc, sh));
+        aff_of(c + 1 < C ? c + 1 : 0, sc2, sh2);
+        xv = make_float4(fmaf(xv.x, sc, sh), left > 1 ? fmaf(xv.y, sc, sh) : fmaf(xv.y, sc2, sh2),
+                         left > 2 ? fmaf(xv.z, sc, sh) : fmaf(xv.z, sc2, sh2),
+                         left > 3 ? fmaf(xv.w, sc, sh) : fmaf(xv.w, sc2, sh2));
       }
       reinterpret_cast<float4*>(y)[q] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
     } else {
@@ -670,7 +675,7 @@ static int dropout_fwd_launch(const uint64_t* rng_state, uint64_t stream_id, flo
                               int64_t HW, const float* scale, const float* shift, const pgv_bn_src* bn, float* y,
                               uint64_t* saved_state, void* stream) {
   const int64_t n = B * C * HW;
-  const int vec = aligned16(x, y, y) && (!scale || HW % 4 == 0) ? 1 : 0;
+  const int vec = aligned16(x, y, y) && (!scale || HW >= 4) ? 1 : 0;
   // (n == 0 still records the state: backward of an empty batch reads it)
   const int aff = !scale ? 0 : (C <= kDropBnMaxC ? 2 : 1);
   auto kern = aff == 0 ? dropout_fwd_kernel<0> : (aff == 1 ? dropout_fwd_kernel<1> : dropout_fwd_kernel<2>);

@@ -744,7 +744,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 7
+    assert _lib.load().pgv_abi_version() == 8
 
 
 def test_empty_batch(ops):
@@ -952,7 +952,7 @@ def test_rng_distributions(ops):
     assert kl2.data_ptr() == buf.data_ptr() and abs(kl2.item() - kl_ref.item()) <= 1e-6 * abs(kl_ref.item())
     # ... and so is the mask-free form the train step uses: forward draws and applies, backward regenerates the mask from
     # the saved copy of the state - also after the generator itself has moved on; optional per-channel affine on the way in
-    for shape in ((256, 64, 16, 24), (3, 5, 7, 11), (2, 1001)):
+    for shape in ((256, 64, 16, 24), (16, 64, 17, 23), (3, 5, 7, 11), (4, 3, 2, 2), (2, 1001)):
         rng_d, ref = DeviceRNG(torch.device('cuda'), seed=7), DeviceRNG(torch.device('cuda'), seed=7)
         x = torch.randn(*shape, device='cuda')
         affine = len(shape) == 4
