@@ -163,7 +163,8 @@ int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_sc
  * call's result), as one call.  With the wave-specialised weight-gradient kernels the partial-gradient reduce pass and
  * the border tap sums (independent of each other) share ONE launch, followed by the coefficient kernel: two dependent
  * launches behind the weight-gradient kernel instead of three; otherwise the pieces run one after the other.
- * scratch: zeroed doubles, >= C_gy*kh*kw + 1, private to the call.  With PGV_PREZEROED gw must hold zeros (the
+ * scratch: zeroed doubles, >= max(C_gy*kh*kw, 1024) + 1, private to the call (the tap sums of few channels are spread
+ * over partial copies).  With PGV_PREZEROED gw must hold zeros (the
  * coefficients are those of THIS call's gradient). */
 typedef struct pgv_coef_req {
   int32_t lower_is_big;
@@ -172,7 +173,7 @@ typedef struct pgv_coef_req {
   const float *scale, *shift, *mean, *rstd; /* of the lower block's BatchNorm */
   int64_t n;          /* elements per channel of the lower block's output */
   float *coef, *ggamma, *gbeta;
-  double* scratch;    /* C_gy*kh*kw + 1 doubles, zeroed: receives the tap sums of gy */
+  double* scratch;    /* max(C_gy*kh*kw, 1024) + 1 doubles, zeroed: receives the tap sums of gy */
 } pgv_coef_req;
 int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small, const float* small_scale, const float* small_shift, float* gw,

@@ -1139,6 +1139,19 @@ int pgv_bn_bwd_coef_from_gy(const pgv_conv_desc* d, int lower_is_big, const floa
   return PGV_OK;
 }
 
+extern "C++" {
+int pgv_tap_replicas(int c_gy, int kk) { return tap_replicas(c_gy, kk); }
+int pgv_bn_bwd_coef_rep(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T, int trep,
+                        const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
+                        float* coef, float* ggamma, float* gbeta, hipStream_t st) {
+  CoefArgs ca = coef_args(d, lower_is_big, w, gw, scale, shift, mean, rstd, n, coef, ggamma, gbeta);
+  ca.trep = trep;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ca.C), dim3(256), 0, st, ca, T);
+  PGV_CHECK_LAUNCH("bn_bwd_coef");
+  return PGV_OK;
+}
+}  // extern "C++"
+
 int pgv_bn_bwd_coef(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T,
                     const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
                     float* coef, float* ggamma, float* gbeta, void* stream) {

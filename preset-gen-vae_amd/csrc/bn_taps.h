@@ -137,7 +137,11 @@ struct CoefArgs {
   float *coef, *ggamma, *gbeta;
   double inv_n;
   int Cb, Cs, KK, lower_is_big, bf16, C;   // C = channels of the lower block
+  int trep = 1;                            // the tap sums arrive as this many partial copies [trep][C_gy * KK] (tap_replicas)
 };
+// Border tap sums of few channels meet on few addresses (C_gy = 1: 384 workgroups on 25 doubles - 15 us of a launch that
+// takes 5 otherwise): they are spread over this many copies of T, added up by the coefficient kernel.
+static inline int tap_replicas(int c_gy, int kk) { return max(1, min(16, 1024 / (c_gy * kk))); }
 // from S_o = sum g*o and S_1 = sum g of channel c (one thread)
 __device__ __forceinline__ void bn_bwd_coef_finish(const CoefArgs& ca, int c, double so, double s1) {
   const double sc = ca.scale[c], sh = ca.shift[c], mu = ca.mean[c], rs = ca.rstd[c];
@@ -155,12 +159,14 @@ __device__ __forceinline__ void bn_bwd_coef_channel(const CoefArgs& ca, int c, T
   const int n_other = ca.lower_is_big ? ca.Cs : ca.Cb;
   const int total = n_other * ca.KK;
   double so = 0.0, s1 = 0.0;
-  for (int e = threadIdx.x; e < total; e += 256) {
+  // (one thread per element AND copy of the tap sums: the copies are independent loads, not a chain per thread)
+  for (int e2 = threadIdx.x; e2 < total * ca.trep; e2 += 256) {
+    const int r = e2 / total, e = e2 - r * total;
     const int co = e / ca.KK, tap = e - co * ca.KK;
     const int64_t idx = ca.lower_is_big ? ((int64_t)co * ca.Cb + c) * ca.KK + tap : ((int64_t)c * ca.Cb + co) * ca.KK + tap;
     const double wv = (double)pgv_opnd(ca.w[idx], ca.bf16 != 0);
-    so = fma(wv, (double)ca.gw[idx], so);
-    s1 = fma(wv, T_of(co * ca.KK + tap), s1);
+    if (r == 0) so = fma(wv, (double)ca.gw[idx], so);
+    s1 = fma(wv, T_of(e2), s1);
   }
   so = pgv_block_sum_d(so, red);
   s1 = pgv_block_sum_d(s1, red);

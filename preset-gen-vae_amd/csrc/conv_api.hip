@@ -243,9 +243,10 @@ int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* b
     if (g_policy == 0 && !g_no_v2) {
       rc = pgv_conv_wgrad_v2(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
                              workspace_bytes, req, st);
-      if (rc == 3)   // weight gradient and tap sums done
-        return pgv_bn_bwd_coef(d, req->lower_is_big, req->w, gw, req->scratch, req->scale, req->shift, req->mean, req->rstd,
-                               req->n, req->coef, req->ggamma, req->gbeta, stream);
+      if (rc == 3)   // weight gradient and tap sums (as partial copies) done
+        return pgv_bn_bwd_coef_rep(d, req->lower_is_big, req->w, gw, req->scratch,
+                                   pgv_tap_replicas(req->lower_is_big ? d->Cs : d->Cb, d->kh * d->kw), req->scale,
+                                   req->shift, req->mean, req->rstd, req->n, req->coef, req->ggamma, req->gbeta, st);
     }
     if (rc == 0 && g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);

@@ -57,7 +57,12 @@ int pgv_conv_down_direct2(const pgv_conv_desc* d, const float* big, const float*
                           const pgv_bwd_fuse* fuse, hipStream_t st);
 
 int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d);
-// (req != null: returns 3 when the tap sums of the output gradient - req->scratch - came out of the same launches)
+// (req != null: returns 3 when the tap sums of the output gradient - req->scratch, as pgv_tap_replicas() partial copies -
+// came out of the same launches)
+int pgv_tap_replicas(int c_gy, int kk);
+int pgv_bn_bwd_coef_rep(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T, int trep,
+                        const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
+                        float* coef, float* ggamma, float* gbeta, hipStream_t st);
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                       void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st);

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // counter alone cost 25 us, and a device-scope __threadfence() per workgroup - an L2 write-back on this chip - 100 us.)
 struct WgradTapsArgs {
   const float* partial; int nparts, n4; float* gw; int accumulate, nred;
-  const float* gy; int B, Cgy, H, W, per, nsplit, gy_is_big, s, p; TapBorder tb; const float* cls; double* T;
+  const float* gy; int B, Cgy, H, W, per, nsplit, gy_is_big, s, p; TapBorder tb; const float* cls; double* T; int trep;
 };
 template <int K>
 __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a)
         const int rho = a.gy_is_big ? (((kh - a.p) % a.s) + a.s) % a.s : 0, kap = a.gy_is_big ? (((kw - a.p) % a.s) + a.s) % a.s : 0;
         t += (double)a.cls[c * m * m + rho * m + kap];
       }
-      atomicAdd(&a.T[(int64_t)c * KK + tid], t);
+      atomicAdd(&a.T[(int64_t)(r % a.trep) * a.Cgy * KK + (int64_t)c * KK + tid], t);   // (copies: tap_replicas)
     }
   }
 }
@@ -383,7 +383,7 @@ inline bool wgrad_taps_setup(const pgv_conv_desc* d, const pgv_coef_req* req, co
   a->nsplit = (int)pgv_cdiv(d->B, a->per);
   a->gy = gy_is_big ? big : small_in;
   a->B = d->B, a->Cgy = C, a->H = H, a->W = W, a->gy_is_big = gy_is_big, a->s = d->stride, a->p = d->pad;
-  a->cls = req->cls, a->T = req->scratch;
+  a->cls = req->cls, a->T = req->scratch, a->trep = tap_replicas(C, K * K);
   *nblocks = a->nred + C * a->nsplit * nz;
   return true;
 }

@@ -183,9 +183,10 @@ def _workspace(device, nbytes):
 
 
 def coef_scratch(geom, lower_is_big):
-    """float64 elements of a ``coef_req`` scratch (``pgv_coef_req.scratch``): the tap sums of the output gradient + 1."""
+    """float64 elements of a ``coef_req`` scratch (``pgv_coef_req.scratch``): the tap sums of the output gradient (as
+    partial copies when its channels are few) + 1."""
     c_gy = geom.Cs if lower_is_big else geom.Cb
-    return c_gy * geom.k * geom.k + 1
+    return max(c_gy * geom.k * geom.k, 1024) + 1
 
 
 def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None,
