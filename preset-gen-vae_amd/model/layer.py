@@ -234,7 +234,10 @@ class ConvStackFn(torch.autograd.Function):
         else:
             if pending is not None:
                 ops.bn_src_finalize(pending)
-            out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur
+            # (a stack whose last block has no BatchNorm returns that block's activation: as a VIEW, so that the tensor
+            # object ctx.saved holds is not the output itself - output -> grad_fn -> ctx -> output would be a reference
+            # cycle that keeps the step's activations alive until a garbage collection)
+            out = ops.affine_nchw(cur, cur_scale, cur_shift) if cur_scale is not None else cur.view_as(cur)
         ctx.blocks, ctx.saved, ctx.params = blocks, saved, params
         ctx.sq = None
         if sq_target is None:
@@ -564,7 +567,10 @@ class EncoderHeadFn(torch.autograd.Function):
         y, scale, mean, rstd, z, kl, eps = rng.bn1d_reparam(
             x, gamma, beta, bn.eps, mom, bn.running_mean if track else None, bn.running_var if track else None,
             bn.num_batches_tracked if track else None, kl_scale, kl_buf)
-        ctx.saved = (x, y, eps, scale, mean, rstd)
+        # (save_for_backward, not an attribute: y is an OUTPUT of this function - kept as an attribute it would close a
+        # reference cycle output -> grad_fn -> ctx -> output and hold the whole step's activations until a garbage
+        # collection: eager steps grew by 780 MB each)
+        ctx.save_for_backward(x, y, eps, scale, mean, rstd)
         ctx.params = (gamma, beta, lin_bias)
         ctx.kl_scale = kl_scale
         ctx.set_materialize_grads(False)
@@ -572,7 +578,7 @@ class EncoderHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_y, g_z, g_kl):
-        x, y, eps, scale, mean, rstd = ctx.saved
+        x, y, eps, scale, mean, rstd = ctx.saved_tensors
         gamma, beta, lin_bias = ctx.params
         c = lambda t: None if t is None else t.contiguous()   # noqa: E731
         gx = torch.empty_like(x)
