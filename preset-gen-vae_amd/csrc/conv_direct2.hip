@@ -180,7 +180,7 @@ struct DownC1Cfg {
 };
 
 template <int CS, int H, int W, int R, bool FUSE>
-__global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) void down_c1_v2_kernel(int B, const float* __restrict__ big,
+__global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 4 : 2) void down_c1_v2_kernel(int B, const float* __restrict__ big,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
@@ -245,30 +245,39 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
       rq[ps] = qq / QW;
       vqq[ps] = qq - rq[ps] * QW;
     }
-    // FUSE: the saved activation of the quad's CS channels is fetched NOW, ahead of the multiply phase - issued in the
+    // FUSE: the saved activation of the quad's channels is fetched ahead of the multiply phase - issued in the
     // epilogue (as it first was) every unit exposed one memory latency to the whole workgroup: 150 us against 59 us for
-    // the plain kernel, slower than the separate reduce pass the fusion replaces
+    // the plain kernel, slower than the separate reduce pass the fusion replaces.  The fused kernel walks the CS channels
+    // in halves (CH at a time) over the same LDS tile: accumulators and prefetched activations of ONE half are live at a
+    // time (32 registers fewer: a fourth workgroup per CU); the second half's activations are requested when the first
+    // half's have been consumed, and are covered by the second half's multiply phase and the other workgroups.
     const int64_t cstride = (int64_t)Hs * Ws;
-    f4u avv[FUSE ? NPASS : 1][FUSE ? CS : 1];
-    if constexpr (FUSE) {
+    constexpr int CH = FUSE ? CS / 2 : CS;   // channels per pass over the tile
+    f4u avv[FUSE ? NPASS : 1][FUSE ? CH : 1];
+    auto fetch_a = [&](int c0) {
+      if constexpr (FUSE) {
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int ow0 = 4 * vqq[ps];
-        const int64_t off = (int64_t)b * CS * cstride + (int64_t)(oh0 + rq[ps]) * Ws + ow0;
-        if (okq[ps] && Ws - ow0 >= 4) {
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int ow0 = 4 * vqq[ps];
+          const int64_t off = (int64_t)b * CS * cstride + (int64_t)(oh0 + rq[ps]) * Ws + ow0;
+          if (okq[ps] && Ws - ow0 >= 4) {
 #pragma unroll
-          for (int cs = 0; cs < CS; ++cs) avv[ps][cs] = *reinterpret_cast<const f4u*>(fuse.a + off + cs * cstride);
+            for (int cs = 0; cs < CH; ++cs) avv[ps][cs] = *reinterpret_cast<const f4u*>(fuse.a + off + (c0 + cs) * cstride);
+          }
         }
       }
-    }
+    };
+    fetch_a(0);
+#pragma unroll
+    for (int c0 = 0; c0 < CS; c0 += CH) {
     // accumulators as channel pairs: one v_pk_fma_f32 per input value, tap and channel pair
-    f32x2 acc[NPASS][4][CS / 2];
+    f32x2 acc[NPASS][4][CH / 2];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c2 = 0; c2 < CS / 2; ++c2) acc[ps][j][c2] = f32x2{bias_r[2 * c2], bias_r[2 * c2 + 1]};
+        for (int c2 = 0; c2 < CH / 2; ++c2) acc[ps][j][c2] = f32x2{bias_r[c0 + 2 * c2], bias_r[c0 + 2 * c2 + 1]};
 #pragma unroll 1
     for (int kh = 0; kh < K5; ++kh) {
       float x[NPASS][11];
@@ -283,11 +292,11 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
       }
 #pragma unroll
       for (int kw = 0; kw < K5; ++kw) {
-        // wl[kh][kw][cs]: the CS weights of one tap, uniform address (broadcast reads), channel pairs adjacent
-        f32x2 wp[CS / 2];
+        // wl[kh][kw][cs]: the weights of one tap, uniform address (broadcast reads), channel pairs adjacent
+        f32x2 wp[CH / 2];
 #pragma unroll
-        for (int c4 = 0; c4 < CS / 4; ++c4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(wl + (kh * K5 + kw) * CS + 4 * c4);
+        for (int c4 = 0; c4 < CH / 4; ++c4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(wl + (kh * K5 + kw) * CS + c0 + 4 * c4);
           wp[2 * c4] = f32x2{t.x, t.y};
           wp[2 * c4 + 1] = f32x2{t.z, t.w};
         }
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
             const float xin = x[ps][2 * j + kw];
             const f32x2 xx = {xin, xin};
 #pragma unroll
-            for (int c2 = 0; c2 < CS / 2; ++c2) acc[ps][j][c2] = __builtin_elementwise_fma(xx, wp[c2], acc[ps][j][c2]);
+            for (int c2 = 0; c2 < CH / 2; ++c2) acc[ps][j][c2] = __builtin_elementwise_fma(xx, wp[c2], acc[ps][j][c2]);
           }
       }
     }
@@ -309,14 +318,15 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
       const int n = Ws - ow0;  // valid pixels from ow0 on
       const int64_t off = (int64_t)b * CS * cstride + (int64_t)(oh0 + rq[ps]) * Ws + ow0;
 #pragma unroll
-      for (int cs = 0; cs < CS; ++cs) {
+      for (int ch = 0; ch < CH; ++ch) {
+        const int cs = c0 + ch;
         float y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = pgv_act_apply(acc[ps][j][cs >> 1][cs & 1], actp);
+        for (int j = 0; j < 4; ++j) y[j] = pgv_act_apply(acc[ps][j][ch >> 1][ch & 1], actp);
         float* o = out + off + cs * cstride;
         if (n >= 4) {
           if constexpr (FUSE) {
-            const f4u av = avv[ps][cs];
+            const f4u av = avv[ps][ch];
             y[0] = pgv_bwd_apply(y[0], av.x, ka_r[cs], kb_r[cs], kc_r[cs], actd);
             y[1] = pgv_bwd_apply(y[1], av.y, ka_r[cs], kb_r[cs], kc_r[cs], actd);
             y[2] = pgv_bwd_apply(y[2], av.z, ka_r[cs], kb_r[cs], kc_r[cs], actd);
@@ -339,6 +349,8 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 3 : 2) vo
             }
         }
       }
+    }
+    if (c0 + CH < CS) fetch_a(c0 + CH);   // (the first half's activations have been consumed)
     }
   }
   if constexpr (FUSE) {  // class sums / bias gradient of the lower block: one float atomic per value per workgroup
