@@ -289,6 +289,12 @@ int pgv_dropout_bwd(const uint64_t* saved_state, uint64_t stream_id, float p, in
                     void* stream);
 /* pgv_dropout_bwd over a [M][N] gradient plus colsum[n] (+)= sum_m gx[m][n] in the same pass - the bias gradient of the
  * nn.Linear whose output the Dropout follows (decoder.py:64-65).  PGV_PREZEROED: colsum already holds zeros. */
+/* pgv_dropout_bwd (gx = g_d * regenerated mask, [B][C][HW]) and pgv_bn_bwd_reduce over gx against the saved activation a
+ * (red[0:C] += sum gx, red[C:2C] += sum gx * a_hat) as ONE pass: the Dropout in front of the encoder's Linear sits on
+ * top of the last conv block's BatchNorm, whose backward needs these projections first. */
+int pgv_dropout_bwd_bn_reduce(const uint64_t* saved_state, uint64_t stream_id, float p, const float* g_d, const float* a,
+                              const float* mean, const float* rstd, int B, int C, int HW, float* gx, double* red, int flags,
+                              void* stream);
 int pgv_dropout_bwd_colsum(const uint64_t* saved_state, uint64_t stream_id, float p, int M, int N, const float* gy,
                            float* gx, float* colsum, int flags, void* stream);
 /* eps ~ N(0,1) i.i.d. (VAE.py:54-55). */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "pgv_dropout_fwd": (c_int, [_P, c_uint64, c_float, _P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P]),
     "pgv_dropout_fwd_bn": (c_int, [_P, c_uint64, c_float, _P, c_int64, c_int, c_int64, _BN, _P, _P, _P]),
     "pgv_dropout_bwd": (c_int, [_P, c_uint64, c_float, c_int64, _P, _P, _P]),
+    "pgv_dropout_bwd_bn_reduce": (c_int, [_P, c_uint64, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pgv_dropout_bwd_colsum": (c_int, [_P, c_uint64, c_float, c_int, c_int, _P, _P, _P, c_int, _P]),
     "pgv_normal": (c_int, [_P, c_uint64, c_int64, _P, _P]),
     "pgv_rng_advance": (c_int, [_P, c_uint64, _P]),

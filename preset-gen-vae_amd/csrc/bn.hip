@@ -7,6 +7,7 @@
 // most one write per element.
 #include "conv_kernels.h"
 #include "bn_taps.h"
+#include "philox.h"
 
 namespace {
 
@@ -342,6 +343,61 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g_o, const float*
       },
       [&](int64_t off) {
         const float g0 = g_o[off];
+        s0 += (double)g0;
+        d0 += (double)(g0 * ((a[off] - mu) * rs));
+      });
+  const double s = pgv_block_sum_d(s0, red);
+  const double dd = pgv_block_sum_d(d0, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&red_out[c], s);
+    atomicAdd(&red_out[C + c], dd);
+  }
+}
+
+// bn_bwd_reduce_kernel over g = (Dropout backward of g_d): the mask is regenerated here (pgv_dropout_bwd), g is written
+// to gx on the way - the Dropout backward pass behind the encoder's Linear and the reduce pass of the top conv block's
+// BatchNorm backward as ONE pass over the gradient (read g_d, a; write gx) instead of two (read g_d, write gx; read gx, a).
+// The 16-byte groups of a plane whose size is not a multiple of 4 start at any element index: a group then takes its
+// masks from two Philox blocks.
+__global__ void dropout_bwd_bn_reduce_kernel(const uint64_t* __restrict__ saved, uint64_t stream_id, float p,
+                                             float keep_scale, const float* __restrict__ g_d,
+                                             const float* __restrict__ a, const float* __restrict__ mean,
+                                             const float* __restrict__ rstd, int B, int C, int HW, int per,
+                                             float* __restrict__ gx, double* __restrict__ red_out) {
+  __shared__ double red[16];
+  const uint64_t seed = saved[0], off0 = saved[1];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float mu = mean[c], rs = rstd[c];
+  double s0 = 0.0, d0 = 0.0;
+  for_each_in_channel2<4>(
+      b0, b1, C, c, HW, g_d, a,
+      [&](int64_t off, const f4u& gd, const f4u& v) {
+        const int r = (int)(off & 3);
+        float m0[4], m1[4];
+        dropout_mask4(off0, (uint64_t)(off >> 2), stream_id, seed, p, keep_scale, m0);
+        if (r) dropout_mask4(off0, (uint64_t)(off >> 2) + 1, stream_id, seed, p, keep_scale, m1);
+        float m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // element off + k: component (r + k) & 3 of block (r + k) >> 2
+          const int e = r + k;
+          const float lo = (e & 3) == 0 ? m0[0] : ((e & 3) == 1 ? m0[1] : ((e & 3) == 2 ? m0[2] : m0[3]));
+          const float hi = (e & 3) == 0 ? m1[0] : ((e & 3) == 1 ? m1[1] : ((e & 3) == 2 ? m1[2] : m1[3]));
+          m[k] = (r && e >= 4) ? hi : lo;
+        }
+        f4u g;
+        g.x = gd.x * m[0], g.y = gd.y * m[1], g.z = gd.z * m[2], g.w = gd.w * m[3];
+        *reinterpret_cast<f4u*>(gx + off) = g;
+        const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+        s0 += (double)((g.x + g.y) + (g.z + g.w));
+        d0 += (double)fmaf(g.x, h0, fmaf(g.y, h1, fmaf(g.z, h2, g.w * h3)));
+      },
+      [&](int64_t off) {
+        float m[4];
+        dropout_mask4(off0, (uint64_t)(off >> 2), stream_id, seed, p, keep_scale, m);
+        const int k = (int)(off & 3);
+        const float g0 = g_d[off] * (k == 0 ? m[0] : (k == 1 ? m[1] : (k == 2 ? m[2] : m[3])));
+        gx[off] = g0;
         s0 += (double)g0;
         d0 += (double)(g0 * ((a[off] - mu) * rs));
       });
@@ -980,6 +1036,24 @@ int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, g_o, a, mean, rstd, B, C, HW, s.per,
                      red);
   PGV_CHECK_LAUNCH("bn_bwd_reduce");
+  return PGV_OK;
+}
+
+int pgv_dropout_bwd_bn_reduce(const uint64_t* saved_state, uint64_t stream_id, float p, const float* g_d, const float* a,
+                              const float* mean, const float* rstd, int B, int C, int HW, float* gx, double* red, int flags,
+                              void* stream) {
+  PGV_CHECK_ARG(saved_state && g_d && a && mean && rstd && gx && red && B >= 0 && C > 0 && HW > 0 && p >= 0.f && p < 1.f,
+                "pgv_dropout_bwd_bn_reduce: bad argument");
+  hipStream_t st = pgv_stream(stream);
+  if (!(flags & PGV_PREZEROED)) {
+    int rc = zero_async(red, sizeof(double) * 2 * C, st, "pgv_dropout_bwd_bn_reduce");
+    if (rc) return rc;
+  }
+  if (B == 0) return PGV_OK;
+  Split s = pick_split(B, C, HW);
+  hipLaunchKernelGGL(dropout_bwd_bn_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, saved_state, stream_id, p,
+                     1.0f / (1.0f - p), g_d, a, mean, rstd, B, C, HW, s.per, gx, red);
+  PGV_CHECK_LAUNCH("dropout_bwd_bn_reduce");
   return PGV_OK;
 }
 

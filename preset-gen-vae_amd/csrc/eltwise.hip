@@ -4,6 +4,7 @@
 // All are HBM-bound streaming kernels: 16 B per lane where alignment allows, grid capped at 2048 blocks with a
 // grid-stride loop, one atomic per block for reductions.
 #include "pgv_common.h"
+#include "philox.h"
 
 namespace {
 
@@ -12,30 +13,6 @@ inline unsigned grid_for(int64_t n, int per_thread = 4) {
   int64_t blocks = pgv_cdiv(n, (int64_t)kBlock * per_thread);
   return (unsigned)max((int64_t)1, min((int64_t)2048, blocks));
 }
-
-// ---- Philox4x32-10 -------------------------------------------------------------------------------------
-struct U4 {
-  uint32_t x, y, z, w;
-};
-__device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id, uint64_t key) {
-  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = (uint32_t)stream_id,
-           c3 = (uint32_t)(stream_id >> 32);
-  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
-                   n3 = (uint32_t)p0;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return U4{c0, c1, c2, c3};
-}
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
 __global__ void dropout_mask_kernel(const uint64_t* __restrict__ rng, uint64_t stream_id, float p, float keep_scale,
                                     int64_t n, float* __restrict__ mask) {

@@ -268,8 +268,9 @@ class ConvStackFn(torch.autograd.Function):
             if g_out is None and not fused_sq:
                 return (None,) * (6 + len(params))
         g_o = g_out.contiguous() if g_out is not None else None
-        if ctx.drop is not None and g_o is not None:
-            g_o = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o)
+        # (nn.Dropout on the stack's output: its backward pass is the first thing to happen to g_out - as a pass of its
+        # own, or, when the top block has a train-mode BatchNorm, inside that block's reduce pass below)
+        drop_pending = ctx.drop is not None and g_o is not None
         dev = saved[-1][3].device
         nb = len(blocks)
         B = saved[-1][3].shape[0]
@@ -334,10 +335,18 @@ class ConvStackFn(torch.autograd.Function):
                 g_y, g_y_fused = g_y_fused, None
             else:
                 red = ggamma = gbeta = None
+                if drop_pending and not (has_bn and mean is not None):
+                    g_o = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o)
+                    drop_pending = False
                 if has_bn and mean is not None:
                     red = arena[a_off:a_off + 2 * C]
                     a_off += 2 * C
-                    ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
+                    if drop_pending:   # Dropout backward + BatchNorm-backward reduce as one pass over the gradient
+                        g_o = ops.dropout_bwd_bn_reduce(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o.reshape(a.shape), a,
+                                                        mean, rstd, red, prezeroed=True)
+                        drop_pending = False
+                    else:
+                        ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
                     ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
                     gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
                 # (eval-mode BN: gamma/beta gradients are not produced)

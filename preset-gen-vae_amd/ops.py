@@ -465,6 +465,20 @@ def dropout_fwd(rng_state, stream_id, p, x, scale=None, shift=None, in_bn=None):
     return y, saved
 
 
+def dropout_bwd_bn_reduce(saved_state, stream_id, p, g_d, a, mean, rstd, red, prezeroed=False):
+    """``dropout_bwd`` of ``g_d`` (shaped like ``a``: [B, C, H, W]) plus ``bn_bwd_reduce`` of the result against ``a`` in the
+    same pass (``pgv_dropout_bwd_bn_reduce``): returns gx, accumulates ``red``."""
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(g_d, a, mean, rstd)
+    _chk64(red)
+    gx = torch.empty_like(a)
+    _lib.check(_lib.load().pgv_dropout_bwd_bn_reduce(saved_state.data_ptr(), stream_id, p, _p(g_d), _p(a), _p(mean),
+                                                     _p(rstd), B, C, HW, _p(gx), _p(red), int(prezeroed), _stream()),
+               "pgv_dropout_bwd_bn_reduce")
+    return gx
+
+
 def dropout_bwd(saved_state, stream_id, p, gy, colsum=None, prezeroed=False):
     """gx = gy * mask (regenerated); ``colsum`` ([N], gy is [M, N]): also colsum (+)= gx.sum(0) in the same pass
     (``pgv_dropout_bwd_colsum``; ``prezeroed``: it already holds zeros)."""

@@ -965,6 +965,15 @@ def test_rng_distributions(ops):
         rng_d.dropout_mask(0.3, (1000,))                               # the generator moves on
         g = torch.randn(*shape, device='cuda')
         assert torch.equal(ops.dropout_bwd(saved, 2, 0.3, g), g * mr)
+        if affine:   # ... with the BatchNorm-backward projections of the result against a saved activation on the way
+            a_s = torch.randn(*shape, device='cuda')
+            mu_c, rs_c = torch.randn(shape[1], device='cuda') * 0.1, torch.rand(shape[1], device='cuda') + 0.5
+            red = torch.zeros(2 * shape[1], device='cuda', dtype=torch.float64)
+            gx = ops.dropout_bwd_bn_reduce(saved, 2, 0.3, g, a_s, mu_c, rs_c, red, prezeroed=True)
+            ref_red = torch.zeros_like(red)
+            ops.bn_bwd_reduce(g * mr, a_s, mu_c, rs_c, ref_red, prezeroed=True)
+            assert torch.equal(gx, g * mr)
+            assert (red - ref_red).abs().max().item() <= 1e-6 * (g * mr).abs().sum().item()
         if len(shape) == 2 or shape[0] == 256:   # ... with the column sums of the result (the Linear bias gradient)
             g2, m2 = g.reshape(shape[0], -1), mr.reshape(shape[0], -1)
             cs = torch.full((g2.shape[1],), 0.5, device='cuda')
