@@ -125,21 +125,23 @@ __device__ __forceinline__ s16x4 pack4(f32x4 v) {
 }
 
 constexpr int FK = 32;                 // K slab
-constexpr int kGemmDepth = 4;          // slabs in flight per workgroup
-constexpr int KROW = FK + 4;           // row stride of a k-contiguous tile [64][KROW]
-constexpr int MROW_A = 64 + 16;        // row stride of an m-contiguous A tile [FK][MROW_A]
-constexpr int NROW_B = 64 + 4;         // row stride of an n-contiguous B tile [FK][NROW_B]
+constexpr int KROW = FK + 4;           // row stride of a k-contiguous tile [T][KROW]
+// (m-contiguous A tile: [FK][TM + 16]; n-contiguous B tile: [FK][TN + 4])
 
-template <bool A_K, bool B_K, bool BF16, int DEPTH>
-__global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, const float* __restrict__ A, int64_t lda,
-                                                        const float* __restrict__ Bm, int64_t ldb,
-                                                        float* __restrict__ C, int64_t ldc,
-                                                        const float* __restrict__ bias_n, int k_per_split, int nsplit,
-                                                        int atomic) {
-  constexpr int A_FLOATS = A_K ? 64 * KROW : FK * MROW_A;
-  constexpr int B_FLOATS = B_K ? 64 * KROW : FK * NROW_B;
+// TM x TN tile per workgroup (64 or 128 each): four waves in 2 x 2, a wave owns a (TM/2) x (TN/2) quarter = NIM x NIN MFMA
+// tiles.  128-wide tiles halve the reads of the operand they span (the z = 512 products moved 805 MB from L2 to LDS at
+// 64 x 64 for 125 MB of operands); DEPTH slabs in flight in registers (4 at 64 x 64, 2 beyond: 8 floats4 per slab).
+template <bool A_K, bool B_K, bool BF16, int TM, int TN, int DEPTH>
+__global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel(
+    int M, int N, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+    float* __restrict__ C, int64_t ldc, const float* __restrict__ bias_n, int k_per_split, int nsplit, int atomic) {
+  constexpr int MROW_A = TM + 16, NROW_B = TN + 4;
+  constexpr int A_FLOATS = A_K ? TM * KROW : FK * MROW_A;
+  constexpr int B_FLOATS = B_K ? TN * KROW : FK * NROW_B;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int LA = TM / 32, LB = TN / 32;   // float4 per thread per slab and operand
+  constexpr int WM = TM / 2, WN = TN / 2, NIM = WM / 16, NIN = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
   // Workgroup -> (m tile, n tile, K split).  Workgroups L, L + 8, L + 16, ... share an XCD and its L2 (round-robin
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
   // panel when K is not split - are given to one XCD, next to each other in time, so that slice is fetched from HBM once
   // and not once per tile (with n tiles fastest, as a plain 3-D grid has them: 100 MB of fabric reads for the 38 MB of
   // the encoder's Linear forward).
-  const int Mt = M >> 6, Nt = N >> 6;
+  const int Mt = M / TM, Nt = N / TN;
   int mt, nt, zs;
   {
     const int L = blockIdx.x, inner = nsplit > 1 ? Mt * Nt : Mt, outer = nsplit > 1 ? nsplit : Nt;
@@ -161,30 +163,34 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
     if (nsplit > 1) mt = in_i / Nt, nt = in_i - mt * Nt, zs = out_i;
     else mt = in_i, nt = out_i, zs = 0;
   }
-  const int m0 = mt * 64, n0 = nt * 64;
+  const int m0 = mt * TM, n0 = nt * TN;
   const int kbeg = zs * k_per_split, kend = min(K, kbeg + k_per_split);
 
-  // loaders: 512 float4 per operand per slab, two per thread
-  int64_t a_src[2], b_src[2];
-  int a_dst[2], b_dst[2];
+  // loaders: T * 8 float4 per operand per slab
+  int64_t a_src[LA], b_src[LB];
+  int a_dst[LA], b_dst[LB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LA; ++i) {
     const int q = tid + 256 * i;
     if (A_K) {  // A[m0 + r][k + 4f]: 8 float4 per row
       const int r = q >> 3, f = q & 7;
       a_src[i] = (int64_t)(m0 + r) * lda + 4 * f;
       a_dst[i] = r * KROW + 4 * f;
-    } else {    // A stored [k][m]: A(m,k) = A[k*lda + m]; 16 float4 per k row
-      const int r = q >> 4, f = q & 15;
+    } else {    // A stored [k][m]: A(m,k) = A[k*lda + m]; TM / 4 float4 per k row
+      const int r = q / (TM / 4), f = q % (TM / 4);
       a_src[i] = (int64_t)r * lda + m0 + 4 * f;
       a_dst[i] = r * MROW_A + 4 * f;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int q = tid + 256 * i;
     if (B_K) {  // B(k,n) = B[n*ldb + k]
       const int r = q >> 3, f = q & 7;
       b_src[i] = (int64_t)(n0 + r) * ldb + 4 * f;
       b_dst[i] = r * KROW + 4 * f;
     } else {    // B[k*ldb + n]
-      const int r = q >> 4, f = q & 15;
+      const int r = q / (TN / 4), f = q % (TN / 4);
       b_src[i] = (int64_t)r * ldb + n0 + 4 * f;
       b_dst[i] = r * NROW_B + 4 * f;
     }
@@ -192,29 +198,29 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
   // DEPTH slabs in flight in registers ahead of the one being multiplied: these products are short-K or split-K with a
   // few slabs per workgroup, and one slab ahead left every workgroup waiting a memory latency per slab (all six Linear
   // products of the step took ~22 us whatever their size)
-  f32x4 ra[DEPTH][2], rb[DEPTH][2];
+  f32x4 ra[DEPTH][LA], rb[DEPTH][LB];
   auto issue = [&](int slot, int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LA; ++i)
       ra[slot][i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + (A_K ? (int64_t)k0 : (int64_t)k0 * lda));
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
       rb[slot][i] = *reinterpret_cast<const f32x4*>(Bm + b_src[i] + (B_K ? (int64_t)k0 : (int64_t)k0 * ldb));
-    }
   };
   auto commit = [&](int slot, float* st) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[slot][i];
-      *reinterpret_cast<f32x4*>(st + A_FLOATS + b_dst[i]) = rb[slot][i];
-    }
-  };
-  // a wave owns a 32x32 quarter of the tile (2x2 MFMA tiles): 8 LDS fragment reads per 16 k against 20 for a 16x64
-  // strip - at 64x64 per workgroup the strip layout moved 80 KB of fragments per slab, 3/4 of the LDS rate at MFMA speed
-  const int wm = wave >> 1, wn = wave & 1;
-  const int a_frag = A_K ? (wm * 32 + m) * KROW + 4 * j : 4 * j * MROW_A + wm * 32 + m;
-  const int b_frag = B_K ? (wn * 32 + m) * KROW + 4 * j : 4 * j * NROW_B + wn * 32 + m;
-  f32x4 acc[4];   // [im][in]
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[slot][i];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4*>(st + A_FLOATS + b_dst[i]) = rb[slot][i];
+  };
+  // a wave owns a quarter of the tile (NIM x NIN MFMA tiles): at 64 x 64, 8 LDS fragment reads per 16 k against 20 for a
+  // 16 x 64 strip (the strip layout moved 80 KB of fragments per slab, 3/4 of the LDS rate at MFMA speed)
+  const int wm = wave >> 1, wn = wave & 1;
+  const int a_frag = A_K ? (wm * WM + m) * KROW + 4 * j : 4 * j * MROW_A + wm * WM + m;
+  const int b_frag = B_K ? (wn * WN + m) * KROW + 4 * j : 4 * j * NROW_B + wn * WN + m;
+  f32x4 acc[NIM * NIN];   // [im][in]
+#pragma unroll
+  for (int t = 0; t < NIM * NIN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kbeg < kend) {
 #pragma unroll
@@ -235,15 +241,18 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
       const float* bp = st + A_FLOATS + b_frag;
 #pragma unroll
       for (int g = 0; g < FK / 16; ++g) {
-        f32x4 a[2], b[2];
+        f32x4 a[NIM], b[NIN];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NIM; ++h) {
           if (A_K) {
             a[h] = *reinterpret_cast<const f32x4*>(ap + 16 * h * KROW + 16 * g);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[h][e] = ap[(16 * g + e) * MROW_A + 16 * h];
           }
+        }
+#pragma unroll
+        for (int h = 0; h < NIN; ++h) {
           if (B_K) {
             b[h] = *reinterpret_cast<const f32x4*>(bp + 16 * h * KROW + 16 * g);
           } else {
@@ -252,17 +261,22 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
           }
         }
         if constexpr (BF16) {
+          s16x4 ap4[NIM], bp4[NIN];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(a[t >> 1]), pack4(b[t & 1]), acc[t], 0, 0, 0);
+          for (int h = 0; h < NIM; ++h) ap4[h] = pack4(a[h]);
+#pragma unroll
+          for (int h = 0; h < NIN; ++h) bp4[h] = pack4(b[h]);
+#pragma unroll
+          for (int t = 0; t < NIM * NIN; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap4[t / NIN], bp4[t % NIN], acc[t], 0, 0, 0);
         } else {
-          // round-robin over the four accumulators: v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a
+          // round-robin over the accumulators: v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a
           // dependent one only after 40
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t >> 1][e], b[t & 1][e], acc[t], 0, 0, 0);
+            for (int t = 0; t < NIM * NIN; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t / NIN][e], b[t % NIN][e], acc[t], 0, 0, 0);
         }
       }
       if (more) commit((u + 1) % DEPTH, lds + (stage ^ 1) * STAGE);
@@ -271,56 +285,86 @@ __global__ __launch_bounds__(256, 3) void gemm_fast_kernel(int M, int N, int K, 
     }
     }
   }
-  // acc[2 im + in][i]: row 32 wm + 16 im + 4j + i, column 32 wn + 16 in + m of the tile.  Out through LDS (the staging
+  // acc[NIN im + in][i]: row WM wm + 16 im + 4j + i, column WN wn + 16 in + m of the tile.  Out through LDS (the staging
   // buffers are free: the K loop ended with a barrier) so that a wave instruction covers whole 128-byte lines of C:
   // 64 consecutive floats per atomic instruction (the split-K products spend a third of their time in these atomics:
   // with 4 half-lines per instruction, as the accumulator layout gives them, ~8 us; laid out 16 quarter-lines wide 35 us),
   // 16 bytes per lane for plain stores.
-  constexpr int TROW = 64 + 4;
-  static_assert(64 * TROW <= 2 * STAGE, "epilogue tile fits in the staging buffers");
+  constexpr int TROW = TN + 4;
+  static_assert(TM * TROW <= 2 * STAGE, "epilogue tile fits in the staging buffers");
   float* tile = lds;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NIM * NIN; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      tile[(32 * wm + 16 * (t >> 1) + 4 * j + i) * TROW + 32 * wn + 16 * (t & 1) + m] = acc[t][i];
+      tile[(WM * wm + 16 * (t / NIN) + 4 * j + i) * TROW + WN * wn + 16 * (t % NIN) + m] = acc[t][i];
   __syncthreads();
   // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
   const bool with_bias = (!atomic || (atomic == 2 && zs == 0)) && bias_n;
   if (atomic) {
-    const int col = tid & 63;
+    constexpr int RPP = 256 / TN;   // rows per pass
+    const int col = tid % TN;
     const float bias = with_bias ? bias_n[n0 + col] : 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int row = (tid >> 6) + 4 * k;
+#pragma unroll 4
+    for (int k = 0; k < TM / RPP; ++k) {
+      const int row = tid / TN + RPP * k;
       atomicAdd(C + (int64_t)(m0 + row) * ldc + n0 + col, tile[row * TROW + col] + bias);
     }
   } else {
-    const int c4 = (tid & 15) * 4;
+    constexpr int QPR = TN / 4, RPP = 256 / QPR;   // 16-byte groups per row, rows per pass
+    const int c4 = (tid % QPR) * 4;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (with_bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) bias[i] = bias_n[n0 + c4 + i];
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = (tid >> 4) + 16 * k;
+#pragma unroll 4
+    for (int k = 0; k < TM / RPP; ++k) {
+      const int row = tid / QPR + RPP * k;
       *reinterpret_cast<f32x4*>(C + (int64_t)(m0 + row) * ldc + n0 + c4) =
           *reinterpret_cast<const f32x4*>(tile + row * TROW + c4) + bias;
     }
   }
 }
 
+template <bool A_K, bool B_K, bool BF16, int TM, int TN>
+int launch_tile(int nsplit, hipStream_t st, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
+  constexpr int DEPTH = (TM + TN > 128) ? 2 : 4;
+  constexpr int A_FLOATS = A_K ? TM * KROW : FK * (TM + 16), B_FLOATS = B_K ? TN * KROW : FK * (TN + 4);
+  constexpr size_t bytes = sizeof(float) * 2 * (A_FLOATS + B_FLOATS);
+  auto kern = gemm_fast_kernel<A_K, B_K, BF16, TM, TN, DEPTH>;
+  if (bytes > 48 * 1024) {   // (above the default dynamic-LDS limit: raised once per kernel)
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        pgv_set_error("pgv_gemm: cannot raise the dynamic LDS limit");
+        return PGV_E_LAUNCH;
+      }
+      raised = true;
+    }
+  }
+  const dim3 grid((unsigned)((M / TM) * (N / TN) * nsplit));
+  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, nsplit, atomic);
+  return PGV_OK;
+}
+
 template <bool A_K, bool B_K>
-void launch_fast(int nsplit, hipStream_t st, int bf16, int M, int N, int K, const float* A, int64_t lda, const float* B,
-                 int64_t ldb, float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
-  const dim3 grid((unsigned)((M / 64) * (N / 64) * nsplit));
-  if (bf16)
-    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, true, kGemmDepth>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C,
-                       ldc, bias_n, k_per_split, nsplit, atomic);
-  else
-    hipLaunchKernelGGL((gemm_fast_kernel<A_K, B_K, false, kGemmDepth>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C,
-                       ldc, bias_n, k_per_split, nsplit, atomic);
+int launch_fast(int tm, int tn, int nsplit, hipStream_t st, int bf16, int M, int N, int K, const float* A, int64_t lda,
+                const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
+#define PGV_GT(BF, TMv, TNv) \
+  return launch_tile<A_K, B_K, BF, TMv, TNv>(nsplit, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic)
+  if (bf16) {
+    if (tm == 128 && tn == 128) PGV_GT(true, 128, 128);
+    if (tm == 128) PGV_GT(true, 128, 64);
+    if (tn == 128) PGV_GT(true, 64, 128);
+    PGV_GT(true, 64, 64);
+  }
+  if (tm == 128 && tn == 128) PGV_GT(false, 128, 128);
+  if (tm == 128) PGV_GT(false, 128, 64);
+  if (tn == 128) PGV_GT(false, 64, 128);
+  PGV_GT(false, 64, 64);
+#undef PGV_GT
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -343,8 +387,16 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
     const int64_t lda = a_k ? sam : sak, ldb = b_k ? sbn : sbk;
     if (pgv_kernel_policy() == 0 && (a_k || a_m) && (b_k || b_n) && M % 64 == 0 && N % 64 == 0 && K % FK == 0 && K > 0 && lda % 4 == 0 &&
         ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C)) {
-      const int tiles = (M / 64) * (N / 64);
-      int splits = (int)max((int64_t)1, min(pgv_cdiv(768, tiles), (int64_t)K / (FK * 4)));
+      // tile edges: 128 where the extent allows it and enough tiles remain to fill the chip (with the K splits)
+      // 128-wide tile edges where the extent divides: in bf16 operand mode only - there the products are bound by the
+      // operand traffic between L2 and LDS, which a 128-wide tile halves (z = 512, six products of the step: 405 -> 348 us;
+      // z = 64: 125 -> 121); on the fp32 matrix pipe they are MFMA-bound and the larger workgroups only lose to wave
+      // quantisation (z = 512: 625 -> 670 us, z = 64: no change)
+      const bool big_ok = (flags & PGV_COMPUTE_BF16) != 0;
+      const int tm = (big_ok && M % 128 == 0 && M >= 256) ? 128 : 64, tn = (big_ok && N % 128 == 0 && N >= 256) ? 128 : 64;
+      const int tiles = (M / tm) * (N / tn);
+      const int target = (tm + tn > 128) ? 512 : 768;   // workgroups that fit at once (2 / 3 per CU)
+      int splits = (int)max((int64_t)1, min(pgv_cdiv(target, tiles), (int64_t)K / (FK * 4)));
       int k_per_split_v = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
       splits = (int)pgv_cdiv(K, k_per_split_v);
       if (splits > 8 && (splits & 7)) {   // a multiple of 8 splits: one XCD per K slice (see the kernel)
@@ -359,14 +411,16 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
         PGV_CHECK_LAUNCH("gemm_init_c");
       }
       const int bf16 = (flags & PGV_COMPUTE_BF16) ? 1 : 0;
+      int rc;
       if (a_k && b_k)
-        launch_fast<true, true>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        rc = launch_fast<true, true>(tm, tn, splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else if (a_k)
-        launch_fast<true, false>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        rc = launch_fast<true, false>(tm, tn, splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else if (b_k)
-        launch_fast<false, true>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        rc = launch_fast<false, true>(tm, tn, splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
       else
-        launch_fast<false, false>(splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+        rc = launch_fast<false, false>(tm, tn, splits, st, bf16, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic);
+      if (rc) return rc;
       PGV_CHECK_LAUNCH("gemm_fast");
       return PGV_OK;
     }

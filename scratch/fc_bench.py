@@ -4,11 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from preset_gen_vae_amd import ops, _lib
 B = 256
+import os
+if os.environ.get('FC_BF16'):
+    ops.set_compute_dtype('bf16')
 for dz in (64, 512):
-    x = torch.randn(B, 24576, device='cuda'); We = torch.randn(2 * dz, 24576, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
+    x = torch.randn(B, 25024, device='cuda'); We = torch.randn(2 * dz, 25024, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
     gye = torch.randn(B, 2 * dz, device='cuda'); gWe = torch.empty_like(We)
-    z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(24576, dz, device='cuda') * 0.01; bd = torch.zeros(24576, device='cuda')
-    gyd = torch.randn(B, 24576, device='cuda'); gWd = torch.empty_like(Wd)
+    z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(25024, dz, device='cuda') * 0.01; bd = torch.zeros(25024, device='cuda')
+    gyd = torch.randn(B, 25024, device='cuda'); gWd = torch.empty_like(Wd)
     for pol in (0, 1):
         _lib.load().pgv_set_kernel_policy(pol)
         ts = [bench.time_kernel(f, iters=5) * 1e3 for f in (
