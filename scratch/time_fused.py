@@ -49,6 +49,8 @@ def main():
         nbytes = lambda *ts: sum(t.numel() * 4 for t in ts)
         rows = [('dgrad plain', lambda: conv(geom, gy, w, None, 0, 0.0, out=out), nbytes(gy, out)),
                 ('dgrad fused', lambda: conv(geom, gy, w, None, 0, 0.0, out=out, bwd_fuse=fuse), nbytes(gy, out, a)),
+                ('dgrad fused + class sums', lambda: conv(geom, gy, w, None, 0, 0.0, out=out,
+                                                          bwd_fuse=fuse + (torch.zeros(4 * C, device=dev),)), nbytes(gy, out, a)),
                 ('act_bwd_coef pass', lambda: ops.act_bwd_coef(out, a, coef, 1, 0.1, out, gb, prezeroed=True), nbytes(out, out, a)),
                 ('class_sums', lambda: ops.conv_class_sums(geom, gy, up, cls, prezeroed=True), nbytes(gy)),
                 ('tap_sums border', lambda: ops.conv_tap_sums(geom, gy, up, T, prezeroed=True, cls=cls), 0),
