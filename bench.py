@@ -216,7 +216,7 @@ def launch_table(ae, B, device, frontend=None):
                 lg = ops.ConvGeom(*lower[1])
                 if lg.Hs * lg.Ws < layer_mod.PASSFREE_MIN_PLANE:
                     lower2 = None
-            cls_lo = torch.zeros(4 * Cl, device=device) if (is_up and lower2 is not None) else None
+            cls_lo = torch.zeros(ops.CLS_COPIES * 4 * Cl, device=device) if (is_up and lower2 is not None) else None
             fuse = (a_lo, coef, gb_lo, 1, 0.1, cls_lo)
 
         # the producer's train-mode BatchNorm is finalized in this block's forward kernel (ops.bn_src: statistics of a
@@ -235,7 +235,8 @@ def launch_table(ae, B, device, frontend=None):
             Cl, gy_t = lo.shape[1], (big if is_up else small)
             m_ = s if is_up else 1
             one4 = [torch.ones(Cl, device=device) for _ in range(4)]
-            coef_req = dict(lower_is_big=not is_up, cls=torch.zeros(gy_t.shape[1] * m_ * m_, device=device), w=w,
+            coef_req = dict(lower_is_big=not is_up,
+                            cls=torch.zeros(gy_t.shape[1] * m_ * m_ * (ops.CLS_COPIES if is_up else 1), device=device), w=w,
                             scale=one4[0], shift=one4[1], mean=one4[2], rstd=one4[3], n=lo.numel() // Cl,
                             coef=torch.empty(3 * Cl, device=device), ggamma=torch.empty(Cl, device=device),
                             gbeta=torch.empty(Cl, device=device),
@@ -292,7 +293,7 @@ def launch_table(ae, B, device, frontend=None):
     # output block: criterion + Hardtanh backward in one pass (pgv_sqerr_act_bwd)
     xo, xt, gy = (torch.randn(B, 1, 257, 347, device=device) for _ in range(3))
     gl, gb1 = torch.ones((), device=device), torch.zeros(1, device=device)
-    cls8 = torch.zeros(4, device=device) if fused_bwd else None   # (class sums of g_y for the block below, as in the step)
+    cls8 = torch.zeros(ops.CLS_COPIES * 4, device=device) if fused_bwd else None   # (class sums of g_y for the block below, as in the step)
     table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1,
                                                                     prezeroed=True, cls=cls8),
                   3 * xo.numel() * 4, 0.0))

@@ -90,14 +90,18 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scal
  * coef ([3C] floats) comes from pgv_bn_bwd_coef (train-mode BatchNorm), or is (scale, 0, 0) for an eval-mode
  * BatchNorm and (1, 0, 0) for a block without BatchNorm.  act' is recovered from the saved activated tensor a.
  * Kernel families without the fused epilogue write g and run pgv_act_bwd_coef in place. */
+#define PGV_CLS_COPIES 8
 typedef struct pgv_bwd_fuse {
   const float* a;    /* saved activated output of the lower block, same shape as the output tensor */
   const float* coef; /* [3C] */
   float* gbias;      /* [C], accumulated into; may be NULL */
   int32_t act;       /* activation of the lower block (PGV_ACT_*) */
   float slope;
-  float* cls;        /* optional [C][4]: g_y summed by (row parity, column parity) class, accumulated into - the class
-                        sums pgv_conv_tap_sums wants when g_y is the output gradient of a stride-2 ConvTranspose2d */
+  float* cls;        /* optional: g_y summed by (row parity, column parity) class, cls[copy][c][2 * (row & 1) + (col & 1)],
+                        accumulated into PGV_CLS_COPIES partial copies of [C][4] (the caller clears them; a workgroup
+                        adds into the copy of its XCD - 256 workgroups finishing together on ONE copy serialise on its
+                        addresses, ~80 ns per atomic) that the consumers add up: pgv_conv_tap_sums / pgv_coef_req.cls
+                        with the output gradient of a stride-2 ConvTranspose2d */
 } pgv_bwd_fuse;
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* small, double* stats,
@@ -135,12 +139,15 @@ int pgv_bn_bwd_coef_from_gy(const pgv_conv_desc* d, int lower_is_big, const floa
  * overwritten (flags & PGV_PREZEROED: accumulated into).
  * cls (may be NULL) = the class sums of gy (pgv_conv_class_sums, or the producer's own: for the small tensor simply the
  * per-channel sum, i.e. the bias gradient of the block that owns gy): with them only the few border rows and columns of
- * gy that some tap cannot pair are read, T = class sum - unpaired border positions; without them gy is read in full. */
+ * gy that some tap cannot pair are read, T = class sum - unpaired border positions; without them gy is read in full.
+ * Layout of cls: gy_is_big (m = stride classes per axis) - PGV_CLS_COPIES partial copies of [C][m*m], added up here
+ * (pgv_bwd_fuse.cls; pgv_conv_class_sums fills copy 0); else [C], one copy. */
 int pgv_conv_tap_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
                       void* stream);
 /* cls[c][(r mod m)*m + (w mod m)] = sum over the batch of gy[:,c,r,w], m = stride when gy is the big tensor of d (a tap
  * of a transposed convolution reaches one residue class of rows / columns), m = 1 (plain channel sums) when it is the
- * small one.  cls: [C][m*m] floats, overwritten (flags & PGV_PREZEROED: accumulated into). */
+ * small one.  cls: gy_is_big - [PGV_CLS_COPIES][C][m*m] floats (copy 0 receives the sums, the other copies are cleared),
+ * else [C]; overwritten (flags & PGV_PREZEROED: accumulated into). */
 int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, float* cls, int flags, void* stream);
 /* g_y = act'(a) * (coef[c]*g + coef[C+c]*a + coef[2C+c]), gbias[c] += sum g_y: the unfused form of pgv_bwd_fuse
  * (in place allowed).  gbias may be NULL; flags: PGV_PREZEROED refers to gbias. */
@@ -245,8 +252,8 @@ int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const f
  * provides a zeroed scalar).  flags: PGV_PREZEROED refers to gbias. */
 int pgv_sqerr_act_bwd(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int act,
                       float slope, float* g_y, float* gbias, float* loss_acc, int flags, void* stream);
-/* The same with the class sums of g_y as a by-product (see pgv_bwd_fuse.cls): planes of W columns, cls [C][4] floats
- * accumulated into (the caller clears them); single-channel tensors with planes of >= 16384 elements only (the
+/* The same with the class sums of g_y as a by-product (see pgv_bwd_fuse.cls): planes of W columns, cls
+ * [PGV_CLS_COPIES][C][4] floats accumulated into (the caller clears them); single-channel tensors with planes of >= 16384 elements only (the
  * spectrogram output layer). */
 int pgv_sqerr_act_bwd_cls(const float* a, const float* x, const float* g_loss, float scale, int B, int C, int HW, int W,
                           int act, float slope, float* g_y, float* gbias, float* loss_acc, float* cls, int flags,

@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void tap_border_kernel(const float* __restrict
     if (blockIdx.y == 0 && blockIdx.z == 0) {   // the class total enters once per channel
       const int m = gy_is_big ? s : 1;
       const int rho = gy_is_big ? (((kh - p) % s) + s) % s : 0, kap = gy_is_big ? (((kw - p) % s) + s) % s : 0;
-      t += (double)cls[c * m * m + rho * m + kap];
+      const int ncopy = gy_is_big ? PGV_CLS_COPIES : 1;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls)
+      for (int r = 0; r < ncopy; ++r) t += (double)cls[(r * C + c) * m * m + rho * m + kap];
     }
     atomicAdd(&T[(int64_t)c * KK + tid], t);
   }
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void sqerr_act_bwd_cls_kernel(const float* __r
   const float v6[6] = {c4[0], c4[1], c4[2], c4[3], (c4[0] + c4[1]) + (c4[2] + c4[3]), sq};
   const float r = pgv_block_sums<6>(v6, red6);
   if (threadIdx.x < 4)
-    atomicAdd(&cls[threadIdx.x], r);
+    atomicAdd(&cls[(blockIdx.x & (PGV_CLS_COPIES - 1)) * 4 + threadIdx.x], r);   // (the copy of this workgroup's XCD; C = 1)
   else if (threadIdx.x == 4) {
     if (gbias) atomicAdd(&gbias[0], r);
   } else if (threadIdx.x == 5) {
@@ -1106,7 +1107,7 @@ int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, 
   PGV_CHECK_ARG(m >= 1 && m <= 3, "pgv_conv_class_sums: stride %d not supported", m);
   hipStream_t st = pgv_stream(stream);
   if (!(flags & PGV_PREZEROED)) {
-    int rc = zero_async(cls, sizeof(float) * C * m * m, st, "pgv_conv_class_sums");
+    int rc = zero_async(cls, sizeof(float) * C * m * m * (gy_is_big ? PGV_CLS_COPIES : 1), st, "pgv_conv_class_sums");
     if (rc) return rc;
   }
   if (d->B == 0) return PGV_OK;

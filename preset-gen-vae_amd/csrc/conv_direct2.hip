@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 4 : 2) vo
     // (DPP row reductions + one barrier: 4*CS wave reductions through ds_bpermute took ~10 us at the end of every workgroup)
     float t = pgv_block_sums<4 * CS>(v32, red);
     if (tid < 4 * CS) {
-      if (fuse.cls) atomicAdd(&fuse.cls[tid], t);
+      if (fuse.cls) atomicAdd(&fuse.cls[(blockIdx.x & (PGV_CLS_COPIES - 1)) * 4 * CS + tid], t);   // (partial copy by XCD)
       // bias gradient = the four classes of a channel added up (lanes 4cs .. 4cs+3)
       t += dpp_mov<0xB1>(t);
       t += dpp_mov<0x4E>(t);

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       if constexpr (APRE) {
         if (fuse.cls) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) atomicAdd(&fuse.cls[4 * cl + k], v[1 + k]);
+          for (int k = 0; k < 4; ++k)   // (into the partial copy of this workgroup's XCD: 64 addresses x 256 workgroups on one
+            atomicAdd(&fuse.cls[(blockIdx.x & (PGV_CLS_COPIES - 1)) * 4 * CS + 4 * cl + k], v[1 + k]);   // copy cost 21 us)
         }
       }
     };

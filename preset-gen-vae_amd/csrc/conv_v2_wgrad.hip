@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a)
       if (by == 0 && bz == 0) {   // the class total enters once per channel
         const int m = a.gy_is_big ? a.s : 1;
         const int rho = a.gy_is_big ? (((kh - a.p) % a.s) + a.s) % a.s : 0, kap = a.gy_is_big ? (((kw - a.p) % a.s) + a.s) % a.s : 0;
-        t += (double)a.cls[c * m * m + rho * m + kap];
+        const int ncopy = a.gy_is_big ? PGV_CLS_COPIES : 1;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls)
+        for (int q = 0; q < ncopy; ++q) t += (double)a.cls[(q * a.Cgy + c) * m * m + rho * m + kap];
       }
       atomicAdd(&a.T[(int64_t)(r % a.trep) * a.Cgy * KK + (int64_t)c * KK + tid], t);   // (copies: tap_replicas)
     }

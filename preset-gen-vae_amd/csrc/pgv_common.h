@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/pgv_hip.h"
+static_assert((PGV_CLS_COPIES & (PGV_CLS_COPIES - 1)) == 0, "copy index = workgroup & (copies - 1)");
 
 #define PGV_WAVE 64
 

@@ -320,7 +320,7 @@ class ConvStackFn(torch.autograd.Function):
             return (i > 0 and passfree[i - 1] and blocks[i].up and blocks[i].stride == 2 and
                     blocks[i - 1].bn is not None and saved[i - 1][5] is not None)
 
-        n_cls = sum(4 * blocks[i].c_out for i in range(nb) if wants_cls(i))
+        n_cls = sum(ops.CLS_COPIES * 4 * blocks[i].c_out for i in range(nb) if wants_cls(i))   # (partial copies per XCD)
         cls_arena = _step_zeros(params[0], n_cls, torch.float32, 'cls', dev) if n_cls else None
         c_off = 0
         for li in range(nb - 1, -1, -1):
@@ -356,8 +356,8 @@ class ConvStackFn(torch.autograd.Function):
                 if fused_sq and li == nb - 1:
                     g_y = torch.empty_like(a)
                     if wants_cls(li) and C == 1 and a.shape[2] * a.shape[3] >= 16384:
-                        cls_cur = cls_arena[c_off:c_off + 4]
-                        c_off += 4
+                        cls_cur = cls_arena[c_off:c_off + ops.CLS_COPIES * 4]
+                        c_off += ops.CLS_COPIES * 4
                     ops.sqerr_act_bwd(a, ctx.sq[0], g_loss.contiguous(), ctx.sq[1], blk.act, blk.slope, g_y, gb,
                                       prezeroed=gb_zero, loss_acc=ctx.sq_deferred, cls=cls_cur)
                 else:
@@ -407,8 +407,8 @@ class ConvStackFn(torch.autograd.Function):
                     gb_low.zero_()
                 cls_low = None
                 if wants_cls(li - 1):
-                    cls_low = cls_arena[c_off:c_off + 4 * Cl]
-                    c_off += 4 * Cl
+                    cls_low = cls_arena[c_off:c_off + ops.CLS_COPIES * 4 * Cl]
+                    c_off += ops.CLS_COPIES * 4 * Cl
                 fuse = (a_low, coef, gb_low, low.act, low.slope, cls_low)
             if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
                 ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero,

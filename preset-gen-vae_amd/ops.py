@@ -39,6 +39,7 @@ def _p(t):
 
 
 PGV_PREZEROED, PGV_COMPUTE_BF16 = 1, 2
+CLS_COPIES = 8   # PGV_CLS_COPIES: class sums (pgv_bwd_fuse.cls) are kept as this many partial copies, one per XCD
 _COMPUTE_FLAGS = 0
 
 
@@ -91,8 +92,8 @@ def _fuse_arg(bwd_fuse, out):
         raise ValueError("bwd_fuse: saved activation and output shapes differ")
     if coef.numel() != 3 * a.shape[1] or (gbias is not None and gbias.numel() != a.shape[1]):
         raise ValueError("bwd_fuse: coef must hold 3*C floats and gbias C floats")
-    if cls is not None and cls.numel() != 4 * a.shape[1]:
-        raise ValueError("bwd_fuse: cls must hold 4*C floats")
+    if cls is not None and cls.numel() != CLS_COPIES * 4 * a.shape[1]:
+        raise ValueError("bwd_fuse: cls must hold CLS_COPIES * 4 * C floats")
     return _lib.BwdFuse(_p(a), _p(coef), _p(gbias), int(act), float(slope), _p(cls))
 
 
@@ -291,8 +292,8 @@ def conv_tap_sums(geom, gy, gy_is_big, T=None, prezeroed=False, cls=None):
     _chk(gy, cls)
     _chk64(T)
     m = geom.stride if gy_is_big else 1
-    if cls is not None and cls.numel() != C * m * m:
-        raise ValueError("conv_tap_sums: cls must hold C * m * m floats")
+    if cls is not None and cls.numel() != C * m * m * (CLS_COPIES if gy_is_big else 1):
+        raise ValueError("conv_tap_sums: cls must hold [CLS_COPIES,] C * m * m floats")
     _lib.check(_lib.load().pgv_conv_tap_sums(ctypes.byref(geom.desc(B)), int(gy_is_big), _p(gy), _p(cls), _p(T),
                                              PGV_PREZEROED if prezeroed else 0, _stream()), "pgv_conv_tap_sums")
     return T
@@ -305,7 +306,7 @@ def conv_class_sums(geom, gy, gy_is_big, cls=None, prezeroed=False):
     C = geom.Cb if gy_is_big else geom.Cs
     m = geom.stride if gy_is_big else 1
     if cls is None:
-        cls = torch.empty(C * m * m, device=gy.device, dtype=torch.float32)
+        cls = torch.empty(C * m * m * (CLS_COPIES if gy_is_big else 1), device=gy.device, dtype=torch.float32)
         prezeroed = False
     _chk(gy, cls)
     _lib.check(_lib.load().pgv_conv_class_sums(ctypes.byref(geom.desc(B)), int(gy_is_big), _p(gy), _p(cls),
@@ -373,7 +374,8 @@ def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=No
 def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, loss_acc=None, cls=None):
     """g_y = act'(a) * 2 scale g_loss (a - x), gbias += sum over (batch, pixels): squared-error criterion + output
     activation of a block without BatchNorm, backward in one pass.  ``loss_acc`` (zeroed scalar) += the criterion.
-    ``cls`` (zeroed [4], single-channel tensors): += the sums of g_y by (row parity, column parity) class."""
+    ``cls`` (zeroed [CLS_COPIES * 4], single-channel tensors): += the sums of g_y by (row parity, column parity) class, spread
+    over partial copies."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // max(1, B * C)
     _chk(a, x, g_loss, g_y, gbias, loss_acc, cls)

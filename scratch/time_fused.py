@@ -42,7 +42,7 @@ def main():
         fuse = (a, coef, gb, 1, 0.1)
         conv = ops.conv_down if up else ops.conv_up
         m = 2 if up else 1
-        cls = torch.zeros(gy.shape[1] * m * m, device=dev)
+        cls = torch.zeros(gy.shape[1] * m * m * (ops.CLS_COPIES if up else 1), device=dev)
         T = torch.zeros(gy.shape[1] * k * k, device=dev, dtype=torch.float64)
         sc, sh, mu, rs = (torch.ones(C, device=dev) for _ in range(4))
         gg, gbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
@@ -50,7 +50,7 @@ def main():
         rows = [('dgrad plain', lambda: conv(geom, gy, w, None, 0, 0.0, out=out), nbytes(gy, out)),
                 ('dgrad fused', lambda: conv(geom, gy, w, None, 0, 0.0, out=out, bwd_fuse=fuse), nbytes(gy, out, a)),
                 ('dgrad fused + class sums', lambda: conv(geom, gy, w, None, 0, 0.0, out=out,
-                                                          bwd_fuse=fuse + (torch.zeros(4 * C, device=dev),)), nbytes(gy, out, a)),
+                                                          bwd_fuse=fuse + (torch.zeros(ops.CLS_COPIES * 4 * C, device=dev),)), nbytes(gy, out, a)),
                 ('act_bwd_coef pass', lambda: ops.act_bwd_coef(out, a, coef, 1, 0.1, out, gb, prezeroed=True), nbytes(out, out, a)),
                 ('class_sums', lambda: ops.conv_class_sums(geom, gy, up, cls, prezeroed=True), nbytes(gy)),
                 ('tap_sums border', lambda: ops.conv_tap_sums(geom, gy, up, T, prezeroed=True, cls=cls), 0),

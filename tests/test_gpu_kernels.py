@@ -398,13 +398,14 @@ def test_conv_bwd_fuse_matches_separate_pass(ops, case, policy):
                 err = (gb.double() - ref.sum(dim=(0, 2, 3))).abs()
                 assert (err <= 2e-6 * l1 + 1e-12).all(), (out_is_big, act, (err / l1).max().item())
                 # class sums of the result as a by-product (kept in the epilogue where the kernel can, else a pass)
-                gb3, cls = torch.zeros(C, device='cuda'), torch.zeros(4 * C, device='cuda')
+                gb3, cls = torch.zeros(C, device='cuda'), torch.zeros(ops.CLS_COPIES * 4 * C, device='cuda')
                 fz = (a, coef, gb3, act, slope, cls)
                 out3 = (ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz) if out_is_big else
                         ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz))
                 assert rel_l2(out3, ref) < 2e-6
                 ref_cls = torch.stack([ref[:, :, r::2, c::2].sum(dim=(0, 2, 3)) for r in range(2) for c in range(2)], dim=1)
-                assert ((cls.double().view(C, 4) - ref_cls).abs() <= 2e-6 * l1.view(C, 1) + 1e-12).all()
+                # (kept as partial copies, one per XCD of the producing workgroups; the consumers add them up)
+                assert ((cls.double().view(ops.CLS_COPIES, C, 4).sum(0) - ref_cls).abs() <= 2e-6 * l1.view(C, 1) + 1e-12).all()
                 assert ((gb3.double() - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
                 # the unfused entry point gives the same (in place)
                 gb2 = torch.empty(C, device='cuda')
@@ -449,7 +450,7 @@ def test_conv_tap_sums(ops, case):
     if s <= 3:
         cls = ops.conv_class_sums(geom, dev(gy_b), True)
         ref_cls = torch.stack([gy_b[:, :, r::s, c::s].sum(dim=(0, 2, 3)) for r in range(s) for c in range(s)], dim=1)
-        assert (cls.cpu().double().view(Cb, s * s) - ref_cls).abs().max().item() <= 1e-6 * l1
+        assert (cls.cpu().double().view(ops.CLS_COPIES, Cb, s * s).sum(0) - ref_cls).abs().max().item() <= 1e-6 * l1
         Tb = ops.conv_tap_sums(geom, dev(gy_b), True, cls=cls)
         assert (Tb.cpu().view(Cb, k, k) - wv.grad[0]).abs().max().item() <= 2e-6 * l1
 
@@ -619,8 +620,9 @@ def test_sqerr_act_bwd_with_class_sums(ops, shape):
     g1, gb1, l1 = torch.empty_like(a), torch.zeros(1, device='cuda'), torch.zeros((), device='cuda')
     ops.sqerr_act_bwd(a, x, gl, scale, ops.PGV_ACT_HARDTANH, 0.0, g1, gb1, prezeroed=True, loss_acc=l1)
     g2, gb2, l2 = torch.empty_like(a), torch.zeros(1, device='cuda'), torch.zeros((), device='cuda')
-    cls = torch.zeros(4, device='cuda')
+    cls = torch.zeros(ops.CLS_COPIES * 4, device='cuda')
     ops.sqerr_act_bwd(a, x, gl, scale, ops.PGV_ACT_HARDTANH, 0.0, g2, gb2, prezeroed=True, loss_acc=l2, cls=cls)
+    cls = cls.view(ops.CLS_COPIES, 4).sum(0)   # (partial copies per XCD)
     assert torch.equal(g1, g2)
     ref = torch.stack([g1.double()[:, :, r::2, c::2].sum() for r in range(2) for c in range(2)])
     tol = 2e-6 * g1.double().abs().sum().item() + 1e-12
