@@ -49,6 +49,7 @@ def main():
         nbytes = lambda *ts: sum(t.numel() * 4 for t in ts)
         rows = [('dgrad plain', lambda: conv(geom, gy, w, None, 0, 0.0, out=out), nbytes(gy, out)),
                 ('dgrad fused', lambda: conv(geom, gy, w, None, 0, 0.0, out=out, bwd_fuse=fuse), nbytes(gy, out, a)),
+                ('dgrad fused, no bias grad', lambda: conv(geom, gy, w, None, 0, 0.0, out=out, bwd_fuse=(a, coef, None, 1, 0.1)), nbytes(gy, out, a)),
                 ('dgrad fused + class sums', lambda: conv(geom, gy, w, None, 0, 0.0, out=out,
                                                           bwd_fuse=fuse + (torch.zeros(ops.CLS_COPIES * 4 * C, device=dev),)), nbytes(gy, out, a)),
                 ('act_bwd_coef pass', lambda: ops.act_bwd_coef(out, a, coef, 1, 0.1, out, gb, prezeroed=True), nbytes(out, out, a)),
