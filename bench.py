@@ -188,8 +188,11 @@ def launch_table(ae, B, device, frontend=None):
         sc_b, sh_b = torch.ones(Cb, device=device), torch.zeros(Cb, device=device)
         sc_s, sh_s = torch.ones(Cs, device=device), torch.zeros(Cs, device=device)
         bias_b, bias_s = torch.zeros(Cb, device=device), torch.zeros(Cs, device=device)
-        stats_b = torch.empty(2 * Cb, device=device, dtype=torch.float64)
-        stats_s = torch.empty(2 * Cs, device=device, dtype=torch.float64)
+        # (BatchNorm statistics as the step keeps them: zeroed partial copies per XCD for the large planes)
+        big_plane = (Hb * Wb if is_up else geom.Hs * geom.Ws) >= layer_mod.PASSFREE_MIN_PLANE
+        nsc = ops.CLS_COPIES if big_plane else 1
+        stats_b = torch.zeros(nsc * 2 * Cb, device=device, dtype=torch.float64)
+        stats_s = torch.zeros(nsc * 2 * Cs, device=device, dtype=torch.float64)
         out_s, out_b = torch.empty_like(small), torch.empty_like(big)
         flops = 2.0 * B * Cs * geom.Hs * geom.Ws * Cb * k * k
         nb, ns, nw = big.numel() * 4, small.numel() * 4, w.numel() * 4
@@ -244,19 +247,23 @@ def launch_table(ae, B, device, frontend=None):
 
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
                bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up,
-               fuse=fuse, in_bn=in_bn, coef_req=coef_req):
+               fuse=fuse, in_bn=in_bn, coef_req=coef_req, sck=nsc > 1):
             if kind == 'conv_down':
                 if is_up:
                     return lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse)
                 if in_bn is not None:
-                    return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, in_bn=in_bn)
-                return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s)
+                    return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, in_bn=in_bn,
+                                                 prezeroed=fs is not None, stats_copies=sck and fs is not None)
+                return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, prezeroed=fs is not None,
+                                             stats_copies=sck and fs is not None)
             if kind == 'conv_up':
                 if not is_up:
                     return lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse)
                 if in_bn is not None:
-                    return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, in_bn=in_bn)
-                return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b)
+                    return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, in_bn=in_bn,
+                                               prezeroed=fb is not None, stats_copies=sck and fb is not None)
+                return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, prezeroed=fb is not None,
+                                           stats_copies=sck and fb is not None)
             return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b, coef_req=coef_req)) \
                 if not is_up else \
                 (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s, coef_req=coef_req))

@@ -55,6 +55,11 @@ typedef struct pgv_conv_desc {
  * BatchNorm affine, weights, gradients) are rounded to bfloat16 (RNE) and multiplied on the bf16 matrix cores
  * (v_mfma_f32_16x16x16_bf16) with fp32 accumulation; tensors in HBM, BatchNorm, losses and Adam stay fp32. */
 #define PGV_COMPUTE_BF16 2
+/* The BatchNorm statistics output of a forward conv call (`stats`) is PGV_CLS_COPIES partial copies [copies][2C] of
+ * doubles, zeroed by the caller, and a workgroup may add into any of them (the wave-specialised kernels use the copy of
+ * their XCD: 256 workgroups finishing together on ONE copy serialise on its 2C addresses, 7-8 us per launch); they are
+ * added up by whoever finalizes: pgv_bn_src.stats_copies / pgv_bn_finalize_src. */
+#define PGV_STATS_COPIES 4
 
 /* ---- library info ------------------------------------------------------------------------------ */
 int pgv_abi_version(void);
@@ -211,7 +216,10 @@ typedef struct pgv_bn_src {
   float *running_mean, *running_var; /* nullable */
   int64_t* num_batches_tracked;      /* nullable */
   float *scale, *shift, *mean, *rstd; /* [C] each, outputs; scale and shift required */
+  int32_t stats_copies;               /* 0 / 1: stats is [2C]; PGV_CLS_COPIES: partial copies (PGV_STATS_COPIES) */
 } pgv_bn_src;
+/* pgv_bn_finalize with its arguments as a pgv_bn_src (adds up the partial copies of the statistics, if any). */
+int pgv_bn_finalize_src(const pgv_bn_src* src, int C, void* stream);
 int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src* in_bn, const float* w, const float* bias,
                      int act, float slope, float* small_out, double* stats, void* stream);
 int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* w,

@@ -41,7 +41,7 @@ class BnSrc(Structure):
     _fields_ = [("stats", c_void_p), ("n", c_int64), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
                 ("momentum", c_float), ("running_mean", c_void_p), ("running_var", c_void_p),
                 ("num_batches_tracked", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("mean", c_void_p),
-                ("rstd", c_void_p)]
+                ("rstd", c_void_p), ("stats_copies", c_int32)]
 
 
 _BN = POINTER(BnSrc)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),
     "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pgv_bn_finalize_src": (c_int, [_BN, c_int, _P]),
     "pgv_bn_eval_affine": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "pgv_affine_nchw": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "pgv_bn1d_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -147,7 +147,7 @@ __global__ void bn_stats_kernel(const float* __restrict__ a, int B, int C, int H
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double inv_n, double unbias,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int copies, int C, double inv_n, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
@@ -156,8 +156,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, doub
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   if (c >= C) return;
-  const double mean = (double)stats[c] * inv_n;
-  double var = (double)stats[C + c] * inv_n - mean * mean;
+  double sum = stats[c], sq = stats[C + c];
+  for (int r = 1; r < copies; ++r) sum += stats[r * 2 * C + c], sq += stats[r * 2 * C + C + c];   // (PGV_STATS_COPIES)
+  const double mean = sum * inv_n;
+  double var = sq * inv_n - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
@@ -978,9 +980,20 @@ int pgv_bn_finalize(const double* stats, int C, int64_t n, const float* gamma, c
   PGV_CHECK_ARG(stats && C > 0 && n > 0, "pgv_bn_finalize: bad argument");
   // torch raises for n==1 in train mode ("Expected more than 1 value per channel"); the host mirrors that.
   const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), stats,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), stats, 1,
                      C, 1.0 / (double)n, unbias, gamma, beta, eps, momentum, running_mean, running_var,
                      num_batches_tracked, scale, shift, mean, rstd);
+  PGV_CHECK_LAUNCH("bn_finalize");
+  return PGV_OK;
+}
+
+int pgv_bn_finalize_src(const pgv_bn_src* s, int C, void* stream) {
+  PGV_CHECK_ARG(s && s->stats && s->scale && s->shift && C > 0 && s->n > 0, "pgv_bn_finalize_src: incomplete pgv_bn_src");
+  const double unbias = s->n > 1 ? (double)s->n / (double)(s->n - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pgv_cdiv(C, 128)), dim3(128), 0, pgv_stream(stream), s->stats,
+                     s->stats_copies > 1 ? s->stats_copies : 1, C, 1.0 / (double)s->n, unbias, s->gamma, s->beta, s->eps,
+                     s->momentum, s->running_mean, s->running_var, s->num_batches_tracked, s->scale, s->shift, s->mean,
+                     s->rstd);
   PGV_CHECK_LAUNCH("bn_finalize");
   return PGV_OK;
 }

@@ -47,6 +47,21 @@ static int check_fuse(const pgv_bwd_fuse* f, const char* who) {
   return PGV_OK;
 }
 
+static int bn_src_finalize(const pgv_bn_src* bn, int C, void* stream) { return pgv_bn_finalize_src(bn, C, stream); }
+// PGV_STATS_COPIES: the statistics output is partial copies that the caller zeroed - for the kernels it is an accumulating
+// output (copy 0 for the families that do not spread it)
+static int clear_stat_copies(const pgv_conv_desc* d, double* stats, int C, pgv_conv_desc* dd, hipStream_t st) {
+  *dd = *d;
+  if (stats && (d->flags & PGV_STATS_COPIES) && !(d->flags & PGV_PREZEROED)) {
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * C * PGV_CLS_COPIES, st) != hipSuccess) {
+      pgv_set_error("pgv_conv: clearing the statistics copies failed");
+      return PGV_E_LAUNCH;
+    }
+  }
+  if (d->flags & PGV_STATS_COPIES) dd->flags |= PGV_PREZEROED;
+  return PGV_OK;
+}
+
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                         const pgv_bwd_fuse* fuse, void* stream) {
@@ -57,6 +72,9 @@ int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* i
   PGV_CHECK_ARG(big && w && small_out, "pgv_conv_down: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_down: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
+  pgv_conv_desc dd;
+  if ((rc = clear_stat_copies(d, stats, d->Cs, &dd, st))) return rc;
+  d = &dd;
   bool fused = false, cls_done = false;
   rc = 0;
   if (g_policy != 1) {
@@ -113,16 +131,14 @@ static int check_bn_src(const pgv_bn_src* bn, const char* who) {
   PGV_CHECK_ARG(bn && bn->stats && bn->scale && bn->shift && bn->n > 0, "%s: incomplete pgv_bn_src", who);
   return PGV_OK;
 }
-static int bn_src_finalize(const pgv_bn_src* bn, int C, void* stream) {
-  return pgv_bn_finalize(bn->stats, C, bn->n, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
-                         bn->num_batches_tracked, bn->scale, bn->shift, bn->mean, bn->rstd, stream);
-}
-
 int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src* in_bn, const float* w, const float* bias,
                      int act, float slope, float* small_out, double* stats, void* stream) {
   int rc = check_desc(d, "pgv_conv_down_bn");
   if (rc) return rc;
   if ((rc = check_bn_src(in_bn, "pgv_conv_down_bn"))) return rc;
+  pgv_conv_desc dd;
+  if ((rc = clear_stat_copies(d, stats, d->Cs, &dd, pgv_stream(stream)))) return rc;
+  d = &dd;
   if (g_policy == 0 && !g_no_v2 && d->B > 0 && big && w && small_out) {
     rc = pgv_conv_down_v2(d, big, in_bn->scale, in_bn->shift, w, bias, act, slope, small_out, stats, nullptr,
                           pgv_stream(stream), in_bn);
@@ -138,6 +154,9 @@ int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_s
   int rc = check_desc(d, "pgv_conv_up_bn");
   if (rc) return rc;
   if ((rc = check_bn_src(in_bn, "pgv_conv_up_bn"))) return rc;
+  pgv_conv_desc dd;
+  if ((rc = clear_stat_copies(d, stats, d->Cb, &dd, pgv_stream(stream)))) return rc;
+  d = &dd;
   if (g_policy == 0 && !g_no_v2 && d->B > 0 && small_in && w && big_out) {
     hipStream_t st = pgv_stream(stream);
     rc = pgv_conv_up_direct2(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, st, in_bn);
@@ -160,6 +179,9 @@ int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float
   PGV_CHECK_ARG(small_in && w && big_out, "pgv_conv_up: null tensor");
   PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
+  pgv_conv_desc dd;
+  if ((rc = clear_stat_copies(d, stats, d->Cb, &dd, st))) return rc;
+  d = &dd;
   bool fused = false, cls_done = false;
   rc = 0;
   if (g_policy != 1) {

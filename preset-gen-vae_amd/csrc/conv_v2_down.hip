@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             int act, float slope, float* __restrict__ out,
                                                             double* __restrict__ stats, pgv_bwd_fuse fuse,
-                                                            pgv_bn_src bn) {
+                                                            pgv_bn_src bn, int stat_copies) {
   using G = DownV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, BANDS = G::BANDS, NW = G::NW, MTW = G::MTW, P = G::P, NT = G::NT;
   constexpr int WP = G::WP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -536,7 +536,8 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
   // addresses: the atomics serialise at the memory side, ~25 ns each - with one per wave they cost 10-25 us per launch).
   // Waves that share channels (NW > 1) are added up through LDS first; the loader waves have left, so this part uses
   // named waits on an LDS flag instead of a workgroup barrier.
-  double* dst = stats;
+  // (PGV_STATS_COPIES: into the partial copy of this workgroup's XCD - the finalize arithmetic adds the copies up)
+  double* dst = (stats && stat_copies) ? stats + (blockIdx.x & (PGV_CLS_COPIES - 1)) * 2 * CS : stats;
   if constexpr (FUSE) {
     // bias gradient of the lower block (and the class sums of g_y, APRE): ONE float atomic per value per workgroup - the
     // 256 workgroups finish together and their atomics serialise per address (4 per workgroup cost 25 us per launch,
@@ -652,7 +653,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   // the two ways the train step calls it: forward of a Conv2D block (producer's BatchNorm folded or not, LeakyReLU,
   // statistics) and input gradient of a TConv2D block (plain product, optional BatchNorm-backward projections)
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse, pgv_bn_src);
+                         double*, pgv_bwd_fuse, pgv_bn_src, int);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
@@ -696,7 +697,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, in_scale, in_shift, w, bias, act,
-                     slope, out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn());
+                     slope, out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn(), (d->flags & PGV_STATS_COPIES) ? 1 : 0);
   PGV_CHECK_LAUNCH("conv_down_v2");
   return with_cls ? 3 : 1;   // (3: handled, class sums included)
 }

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
                                                           const float* __restrict__ in_shift,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int act, float slope, float* __restrict__ out,
-                                                          double* __restrict__ stats, pgv_bwd_fuse fuse, pgv_bn_src bn) {
+                                                          double* __restrict__ stats, pgv_bwd_fuse fuse, pgv_bn_src bn,
+                                                          int stat_copies) {
   using G = UpV2Cfg<CB, CS, W, H, R, MW, CK>;
   constexpr int Ws = G::Ws, Hs = G::Hs, Wg = G::Wg, Hg = G::Hg, Wgp = G::Wgp, BANDS = G::BANDS, NW = G::NW;
   constexpr int MTW = G::MTW, P = G::P, NT = G::NT, WsP = G::WsP, PLANE = G::PLANE, NCH = G::NCH, S = G::S, BUF = G::BUF;
@@ -666,7 +667,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
   if constexpr (DEFER) static_for<0, MTW * NT>([&](auto qc) { store_pending(qc); });  // the last unit
   V2_FLUSH();
   // statistics / projections: one float64 atomic per channel per workgroup (see conv_down_ws_kernel)
-  double* dst = stats;
+  // (PGV_STATS_COPIES: into the partial copy of this workgroup's XCD - the finalize arithmetic adds the copies up)
+  double* dst = (stats && stat_copies) ? stats + (blockIdx.x & (PGV_CLS_COPIES - 1)) * 2 * CB : stats;
   if constexpr (FUSE) {
     // bias gradient of the lower block: ONE float atomic per channel per workgroup (see conv_down_ws_kernel); waves that
     // share channels are added up through LDS first
@@ -758,7 +760,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   if (d->Cb != CB || d->Cs != CS) return 0;
   if (stats && fuse) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, int, float, float*,
-                         double*, pgv_bwd_fuse, pgv_bn_src);
+                         double*, pgv_bwd_fuse, pgv_bn_src, int);
   kern_t kern;
   const bool leaky = act == PGV_ACT_LEAKY_RELU && slope >= 0.f && slope <= 1.f;
   const int actk = act == PGV_ACT_NONE ? 0 : (leaky ? 1 : 2);
@@ -815,7 +817,7 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
   const int grid = min(units, 256);
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, small_in, in_scale, in_shift, w, bias, act, slope,
-                     out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn());
+                     out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn(), (d->flags & PGV_STATS_COPIES) ? 1 : 0);
   PGV_CHECK_LAUNCH("conv_up_v2");
   return 1;
 }

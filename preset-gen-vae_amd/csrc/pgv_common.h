@@ -80,8 +80,10 @@ __device__ __forceinline__ double pgv_block_sum_d(double v, double* smem /* >= 1
 // backward pass reads and updates the running statistics.
 __device__ __forceinline__ void pgv_bn_finalize_dev(const pgv_bn_src& s, int C, int c, bool writer, float& sc, float& sh) {
   const double inv_n = 1.0 / (double)s.n;
-  const double mean = s.stats[c] * inv_n;
-  double var = s.stats[C + c] * inv_n - mean * mean;
+  double sum = s.stats[c], sq = s.stats[C + c];
+  for (int r = 1; r < s.stats_copies; ++r) sum += s.stats[r * 2 * C + c], sq += s.stats[r * 2 * C + C + c];   // (PGV_STATS_COPIES)
+  const double mean = sum * inv_n;
+  double var = sq * inv_n - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const double rstd = 1.0 / sqrt(var + (double)s.eps);
   const double g = s.gamma ? (double)s.gamma[c] : 1.0, bt = s.beta ? (double)s.beta[c] : 0.0;

@@ -177,7 +177,18 @@ class ConvStackFn(torch.autograd.Function):
         pi = 0
         # BatchNorm statistics of all blocks in one arena cleared by ONE fill (PGV_PREZEROED): a memset node per block
         # costs ~5 us of dependent-launch latency each
-        n_stats = sum(2 * blk.c_out for blk in blocks if blk.bn is not None) if training else 0
+        # (as CLS_COPIES partial copies each: the kernels' end-of-kernel atomics then stay inside their XCD's L2 - 256
+        # workgroups finishing together on one copy cost the transposed-conv kernels 7-8 us per launch)
+        # (only for the large planes, whose kernels spread them: the deep layers' kernels add into one copy anyway)
+        def stat_copies(blk, h, w):
+            go = blk.geom(h, w)
+            ho, wo = (go.Hb, go.Wb) if blk.up else (go.Hs, go.Ws)
+            return (ops.CLS_COPIES if ho * wo >= PASSFREE_MIN_PLANE else 1), ho, wo
+        n_stats, hh, ww = 0, x.shape[2], x.shape[3]
+        for blk in blocks:
+            sc_b, hh, ww = stat_copies(blk, hh, ww)
+            if blk.bn is not None and training:
+                n_stats += sc_b * 2 * blk.c_out
         arena = _step_zeros(params[0], n_stats, torch.float64, 'stats', dev) if n_stats else None
         a_off = 0
         for blk in blocks:
@@ -192,16 +203,18 @@ class ConvStackFn(torch.autograd.Function):
             C = blk.c_out
             stats = None
             if has_bn and training:
-                stats = arena[a_off:a_off + 2 * C]
-                a_off += 2 * C
+                SC = stat_copies(blk, cur.shape[2], cur.shape[3])[0]
+                stats = arena[a_off:a_off + SC * 2 * C]
+                a_off += SC * 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
             # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
             if pending is not None:
-                a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending)
+                a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending,
+                       stats_copies=stats is not None and SC > 1)
                 pending = None
             else:
                 a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats,
-                       prezeroed=stats is not None)
+                       prezeroed=stats is not None, stats_copies=stats is not None and SC > 1)
             scale = shift = mean = rstd = None
             if has_bn:
                 vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
@@ -217,7 +230,8 @@ class ConvStackFn(torch.autograd.Function):
                     # BatchNorm - the next block's, or the output pass below
                     pending = ops.bn_src(stats, n, gamma, beta, bn.eps, mom, bn.running_mean if track else None,
                                          bn.running_var if track else None,
-                                         bn.num_batches_tracked if track else None, scale, shift, mean, rstd)
+                                         bn.num_batches_tracked if track else None, scale, shift, mean, rstd,
+                                         stats_copies=SC)
                 else:
                     ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
                     mean = rstd = None

@@ -38,7 +38,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-PGV_PREZEROED, PGV_COMPUTE_BF16 = 1, 2
+PGV_PREZEROED, PGV_COMPUTE_BF16, PGV_STATS_COPIES = 1, 2, 4
 CLS_COPIES = 8   # PGV_CLS_COPIES: class sums (pgv_bwd_fuse.cls) are kept as this many partial copies, one per XCD
 _COMPUTE_FLAGS = 0
 
@@ -98,32 +98,36 @@ def _fuse_arg(bwd_fuse, out):
 
 
 def bn_src(stats, n, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, mean,
-           rstd):
+           rstd, stats_copies=1):
     """``pgv_bn_src``: a BatchNorm whose statistics have been accumulated and whose finalize step (``bn_finalize`` with
     these arguments) is left to the kernel that consumes it (``conv_down`` / ``conv_up`` / ``dropout_fwd`` with
-    ``in_bn=``).  Keeps the tensors alive; ``scale`` / ``shift`` / ``mean`` / ``rstd`` are outputs."""
+    ``in_bn=``).  Keeps the tensors alive; ``scale`` / ``shift`` / ``mean`` / ``rstd`` are outputs.  ``stats_copies`` =
+    CLS_COPIES: ``stats`` is that many partial copies of [2C] (a forward conv called with ``stats_copies=True``)."""
+    if stats.numel() < 2 * scale.numel() * max(1, int(stats_copies)):
+        raise ValueError("bn_src: stats holds fewer than stats_copies * 2C values")
     _chk64(stats)
     _chk(gamma, beta, running_mean, running_var, scale, shift, mean, rstd)
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise ValueError("num_batches_tracked must be an int64 device tensor")
     s = _lib.BnSrc(_p(stats), int(n), _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
-                   _p(running_var), _p(num_batches_tracked), _p(scale), _p(shift), _p(mean), _p(rstd))
+                   _p(running_var), _p(num_batches_tracked), _p(scale), _p(shift), _p(mean), _p(rstd), int(stats_copies))
     s._keep = (stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd)
     return s
 
 
 def bn_src_finalize(src):
     """The finalize step of a ``bn_src`` as a launch of its own (no consumer kernel to ride in)."""
-    stats, gamma, beta, rm, rv, nbt, scale, shift, mean, rstd = src._keep
-    bn_finalize(stats, src.n, gamma, beta, src.eps, src.momentum, rm, rv, scale, shift, mean, rstd,
-                num_batches_tracked=nbt)
+    C = src._keep[6].numel()
+    _lib.check(_lib.load().pgv_bn_finalize_src(ctypes.byref(src), C, _stream()), "pgv_bn_finalize_src")
 
 
 def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-              bwd_fuse=None, in_bn=None):
+              bwd_fuse=None, in_bn=None, stats_copies=False):
     """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it.
-    ``in_bn`` (a ``bn_src``): the input's BatchNorm, finalized by this call (``pgv_conv_down_bn``)."""
+    ``in_bn`` (a ``bn_src``): the input's BatchNorm, finalized by this call (``pgv_conv_down_bn``).  ``stats_copies``:
+    ``stats`` is CLS_COPIES zeroed partial copies of [2C] (PGV_STATS_COPIES)."""
     B = big.shape[0]
+    fl = int(prezeroed) | (PGV_STATS_COPIES if stats_copies else 0)
     if out is None:
         out = torch.empty((B, geom.Cs, geom.Hs, geom.Ws), device=big.device, dtype=torch.float32)
     _chk(big, w, bias, in_scale, in_shift, out)
@@ -132,19 +136,20 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
     if in_bn is not None:
         if bwd_fuse is not None or in_scale is not None:
             raise ValueError("conv_down: in_bn excludes in_scale / bwd_fuse")
-        _lib.check(lib.pgv_conv_down_bn(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), ctypes.byref(in_bn), _p(w),
+        _lib.check(lib.pgv_conv_down_bn(ctypes.byref(geom.desc(B, fl)), _p(big), ctypes.byref(in_bn), _p(w),
                                         _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_down_bn")
         return out
     f = _fuse_arg(bwd_fuse, out)
-    _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(big), _p(in_scale),
+    _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, fl)), _p(big), _p(in_scale),
                                        _p(in_shift), _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                        None if f is None else ctypes.byref(f), _stream()), "pgv_conv_down")
     return out
 
 
 def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-            bwd_fuse=None, in_bn=None):
+            bwd_fuse=None, in_bn=None, stats_copies=False):
     B = small.shape[0]
+    fl = int(prezeroed) | (PGV_STATS_COPIES if stats_copies else 0)
     if out is None:
         out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
     _chk(small, w, bias, in_scale, in_shift, out)
@@ -153,11 +158,11 @@ def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stat
     if in_bn is not None:
         if bwd_fuse is not None or in_scale is not None:
             raise ValueError("conv_up: in_bn excludes in_scale / bwd_fuse")
-        _lib.check(lib.pgv_conv_up_bn(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), ctypes.byref(in_bn), _p(w),
+        _lib.check(lib.pgv_conv_up_bn(ctypes.byref(geom.desc(B, fl)), _p(small), ctypes.byref(in_bn), _p(w),
                                       _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_up_bn")
         return out
     f = _fuse_arg(bwd_fuse, out)
-    _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, int(prezeroed))), _p(small), _p(in_scale), _p(in_shift),
+    _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, fl)), _p(small), _p(in_scale), _p(in_shift),
                                      _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                      None if f is None else ctypes.byref(f), _stream()), "pgv_conv_up")
     return out

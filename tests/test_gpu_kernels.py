@@ -494,6 +494,24 @@ def test_conv_finalizes_the_input_batchnorm(ops, case, policy):
             for a, b in zip(*res):
                 assert torch.equal(a, b)
             assert res[1][3].item() == 4
+            # the statistics OUTPUT as partial copies (PGV_STATS_COPIES): the copies add up to the one-copy result, and
+            # a finalize over the copies gives the same vectors as over their sum
+            Cout = Cb if up else Cs
+            st1 = torch.zeros(2 * Cout, device='cuda', dtype=torch.float64)
+            st8 = torch.zeros(ops.CLS_COPIES * 2 * Cout, device='cuda', dtype=torch.float64)
+            y1 = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st1, prezeroed=True)
+            y8 = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, stats=st8, prezeroed=True, stats_copies=True)
+            assert torch.equal(y1, y8)
+            s8 = st8.view(ops.CLS_COPIES, 2 * Cout).sum(0)
+            assert (s8 - st1).abs().max().item() <= 1e-9 * st1.abs().max().item()
+            n_o = y1.numel() // Cout
+            g_o, b_o = dev(1.0 + 0.3 * synth_vec((Cout,), 2.1, 0.1)), dev(0.3 * synth_vec((Cout,), 2.9, 0.6))
+            va = [torch.empty(Cout, device='cuda') for _ in range(4)]
+            vb = [torch.empty(Cout, device='cuda') for _ in range(4)]
+            ops.bn_src_finalize(ops.bn_src(s8.contiguous(), n_o, g_o, b_o, 1e-5, 0.1, None, None, None, *va))
+            ops.bn_src_finalize(ops.bn_src(st8, n_o, g_o, b_o, 1e-5, 0.1, None, None, None, *vb, stats_copies=ops.CLS_COPIES))
+            for a, b in zip(va, vb):
+                assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
         # the Dropout in front of the encoder's Linear: same draw, same values
         C, HW = Cb, 24
         x = dev(synth_vec((B, C, 4, 6), 0.371, 0.2))
