@@ -212,7 +212,7 @@ def launch_table(ae, B, device, frontend=None):
             Cl = lo.shape[1]
             a_lo = torch.randn_like(lo)
             coef = torch.cat([torch.ones(Cl, device=device), 0.01 * torch.randn(2 * Cl, device=device)])
-            gb_lo = torch.zeros(Cl, device=device)
+            gb_lo = torch.zeros(ops.CLS_COPIES * Cl, device=device)   # (per-XCD partial copies: pgv_bwd_fuse.gbias_copies)
             # (class sums are kept when the lower block is itself a stride-2 ConvTranspose2d with a block below it)
             lower2 = layers[li - 2] if li > 1 and layers[li - 2][3] == is_up else None
             if lower2 is not None:   # ... whose own output plane is large enough for the pass-free backward
@@ -220,7 +220,7 @@ def launch_table(ae, B, device, frontend=None):
                 if lg.Hs * lg.Ws < layer_mod.PASSFREE_MIN_PLANE:
                     lower2 = None
             cls_lo = torch.zeros(ops.CLS_COPIES * 4 * Cl, device=device) if (is_up and lower2 is not None) else None
-            fuse = (a_lo, coef, gb_lo, 1, 0.1, cls_lo)
+            fuse = (a_lo, coef, gb_lo, 1, 0.1, cls_lo, ops.CLS_COPIES)
 
         # the producer's train-mode BatchNorm is finalized in this block's forward kernel (ops.bn_src: statistics of a
         # zero-mean unit-variance input stand in), no launch of its own
@@ -245,9 +245,19 @@ def launch_table(ae, B, device, frontend=None):
                             gbeta=torch.empty(Cl, device=device),
                             scratch=torch.zeros(ops.coef_scratch(geom, not is_up), device=device, dtype=torch.float64))
 
+        # this block's own bias gradient arrives as partial copies when the block above fused its backward
+        # (pgv_bias_req: added up by the reduce launch of this weight gradient)
+        bias_fin = None
+        a_self = big if is_up else small
+        if upper is not None and fused_bwd and (ops.compute_dtype() == 'fp32' or B * a_self.shape[2] * a_self.shape[3] >=
+                                                layer_mod.BF16_PASSFREE_MIN_N) and \
+                a_self.shape[2] * a_self.shape[3] >= layer_mod.PASSFREE_MIN_PLANE:
+            Cself = a_self.shape[1]
+            bias_fin = (torch.zeros(ops.CLS_COPIES * Cself, device=device), torch.zeros(Cself, device=device), False)
+
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
                bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up,
-               fuse=fuse, in_bn=in_bn, coef_req=coef_req, sck=nsc > 1):
+               fuse=fuse, in_bn=in_bn, coef_req=coef_req, sck=nsc > 1, bias_fin=bias_fin):
             if kind == 'conv_down':
                 if is_up:
                     return lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse)
@@ -264,9 +274,11 @@ def launch_table(ae, B, device, frontend=None):
                                                prezeroed=fb is not None, stats_copies=sck and fb is not None)
                 return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, prezeroed=fb is not None,
                                            stats_copies=sck and fb is not None)
-            return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b, coef_req=coef_req)) \
+            return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b, coef_req=coef_req,
+                                           bias_finish=bias_fin)) \
                 if not is_up else \
-                (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s, coef_req=coef_req))
+                (lambda: ops.conv_wgrad(geom, big, small, gw, small_scale=sc_s, small_shift=sh_s, coef_req=coef_req,
+                                        bias_finish=bias_fin))
 
         for kind in ('conv_down', 'conv_up', 'conv_wgrad'):
             if name == 'enc1' and kind == 'conv_up':

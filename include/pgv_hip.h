@@ -107,6 +107,10 @@ typedef struct pgv_bwd_fuse {
                         adds into the copy of its XCD - 256 workgroups finishing together on ONE copy serialise on its
                         addresses, ~80 ns per atomic) that the consumers add up: pgv_conv_tap_sums / pgv_coef_req.cls
                         with the output gradient of a stride-2 ConvTranspose2d */
+  int32_t gbias_copies; /* 0: gbias is [C].  PGV_CLS_COPIES: gbias is that many zeroed partial copies of [C] (a workgroup
+                           adds into the copy of its XCD - the same-address atomics of 256 workgroups finishing together
+                           cost the fused kernels 3-6 us each); the sums reach the bias gradient through the pgv_bias_req
+                           of the block's own weight-gradient call (pgv_conv_wgrad_ex), which runs next */
 } pgv_bwd_fuse;
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* small, double* stats,
@@ -186,10 +190,25 @@ typedef struct pgv_coef_req {
   int64_t n;          /* elements per channel of the lower block's output */
   float *coef, *ggamma, *gbeta;
   double* scratch;    /* max(C_gy*kh*kw, 1024) + 1 doubles, zeroed: receives the tap sums of gy */
+  int32_t cls_copies; /* 0: by the rule of pgv_conv_tap_sums (copies for the big tensor, one [C] for the small one);
+                         PGV_CLS_COPIES: cls is partial copies also for the small tensor (a bias gradient kept as
+                         pgv_bwd_fuse.gbias_copies) */
 } pgv_coef_req;
 int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small, const float* small_scale, const float* small_shift, float* gw,
                         void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, void* stream);
+/* ... and the bias gradient of the block itself from partial copies (pgv_bwd_fuse.gbias_copies), as one more role of the
+ * reduce launch: gbias[c] = (accumulate ? gbias[c] : 0) + sum over the PGV_CLS_COPIES copies of copies[.][c].  req / bias
+ * may be NULL. */
+typedef struct pgv_bias_req {
+  const float* copies; /* [PGV_CLS_COPIES][C] */
+  float* gbias;        /* [C] */
+  int32_t C;
+  int32_t accumulate;
+} pgv_bias_req;
+int pgv_conv_wgrad_ex(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small, const float* small_scale, const float* small_shift, float* gw, void* workspace,
+                      int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias, void* stream);
 
 /* ---- BatchNorm (nn.BatchNorm2d / BatchNorm1d train mode, layer.py:21-26, encoder.py:86-87) ------- */
 /* stats[0:C] = sum, stats[C:2C] = sum of squares over (B,HW) of a[B,C,HW]. Overwrites stats.

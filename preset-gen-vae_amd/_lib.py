@@ -29,7 +29,7 @@ class BwdFuse(Structure):
     """Mirror of ``pgv_bwd_fuse``: BatchNorm + activation backward of the next-lower block fused into an
     input-gradient call."""
     _fields_ = [("a", c_void_p), ("coef", c_void_p), ("gbias", c_void_p), ("act", c_int32), ("slope", c_float),
-                ("cls", c_void_p)]
+                ("cls", c_void_p), ("gbias_copies", c_int32)]
 
 
 _FUSE = POINTER(BwdFuse)
@@ -52,10 +52,19 @@ class CoefReq(Structure):
     call."""
     _fields_ = [("lower_is_big", c_int32), ("cls", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("mean", c_void_p), ("rstd", c_void_p), ("n", c_int64), ("coef", c_void_p), ("ggamma", c_void_p),
-                ("gbeta", c_void_p), ("scratch", c_void_p)]
+                ("gbeta", c_void_p), ("scratch", c_void_p), ("cls_copies", c_int32)]
 
 
 _COEF = POINTER(CoefReq)
+
+
+class BiasReq(Structure):
+    """Mirror of ``pgv_bias_req``: the block's bias gradient from its per-XCD partial copies, asked of its weight-gradient
+    call."""
+    _fields_ = [("copies", c_void_p), ("gbias", c_void_p), ("C", c_int32), ("accumulate", c_int32)]
+
+
+_BIAS = POINTER(BiasReq)
 
 # name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
@@ -71,6 +80,7 @@ SIGNATURES = {
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),
+    "pgv_conv_wgrad_ex": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _BIAS, _P]),
     "pgv_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "pgv_bn_finalize": (c_int, [_P, c_int, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_bn_finalize_src": (c_int, [_BN, c_int, _P]),

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict
 template <int K>
 __global__ __launch_bounds__(256) void tap_border_kernel(const float* __restrict__ gy, int B, int C, int H, int W, int per,
                                                          int gy_is_big, int s, int p, TapBorder tb,
-                                                         const float* __restrict__ cls, double* __restrict__ T) {
+                                                         const float* __restrict__ cls, int cls_copies,
+                                                         double* __restrict__ T) {
   constexpr int KK = K * K;
   __shared__ float res[KK];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void tap_border_kernel(const float* __restrict
     if (blockIdx.y == 0 && blockIdx.z == 0) {   // the class total enters once per channel
       const int m = gy_is_big ? s : 1;
       const int rho = gy_is_big ? (((kh - p) % s) + s) % s : 0, kap = gy_is_big ? (((kw - p) % s) + s) % s : 0;
-      const int ncopy = gy_is_big ? PGV_CLS_COPIES : 1;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls)
+      const int ncopy = cls_copies;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls)
       for (int r = 0; r < ncopy; ++r) t += (double)cls[(r * C + c) * m * m + rho * m + kap];
     }
     atomicAdd(&T[(int64_t)c * KK + tid], t);
@@ -1133,7 +1134,7 @@ int pgv_conv_class_sums(const pgv_conv_desc* d, int gy_is_big, const float* gy, 
 }
 
 static int tap_sums_launch(const pgv_conv_desc* d, int gy_is_big, const float* gy, const float* cls, double* T, int flags,
-                           hipStream_t st) {
+                           hipStream_t st, int cls_copies = 0) {
   const int C = gy_is_big ? d->Cb : d->Cs, H = gy_is_big ? d->Hb : d->Hs, W = gy_is_big ? d->Wb : d->Ws;
   const int oH = gy_is_big ? d->Hs : d->Hb, oW = gy_is_big ? d->Ws : d->Wb;
   const int K = d->kh;
@@ -1150,7 +1151,7 @@ static int tap_sums_launch(const pgv_conv_desc* d, int gy_is_big, const float* g
     const int nz = (int)max((int64_t)1, pgv_cdiv(NE, kTapChunk));
     const int per = (int)max((int64_t)1, min((int64_t)16, pgv_cdiv((int64_t)d->B * C * nz, 512)));
     const int nsplit = (int)pgv_cdiv(d->B, per);
-    typedef void (*kern_t)(const float*, int, int, int, int, int, int, int, int, TapBorder, const float*, double*);
+    typedef void (*kern_t)(const float*, int, int, int, int, int, int, int, int, TapBorder, const float*, int, double*);
     kern_t kern = nullptr;
     switch (K) {
       case 1: kern = (kern_t)tap_border_kernel<1>; break;
@@ -1160,7 +1161,7 @@ static int tap_sums_launch(const pgv_conv_desc* d, int gy_is_big, const float* g
       default: kern = (kern_t)tap_border_kernel<5>; break;
     }
     hipLaunchKernelGGL(kern, dim3(C, nsplit, nz), dim3(256), 0, st, gy, d->B, C, H, W, per, gy_is_big, d->stride, d->pad,
-                       tb, cls, T);
+                       tb, cls, cls_copies > 0 ? cls_copies : (gy_is_big ? PGV_CLS_COPIES : 1), T);
     PGV_CHECK_LAUNCH("conv_tap_sums (border)");
     return PGV_OK;
   }
@@ -1229,6 +1230,18 @@ int pgv_bn_bwd_coef_from_gy(const pgv_conv_desc* d, int lower_is_big, const floa
 
 extern "C++" {
 int pgv_tap_replicas(int c_gy, int kk) { return tap_replicas(c_gy, kk); }
+int pgv_bn_bwd_coef_from_gy_cc(const pgv_conv_desc* d, int lower_is_big, const float* gy, const float* cls, int cls_copies,
+                               double* T, const float* w, const float* gw, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, int64_t n, float* coef, float* ggamma, float* gbeta,
+                               int flags, hipStream_t st) {
+  const int gy_is_big = !lower_is_big;
+  const CoefArgs ca = coef_args(d, lower_is_big, w, gw, scale, shift, mean, rstd, n, coef, ggamma, gbeta);
+  int rc = tap_sums_launch(d, gy_is_big, gy, cls, T, flags, st, cls_copies);
+  if (rc || d->B == 0) return rc;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ca.C), dim3(256), 0, st, ca, (const double*)T);
+  PGV_CHECK_LAUNCH("bn_bwd_coef");
+  return PGV_OK;
+}
 int pgv_bn_bwd_coef_rep(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T, int trep,
                         const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
                         float* coef, float* ggamma, float* gbeta, hipStream_t st) {

@@ -236,14 +236,22 @@ int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d) {
 int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                    const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                    void* workspace, int64_t workspace_bytes, void* stream) {
-  return pgv_conv_wgrad_coef(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
-                             workspace_bytes, nullptr, stream);
+  return pgv_conv_wgrad_ex(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes,
+                           nullptr, nullptr, stream);
 }
 
 int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, void* stream) {
+  return pgv_conv_wgrad_ex(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes,
+                           req, nullptr, stream);
+}
+
+int pgv_conv_wgrad_ex(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                      const float* small_in, const float* small_scale, const float* small_shift, float* gw, void* workspace,
+                      int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias, void* stream) {
   int rc = check_desc(d, "pgv_conv_wgrad");
+  PGV_CHECK_ARG(bias == nullptr || (bias->copies && bias->gbias && bias->C > 0), "pgv_conv_wgrad_ex: incomplete pgv_bias_req");
   PGV_CHECK_ARG(req == nullptr || (req->cls && req->w && req->scale && req->shift && req->mean && req->rstd && req->coef &&
                                    req->scratch && req->n > 0),
                 "pgv_conv_wgrad_coef: incomplete pgv_coef_req");
@@ -254,8 +262,15 @@ int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* b
                 "pgv_conv_wgrad: scale/shift must come together");
   hipStream_t st = pgv_stream(stream);
   // the coefficients of the block below when they did not come out of the weight-gradient launches themselves
+  // (and the bias gradient from its partial copies, as a launch of its own, when the reduce launch did not carry it)
+  bool bias_done = false;   // (true: the wave-specialised kernels' reduce launch carried the bias role)
   auto coef_after = [&](int rc_w) -> int {
+    if (rc_w == 0 && bias && !bias_done) rc_w = pgv_bias_finish(bias, st);
     if (rc_w || !req || d->B == 0) return rc_w;
+    if (req->cls_copies > 1)   // class sums kept as partial copies also for the small tensor (a bias gradient)
+      return pgv_bn_bwd_coef_from_gy_cc(d, req->lower_is_big, req->lower_is_big ? small_in : big, req->cls, req->cls_copies,
+                                        req->scratch, req->w, gw, req->scale, req->shift, req->mean, req->rstd, req->n,
+                                        req->coef, req->ggamma, req->gbeta, PGV_PREZEROED, st);
     return pgv_bn_bwd_coef_from_gy(d, req->lower_is_big, req->lower_is_big ? small_in : big, req->cls, req->scratch, req->w,
                                    gw, req->scale, req->shift, req->mean, req->rstd, req->n, req->coef, req->ggamma,
                                    req->gbeta, PGV_PREZEROED, stream);
@@ -264,7 +279,8 @@ int pgv_conv_wgrad_coef(const pgv_conv_desc* d, const float* big, const float* b
     rc = 0;
     if (g_policy == 0 && !g_no_v2) {
       rc = pgv_conv_wgrad_v2(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
-                             workspace_bytes, req, st);
+                             workspace_bytes, req, bias, st);
+      bias_done = rc >= 1;
       if (rc == 3)   // weight gradient and tap sums (as partial copies) done
         return pgv_bn_bwd_coef_rep(d, req->lower_is_big, req->w, gw, req->scratch,
                                    pgv_tap_replicas(req->lower_is_big ? d->Cs : d->Cb, d->kh * d->kw), req->scale,

@@ -397,10 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
           atomicAdd(&fuse.cls[4 * tid + k], v);
           t += v;
         }
-        if (fuse.gbias) atomicAdd(&fuse.gbias[tid], t);
+        if (fuse.gbias) atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * Cs : 0) + tid], t);
       }
     } else {
-      if (fuse.gbias && tid < MT * 16 && tid < Cs) atomicAdd(&fuse.gbias[tid], st_tile[tid]);
+      if (fuse.gbias && tid < MT * 16 && tid < Cs)
+        atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * Cs : 0) + tid], st_tile[tid]);
     }
   }
   BAND_FLUSH();
@@ -1064,7 +1065,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
   }
   if constexpr (FUSE) {
     __syncthreads();
-    if (fuse.gbias && tid < MT * 4 && tid < Cb) atomicAdd(&fuse.gbias[tid], st_tile[tid]);
+    if (fuse.gbias && tid < MT * 4 && tid < Cb)
+      atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * Cb : 0) + tid], st_tile[tid]);
   }
   BAND_FLUSH();
 }

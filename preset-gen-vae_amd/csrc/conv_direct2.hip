@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256, (R * ((W / 2 + 1) + 3) / 4 <= 256) ? 4 : 2) vo
       // bias gradient = the four classes of a channel added up (lanes 4cs .. 4cs+3)
       t += dpp_mov<0xB1>(t);
       t += dpp_mov<0x4E>(t);
-      if (fuse.gbias && (tid & 3) == 0) atomicAdd(&fuse.gbias[tid >> 2], t);
+      if (fuse.gbias && (tid & 3) == 0)
+        atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * CS : 0) + (tid >> 2)], t);
     }
   }
 }

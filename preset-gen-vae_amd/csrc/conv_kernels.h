@@ -60,12 +60,20 @@ int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d);
 // (req != null: returns 3 when the tap sums of the output gradient - req->scratch, as pgv_tap_replicas() partial copies -
 // came out of the same launches)
 int pgv_tap_replicas(int c_gy, int kk);
+// pgv_bn_bwd_coef_from_gy with an explicit number of class-sum copies (pgv_coef_req.cls_copies)
+int pgv_bn_bwd_coef_from_gy_cc(const pgv_conv_desc* d, int lower_is_big, const float* gy, const float* cls, int cls_copies,
+                               double* T, const float* w, const float* gw, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, int64_t n, float* coef, float* ggamma, float* gbeta,
+                               int flags, hipStream_t st);
 int pgv_bn_bwd_coef_rep(const pgv_conv_desc* d, int lower_is_big, const float* w, const float* gw, const double* T, int trep,
                         const float* scale, const float* shift, const float* mean, const float* rstd, int64_t n,
                         float* coef, float* ggamma, float* gbeta, hipStream_t st);
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st);
+                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias,
+                      hipStream_t st);
+// (bias != null: the reduce launch also sums the block's bias-gradient copies into their destination, pgv_bias_req)
+int pgv_bias_finish(const pgv_bias_req* bias, hipStream_t st);   // the same as a launch of its own (other weight-gradient kernels)
 
 // Direct vector-ALU kernels for the 1 <-> 8 channel 5x5 layers (conv_direct.hip): tried first.
 int pgv_conv_down_direct(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float
       }
     }
     auto flush = [&](int cl, const float (&v)[NV]) {
-      if (fuse.gbias) atomicAdd(&fuse.gbias[cl], v[0]);
+      if (fuse.gbias) atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * CS : 0) + cl], v[0]);
       if constexpr (APRE) {
         if (fuse.cls) {
 #pragma unroll

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       if constexpr (NW == 1) {
         if ((lane & 15) == 0) {
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) atomicAdd(&fuse.gbias[(wm * MTW + m) * 4 + ech], vals[m]);
+          for (int m = 0; m < MTW; ++m) atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * CB : 0) + (wm * MTW + m) * 4 + ech], vals[m]);
         }
       } else {
         float* red = tile0;  // [NW][CB]
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
               float v = 0.f;
 #pragma unroll
               for (int j = 0; j < NW; ++j) v += red[j * CB + cl];
-              atomicAdd(&fuse.gbias[cl], v);
+              atomicAdd(&fuse.gbias[(fuse.gbias_copies ? (blockIdx.x & (PGV_CLS_COPIES - 1)) * CB : 0) + cl], v);
             }
           }
         }

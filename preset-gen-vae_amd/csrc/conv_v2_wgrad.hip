@@ -277,8 +277,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(int B, const floa
 // gw[e] (+)= sum over the workgroups' partial gradients.  A block = 8 float4 elements x 32 slices of the partials: with
 // 256 partials every thread has its 8 loads in flight at once - the pass costs about one memory round trip (a thread
 // that walks 32 partials one after the other made this kernel take 10 us).
+// One more role of the reduce launches (pgv_bias_req): the block's bias gradient from the per-XCD partial copies its
+// producer kept (pgv_bwd_fuse.gbias_copies) - workgroups behind the reduce (and border) ones, a thread per channel.
+struct BiasFin {
+  const float* copies; float* gbias; int C, accumulate;
+};
+__device__ __forceinline__ void bias_finish_role(const BiasFin& b, int blk) {
+  const int c = blk * 256 + threadIdx.x;
+  if (c >= b.C) return;
+  float t = b.accumulate ? b.gbias[c] : 0.f;
+#pragma unroll
+  for (int r = 0; r < PGV_CLS_COPIES; ++r) t += b.copies[r * b.C + c];
+  b.gbias[c] = t;
+}
+inline BiasFin bias_fin(const pgv_bias_req* b) {
+  BiasFin f = {nullptr, nullptr, 0, 0};
+  if (b) f.copies = b->copies, f.gbias = b->gbias, f.C = b->C, f.accumulate = b->accumulate;
+  return f;
+}
+inline int bias_blocks(const pgv_bias_req* b) { return b ? (b->C + 255) / 256 : 0; }
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int n4,
-                                                           float* __restrict__ gw, int accumulate) {
+                                                           float* __restrict__ gw, int accumulate, BiasFin bf, int nred) {
+  if ((int)blockIdx.x >= nred) {
+    bias_finish_role(bf, blockIdx.x - nred);
+    return;
+  }
   __shared__ f32x4 red[32][8];
   const int el = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int e = blockIdx.x * 8 + el;
@@ -317,6 +341,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct WgradTapsArgs {
   const float* partial; int nparts, n4; float* gw; int accumulate, nred;
   const float* gy; int B, Cgy, H, W, per, nsplit, gy_is_big, s, p; TapBorder tb; const float* cls; double* T; int trep;
+  int cls_copies, ntap; BiasFin bf;
 };
 template <int K>
 __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a) {
@@ -349,6 +374,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a)
       if (a.accumulate) sv += *o;
       *o = sv;
     }
+  } else if ((int)blockIdx.x >= a.nred + a.ntap) {
+    bias_finish_role(a.bf, blockIdx.x - a.nred - a.ntap);
   } else {
     const int bid = blockIdx.x - a.nred;
     const int c = bid % a.Cgy, r = bid / a.Cgy, by = r % a.nsplit, bz = r / a.nsplit;
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(WgradTapsArgs a)
       if (by == 0 && bz == 0) {   // the class total enters once per channel
         const int m = a.gy_is_big ? a.s : 1;
         const int rho = a.gy_is_big ? (((kh - a.p) % a.s) + a.s) % a.s : 0, kap = a.gy_is_big ? (((kw - a.p) % a.s) + a.s) % a.s : 0;
-        const int ncopy = a.gy_is_big ? PGV_CLS_COPIES : 1;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls)
+        const int ncopy = a.cls_copies;   // (partial copies by XCD of the producers: pgv_bwd_fuse.cls / gbias_copies)
         for (int q = 0; q < ncopy; ++q) t += (double)a.cls[(q * a.Cgy + c) * m * m + rho * m + kap];
       }
       atomicAdd(&a.T[(int64_t)(r % a.trep) * a.Cgy * KK + (int64_t)c * KK + tid], t);   // (copies: tap_replicas)
@@ -385,19 +412,23 @@ inline bool wgrad_taps_setup(const pgv_conv_desc* d, const pgv_coef_req* req, co
   a->gy = gy_is_big ? big : small_in;
   a->B = d->B, a->Cgy = C, a->H = H, a->W = W, a->gy_is_big = gy_is_big, a->s = d->stride, a->p = d->pad;
   a->cls = req->cls, a->T = req->scratch, a->trep = tap_replicas(C, K * K);
-  *nblocks = a->nred + C * a->nsplit * nz;
+  a->cls_copies = req->cls_copies > 0 ? req->cls_copies : (gy_is_big ? PGV_CLS_COPIES : 1);
+  a->ntap = C * a->nsplit * nz;
+  *nblocks = a->nred + a->ntap;
   return true;
 }
 
 // reduce + border launch; 1 when launched, 0 when the border form does not apply (the caller reduces on its own)
-inline int launch_wgrad_reduce_taps(const pgv_conv_desc* d, const pgv_coef_req* req, const float* big,
-                                    const float* small_in, const float* partial, int nparts, int n4, float* gw,
-                                    hipStream_t st) {
+inline int launch_wgrad_reduce_taps(const pgv_conv_desc* d, const pgv_coef_req* req, const pgv_bias_req* bias,
+                                    const float* big, const float* small_in, const float* partial, int nparts, int n4,
+                                    float* gw, hipStream_t st) {
   WgradTapsArgs a;
+  a.bf = bias_fin(bias);
   a.partial = partial, a.nparts = nparts, a.n4 = n4, a.gw = gw;
   a.accumulate = (d->flags & PGV_PREZEROED) ? 1 : 0, a.nred = (n4 + 7) / 8;
   int nblocks = 0;
   if (!wgrad_taps_setup(d, req, big, small_in, &a, &nblocks)) return 0;
+  nblocks += bias_blocks(bias);
   if (d->kh == 4)
     hipLaunchKernelGGL(wgrad_reduce_taps_kernel<4>, dim3(nblocks), dim3(256), 0, st, a);
   else
@@ -628,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
 template <int R>
 int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* small_in, const float* small_scale,
                      const float* small_shift, float* gw, void* workspace, int64_t workspace_bytes,
-                     const pgv_coef_req* req, hipStream_t st) {
+                     const pgv_coef_req* req, const pgv_bias_req* bias, hipStream_t st) {
   using G = Wgrad5Cfg<8, 347, 257, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -645,11 +676,11 @@ int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* smal
   PGV_CHECK_LAUNCH("conv_wgrad5_v2");
   const int n4 = 8 * G::NTAP / 4;
   if (req) {   // reduce + the tap sums of the output gradient in one launch (3: the caller goes on with the coefficients)
-    const int rc = launch_wgrad_reduce_taps(d, req, big, small_in, (const float*)workspace, nparts, n4, gw, st);
+    const int rc = launch_wgrad_reduce_taps(d, req, bias, big, small_in, (const float*)workspace, nparts, n4, gw, st);
     if (rc) return rc < 0 ? rc : 3;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, nparts, n4, gw,
-                     (d->flags & PGV_PREZEROED) ? 1 : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8 + bias_blocks(bias)), dim3(256), 0, st, (const float*)workspace,
+                     nparts, n4, gw, (d->flags & PGV_PREZEROED) ? 1 : 0, bias_fin(bias), (n4 + 7) / 8);
   PGV_CHECK_LAUNCH("conv_wgrad5_v2 reduce");
   return 1;
 }
@@ -657,7 +688,8 @@ int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* smal
 template <int CB, int CS, int W, int H, int R>
 int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                     const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                    void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st) {
+                    void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias,
+                    hipStream_t st) {
   using G = WgradV2Cfg<CB, CS, W, H, R>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -677,12 +709,12 @@ int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_s
   PGV_CHECK_LAUNCH("conv_wgrad_v2");
   const int n4 = CS * CB * 16 / 4;
   if (req) {   // reduce + the tap sums of the output gradient in one launch (3: the caller goes on with the coefficients)
-    const int rc = launch_wgrad_reduce_taps(d, req, big, small_in, (const float*)workspace, grid, n4, gw, st);
+    const int rc = launch_wgrad_reduce_taps(d, req, bias, big, small_in, (const float*)workspace, grid, n4, gw, st);
     if (rc) return rc < 0 ? rc : 3;
   }
   // PGV_PREZEROED: gw holds zeros or an earlier partial sum to add to; otherwise it is overwritten
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8), dim3(256), 0, st, (const float*)workspace, grid, n4, gw,
-                     (d->flags & PGV_PREZEROED) ? 1 : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8 + bias_blocks(bias)), dim3(256), 0, st, (const float*)workspace,
+                     grid, n4, gw, (d->flags & PGV_PREZEROED) ? 1 : 0, bias_fin(bias), (n4 + 7) / 8);
   PGV_CHECK_LAUNCH("conv_wgrad_v2 reduce");
   return 1;
 }
@@ -702,22 +734,31 @@ int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d) {
   return 0;
 }
 
+__global__ __launch_bounds__(256) void bias_finish_kernel(BiasFin bf) { bias_finish_role(bf, blockIdx.x); }
+int pgv_bias_finish(const pgv_bias_req* bias, hipStream_t st) {
+  if (!bias || bias->C <= 0) return PGV_OK;
+  hipLaunchKernelGGL(bias_finish_kernel, dim3(bias_blocks(bias)), dim3(256), 0, st, bias_fin(bias));
+  PGV_CHECK_LAUNCH("bias_finish");
+  return PGV_OK;
+}
+
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, hipStream_t st) {
+                      void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias,
+                      hipStream_t st) {
   if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->B > 0 &&
       d->Cb == 1 && d->Cs == 8 && d->Hb == 257 && d->Wb == 347 && !big_scale)
-    return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, st);
+    return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, bias, st);
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if ((d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
   if (d->Hb == 33 && d->Wb == 45)
     return launch_wgrad_v2<32, 64, 45, 33, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                              workspace, workspace_bytes, req, st);
+                                              workspace, workspace_bytes, req, bias, st);
   if (d->Hb == 65 && d->Wb == 88)
     return launch_wgrad_v2<16, 32, 88, 65, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                              workspace, workspace_bytes, req, st);
+                                              workspace, workspace_bytes, req, bias, st);
   if (d->Hb == 129 && d->Wb == 174)
     return launch_wgrad_v2<8, 16, 174, 129, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
-                                               workspace, workspace_bytes, req, st);
+                                               workspace, workspace_bytes, req, bias, st);
   return 0;
 }

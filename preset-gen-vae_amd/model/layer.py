@@ -337,6 +337,14 @@ class ConvStackFn(torch.autograd.Function):
         n_cls = sum(ops.CLS_COPIES * 4 * blocks[i].c_out for i in range(nb) if wants_cls(i))   # (partial copies per XCD)
         cls_arena = _step_zeros(params[0], n_cls, torch.float32, 'cls', dev) if n_cls else None
         c_off = 0
+        # bias gradients that a fused input gradient produces: as per-XCD partial copies too (the same-address atomics of
+        # 256 workgroups finishing together cost those kernels 3-6 us each), added up by the reduce launch of the block's
+        # own weight gradient (ops.conv_wgrad, bias_finish)
+        n_gbc = sum(ops.CLS_COPIES * blocks[i].c_out for i in range(nb - 1) if passfree[i])
+        gbc_arena = _step_zeros(params[0], n_gbc, torch.float32, 'gbc', dev) if n_gbc else None
+        b_off = 0
+        bias_pending = None      # (copies, destination, accumulate) of the current block's bias gradient, if it came as copies
+        gb_is_copies = False
         for li in range(nb - 1, -1, -1):
             blk = blocks[li]
             inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
@@ -400,8 +408,10 @@ class ConvStackFn(torch.autograd.Function):
                     t_off += tap_slot(li - 1)
                     # class sums of g_y: for a Conv2d consumer simply this block's bias gradient; for a ConvTranspose2d
                     # one the sums by row / column parity class
+                    cls_copies = 0
                     if not blk.up:
                         cls = gb_cur.reshape(-1)
+                        cls_copies = ops.CLS_COPIES if gb_is_copies else 0
                     elif cls_cur is not None:
                         cls = cls_cur
                     else:
@@ -411,25 +421,27 @@ class ConvStackFn(torch.autograd.Function):
                     gbt_low, grads[pl + 3] = _grad_dest(params[pl + 3])
                     coef_req = dict(lower_is_big=not blk.up, cls=cls, w=w, scale=in_scale, shift=in_shift, mean=mean_low,
                                     rstd=rstd_low, n=a_low.numel() // Cl, coef=coef, ggamma=gg_low, gbeta=gbt_low,
-                                    scratch=T)
+                                    scratch=T, cls_copies=cls_copies)
                 elif low.bn is not None:   # eval-mode BatchNorm: g_a = scale * g
                     coef = torch.cat([in_scale, torch.zeros(2 * Cl, device=dev, dtype=torch.float32)])
                 else:                      # no BatchNorm (the first encoder block): activation backward only
                     coef = _identity_coef(Cl, dev)
                 gb_low, grads[pl + 1], gb_zero = _grad_dest(params[pl + 1], accumulated=True)
-                if not gb_zero:
-                    gb_low.zero_()
+                gb_copies = gbc_arena[b_off:b_off + ops.CLS_COPIES * Cl]
+                b_off += ops.CLS_COPIES * Cl
+                bias_next = (gb_copies, gb_low.reshape(-1), False)
                 cls_low = None
                 if wants_cls(li - 1):
                     cls_low = cls_arena[c_off:c_off + ops.CLS_COPIES * 4 * Cl]
                     c_off += ops.CLS_COPIES * 4 * Cl
-                fuse = (a_low, coef, gb_low, low.act, low.slope, cls_low)
+                fuse = (a_low, coef, gb_copies, low.act, low.slope, cls_low, ops.CLS_COPIES)
             if blk.up:   # ConvTranspose2d: big = g_y, small = block input (folded BN of the producer)
                 ops.conv_wgrad(geom, g_y, inp, gw, small_scale=in_scale, small_shift=in_shift, prezeroed=gw_zero,
-                               coef_req=coef_req)
+                               coef_req=coef_req, bias_finish=bias_pending)
             else:        # Conv2d: big = block input, small = g_y
                 ops.conv_wgrad(geom, inp, g_y, gw, big_scale=in_scale, big_shift=in_shift, prezeroed=gw_zero,
-                               coef_req=coef_req)
+                               coef_req=coef_req, bias_finish=bias_pending)
+            bias_pending, gb_is_copies = None, False
             # (announced only now: the coefficient arithmetic reads this block's bias and weight gradients, which a
             # gradient exchange rewrites in place)
             _grad_done(params[pi + 1], w)
@@ -441,6 +453,7 @@ class ConvStackFn(torch.autograd.Function):
                 if fuse is not None:
                     g_y_fused, g_o = g_o, None
                     gb_cur, cls_cur = fuse[2], fuse[5]
+                    bias_pending, gb_is_copies = bias_next, True
                     low = blocks[li - 1]
                     pl = pis[li - 1]
                     if low.bn is not None and saved[li - 1][5] is not None:

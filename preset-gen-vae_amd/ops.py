@@ -79,7 +79,7 @@ class ConvGeom:
 
 
 def _fuse_arg(bwd_fuse, out):
-    """``bwd_fuse`` = (a, coef, gbias, act, slope[, cls]): the call's product is the gradient of the BatchNorm output of
+    """``bwd_fuse`` = (a, coef, gbias, act, slope[, cls[, gbias_copies]]): the call's product is the gradient of the BatchNorm output of
     the next-lower block; its BatchNorm + activation backward ``act'(a) * (coef[0]*g + coef[1]*a + coef[2])`` is applied
     before the store, ``gbias`` (caller-cleared, may be None) receives the bias gradient and ``cls`` (optional,
     caller-cleared [C*4]) the sums of the result by (row parity, column parity) class (``pgv_bwd_fuse``)."""
@@ -87,14 +87,17 @@ def _fuse_arg(bwd_fuse, out):
         return None
     a, coef, gbias, act, slope = bwd_fuse[:5]
     cls = bwd_fuse[5] if len(bwd_fuse) > 5 else None
+    gbias_copies = int(bwd_fuse[6]) if len(bwd_fuse) > 6 else 0
     _chk(a, coef, gbias, cls)
+    if gbias_copies not in (0, CLS_COPIES) or (gbias_copies and (gbias is None or gbias.numel() != CLS_COPIES * a.shape[1])):
+        raise ValueError("bwd_fuse: gbias_copies must be 0 or CLS_COPIES, with gbias holding CLS_COPIES * C floats")
     if a.shape != out.shape:
         raise ValueError("bwd_fuse: saved activation and output shapes differ")
-    if coef.numel() != 3 * a.shape[1] or (gbias is not None and gbias.numel() != a.shape[1]):
+    if coef.numel() != 3 * a.shape[1] or (gbias is not None and not gbias_copies and gbias.numel() != a.shape[1]):
         raise ValueError("bwd_fuse: coef must hold 3*C floats and gbias C floats")
     if cls is not None and cls.numel() != CLS_COPIES * 4 * a.shape[1]:
         raise ValueError("bwd_fuse: cls must hold CLS_COPIES * 4 * C floats")
-    return _lib.BwdFuse(_p(a), _p(coef), _p(gbias), int(act), float(slope), _p(cls))
+    return _lib.BwdFuse(_p(a), _p(coef), _p(gbias), int(act), float(slope), _p(cls), gbias_copies)
 
 
 def bn_src(stats, n, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, mean,
@@ -196,36 +199,47 @@ def coef_scratch(geom, lower_is_big):
 
 
 def conv_wgrad(geom, big, small, gw, big_scale=None, big_shift=None, small_scale=None, small_shift=None,
-               prezeroed=False, coef_req=None):
+               prezeroed=False, coef_req=None, bias_finish=None):
     """``prezeroed``: ``gw`` already holds zeros (e.g. a slice of the zero_grad'ed flat gradient buffer).
     ``coef_req``: also the BatchNorm-backward coefficients of the block below (``pgv_conv_wgrad_coef``) - a dict with the
-    fields of ``pgv_coef_req``; ``scratch`` is zeroed float64 of ``coef_scratch(geom, lower_is_big)`` elements."""
+    fields of ``pgv_coef_req``; ``scratch`` is zeroed float64 of ``coef_scratch(geom, lower_is_big)`` elements; ``cls_copies``
+    (optional) = CLS_COPIES when ``cls`` of a Conv2d consumer is a bias gradient kept as partial copies.
+    ``bias_finish`` = (copies [CLS_COPIES * C], gbias [C], accumulate): also this block's bias gradient from the partial
+    copies its producer kept (``pgv_bias_req``), in the reduce launch of the weight gradient."""
     B = big.shape[0]
     _chk(big, small, gw, big_scale, big_shift, small_scale, small_shift)
     lib = _lib.load()
     d = geom.desc(B, int(prezeroed))
     nbytes = lib.pgv_conv_wgrad_workspace(ctypes.byref(d))
     ws = _workspace(big.device, nbytes)
-    if coef_req is None:
+    if coef_req is None and bias_finish is None:
         _lib.check(lib.pgv_conv_wgrad(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small),
                                       _p(small_scale), _p(small_shift), _p(gw), _p(ws), nbytes, _stream()),
                    "pgv_conv_wgrad")
         return gw
-    r = coef_req
-    lower_is_big = bool(r['lower_is_big'])
-    _chk(r['cls'], r['w'], r['scale'], r['shift'], r['mean'], r['rstd'], r['coef'], r.get('ggamma'), r.get('gbeta'))
-    _chk64(r['scratch'])
-    c_low, c_gy = (geom.Cb, geom.Cs) if lower_is_big else (geom.Cs, geom.Cb)
-    if r['scratch'].numel() < coef_scratch(geom, lower_is_big):
-        raise ValueError("conv_wgrad: coef_req scratch needs coef_scratch(geom, lower_is_big) doubles")
-    if r['coef'].numel() < 3 * c_low:
-        raise ValueError("conv_wgrad: coef_req coef needs 3*C_lower floats")
-    req = _lib.CoefReq(int(lower_is_big), _p(r['cls']), _p(r['w']), _p(r['scale']), _p(r['shift']), _p(r['mean']),
-                       _p(r['rstd']), int(r['n']), _p(r['coef']), _p(r.get('ggamma')), _p(r.get('gbeta')),
-                       _p(r['scratch']))
-    _lib.check(lib.pgv_conv_wgrad_coef(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small),
-                                       _p(small_scale), _p(small_shift), _p(gw), _p(ws), nbytes, ctypes.byref(req),
-                                       _stream()), "pgv_conv_wgrad_coef")
+    req = bias = None
+    if coef_req is not None:
+        r = coef_req
+        lower_is_big = bool(r['lower_is_big'])
+        _chk(r['cls'], r['w'], r['scale'], r['shift'], r['mean'], r['rstd'], r['coef'], r.get('ggamma'), r.get('gbeta'))
+        _chk64(r['scratch'])
+        c_low = geom.Cb if lower_is_big else geom.Cs
+        if r['scratch'].numel() < coef_scratch(geom, lower_is_big):
+            raise ValueError("conv_wgrad: coef_req scratch needs coef_scratch(geom, lower_is_big) doubles")
+        if r['coef'].numel() < 3 * c_low:
+            raise ValueError("conv_wgrad: coef_req coef needs 3*C_lower floats")
+        req = _lib.CoefReq(int(lower_is_big), _p(r['cls']), _p(r['w']), _p(r['scale']), _p(r['shift']), _p(r['mean']),
+                           _p(r['rstd']), int(r['n']), _p(r['coef']), _p(r.get('ggamma')), _p(r.get('gbeta')),
+                           _p(r['scratch']), int(r.get('cls_copies', 0)))
+    if bias_finish is not None:
+        copies, gb, acc = bias_finish
+        _chk(copies, gb)
+        if copies.numel() != CLS_COPIES * gb.numel():
+            raise ValueError("conv_wgrad: bias_finish copies must hold CLS_COPIES * C floats")
+        bias = _lib.BiasReq(_p(copies), _p(gb), gb.numel(), int(bool(acc)))
+    _lib.check(lib.pgv_conv_wgrad_ex(ctypes.byref(d), _p(big), _p(big_scale), _p(big_shift), _p(small), _p(small_scale),
+                                     _p(small_shift), _p(gw), _p(ws), nbytes, None if req is None else ctypes.byref(req),
+                                     None if bias is None else ctypes.byref(bias), _stream()), "pgv_conv_wgrad_ex")
     return gw
 
 

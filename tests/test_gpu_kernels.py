@@ -457,6 +457,49 @@ def test_conv_tap_sums(ops, case):
 
 @pytest.mark.parametrize("policy", [0, 3])
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 3), (16, 32, 4, 2, 2, 65, 88, 3), (32, 64, 4, 2, 2, 33, 45, 5),
+                                  (1, 8, 5, 2, 2, 257, 347, 2), (3, 5, 4, 2, 2, 10, 13, 2)])
+def test_bias_gradient_through_partial_copies(ops, case, policy):
+    """pgv_bwd_fuse.gbias_copies + pgv_bias_req: a fused input gradient adds the lower block's bias gradient into per-XCD
+    partial copies, the reduce launch of that block's own weight gradient adds them up - the same bias gradient as the
+    one-copy form, the same weight gradient as without the request (also on top of an earlier value: accumulate)."""
+    from preset_gen_vae_amd import _lib
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    lib = _lib.load()
+    lib.pgv_set_kernel_policy(policy)
+    try:
+        for up in (False, True):   # consumer is a Conv2d (its input gradient = conv_up) / a ConvTranspose2d (conv_down)
+            gy_shape = (B, Cs, geom.Hs, geom.Ws) if not up else (B, Cb, Hb, Wb)
+            lo_shape = (B, Cb, Hb, Wb) if not up else (B, Cs, geom.Hs, geom.Ws)
+            Cl = lo_shape[1]
+            gy, a = dev(synth_vec(gy_shape, 0.7719, 1.1)), dev(synth_vec(lo_shape, 0.9137, 0.3) * 1.5)
+            w = dev(synth_vec((Cs, Cb, k, k), 0.6180, 0.7) * 0.1)
+            coef = torch.cat([torch.ones(Cl, device='cuda'), 0.01 * dev(synth_vec((2 * Cl,), 1.7, 0.2))])
+            conv = ops.conv_up if not up else ops.conv_down
+            gb1 = torch.zeros(Cl, device='cuda')
+            g1 = conv(geom, gy, w, None, 0, 0.0, bwd_fuse=(a, coef, gb1, 1, 0.1))
+            copies = torch.zeros(ops.CLS_COPIES * Cl, device='cuda')
+            g2 = conv(geom, gy, w, None, 0, 0.0, bwd_fuse=(a, coef, copies, 1, 0.1, None, ops.CLS_COPIES))
+            assert torch.equal(g1, g2)
+            # the lower block's own weight gradient (any geometry whose gradient tensor is g2 will do: reuse this one with
+            # g2 in the role of the tensor of its shape) carries the bias request
+            big_t, small_t = (g2, dev(synth_vec((B, Cs, geom.Hs, geom.Ws), 0.31, 0.4))) if not up else \
+                (dev(synth_vec((B, Cb, Hb, Wb), 0.31, 0.4)), g2)
+            gw_ref, gw = torch.empty_like(w), torch.empty_like(w)
+            ops.conv_wgrad(geom, big_t, small_t, gw_ref)
+            for acc, start in ((False, float('nan')), (True, 0.25)):
+                gb2 = torch.full((Cl,), start, device='cuda')
+                ops.conv_wgrad(geom, big_t, small_t, gw, bias_finish=(copies, gb2, acc))
+                # (not bit-equal: the round-1 weight-gradient kernels accumulate with float atomics)
+                assert (gw - gw_ref).abs().max().item() <= 1e-5 * gw_ref.abs().max().item()
+                tol = 2e-6 * g1.abs().sum().item() / Cl + 1e-6
+                assert (gb2 - (0.25 if acc else 0.0) - gb1).abs().max().item() <= tol, (up, acc)
+    finally:
+        lib.pgv_set_kernel_policy(0)
+
+
+@pytest.mark.parametrize("policy", [0, 3])
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 3), (16, 32, 4, 2, 2, 65, 88, 3), (32, 64, 4, 2, 2, 33, 45, 5),
                                   (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2)])
 def test_conv_finalizes_the_input_batchnorm(ops, case, policy):
     """pgv_conv_down_bn / pgv_conv_up_bn / pgv_dropout_fwd_bn (pgv_bn_src): the consumer kernel finalizes its input's
@@ -601,6 +644,11 @@ def test_bn_backward_without_a_pass(ops, case, policy):
                 coef3, gg3, gbt3 = torch.empty_like(coef), torch.empty_like(gg), torch.empty_like(gbt)
                 req = dict(lower_is_big=lower_is_big, cls=cls, w=w_d, scale=sc_d, shift=sh_d, mean=mu_d, rstd=rs_d,
                            n=B * H * W, coef=coef3, ggamma=gg3, gbeta=gbt3, scratch=T3)
+                if lower_is_big and prior is not None:
+                    # the class sums of a Conv2d consumer = its bias gradient, here kept as partial copies (cls_copies)
+                    spread = torch.zeros(ops.CLS_COPIES, cls.numel(), device='cuda')
+                    spread[1], spread[6] = 0.25 * cls, 0.75 * cls
+                    req.update(cls=spread.reshape(-1), cls_copies=ops.CLS_COPIES)
                 if lower_is_big:
                     ops.conv_wgrad(geom, a_d, gy_d, gw3, big_scale=sc_d, big_shift=sh_d, prezeroed=prior is not None,
                                    coef_req=req)
