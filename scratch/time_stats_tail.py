@@ -6,7 +6,7 @@ import bench
 from preset_gen_vae_amd import ops
 B = 256
 dev = torch.device('cuda', 0)
-for (Cb, Cs, k, Hb, Wb) in ((8, 16, 4, 129, 174), (16, 32, 4, 65, 88), (32, 64, 4, 33, 45)):
+for (Cb, Cs, k, Hb, Wb) in ((8, 16, 4, 129, 174), (16, 32, 4, 65, 88), (32, 64, 4, 33, 45), (64, 128, 4, 17, 23), (128, 256, 4, 9, 12), (256, 512, 4, 5, 7)):
     geom = ops.ConvGeom(Cb, Cs, k, 2, 2, Hb, Wb)
     big = torch.randn(B, Cb, Hb, Wb, device=dev); small = torch.randn(B, Cs, geom.Hs, geom.Ws, device=dev)
     w = torch.randn(Cs, Cb, k, k, device=dev) * 0.05
