@@ -409,6 +409,50 @@ int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, int hop, int
              float norm, const int32_t* mel_row_ptr, const int32_t* mel_col, const float* mel_val, int n_mels,
              int out_mode, float floor_lin, float affine_a, float affine_b, float* out, void* stream);
 
+/* ---- preset-parameter losses and metrics (model/loss.py:72-315) ------------------------ */
+/* Tables of a PresetIndexesHelper, all DEVICE pointers (built once per helper by the caller):
+ *   num_idx[n_num]        learnable columns of the numerical parameters (get_numerical_learnable_indexes)
+ *   cat_idx[n_groups][K]  columns of every one-hot group, padded with -1 (get_categorical_learnable_indexes)
+ *   rule_trig[n_rules]    useless-parameter rules (data/preset.py:259-281): rule r fires for a row when
+ *                         u_in[row][rule_trig[r]] < 1e-3 (a Dexed operator at zero output level); n_rules <= 32
+ *   num_rules[n_num], cat_rules[n_groups]   bit r set: the column / group is useless when rule r fires. */
+typedef struct pgv_params_tables {
+  int32_t n_num;
+  const int32_t* num_idx;
+  const uint32_t* num_rules;
+  int32_t n_groups, K;
+  const int32_t* cat_idx;
+  const uint32_t* cat_rules;
+  int32_t n_rules;
+  const int32_t* rule_trig;
+} pgv_params_tables;
+#define PGV_PARAMS_CCE 0         /* cat_bce=False, cat_softmax=False: -log of the target's probability */
+#define PGV_PARAMS_CCE_SOFTMAX 1 /* cat_softmax=True: softmax(q / softmax_t) first (loss.py:166-167) */
+#define PGV_PARAMS_BCE 2         /* cat_bce=True: F.binary_cross_entropy(mean) / 8 (loss.py:172-174) */
+/* SynthParamsLoss.__call__ (loss.py:118-183) and its gradient in one launch: loss[0] = numerical term (nn.MSELoss
+ * 'mean' if normalize else L2Loss = sum / B, useless columns zeroed on both sides) + cat_factor * sum over groups of the
+ * categorical term over the group's useful rows (/ n_groups if normalize); grad[B][L] (nullable) = d loss / d u_out,
+ * zero in columns that no term reads.  u_in is not modified (the reference zeroes useless columns in place).
+ * workspace: 8 * (1 + min(B, 1024)) bytes whose FIRST 8 BYTES ARE ZERO before the first call (an arrival counter that
+ * every call leaves at zero); private to the call until it completes. */
+int pgv_params_loss(const float* u_out, const float* u_in, int B, int L, const pgv_params_tables* t, int mode,
+                    float softmax_t, int normalize, float cat_factor, float* loss, float* grad, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+/* The column pairs the two metrics compare, one item per VST parameter (tables are device pointers):
+ *   PGV_PARAMS_COL_QUANTIZED     in = u_in[first], out = round(u_out[first] * (card-1)) / (card-1) if card > 0 else
+ *                                u_out[first]                        (QuantizedNumericalParamsLoss, loss.py:231-240)
+ *   PGV_PARAMS_COL_ONEHOT_VALUE  argmax over idx[first .. first+len) / (len-1) on both sides          (loss.py:242-252)
+ *   PGV_PARAMS_COL_CLASS         round(u[first] * (card-1)) on both sides       (CategoricalParamsAccuracy, :287-297)
+ *   PGV_PARAMS_COL_ONEHOT_CLASS  argmax over idx[first .. first+len) on both sides                          (:299-306)
+ * in_cols / out_cols [B][n_items] (nullable), match[n_items] (nullable) = fraction of rows with in == out. */
+#define PGV_PARAMS_COL_QUANTIZED 0
+#define PGV_PARAMS_COL_ONEHOT_VALUE 1
+#define PGV_PARAMS_COL_CLASS 2
+#define PGV_PARAMS_COL_ONEHOT_CLASS 3
+int pgv_params_columns(const float* u_out, const float* u_in, int B, int L, int n_items, const int32_t* kind,
+                       const int32_t* first, const int32_t* len, const float* card, const int32_t* idx, float* in_cols,
+                       float* out_cols, float* match, void* stream);
+
 /* ---- misc -------------------------------------------------------------------------------------------- */
 int pgv_fill(float* p, int64_t n, float v, void* stream);
 /* y = a*x + y */

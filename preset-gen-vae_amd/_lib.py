@@ -66,6 +66,17 @@ class BiasReq(Structure):
 
 _BIAS = POINTER(BiasReq)
 
+
+class ParamsTables(Structure):
+    """Mirror of ``pgv_params_tables``: the index tables of a PresetIndexesHelper (device pointers)."""
+    _fields_ = [("n_num", c_int32), ("num_idx", c_void_p), ("num_rules", c_void_p), ("n_groups", c_int32), ("K", c_int32),
+                ("cat_idx", c_void_p), ("cat_rules", c_void_p), ("n_rules", c_int32), ("rule_trig", c_void_p)]
+
+
+_PT = POINTER(ParamsTables)
+PGV_PARAMS_CCE, PGV_PARAMS_CCE_SOFTMAX, PGV_PARAMS_BCE = 0, 1, 2
+PGV_PARAMS_COL_QUANTIZED, PGV_PARAMS_COL_ONEHOT_VALUE, PGV_PARAMS_COL_CLASS, PGV_PARAMS_COL_ONEHOT_CLASS = 0, 1, 2, 3
+
 # name -> (restype, argtypes); must list every function include/pgv_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
     "pgv_abi_version": (c_int, []),
@@ -131,6 +142,8 @@ SIGNATURES = {
     "pgv_stft": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_int, c_float,
                          c_float, c_float, _P, _P]),
     "pgv_fill": (c_int, [_P, c_int64, c_float, _P]),
+    "pgv_params_loss": (c_int, [_P, _P, c_int, c_int, _PT, c_int, c_float, c_int, c_float, _P, _P, _P, c_int64, _P]),
+    "pgv_params_columns": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_axpy": (c_int, [c_int64, c_float, _P, _P, _P]),
     "pgv_copy": (c_int, [_P, _P, c_int64, _P]),
 }

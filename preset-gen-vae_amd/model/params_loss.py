@@ -1,4 +1,5 @@
-"""Preset-regression losses and metrics evaluated ON THE DEVICE without host synchronisation.
+"""Preset-regression losses and metrics evaluated ON THE DEVICE by the HIP kernels of ``csrc/params_loss.hip``, without
+host synchronisation.
 
 Mirrors of the reference's ``model/loss.py``:
 
@@ -8,10 +9,13 @@ Mirrors of the reference's ``model/loss.py``:
 * ``QuantizedNumericalParamsLoss`` (:187-261): numerical VST parameters after the synth's quantisation;
 * ``CategoricalParamsAccuracy`` (:265-315).
 
-The reference walks rows, parameters and groups in Python and calls ``.item()`` per group; here every group is a
-padded row of one index matrix, so a call is a handful of gathers / masked reductions and returns device scalars
-(``CategoricalParamsAccuracy`` with ``reduce=False`` is the only path that reads values back, once).  Unlike the
-reference (loss.py:134-135) the inputs are not modified in place.
+The reference walks rows, parameters and groups in Python and calls ``.item()`` per group; here the helper's index
+lists become device tables once (``ops.params_tables`` / ``ops.params_item_tables``) and a call is ONE launch:
+``pgv_params_loss`` returns the loss and its gradient w.r.t. the network output (a workgroup per row, a thread per
+numerical column / one-hot group, deterministic cross-workgroup sum), ``pgv_params_columns`` the column pairs and match
+rates of the two metrics (+ ``pgv_sqerr_fwd`` for the quantised MSE).  ``CategoricalParamsAccuracy`` with
+``reduce=False`` is the only path that reads values back, once.  Unlike the reference (loss.py:134-135) the inputs are
+not modified in place.  Like every other op of the package there is no CPU path: tensors must live on a ROCm device.
 
 Useless-parameter rules: ``idx_helper.useless_rules`` = ``[(trigger_learn_idx, [num_learn_idx...],
 [cat_first_learn_idx...]), ...]`` (a row's listed parameters are useless when ``u_in[row, trigger] < 1e-3``) if the
@@ -19,9 +23,8 @@ helper provides it, else the Dexed rule built from ``full_to_learnable`` exactly
 else none."""
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from . import loss as _loss
+from .. import ops
 
 
 def _dexed_useless_rules(idx_helper):
@@ -57,6 +60,26 @@ def _useless_rules(idx_helper):
     return []
 
 
+class _ParamsLossFn(torch.autograd.Function):
+    """loss, d loss / d u_out from one ``pgv_params_loss`` launch; backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, u_out, u_in, crit):
+        loss, grad = ops.params_loss(u_out, u_in, crit._tables_on(u_in.device), crit._mode, crit.cat_softmax_t,
+                                     crit.normalize_losses, crit.cat_loss_factor, want_grad=u_out.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return (grad * g if grad is not None else None), None, None
+
+
+def _f32c(t):
+    return t.detach().float().contiguous() if not (t.dtype == torch.float32 and t.is_contiguous()) else t
+
+
 class SynthParamsLoss:
     def __init__(self, idx_helper, normalize_losses, categorical_loss_factor=0.2, prevent_useless_params_loss=True,
                  cat_bce=True, cat_softmax=False, cat_softmax_t=0.1):
@@ -68,120 +91,65 @@ class SynthParamsLoss:
         self.cat_bce, self.cat_softmax, self.cat_softmax_t = cat_bce, cat_softmax, cat_softmax_t
         self.cat_loss_factor = categorical_loss_factor
         self.prevent_useless_params_loss = prevent_useless_params_loss
-        self.numerical_criterion = _loss.MSELoss(reduction='mean') if normalize_losses else _loss.L2Loss()
         self.num_indexes = list(idx_helper.get_numerical_learnable_indexes())
         self.cat_indexes = [list(g) for g in idx_helper.get_categorical_learnable_indexes()]
         self._rules = _useless_rules(idx_helper) if prevent_useless_params_loss else []
+        self._mode = ops.PARAMS_BCE if cat_bce else (ops.PARAMS_CCE_SOFTMAX if cat_softmax else ops.PARAMS_CCE)
         self._tables = {}
 
-    def _dev_tables(self, device, L):
-        key = (str(device), L)
-        t = self._tables.get(key)
-        if t is not None:
-            return t
-        G = len(self.cat_indexes)
-        K = max((len(g) for g in self.cat_indexes), default=1)
-        idx = torch.zeros((G, K), dtype=torch.long)
-        valid = torch.zeros((G, K), dtype=torch.bool)
-        for gi, g in enumerate(self.cat_indexes):
-            idx[gi, :len(g)] = torch.tensor(g, dtype=torch.long)
-            valid[gi, :len(g)] = True
-        first_to_group = {g[0]: gi for gi, g in enumerate(self.cat_indexes)}
-        R = len(self._rules)
-        trig = torch.tensor([r[0] for r in self._rules], dtype=torch.long)
-        num_member = torch.zeros((R, L), dtype=torch.float32)
-        cat_member = torch.zeros((R, max(G, 1)), dtype=torch.float32)
-        for ri, (_, nums, cats) in enumerate(self._rules):
-            for n in nums:
-                num_member[ri, n] = 1.0
-            for c in cats:
-                if c in first_to_group:
-                    cat_member[ri, first_to_group[c]] = 1.0
-        t = {'num_idx': torch.tensor(self.num_indexes, dtype=torch.long, device=device),
-             'cat_idx': idx.to(device), 'cat_valid': valid.to(device), 'trig': trig.to(device),
-             'num_member': num_member.to(device), 'cat_member': cat_member.to(device)}
-        self._tables[key] = t
+    def _tables_on(self, device):
+        t = self._tables.get(device)
+        if t is None:
+            t = self._tables[device] = ops.params_tables(device, self.num_indexes, self.cat_indexes, self._rules)
         return t
 
     def __call__(self, u_out, u_in):
         """Categorical parameters must be one-hot encoded.  Returns a 0-d tensor on the inputs' device."""
-        B, L = u_in.shape
-        t = self._dev_tables(u_in.device, L)
-        useless_num = useless_cat = None
-        if self._rules:
-            off = (u_in[:, t['trig']] < 1e-3).to(u_in.dtype)                 # [B, R]
-            useless_num = (off @ t['num_member']) > 0                          # [B, L]
-            useless_cat = (off @ t['cat_member']) > 0                          # [B, G]
-        num_loss = 0.0
-        if len(self.num_indexes) > 0:
-            a, b = u_out[:, t['num_idx']], u_in[:, t['num_idx']]
-            if useless_num is not None:                                        # loss.py:128-135 zeroes both sides
-                keep = ~useless_num[:, t['num_idx']]
-                a, b = a * keep, b * keep
-            num_loss = self.numerical_criterion(a.contiguous(), b.contiguous())
-        cat_loss = 0.0
-        G = len(self.cat_indexes)
-        if G > 0:
-            q = u_out[:, t['cat_idx']]                                         # [B, G, K]
-            p = u_in[:, t['cat_idx']]
-            valid = t['cat_valid'].unsqueeze(0)                                # [1, G, K]
-            row_ok = torch.ones((B, G), dtype=torch.bool, device=u_in.device) if useless_cat is None else ~useless_cat
-            n_rows = row_ok.sum(dim=0).to(u_out.dtype)                         # useful rows per group
-            if not self.cat_bce:
-                if self.cat_softmax:
-                    q = torch.softmax((q / self.cat_softmax_t).masked_fill(~valid, float('-inf')), dim=2)
-                target = p.bool() & valid
-                # one probability per row and group (one-hot target): -sum log q_target / useful rows (loss.py:166-171)
-                logq = torch.log(torch.where(target, q, torch.ones_like(q))).sum(dim=2)        # [B, G]
-                per_group = -(logq * row_ok).sum(dim=0) / n_rows
-            else:
-                bce = F.binary_cross_entropy(q, p, reduction='none')           # [B, G, K]
-                k_g = t['cat_valid'].sum(dim=1).to(u_out.dtype)                                # group sizes
-                per_group = (bce * valid * row_ok.unsqueeze(2)).sum(dim=(0, 2)) / (n_rows * k_g) / 8.0
-            cat_loss = per_group.sum()
-            if self.normalize_losses:
-                cat_loss = cat_loss / G
-        return num_loss + cat_loss * self.cat_loss_factor
+        u_in = _f32c(u_in)
+        if u_out.dtype != torch.float32 or not u_out.is_contiguous():
+            u_out = u_out.float().contiguous()
+        return _ParamsLossFn.apply(u_out, u_in, self)
 
 
 class QuantizedNumericalParamsLoss:
-    """loss.py:187-261 (detached: a metric, not differentiable)."""
+    """loss.py:187-261 (detached: a metric, not differentiable).  ``numerical_loss`` None = nn.MSELoss() evaluated by
+    ``pgv_sqerr_fwd``; any other criterion is called on the two column matrices ``pgv_params_columns`` produced."""
 
     def __init__(self, idx_helper, numerical_loss=None, limited_vst_params_indexes=None):
         self.idx_helper = idx_helper
-        self.numerical_loss = numerical_loss if numerical_loss is not None else torch.nn.MSELoss()
+        if isinstance(numerical_loss, torch.nn.MSELoss) and numerical_loss.reduction == 'mean':
+            numerical_loss = None
+        self.numerical_loss = numerical_loss
         for vst_idx in idx_helper.num_idx_learned_as_cat:
             assert idx_helper.vst_param_cardinals[vst_idx] > 0
         self.limited_vst_params_indexes = limited_vst_params_indexes
         lim = limited_vst_params_indexes
-        self._as_num = [(v, l) for v, l in idx_helper.num_idx_learned_as_num.items() if lim is None or v in lim]
-        self._as_cat = [(v, list(l)) for v, l in idx_helper.num_idx_learned_as_cat.items() if lim is None or v in lim]
+        self._items = [(ops._lib.PGV_PARAMS_COL_QUANTIZED, l, idx_helper.vst_param_cardinals[v])
+                       for v, l in idx_helper.num_idx_learned_as_num.items() if lim is None or v in lim]
+        self._items += [(ops._lib.PGV_PARAMS_COL_ONEHOT_VALUE, list(l), len(l))
+                        for v, l in idx_helper.num_idx_learned_as_cat.items() if lim is None or v in lim]
         self.num_params_count = len(idx_helper.num_idx_learned_as_num) + len(idx_helper.num_idx_learned_as_cat)
+        self._tables = {}
 
     @torch.no_grad()
     def __call__(self, u_out, u_in):
-        dev, dt = u_in.device, u_in.dtype
-        cols_in, cols_out = [], []
-        if self._as_num:
-            idx = torch.tensor([l for _, l in self._as_num], dtype=torch.long, device=dev)
-            card = torch.tensor([float(self.idx_helper.vst_param_cardinals[v]) for v, _ in self._as_num], device=dev,
-                                dtype=dt)
-            o = u_out[:, idx]
-            quant = torch.round(o * (card - 1.0)) / (card - 1.0)
-            cols_in.append(u_in[:, idx])
-            cols_out.append(torch.where(card > 0, quant, o))                   # cardinal < 0: continuous parameter
-        for _, learn in self._as_cat:
-            idx = torch.tensor(learn, dtype=torch.long, device=dev)
-            c = float(len(learn))
-            cols_in.append((torch.argmax(u_in[:, idx], dim=-1).to(dt) / (c - 1.0)).unsqueeze(1))
-            cols_out.append((torch.argmax(u_out[:, idx], dim=-1).to(dt) / (c - 1.0)).unsqueeze(1))
-        n_used = sum(c.shape[1] for c in cols_in)
-        if self.limited_vst_params_indexes is not None and n_used < self.num_params_count:
-            # the reference pre-allocates num_params_count columns and leaves the unused ones at zero (loss.py:222-224)
-            pad = torch.zeros((u_in.shape[0], self.num_params_count - n_used), device=dev, dtype=dt)
-            cols_in.append(pad)
-            cols_out.append(pad)
-        return self.numerical_loss(torch.cat(cols_out, dim=1), torch.cat(cols_in, dim=1))
+        u_out, u_in = _f32c(u_out), _f32c(u_in)
+        t = self._tables.get(u_in.device)
+        if t is None:
+            t = self._tables[u_in.device] = ops.params_item_tables(u_in.device, self._items)
+        B, n_used = u_in.shape[0], len(self._items)
+        # the reference pre-allocates num_params_count columns and leaves the unused ones at zero (loss.py:222-224)
+        n_cols = self.num_params_count if self.limited_vst_params_indexes is not None else n_used
+        if n_used == 0:
+            cols_in = cols_out = torch.zeros((B, n_cols), device=u_in.device)
+        else:
+            cols_in, cols_out, _ = ops.params_columns(u_out, u_in, t, want_match=False)
+        if self.numerical_loss is None:
+            return ops.sqerr_fwd(cols_out, cols_in, 1.0 / (B * n_cols)) if n_used else cols_in.sum() / (B * n_cols)
+        if n_cols > n_used:
+            pad = torch.zeros((B, n_cols - n_used), device=u_in.device)
+            cols_in, cols_out = torch.cat([cols_in, pad], dim=1), torch.cat([cols_out, pad], dim=1)
+        return self.numerical_loss(cols_out, cols_in)
 
 
 class CategoricalParamsAccuracy:
@@ -193,28 +161,27 @@ class CategoricalParamsAccuracy:
         self.reduce = reduce
         self.percentage_output = percentage_output
         self.limited_vst_params_indexes = limited_vst_params_indexes
+        lim = limited_vst_params_indexes
+        self._keys, self._items = [], []
+        for vst_idx, learn_idx in idx_helper.cat_idx_learned_as_num.items():
+            if lim is None or vst_idx in lim:
+                self._keys.append(vst_idx)
+                self._items.append((ops._lib.PGV_PARAMS_COL_CLASS, learn_idx, idx_helper.vst_param_cardinals[vst_idx]))
+        for vst_idx, learn_indexes in idx_helper.cat_idx_learned_as_cat.items():
+            if lim is None or vst_idx in lim:
+                self._keys.append(vst_idx)
+                self._items.append((ops._lib.PGV_PARAMS_COL_ONEHOT_CLASS, list(learn_indexes), len(learn_indexes)))
+        self._tables = {}
 
     @torch.no_grad()
     def __call__(self, u_out, u_in):
-        lim = self.limited_vst_params_indexes
-        keys, accs = [], []
-        for vst_idx, learn_idx in self.idx_helper.cat_idx_learned_as_num.items():
-            if lim is not None and vst_idx not in lim:
-                continue
-            card = float(self.idx_helper.vst_param_cardinals[vst_idx])
-            tgt = torch.round(u_in[:, learn_idx] * (card - 1.0)).to(torch.int32)
-            out = torch.round(u_out[:, learn_idx] * (card - 1.0)).to(torch.int32)
-            keys.append(vst_idx)
-            accs.append((tgt == out).to(torch.float32).mean())
-        for vst_idx, learn_indexes in self.idx_helper.cat_idx_learned_as_cat.items():
-            if lim is not None and vst_idx not in lim:
-                continue
-            idx = torch.tensor(list(learn_indexes), dtype=torch.long, device=u_in.device)
-            keys.append(vst_idx)
-            accs.append((torch.argmax(u_in[:, idx], dim=-1) == torch.argmax(u_out[:, idx], dim=-1))
-                        .to(torch.float32).mean())
-        acc = torch.stack(accs) * (100.0 if self.percentage_output else 1.0)
+        u_out, u_in = _f32c(u_out), _f32c(u_in)
+        t = self._tables.get(u_in.device)
+        if t is None:
+            t = self._tables[u_in.device] = ops.params_item_tables(u_in.device, self._items)
+        _, _, match = ops.params_columns(u_out, u_in, t, want_cols=False)
+        acc = match * (100.0 if self.percentage_output else 1.0)
         if self.reduce:
             return acc.mean()
         vals = acc.cpu().numpy()
-        return {k: float(v) for k, v in zip(keys, np.asarray(vals, dtype=np.float64))}
+        return {k: float(v) for k, v in zip(self._keys, np.asarray(vals, dtype=np.float64))}

@@ -658,3 +658,93 @@ def fill(t, v):
 def copy(src, dst):
     _chk(src, dst)
     _lib.check(_lib.load().pgv_copy(_p(src), _p(dst), src.numel(), _stream()), "pgv_copy")
+
+
+# ---- preset-parameter losses and metrics -------------------------------------------------------------
+PARAMS_CCE, PARAMS_CCE_SOFTMAX, PARAMS_BCE = _lib.PGV_PARAMS_CCE, _lib.PGV_PARAMS_CCE_SOFTMAX, _lib.PGV_PARAMS_BCE
+_PARAMS_WS = {}
+
+
+def params_tables(device, num_idx, cat_groups, rules):
+    """``pgv_params_tables`` of a PresetIndexesHelper on ``device``: ``num_idx`` the numerical learnable columns,
+    ``cat_groups`` the one-hot groups (lists of columns), ``rules`` = [(trigger column, [numerical columns], [first
+    columns of groups]), ...] (data/preset.py:259-281).  The returned structure keeps its device tensors alive."""
+    if len(rules) > 32:
+        raise ValueError("at most 32 useless-parameter rules")
+    G, K = len(cat_groups), max((len(g) for g in cat_groups), default=1)
+    i32 = dict(dtype=torch.int32, device=device)
+    cat = torch.full((max(G, 1), K), -1, dtype=torch.int32)
+    for gi, g in enumerate(cat_groups):
+        cat[gi, :len(g)] = torch.tensor(list(g), dtype=torch.int32)
+    first_to_group = {g[0]: gi for gi, g in enumerate(cat_groups)}
+    num_pos = {c: i for i, c in enumerate(num_idx)}
+    num_rules, cat_rules = [0] * max(len(num_idx), 1), [0] * max(G, 1)
+    for r, (_, nums, cats) in enumerate(rules):
+        for n in nums:
+            if n in num_pos:
+                num_rules[num_pos[n]] |= 1 << r
+        for c in cats:
+            if c in first_to_group:
+                cat_rules[first_to_group[c]] |= 1 << r
+    keep = (torch.tensor(list(num_idx) or [0], **i32), torch.tensor(num_rules, dtype=torch.int64).to(**i32),
+            cat.to(device), torch.tensor(cat_rules, dtype=torch.int64).to(**i32),
+            torch.tensor([r[0] for r in rules] or [0], **i32))
+    t = _lib.ParamsTables(len(num_idx), _p(keep[0]), _p(keep[1]), G, K, _p(keep[2]), _p(keep[3]), len(rules), _p(keep[4]))
+    t._keep = keep
+    return t
+
+
+def params_loss(u_out, u_in, tables, mode, softmax_t, normalize, cat_factor, want_grad=True):
+    """``pgv_params_loss``: (loss 0-d tensor, d loss / d u_out or None) of SynthParamsLoss in one launch."""
+    _chk(u_out, u_in)
+    if u_out.shape != u_in.shape or u_out.dim() != 2:
+        raise ValueError("params_loss: u_out and u_in must be [B, L] tensors of the same shape")
+    B, L = u_in.shape
+    key = (u_in.device, _stream())
+    need = 8 * (1 + min(B, 1024))
+    ws = _PARAMS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        # zeroed once: the arrival counter in its first word is left at zero by every call.  A superseded buffer stays
+        # alive (a captured graph may still replay into it).
+        _PARAMS_WS.setdefault('_old', []).append(ws)
+        ws = torch.zeros(max(need, 8 * 1025), dtype=torch.uint8, device=u_in.device)
+        _PARAMS_WS[key] = ws
+    loss = torch.empty((), device=u_in.device, dtype=torch.float32)
+    grad = torch.empty_like(u_out) if want_grad else None
+    _lib.check(_lib.load().pgv_params_loss(_p(u_out), _p(u_in), B, L, ctypes.byref(tables), int(mode), float(softmax_t),
+                                           int(bool(normalize)), float(cat_factor), _p(loss), _p(grad), _p(ws), ws.numel(),
+                                           _stream()), "pgv_params_loss")
+    return loss, grad
+
+
+def params_item_tables(device, items):
+    """Item tables of ``pgv_params_columns``: ``items`` = [(kind, column or list of columns, cardinal), ...]."""
+    kind, first, length, card, idx = [], [], [], [], []
+    for k, cols, c in items:
+        kind.append(int(k))
+        if isinstance(cols, (list, tuple)):
+            first.append(len(idx))
+            length.append(len(cols))
+            idx += [int(v) for v in cols]
+        else:
+            first.append(int(cols))
+            length.append(1)
+        card.append(float(c))
+    i32 = dict(dtype=torch.int32, device=device)
+    return (torch.tensor(kind or [0], **i32), torch.tensor(first or [0], **i32), torch.tensor(length or [0], **i32),
+            torch.tensor(card or [0.0], dtype=torch.float32, device=device), torch.tensor(idx or [0], **i32), len(items))
+
+
+def params_columns(u_out, u_in, item_tables, want_cols=True, want_match=True):
+    """``pgv_params_columns``: (in_cols [B, n], out_cols [B, n], match [n]) for the items of ``params_item_tables``."""
+    _chk(u_out, u_in)
+    kind, first, length, card, idx, n = item_tables
+    B, L = u_in.shape
+    f32 = dict(device=u_in.device, dtype=torch.float32)
+    in_cols = torch.empty((B, n), **f32) if want_cols else None
+    out_cols = torch.empty((B, n), **f32) if want_cols else None
+    match = torch.empty((n,), **f32) if want_match else None
+    _lib.check(_lib.load().pgv_params_columns(_p(u_out), _p(u_in), B, L, n, _p(kind), _p(first), _p(length), _p(card),
+                                              _p(idx), _p(in_cols), _p(out_cols), _p(match), _stream()),
+               "pgv_params_columns")
+    return in_cols, out_cols, match

@@ -153,3 +153,60 @@ class MiniPresetIndexesHelper:
                 nums += n
                 cats += c
         return nums, cats
+
+
+class RandomPresetIndexesHelper(MiniPresetIndexesHelper):
+    """A seeded Dexed-sized learnable representation (numerical columns, one-hot groups of 2..32 classes, six 'operator
+    volume' rules that make numerical columns and groups useless, a few columns no term reads) for the f4 kernels."""
+
+    def __init__(self, seed=0, n_num=60, n_groups=40, n_rules=6, n_unused=5):
+        import random
+        rnd = random.Random(seed)
+        sizes = [rnd.choice([2, 3, 4, 5, 8, 12, 32]) for _ in range(n_groups)]
+        cols = list(range(n_num + sum(sizes) + n_unused))
+        rnd.shuffle(cols)
+        self._num = sorted(cols[:n_num])
+        pos, self._groups = n_num, []
+        for s in sizes:
+            self._groups.append(sorted(cols[pos:pos + s]))
+            pos += s
+        self.learnable_preset_size = len(cols)
+        trig = self._num[:n_rules]
+        others = self._num[n_rules:]
+        self.useless_rules = []
+        for r in range(n_rules):
+            nums = rnd.sample(others, 6)
+            cats = [g[0] for g in rnd.sample(self._groups, 5)]
+            self.useless_rules.append((trig[r], nums, cats))
+        n_as_num = n_num - 8
+        self.num_idx_learned_as_num = {v: c for v, c in enumerate(self._num[:n_as_num])}
+        self.cat_idx_learned_as_num = {1000 + i: c for i, c in enumerate(self._num[n_as_num:])}
+        half = n_groups // 2
+        self.num_idx_learned_as_cat = {2000 + i: g for i, g in enumerate(self._groups[:half])}
+        self.cat_idx_learned_as_cat = {3000 + i: g for i, g in enumerate(self._groups[half:])}
+        self.vst_param_cardinals = {v: rnd.choice([-1, 2, 5, 17, 100]) for v in self.num_idx_learned_as_num}
+        self.vst_param_cardinals.update({v: rnd.choice([2, 3, 7]) for v in self.cat_idx_learned_as_num})
+        self.vst_param_cardinals.update({v: len(g) for v, g in self.num_idx_learned_as_cat.items()})
+        self.vst_param_cardinals.update({v: len(g) for v, g in self.cat_idx_learned_as_cat.items()})
+
+    def get_numerical_learnable_indexes(self):
+        return list(self._num)
+
+    def get_categorical_learnable_indexes(self):
+        return [list(g) for g in self._groups]
+
+    def random_batch(self, B, seed=1):
+        """(u_in one-hot targets with some zero 'volumes', u_out probabilities in (0, 1)) as float64 CPU tensors."""
+        import torch
+        gen = torch.Generator().manual_seed(seed)
+        L = self.learnable_preset_size
+        u_in = torch.rand((B, L), generator=gen, dtype=torch.float64)
+        u_out = torch.rand((B, L), generator=gen, dtype=torch.float64) * 0.9 + 0.05
+        for g in self._groups:
+            cls = torch.randint(0, len(g), (B,), generator=gen)
+            u_in[:, g] = 0.0
+            u_in[torch.arange(B), torch.tensor(g)[cls]] = 1.0
+        for trig, _, _ in self.useless_rules:
+            off = torch.rand((B,), generator=gen) < 0.3
+            u_in[off, trig] = 0.0
+        return u_in, u_out

@@ -651,6 +651,85 @@ def test_params_losses_on_device_f4():
     assert nums == g['dexed/useless_num'].tolist() and cats == g['dexed/useless_cat'].tolist()
 
 
+@pytest.mark.parametrize("B", [3, 256, 1500])
+def test_params_loss_kernels_vs_oracle_dexed_sized(B):
+    """f4 at working size: ``pgv_params_loss`` / ``pgv_params_columns`` on a Dexed-sized representation (60 numerical
+    columns, 40 one-hot groups of 2..32 classes, six useless-parameter rules) against the float64 CPU restatement of the
+    reference's loops (oracle/params_oracle.py, pinned by params_loss.npz): loss, gradient w.r.t. the network output,
+    quantised MSE, accuracies.  B = 1500 exceeds the grid cap (rows strided over workgroups); every call is repeated to
+    check that the arrival counter of the cross-workgroup sum is left ready."""
+    from helpers import RandomPresetIndexesHelper
+    from oracle import params_oracle as po
+    from preset_gen_vae_amd.model import params_loss as pl
+    helper = RandomPresetIndexesHelper(seed=5)
+    u_in64, u_out64 = helper.random_batch(B, seed=B)
+    u_in, raw = _cuda32(u_in64), _cuda32(u_out64)
+    u_in64, u_out64 = u_in.double().cpu(), raw.double().cpu()              # the float32 values, in float64
+    variants = {'cce_softmax': dict(cat_bce=False, cat_softmax=True, cat_softmax_t=0.2),
+                'cce_probs': dict(cat_bce=False, cat_softmax=False), 'bce': dict(cat_bce=True, cat_softmax=False)}
+    for norm in (True, False):
+        for useless in (True, False):
+            for name, kw in variants.items():
+                crit = pl.SynthParamsLoss(helper, norm, categorical_loss_factor=0.2,
+                                          prevent_useless_params_loss=useless, **kw)
+                ref_in = u_out64.clone().requires_grad_(True)
+                ref = po.synth_params_loss(ref_in, u_in64, helper, norm, prevent_useless_params_loss=useless, **kw)
+                ref.backward()
+                for _ in range(2):
+                    u_out = raw.clone().requires_grad_(True)
+                    loss = crit(u_out, u_in)
+                    (3.0 * loss).backward()
+                    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (name, norm, useless)
+                    assert rel_l2(u_out.grad / 3.0, ref_in.grad) < 1e-5, (name, norm, useless)
+    q = pl.QuantizedNumericalParamsLoss(helper)(raw, u_in)
+    assert abs(q.item() - po.quantized_numerical_params_loss(u_out64.float(), u_in64.float(), helper).item()) < 1e-6
+    lim = list(helper.num_idx_learned_as_num)[:7] + list(helper.num_idx_learned_as_cat)[:3]
+    q = pl.QuantizedNumericalParamsLoss(helper, torch.nn.L1Loss(), limited_vst_params_indexes=lim)(raw, u_in)
+    a, b = u_out64.float(), u_in64.float()
+    ref_cols = po.quantized_numerical_params_loss                        # same columns, L1 instead of MSE
+    import torch.nn.functional as F
+    orig = F.mse_loss
+    try:
+        F.mse_loss = F.l1_loss
+        ref_q = ref_cols(a, b, helper, lim).item()
+    finally:
+        F.mse_loss = orig
+    assert abs(q.item() - ref_q) < 1e-6
+    accd = pl.CategoricalParamsAccuracy(helper, reduce=False, percentage_output=False)(raw, u_in)
+    ref_acc = po.categorical_params_accuracy(a, b, helper, percentage_output=False)
+    assert list(accd.keys()) == list(ref_acc.keys())
+    assert max(abs(accd[k] - ref_acc[k]) for k in ref_acc) < 1e-6
+    acc = pl.CategoricalParamsAccuracy(helper)(raw, u_in)
+    assert abs(acc.item() - 100.0 * sum(ref_acc.values()) / len(ref_acc)) < 1e-3
+
+
+def test_params_loss_is_one_launch_and_graph_safe():
+    """The f4 loss is capture-safe (no allocation inside the call apart from torch's caching allocator, no host
+    synchronisation): a captured call replays to the same value."""
+    from helpers import RandomPresetIndexesHelper
+    from preset_gen_vae_amd import ops
+    helper = RandomPresetIndexesHelper(seed=2)
+    u_in64, u_out64 = helper.random_batch(64, seed=9)
+    u_in, u_out = _cuda32(u_in64), _cuda32(u_out64)
+    from preset_gen_vae_amd.model import params_loss as pl
+    crit = pl.SynthParamsLoss(helper, True, cat_bce=False, cat_softmax=True)
+    eager = crit(u_out, u_in).item()
+    tables = crit._tables_on(u_in.device)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.params_loss(u_out, u_in, tables, crit._mode, crit.cat_softmax_t, True, crit.cat_loss_factor)   # workspace
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            loss, grad = ops.params_loss(u_out, u_in, tables, crit._mode, crit.cat_softmax_t, True, crit.cat_loss_factor)
+    for _ in range(3):
+        loss.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert loss.item() == eager
+
+
 def test_train_step_l2loss_unnormalized_vs_golden():
     """normalize_losses=False (train.py:105-106: loss.L2Loss; Dkl / B): the golden's ``train/l2loss`` and
     ``train/latent_unnormalized`` and the oracle's gradients for that configuration."""
