@@ -16,6 +16,19 @@
 // v_mfma_f32_16x16x16_bf16 per (channel, tile) instead of four fp32 steps.
 #include "conv_tile.h"
 
+#ifdef PGV_DEEP_STAMPS
+__device__ unsigned long long g_deep_stamps[8 * 64 * 8];
+extern "C" int pgv_debug_read_stamps(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_deep_stamps), sizeof(unsigned long long) * n);
+}
+#define DEEP_STAMP(s, k)                                                                                  \
+  do {                                                                                                    \
+    if (blockIdx.x == PGV_DEEP_STAMPS && lane == 0 && (s) < 64) g_deep_stamps[((threadIdx.x >> 6) * 64 + (s)) * 8 + (k)] = clock64(); \
+  } while (0)
+#else
+#define DEEP_STAMP(s, k)
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -44,25 +57,33 @@ __device__ __forceinline__ void deep_block(int nmb, int groups, int& mb, int& gr
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
 // GEMM: M = cs (64 per workgroup, 16 per wave), N = the NS*Hs*Ws output pixels of NS samples, K = (cb, 16 taps).
-template <int H, int W, int NS, int CK>
+template <int H, int W, int NS, int CK, int NTHR = 512>
 struct DeepDown {
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
-  static constexpr int HP = 2 * Hs + 2, WP = 2 * Ws + 2, PLANE = HP * WP;  // rows / cols -2 .. 2*Hs-1 / 2*Ws-1
+  // rows / cols -2 .. 2*Hs-1 / 2*Ws-1.  Row and plane strides are padded so that the 16 lanes of a B-fragment read
+  // (ds_read2_b64: banks (a/4) mod 32, 16 contiguous lanes per LDS cycle; lane = output pixel n -> address
+  // si*PLANE + (2 oh + kh)*WP + 2 ow) fall on distinct banks: with WP = Ws (mod 16) and PLANE/2 = P (mod 16) the bank pair
+  // of pixel n is n mod 16.  Unpadded (WP = 2 Ws + 2) the reads of the 5x7 / 9x12 / 17x23 layers took 2.0 / 2.6 / 1.9
+  // LDS cycles per group instead of 1 (SQ_LDS_BANK_CONFLICT = 0.41-0.57 of SQ_LDS_IDX_ACTIVE); 9x12 (odd Ws) keeps 1.6.
+  static constexpr int HP = 2 * Hs + 2;
+  static constexpr int WP = (H == 5 && W == 7) ? 12 : (H == 9 && W == 12) ? 26 : (H == 17 && W == 23) ? 28 : 2 * Ws + 2;
+  static constexpr int PLANE = (H == 5 && W == 7 && NS == 4) ? 104 : (H == 9 && W == 12 && NS == 2) ? 330 : HP * WP;
+  static_assert(WP >= 2 * Ws + 2 && PLANE >= HP * WP, "padded plane");
   static constexpr int N = NS * P, NT = (N + 15) / 16;
   static constexpr int AS = CK * 16 + 4;                 // weight row stride: 16-byte aligned, banks spread by 4
   static constexpr int A_FLOATS = 64 * AS;
   static constexpr int CH_STRIDE = NS * PLANE;
   static constexpr int B_FLOATS = CK * CH_STRIDE;
   static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
-  static constexpr int QA = 64 * CK * 4 / 256;           // float4 weight loads per thread per slab
+  static constexpr int QA = 64 * CK * 4 / NTHR;           // float4 weight loads per thread per slab
   static constexpr int QB_ITEMS = NS * CK * HW / 4;      // float4 plane loads per slab (whole workgroup)
-  static constexpr int QB = (QB_ITEMS + 255) / 256;
-  static_assert(CK % 4 == 0 && (CK * HW) % 4 == 0, "16-byte plane runs");
+  static constexpr int QB = (QB_ITEMS + NTHR - 1) / NTHR;
+  static_assert(CK % 4 == 0 && (CK * HW) % 4 == 0 && (64 * CK * 4) % NTHR == 0, "16-byte plane runs");
   static_assert(PLANE % 2 == 0 && WP % 2 == 0, "8-byte aligned tap rows");
 };
 
 template <int H, int W, int NS, int CK, bool BF16>
-__global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, const float* __restrict__ big,
+__global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, const float* __restrict__ big,
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
@@ -71,24 +92,32 @@ __global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, c
   using G = DeepDown<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 8 waves: waves 0-3 and 4-7 hold the same 64 x N output tile and split the channels of every K slab between them
+  // (kg = 0 / 1: channels [0, CK/2) / [CK/2, CK)), added up through LDS before the epilogue.  With 4-wave workgroups a
+  // SIMD saw 2 waves (one per co-resident workgroup), both in the same phase: the period of a slab was the SUM of its
+  // matrix time and its LDS time (fragment reads, commit).  4 waves per SIMD interleave the two.
+  constexpr int NTHR = 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, kg = wave8 >> 2;
   const int m = lane & 15, j = lane >> 4;
   int mb, grp;
   deep_block(CS / 64, groups, mb, grp);
   const int cs0 = mb * 64, b0 = grp * NS;
 
   // zero both stages' planes once (the data cells are rewritten every slab, the padding never)
-  for (int i = tid; i < G::B_FLOATS; i += 256) {
+  for (int i = tid; i < G::B_FLOATS; i += NTHR) {
     lds[G::A_FLOATS + i] = 0.f;
     lds[G::STAGE + G::A_FLOATS + i] = 0.f;
   }
-  stage_affine(aff, in_scale, in_shift, CB, tid);
+  for (int i = tid; i < CB; i += NTHR) {   // identity when the input carries no folded BatchNorm: the commit is branch-free
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[CB + i] = in_scale ? in_shift[i] : 0.f;
+  }
 
   // ---- loader coordinates (identical for every slab)
   int a_src[G::QA], a_dst[G::QA];
 #pragma unroll
   for (int i = 0; i < G::QA; ++i) {
-    const int q = tid + 256 * i, row = q / (CK * 4), f = q - row * (CK * 4);
+    const int q = tid + NTHR * i, row = q / (CK * 4), f = q - row * (CK * 4);
     a_src[i] = (cs0 + row) * CB * 16 + 4 * f;
     a_dst[i] = row * G::AS + 4 * f;
   }
@@ -96,8 +125,8 @@ __global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, c
   bool b_ok[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
-    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
-    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int q = min(tid + NTHR * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + NTHR * i < G::QB_ITEMS;
     const int si = q / (CK * G::HW / 4), qq = q - si * (CK * G::HW / 4);
     const int bs = min(b0 + si, B - 1);  // partial last group: duplicate the last sample (masked at the store)
     b_src[i] = bs * CB * G::HW + 4 * qq;
@@ -121,44 +150,91 @@ __global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, c
 #pragma unroll
   for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[G::QA], rb[G::QB];
-  auto issue = [&](int slab) {
-    const int cb0 = slab * CK;
-#pragma unroll
-    for (int i = 0; i < G::QA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + cb0 * 16);
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(big + b_src[i] + cb0 * G::HW);
+  // Loads run TWO slabs ahead of the MFMA loop in two register sets, and the commit of slab s+1 sits in the MIDDLE of slab
+  // s's MFMA block: its loads are then 1.5 slabs old (no wait), its LDS writes issue under the running matrix pipe, and
+  // the only non-MFMA time of a slab is its barrier.  (With one set, issued at the top of the slab and committed after the
+  // block, the commit phase waited for the loads and the two co-resident workgroups of a CU - which move in lockstep -
+  // left the pipe idle together: MFMA time and the load / commit skeleton of the kernel ADDED UP, 46 + 53 of 102 us on
+  // the 17x23 layer.)
+  struct RegSet {
+    f32x4 a[G::QA], b[G::QB];
   };
-  auto commit = [&](int slab, float* st) {
+  RegSet r0, r1;
+  // (the loads are inline asm with manual s_waitcnt: the compiler's counter model merges the two in-flight sets at the
+  // loop header and waits for BOTH at every commit - vmcnt(4..0) where vmcnt(9..5) is meant - which halves the distance)
+  constexpr int NLD = G::QA + G::QB;
+  auto issue = [&](int slab, RegSet& r) {
     const int cb0 = slab * CK;
 #pragma unroll
-    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = ra[i];
+    for (int i = 0; i < G::QA; ++i)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.a[i]) : "v"((a_src[i] + cb0 * 16) * 4), "s"(w) : "memory");
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.b[i]) : "v"((b_src[i] + cb0 * G::HW) * 4), "s"(big) : "memory");
+  };
+  // `younger`: the other set has been requested after this one and may stay in flight
+  auto wait_set = [&](RegSet& r, bool younger) {
+    if (younger)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) asm volatile("" : "+v"(r.a[i]));   // the values exist from here on
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) asm volatile("" : "+v"(r.b[i]));
+  };
+  // The folded-BatchNorm affine of the slab to commit is fetched from the LDS table at the START of the slab step, all
+  // 8 QB values at once: fetched inside the commit (one dependent LDS round trip per element, in a branch each) the
+  // commit of the plane data took 1500 (5x7) / 3200 (17x23) clocks of a 4900 / 9800-clock slab, with the other waves of
+  // the workgroup waiting at the barrier and the co-resident workgroup in the same phase.
+  float bsc[G::QB][4], bsh[G::QB][4];
+  auto fetch_aff = [&](int slab) {
+    const int cb0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bsc[i][e] = aff[cb0 + b_ch[i][e]];
+        bsh[i][e] = aff[CB + cb0 + b_ch[i][e]];
+      }
+  };
+  auto commit = [&](float* st, const RegSet& r) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<f32x4*>(st + a_dst[i]) = r.a[i];
     float* bt = st + G::A_FLOATS;
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(r.b[i][e], bsc[i][e], bsh[i][e]);
       if (b_ok[i]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = rb[i][e];
-          if (in_scale) v = fmaf(v, aff[cb0 + b_ch[i][e]], aff[CB + cb0 + b_ch[i][e]]);
-          bt[b_dst[i][e]] = v;
-        }
+        for (int e = 0; e < 4; ++e) bt[b_dst[i][e]] = v[e];
       }
     }
   };
 
   const int nslab = CB / CK;
-  issue(0);
-  __syncthreads();  // planes zeroed, affine staged
-  commit(0, lds);
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
+  // one slab: MFMA block over stage (s & 1); half way, slab s+1 (in `rn`) goes to the other stage and slab s+3 is
+  // requested into the registers it frees
+  auto slab_step = [&](int s, RegSet& rn) {
     const float* st = lds + (s & 1) * G::STAGE;
-    if (s + 1 < nslab) issue(s + 1);
     const float* ap = st + a_frag;
     const float* bp = st + G::A_FLOATS;
+    DEEP_STAMP(s, 0);
+    fetch_aff(min(s + 1, nslab - 1));
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the fetch to the commit)
 #pragma unroll
-    for (int ch = 0; ch < CK; ++ch) {
+    for (int cc = 0; cc < CK / 2; ++cc) {
+      const int ch = kg * (CK / 2) + cc;
+      if (cc == CK / 4 && s + 1 < nslab) {
+        DEEP_STAMP(s, 1);
+        wait_set(rn, s + 2 < nslab);
+        DEEP_STAMP(s, 2);
+        commit(lds + ((s + 1) & 1) * G::STAGE, rn);
+        if (s + 3 < nslab) issue(s + 3, rn);
+        DEEP_STAMP(s, 3);
+      }
       const f32x4 a = *reinterpret_cast<const f32x4*>(ap + ch * 16);
       if constexpr (BF16) {
         const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
@@ -176,10 +252,35 @@ __global__ __launch_bounds__(256) void deep_down_kernel(int B, int CB, int CS, c
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kw], bp[bn[t] + ch * G::CH_STRIDE + kw], acc[t], 0, 0, 0);
       }
     }
-    if (s + 1 < nslab) commit(s + 1, lds + ((s + 1) & 1) * G::STAGE);
+    DEEP_STAMP(s, 4);
     __syncthreads();
+    DEEP_STAMP(s, 5);
+  };
+  issue(0, r0);
+  if (nslab > 1) issue(1, r1);
+  __syncthreads();  // planes zeroed, affine staged
+  fetch_aff(0);
+  wait_set(r0, nslab > 1);
+  commit(lds, r0);
+  if (nslab > 2) issue(2, r0);
+  __syncthreads();
+  for (int s = 0; s < nslab; s += 2) {
+    slab_step(s, r1);
+    if (s + 1 < nslab) slab_step(s + 1, r0);
   }
 
+  // ---- the two K groups' partial tiles -> waves 0-3 (the last slab's barrier has passed: the stages are free)
+  {
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    if (kg == 1) {
+#pragma unroll
+      for (int t = 0; t < G::NT; ++t) red[(t * 4 + wave) * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) acc[t] += red[(t * 4 + wave) * 64 + lane];
+  }
   // ---- epilogue: acc[t][i] = channel cs0 + wave*16 + 4j + i, pixel n = t*16 + m
   const pgv_act_params ap = pgv_act_setup(act, slope);
   float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -232,7 +333,7 @@ int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_s
     return PGV_E_LAUNCH;
   }
   const int groups = (d->B + NS - 1) / NS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big,
                      in_scale, in_shift, w, bias, act, slope, out, stats, groups);
   PGV_CHECK_LAUNCH("conv_down_deep");
   return 1;
