@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
                                                         const float* __restrict__ in_shift,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int act, float slope, float* __restrict__ out,
-                                                        double* __restrict__ stats, int groups) {
+                                                        double* __restrict__ stats, int groups, int stat_stride) {
   using G = DeepDown<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CB]
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     }
   }
   if (stats) {
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
@@ -334,7 +335,8 @@ int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_s
   }
   const int groups = (d->B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big,
-                     in_scale, in_shift, w, bias, act, slope, out, stats, groups);
+                     in_scale, in_shift, w, bias, act, slope, out, stats, groups,
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0);
   PGV_CHECK_LAUNCH("conv_down_deep");
   return 1;
 }
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       int act, float slope, float* __restrict__ out,
-                                                      double* __restrict__ stats, int groups) {
+                                                      double* __restrict__ stats, int groups, int stat_stride) {
   using G = DeepUp<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CS]
@@ -537,6 +539,7 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
       }
     }
   if (stats) {
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
@@ -567,7 +570,8 @@ int launch_deep_up(const pgv_conv_desc* d, const float* small_in, const float* i
   }
   const int groups = (d->B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / 64))), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in,
-                     in_scale, in_shift, w, bias, act, slope, out, stats, groups);
+                     in_scale, in_shift, w, bias, act, slope, out, stats, groups,
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0);
   PGV_CHECK_LAUNCH("conv_up_deep");
   return 1;
 }
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
                                                      const float* __restrict__ in_shift,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      int act, float slope, float* __restrict__ out,
-                                                     double* __restrict__ stats, int groups) {
+                                                     double* __restrict__ stats, int groups, int stat_stride) {
   using G = K1Fwd<P, NS, CK, TRANSA>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -951,6 +955,7 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
     }
   }
   if (stats) {
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
                                                          const float* __restrict__ in_shift,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          int act, float slope, float* __restrict__ out,
-                                                         double* __restrict__ stats, int groups) {
+                                                         double* __restrict__ stats, int groups, int stat_stride) {
   constexpr int N = NS * P, NT = (N + 15) / 16, NTW = (NT + 1) / 2;   // column tiles per wave (parity split)
   constexpr int AS = CK + 4, A_FLOATS = 128 * AS, CH_STRIDE = NS * P, B_FLOATS = CK * CH_STRIDE;
   constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
@@ -1101,6 +1106,7 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
       }
     }
     if (stats) {
+      stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
@@ -1131,7 +1137,7 @@ int launch_k1_down128(int B, int CIN, int COUT, int flags, const float* in, cons
   }
   const int groups = (B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (COUT / 128))), dim3(512), bytes, st, B, CIN, COUT, in, in_scale,
-                     in_shift, w, bias, act, slope, out, stats, groups);
+                     in_shift, w, bias, act, slope, out, stats, groups, (flags & PGV_STATS_COPIES) ? 2 * COUT : 0);
   PGV_CHECK_LAUNCH(who);
   return 1;
 }
@@ -1154,7 +1160,7 @@ int launch_k1_fwd(int B, int CIN, int COUT, int flags, const float* in, const fl
   }
   const int groups = (B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (COUT / 64))), dim3(256), bytes, st, B, CIN, COUT, in, in_scale,
-                     in_shift, w, bias, act, slope, out, stats, groups);
+                     in_shift, w, bias, act, slope, out, stats, groups, (flags & PGV_STATS_COPIES) ? 2 * COUT : 0);
   PGV_CHECK_LAUNCH(who);
   return 1;
 }

@@ -179,11 +179,12 @@ class ConvStackFn(torch.autograd.Function):
         # costs ~5 us of dependent-launch latency each
         # (as CLS_COPIES partial copies each: the kernels' end-of-kernel atomics then stay inside their XCD's L2 - 256
         # workgroups finishing together on one copy cost the transposed-conv kernels 7-8 us per launch)
-        # (only for the large planes, whose kernels spread them: the deep layers' kernels add into one copy anyway)
+        # (every plane size: the deep-layer kernels spread them too - 17x23: 10 / 18 us per forward launch went into 256
+        # same-address float64 atomics per channel; families without copies add into copy 0)
         def stat_copies(blk, h, w):
             go = blk.geom(h, w)
             ho, wo = (go.Hb, go.Wb) if blk.up else (go.Hs, go.Ws)
-            return (ops.CLS_COPIES if ho * wo >= PASSFREE_MIN_PLANE else 1), ho, wo
+            return ops.CLS_COPIES, ho, wo
         n_stats, hh, ww = 0, x.shape[2], x.shape[3]
         for blk in blocks:
             sc_b, hh, ww = stat_copies(blk, hh, ww)
