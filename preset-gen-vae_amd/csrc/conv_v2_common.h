@@ -317,7 +317,9 @@ struct StageLean {
     // inline asm: see StageV2::issue_slot (the compiler's s_waitcnt bookkeeping would drain both sets in flight)
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(s.v[J]) : "v"(off), "s"(rsrc) : "memory");
   }
-  template <int J, bool EDGE, bool AFF>
+  // BF16 (PGV_COMPUTE_BF16): the committed operand is rounded to bfloat16, pairs through v_cvt_pk_bf16_f32 (3 instructions
+  // per two floats)
+  template <int J, bool EDGE, bool AFF, bool BF16 = false>
   static __device__ __forceinline__ void commit_slot(const Geo& g, const Set& s, float* __restrict__ tile, int tid,
                                                      unsigned bad) {
     if (256 * (J + 1) <= ITEMS || tid + 256 * J < ITEMS) {
@@ -330,6 +332,13 @@ struct StageLean {
         asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(lo), "v"(ma));
         asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(hi), "v"(ma));
         x = f32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      if (BF16) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 lo = {(__bf16)x.x, (__bf16)x.y}, hi = {(__bf16)x.z, (__bf16)x.w};
+        const unsigned ul = __builtin_bit_cast(unsigned, lo), uh = __builtin_bit_cast(unsigned, hi);
+        x = f32x4{__uint_as_float(ul << 16), __uint_as_float(ul & 0xFFFF0000u), __uint_as_float(uh << 16),
+                  __uint_as_float(uh & 0xFFFF0000u)};
       }
       if (ZTAIL && NP != 0) {
         const int km = __builtin_amdgcn_sbfe((int)g.whole, J, 1);  // -1: keep, 0: the row ends inside this chunk

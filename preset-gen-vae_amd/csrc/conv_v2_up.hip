@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv_up_ws_kernel(int B, const float* 
       item_geo(it, rs, bad);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // the older set has landed
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF>(geo, sx, dst, ltid, bad); });
+      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF, BF16>(geo, sx, dst, ltid, bad); });
     };
     issue_all(sB, 1);  // (item 0 went out during the set-up)
     commit_all(sA, 0, tile0);
@@ -791,7 +791,10 @@ int launch_up_v2(const pgv_conv_desc* d, const float* small_in, const float* in_
                        : (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 0, true>;
   }
   if (bf16) {   // operand-rounding instantiations exist for the 33x45 layer in the forms the train step issues
-    if constexpr (W == 45 && !STG) {
+    if constexpr (STG) {   // ... and for the 129x174 input gradient with the fused backward epilogue
+      if (!(fuse && !in_scale && actk == 0)) return 0;
+      kern = (kern_t)conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true, true>;
+    } else if constexpr (W == 45 && !STG) {
 #define PGV_UKB(F, A, C) (kern_t) conv_up_ws_kernel<CB, CS, W, H, R, MW, CK, F, A, C, false, true>
       if (fuse && !in_scale && actk == 0)
         kern = PGV_UKB(true, false, 0);
@@ -831,7 +834,8 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   // bf16 operand mode: only the 33x45 layer comes here (operands rounded at the LDS commit / weight load, fp32 MFMA: 95 us
   // against 157 us for the band kernel's bf16 loop at this shape; the other shapes' band kernels are faster than this form)
-  if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 33 && d->Wb == 45)) return 0;
+  // (and the fused 129x174 input gradient: 204 us on the band kernel's bf16 loop)
+  if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 33 && d->Wb == 45) && !(d->Hb == 129 && d->Wb == 174 && fuse)) return 0;
   // fused backward epilogue (pgv_bwd_fuse): 129x174 prefetches the saved activation during the k-steps (APRE), the
   // multi-chunk layers run a ring of buffer loads through the epilogue (WIN); only plain input-gradient products
   // (65x88: 128 accumulator registers leave no room for the ring - it spills; the band kernel's fused epilogue stays)
