@@ -92,12 +92,14 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
   using G = DeepDown<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CB]
-  // 8 waves: waves 0-3 and 4-7 hold the same 64 x N output tile and split the channels of every K slab between them
-  // (kg = 0 / 1: channels [0, CK/2) / [CK/2, CK)), added up through LDS before the epilogue.  With 4-wave workgroups a
-  // SIMD saw 2 waves (one per co-resident workgroup), both in the same phase: the period of a slab was the SUM of its
-  // matrix time and its LDS time (fragment reads, commit).  4 waves per SIMD interleave the two.
-  constexpr int NTHR = 512;
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, kg = wave8 >> 2;
+  // 8 waves = 2 (M: 32 output channels each, two 16-row MFMA tiles) x 4 (K: the channels of every slab dealt over four
+  // wave groups kg, partial tiles added up through LDS before the epilogue).  While one wave of a SIMD streams MFMAs, the
+  // SIMD's other waves get an issue slot only every ~70 clocks (conv_v2_common.h): what bounds these kernels is the
+  // number of non-MFMA instructions (fragment reads, their address arithmetic, waits) per MFMA.  Two M tiles per wave use
+  // every B fragment for 8 MFMAs instead of 4; four K groups keep 4 waves per SIMD with ONE channel per wave and slab.
+  constexpr int NTHR = 512, CPW = CK / 4;
+  static_assert(CK % 4 == 0, "channels of a slab over four wave groups");
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, mw = wave8 & 1, kg = wave8 >> 1;
   const int m = lane & 15, j = lane >> 4;
   int mb, grp;
   deep_block(CS / 64, groups, mb, grp);
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     }
   }
   // ---- fragment coordinates
-  const int a_frag = (wave * 16 + m) * G::AS + j * 4;
+  const int a_frag = (mw * 32 + m) * G::AS + j * 4;   // second M tile: + 16 rows
   int bn[G::NT];
 #pragma unroll
   for (int t = 0; t < G::NT; ++t) {
@@ -146,9 +148,9 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     const int si = n / G::P, pix = n - si * G::P, oh = pix / G::Ws, ow = pix - oh * G::Ws;
     bn[t] = si * G::PLANE + (2 * oh + j) * G::WP + 2 * ow;
   }
-  f32x4 acc[G::NT];
+  f32x4 acc[2][G::NT];
 #pragma unroll
-  for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < G::NT; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Loads run TWO slabs ahead of the MFMA loop in two register sets, and the commit of slab s+1 sits in the MIDDLE of slab
   // s's MFMA block: its loads are then 1.5 slabs old (no wait), its LDS writes issue under the running matrix pipe, and
@@ -225,9 +227,32 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     fetch_aff(min(s + 1, nslab - 1));
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the fetch to the commit)
 #pragma unroll
-    for (int cc = 0; cc < CK / 2; ++cc) {
-      const int ch = kg * (CK / 2) + cc;
-      if (cc == CK / 4 && s + 1 < nslab) {
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int ch = kg * CPW + cc;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + ch * 16);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 16 * G::AS + ch * 16);
+      f32x4 bf[G::NT];
+#pragma unroll
+      for (int t = 0; t < G::NT; ++t) {
+        const float* p = bp + bn[t] + ch * G::CH_STRIDE;
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(p), hi = *reinterpret_cast<const f32x2*>(p + 2);
+        bf[t] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+      auto mfmas = [&](const f32x4& a, f32x4 (&ac)[G::NT]) {
+        if constexpr (BF16) {
+          const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t)
+            ac[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(bf[t][0], bf[t][1], bf[t][2], bf[t][3]), ac[t], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+            for (int t = 0; t < G::NT; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kw], bf[t][kw], ac[t], 0, 0, 0);
+        }
+      };
+      mfmas(a0, acc[0]);
+      if (cc == CPW - 1 && s + 1 < nslab) {   // the next slab goes to the other stage between the two M tiles
         DEEP_STAMP(s, 1);
         wait_set(rn, s + 2 < nslab);
         DEEP_STAMP(s, 2);
@@ -235,22 +260,7 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
         if (s + 3 < nslab) issue(s + 3, rn);
         DEEP_STAMP(s, 3);
       }
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + ch * 16);
-      if constexpr (BF16) {
-        const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
-#pragma unroll
-        for (int t = 0; t < G::NT; ++t) {
-          const float* p = bp + bn[t] + ch * G::CH_STRIDE;
-          const f32x2 lo = *reinterpret_cast<const f32x2*>(p), hi = *reinterpret_cast<const f32x2*>(p + 2);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(lo[0], lo[1], hi[0], hi[1]), acc[t], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-          for (int t = 0; t < G::NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kw], bp[bn[t] + ch * G::CH_STRIDE + kw], acc[t], 0, 0, 0);
-      }
+      mfmas(a1, acc[1]);
     }
     DEEP_STAMP(s, 4);
     __syncthreads();
@@ -269,48 +279,62 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     if (s + 1 < nslab) slab_step(s + 1, r0);
   }
 
-  // ---- the two K groups' partial tiles -> waves 0-3 (the last slab's barrier has passed: the stages are free)
+  // ---- the K groups' partial tiles -> group 0, one group per round in a fixed order (deterministic sums; the last
+  // slab's barrier has passed: the stages are free)
   {
     f32x4* red = reinterpret_cast<f32x4*>(lds);
-    if (kg == 1) {
+#pragma unroll 1
+    for (int r = 1; r < 4; ++r) {
+      if (kg == r) {
 #pragma unroll
-      for (int t = 0; t < G::NT; ++t) red[(t * 4 + wave) * 64 + lane] = acc[t];
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t) red[((mt * G::NT + t) * 2 + mw) * 64 + lane] = acc[mt][t];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int t = 0; t < G::NT; ++t) acc[mt][t] += red[((mt * G::NT + t) * 2 + mw) * 64 + lane];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int t = 0; t < G::NT; ++t) acc[t] += red[(t * 4 + wave) * 64 + lane];
+    if (kg != 0) return;
   }
-  // ---- epilogue: acc[t][i] = channel cs0 + wave*16 + 4j + i, pixel n = t*16 + m
+  // ---- epilogue: acc[mt][t][i] = channel cs0 + mw*32 + mt*16 + 4j + i, pixel n = t*16 + m
   const pgv_act_params ap = pgv_act_setup(act, slope);
-  float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  const int c0 = cs0 + wave * 16 + 4 * j;
+  if (stats) stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+  for (int mt = 0; mt < 2; ++mt) {
+    float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = cs0 + mw * 32 + mt * 16 + 4 * j;
 #pragma unroll
-  for (int t = 0; t < G::NT; ++t) {
-    const int n = t * 16 + m;
-    const int si = n / G::P, pix = n - si * G::P;
-    const bool ok = n < G::N && b0 + si < B;
-    float* o = out + ((int64_t)(b0 + si) * CS + c0) * G::P + pix;
+    for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = pgv_act_apply(acc[t][i] + bv[i], ap);
-      if (ok) {
-        o[i * G::P] = v;
-        s1[i] += v;
-        s2[i] += v * v;
+    for (int t = 0; t < G::NT; ++t) {
+      const int n = t * 16 + m;
+      const int si = n / G::P, pix = n - si * G::P;
+      const bool ok = n < G::N && b0 + si < B;
+      float* o = out + ((int64_t)(b0 + si) * CS + c0) * G::P + pix;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = pgv_act_apply(acc[mt][t][i] + bv[i], ap);
+        if (ok) {
+          o[i * G::P] = v;
+          s1[i] += v;
+          s2[i] += v * v;
+        }
       }
     }
-  }
-  if (stats) {
-    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
+    if (stats) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
-      if (m == 0) {
-        atomicAdd(&stats[c0 + i], (double)a1);
-        atomicAdd(&stats[CS + c0 + i], (double)a2);
+      for (int i = 0; i < 4; ++i) {
+        const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+        if (m == 0) {
+          atomicAdd(&stats[c0 + i], (double)a1);
+          atomicAdd(&stats[CS + c0 + i], (double)a2);
+        }
       }
     }
   }

@@ -83,7 +83,12 @@ def test_conv_down_up_wgrad(ops, case, policy):
         # down without affine / bias / activation (the form used for ConvTranspose2d input gradients)
         ref = F.conv2d(big, w, None, stride=s, padding=p)
         got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
-        assert rel_l2(got, ref) < 1e-5
+        # The structured inputs cancel: at the 5x7 shape |ref| is 1/4000 of the convolution of the absolute values, so
+        # rel-L2 measures fp32 summation ORDER (4.8e-6 for the sequential generic kernel, 1.6e-5 for the deep-layer
+        # kernel's four K groups; scratch/acc_noise.py).  Where 1e-5 is not met the error must be below one unit
+        # roundoff (6e-8) of the scale rounding errors are proportional to - measured 4e-9.
+        err_abs = (got.double().cpu() - ref).norm() / F.conv2d(big.abs(), w.abs(), None, stride=s, padding=p).norm()
+        assert rel_l2(got, ref) < 1e-5 or (rel_l2(got, ref) < 5e-5 and err_abs.item() < 2e-8)
         # up: transposed conv of the lazily-normalised small tensor; output_padding implied by Hb/Wb
         oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
         ref = F.conv_transpose2d(_affine(small, sc_s, sh_s), w, bias_b, stride=s, padding=p,
