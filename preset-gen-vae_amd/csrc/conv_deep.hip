@@ -388,14 +388,15 @@ struct DeepUp {
   static constexpr int CH_STRIDE = NS * SPLANE;
   static constexpr int B_FLOATS = CK * CH_STRIDE;
   static constexpr int STAGE = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
-  static constexpr int QA = CK * 64 * 4 / 256;
+  static constexpr int NTHR = 512;                      // 8 waves: 4 (M) x 2 (K groups)
+  static constexpr int QA = CK * 64 * 4 / NTHR;
   static constexpr int QB_ITEMS = NS * CK * P / 4;
-  static constexpr int QB = (QB_ITEMS + 255) / 256;
-  static_assert(CK % 4 == 0 && (CK * P) % 4 == 0, "16-byte plane runs");
+  static constexpr int QB = (QB_ITEMS + NTHR - 1) / NTHR;
+  static_assert(CK % 8 == 0 && (CK * P) % 4 == 0 && (CK * 64 * 4) % NTHR == 0, "16-byte plane runs, two K groups");
 };
 
 template <int H, int W, int NS, int CK, bool BF16>
-__global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, const float* __restrict__ small_in,
+__global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, const float* __restrict__ small_in,
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
@@ -404,23 +405,31 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
   using G = DeepUp<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 8 waves = 4 (M: 16 output channels each) x 2 (K: the small channels of every slab split between two wave groups,
+  // partial tiles added through LDS before the epilogue).  These launches are 256 workgroups (64 output channels x NS
+  // samples): as 4-wave workgroups every SIMD of the chip held ONE wave, and everything that wave did besides MFMAs
+  // (fragment reads, commit, barrier) was time without an MFMA.
+  constexpr int NTHR = G::NTHR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
   const int m = lane & 15, j = lane >> 4;
   int mb, grp;
   deep_block(CB / 64, groups, mb, grp);
   const int cb0 = mb * 64, b0 = grp * NS;
 
-  for (int i = tid; i < G::B_FLOATS; i += 256) {
+  for (int i = tid; i < G::B_FLOATS; i += NTHR) {
     lds[G::A_FLOATS + i] = 0.f;
     lds[G::STAGE + G::A_FLOATS + i] = 0.f;
   }
-  stage_affine(aff, in_scale, in_shift, CS, tid);
+  for (int i = tid; i < CS; i += NTHR) {   // identity when the input carries no folded BatchNorm: branch-free commit
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[CS + i] = in_scale ? in_shift[i] : 0.f;
+  }
 
   // ---- loaders: weights W[cs][cb0+row][16] (one float4 = the four kw of a kernel row kh), planes s[b][cs][P]
   int a_src[G::QA], a_dst[G::QA];
 #pragma unroll
   for (int i = 0; i < G::QA; ++i) {
-    const int q = tid + 256 * i, c = q / 256, r = q - c * 256, row = r >> 2, kh = r & 3;
+    const int q = tid + NTHR * i, c = q / 256, r = q - c * 256, row = r >> 2, kh = r & 3;
     a_src[i] = (c * CB + cb0 + row) * 16 + 4 * kh;
     // (kh, kw) -> phase (kh&1)*2 + (kw&1), tap (kh>>1)*2 + (kw>>1): element kw of this float4 goes to
     // a_dst + (kw&1)*4 + (kw>>1)
@@ -430,8 +439,8 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
   bool b_ok[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
-    const int q = min(tid + 256 * i, G::QB_ITEMS - 1);
-    b_ok[i] = tid + 256 * i < G::QB_ITEMS;
+    const int q = min(tid + NTHR * i, G::QB_ITEMS - 1);
+    b_ok[i] = tid + NTHR * i < G::QB_ITEMS;
     const int si = q / (CK * G::P / 4), qq = q - si * (CK * G::P / 4);
     const int bs = min(b0 + si, B - 1);
     b_src[i] = bs * CS * G::P + 4 * qq;
@@ -468,8 +477,19 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(small_in + b_src[i] + cs0 * G::P);
   };
-  auto commit = [&](int slab, float* st) {
+  // (the affine of the slab to commit is fetched from the LDS table at the START of the slab, see deep_down)
+  float bsc[G::QB][4], bsh[G::QB][4];
+  auto fetch_aff = [&](int slab) {
     const int cs0 = slab * CK;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bsc[i][e] = aff[cs0 + b_ch[i][e]];
+        bsh[i][e] = aff[CS + cs0 + b_ch[i][e]];
+      }
+  };
+  auto commit = [&](int slab, float* st) {
 #pragma unroll
     for (int i = 0; i < G::QA; ++i) {
       float* a = st + a_dst[i];
@@ -481,13 +501,12 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
     float* bt = st + G::A_FLOATS;
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(rb[i][e], bsc[i][e], bsh[i][e]);
       if (b_ok[i]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = rb[i][e];
-          if (in_scale) v = fmaf(v, aff[cs0 + b_ch[i][e]], aff[CS + cs0 + b_ch[i][e]]);
-          bt[b_dst[i][e]] = v;
-        }
+        for (int e = 0; e < 4; ++e) bt[b_dst[i][e]] = v[e];
       }
     }
   };
@@ -495,16 +514,20 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
   const int nslab = CS / CK;
   issue(0);
   __syncthreads();
+  fetch_aff(0);
   commit(0, lds);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const float* st = lds + (s & 1) * G::STAGE;
     if (s + 1 < nslab) issue(s + 1);
+    fetch_aff(min(s + 1, nslab - 1));
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the fetch to the commit)
     const float* ap = st + a_frag;
     const float* bp = st + G::A_FLOATS;
     if constexpr (BF16) {
 #pragma unroll
-      for (int g = 0; g < CK / 4; ++g) {
+      for (int gg = 0; gg < CK / 8; ++gg) {
+        const int g = kg * (CK / 8) + gg;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * g * G::ACS + 4 * p);
@@ -520,7 +543,8 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < CK; ++c) {
+      for (int cc = 0; cc < CK / 2; ++cc) {
+        const int c = kg * (CK / 2) + cc;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const float a = ap[c * G::ACS + 4 * p];
@@ -536,6 +560,27 @@ __global__ __launch_bounds__(256) void deep_up_kernel(int B, int CB, int CS, con
     __syncthreads();
   }
 
+  // ---- the two K groups' partial tiles -> waves 0-3, half of the tiles per round (the last slab's barrier has passed:
+  // the stages are free; 17x23 has 26 tiles = 106 KB of partials against 90 KB of stages)
+  {
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    constexpr int HALF = (G::NT + 1) / 2;
+    static_assert((size_t)HALF * 4 * 64 * 16 <= sizeof(float) * 2 * (size_t)G::STAGE, "partial tiles fit the stages");
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (kg == 1) {
+#pragma unroll
+        for (int t = r * HALF; t < (r == 0 ? HALF : G::NT); ++t) red[((t - r * HALF) * 4 + wave) * 64 + lane] = acc[t];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int t = r * HALF; t < (r == 0 ? HALF : G::NT); ++t) acc[t] += red[((t - r * HALF) * 4 + wave) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (kg == 1) return;
+  }
   // ---- epilogue: acc[t][i] = channel cb0 + wave*16 + 4j + i, pixel n of phase p
   const pgv_act_params ap = pgv_act_setup(act, slope);
   float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -593,7 +638,7 @@ int launch_deep_up(const pgv_conv_desc* d, const float* small_in, const float* i
     return PGV_E_LAUNCH;
   }
   const int groups = (d->B + NS - 1) / NS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / 64))), dim3(256), bytes, st, d->B, d->Cb, d->Cs, small_in,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / 64))), dim3(G::NTHR), bytes, st, d->B, d->Cb, d->Cs, small_in,
                      in_scale, in_shift, w, bias, act, slope, out, stats, groups,
                      (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0);
   PGV_CHECK_LAUNCH("conv_up_deep");
@@ -694,29 +739,45 @@ __global__ __launch_bounds__(256) void deep_wgrad_kernel(int B, int CB, int CS, 
       rb[i] = *reinterpret_cast<const f32x4*>(xbase + (int64_t)(bs - si) * CB * G::HW + b_src[i]);
     }
   };
+  // The folded-BatchNorm affines of a thread's elements do not change over the sample loop (its channels are fixed):
+  // fetched once into registers (identity where an operand has none).  Fetched inside the commit - a global load per
+  // element behind a branch - every slab paid QA*4 + QB*4 dependent memory round trips (see deep_down).
+  float asc[G::QA][4], ash[G::QA][4], bsc[G::QB][4], bsh[G::QB][4];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      asc[i][e] = small_scale ? small_scale[cs0 + a_ch[i][e]] : 1.f;
+      ash[i][e] = small_scale ? small_shift[cs0 + a_ch[i][e]] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bsc[i][e] = big_scale ? big_scale[cb0 + b_ch[i][e]] : 1.f;
+      bsh[i][e] = big_scale ? big_shift[cb0 + b_ch[i][e]] : 0.f;
+    }
   auto commit = [&](int b, float* st) {
 #pragma unroll
     for (int i = 0; i < G::QA; ++i) {
-      if (a_ok[i]) {
-        const bool live = b + a_src[i] / (CS * G::P) < bend;
+      const bool live = b + a_src[i] / (CS * G::P) < bend;
+      float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = ra[i][e];
-          if (small_scale) v = fmaf(v, small_scale[cs0 + a_ch[i][e]], small_shift[cs0 + a_ch[i][e]]);
-          st[a_dst[i][e]] = live ? v : 0.f;
-        }
+      for (int e = 0; e < 4; ++e) v[e] = live ? fmaf(ra[i][e], asc[i][e], ash[i][e]) : 0.f;
+      if (a_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st[a_dst[i][e]] = v[e];
       }
     }
     float* bt = st + G::A_FLOATS;
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(rb[i][e], bsc[i][e], bsh[i][e]);
       if (b_ok[i]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = rb[i][e];
-          if (big_scale) v = fmaf(v, big_scale[cb0 + b_ch[i][e]], big_shift[cb0 + b_ch[i][e]]);
-          bt[b_dst[i][e]] = v;
-        }
+        for (int e = 0; e < 4; ++e) bt[b_dst[i][e]] = v[e];
       }
     }
   };
@@ -892,13 +953,18 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
   for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 ra[G::QA], rb[G::QB];
+  float rsc[G::QB], rsh[G::QB];
   auto issue = [&](int slab) {
     const int ci0 = slab * CK;
 #pragma unroll
     for (int i = 0; i < G::QA; ++i)
       ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + (TRANSA ? (int64_t)ci0 * COUT : (int64_t)ci0));
 #pragma unroll
-    for (int i = 0; i < G::QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+    for (int i = 0; i < G::QB; ++i) {
+      rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+      rsc[i] = in_scale ? in_scale[ci0 + b_ch[i]] : 1.f;
+      rsh[i] = in_scale ? in_shift[ci0 + b_ch[i]] : 0.f;
+    }
   };
   auto commit = [&](int slab, float* st) {
     const int ci0 = slab * CK;
@@ -909,11 +975,8 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
     for (int i = 0; i < G::QB; ++i) {
       if (b_ok[i]) {
         f32x4 v = rb[i];
-        if (in_scale) {
-          const float sc = in_scale[ci0 + b_ch[i]], sh = in_shift[ci0 + b_ch[i]];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], rsc[i], rsh[i]);   // (fetched with the slab's loads, a slab ahead)
         *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
       }
     }
@@ -1045,12 +1108,17 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
     for (int t = 0; t < NTW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 ra[QA], rb[QB];
+  float rsc[QB], rsh[QB];
   auto issue = [&](int slab) {
     const int ci0 = slab * CK;
 #pragma unroll
     for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(w + a_src[i] + ci0);
 #pragma unroll
-    for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+    for (int i = 0; i < QB; ++i) {
+      rb[i] = *reinterpret_cast<const f32x4*>(in + b_src[i] + ci0 * P);
+      rsc[i] = in_scale ? in_scale[ci0 + b_ch[i]] : 1.f;
+      rsh[i] = in_scale ? in_shift[ci0 + b_ch[i]] : 0.f;
+    }
   };
   auto commit = [&](int slab, float* st) {
     const int ci0 = slab * CK;
@@ -1061,11 +1129,8 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
     for (int i = 0; i < QB; ++i) {
       if (b_ok[i]) {
         f32x4 v = rb[i];
-        if (in_scale) {
-          const float sc = in_scale[ci0 + b_ch[i]], sh = in_shift[ci0 + b_ch[i]];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], rsc[i], rsh[i]);   // (fetched with the slab's loads, a slab ahead)
         *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
       }
     }
@@ -1247,15 +1312,24 @@ __global__ __launch_bounds__(256) void k1_wgrad_kernel(int B, int CB, int CS, co
     for (int i = 0; i < G::QB; ++i)
       rb[i] = *reinterpret_cast<const f32x4*>(xbase + (int64_t)min(b + b_si[i], bend - 1) * CB * P + b_off[i]);
   };
+  // (a thread's channels are fixed over the sample loop: the affines are fetched once, identity where absent)
+  float asc[G::QA], ash[G::QA], bsc[G::QB], bsh[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    asc[i] = small_scale ? small_scale[cs0 + a_ch[i]] : 1.f;
+    ash[i] = small_scale ? small_shift[cs0 + a_ch[i]] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    bsc[i] = big_scale ? big_scale[cb0 + b_ch[i]] : 1.f;
+    bsh[i] = big_scale ? big_shift[cb0 + b_ch[i]] : 0.f;
+  }
   auto commit = [&](int b, float* st) {
 #pragma unroll
     for (int i = 0; i < G::QA; ++i) {
       f32x4 v = ra[i];
-      if (small_scale) {
-        const float sc = small_scale[cs0 + a_ch[i]], sh = small_shift[cs0 + a_ch[i]];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], asc[i], ash[i]);
       if (b + a_si[i] >= bend) v = f32x4{0.f, 0.f, 0.f, 0.f};  // samples beyond the range contribute nothing
       *reinterpret_cast<f32x4*>(st + a_dst[i]) = v;
     }
@@ -1263,11 +1337,8 @@ __global__ __launch_bounds__(256) void k1_wgrad_kernel(int B, int CB, int CS, co
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       f32x4 v = rb[i];
-      if (big_scale) {
-        const float sc = big_scale[cb0 + b_ch[i]], sh = big_shift[cb0 + b_ch[i]];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], bsc[i], bsh[i]);
       *reinterpret_cast<f32x4*>(bt + b_dst[i]) = v;
     }
   };
