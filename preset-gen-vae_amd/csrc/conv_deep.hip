@@ -451,9 +451,11 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
       b_dst[i][e] = ch * G::CH_STRIDE + si * G::SPLANE + r * G::SWP + c;
     }
   }
-  // ---- fragment coordinates.  fp32: lane group j is the tap (th, tw) = (j>>1, j&1) of one small channel;
-  // bf16: lane group j is small channel 4g + j, the four taps are the lane's four consecutive k values.
-  const int a_frag = (wave * 16 + m) * G::AS + (BF16 ? j * G::ACS : j);
+  // ---- fragment coordinates.  Lane group j is small channel 4g + j in both precisions: the lane's four taps are four
+  // consecutive k values of ONE bf16 MFMA, or the operands of FOUR fp32 MFMAs (one per tap, k = the 4 channels) fetched
+  // by one 16-byte weight read and two 8-byte plane reads.  (fp32 used to take the tap as k: one 4-byte read of each
+  // operand per MFMA; with two waves per SIMD the non-MFMA instructions per MFMA are what bounds the kernel.)
+  const int a_frag = (wave * 16 + m) * G::AS + j * G::ACS;
   int bn[G::NT];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
       const int per = G::hu(p) * G::wu(p);
       const int si = n / per, rem = n - si * per, u = rem / G::wu(p), v = rem - u * G::wu(p);
       const int base = si * G::SPLANE + (u + 1) * G::SWP + v + 1;
-      bn[G::tile0(p) + tt] = BF16 ? base + j * G::CH_STRIDE : base - (j >> 1) * G::SWP - (j & 1);
+      bn[G::tile0(p) + tt] = base + j * G::CH_STRIDE;
     }
   f32x4 acc[G::NT];
 #pragma unroll
@@ -543,16 +545,23 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
       }
     } else {
 #pragma unroll
-      for (int cc = 0; cc < CK / 2; ++cc) {
-        const int c = kg * (CK / 2) + cc;
+      for (int gg = 0; gg < CK / 8; ++gg) {
+        const int g = kg * (CK / 8) + gg;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const float a = ap[c * G::ACS + 4 * p];
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * g * G::ACS + 4 * p);
+          float bq[G::ntp(p)][4];
 #pragma unroll
           for (int tt = 0; tt < G::ntp(p); ++tt) {
-            const int t = G::tile0(p) + tt;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[bn[t] + c * G::CH_STRIDE], acc[t], 0, 0, 0);
+            const float* q = bp + bn[G::tile0(p) + tt] + 4 * g * G::CH_STRIDE;
+            bq[tt][0] = q[0], bq[tt][1] = q[-1], bq[tt][2] = q[-G::SWP], bq[tt][3] = q[-G::SWP - 1];
           }
+#pragma unroll
+          for (int tap = 0; tap < 4; ++tap)   // (tiles inside: consecutive MFMAs on different accumulators)
+#pragma unroll
+            for (int tt = 0; tt < G::ntp(p); ++tt)
+              acc[G::tile0(p) + tt] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap], bq[tt][tap], acc[G::tile0(p) + tt], 0, 0, 0);
         }
       }
     }
