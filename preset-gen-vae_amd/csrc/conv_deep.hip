@@ -300,42 +300,56 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
       }
       __syncthreads();
     }
-    if (kg != 0) return;
   }
-  // ---- epilogue: acc[mt][t][i] = channel cs0 + mw*32 + mt*16 + 4j + i, pixel n = t*16 + m
+  // ---- epilogue: acc[mt][t][i] = channel cs0 + mw*32 + mt*16 + 4j + i, pixel n = t*16 + m.  The tile is assembled as
+  // [sample][channel][P] in the free stages and copied out by all 8 waves: a sample's 64 planes are one contiguous run of
+  // the output (written from the accumulators - 64-byte pieces P floats apart - the output moved at ~0.5 TB/s: one slab +
+  // prologue + epilogue cost 39 / 25 / 17 us for 14 / 7 / 3 MB of output).
   const pgv_act_params ap = pgv_act_setup(act, slope);
+  static_assert(NS * 64 * G::P <= 2 * G::STAGE, "output tile fits the stages");
   if (stats) stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
+  if (kg == 0) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const int c0 = cs0 + mw * 32 + mt * 16 + 4 * j;
+    for (int mt = 0; mt < 2; ++mt) {
+      float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      const int cl = mw * 32 + mt * 16 + 4 * j, c0 = cs0 + cl;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+      for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
 #pragma unroll
-    for (int t = 0; t < G::NT; ++t) {
-      const int n = t * 16 + m;
-      const int si = n / G::P, pix = n - si * G::P;
-      const bool ok = n < G::N && b0 + si < B;
-      float* o = out + ((int64_t)(b0 + si) * CS + c0) * G::P + pix;
+      for (int t = 0; t < G::NT; ++t) {
+        const int n = t * 16 + m;
+        const int si = n / G::P, pix = n - si * G::P;
+        const bool ok = n < G::N && b0 + si < B;
+        float* o = lds + (si * 64 + cl) * G::P + pix;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = pgv_act_apply(acc[mt][t][i] + bv[i], ap);
-        if (ok) {
-          o[i * G::P] = v;
-          s1[i] += v;
-          s2[i] += v * v;
+        for (int i = 0; i < 4; ++i) {
+          const float v = pgv_act_apply(acc[mt][t][i] + bv[i], ap);
+          if (ok) {
+            o[i * G::P] = v;
+            s1[i] += v;
+            s2[i] += v * v;
+          }
+        }
+      }
+      if (stats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
+          if (m == 0) {
+            atomicAdd(&stats[c0 + i], (double)a1);
+            atomicAdd(&stats[CS + c0 + i], (double)a2);
+          }
         }
       }
     }
-    if (stats) {
+  }
+  __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);
-        if (m == 0) {
-          atomicAdd(&stats[c0 + i], (double)a1);
-          atomicAdd(&stats[CS + c0 + i], (double)a2);
-        }
-      }
+  for (int si = 0; si < NS; ++si) {
+    if (b0 + si < B) {
+      float* dst = out + ((int64_t)(b0 + si) * CS + cs0) * G::P;
+      const float* src = lds + si * 64 * G::P;
+      for (int i = tid; i < 64 * G::P; i += NTHR) dst[i] = src[i];
     }
   }
 }
@@ -513,7 +527,11 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
     }
   };
 
+#ifdef PGV_DEEP_UP_ONE_SLAB   // timing aid (scratch/): prologue + one slab + epilogue
+  const int nslab = 1;
+#else
   const int nslab = CS / CK;
+#endif
   issue(0);
   __syncthreads();
   fetch_aff(0);
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * g * G::ACS + 4 * p);
-          float bq[G::ntp(p)][4];
+          float bq[G::ntp(0)][4];   // (phase 0 has the most tiles)
 #pragma unroll
           for (int tt = 0; tt < G::ntp(p); ++tt) {
             const float* q = bp + bn[G::tile0(p) + tt] + 4 * g * G::CH_STRIDE;
@@ -588,34 +606,55 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
       }
       __syncthreads();
     }
-    if (kg == 1) return;
   }
-  // ---- epilogue: acc[t][i] = channel cb0 + wave*16 + 4j + i, pixel n of phase p
+  // ---- epilogue: acc[t][i] = channel cb0 + wave*16 + 4j + i, pixel n of phase p.  The output leaves through LDS: a
+  // lane's pixels of one phase are every second float of a row, and written straight from the accumulators (4-byte
+  // stores, 8 bytes apart, the other half of every line coming from another phase's tile much later) the output moved
+  // at 0.55 TB/s - 46 of the 17x23 layer's 103 us (one slab + prologue + epilogue = 54 / 30 / 20 us for 25.6 / 14 / 9 MB
+  // of output).  Per round, half of the 64 channels are assembled as [sample][channel][H*W] in the free stages and
+  // copied out by all 8 waves as whole lines (a sample's 32 planes are one contiguous run of the output).
   const pgv_act_params ap = pgv_act_setup(act, slope);
   float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int c0 = cb0 + wave * 16 + 4 * j;
 #pragma unroll
   for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+  static_assert(sizeof(float) * NS * 32 * G::HW <= sizeof(float) * 2 * (size_t)G::STAGE, "output half fits the stages");
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (kg == 0 && (wave >> 1) == h) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int tt = 0; tt < G::ntp(p); ++tt) {
-      const int t = G::tile0(p) + tt;
-      const int n = tt * 16 + m;
-      const int per = G::hu(p) * G::wu(p);
-      const int si = n / per, rem = n - si * per, u = rem / G::wu(p), v = rem - u * G::wu(p);
-      const bool ok = n < G::cnt(p) && b0 + si < B;
-      float* o = out + ((int64_t)(b0 + si) * CB + c0) * G::HW + (2 * u + (p >> 1)) * W + 2 * v + (p & 1);
+        for (int tt = 0; tt < G::ntp(p); ++tt) {
+          const int t = G::tile0(p) + tt;
+          const int n = tt * 16 + m;
+          const int per = G::hu(p) * G::wu(p);
+          const int si = n / per, rem = n - si * per, u = rem / G::wu(p), v = rem - u * G::wu(p);
+          const bool ok = n < G::cnt(p) && b0 + si < B;
+          float* o = lds + (si * 32 + (wave & 1) * 16 + 4 * j) * G::HW + (2 * u + (p >> 1)) * W + 2 * v + (p & 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float val = pgv_act_apply(acc[t][i] + bv[i], ap);
-        if (ok) {
-          o[i * G::HW] = val;
-          s1[i] += val;
-          s2[i] += val * val;
+          for (int i = 0; i < 4; ++i) {
+            const float val = pgv_act_apply(acc[t][i] + bv[i], ap);
+            if (ok) {
+              o[i * G::HW] = val;
+              s1[i] += val;
+              s2[i] += val * val;
+            }
+          }
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int si = 0; si < NS; ++si) {
+      if (b0 + si < B) {
+        float* dst = out + ((int64_t)(b0 + si) * CB + cb0 + 32 * h) * G::HW;
+        const float* src = lds + si * 32 * G::HW;
+        for (int i = tid; i < 32 * G::HW; i += NTHR) dst[i] = src[i];
       }
     }
+    __syncthreads();
+  }
+  if (kg == 1) return;
   if (stats) {
     stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
