@@ -368,7 +368,9 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     goes to gpurun_out/bench_kernel_table.json."""
     rows = []
     for label, fn, bytes_, flops in launch_table(ae, B, device, frontend):
-        ms = time_kernel(fn, iters=5)
+        # median of three 5-launch averages: one disturbed replay (another tenant of the box, a clock ramp) would otherwise
+        # push a launch over the 2 % line AND to the bottom of the fractions at once (seen: conv_wgrad[dec8] 0.43 -> 0.25)
+        ms = sorted(time_kernel(fn, iters=5) for _ in range(3))[1]
         t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (matrix_peak * 1e12)
         bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
         frac = max(t_hbm, t_mfma) * 1e3 / ms if ms > 0 else 0.0
