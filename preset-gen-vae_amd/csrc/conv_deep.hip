@@ -360,6 +360,8 @@ int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_s
                      hipStream_t st) {
   using G = DeepDown<H, W, NS, CK>;
   if (d->Cs % 64 || d->Cb % CK) return 0;
+  // (the loader's inline-asm loads carry 32-bit byte offsets from the tensor bases)
+  if ((int64_t)d->B * d->Cb * G::HW * 4 >= (int64_t)1 << 31 || (int64_t)d->Cs * d->Cb * 64 >= (int64_t)1 << 31) return 0;
   const size_t bytes = sizeof(float) * (2 * G::STAGE + 2 * (size_t)d->Cb + 8);
   if (bytes > (size_t)kMaxLds) return 0;
   const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
