@@ -1222,6 +1222,7 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
     __syncthreads();
   }
   const pgv_act_params apar = pgv_act_setup(act, slope);
+  if (stats) stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1245,7 +1246,6 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
       }
     }
     if (stats) {
-      stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float a1 = group16_sum(s1[i]), a2 = group16_sum(s2[i]);

@@ -505,7 +505,10 @@ def test_bias_gradient_through_partial_copies(ops, case, policy):
 
 @pytest.mark.parametrize("policy", [0, 3])
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 3), (16, 32, 4, 2, 2, 65, 88, 3), (32, 64, 4, 2, 2, 33, 45, 5),
-                                  (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2)])
+                                  (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2),
+                                  # deep-layer kernels (statistics copies per XCD since ABI v9), ragged sample groups
+                                  (64, 128, 4, 2, 2, 17, 23, 19), (128, 256, 4, 2, 2, 9, 12, 19),
+                                  (256, 512, 4, 2, 2, 5, 7, 21), (512, 2048, 1, 1, 0, 3, 4, 19)])
 def test_conv_finalizes_the_input_batchnorm(ops, case, policy):
     """pgv_conv_down_bn / pgv_conv_up_bn / pgv_dropout_fwd_bn (pgv_bn_src): the consumer kernel finalizes its input's
     BatchNorm in its prologue - the same output, the same scale / shift / mean / rstd vectors, the same running
