@@ -151,7 +151,10 @@ def test_band_kernels_many_units(ops, case):
     assert rel_l2(gw2, gw) < 1e-5       # float atomics: run-to-run differences stay at rounding level
 
 
-@pytest.mark.parametrize("shape", [(8, 16, 4, 129, 174), (16, 32, 4, 65, 88), (32, 64, 4, 33, 45), (1, 8, 5, 257, 347)])
+@pytest.mark.parametrize("shape", [(8, 16, 4, 129, 174), (16, 32, 4, 65, 88), (32, 64, 4, 33, 45), (1, 8, 5, 257, 347),
+                                   # deep-layer kernels: sample groups of 1 / 4 / 4 (conv), 1 / 2 / 4 (transposed conv), ragged
+                                   # last groups, outputs staged through LDS, K groups reduced through LDS
+                                   (64, 128, 4, 17, 23), (128, 256, 4, 9, 12), (256, 512, 4, 5, 7)])
 @pytest.mark.parametrize("B", [1, 19, 257])
 def test_conv_products_odd_batches(ops, shape, B):
     """The persistent kernels (wave-specialised / direct, XCD-aware unit order, deferred stores, per-workgroup partial
