@@ -425,6 +425,39 @@ def test_conv_bwd_fuse_matches_separate_pass(ops, case, policy):
         lib.pgv_set_kernel_policy(0)
 
 
+@pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 40), (16, 32, 4, 2, 2, 65, 88, 9), (32, 64, 4, 2, 2, 33, 45, 6)])
+def test_conv_bwd_fuse_bf16_operand_mode(ops, case):
+    """The fused backward epilogue in bf16 operand mode (PGV_COMPUTE_BF16): the 129x174 input gradient runs the
+    wave-specialised kernel with the operands rounded in the lean loader's commit, 33x45 the rolling-window form, 65x88 the
+    band kernel's bf16 loop.  The epilogue input must be the bf16-mode product itself (float64 convolution of the rounded
+    operands, 1e-5), and the fused result the separate pass applied to it."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, *_ = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    Hs, Ws = geom.Hs, geom.Ws
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    prod_up = F.conv_transpose2d(_bf16(small), _bf16(w), None, stride=s, padding=p, output_padding=(oph, opw))
+    prod_down = F.conv2d(_bf16(big), _bf16(w), None, stride=s, padding=p)
+    big, small, w = dev(big), dev(small), dev(w)
+    ops.set_compute_dtype('bf16')
+    try:
+        for out_is_big, prod in ((True, prod_up), (False, prod_down)):
+            C = Cb if out_is_big else Cs
+            a = ((big if out_is_big else small) * 1.3 + 0.1).contiguous()
+            coef = dev(torch.cat([1.0 + 0.3 * synth_vec((C,), 4.1, 0.2), 0.05 * synth_vec((C,), 4.7, 0.3),
+                                  0.02 * synth_vec((C,), 5.3, 0.8)]))
+            gb = torch.zeros(C, device='cuda')
+            fz = (a, coef, gb, ops.PGV_ACT_LEAKY_RELU, 0.1)
+            out = (ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz) if out_is_big else
+                   ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz))
+            ref = _bwd_apply_ref(prod.cuda(), a, coef, ops.PGV_ACT_LEAKY_RELU, 0.1)
+            assert rel_l2(out, ref) < 1e-5, (out_is_big, rel_l2(out, ref))
+            l1 = ref.abs().sum(dim=(0, 2, 3))
+            assert ((gb.double() - ref.sum(dim=(0, 2, 3))).abs() <= 1e-5 * l1 + 1e-12).all()
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 @pytest.mark.parametrize("case", CONV_CASES + [(8, 16, 4, 2, 2, 129, 174, 24), (16, 32, 4, 2, 2, 64, 87, 5),
                                                (1, 8, 5, 2, 2, 257, 347, 9), (2, 3, 2, 2, 0, 8, 10, 3)])
 def test_conv_tap_sums(ops, case):
