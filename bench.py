@@ -4,7 +4,8 @@ on [256,1,257,347] fp32 log-mel inputs per GPU (BASELINE.json ``metric``; worklo
 conv-VAE, z=64, fp32, batch 256; ``--arch speccnn8l1_bn`` runs the reference-exact 8-layer stack instead).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or
+     bare - bench.py then starts the N ranks itself as child processes of that launcher and exits with their status)
 
 One rank per GPU; each rank owns a 256-row shard (weak scaling), gradients are summed by RCCL all-reduce buckets.
 Rank 0 prints ONE JSON line with the contract fields plus ``roofline`` (dominant kernel, measured live with HIP events
@@ -639,14 +640,34 @@ EXTRA_CONFIGS = [
 ]
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves, as CHILD processes of
+    ``torch.distributed.run`` (one per GPU, rendezvous on 127.0.0.1, a free port), and hand their exit status back.
+    This process has made no GPU call yet (``import torch`` does not initialise HIP) and makes none afterwards; it never
+    replaces itself with another program."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's intra-node transport on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK') or 0)
+    local_rank = int(os.environ.get('LOCAL_RANK') or 0)
+    world = int(os.environ.get('WORLD_SIZE') or 1)
+    if args.gpus > 1 and not os.environ.get('WORLD_SIZE'):   # (unset or empty: no launcher above us)
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or without a launcher (bench.py then starts its own ranks)")
     import torch.distributed as dist
     from preset_gen_vae_amd import _lib
     _lib.load()   # fails loudly if the HIP library is missing

@@ -323,7 +323,8 @@ def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, 
     """One minibatch of train.py:203-248: forward, MSE + beta*Dkl (+ controls loss), backward, Adam.
 
     ``reg`` (optional) adds the preset-regression network of train.py:220,238-246: dict(sd={'reg_model...': tensor},
-    v_in=[B, L] targets, masks=[two keep/(1-p) dropout masks] or None); its parameters then appear in ``grads`` /
+    v_in=[B, L] targets, masks=[two keep/(1-p) dropout masks] or None, criterion=optional controls loss); its
+    parameters then appear in ``grads`` /
     ``new_sd`` / ``adam_state`` under 'reg.<key>' and the result carries 'controls' and 'v_out'.
 
     Returns dict(losses, outputs, grads{key}, new_sd{key}, adam_state)."""
@@ -346,7 +347,9 @@ def train_step(sd, x, arch, dim_z, eps, enc_mask=None, dec_mask=None, beta=0.2, 
         rsd = {k[len('reg.'):]: v for k, v in full.items() if k.startswith('reg.')}
         rbuf = {}
         v_out = mlp_regression_forward(rsd, z, True, reg.get('masks'), rbuf)      # train.py:220
-        cont = numeric_params_loss(v_out, reg['v_in'])                           # train.py:238-239
+        # train.py:238-239; default = the numeric branch, ``reg['criterion']`` = any callable(v_out, v_in), e.g. the
+        # full SynthParamsLoss restatement of oracle/params_oracle.py (train.py:111-116)
+        cont = reg.get('criterion', numeric_params_loss)(v_out, reg['v_in'])
         total = total + cont                                                       # train.py:246
         new_buffers.update({'reg.' + k: v for k, v in rbuf.items()})
     keys = list(params.keys())

@@ -55,39 +55,39 @@ def build_extended_ae_model(model_config, train_config, idx_helper):
     return encoder_model, decoder_model, ae_model, extended_ae_model
 
 
-def _is_attr_equal(attr1, attr2):
-    """Compares two config attributes - lists auto converted to tuples (reference build.py:83-87)."""
-    _attr1 = tuple(attr1) if isinstance(attr1, list) else attr1
-    _attr2 = tuple(attr2) if isinstance(attr2, list) else attr2
-    return _attr1 == _attr2
+# Which fields of a checkpoint's config.json must agree with the running config.py before training may resume
+# (behaviour of reference build.py:90-122: a mismatch in any of them raises ValueError).
+_RESUME_LOCKED = (
+    ('model', 'Model', ('name', 'run_name', 'encoder_architecture', 'dim_z', 'concat_midi_to_z', 'latent_flow_arch',
+                        'logs_root_dir', 'note_duration', 'stack_spectrograms', 'increased_dataset_size', 'stft_args',
+                        'spectrogram_size', 'mel_bins')),
+    ('train', 'Train', ('minibatch_size', 'test_holdout_proportion', 'normalize_losses', 'optimizer',
+                        'scheduler_name')),
+)
 
 
-def check_configs_on_resume_from_checkpoint(new_model_config, new_train_config, config_json_checkpoint):
-    """Consistency check between the config saved with the last checkpoint (config.json) and the new config.py
-    (reference build.py:90-122, same attribute lists, same messages).
-
-    :raises: ValueError if any incompatibility is found"""
-    prev_config = config_json_checkpoint['model']
-    attributes_to_check = ['name', 'run_name', 'encoder_architecture', 'dim_z', 'concat_midi_to_z', 'latent_flow_arch',
-                           'logs_root_dir', 'note_duration', 'stack_spectrograms', 'increased_dataset_size',
-                           'stft_args', 'spectrogram_size', 'mel_bins']
-    for attr in attributes_to_check:
-        if not _is_attr_equal(prev_config[attr], _config_attr(new_model_config, attr)):
-            raise ValueError("Model attribute '{}' is different in the new config.py ({}) and the old config.json ({})"
-                             .format(attr, _config_attr(new_model_config, attr), prev_config[attr]))
-    prev_config = config_json_checkpoint['train']
-    attributes_to_check = ['minibatch_size', 'test_holdout_proportion', 'normalize_losses', 'optimizer',
-                           'scheduler_name']
-    for attr in attributes_to_check:
-        if not _is_attr_equal(prev_config[attr], _config_attr(new_train_config, attr)):
-            raise ValueError("Train attribute '{}' is different in the new config.py ({}) and the old config.json ({})"
-                             .format(attr, _config_attr(new_train_config, attr), prev_config[attr]))
+def _canonical(value):
+    """JSON has no tuples: a tuple saved to config.json comes back as a list, at any nesting depth."""
+    if isinstance(value, (list, tuple)):
+        return tuple(_canonical(v) for v in value)
+    return value
 
 
 def _config_attr(cfg, attr):
-    """The reference reads ``cfg.__dict__[attr]`` (its config classes are plain namespaces filled at import); class
-    attributes of a config class that was never instantiated live on the class, so look there as well."""
-    d = cfg.__dict__
-    if attr in d:
-        return d[attr]
-    return getattr(cfg, attr)
+    """Instance attribute first (the reference's config namespaces are filled at import), class attribute otherwise."""
+    return vars(cfg)[attr] if attr in vars(cfg) else getattr(cfg, attr)
+
+
+def check_configs_on_resume_from_checkpoint(new_model_config, new_train_config, config_json_checkpoint):
+    """Refuse to resume a run whose saved configuration disagrees with the current one on a field that shapes the
+    model, the data or the optimizer (the fields of ``_RESUME_LOCKED``).
+
+    :raises: ValueError naming the first field that differs"""
+    current = {'model': new_model_config, 'train': new_train_config}
+    for section, title, fields in _RESUME_LOCKED:
+        saved = config_json_checkpoint[section]
+        for field in fields:
+            now = _config_attr(current[section], field)
+            if _canonical(saved[field]) != _canonical(now):
+                raise ValueError(f"{title} attribute '{field}' changed since the checkpoint was written: "
+                                 f"config.py has {now!r}, the checkpoint's config.json has {saved[field]!r}")

@@ -564,7 +564,7 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         wp, bp = ctx.params
         gy = gy.contiguous()
-        bias_done, gb_ret = ctx.bias_elsewhere, None
+        bias_done, gb_ret, gb_zero = ctx.bias_elsewhere, None, False
         if ctx.drop is not None:
             gb = None
             if bp is not None and not bias_done:

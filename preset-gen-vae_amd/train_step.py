@@ -25,7 +25,13 @@ from .model import loss as loss_mod
 
 class VAETrainStep:
     def __init__(self, ae_model, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, beta=0.2, normalize_losses=True,
-                 reg_model=None, grad_sync=None, use_graph=False):
+                 reg_model=None, grad_sync=None, use_graph=False, controls_criterion=None, monitors=None):
+        """``controls_criterion``: callable(v_out, v_in) -> 0-d loss, the backprop criterion of the preset-regression
+        output (train.py:108-116: ``model.params_loss.SynthParamsLoss``; default: MSE over all columns, the numeric branch
+        of that loss on an all-numerical representation).  ``monitors``: {name: callable(v_out, v_in)} evaluated under
+        ``no_grad`` on every minibatch BEFORE the controls criterion, as train.py:229-233 does with
+        ``QuantizedNumericalParamsLoss`` / ``CategoricalParamsAccuracy``; their values come back as
+        ``out['monitors'][name]`` (device tensors, no host synchronisation; captured with the rest of the step)."""
         self.model = ae_model
         self.reg_model = reg_model
         self.beta = float(beta)
@@ -49,7 +55,9 @@ class VAETrainStep:
         if hasattr(vae, 'fuse_recons_criterion'):
             # (deferred: this class always runs backward before anybody reads the loss values)
             vae.fuse_recons_criterion = ('mse_mean' if normalize_losses else 'l2_batch') + '+deferred'
-        self.controls_criterion = loss_mod.MSELoss(reduction='mean')
+        self.controls_criterion = controls_criterion if controls_criterion is not None else \
+            loss_mod.MSELoss(reduction='mean')
+        self.monitors = dict(monitors or {})
         self.use_graph = use_graph
         self._const = {}
         self._graph = None
@@ -79,6 +87,12 @@ class VAETrainStep:
 
     def _forward_backward(self, x, v_in=None, inject=None, hooks=False):
         inject = inject or {}
+        pending = self._rng()
+        if pending is not None and pending.owed:
+            # a forward whose optimizer step never came (gradient accumulation, a loss probe) left its generator advance
+            # with us: apply it now, or this forward would draw the same Dropout masks and eps again
+            from . import ops
+            ops.rng_advance(pending.state, pending.take_owed())
         self.optimizer.zero_grad()
         if self.grad_sync is not None and hooks:
             self.grad_sync.start_step()
@@ -100,20 +114,26 @@ class VAETrainStep:
         # the reported total is one fused multiply-add
         one, beta_t = self._constants(x.device)
         roots, root_grads = [recons, lat], [one, beta_t]
-        cont = None
+        cont, mon = None, None
         if self.reg_model is not None and v_in is not None:
             v_out = self.reg_model(zK)
-            cont = self.controls_criterion(v_out, v_in)
+            if self.monitors:                                    # train.py:229-233
+                with torch.no_grad():
+                    mon = {name: fn(v_out.detach(), v_in) for name, fn in self.monitors.items()}
+            cont = self.controls_criterion(v_out, v_in)          # train.py:238-239
             roots.append(cont)
             root_grads.append(one)
         torch.autograd.backward(roots, root_grads)
         # total = recons + lat * beta (+ controls), evaluated by the optimizer's step-counter launch (after backward:
         # recons may be a deferred value that the backward kernels deliver)
-        total = torch.empty((), device=x.device, dtype=torch.float32)
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            total = torch.empty((), device=x.device, dtype=torch.float32)   # (written by the captured optimizer launch)
+        else:   # NaN until _optimizer_step has run: a caller of _forward_backward alone never reads garbage
+            total = torch.full((), float('nan'), device=x.device, dtype=torch.float32)
         terms = (recons.detach(), lat.detach(), beta_t, None if cont is None else cont.detach(), total)
         return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total, '_total_terms': terms,
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
-                'x_out': x_out.detach()}
+                'x_out': x_out.detach(), 'monitors': mon}
 
     def _constants(self, device):
         """(1, beta) as device scalars.  beta is written IN PLACE when ``self.beta`` changed (``set_beta``, or a caller
@@ -142,9 +162,9 @@ class VAETrainStep:
         """One minibatch.  Returns the losses / outputs as device tensors.  They are buffers of the step - in graph mode
         the captured step's static buffers, in eager mode ``z_mu_logvar`` may live in the optimizer's step scratch (the
         encoder's split-K linear layer accumulates into a slice cleared by ``zero_grad``): read them before the next
-        ``step`` overwrites them."""
+        ``step`` overwrites them.  Eager mode returns tensors the caller owns (``_owned``)."""
         if not self.use_graph or inject:
-            return self._step_body(x, v_in, inject)
+            return self._owned(self._step_body(x, v_in, inject))
         if self._graph is None:
             self._capture(x, v_in)
         # schedules: the captured kernels read lr / beta from device memory; refresh those words when the host-side
@@ -161,6 +181,18 @@ class VAETrainStep:
             self.grad_sync.exchange()
             self._graph_update.replay()
         return self._out
+
+    def _owned(self, out):
+        """Eager mode hands out tensors the caller may keep across steps (epoch-level latent metrics keep a list of
+        them): anything that lives in the optimizer's step scratch - ``z_mu_logvar`` when the encoder's split-K linear
+        layer accumulated into a zero_grad'ed slice, the Dkl word - would be cleared by the next ``zero_grad`` and
+        rewritten by the next step, so it is copied into a tensor of its own.  (Graph mode returns the captured step's
+        static buffers by contract: see ``step``.)"""
+        scratch = self.flat._grad_and_scratch.untyped_storage().data_ptr()
+        for k, t in out.items():
+            if torch.is_tensor(t) and t.untyped_storage().data_ptr() == scratch:
+                out[k] = t.clone()
+        return out
 
     @property
     def static_input(self):

@@ -432,6 +432,85 @@ def run_regstep_case(out_dir):
           os.path.getsize(path) // 1024, 'KiB')
 
 
+def run_regstep_cat_case(out_dir):
+    """train.py:203-248 as ``run_regstep_case``, with the criteria the reference actually trains with: controls loss =
+    ``SynthParamsLoss`` INCLUDING its categorical branch and the useless-parameter exclusion (train.py:111-116, the
+    default cat_softmax configuration), and the two monitoring metrics evaluated on every minibatch under ``no_grad``
+    before it (train.py:229-233: QuantizedNumericalParamsLoss, CategoricalParamsAccuracy), on the 14-column
+    representation of tests/helpers.MiniPresetIndexesHelper."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import MiniPresetIndexesHelper
+    arch, dim_z, B = 'speccnn4l1_bn', 64, 4
+    vae = build_reference_vae(arch, dim_z, B, False).double()
+    template = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    vae.load_state_dict(vo.closed_form_state_dict(template, seed=1234, dtype=torch.float64))
+    helper = MiniPresetIndexesHelper()
+    reg = ref_regression.MLPRegression('3l1024', dim_z, helper, dropout_p=0.4, cat_softmax_activation=False).double()
+    rtemplate = {k: tuple(v.shape) for k, v in reg.state_dict().items()}
+    reg.load_state_dict(vo.closed_form_state_dict(rtemplate, seed=4321, dtype=torch.float64))
+    x = synth_input(B)
+    eps = synth_vec((B, dim_z), 1.2345, 0.4) * 1.3
+    L = helper.learnable_preset_size
+    v_in = 0.5 * (synth_vec((B, L), 0.377, 0.6) + 1.0)
+    v_in[:, 1] = torch.round(v_in[:, 1] * 4) / 4
+    v_in[:, 2] = torch.round(v_in[:, 2] * 2) / 2
+    v_in[:, 13] = torch.round(v_in[:, 13] * 3) / 3
+    v_in[2, 0] = 0.0                                   # 'operator volumes' at zero: rules of the helper fire
+    v_in[3, 1] = 0.0
+    for g in helper.get_categorical_learnable_indexes():
+        cls = (torch.arange(B) * 3 + len(g)) % len(g)
+        v_in[:, g] = torch.nn.functional.one_hot(cls, len(g)).double()
+    enc_mask = keep_mask((B, vae.encoder.mlp[1].in_features), 0.3, 0.7071, 0.1)
+    dec_mask = keep_mask((B, vae.decoder.mlp[0].out_features), 0.3, 0.5772, 0.9)
+    vae.encoder.mlp[0] = _MaskMul(enc_mask)
+    vae.decoder.mlp[1] = _MaskMul(dec_mask)
+    rmasks = [keep_mask((B, 1024), 0.4, 0.61 + 0.1 * i, 0.2 * i) for i in range(2)]
+    reg.reg_model.drp1 = _MaskMul(rmasks[0])
+    reg.reg_model.drp2 = _MaskMul(rmasks[1])
+    _FixedNormal.eps = eps
+    vae.train(), reg.train()
+    params = list(vae.parameters()) + list(reg.parameters())
+    opt = torch.optim.Adam(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    crit = ref_loss.SynthParamsLoss(helper, True, cat_bce=False, cat_softmax=True, cat_softmax_t=0.2)   # train.py:111-116
+    qloss_crit = ref_loss.QuantizedNumericalParamsLoss(helper, numerical_loss=nn.MSELoss(reduction='mean'))  # :118-119
+    acc_crit = ref_loss.CategoricalParamsAccuracy(helper, reduce=True, percentage_output=True)               # :120-121
+    with mock.patch.object(ref_VAE, 'Normal', _FixedNormal):
+        opt.zero_grad()
+        zml, z0, zk, ladj, x_out = vae(x)
+        v_out = reg(zk)
+        recons = nn.MSELoss(reduction='mean')(x_out, x)
+        lat = vae.latent_loss(zml)
+        lat_b = lat * 0.2
+        with torch.no_grad():                                                     # train.py:229-233
+            qloss = qloss_crit(v_out, v_in)
+            acc = acc_crit(v_out, v_in)
+        v_out_seen = v_out.detach().clone()
+        cont = crit(v_out, v_in.clone())          # (writes zeros into the useless columns of both arguments, loss.py:134-135)
+        (recons + lat_b + torch.tensor([0.0], dtype=torch.float64) + cont).backward()
+    out = {'meta/arch': np.array(arch), 'meta/dim_z': np.array(dim_z), 'meta/B': np.array(B),
+           'meta/seed': np.array(1234), 'meta/reg_seed': np.array(4321), 'meta/beta': np.array(0.2),
+           'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4),
+           'meta/reg_keys': np.array(list(rtemplate.keys())),
+           'meta/reg_shapes': np.array([' '.join(str(d) for d in v) for v in rtemplate.values()]),
+           'in/eps': eps.numpy(), 'in/v_in': v_in.numpy(),
+           'in/enc_mask_bits': np.packbits((enc_mask > 0).numpy()), 'in/dec_mask_bits': np.packbits((dec_mask > 0).numpy()),
+           'in/enc_mask_shape': np.array(enc_mask.shape), 'in/dec_mask_shape': np.array(dec_mask.shape),
+           'in/reg_mask0_bits': np.packbits((rmasks[0] > 0).numpy()),
+           'in/reg_mask1_bits': np.packbits((rmasks[1] > 0).numpy()),
+           'train/z_mu_logvar': zml.detach().numpy(), 'train/v_out': v_out_seen.numpy(),
+           'train/recons': np.array(recons.item()), 'train/latent': np.array(lat.item()),
+           'train/controls': np.array(cont.item()), 'train/total': np.array((recons + lat_b + cont).item()),
+           'train/qloss': np.array(float(qloss)), 'train/accuracy': np.array(float(acc))}
+    for k, p in reg.named_parameters():
+        pack_big('grad_reg/' + k, p.grad, out)
+    for k in ('encoder.mlp.1.weight', 'encoder.mlp.1.bias'):
+        pack_big('grad/' + k, dict(vae.named_parameters())[k].grad, out)
+    path = os.path.join(out_dir, 'regstep_4l_b4_cat.npz')
+    np.savez_compressed(path, **out)
+    print('regstep_cat recons', recons.item(), 'lat', lat.item(), 'cont', cont.item(), 'qloss', float(qloss), 'acc',
+          float(acc), '->', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 def run_probability_case(out_dir):
     """utils/probability.py:13-29 and the ELBO combination of FlowVAE.latent_loss (VAE.py:183-193; the flow output z_K
     and log|det J| are given tensors here - the nflows transform is out of scope)."""
@@ -602,6 +681,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'regstep':
         run_regstep_case(HERE)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'regstep_cat':
+        run_regstep_cat_case(HERE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'b16':
         run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)
         run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
@@ -619,6 +701,7 @@ if __name__ == '__main__':
     run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)       # B = 16 capture
     run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
     run_regstep_case(HERE)
+    run_regstep_cat_case(HERE)
     run_dataset_seam_case(HERE)
     run_probability_case(HERE)
     run_params_loss_case(HERE)

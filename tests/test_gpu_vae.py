@@ -1102,3 +1102,119 @@ def test_graph_mode_schedules_and_first_step():
     step.step(x)
     torch.cuda.synchronize()
     assert any(not torch.equal(v.detach(), frozen[k]) for k, v in ae.named_parameters())
+
+
+def test_eager_outputs_survive_the_next_step():
+    """in eager mode ``z_mu_logvar`` (the encoder Linear's split-K output without the latent BatchNorm1d) and
+    the Dkl word are produced in the optimizer's step scratch, which the next ``zero_grad`` clears: ``step`` must hand out
+    copies, so a caller that keeps the outputs of step k (epoch-level latent metrics) still holds them after step k+1."""
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    B = 4
+    for output_bn in (False, True):
+        ae = _build('speccnn4l1_bn', 64, B, output_bn).cuda().train()
+        step = VAETrainStep(ae, use_graph=False)
+        x = _cuda32(synth_input(B))
+        out = step.step(x)
+        kept = {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+        assert kept['z_mu_logvar'].abs().max().item() > 0 and kept['latent'].item() > 0
+        step.step(x * 0.5)
+        torch.cuda.synchronize()
+        for k, v in kept.items():
+            assert torch.equal(out[k], v), (output_bn, k)
+
+
+def test_consecutive_forwards_without_optimizer_step_draw_fresh_randomness():
+    """the generator advance of a forward rides in the optimizer's step-counter launch; a second forward
+    without that launch in between (gradient accumulation, a loss probe) must not repeat eps and the Dropout masks, and
+    the total of a lone ``_forward_backward`` is NaN (not uninitialised memory) until the optimizer step writes it."""
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    B = 4
+    ae = _build('speccnn4l1_bn', 64, B, True).cuda().train()
+    step = VAETrainStep(ae, use_graph=False)
+    x = _cuda32(synth_input(B))
+    a = step._forward_backward(x)
+    za, ta = a['x_out'].clone(), a['total'].clone()
+    b = step._forward_backward(x)
+    torch.cuda.synchronize()
+    assert torch.isnan(ta).item()
+    assert rel_l2(b['x_out'], za) > 1e-3          # other eps, other masks
+    step._optimizer_step(b)
+    torch.cuda.synchronize()
+    assert abs(b['total'].item() - (b['recons'].item() + step.beta * b['latent'].item())) < 1e-5 * abs(b['total'].item())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_with_synth_params_loss_and_monitors_vs_reference_golden(use_graph):
+    """train.py:111-116, 229-243 inside the step: ``VAETrainStep(controls_criterion=SynthParamsLoss(...), monitors={...})``
+    - the categorical cross-entropy / useless-parameter criterion as the controls loss that is back-propagated through
+    the regression network INTO the encoder, and the two per-minibatch metrics, all evaluated by the f4 HIP kernels
+    inside the (captured) step - against the golden the reference's own classes produced (regstep_4l_b4_cat.npz)."""
+    import torch.nn as nn
+    from helpers import MiniPresetIndexesHelper
+    from preset_gen_vae_amd.model import params_loss, regression
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    from test_oracle_golden import regstep_inputs
+    g = load_golden('regstep_4l_b4_cat.npz')
+    i = regstep_inputs(g)
+    arch, dim_z, B = i['arch'], i['dim_z'], i['B']
+    helper = MiniPresetIndexesHelper()
+
+    class MaskMul(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            return x * self.m if self.training else x
+
+    ae = _build(arch, dim_z, B, False, fc_dropout=0.0 if use_graph else 0.3)
+    ae.load_state_dict({k: (v if v.dtype == torch.long else v.float()) for k, v in i['sd'].items()})
+    reg = regression.MLPRegression('3l1024', dim_z, helper, 0.4, cat_softmax_activation=False)
+    assert list(reg.state_dict().keys()) == list(i['rtpl'].keys())
+    reg.load_state_dict({k: (v if v.dtype == torch.long else v.float()) for k, v in i['rsd'].items()})
+    reg.reg_model.drp1, reg.reg_model.drp2 = MaskMul(_cuda32(i['rmasks'][0])), MaskMul(_cuda32(i['rmasks'][1]))
+    ae, reg = ae.cuda().train(), reg.cuda().train()
+    crit = params_loss.SynthParamsLoss(helper, True, cat_bce=False, cat_softmax=True, cat_softmax_t=0.2)
+    monitors = {'qloss': params_loss.QuantizedNumericalParamsLoss(helper, numerical_loss=nn.MSELoss(reduction='mean')),
+                'accuracy': params_loss.CategoricalParamsAccuracy(helper, reduce=True, percentage_output=True)}
+    step = VAETrainStep(ae, lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+                        beta=float(g['meta/beta']), normalize_losses=True, reg_model=reg, controls_criterion=crit,
+                        monitors=monitors, use_graph=use_graph)
+    x, v_in = _cuda32(i['x']), _cuda32(i['v_in'])
+    if not use_graph:
+        # the golden's eps / Dropout masks injected: every number of the step is comparable
+        inject = {'eps': _cuda32(i['eps']), 'enc_dropout_mask': _cuda32(i['enc_mask']),
+                  'dec_dropout_mask': _cuda32(i['dec_mask'])}
+        out = step.step(x, v_in=v_in, inject=inject)
+        torch.cuda.synchronize()
+        for key in ('recons', 'latent', 'controls', 'total'):
+            ref = float(g['train/' + key])
+            assert abs(out[key].item() - ref) <= 2e-4 * abs(ref), (key, out[key].item(), ref)
+        assert abs(out['monitors']['qloss'].item() - float(g['train/qloss'])) <= 1e-4 * float(g['train/qloss'])
+        assert abs(out['monitors']['accuracy'].item() - float(g['train/accuracy'])) <= 1e-4
+        assert rel_l2(out['z_mu_logvar'], torch.tensor(g['train/z_mu_logvar'])) < 2e-4
+        params = {'reg.' + k: p for k, p in reg.named_parameters()}
+        params.update({k: p for k, p in ae.named_parameters()})
+        n = 0
+        for k, p in params.items():
+            key = ('grad_reg/' + k[4:]) if k.startswith('reg.') else ('grad/' + k)
+            if key + '/checksum' in g.files and float(g[key + '/checksum'][2]) > 1e-9:
+                check_big('grad ' + k, p.grad, g, key, 5e-3, atol=1e-9)
+                n += 1
+        assert n >= 8
+        return
+    # captured step (generator-drawn eps, fc Dropout off): the criterion and the monitors replay from the graph with the
+    # minibatch's targets read from the static buffer - values must follow v_in from replay to replay, and equal what
+    # the same kernels return when called eagerly on the step's own v_out
+    out = step.step(x, v_in=v_in)
+    torch.cuda.synchronize()
+    first = {k: out['monitors'][k].item() for k in monitors}
+    c1 = out['controls'].item()
+    assert c1 > 0 and abs(out['total'].item() - (out['recons'].item() + step.beta * out['latent'].item() + c1)) \
+        < 1e-5 * abs(out['total'].item())
+    v2 = v_in.clone()
+    v2[:, [4, 5, 6]] = v2[:, [5, 6, 4]]          # other classes of the first one-hot group
+    out = step.step(x, v_in=v2)
+    torch.cuda.synchronize()
+    assert out['controls'].item() != c1
+    assert set(first) == {'qloss', 'accuracy'} and 0.0 <= first['accuracy'] <= 100.0

@@ -218,3 +218,22 @@ def test_preset_activation_softmax_branch_matches_reference():
     assert (y.detach() - torch.tensor(g['act_softmax/out'])).abs().max().item() < 1e-12
     (y * torch.tensor(g['act_softmax/gy'])).sum().backward()
     assert (x.grad - torch.tensor(g['act_softmax/gx'])).abs().max().item() < 1e-12
+
+
+def test_bench_starts_its_own_ranks_for_more_than_one_gpu():
+    """``python bench.py --gpus 2`` with no launcher above it (the form the round driver uses) must start the two ranks
+    itself - as child processes of torch.distributed.run, never by replacing a process - instead of exiting with an
+    instruction.  Without a GPU the children get as far as the device check and fail THERE; the parent hands their
+    status back."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['WORLD_SIZE'] = ''                    # an empty value counts as "no launcher" too
+    env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs a ROCm GPU') >= 2, r.stderr[-2000:]
+    assert 'launch with torch.distributed.run' not in r.stderr

@@ -110,6 +110,36 @@ def test_train_step_with_regression_matches_reference():
     assert n == len([k for k in r['new_sd'] if not k.endswith('num_batches_tracked')])
 
 
+def test_train_step_with_synth_params_loss_matches_reference():
+    """The same step with the criteria train.py really uses: SynthParamsLoss incl. its categorical branch and the
+    useless-parameter exclusion as controls loss (train.py:111-116, 238-239) and the two per-minibatch monitoring metrics
+    (train.py:229-233); golden regstep_4l_b4_cat.npz from the reference's own classes."""
+    from helpers import MiniPresetIndexesHelper
+    from oracle import params_oracle as po
+    g = load_golden('regstep_4l_b4_cat.npz')
+    i = regstep_inputs(g)
+    helper = MiniPresetIndexesHelper()
+    crit = lambda v_out, v_in: po.synth_params_loss(v_out, v_in, helper, True, cat_bce=False, cat_softmax=True,  # noqa: E731
+                                                    cat_softmax_t=0.2)
+    r = vo.train_step(i['sd'], i['x'], i['arch'], i['dim_z'], i['eps'], i['enc_mask'], i['dec_mask'],
+                      beta=float(g['meta/beta']), lr=float(g['meta/lr']), weight_decay=float(g['meta/weight_decay']),
+                      reg=dict(sd=i['rsd'], v_in=i['v_in'], masks=i['rmasks'], criterion=crit))
+    assert rel_l2(r['v_out'], torch.tensor(g['train/v_out'])) < 1e-10
+    for key in ('recons', 'latent', 'controls', 'total'):
+        assert abs(r[key].item() - float(g['train/' + key])) <= 1e-10 * abs(float(g['train/' + key])), key
+    q = po.quantized_numerical_params_loss(r['v_out'], i['v_in'], helper)
+    a = np.mean(list(po.categorical_params_accuracy(r['v_out'], i['v_in'], helper).values()))   # reduce=True, loss.py:313
+    # (the reference collects the quantised columns in float32 tensors, loss.py:222-224: its metric is a float32 number)
+    assert abs(float(q) - float(g['train/qloss'])) <= 1e-6 * float(q) and abs(float(a) - float(g['train/accuracy'])) <= 1e-9
+    n = 0
+    for k, gr in r['grads'].items():
+        key = ('grad_reg/' + k[4:]) if k.startswith('reg.') else ('grad/' + k)
+        if key + '/checksum' in g.files:
+            check_big('grad ' + k, gr, g, key, 1e-8)
+            n += 1
+    assert n >= 10
+
+
 def test_layer_blocks_match_reference():
     g = load_golden('layers_small.npz')
     names = sorted({k.split('/')[0] for k in g.files})
