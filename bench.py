@@ -45,10 +45,12 @@ def parse():
                     help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
                          "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
-    ap.add_argument("--dist-mode", default="eager", choices=["eager", "two-graph"],
-                    help="N > 1 launch mode: eager = every kernel launched from Python, bucketed all-reduce from "
-                         "gradient-ready hooks overlapped with backward; two-graph = [fwd+bwd] and [Adam] as two "
-                         "hipGraphs around an eagerly launched, non-overlapped all-reduce")
+    ap.add_argument("--dist-mode", default="bucket-graphs", choices=["bucket-graphs", "eager", "two-graph"],
+                    help="N > 1 launch mode: bucket-graphs = the captured step cut at the gradient-bucket boundaries "
+                         "(k + 2 hipGraphs), each bucket's all-reduce launched between two replays on the communication "
+                         "stream: replay AND overlap; eager = every kernel launched from Python, all-reduce from "
+                         "gradient-ready hooks; two-graph = [fwd+bwd] and [Adam] as two hipGraphs around a non-overlapped "
+                         "exchange")
     ap.add_argument("--dist-graph", action="store_true", help="alias of --dist-mode two-graph")
     ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets (N > 1)")
     ap.add_argument("--latent-reg", default="bn", choices=["bn", "none"],
@@ -543,7 +545,8 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     if dist_on:
         sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=args.buckets))
     step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
-                        beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph)
+                        beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph,
+                        graph_buckets=args.dist_mode == 'bucket-graphs')
 
     frontend = None
     if args.input == "audio":
@@ -570,10 +573,12 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    n_coll0 = step.grad_sync.n_collectives if step.grad_sync is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step(x)
     torch.cuda.synchronize()
+    n_coll = (step.grad_sync.n_collectives - n_coll0) if step.grad_sync is not None else 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -602,7 +607,12 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         value = args.batch * world * args.steps / elapsed
         launch = "eager"
         if use_graph:
-            launch = "hipGraph" if not dist_on else {'two-graph': "2 hipGraphs + eager all-reduce"}[args.dist_mode]
+            launch = "hipGraph"
+            if dist_on and args.dist_mode == 'two-graph':
+                launch = "2 hipGraphs + eager all-reduce"
+            elif dist_on:
+                launch = (f"{len(step._bucket_graphs) + 1} hipGraphs cut at the gradient buckets, all-reduce of a bucket "
+                          f"launched between two replays (overlaps the rest of backward)")
         cfg = {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
                            f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
                            + (" computed on the GPU from raw audio [B, 88576] inside the timed step"
@@ -613,6 +623,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
             cfg["grad_buckets_bytes"] = [4 * (hi - lo) for lo, hi in step.grad_sync.ranges]
+            cfg["collective_launches_per_step"] = n_coll / max(1, args.steps)
         line = {
             "metric": "spectrograms/sec per VAE train step (batch 256, 1x257x347)", "value": round(value, 2),
             "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -369,7 +369,18 @@ int launch_fast(int tm, int tn, int nsplit, hipStream_t st, int bf16, int M, int
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int init_c_launch(float* C, int M, int N, int64_t ldc, const float* bias_n, hipStream_t st) {
+  hipLaunchKernelGGL(init_c_kernel, dim3((unsigned)min((int64_t)1024, pgv_cdiv((int64_t)M * N, 256))), dim3(256), 0, st, C,
+                     M, N, ldc, bias_n);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 }  // namespace
+
+// gemm_frag.hip: the LDS-free fragment-streaming kernels for the nn.Linear shapes (1 = launched, 0 = shape not covered)
+int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                  float* C, int64_t ldc, const float* bias_n, int flags, hipStream_t st,
+                  int (*init_c)(float*, int, int, int64_t, const float*, hipStream_t));
 
 extern "C" {
 
@@ -381,6 +392,15 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
   PGV_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && A && B && C && ldc >= N, "pgv_gemm: bad argument");
   if (M == 0) return PGV_OK;
   hipStream_t st = pgv_stream(stream);
+  // ---- nn.Linear shapes, fp32: fragments streamed straight from global memory, no LDS tiles (gemm_frag.hip)
+  if (pgv_kernel_policy() == 0 && M > 0 && K > 0) {
+    const int rc = pgv_gemm_frag(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias_n, flags, st, init_c_launch);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      PGV_CHECK_LAUNCH("gemm_frag");
+      return PGV_OK;
+    }
+  }
   // ---- fast path: tile-aligned extents, one unit stride per operand, 16-byte aligned rows
   {
     const bool a_k = sak == 1, a_m = sam == 1 && !a_k, b_k = sbk == 1, b_n = sbn == 1 && !b_k;

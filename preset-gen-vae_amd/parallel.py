@@ -10,7 +10,9 @@ train.py:222-225).  BatchNorm batch statistics stay per rank, exactly like DataP
 
 Buckets are contiguous slices of the flat gradient in gradient-ready order (decoder output layer first).  When the
 last gradient of a bucket has been launched on the compute stream, an event is recorded and the bucket's all-reduce is
-enqueued on a dedicated communication stream; ``wait()`` joins the streams before the optimizer step.  xGMI is
+enqueued on a dedicated communication stream; ``wait()`` joins the streams before the optimizer step.  The same
+notifications cut a CAPTURED step into one hipGraph per bucket (``capture_cuts`` / ``launch_bucket``,
+``train_step.VAETrainStep._capture_bucket_graphs``): replay and overlap together.  xGMI is
 point-to-point (7 links/GPU), so a few large buckets (default 4 over 19.7-49.8 MB) are preferred to many small ones.
 """
 import torch
@@ -37,6 +39,8 @@ class GradAllReduce:
         self.use_cuda = flat.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat.flat_grad.device) if self.use_cuda else None
         self._works = []
+        self._on_bucket = None
+        self.n_collectives = 0     # bucket launches so far (also counted on one rank, where the collective is skipped)
 
     # -- hooks ---------------------------------------------------------------------------------------------
     def install(self):
@@ -60,8 +64,24 @@ class GradAllReduce:
         if self._done[bi] >= self._need[bi] and not self._launched[bi]:
             self._launch(bi)
 
+    def capture_cuts(self, on_bucket):
+        """While a step is being captured into hipGraphs (``VAETrainStep._capture_bucket_graphs``): a complete bucket
+        calls ``on_bucket(bi)`` instead of launching its collective - the train step cuts the capture there and launches
+        the collective itself between two replays (``launch_bucket``).  None switches back."""
+        self._on_bucket = on_bucket
+
+    def launch_bucket(self, bi):
+        """The all-reduce of bucket ``bi`` behind everything already queued on the current stream (bucket-graph mode:
+        the graph that completes the bucket has just been replayed)."""
+        if not self._launched[bi]:
+            self._launch(bi)
+
     def _launch(self, bi):
         self._launched[bi] = True
+        if self._on_bucket is not None:
+            self._on_bucket(bi)
+            return
+        self.n_collectives += 1
         if self.world_size == 1:
             return
         lo, hi = self.ranges[bi]
@@ -85,7 +105,7 @@ class GradAllReduce:
     def wait(self):
         """Flush buckets whose parameters produced no gradient this step, then join communication."""
         for bi in range(len(self.ranges)):
-            if not self._launched[bi]:
+            if not self._launched[bi] and self._on_bucket is None:
                 self._launch(bi)
         if self.world_size == 1:
             return

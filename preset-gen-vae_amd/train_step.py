@@ -12,11 +12,15 @@ Launch modes:
   eager, 1 rank      every kernel launched from Python;
   graph, 1 rank      one hipGraph = zero_grad + forward + losses + backward + Adam;
   eager, N ranks     bucketed all-reduce launched from gradient-ready hooks, overlapped with the rest of backward;
-  graph, N ranks     two hipGraphs around an eagerly launched exchange: [zero_grad + forward + losses + backward],
-                     the bucketed all-reduce on the communication stream, [Adam].  No collective is captured (the
-                     exchange stays an ordinary RCCL launch), the ~100 compute launches still replay from the device;
-                     what is given up is the overlap of the exchange with backward (a 20-50 MB all-reduce over xGMI,
-                     a fraction of the ~0.7 ms of host launch time the graphs save)."""
+  graph, N ranks     ``graph_buckets=True`` (default): the step is cut at the gradient-bucket boundaries into k + 2
+                     hipGraphs - [zero_grad + forward + backward until bucket 0 is complete], [... until bucket 1], ...,
+                     [rest of backward], [Adam].  Between two replays the host enqueues that bucket's all-reduce on the
+                     communication stream (an ordinary RCCL launch behind an event of the compute stream; no collective is
+                     captured), so the exchange of bucket i overlaps the backward graphs that follow it AND the ~50
+                     compute launches replay from the device: k + 2 graph launches and k collective launches per step
+                     instead of ~100 kernel launches from Python.
+                     ``graph_buckets=False``: two hipGraphs around the whole exchange ([zero_grad .. backward], all
+                     buckets, [Adam]) - replay without overlap (round 3's form, kept for A/B timing)."""
 import torch
 
 from . import optim as optim_mod
@@ -25,7 +29,8 @@ from .model import loss as loss_mod
 
 class VAETrainStep:
     def __init__(self, ae_model, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, beta=0.2, normalize_losses=True,
-                 reg_model=None, grad_sync=None, use_graph=False, controls_criterion=None, monitors=None):
+                 reg_model=None, grad_sync=None, use_graph=False, controls_criterion=None, monitors=None,
+                 graph_buckets=True):
         """``controls_criterion``: callable(v_out, v_in) -> 0-d loss, the backprop criterion of the preset-regression
         output (train.py:108-116: ``model.params_loss.SynthParamsLoss``; default: MSE over all columns, the numeric branch
         of that loss on an all-numerical representation).  ``monitors``: {name: callable(v_out, v_in)} evaluated under
@@ -59,6 +64,8 @@ class VAETrainStep:
             loss_mod.MSELoss(reduction='mean')
         self.monitors = dict(monitors or {})
         self.use_graph = use_graph
+        self.graph_buckets = bool(graph_buckets)
+        self._bucket_graphs = None     # [(hipGraph, [buckets complete when it has run])], bucket-graph mode
         self._const = {}
         self._graph = None
         self._graph_update = None
@@ -176,6 +183,15 @@ class VAETrainStep:
             self._static_x.copy_(x, non_blocking=True)
         if v_in is not None and v_in.data_ptr() != self._static_v.data_ptr():
             self._static_v.copy_(v_in, non_blocking=True)
+        if self._bucket_graphs is not None:
+            self.grad_sync.start_step()
+            for graph, ready in self._bucket_graphs:
+                graph.replay()
+                for bi in ready:                 # behind an event of the compute stream, on the communication stream
+                    self.grad_sync.launch_bucket(bi)
+            self.grad_sync.wait()                # (buckets nobody announced + join of the two streams)
+            self._graph_update.replay()
+            return self._out
         self._graph.replay()
         if self._graph_update is not None:
             self.grad_sync.exchange()
@@ -242,6 +258,9 @@ class VAETrainStep:
             with torch.cuda.graph(self._graph):
                 self._out = self._step_body(self._static_x, self._static_v)
             return
+        if self.graph_buckets:
+            self._capture_bucket_graphs()
+            return
         # N ranks: [zero_grad + forward + backward] | eager exchange | [Adam]; the capture itself leaves the parameters
         # untouched (captured work does not run), so every rank still holds identical replicas afterwards
         with torch.cuda.graph(self._graph):
@@ -249,3 +268,53 @@ class VAETrainStep:
         self._graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_update):
             self._optimizer_step(self._out)
+
+    def _capture_bucket_graphs(self):
+        """Cut the captured step at the gradient-bucket boundaries.  The capture runs the ordinary step body with the
+        gradient-ready hook installed; when the last gradient of a bucket has been launched, the hook ENDS the running
+        capture and begins the next one on the same stream and memory pool - nothing executes and nothing is enqueued
+        in between, so the k + 1 graphs replayed back to back are exactly the one-graph step.  Autograd's device
+        thread is switched off for the capture (``set_multithreading_enabled(False)``): stream capture has to be ended by
+        the thread that began it, and the hooks fire from inside ``Function.backward``."""
+        from .model import layer
+        sync = self.grad_sync
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        graphs, state = [], {'graph': None, 'ready': []}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(capture_error_mode='thread_local', **({'pool': graphs[0][0].pool()} if graphs else {}))
+            state['graph'], state['ready'] = g, []
+
+        def cut():
+            state['graph'].capture_end()
+            graphs.append((state['graph'], state['ready']))
+
+        def on_bucket(bi):                       # called by GradAllReduce in place of the collective launch
+            state['ready'].append(bi)
+            cut()
+            begin()
+
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        prev_hook = layer.GRAD_READY_HOOK
+        with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
+            sync.capture_cuts(on_bucket)
+            layer.GRAD_READY_HOOK = sync._on_grad_ready
+            try:
+                begin()
+                self._out = self._forward_backward(self._static_x, self._static_v, hooks=True)
+                cut()
+            finally:
+                layer.GRAD_READY_HOOK = prev_hook
+                sync.capture_cuts(None)
+            self._graph_update = torch.cuda.CUDAGraph()
+            self._graph_update.capture_begin(pool=graphs[0][0].pool(), capture_error_mode='thread_local')
+            self._optimizer_step(self._out)
+            self._graph_update.capture_end()
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self._bucket_graphs = graphs
+        self._graph = graphs[0][0]

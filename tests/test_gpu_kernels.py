@@ -923,7 +923,10 @@ def test_batchnorm_pieces(ops, shape):
 
 
 @pytest.mark.parametrize("mnk", [(256, 128, 25024), (256, 25024, 64), (16, 128, 24576), (5, 7, 3), (64, 64, 64),
-                                 (2, 24576, 64), (130, 70, 33)])
+                                 (2, 24576, 64), (130, 70, 33),
+                                 # the fragment-streaming kernels (gemm_frag.hip): z = 512 extents, K splits that do not
+                                 # divide the chunk count, single-chunk-pair K, ragged job counts
+                                 (256, 1024, 25024), (256, 25024, 512), (96, 192, 4112), (32, 64, 32), (160, 320, 48)])
 def test_linear_gemm(ops, mnk):
     M, N, K = mnk
     x = synth_vec((M, K), 0.771, 0.3)

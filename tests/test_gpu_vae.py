@@ -321,38 +321,47 @@ def test_train_step_bf16_operand_mode_vs_oracle(arch, dim_z):
 
 
 def test_two_graph_launch_mode_matches_single_graph():
-    """train_step's N-rank graph mode ([zero_grad + fwd + bwd] graph, eager exchange, [Adam] graph) against the
-    one-graph mode, on one rank (the exchange is then a no-op, the two-graph sequencing is what is under test):
-    the parameter UPDATES of 3 steps (the capture warm-ups are rolled back) must agree."""
+    """train_step's N-rank graph modes - the step cut at the gradient buckets (k + 2 graphs, a bucket's all-reduce
+    between two replays) and [zero_grad + fwd + bwd] graph, eager exchange, [Adam] graph - against the one-graph mode,
+    on one rank (the exchange is then a no-op, the sequencing of the graphs is what is under test): the parameter
+    UPDATES of 3 steps (the capture warm-ups are rolled back) must agree."""
     from preset_gen_vae_amd import parallel
     from preset_gen_vae_amd.train_step import VAETrainStep
     arch, dim_z, B = 'speccnn4l1_bn', 64, 4
     x = _cuda32(synth_input(B))
     finals = []
-    for two_graphs in (False, True):
+    for mode in ('one-graph', 'two-graph', 'bucket-graphs'):
+        two_graphs = mode != 'one-graph'
         ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
         _load_closed_form(ae, arch, dim_z, False, 99)
         ae = ae.cuda().train()
         torch.manual_seed(7)
         before = {k: v.detach().clone() for k, v in ae.named_parameters()}
         sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=3)) if two_graphs else None
-        step = VAETrainStep(ae, lr=1e-5, grad_sync=sync, use_graph=True)
+        step = VAETrainStep(ae, lr=1e-5, grad_sync=sync, use_graph=True, graph_buckets=mode == 'bucket-graphs')
         for _ in range(3):
             out = step.step(x)
         torch.cuda.synchronize()
         assert (step._graph_update is not None) == two_graphs
+        if mode == 'bucket-graphs':
+            # the step was cut where each of the 3 buckets became complete: 3 graphs that end with a bucket + the rest of
+            # backward (+ the optimizer graph); every bucket is launched once per step, between two replays
+            # (2 capture warm-ups + 3 replayed steps, 3 buckets each)
+            assert [r for _, r in step._bucket_graphs] == [[0], [1], [2], []]
+            assert step.grad_sync.n_collectives == 15
         # (conv biases in front of a BatchNorm have a mathematically zero gradient: Adam turns their float noise into
         # +-lr updates, so they are not comparable between any two runs)
         finals.append((out['total'].item(), {k: v.detach() - before[k] for k, v in ae.named_parameters()
                                               if not k.endswith('conv.bias')}))
-    assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * abs(finals[0][0])
-    for k, dv in finals[0][1].items():
-        assert dv.abs().max().item() > 1e-5             # three Adam steps of 1e-5 happened
-        # Adam's first steps move every element by ~lr*sign(g): compare where the sign of the gradient was stable over
-        # the three steps (|update| ~ 3 lr); elements whose gradient hovers around zero flip with float-atomics noise
-        stable = dv.abs() > 0.9 * 3 * 1e-5
-        if stable.float().mean().item() > 0.05:
-            assert rel_l2(finals[1][1][k][stable], dv[stable]) < 2e-2, k
+    for other in finals[1:]:
+        assert abs(finals[0][0] - other[0]) <= 1e-4 * abs(finals[0][0])
+        for k, dv in finals[0][1].items():
+            assert dv.abs().max().item() > 1e-5             # three Adam steps of 1e-5 happened
+            # Adam's first steps move every element by ~lr*sign(g): compare where the sign of the gradient was stable over
+            # the three steps (|update| ~ 3 lr); elements whose gradient hovers around zero flip with float-atomics noise
+            stable = dv.abs() > 0.9 * 3 * 1e-5
+            if stable.float().mean().item() > 0.05:
+                assert rel_l2(other[1][k][stable], dv[stable]) < 2e-2, k
 
 
 @pytest.mark.parametrize("normalize", [True, False])

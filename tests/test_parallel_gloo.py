@@ -114,3 +114,61 @@ def test_single_process_is_a_noop():
     p.grad.fill_(3.0)
     sync.wait()
     assert torch.all(p.grad == 3.0)
+
+
+def _worker_cuts(rank, world, port, ret):
+    """The bucket-graph protocol of VAETrainStep without the graphs (they need a GPU): pass 1 = "capture" - the hooks
+    report complete buckets to ``capture_cuts`` and launch NOTHING; pass 2..3 = "replays" - the gradients of a segment are
+    written, then that segment's buckets are launched with ``launch_bucket``, the rest by ``wait``."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from preset_gen_vae_amd import optim, parallel
+        from preset_gen_vae_amd.model import layer
+        tpl, sd, grads = _shard_grads(rank, world)
+        params = {k: torch.nn.Parameter(sd[k].float()) for k in grads}
+        name_of = {id(v): k for k, v in params.items()}
+        flat = optim.FlatParams(list(params.values()))
+        sync = parallel.GradAllReduce(flat, n_buckets=3)
+        segments, cur = [], []                     # [(parameters whose gradient the segment writes, buckets complete)]
+        sync.capture_cuts(lambda bi: (segments.append((list(cur), [bi])), cur.clear()))
+        layer.GRAD_READY_HOOK = sync._on_grad_ready
+        sync.start_step()
+        for p in flat.params:
+            cur.append(p)
+            layer._grad_done(p)
+        segments.append((list(cur), []))
+        layer.GRAD_READY_HOOK = None
+        sync.capture_cuts(None)
+        assert sync.n_collectives == 0 and [b for _, b in segments] == [[0], [1], [2], []]
+        worst = 0.0
+        for _ in range(2):                         # two "replayed" steps
+            flat.flat_grad.zero_()
+            sync.start_step()
+            for ps, ready in segments:
+                for p in ps:
+                    p.grad.copy_(grads[name_of[id(p)]].float())
+                for bi in ready:
+                    sync.launch_bucket(bi)
+            sync.wait()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, {k: v.double() for k, v in grads.items()})
+            for k, p in params.items():
+                total = sum(gr[k] for gr in gathered)
+                worst = max(worst, (p.grad.double() - total).abs().max().item() / max(total.abs().max().item(), 1e-12))
+        if rank == 0:
+            ret['worst'] = worst
+            ret['collectives'] = sync.n_collectives
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_graph_protocol_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_cuts, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret['collectives'] == 6            # 3 buckets x 2 steps, none during the capture pass
+    assert ret['worst'] < 1e-6
