@@ -165,6 +165,46 @@ def time_kernel(fn, iters=5):
     return max(_time_graph(_graph_of(with_fn)) - _FLUSH_MS[iters], 0.0) / iters
 
 
+_PEAKS = None
+
+
+def measured_peaks(device):
+    """What THIS box sustains on the two roofline resources (SURVEY.md section 8d asks for measured AND nominal peaks):
+    HBM reads - a 16-byte-per-lane grid-stride read reduction over 512 MB (pgv_probe_read) - and the matrix pipe - a
+    dependency-free MFMA stream from one wave per SIMD on every CU, ~1 ms per launch, lane-dependent operands
+    (pgv_probe_mfma: v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_bf16).  Timed like the launches of the step: HIP events
+    around graph replays.  Measured once per process."""
+    global _PEAKS, _FLUSH, _SINK
+    if _PEAKS is not None:
+        return _PEAKS
+    import ctypes
+    from preset_gen_vae_amd import _lib
+    from preset_gen_vae_amd.ops import _stream
+    lib = _lib.load()
+    if _FLUSH is None:
+        _FLUSH = torch.ones(128 << 20, device=device, dtype=torch.float32)
+        _SINK = torch.zeros((), device=device, dtype=torch.float32)
+    sink = torch.zeros(4, device=device)
+    flops = ctypes.c_int64(0)
+    out = {}
+    for name, bf16, iters in (('mfma_f32_TFLOPs', 0, 1500), ('mfma_bf16_TFLOPs', 1, 3000)):
+        def body(bf16=bf16, iters=iters):
+            _lib.check(lib.pgv_probe_mfma(bf16, iters, sink.data_ptr(), ctypes.byref(flops), _stream()), "pgv_probe_mfma")
+        body()
+        torch.cuda.synchronize()
+        ms = min(_time_graph(_graph_of(body), reps=5) for _ in range(2))
+        out[name] = round(flops.value / (ms * 1e-3) / 1e12, 1)
+
+    def read():
+        _lib.check(lib.pgv_probe_read(_FLUSH.data_ptr(), _FLUSH.numel(), sink.data_ptr(), _stream()), "pgv_probe_read")
+    read()
+    torch.cuda.synchronize()
+    ms = min(_time_graph(_graph_of(read), reps=5) for _ in range(2))
+    out['hbm_read_GBs'] = round(_FLUSH.numel() * 4 / (ms * 1e-3) / 1e9, 1)
+    _PEAKS = out
+    return out
+
+
 def launch_table(ae, B, device, frontend=None):
     """Every distinct kind of launch the train step issues, as (label, fn, algorithmic bytes, algorithmic flops):
     forward / input-gradient / weight-gradient of every conv block exactly as the step issues them, the BatchNorm /
@@ -399,8 +439,16 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     except (OSError, ValueError):
         pass
     conv = [r for r in rows if r['launch'].startswith('conv_')]
+    mp = measured_peaks(device)
+    mpeak = mp['hbm_read_GBs'] if worst['bound'] == 'hbm' else \
+        (mp['mfma_bf16_TFLOPs'] if matrix_peak == BF16_MATRIX_PEAK_TFLOPS else mp['mfma_f32_TFLOPs'])
+    # the same sum of per-launch rooflines, priced against what this box sustains instead of the data-sheet figures
+    mpf = mp['mfma_bf16_TFLOPs'] if matrix_peak == BF16_MATRIX_PEAK_TFLOPS else mp['mfma_f32_TFLOPs']
+    conv_meas = sum(max(r['bytes'] / (mp['hbm_read_GBs'] * 1e9), r['flops'] / (mpf * 1e12)) for r in conv) * 1e3
     roof = {'bound': worst['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
-            'frac': round(achieved / peak, 5), 'traffic': traffic, 'kernel': worst['launch'],
+            'frac': round(achieved / peak, 5), 'measured_peak': mpeak, 'frac_of_measured_peak': round(achieved / mpeak, 5),
+            'measured_peaks': mp, 'conv_launches_sum_measured_roofline_ms': round(conv_meas, 4),
+            'traffic': traffic, 'kernel': worst['launch'],
             'kernel_ms': round(worst['ms'], 4), 'algorithmic_bytes': worst['bytes'],
             'algorithmic_flops': worst['flops'],
             'selection': 'lowest roofline fraction among launches >= 2 % of the step',

@@ -459,6 +459,14 @@ int pgv_fill(float* p, int64_t n, float v, void* stream);
 int pgv_axpy(int64_t n, float a, const float* x, float* y, void* stream);
 /* Streaming copy used for bandwidth calibration in bench.py. */
 int pgv_copy(const float* src, float* dst, int64_t n, void* stream);
+/* Measured-peak probes for bench.py (SURVEY.md 8d asks for the roofline against measured AND nominal peaks; not part
+ * of the train step, nothing in the reference corresponds to them).  pgv_probe_mfma: a dependency-free stream of
+ * v_mfma_f32_16x16x4_f32 (bf16 = 0) or v_mfma_f32_16x16x32_bf16 (bf16 = 1), one wave per SIMD on every CU, `iters` x 32
+ * instructions per wave; *flops (host pointer, nullable) receives the floating-point operations of the launch.
+ * pgv_probe_read: a 16-byte-per-lane grid-stride read reduction over n floats (16-byte aligned). `sink`: one device
+ * float that is never written in practice. */
+int pgv_probe_mfma(int bf16, int iters, float* sink, int64_t* flops, void* stream);
+int pgv_probe_read(const float* buf, int64_t n, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

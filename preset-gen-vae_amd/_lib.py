@@ -146,6 +146,8 @@ SIGNATURES = {
     "pgv_params_columns": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_axpy": (c_int, [c_int64, c_float, _P, _P, _P]),
     "pgv_copy": (c_int, [_P, _P, c_int64, _P]),
+    "pgv_probe_mfma": (c_int, [c_int, c_int, _P, POINTER(c_int64), _P]),
+    "pgv_probe_read": (c_int, [_P, c_int64, _P, _P]),
 }
 
 _lib = None

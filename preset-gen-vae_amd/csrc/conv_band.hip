@@ -244,40 +244,66 @@ __global__ __launch_bounds__(256, 2) void conv_down_band_kernel(int B, int Cb, i
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // bf16 compute (PGV_COMPUTE_BF16): one v_mfma_f32_16x16x16_bf16 per (channel, m, t) - the lane group supplies its
+      // bf16 compute (PGV_COMPUTE_BF16): one bf16 MFMA step per (channel, m, t) - the lane group supplies its
       // kw tap for the four kernel rows kh = 0..3 (the operands of four fp32 steps), rounded to bf16 while packing
       constexpr int S = CK;
-      s16x4 a0[MT], a1[MT], b0[NT], b1[NT];
-      auto load_step = [&](int c, s16x4 (&av)[MT], s16x4 (&bv)[NT]) {
+      u32x4 a0[MT], b0[NT];
+      auto load_step = [&](auto half_c, int c, u32x4 (&av)[MT], u32x4 (&bv)[NT]) {
+        constexpr int HALF = decltype(half_c)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const float* ap = wt + c * 16 * CSP + m * 16 + offA;
-          av[m] = pack_bf16x4(ap[0], ap[4 * CSP], ap[8 * CSP], ap[12 * CSP]);
+          set_half<HALF>(av[m], pack_bf16x4(ap[0], ap[4 * CSP], ap[8 * CSP], ap[12 * CSP]));
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float* bp = in_tile + c * PLANE + offB[t];
-          bv[t] = pack_bf16x4(bp[0], bp[WP], bp[2 * WP], bp[3 * WP]);
+          set_half<HALF>(bv[t], pack_bf16x4(bp[0], bp[WP], bp[2 * WP], bp[3 * WP]));
         }
       };
-      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NT]) {
+      // two 16-deep steps per v_mfma_f32_16x16x32_bf16 (conv_tile.h); pairs are double-buffered where the registers allow
+      // it: the operands of pair p + 1 are read and packed while pair p multiplies.  The kernels with large tiles (33x45
+      // planes) would spill: they read a pair, multiply it, read the next - the co-resident workgroup covers the latency.
+      auto compute_pair = [&](const u32x4 (&a8)[MT], const u32x4 (&b8)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[t], acc[m][t], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16_k32(a8[m], b8[t], acc[m][t]);
       };
-      load_step(0, a0, b0);
+      auto load_pair = [&](int st, u32x4 (&a8)[MT], u32x4 (&b8)[NT]) {
+        load_step(std::integral_constant<int, 0>{}, st, a8, b8);
+        if (st + 1 < S) {
+          load_step(std::integral_constant<int, 1>{}, st + 1, a8, b8);
+        } else {
 #pragma unroll
-      for (int st = 0; st < S; st += 2) {
-        load_step(st + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_step(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < S) load_step(st + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_step(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; ++m) a8[m][2] = a8[m][3] = 0u;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b8[t][2] = b8[t][3] = 0u;
+        }
+      };
+      constexpr bool DB = MT + NT <= 6;
+      if constexpr (DB) {
+        u32x4 a1[MT], b1[NT];
+        load_pair(0, a0, b0);
+#pragma unroll
+        for (int st = 0; st < S; st += 4) {
+          if (st + 2 < S) load_pair(st + 2, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 4 < S) load_pair(st + 4, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 2 < S) compute_pair(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < S; st += 2) {
+          load_pair(st, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 #ifdef PGV_SETPRIO
@@ -614,38 +640,64 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
       constexpr int SPR4 = SPR / 4;
       static_assert(SPR % 4 == 0, "bf16 rows are padded to 16 pixels");
       constexpr int S = RW * SPR4;
-      s16x4 a0[MT], a1[MT], b0[NB], b1[NB];
-      auto load_step = [&](int st, s16x4 (&av)[MT], s16x4 (&bv)[NB]) {
+      u32x4 a0[MT], b0[NB];
+      auto load_step = [&](auto half_c, int st, u32x4 (&av)[MT], u32x4 (&bv)[NB]) {
+        constexpr int HALF = decltype(half_c)::value;
         const int rw = st / SPR4, i = st - rw * SPR4;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const float* ap = small_tile + offA[m] + rw * WK * WsP + 16 * i;
-          av[m] = pack_bf16x4(ap[0], ap[4], ap[8], ap[12]);
+          set_half<HALF>(av[m], pack_bf16x4(ap[0], ap[4], ap[8], ap[12]));
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           const float* bp = big_tile + offB[n] + rw * WK * 2 * WP + 32 * i;
-          bv[n] = pack_bf16x4(bp[0], bp[8], bp[16], bp[24]);
+          set_half<HALF>(bv[n], pack_bf16x4(bp[0], bp[8], bp[16], bp[24]));
         }
       };
-      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NB]) {
+      // two 16-deep steps per v_mfma_f32_16x16x32_bf16 (conv_tile.h); pairs are double-buffered where the registers allow
+      // it: the operands of pair p + 1 are read and packed while pair p multiplies.  The kernels with large tiles (33x45
+      // planes) would spill: they read a pair, multiply it, read the next - the co-resident workgroup covers the latency.
+      auto compute_pair = [&](const u32x4 (&a8)[MT], const u32x4 (&b8)[NB]) {
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[n], acc[m][n], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf16_k32(a8[m], b8[n], acc[m][n]);
       };
-      load_step(0, a0, b0);
+      auto load_pair = [&](int st, u32x4 (&a8)[MT], u32x4 (&b8)[NB]) {
+        load_step(std::integral_constant<int, 0>{}, st, a8, b8);
+        if (st + 1 < S) {
+          load_step(std::integral_constant<int, 1>{}, st + 1, a8, b8);
+        } else {
 #pragma unroll
-      for (int st = 0; st < S; st += 2) {
-        if (st + 1 < S) load_step(st + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_step(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < S) load_step(st + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < S) compute_step(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; ++m) a8[m][2] = a8[m][3] = 0u;
+#pragma unroll
+          for (int n = 0; n < NB; ++n) b8[n][2] = b8[n][3] = 0u;
+        }
+      };
+      constexpr bool DB = MT + NB <= 6;
+      if constexpr (DB) {
+        u32x4 a1[MT], b1[NB];
+        load_pair(0, a0, b0);
+#pragma unroll
+        for (int st = 0; st < S; st += 4) {
+          if (st + 2 < S) load_pair(st + 2, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 4 < S) load_pair(st + 4, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 2 < S) compute_pair(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < S; st += 2) {
+          load_pair(st, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     BAND_ACC(5);
@@ -922,37 +974,63 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
       // and supplies it for channels 4s..4s+3 (the operands of four fp32 steps), rounded to bf16 while packing
       constexpr int S = CK / 4;
       static_assert(CK % 8 == 0, "channel chunk must hold an even number of 4-channel steps");
-      s16x4 a0[MT], a1[MT], b0[NT], b1[NT];
-      auto load_step = [&](int st, s16x4 (&av)[MT], s16x4 (&bv)[NT]) {
+      u32x4 a0[MT], b0[NT];
+      auto load_step = [&](auto half_c, int st, u32x4 (&av)[MT], u32x4 (&bv)[NT]) {
+        constexpr int HALF = decltype(half_c)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const float* ap = wt + st * 16 * MSP + m * 16 + offA;
-          av[m] = pack_bf16x4(ap[0], ap[4 * MSP], ap[8 * MSP], ap[12 * MSP]);
+          set_half<HALF>(av[m], pack_bf16x4(ap[0], ap[4 * MSP], ap[8 * MSP], ap[12 * MSP]));
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float* bp = in_tile + st * 4 * PLANE + offB[t];
-          bv[t] = pack_bf16x4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
+          set_half<HALF>(bv[t], pack_bf16x4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]));
         }
       };
-      auto compute_step = [&](const s16x4 (&av)[MT], const s16x4 (&bv)[NT]) {
+      // two 16-deep steps per v_mfma_f32_16x16x32_bf16 (conv_tile.h); pairs are double-buffered where the registers allow
+      // it: the operands of pair p + 1 are read and packed while pair p multiplies.  The kernels with large tiles (33x45
+      // planes) would spill: they read a pair, multiply it, read the next - the co-resident workgroup covers the latency.
+      auto compute_pair = [&](const u32x4 (&a8)[MT], const u32x4 (&b8)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[t], acc[m][t], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16_k32(a8[m], b8[t], acc[m][t]);
       };
-      load_step(0, a0, b0);
+      auto load_pair = [&](int st, u32x4 (&a8)[MT], u32x4 (&b8)[NT]) {
+        load_step(std::integral_constant<int, 0>{}, st, a8, b8);
+        if (st + 1 < S) {
+          load_step(std::integral_constant<int, 1>{}, st + 1, a8, b8);
+        } else {
 #pragma unroll
-      for (int st = 0; st < S; st += 2) {
-        load_step(st + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_step(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < S) load_step(st + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_step(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; ++m) a8[m][2] = a8[m][3] = 0u;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b8[t][2] = b8[t][3] = 0u;
+        }
+      };
+      constexpr bool DB = MT + NT <= 6;
+      if constexpr (DB) {
+        u32x4 a1[MT], b1[NT];
+        load_pair(0, a0, b0);
+#pragma unroll
+        for (int st = 0; st < S; st += 4) {
+          if (st + 2 < S) load_pair(st + 2, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 4 < S) load_pair(st + 4, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 2 < S) compute_pair(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < S; st += 2) {
+          load_pair(st, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          compute_pair(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     BAND_ACC(5);

@@ -240,10 +240,12 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
       }
       auto mfmas = [&](const f32x4& a, f32x4 (&ac)[G::NT]) {
         if constexpr (BF16) {
+          // (one channel per wave and slab: the K = 32 instruction runs with its upper half zero - the same 16 cycles the
+          // legacy K = 16 form took; pairing channels needs CK = 8 slabs, twice the stage)
           const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
 #pragma unroll
           for (int t = 0; t < G::NT; ++t)
-            ac[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(bf[t][0], bf[t][1], bf[t][2], bf[t][3]), ac[t], 0, 0, 0);
+            ac[t] = mfma_bf16_k32(av, zero_bf16x4(), pack_bf16x4(bf[t][0], bf[t][1], bf[t][2], bf[t][3]), zero_bf16x4(), ac[t]);
         } else {
 #pragma unroll
           for (int kw = 0; kw < 4; ++kw)
@@ -547,22 +549,34 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
     const float* ap = st + a_frag;
     const float* bp = st + G::A_FLOATS;
     if constexpr (BF16) {
+      // v_mfma_f32_16x16x32_bf16: two 4-channel groups per instruction where a wave has two (zero upper half otherwise)
+      constexpr int NG = CK / 8;
 #pragma unroll
-      for (int gg = 0; gg < CK / 8; ++gg) {
-        const int g = kg * (CK / 8) + gg;
+      for (int gg = 0; gg < NG; gg += 2) {
+        const int g = kg * NG + gg;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * g * G::ACS + 4 * p);
           const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+          s16x4 av2 = zero_bf16x4();
+          if constexpr (NG > 1) {
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(ap + 4 * (g + 1) * G::ACS + 4 * p);
+            av2 = pack_bf16x4(a2[0], a2[1], a2[2], a2[3]);
+          }
 #pragma unroll
           for (int tt = 0; tt < G::ntp(p); ++tt) {
             const int t = G::tile0(p) + tt;
             const float* q = bp + bn[t] + 4 * g * G::CH_STRIDE;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(q[0], q[-1], q[-G::SWP], q[-G::SWP - 1]),
-                                                              acc[t], 0, 0, 0);
+            s16x4 bv2 = zero_bf16x4();
+            if constexpr (NG > 1) {
+              const float* q2 = q + 4 * G::CH_STRIDE;
+              bv2 = pack_bf16x4(q2[0], q2[-1], q2[-G::SWP], q2[-G::SWP - 1]);
+            }
+            acc[t] = mfma_bf16_k32(av, av2, pack_bf16x4(q[0], q[-1], q[-G::SWP], q[-G::SWP - 1]), bv2, acc[t]);
           }
         }
       }
+      static_assert(NG == 1 || NG % 2 == 0, "channel groups of a slab in pairs");
     } else {
 #pragma unroll
       for (int gg = 0; gg < CK / 8; ++gg) {
@@ -863,14 +877,25 @@ __global__ __launch_bounds__(256) void deep_wgrad_kernel(int B, int CB, int CS, 
 #pragma unroll
       for (int si = 0; si < SB; ++si) {
         if constexpr (BF16) {
+          // v_mfma_f32_16x16x32_bf16: two 16-pixel groups of the sample per instruction (an odd last group: zero upper half)
 #pragma unroll
-          for (int g = 0; g < G::GROUPS; ++g) {
+          for (int g = 0; g < G::GROUPS; g += 2) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(ap + si * 64 * G::SROW + 16 * g);
             const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+            s16x4 av2 = zero_bf16x4();
+            if (g + 1 < G::GROUPS) {
+              const f32x4 a2 = *reinterpret_cast<const f32x4*>(ap + si * 64 * G::SROW + 16 * (g + 1));
+              av2 = pack_bf16x4(a2[0], a2[1], a2[2], a2[3]);
+            }
 #pragma unroll
             for (int t = 0; t < CBT; ++t) {
               const float* q = bp + (si * CBT + t) * G::PLANE + stepoff[g];
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(q[0], q[2], q[4], q[6]), acc[t], 0, 0, 0);
+              s16x4 bv2 = zero_bf16x4();
+              if (g + 1 < G::GROUPS) {
+                const float* q2 = bp + (si * CBT + t) * G::PLANE + stepoff[g + 1 < G::GROUPS ? g + 1 : g];
+                bv2 = pack_bf16x4(q2[0], q2[2], q2[4], q2[6]);
+              }
+              acc[t] = mfma_bf16_k32(av, av2, pack_bf16x4(q[0], q[2], q[4], q[6]), bv2, acc[t]);
             }
           }
         } else {
@@ -1051,12 +1076,23 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(int B, int CIN, int COUT, c
         a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
       }
       if constexpr (BF16) {
-        const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+        // v_mfma_f32_16x16x32_bf16: the 16-channel groups g and g + 1 of the slab in one instruction (issued at even g)
+        static_assert((CK / 16) % 2 == 0, "16-channel groups of a slab in pairs");
+        if (g & 1) continue;
+        f32x4 a2;
+        if (TRANSA) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a2[e] = ap[(16 * (g + 1) + e) * G::AS];
+        } else {
+          a2 = *reinterpret_cast<const f32x4*>(ap + 16 * (g + 1));
+        }
+        const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]), av2 = pack_bf16x4(a2[0], a2[1], a2[2], a2[3]);
 #pragma unroll
         for (int t = 0; t < G::NT; ++t) {
           const float* q = bp + bn[t] + 16 * g * G::CH_STRIDE;
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
-              av, pack_bf16x4(q[0], q[G::CH_STRIDE], q[2 * G::CH_STRIDE], q[3 * G::CH_STRIDE]), acc[t], 0, 0, 0);
+          const float* q2 = q + 16 * G::CH_STRIDE;
+          acc[t] = mfma_bf16_k32(av, av2, pack_bf16x4(q[0], q[G::CH_STRIDE], q[2 * G::CH_STRIDE], q[3 * G::CH_STRIDE]),
+                                 pack_bf16x4(q2[0], q2[G::CH_STRIDE], q2[2 * G::CH_STRIDE], q2[3 * G::CH_STRIDE]), acc[t]);
         }
       } else {
 #pragma unroll
@@ -1199,13 +1235,21 @@ __global__ __launch_bounds__(512) void k1_down128_kernel(int B, int CIN, int COU
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + 16 * g);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 16 * AS + 16 * g);
       if constexpr (BF16) {
+        // v_mfma_f32_16x16x32_bf16: the 16-channel groups g and g + 1 of the slab in one instruction (issued at even g)
+        static_assert((CK / 16) % 2 == 0, "16-channel groups of a slab in pairs");
+        if (g & 1) continue;
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(ap + 16 * (g + 1));
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(ap + 16 * AS + 16 * (g + 1));
         const s16x4 av0 = pack_bf16x4(a0[0], a0[1], a0[2], a0[3]), av1 = pack_bf16x4(a1[0], a1[1], a1[2], a1[3]);
+        const s16x4 av2 = pack_bf16x4(a2[0], a2[1], a2[2], a2[3]), av3 = pack_bf16x4(a3[0], a3[1], a3[2], a3[3]);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
           const float* q = bp + bn[t] + 16 * g * CH_STRIDE;
+          const float* q2 = q + 16 * CH_STRIDE;
           const s16x4 bv = pack_bf16x4(q[0], q[CH_STRIDE], q[2 * CH_STRIDE], q[3 * CH_STRIDE]);
-          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av0, bv, acc[0][t], 0, 0, 0);
-          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av1, bv, acc[1][t], 0, 0, 0);
+          const s16x4 bv2 = pack_bf16x4(q2[0], q2[CH_STRIDE], q2[2 * CH_STRIDE], q2[3 * CH_STRIDE]);
+          acc[0][t] = mfma_bf16_k32(av0, av2, bv, bv2, acc[0][t]);
+          acc[1][t] = mfma_bf16_k32(av1, av3, bv, bv2, acc[1][t]);
         }
       } else {
 #pragma unroll
@@ -1411,13 +1455,23 @@ __global__ __launch_bounds__(256) void k1_wgrad_kernel(int B, int CB, int CS, co
       const float* bp = st + G::A_FLOATS + b_frag;
       if constexpr (BF16) {
 #pragma unroll
-        for (int g = 0; g < G::KS / 16; ++g) {
+        for (int g = 0; g < G::KS / 16; g += 2) {   // v_mfma_f32_16x16x32_bf16: two 16-deep steps per instruction
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * g);
           const s16x4 av = pack_bf16x4(a[0], a[1], a[2], a[3]);
+          s16x4 av2 = zero_bf16x4();
+          if (g + 1 < G::KS / 16) {
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(ap + 16 * (g + 1));
+            av2 = pack_bf16x4(a2[0], a2[1], a2[2], a2[3]);
+          }
 #pragma unroll
           for (int t = 0; t < G::NT; ++t) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(bp + 16 * t * G::ROW + 16 * g);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, pack_bf16x4(x[0], x[1], x[2], x[3]), acc[t], 0, 0, 0);
+            s16x4 bv2 = zero_bf16x4();
+            if (g + 1 < G::KS / 16) {
+              const f32x4 x2 = *reinterpret_cast<const f32x4*>(bp + 16 * t * G::ROW + 16 * (g + 1));
+              bv2 = pack_bf16x4(x2[0], x2[1], x2[2], x2[3]);
+            }
+            acc[t] = mfma_bf16_k32(av, av2, pack_bf16x4(x[0], x[1], x[2], x[3]), bv2, acc[t]);
           }
         }
       } else {

@@ -6,7 +6,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// bf16 operands of v_mfma_f32_16x16x16_bf16 (PGV_COMPUTE_BF16): four consecutive k values per lane, packed from
+// bf16 operands (PGV_COMPUTE_BF16) as the kernels build them: four consecutive k values per lane and 16-deep step, packed from
 // fp32 with round-to-nearest-even (v_cvt_pk_bf16_f32); products of bf16 values are exact in fp32, accumulation is fp32
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -15,6 +15,30 @@ __device__ __forceinline__ s16x4 pack_bf16x4(float a, float b, float c, float d)
   const unsigned u[2] = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
   return __builtin_bit_cast(s16x4, u);
 }
+// gfx950's K = 32 form: one v_mfma_f32_16x16x32_bf16 consumes the operands of TWO consecutive 16-deep steps - a lane's
+// eight values are its four of step s followed by its four of step s + 1 (the contraction only needs A and B to agree on
+// the position of every k, and both are built this way), in the 16 cycles the legacy 16x16x16 form spends on one step.
+// An odd step count pads the last pair with zeros.
+// The eight values live in ONE 4-register operand (u32x4) whose halves are written in place (set_half): built from two
+// separate s16x4 values the register allocator has to copy them next to each other (spills in the large-tile kernels).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int HALF>
+__device__ __forceinline__ void set_half(u32x4& dst, s16x4 v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 u = __builtin_bit_cast(u32x2, v);
+  dst[2 * HALF] = u[0];
+  dst[2 * HALF + 1] = u[1];
+}
+__device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16_k32(s16x4 a_lo, s16x4 a_hi, s16x4 b_lo, s16x4 b_hi, f32x4 acc) {
+  u32x4 a, b;
+  set_half<0>(a, a_lo), set_half<1>(a, a_hi), set_half<0>(b, b_lo), set_half<1>(b, b_hi);
+  return mfma_bf16_k32(a, b, acc);
+}
+__device__ __forceinline__ s16x4 zero_bf16x4() { return s16x4{0, 0, 0, 0}; }
 // fp32 value rounded to bf16 precision (kernels without a bf16 MFMA loop emulate the operand precision this way)
 __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
 

@@ -118,6 +118,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int HALF>
+__device__ __forceinline__ void set_half(u32x4& dst, s16x4 v) {   // (conv_tile.h has the same helper for the conv kernels)
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 u = __builtin_bit_cast(u32x2, v);
+  dst[2 * HALF] = u[0];
+  dst[2 * HALF + 1] = u[1];
+}
 __device__ __forceinline__ s16x4 pack4(f32x4 v) {
   const bf16x2_t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
   const unsigned u[2] = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
@@ -239,9 +248,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
       if (k0 + DEPTH * FK < kend) issue(u, k0 + DEPTH * FK);
       const float* ap = st + a_frag;
       const float* bp = st + A_FLOATS + b_frag;
-#pragma unroll
-      for (int g = 0; g < FK / 16; ++g) {
-        f32x4 a[NIM], b[NIN];
+      auto frags = [&](int g, f32x4 (&a)[NIM], f32x4 (&b)[NIN]) {
 #pragma unroll
         for (int h = 0; h < NIM; ++h) {
           if (A_K) {
@@ -260,16 +267,28 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
             for (int e = 0; e < 4; ++e) b[h][e] = bp[(16 * g + e) * NROW_B + 16 * h];
           }
         }
-        if constexpr (BF16) {
-          s16x4 ap4[NIM], bp4[NIN];
+      };
+      if constexpr (BF16) {
+        // v_mfma_f32_16x16x32_bf16: the slab's two 16-deep halves in one instruction per tile (a lane's eight values = its
+        // four of the first half, then its four of the second: both operands are built the same way)
+        static_assert(FK == 32, "one K = 32 MFMA per tile and slab");
+        f32x4 a0[NIM], b0[NIN], a1[NIM], b1[NIN];
+        frags(0, a0, b0);
+        frags(1, a1, b1);
+        u32x4 a8[NIM], b8[NIN];
 #pragma unroll
-          for (int h = 0; h < NIM; ++h) ap4[h] = pack4(a[h]);
+        for (int h = 0; h < NIM; ++h) set_half<0>(a8[h], pack4(a0[h])), set_half<1>(a8[h], pack4(a1[h]));
 #pragma unroll
-          for (int h = 0; h < NIN; ++h) bp4[h] = pack4(b[h]);
+        for (int h = 0; h < NIN; ++h) set_half<0>(b8[h], pack4(b0[h])), set_half<1>(b8[h], pack4(b1[h]));
 #pragma unroll
-          for (int t = 0; t < NIM * NIN; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap4[t / NIN], bp4[t % NIN], acc[t], 0, 0, 0);
-        } else {
+        for (int t = 0; t < NIM * NIN; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a8[t / NIN]),
+                                                           __builtin_bit_cast(bf16x8_t, b8[t % NIN]), acc[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int g = 0; g < FK / 16; ++g) {
+          f32x4 a[NIM], b[NIN];
+          frags(g, a, b);
           // round-robin over the accumulators: v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a
           // dependent one only after 40
 #pragma unroll
