@@ -1168,7 +1168,11 @@ def test_block_chain_bf16_vs_oracle(ops, kind):
             ref = gp[scope + k]
             if ref.abs().max() < 1e-7:      # (a zero gradient has no relative error)
                 continue
-            assert rel_l2(v.grad, ref) < 3 * max(rel_l2(gp64[scope + k], ref), 2e-5), k
+            # (factor 4 for the parameter gradients since round 4: the K = 32 MFMA adds the products of two 16-deep steps
+            # in another order, which moves float32 sums by an ulp and a few downstream operands across a bf16 boundary -
+            # enc2conv.bias, a sum over 40 k such elements, landed at 3.2 x the oracle's own fp32-vs-fp64 distance; every
+            # product is checked exactly in test_conv_bf16_operand_mode)
+            assert rel_l2(v.grad, ref) < 4 * max(rel_l2(gp64[scope + k], ref), 2e-5), k
 
 
 def test_layer_blocks_against_reference_goldens(ops):
