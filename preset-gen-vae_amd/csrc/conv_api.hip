@@ -142,6 +142,10 @@ int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src*
   if (g_policy == 0 && !g_no_v2 && d->B > 0 && big && w && small_out) {
     rc = pgv_conv_down_v2(d, big, in_bn->scale, in_bn->shift, w, bias, act, slope, small_out, stats, nullptr,
                           pgv_stream(stream), in_bn);
+    // (the deep k4 layers: the same fold in deep_down_kernel's prologue - seven bn_finalize launches per 8-layer step)
+    if (rc == 0)
+      rc = pgv_conv_down_deep(d, big, in_bn->scale, in_bn->shift, w, bias, act, slope, small_out, stats,
+                              pgv_stream(stream), in_bn);
     if (rc < 0) return rc;
     if (rc >= 1) return PGV_OK;
   }
@@ -162,6 +166,8 @@ int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_s
     rc = pgv_conv_up_direct2(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, st, in_bn);
     if (rc == 0)
       rc = pgv_conv_up_v2(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, nullptr, st, in_bn);
+    if (rc == 0)
+      rc = pgv_conv_up_deep(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, st, in_bn);
     if (rc < 0) return rc;
     if (rc >= 1) return PGV_OK;
   }

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
                                                         const float* __restrict__ in_shift,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int act, float slope, float* __restrict__ out,
-                                                        double* __restrict__ stats, int groups, int stat_stride) {
+                                                        double* __restrict__ stats, int groups, int stat_stride,
+                                                        pgv_bn_src in_bn) {
   using G = DeepDown<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CB]
@@ -111,8 +112,14 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
     lds[G::STAGE + G::A_FLOATS + i] = 0.f;
   }
   for (int i = tid; i < CB; i += NTHR) {   // identity when the input carries no folded BatchNorm: the commit is branch-free
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[CB + i] = in_scale ? in_shift[i] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    // (pgv_conv_down_bn: the producer's BatchNorm is finalized here, from its statistics, instead of by a launch of its own)
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CB, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CB + i] = sh;
   }
 
   // ---- loader coordinates (identical for every slab)
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(512) void deep_down_kernel(int B, int CB, int CS, c
 template <int H, int W, int NS, int CK>
 int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                     hipStream_t st) {
+                     hipStream_t st, const pgv_bn_src* bn = nullptr) {
   using G = DeepDown<H, W, NS, CK>;
   if (d->Cs % 64 || d->Cb % CK) return 0;
   // (the loader's inline-asm loads carry 32-bit byte offsets from the tensor bases)
@@ -378,7 +385,7 @@ int launch_deep_down(const pgv_conv_desc* d, const float* big, const float* in_s
   const int groups = (d->B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big,
                      in_scale, in_shift, w, bias, act, slope, out, stats, groups,
-                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0);
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0, bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_down_deep");
   return 1;
 }
@@ -419,7 +426,8 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       int act, float slope, float* __restrict__ out,
-                                                      double* __restrict__ stats, int groups, int stat_stride) {
+                                                      double* __restrict__ stats, int groups, int stat_stride,
+                                                      pgv_bn_src in_bn) {
   using G = DeepUp<H, W, NS, CK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * G::STAGE;  // [2*CS]
@@ -439,8 +447,14 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
     lds[G::STAGE + G::A_FLOATS + i] = 0.f;
   }
   for (int i = tid; i < CS; i += NTHR) {   // identity when the input carries no folded BatchNorm: branch-free commit
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[CS + i] = in_scale ? in_shift[i] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    // (pgv_conv_up_bn: the producer's BatchNorm is finalized here, from its statistics, instead of by a launch of its own)
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CS, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CS + i] = sh;
   }
 
   // ---- loaders: weights W[cs][cb0+row][16] (one float4 = the four kw of a kernel row kh), planes s[b][cs][P]
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(512) void deep_up_kernel(int B, int CB, int CS, con
 template <int H, int W, int NS, int CK>
 int launch_deep_up(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                    const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                   hipStream_t st) {
+                   hipStream_t st, const pgv_bn_src* bn = nullptr) {
   using G = DeepUp<H, W, NS, CK>;
   if (d->Cb % 64 || d->Cs % CK) return 0;
   const size_t bytes = sizeof(float) * (2 * G::STAGE + 2 * (size_t)d->Cs + 8);
@@ -704,7 +718,7 @@ int launch_deep_up(const pgv_conv_desc* d, const float* small_in, const float* i
   const int groups = (d->B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / 64))), dim3(G::NTHR), bytes, st, d->B, d->Cb, d->Cs, small_in,
                      in_scale, in_shift, w, bias, act, slope, out, stats, groups,
-                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0);
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_up_deep");
   return 1;
 }
@@ -1527,9 +1541,12 @@ bool shape_k1_3x4(const pgv_conv_desc* d) {
 
 }  // namespace
 
+// ``bn`` (optional): the input's BatchNorm, finalized in the kernel's prologue (pgv_conv_down_bn / pgv_conv_up_bn); the
+// 1x1 kernels fetch the affine per slab from global memory and do not take it: 0 is returned and the caller finalizes first.
 int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                       hipStream_t st) {
+                       hipStream_t st, const pgv_bn_src* bn) {
+  if (bn && shape_k1_3x4(d)) return 0;
   if (shape_k1_3x4(d) && d->Cs % 128 == 0)
     return launch_k1_down128<12, 16, 32>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
                                          stats, st, "conv_down_deep");
@@ -1537,24 +1554,25 @@ int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in
     return launch_k1_fwd<12, 16, 32, false>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,
                                            stats, st, "conv_down_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
-  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down<17, 23, 1, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down<17, 23, 1, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
   // (4 samples per workgroup: 140 pixels = 9 tiles, 3 % padding instead of 12.5 %, and half the weight traffic per sample;
   // 256 workgroups of 8 waves: 128 -> 104 us)
-  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down<5, 7, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down<9, 12, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down<5, 7, 4, 4>(d, big, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
   return 0;
 }
 
 int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                     hipStream_t st) {
+                     hipStream_t st, const pgv_bn_src* bn) {
+  if (bn && shape_k1_3x4(d)) return 0;
   if (shape_k1_3x4(d))
     return launch_k1_fwd<12, 4, 64, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,
                                           out, stats, st, "conv_up_deep");
   if (!shape_k4(d) || d->Cb < 64) return 0;
-  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
-  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up<5, 7, 4, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st);
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up<17, 23, 1, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up<9, 12, 2, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up<5, 7, 4, 8>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn);
   return 0;
 }
 

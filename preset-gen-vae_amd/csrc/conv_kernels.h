@@ -100,11 +100,11 @@ int pgv_conv_wgrad_gemm(const pgv_conv_desc* d, const float* big, const float* b
 // Raw-plane implicit-GEMM kernels for the deep k4 layers (conv_deep.hip): tried before the gather-GEMM.
 int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                       hipStream_t st);
+                       hipStream_t st, const pgv_bn_src* bn = nullptr);
 
 int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
-                     hipStream_t st);
+                     hipStream_t st, const pgv_bn_src* bn = nullptr);
 
 int pgv_conv_wgrad_deep(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
