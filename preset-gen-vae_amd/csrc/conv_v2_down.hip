@@ -47,8 +47,14 @@ struct DownV2Cfg {
 // ---------------------------------------------------------------------------------------------------------------
 // STG: lean loader (StageLean, row tails cleared by the loader) + deferred stores, as in conv_up_ws_kernel: for the
 // 129x174 layer, whose StageV2 loader co-limits it and whose output leaves in bursts.
+// Two workgroups per CU (V2_DOWN_WPS = 4 waves per SIMD): units of R = 5 rows whose LDS double buffer is half the size.
+// Experiment of round 4: two INDEPENDENT wave-specialised workgroups on a CU could fill each other's
+// prologue / epilogue / barrier bubbles on the matrix pipe.
+template <int R, int W>
+constexpr int V2_DOWN_WPS = (W == 88 && R == 5) ? 4 : 2;
+
 template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false>
-__global__ __launch_bounds__(512, 2) void conv_down_ws_kernel(int B, const float* __restrict__ big,
+__global__ __launch_bounds__(512, (V2_DOWN_WPS<R, W>)) void conv_down_ws_kernel(int B, const float* __restrict__ big,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
@@ -694,7 +700,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
     return PGV_E_LAUNCH;
   }
   const int units = d->B * G::BANDS;
-  const int grid = min(units, 256);
+  const int grid = min(units, 256 * (V2_DOWN_WPS<R, W> / 2));
   const pgv_bwd_fuse fz = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, in_scale, in_shift, w, bias, act,
                      slope, out, stats, fuse ? *fuse : fz, bn ? *bn : pgv_no_bn(), (d->flags & PGV_STATS_COPIES) ? 1 : 0);
@@ -703,6 +709,12 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
 }
 
 }  // namespace
+
+static int g_v2_down_variant = 0;
+extern "C" int pgv_dbg_set_v2_down_variant(int v) {
+  g_v2_down_variant = v;
+  return 0;
+}
 
 // Returns 1 when handled, 0 when the shape / mode is not covered (the caller falls back to conv_band.hip), < 0 on error.
 // Fused BatchNorm-backward projections (pgv_bwd_fuse) in the wave-specialised kernels: the saved-activation loads sit in
@@ -717,6 +729,8 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
   if (d->flags & PGV_COMPUTE_BF16) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
     return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
+  if (d->Hb == 65 && d->Wb == 88 && g_v2_down_variant == 1)   // (experiment: 7 bands of 5 rows, two workgroups per CU)
+    return launch_down_v2<16, 32, 88, 65, 5, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   if (d->Hb == 65 && d->Wb == 88)   // 16 -> 32 channels, 33x45 outputs: 3 bands of 11 rows, waves 2 (M) x 2 (pixels)
     return launch_down_v2<16, 32, 88, 65, 11, 2, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   if (d->Hb == 129 && d->Wb == 174)  // 8 -> 16 channels, 65x88 outputs: 13 bands of 5 rows, waves split the pixels

@@ -35,17 +35,25 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float* __res
   if (s == 12345.678f) sink[0] = s;   // (keeps the loop alive; never true in practice)
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void probe_read_kernel(const f32x4* __restrict__ buf, int64_t n4, float* __restrict__ sink) {
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    s0 += buf[i], s1 += buf[i + stride], s2 += buf[i + 2 * stride], s3 += buf[i + 3 * stride];
+  // U 16-byte loads in flight per lane, every workgroup walks its own contiguous slab (one DRAM page stream per workgroup)
+  f32x4 s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+  int64_t i = lo + threadIdx.x;
+  for (; i + (U - 1) * 256 < hi; i += U * 256) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] += __builtin_nontemporal_load(buf + i + u * 256);
   }
-  for (; i < n4; i += stride) s0 += buf[i];
-  const f32x4 s = (s0 + s1) + (s2 + s3);
-  const float t = (s[0] + s[1]) + (s[2] + s[3]);
-  if (t == 12345.678f) sink[0] = t;
+  for (; i < hi; i += 256) s[0] += buf[i];
+  f32x4 t = s[0];
+#pragma unroll
+  for (int u = 1; u < U; ++u) t += s[u];
+  const float r = (t[0] + t[1]) + (t[2] + t[3]);
+  if (r == 12345.678f) sink[0] = r;
 }
 
 }  // namespace
@@ -66,7 +74,7 @@ int pgv_probe_mfma(int bf16, int iters, float* sink, int64_t* flops, void* strea
 
 int pgv_probe_read(const float* buf, int64_t n, float* sink, void* stream) {
   PGV_CHECK_ARG(buf && sink && n >= 4 && (reinterpret_cast<uintptr_t>(buf) & 15) == 0, "pgv_probe_read: bad argument");
-  hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 8), dim3(256), 0, pgv_stream(stream),
+  hipLaunchKernelGGL(probe_read_kernel<8>, dim3(256 * 8), dim3(256), 0, pgv_stream(stream),
                      reinterpret_cast<const f32x4*>(buf), n / 4, sink);
   PGV_CHECK_LAUNCH("probe_read");
   return PGV_OK;
