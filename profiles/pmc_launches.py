@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REPS = 3
-LABELS_FILE = os.path.join(ROOT, 'gpurun_out', 'pmc_labels.json')
+LABELS_FILE = os.path.join(ROOT, 'gpurun_out', os.environ.get('PMC_LABELS', 'pmc_labels.json'))
 SENTINEL = 'erfinv'   # substring of the sentinel's kernel name (at::native::erfinv_kernel_cuda ...)
 
 
@@ -34,8 +34,12 @@ def build_table():
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.utils import audio
     B = 256
+    # PMC_ARCH / PMC_DZ / PMC_DTYPE select the configuration (round 4: the 8-layer and the bf16 z = 512 steps too)
+    from preset_gen_vae_amd import ops
+    ops.set_compute_dtype(os.environ.get('PMC_DTYPE', 'fp32'))
     mc, tc = copy.copy(config.model), copy.copy(config.train)
-    mc.encoder_architecture, mc.dim_z, mc.input_tensor_size = 'speccnn4l1_bn', 64, (B, 1, 257, 347)
+    mc.encoder_architecture = os.environ.get('PMC_ARCH', 'speccnn4l1_bn')
+    mc.dim_z, mc.input_tensor_size = int(os.environ.get('PMC_DZ', 64)), (B, 1, 257, 347)
     _, _, ae = mbuild.build_ae_model(mc, tc)
     dev = torch.device('cuda', 0)
     ae = ae.to(dev).train()
@@ -113,7 +117,7 @@ def traffic(fetch_dir, write_dir):
 def mfma(d):
     out = {'_about': 'matrix-pipe utilisation per launch: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / '
                      '(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); GRBM_GUI_ACTIVE is reported summed over the 8 XCDs '
-                     '(1.6 M for a 75 us kernel). profiles/pmc_launches.py, fp32 MFMA path, batch 256'}
+                     '(1.6 M for a 75 us kernel). profiles/pmc_launches.py, batch 256, configuration ' + os.environ.get('PMC_ARCH', 'speccnn4l1_bn') + ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32')}
     for lab, c, names in segments(d):
         if lab['algorithmic_flops'] <= 0:
             continue
