@@ -18,6 +18,8 @@ def main():
     arch = 'speccnn8l1_bn' if '--8l' in sys.argv else 'speccnn4l1_bn'
     B = 256
     lib = _lib.load()
+    from preset_gen_vae_amd import ops
+    ops.set_compute_dtype(os.environ.get('DTYPE', 'fp32'))
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture, mc.dim_z, mc.input_tensor_size = arch, 64, (B, 1, 257, 347)
     tc.latent_flow_input_regularization = 'none'

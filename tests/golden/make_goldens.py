@@ -687,6 +687,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'b16':
         run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)
         run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
+        run_vae_case('speccnn8l1_bn', 64, 16, True, 'vae8l_b16_outbn', HERE)
+        run_vae_case('speccnn4l1_bn', 64, 16, True, 'vae4l_b16_outbn', HERE)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'stacked':
         run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
@@ -700,6 +702,9 @@ if __name__ == '__main__':
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
     run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)       # B = 16 capture
     run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
+    # the reference's DEFAULT regularisation ('bn': BatchNorm1d on the encoder output, config.py:92) at the capture size
+    run_vae_case('speccnn8l1_bn', 64, 16, True, 'vae8l_b16_outbn', HERE)
+    run_vae_case('speccnn4l1_bn', 64, 16, True, 'vae4l_b16_outbn', HERE)
     run_regstep_case(HERE)
     run_regstep_cat_case(HERE)
     run_dataset_seam_case(HERE)

@@ -111,11 +111,13 @@ def _region_pairs(masks, sd64, x, arch, dim_z, eps, enc_mask, dec_mask):
 
 
 @pytest.mark.parametrize("name", ["vae4l_b2.npz", "vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b16.npz",
-                                  "vae8l_b16.npz"])
+                                  "vae8l_b16.npz", "vae4l_b16_outbn.npz", "vae8l_b16_outbn.npz"])
 def test_train_step_parity(name):
     """B = 2 goldens: tolerance = max(SURVEY 8c, 4x the reference arithmetic's own float32 noise) - the deepest
     BatchNorms see 24 values per channel there.  B = 16 goldens (SURVEY 8c's capture size): the SURVEY 8c tolerances
-    as they stand (activations 1e-5, losses 1e-5, gradients 5e-3), no noise escape."""
+    as they stand (activations 1e-5, losses 1e-5, gradients 5e-3), no noise escape - since round 4 also with the
+    reference's DEFAULT latent regularisation ('bn', config.py:92: BatchNorm1d on the encoder output, the configuration
+    bench.py times), i.e. the one-launch encoder head (pgv_bn1d_reparam_*) inside the strict comparison."""
     from oracle import vae_oracle as vo
     from preset_gen_vae_amd.train_step import VAETrainStep
     g = load_golden(name)
@@ -200,6 +202,8 @@ def test_train_step_parity(name):
         assert (got.double().cpu() - gr).abs().max().item() <= max(5e-3 * gmax, 0.0 if strict else 4 * noise_abs) + 1e-9, \
             (k, gmax, noise_abs)
     print(f"{name}: worst gradient error / tolerance = {worst:.3f}")
+    if strict:   # (measured 0.002 - 0.022 on the four B = 16 goldens: hold the strict cases to a tenth of SURVEY 8c's 5e-3)
+        assert worst < 0.1, worst
     # post-Adam parameters and BN buffers
     sd_new = ae.state_dict()
     for k, v in ora['new_sd'].items():

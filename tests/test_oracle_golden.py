@@ -32,7 +32,7 @@ def reference_template(g):
 
 
 @pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz", "vae8l_b2_c2.npz",
-                                  "vae8l_b16.npz", "vae4l_b16.npz"])
+                                  "vae8l_b16.npz", "vae4l_b16.npz", "vae8l_b16_outbn.npz", "vae4l_b16_outbn.npz"])
 def test_train_step_matches_reference(name):
     g = load_golden(name)
     arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
