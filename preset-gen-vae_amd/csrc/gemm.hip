@@ -140,16 +140,23 @@ constexpr int KROW = FK + 4;           // row stride of a k-contiguous tile [T][
 // TM x TN tile per workgroup (64 or 128 each): four waves in 2 x 2, a wave owns a (TM/2) x (TN/2) quarter = NIM x NIN MFMA
 // tiles.  128-wide tiles halve the reads of the operand they span (the z = 512 products moved 805 MB from L2 to LDS at
 // 64 x 64 for 125 MB of operands); DEPTH slabs in flight in registers (4 at 64 x 64, 2 beyond: 8 floats4 per slab).
+// TM = 256 ("batch-resident": all rows of a minibatch of 256 in one workgroup, the weight operand streamed once per
+// K split): 512 threads, waves 4 x 2, the same 16 MFMA tiles per wave as 128 x 128 at 256 threads.
+template <int TM>
+constexpr int GemmThreads = TM >= 256 ? 512 : 256;
+
 template <bool A_K, bool B_K, bool BF16, int TM, int TN, int DEPTH>
-__global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel(
+__global__ __launch_bounds__((GemmThreads<TM>), (TM >= 256 ? 2 : ((TM + TN > 128) ? 2 : 3))) void gemm_fast_kernel(
     int M, int N, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
     float* __restrict__ C, int64_t ldc, const float* __restrict__ bias_n, int k_per_split, int nsplit, int atomic) {
   constexpr int MROW_A = TM + 16, NROW_B = TN + 4;
   constexpr int A_FLOATS = A_K ? TM * KROW : FK * MROW_A;
   constexpr int B_FLOATS = B_K ? TN * KROW : FK * NROW_B;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int LA = TM / 32, LB = TN / 32;   // float4 per thread per slab and operand
-  constexpr int WM = TM / 2, WN = TN / 2, NIM = WM / 16, NIN = WN / 16;
+  constexpr int NTHR = GemmThreads<TM>, WROWS = NTHR / 128;   // waves as WROWS x 2
+  constexpr int LA = TM * 8 / NTHR, LB = TN * 8 / NTHR;   // float4 per thread per slab and operand
+  static_assert(LA >= 1 && LB >= 1, "loader");
+  constexpr int WM = TM / WROWS, WN = TN / 2, NIM = WM / 16, NIN = WN / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, j = lane >> 4;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
   int a_dst[LA], b_dst[LB];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    const int q = tid + 256 * i;
+    const int q = tid + NTHR * i;
     if (A_K) {  // A[m0 + r][k + 4f]: 8 float4 per row
       const int r = q >> 3, f = q & 7;
       a_src[i] = (int64_t)(m0 + r) * lda + 4 * f;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
-    const int q = tid + 256 * i;
+    const int q = tid + NTHR * i;
     if (B_K) {  // B(k,n) = B[n*ldb + k]
       const int r = q >> 3, f = q & 7;
       b_src[i] = (int64_t)(n0 + r) * ldb + 4 * f;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
   // with 4 half-lines per instruction, as the accumulator layout gives them, ~8 us; laid out 16 quarter-lines wide 35 us),
   // 16 bytes per lane for plain stores.
   constexpr int TROW = TN + 4;
-  static_assert(TM * TROW <= 2 * STAGE, "epilogue tile fits in the staging buffers");
+  // (the launcher sizes the dynamic LDS as max(2 stages, this tile): 256-row tiles need more than their stages)
   float* tile = lds;
 #pragma unroll
   for (int t = 0; t < NIM * NIN; ++t)
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
   // atomic == 2: C held zeros on entry (PGV_PREZEROED) - no clearing launch, the first K split brings the bias
   const bool with_bias = (!atomic || (atomic == 2 && zs == 0)) && bias_n;
   if (atomic) {
-    constexpr int RPP = 256 / TN;   // rows per pass
+    constexpr int RPP = NTHR / TN;   // rows per pass
     const int col = tid % TN;
     const float bias = with_bias ? bias_n[n0 + col] : 0.f;
 #pragma unroll 4
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256, (TM + TN > 128) ? 2 : 3) void gemm_fast_kernel
       atomicAdd(C + (int64_t)(m0 + row) * ldc + n0 + col, tile[row * TROW + col] + bias);
     }
   } else {
-    constexpr int QPR = TN / 4, RPP = 256 / QPR;   // 16-byte groups per row, rows per pass
+    constexpr int QPR = TN / 4, RPP = NTHR / QPR;   // 16-byte groups per row, rows per pass
     const int c4 = (tid % QPR) * 4;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (with_bias) {
@@ -351,7 +358,9 @@ int launch_tile(int nsplit, hipStream_t st, int M, int N, int K, const float* A,
                 float* C, int64_t ldc, const float* bias_n, int k_per_split, int atomic) {
   constexpr int DEPTH = (TM + TN > 128) ? 2 : 4;
   constexpr int A_FLOATS = A_K ? TM * KROW : FK * (TM + 16), B_FLOATS = B_K ? TN * KROW : FK * (TN + 4);
-  constexpr size_t bytes = sizeof(float) * 2 * (A_FLOATS + B_FLOATS);
+  constexpr size_t stage_bytes = sizeof(float) * 2 * (A_FLOATS + B_FLOATS), tile_bytes = sizeof(float) * TM * (TN + 4);
+  constexpr size_t bytes = stage_bytes > tile_bytes ? stage_bytes : tile_bytes;
+  static_assert(bytes <= 160 * 1024, "LDS budget");
   auto kern = gemm_fast_kernel<A_K, B_K, BF16, TM, TN, DEPTH>;
   if (bytes > 48 * 1024) {   // (above the default dynamic-LDS limit: raised once per kernel)
     static bool raised = false;
@@ -364,7 +373,7 @@ int launch_tile(int nsplit, hipStream_t st, int M, int N, int K, const float* A,
     }
   }
   const dim3 grid((unsigned)((M / TM) * (N / TN) * nsplit));
-  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, nsplit, atomic);
+  hipLaunchKernelGGL(kern, grid, dim3(GemmThreads<TM>), bytes, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, nsplit, atomic);
   return PGV_OK;
 }
 
@@ -374,6 +383,8 @@ int launch_fast(int tm, int tn, int nsplit, hipStream_t st, int bf16, int M, int
 #define PGV_GT(BF, TMv, TNv) \
   return launch_tile<A_K, B_K, BF, TMv, TNv>(nsplit, st, M, N, K, A, lda, B, ldb, C, ldc, bias_n, k_per_split, atomic)
   if (bf16) {
+    if (tm == 256 && tn == 128) PGV_GT(true, 256, 128);
+    if (tm == 256) PGV_GT(true, 256, 64);
     if (tm == 128 && tn == 128) PGV_GT(true, 128, 128);
     if (tm == 128) PGV_GT(true, 128, 64);
     if (tn == 128) PGV_GT(true, 64, 128);
@@ -400,6 +411,12 @@ int init_c_launch(float* C, int M, int N, int64_t ldc, const float* bias_n, hipS
 int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                   float* C, int64_t ldc, const float* bias_n, int flags, hipStream_t st,
                   int (*init_c)(float*, int, int, int64_t, const float*, hipStream_t));
+
+static int g_gemm_tiles = 0;
+extern "C" int pgv_dbg_set_gemm_tiles(int v) {
+  g_gemm_tiles = v;
+  return 0;
+}
 
 extern "C" {
 
@@ -432,9 +449,14 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
       // z = 64: 125 -> 121); on the fp32 matrix pipe they are MFMA-bound and the larger workgroups only lose to wave
       // quantisation (z = 512: 625 -> 670 us, z = 64: no change)
       const bool big_ok = (flags & PGV_COMPUTE_BF16) != 0;
-      const int tm = (big_ok && M % 128 == 0 && M >= 256) ? 128 : 64, tn = (big_ok && N % 128 == 0 && N >= 256) ? 128 : 64;
+      // 256-row tiles (one 512-thread workgroup per CU holds every row of a 256-row minibatch, so that the weight operand
+      // passes L2 -> LDS once per K split): measured SLOWER than two 128 x 128 workgroups per CU - six z = 512 products
+      // 385-393 us against 320-335 (same box, alternating) - one workgroup per CU leaves nobody to cover its barriers.
+      // Kept behind pgv_dbg_set_gemm_tiles(1) for A/B timing and covered by test_linear_gemm_bf16_operand_mode.
+      int tm = (big_ok && M % 128 == 0 && M >= 256) ? 128 : 64, tn = (big_ok && N % 128 == 0 && N >= 256) ? 128 : 64;
+      if (big_ok && M % 256 == 0 && (g_gemm_tiles & 1)) tm = 256;
       const int tiles = (M / tm) * (N / tn);
-      const int target = (tm + tn > 128) ? 512 : 768;   // workgroups that fit at once (2 / 3 per CU)
+      const int target = tm == 256 ? 256 : ((tm + tn > 128) ? 512 : 768);   // workgroups that fit at once (1 / 2 / 3 per CU)
       int splits = (int)max((int64_t)1, min(pgv_cdiv(target, tiles), (int64_t)K / (FK * 4)));
       int k_per_split_v = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
       splits = (int)pgv_cdiv(K, k_per_split_v);

@@ -5,6 +5,8 @@ import bench
 from preset_gen_vae_amd import ops, _lib
 B = 256
 import os
+if os.environ.get('FC_TILES'):
+    _lib.load().pgv_dbg_set_gemm_tiles(int(os.environ['FC_TILES']))
 if os.environ.get('FC_BF16'):
     ops.set_compute_dtype('bf16')
 for dz in (64, 512):
@@ -12,7 +14,7 @@ for dz in (64, 512):
     gye = torch.randn(B, 2 * dz, device='cuda'); gWe = torch.empty_like(We)
     z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(25024, dz, device='cuda') * 0.01; bd = torch.zeros(25024, device='cuda')
     gyd = torch.randn(B, 25024, device='cuda'); gWd = torch.empty_like(Wd)
-    for pol in (0, 1):
+    for pol in (0, 0, 1):
         _lib.load().pgv_set_kernel_policy(pol)
         ts = [bench.time_kernel(f, iters=5) * 1e3 for f in (
             lambda: ops.linear_fwd(x, We, be), lambda: ops.linear_dgrad(gye, We), lambda: ops.linear_wgrad(gye, x, gWe),

@@ -947,24 +947,30 @@ def test_linear_gemm(ops, mnk):
     assert rel_l2(gb, br.grad) < 1e-5
 
 
-def test_linear_gemm_bf16_operand_mode(ops):
-    """pgv_gemm flags = PGV_COMPUTE_BF16: the three nn.Linear products with bf16-rounded operands."""
-    M, N, K = 64, 128, 24576
+@pytest.mark.parametrize("mnk", [(64, 128, 24576), (256, 1024, 3200), (256, 192, 4096), (512, 256, 1056)])
+def test_linear_gemm_bf16_operand_mode(ops, mnk):
+    """pgv_gemm flags = PGV_COMPUTE_BF16: the three nn.Linear products with bf16-rounded operands (M = 256 / 512: the
+    256-row tiles of round 4, 128- and 64-wide)."""
+    M, N, K = mnk
     x = synth_vec((M, K), 0.771, 0.3)
     w = synth_vec((N, K), 0.613, 0.8) / np.sqrt(K)
     b = synth_vec((N,), 1.1, 0.2)
     gy = synth_vec((M, N), 0.913, 0.5)
     dx, dw, db, dgy = dev(x), dev(w), dev(b), dev(gy)
+    from preset_gen_vae_amd import _lib
     ops.set_compute_dtype('bf16')
     try:
-        y = ops.linear_fwd(dx, dw, db)
-        assert rel_l2(y, _bf16(x) @ _bf16(w).t() + b.float().double()) < 1e-5
-        assert rel_l2(y, F.linear(x, w, b)) > 2e-4
-        assert rel_l2(ops.linear_dgrad(dgy, dw), _bf16(gy) @ _bf16(w)) < 1e-5
-        gw = torch.empty_like(dw)
-        ops.linear_wgrad(dgy, dx, gw)
-        assert rel_l2(gw, _bf16(gy).t() @ _bf16(x)) < 1e-5
+        for tiles in ((0, 1) if M % 256 == 0 else (0,)):   # (1: the 256-row tiles, off by default - slower, gemm.hip)
+            _lib.load().pgv_dbg_set_gemm_tiles(tiles)
+            y = ops.linear_fwd(dx, dw, db)
+            assert rel_l2(y, _bf16(x) @ _bf16(w).t() + b.float().double()) < 1e-5
+            assert rel_l2(y, F.linear(x, w, b)) > 2e-4
+            assert rel_l2(ops.linear_dgrad(dgy, dw), _bf16(gy) @ _bf16(w)) < 1e-5
+            gw = torch.empty_like(dw)
+            ops.linear_wgrad(dgy, dx, gw)
+            assert rel_l2(gw, _bf16(gy).t() @ _bf16(x)) < 1e-5
     finally:
+        _lib.load().pgv_dbg_set_gemm_tiles(0)
         ops.set_compute_dtype('fp32')
 
 
