@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
                                                                const float* __restrict__ small_in,
                                                                const float* __restrict__ small_scale,
                                                                const float* __restrict__ small_shift,
-                                                               float* __restrict__ gw) {
+                                                               float* __restrict__ gw, float* __restrict__ partial) {
   using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, BF16>;
   constexpr int KK = G::KK, NTAP = G::NTAP, NB = G::NB, WK = G::WK, R = G::R, CS = G::CS, Ws = G::Ws, Hs = G::Hs;
   constexpr int WP = G::WP, WsP = G::WsP, PLANE_B = G::PLANE_B, PLANE_S = G::PLANE_S, SPR = G::SPR, BANDS = G::BANDS;
@@ -707,6 +707,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
   // ---- flush: D col = lane&15 = tap within the tap tile, row = (lane>>4)*4 + reg = cs within the M tile.  Waves that
   // split the rows of the band (WK > 1) hold partial sums of the same elements: they are added up through LDS first,
   // so the workgroup issues one coalesced float atomic per weight element.
+  // ``partial`` (pgv_conv_wgrad_band_partial): the workgroup's sums go to slot blockIdx.x / NSPLIT of a workspace in the
+  // layout of gw, with plain stores, and the reduce launch of the wave-specialised path (conv_v2_wgrad.hip) adds the
+  // slots up.  Measured on the bf16 operand mode (phase stamps, scratch/phase_wgrad_bf16.py): the item loops of the
+  // 65x88 / 33x45 kernels took 29 / 27 us of 60 / 72 us launches - the rest was this flush as float atomics, 512
+  // workgroups x up to 128 KB = 67 MB of atomic traffic at the ~1.3 TB/s the memory side retires them.
+  float* const dst = partial ? partial + (size_t)(blockIdx.x / NSPLIT) * ((size_t)Cs * Cb * KK) : gw;
   constexpr int NTT = CB * NTAP;  // N tiles in total
   if constexpr (WK > 1) {
     __syncthreads();
@@ -727,7 +733,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < WK; ++k) v += red[k * CS * NTT * 16 + e];
-      if (cs < Cs && cb < ncb && tau < KK) atomicAdd(&gw[((int64_t)cs * Cb + cb0 + cb) * KK + tau], v);
+      if (cs < Cs && cb < ncb && tau < KK) {
+        float* o = &dst[((int64_t)cs * Cb + cb0 + cb) * KK + tau];
+        if (partial) *o = v;
+        else atomicAdd(o, v);
+      }
     }
   } else {
 #pragma unroll
@@ -740,7 +750,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int cs = m * 16 + (lane >> 4) * 4 + reg;
-            if (cs < Cs) atomicAdd(&gw[((int64_t)cs * Cb + cb0 + cb) * KK + tau], acc[m][n][reg]);
+            if (cs < Cs) {
+              float* o = &dst[((int64_t)cs * Cb + cb0 + cb) * KK + tau];
+              if (partial) *o = acc[m][n][reg];
+              else atomicAdd(o, acc[m][n][reg]);
+            }
           }
       }
     }
@@ -750,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
 template <int KS, int MT, int CSL, int CB, int NSPLIT, int WN, int RW, int W, int H, bool BF16>
 int launch_wgrad_band_t(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
-                        hipStream_t st) {
+                        hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0, int* nparts = nullptr) {
   using G = WgradCfg<KS, MT, CSL, CB, NSPLIT, WN, RW, W, H, BF16>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds, "LDS budget");
@@ -759,19 +773,24 @@ int launch_wgrad_band_t(const pgv_conv_desc* d, const float* big, const float* b
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_band");
   if (rc) return rc;
-  if (!(d->flags & PGV_PREZEROED) && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * G::KK, st) != hipSuccess) {
-    pgv_set_error("conv_wgrad_band: memset failed");
-    return PGV_E_LAUNCH;
-  }
   const int units = d->B * G::BANDS;
-  if (units == 0) return 1;
   int per_cu = (int)min((size_t)2, (size_t)kMaxLds / bytes);
 #ifdef PGV_PHASE_TIMING
   if (getenv("PGV_WGRAD_PER_CU")) per_cu = atoi(getenv("PGV_WGRAD_PER_CU"));
 #endif
   const int grid = min(units, 256 * per_cu / NSPLIT) * NSPLIT;
+  if (partial) {   // one slot of the workspace per group of NSPLIT workgroups (they write disjoint channel ranges of it)
+    if (units == 0 || d->Cb != CB * NSPLIT || (int64_t)(grid / NSPLIT) * d->Cs * d->Cb * G::KK * (int64_t)sizeof(float) > partial_bytes)
+      return 0;
+    *nparts = grid / NSPLIT;
+  } else if (!(d->flags & PGV_PREZEROED) &&
+             hipMemsetAsync(gw, 0, sizeof(float) * (size_t)d->Cs * d->Cb * G::KK, st) != hipSuccess) {
+    pgv_set_error("conv_wgrad_band: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  if (units == 0) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, d->B, d->Cb, d->Cs, big, big_scale, big_shift, small_in,
-                     small_scale, small_shift, gw);
+                     small_scale, small_shift, gw, partial);
   PGV_CHECK_LAUNCH("conv_wgrad_band");
   return 1;
 }
@@ -1217,6 +1236,23 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
   if (d->Hb == 65 && d->Wb == 88) PGV_WGB(4, 2, 32, 16, 1, 2, 1, 88, 65);
   if (d->Hb == 33 && d->Wb == 45) PGV_WGB(4, 4, 64, 16, 2, 4, 3, 45, 33);
 #undef PGV_WGB
+  return 0;
+}
+
+// The same kernels with their result left as per-workgroup partial gradients in ``partial`` (*nparts slots in the layout
+// of gw) for the reduce launch of conv_v2_wgrad.hip.  bf16 operand mode, the three k4 layers at the reference sizes and
+// channel counts; 0 = not covered (nothing launched).
+int pgv_conv_wgrad_band_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                                const float* small_in, const float* small_scale, const float* small_shift, float* partial,
+                                int64_t partial_bytes, int* nparts, hipStream_t st) {
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || !(d->flags & PGV_COMPUTE_BF16) || !partial) return 0;
+#define PGV_WGP(...)                                                                                                  \
+  return launch_wgrad_band_t<__VA_ARGS__, true>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, nullptr, \
+                                                st, partial, partial_bytes, nparts)
+  if (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16) PGV_WGP(4, 1, 16, 8, 1, 1, 1, 174, 129);
+  if (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) PGV_WGP(4, 2, 32, 16, 1, 2, 1, 88, 65);
+  if (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) PGV_WGP(4, 4, 64, 16, 2, 4, 3, 45, 33);
+#undef PGV_WGP
   return 0;
 }
 

@@ -36,6 +36,9 @@ int pgv_conv_up_band(const pgv_conv_desc* d, const float* small_in, const float*
 int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                         const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                         hipStream_t st);
+int pgv_conv_wgrad_band_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                                const float* small_in, const float* small_scale, const float* small_shift, float* partial,
+                                int64_t partial_bytes, int* nparts, hipStream_t st);
 
 // Second-generation kernels (conv_v2.hip): one workgroup per CU, waves split M, weights from registers; tried first.
 // (bn != null: in_scale / in_shift are bn->scale / bn->shift, not yet computed - the kernel finalizes the BatchNorm in its

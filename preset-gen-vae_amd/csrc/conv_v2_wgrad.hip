@@ -726,11 +726,12 @@ int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d) {
   if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->Cb == 1 &&
       d->Cs == 8 && d->Hb == 257 && d->Wb == 347)
     return (int64_t)4 * 256 * 8 * 25 * sizeof(float);  // one partial gradient per MFMA wave
-  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4 || (d->flags & PGV_COMPUTE_BF16)) return 0;
+  if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  // (bf16 operand mode: the band kernels leave up to 512 partial gradients - two workgroups per CU - for the same reduce)
   if ((d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) ||
       (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
       (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16))
-    return (int64_t)256 * d->Cs * d->Cb * 16 * sizeof(float);
+    return (int64_t)((d->flags & PGV_COMPUTE_BF16) ? 512 : 256) * d->Cs * d->Cb * 16 * sizeof(float);
   return 0;
 }
 
@@ -750,7 +751,25 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
       d->Cb == 1 && d->Cs == 8 && d->Hb == 257 && d->Wb == 347 && !big_scale)
     return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, bias, st);
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
-  if ((d->flags & PGV_COMPUTE_BF16) || d->B <= 0) return 0;
+  if (d->B <= 0) return 0;
+  if (d->flags & PGV_COMPUTE_BF16) {
+    // bf16 operand mode: the band kernels (v_mfma_f32_16x16x32_bf16) leave per-workgroup partial gradients in the workspace
+    // and the reduce launch of this file adds them up - with the tap sums / bias roles the fp32 step folds into it
+    if (!workspace || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
+    int nparts = 0;
+    int rc = pgv_conv_wgrad_band_partial(d, big, big_scale, big_shift, small_in, small_scale, small_shift, (float*)workspace,
+                                         workspace_bytes, &nparts, st);
+    if (rc <= 0) return rc;
+    const int n4 = d->Cs * d->Cb * 16 / 4;
+    if (req) {
+      rc = launch_wgrad_reduce_taps(d, req, bias, big, small_in, (const float*)workspace, nparts, n4, gw, st);
+      if (rc) return rc < 0 ? rc : 3;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8 + bias_blocks(bias)), dim3(256), 0, st, (const float*)workspace,
+                       nparts, n4, gw, (d->flags & PGV_PREZEROED) ? 1 : 0, bias_fin(bias), (n4 + 7) / 8);
+    PGV_CHECK_LAUNCH("conv_wgrad_band reduce");
+    return 1;
+  }
   if (d->Hb == 33 && d->Wb == 45)
     return launch_wgrad_v2<32, 64, 45, 33, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,
                                               workspace, workspace_bytes, req, bias, st);
