@@ -53,7 +53,10 @@ struct DownV2Cfg {
 template <int R, int W>
 constexpr int V2_DOWN_WPS = (W == 88 && R == 5) ? 4 : 2;
 
-template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false>
+// BF16 (STG forms only): PGV_COMPUTE_BF16 - both operands rounded to bfloat16, the input where the lean loader commits
+// it to LDS, the weights where they are loaded; fp32 MFMA (products of bf16 values are exact in fp32).
+template <int CB, int CS, int W, int H, int R, int MW, int CK, bool FUSE, bool HAS_AFF, int ACT, bool STG = false,
+          bool BF16 = false>
 __global__ __launch_bounds__(512, (V2_DOWN_WPS<R, W>)) void conv_down_ws_kernel(int B, const float* __restrict__ big,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, (V2_DOWN_WPS<R, W>)) void conv_down_ws_kernel(
       item_geo(it, rs, bad);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // the older set has landed
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF>(geo, sx, dst, ltid, bad); });
+      static_for<0, NL>([&](auto j) { Lean::template commit_slot<decltype(j)::value, true, HAS_AFF, BF16>(geo, sx, dst, ltid, bad); });
     };
     issue_all(sB, 1);  // (item 0 went out during the set-up)
     commit_all(sA, 0, tile0);
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(512, (V2_DOWN_WPS<R, W>)) void conv_down_ws_kernel(
   unsigned wl[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) wl[m] = (unsigned)((((wm * MTW + m) * 16 + (lane & 15)) * CB * 16 + (lane >> 4)) * 4);
-  auto wload = [&](int m, int elem) { return *reinterpret_cast<const float*>(wb + (size_t)elem * 4 + wl[m]); };
+  auto wload = [&](int m, int elem) { return pgv_opnd(*reinterpret_cast<const float*>(wb + (size_t)elem * 4 + wl[m]), BF16); };
+  static_assert(!BF16 || STG, "operand rounding: lean-loader forms only");
   const pgv_act_params actp = pgv_act_setup(act, slope);
   // D^T = X^T W^T: the accumulator of a lane is 4 consecutive pixels (rows (lane>>4)*4 + reg) of one channel (lane & 15)
   const int ech = lane & 15, epx = 4 * (lane >> 4);
@@ -680,10 +684,14 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
 #undef PGV_DK
   // lean loader + deferred stores for the layer where they pay (129x174, one channel chunk); plain / LeakyReLU forms
   bool with_cls = false;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  bool bf16_ok = false;
   if constexpr (W == 174 && G::NCH == 1) {
     if (fuse && !in_scale && actk == 0) {   // fused backward epilogue with the saved activation prefetched (APRE)
-      kern = (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true>;
+      kern = bf16 ? (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true, true>
+                  : (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, true, false, 0, true>;
       with_cls = fuse->cls != nullptr;
+      bf16_ok = true;   // (bf16 operand mode: this form only - 80 us band kernel + 39 us class-sum pass otherwise)
     }
     if (!fuse && actk != 2) {
       if (in_scale)
@@ -694,6 +702,7 @@ int launch_down_v2(const pgv_conv_desc* d, const float* big, const float* in_sca
                          : (kern_t)conv_down_ws_kernel<CB, CS, W, H, R, MW, CK, false, false, 0, true>;
     }
   }
+  if (bf16 && !bf16_ok) return 0;
   if (int rc = raise_lds_once((const void*)kern, "conv_down_v2")) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
     pgv_set_error("conv_down_v2: memset failed");
@@ -726,7 +735,8 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                      const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
-  if (d->flags & PGV_COMPUTE_BF16) return 0;
+  // (bf16 operand mode: only the fused 129x174 input gradient has an operand-rounding instantiation, see launch_down_v2)
+  if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 129 && d->Wb == 174 && fuse)) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways
     return launch_down_v2<32, 64, 45, 33, 17, 4, 8>(d, big, in_scale, in_shift, w, bias, act, slope, small_out, stats, fuse, bn, st);
   if (d->Hb == 65 && d->Wb == 88 && g_v2_down_variant == 1)   // (experiment: 7 bands of 5 rows, two workgroups per CU)

@@ -526,7 +526,7 @@ def _small_zeros(param, shape, tag):
     for v in shape:
         n *= int(v)
     flat = getattr(param, '_pgv_flat', None)
-    if flat is None or n > 1 << 15 or getattr(param, '_pgv_shared', False):
+    if flat is None or n > 1 << 18 or getattr(param, '_pgv_shared', False):
         return None
     t = flat.step_scratch((id(param), tag), n, torch.float32)
     # (.data: same memory, but not a view of the scratch buffer as far as autograd is concerned - in-place torch ops on

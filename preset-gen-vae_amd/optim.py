@@ -15,7 +15,7 @@ from . import _lib, ops
 
 _ALIGN = 64  # floats (256 B): 16-byte streaming accesses, and gradient slices start on a cache-line boundary - the
 # weight-gradient kernels flush with float atomics, which run ~1.5x slower when their 64-byte segments straddle lines
-_SCRATCH = 1 << 17   # floats of step scratch behind the flat gradient (512 KB)
+_SCRATCH = 1 << 20   # floats of step scratch behind the flat gradient (4 MB: the z = 512 split-K outputs [256, 1024] fit too)
 
 
 class FlatParams:
