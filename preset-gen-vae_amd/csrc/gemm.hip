@@ -457,7 +457,10 @@ int pgv_gemm(int M, int N, int K, const float* A, int64_t sam, int64_t sak, cons
       if (big_ok && M % 256 == 0 && (g_gemm_tiles & 1)) tm = 256;
       const int tiles = (M / tm) * (N / tn);
       const int target = tm == 256 ? 256 : ((tm + tn > 128) ? 512 : 768);   // workgroups that fit at once (1 / 2 / 3 per CU)
-      int splits = (int)max((int64_t)1, min(pgv_cdiv(target, tiles), (int64_t)K / (FK * 4)));
+      // K splits only while the tiles alone leave at least half of the workgroup slots empty: 390 tiles of the z = 512
+      // input gradient [256 x 25 024] were split in two (ceil(512 / 390)), i.e. a 25.6 MB output initialised by a launch of
+      // its own and then written twice with float atomics
+      int splits = (int)max((int64_t)1, min((int64_t)target / tiles, (int64_t)K / (FK * 4)));
       int k_per_split_v = (int)(pgv_cdiv(pgv_cdiv(K, splits), FK) * FK);
       splits = (int)pgv_cdiv(K, k_per_split_v);
       if (splits > 8 && (splits & 7)) {   // a multiple of 8 splits: one XCD per K slice (see the kernel)
