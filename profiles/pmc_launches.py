@@ -128,8 +128,34 @@ def mfma(d):
     print(json.dumps(out, indent=1))
 
 
+def counters(dirs):
+    """Raw SQ counters per launch label from one or more passes (round 4: SQ_INSTS_VALU / SQ_WAIT_INST_LDS / SQ_BUSY_CYCLES
+    ... behind DESIGN.md 3.9), plus two ratios: wave cycles parked (s_waitcnt / barrier) and VALU instructions per MFMA."""
+    out = {'_about': 'SQ counters per launch (sum over the launch\'s kernels, per repetition), rocprofv3 --kernel-trace --pmc '
+                     'passes of profiles/pmc_launches.py; configuration ' + os.environ.get('PMC_ARCH', 'speccnn4l1_bn') +
+                     ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32') +
+                     '.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles '
+                     '(MI355X_MICROARCH.md).'}
+    merged = {}
+    for d in dirs:
+        for lab, c, names in segments(d):
+            e = merged.setdefault(lab['launch'], {'kernels': names})
+            e.update({k: round(v, 1) for k, v in c.items()})
+    for k, e in merged.items():
+        if e.get('SQ_WAVE_CYCLES'):
+            e['parked_frac_of_wave_cycles'] = round(e.get('SQ_WAIT_ANY', 0.0) / e['SQ_WAVE_CYCLES'], 4)
+            e['issue_stall_frac_of_wave_cycles'] = round(e.get('SQ_WAIT_INST_ANY', 0.0) / e['SQ_WAVE_CYCLES'], 4)
+        if e.get('SQ_INSTS_VALU_MFMA_MOPS_F32') and e.get('SQ_INSTS_VALU'):
+            # MOPS_F32 counts 512 MACs per unit: one v_mfma_f32_16x16x4_f32 = 2 units
+            e['valu_insts_per_f32_mfma'] = round(e['SQ_INSTS_VALU'] / (e['SQ_INSTS_VALU_MFMA_MOPS_F32'] / 2.0), 3)
+        out[k] = e
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'run':
+    if sys.argv[1] == 'counters':
+        counters(sys.argv[2:])
+    elif sys.argv[1] == 'run':
         run()
     elif sys.argv[1] == 'traffic':
         traffic(sys.argv[2], sys.argv[3])
