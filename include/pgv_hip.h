@@ -44,6 +44,9 @@ typedef struct pgv_conv_desc {
   int32_t kh, kw;          /* kernel */
   int32_t stride, pad;     /* same on both axes (reference uses [2,2]/2 or [1,1]/0) */
   int32_t flags;           /* PGV_PREZEROED: the accumulated outputs of the call (stats / gw) already hold zeros */
+  const void* w_shadow;    /* optional (may be NULL): the bf16 shadow of the call's weight tensor, written by
+                              pgv_conv_weight_shadow for this descriptor's layer and still current - PGV_COMPUTE_BF16
+                              calls of the deep layers then run their bf16-native kernels (ABI v11) */
 } pgv_conv_desc;
 
 /* Reduction outputs (BN statistics, weight / bias gradients, BN-backward projections) are accumulated with atomics.
@@ -85,6 +88,15 @@ int pgv_conv_down(const pgv_conv_desc* d, const float* big, const float* in_scal
 int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scale, const float* in_shift,
                 const float* w, const float* bias, int act, float slope, float* big, double* stats,
                 void* stream);
+
+/* bf16 weight shadow (PGV_COMPUTE_BF16; nn.Conv2d / nn.ConvTranspose2d weights of the deep layers, model/encoder.py:249-255,
+ * model/decoder.py:205-210): the weight tensor rounded to bfloat16 and laid out channel-innermost, once for the forward
+ * and once for the transposed direction, so that the kernels stream half the bytes and copy weight slabs to LDS as they
+ * are.  pgv_conv_weight_shadow_bytes: bytes of the shadow of this layer, 0 when the layer has no bf16-native kernels
+ * (every call then behaves as without a shadow).  pgv_conv_weight_shadow writes it (16-byte aligned, caller-owned; one
+ * launch, to be repeated whenever w changes: once per optimizer step); calls pass it in pgv_conv_desc.w_shadow. */
+int64_t pgv_conv_weight_shadow_bytes(const pgv_conv_desc* d);
+int pgv_conv_weight_shadow(const pgv_conv_desc* d, const float* w, void* shadow, void* stream);
 
 /* Optional fusion for input-gradient calls (backward of model/layer.py:21-26 under train.py:246).  The product of the
  * call is g, the gradient w.r.t. the BatchNorm output o of the next-lower block; with a pgv_bwd_fuse it is never

@@ -18,7 +18,7 @@ PGV_PREZEROED = 1
 class ConvDesc(Structure):
     """Mirror of ``pgv_conv_desc`` (include/pgv_hip.h)."""
     _fields_ = [(n, c_int32) for n in ("B", "Cb", "Hb", "Wb", "Cs", "Hs", "Ws", "kh", "kw", "stride", "pad",
-                                        "flags")]
+                                        "flags")] + [("w_shadow", c_void_p)]
 
 
 _P = c_void_p  # device pointers travel as integers
@@ -88,6 +88,8 @@ SIGNATURES = {
     "pgv_conv_up_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
     "pgv_conv_down_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_up_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_weight_shadow_bytes": (c_int64, [_DESC]),
+    "pgv_conv_weight_shadow": (c_int, [_DESC, _P, _P, _P]),
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),

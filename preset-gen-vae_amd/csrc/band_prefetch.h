@@ -162,6 +162,47 @@ struct FlatPrefetch {
       v[j] = f32x4{t.x, t.y, t.z, t.w};
     }
   }
+  // f(channel, tile row, chunk of the row, x): the finished values of every chunk this lane holds - affine applied, exact
+  // zeros outside the image and behind the end of a row - for kernels that commit them in another format than the fp32
+  // tile (conv_wgrad_bf16.hip: bfloat16 planes)
+  template <class F>
+  __device__ __forceinline__ void each(const float* __restrict__ aff, int C, int c0, int tid, F&& f) const {
+    float sc[NPF], sh[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int cg = min(c0 + (int)((meta[j] >> 12) & 255), C - 1);
+      sc[j] = aff ? aff[cg] : 1.0f;
+      sh[j] = aff ? aff[C + cg] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      if (256 * (j + 1) <= ITEMS || tid + 256 * j < ITEMS) {
+        const f32x4 t = v[j];
+        const bool on = (live >> j) & 1u;
+        const float m = on ? sc[j] : 0.f, a = on ? sh[j] : 0.f;
+        f32x4 x;
+        if (NP == 0) {
+          x.x = fmaf(t.x, m, a);
+          x.y = fmaf(t.y, m, a);
+          x.z = fmaf(t.z, m, a);
+          x.w = fmaf(t.w, m, a);
+        } else {
+          const bool part = ((meta[j] >> 8) & 15) < 4;
+          const float e0 = part ? t[(4 - NP) & 3] : t.x;
+          const float e1 = part ? t[(5 - NP) & 3] : t.y;
+          const float e2 = part ? t[(6 - NP) & 3] : t.z;
+          const float m1 = (part && NP < 2) ? 0.f : m, a1 = (part && NP < 2) ? 0.f : a;
+          const float m2 = (part && NP < 3) ? 0.f : m, a2 = (part && NP < 3) ? 0.f : a;
+          const float m3 = part ? 0.f : m, a3 = part ? 0.f : a;
+          x.x = fmaf(e0, m, a);
+          x.y = fmaf(e1, m1, a1);
+          x.z = fmaf(e2, m2, a2);
+          x.w = fmaf(t.w, m3, a3);
+        }
+        f((int)((meta[j] >> 12) & 255), (int)(meta[j] & 255), (int)(meta[j] >> 20), x);
+      }
+    }
+  }
   __device__ __forceinline__ void commit(float* __restrict__ tile, const float* __restrict__ aff, int C, int c0,
                                          int /*nch*/, int tid, bool bf16 = false) {
     float* lane_tile = tile + 4 * tid;

@@ -31,7 +31,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 10; }
+int pgv_abi_version(void) { return 11; }
 const char* pgv_last_error(void) { return g_err; }
 static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {
@@ -60,6 +60,20 @@ static int clear_stat_copies(const pgv_conv_desc* d, double* stats, int C, pgv_c
   }
   if (d->flags & PGV_STATS_COPIES) dd->flags |= PGV_PREZEROED;
   return PGV_OK;
+}
+
+int64_t pgv_conv_weight_shadow_bytes(const pgv_conv_desc* d) {
+  if (!d || check_desc(d, "pgv_conv_weight_shadow_bytes")) return 0;
+  return pgv_conv_weight_shadow_bytes_impl(d);
+}
+int pgv_conv_weight_shadow(const pgv_conv_desc* d, const float* w, void* shadow, void* stream) {
+  int rc = check_desc(d, "pgv_conv_weight_shadow");
+  if (rc) return rc;
+  PGV_CHECK_ARG(w && shadow && ((uintptr_t)shadow & 15) == 0 && ((uintptr_t)w & 15) == 0,
+                "pgv_conv_weight_shadow: null or misaligned pointer");
+  PGV_CHECK_ARG(pgv_conv_weight_shadow_bytes_impl(d) > 0, "pgv_conv_weight_shadow: this layer has no weight shadow");
+  rc = pgv_conv_weight_shadow_impl(d, w, shadow, pgv_stream(stream));
+  return rc < 0 ? rc : PGV_OK;
 }
 
 int pgv_conv_down_fused(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,

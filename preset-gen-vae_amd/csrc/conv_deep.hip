@@ -15,6 +15,7 @@
 // PGV_COMPUTE_BF16: the same tiles, operands packed to bf16 while they are read (v_cvt_pk_bf16_f32), one
 // v_mfma_f32_16x16x16_bf16 per (channel, tile) instead of four fp32 steps.
 #include "conv_tile.h"
+#include "conv_deep_common.h"
 
 #ifdef PGV_DEEP_STAMPS
 __device__ unsigned long long g_deep_stamps[8 * 64 * 8];
@@ -32,27 +33,6 @@ extern "C" int pgv_debug_read_stamps(unsigned long long* dst, int n) {
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// XCD-aware (channel block, sample group) of a workgroup.  Workgroups are dealt round-robin over the 8 XCDs, each with
-// its own L2: with blockIdx = mb * groups + grp every XCD works on ALL channel blocks at once and streams the whole
-// weight tensor (up to 8 MB against a 4 MB L2) again and again.  Here the workgroups of one XCD share a channel block
-// whenever the block count divides 8 (its weight slice, 1 MB or less, then stays in that XCD's L2 for all sample
-// groups); a speed matter only.
-__device__ __forceinline__ void deep_block(int nmb, int groups, int& mb, int& grp) {
-  const int b = (int)blockIdx.x;
-  if (nmb <= 8 && 8 % nmb == 0 && (nmb * groups) % 8 == 0) {
-    const int x = b & 7, q = b >> 3, per = 8 / nmb;   // per = XCDs per channel block
-    mb = x % nmb;
-    grp = q * per + x / nmb;
-  } else if (nmb % 8 == 0) {   // more channel blocks than XCDs: nmb / 8 of them per XCD, one after the other
-    const int x = b & 7, q = b >> 3;
-    mb = x * (nmb / 8) + q / groups;
-    grp = q % groups;
-  } else {
-    mb = b / groups;
-    grp = b - mb * groups;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
@@ -1546,6 +1526,7 @@ bool shape_k1_3x4(const pgv_conv_desc* d) {
 int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
                        hipStream_t st, const pgv_bn_src* bn) {
+  if (int rc = pgv_conv_down_deep_bf16(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn)) return rc;
   if (bn && shape_k1_3x4(d)) return 0;
   if (shape_k1_3x4(d) && d->Cs % 128 == 0)
     return launch_k1_down128<12, 16, 32>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,

@@ -1,0 +1,369 @@
+// bf16-NATIVE kernels of the deep k4 s2 p2 layers (17x23, 9x12 and 5x7 planes, 64..512 channels; model/encoder.py:249-255,
+// model/decoder.py:205-210) for PGV_COMPUTE_BF16.  The fp32-image kernels of conv_deep.hip run this mode at 0.5-0.6 of
+// their fp32 time: they are bound by the instructions AROUND the matrix instruction (fp32 fragment reads, packing, one
+// half-empty K = 32 instruction per channel and slab), not by it.  Here both operands are rounded ONCE, on their way into
+// LDS, and live there in the layout v_mfma_f32_16x16x32_bf16 reads with one 16-byte load per fragment:
+//   * channel-innermost images: a plane pixel is 16 channels = two 16-byte halves (8 channels each), so the B fragment of
+//     output pixel n, kernel row kh, for lane group kq = kernel column kw is the half-pixel at (2oh+kh, 2ow+kq): the K = 32
+//     of one instruction is 8 channels x the 4 kernel columns of one kernel row.  The half of channel group g is stored at
+//     g ^ bit3(pixel index), which makes the 16-lane groups of ds_read_b128 conflict free without padding the pixel;
+//   * weights come from a bf16 SHADOW of the layer's weight, [cs][cb/8][16 taps][8 channels] (pgv_conv_weight_shadow, one
+//     launch per layer and step): a slab of a weight row is 512 contiguous bytes, copied to LDS as it is.  The shadow
+//     halves the weight stream, the bound of these layers (every sample group streams the whole weight through L2).
+// One workgroup = 64 output channels x NS samples; 8 waves = 8 K groups (2 channel groups x 4 kernel rows of a 16-channel
+// slab), each with the full 64 x N register tile: (4 + NT) fragment reads per 4 NT instructions.
+#include "conv_tile.h"
+#include "conv_deep_common.h"
+
+static unsigned long long* g_deep_bf16_stamps = nullptr;   // device buffer of the timing scripts: clock64() at the phase marks
+extern "C" void pgv_dbg_set_deep_bf16_stamps(void* p) { g_deep_bf16_stamps = (unsigned long long*)p; }
+#define BSTAMP(k)                                                                                   \
+  do {                                                                                              \
+    if (stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 77)) stamps[(blockIdx.x ? 16 : 0) + (k)] = clock64(); \
+  } while (0)
+static int g_deep_bf16_dbg = 0;   // ablation knob of the timing scripts: 1 no matrix instructions, 2 no loads, 4 no commits
+extern "C" int pgv_dbg_set_deep_bf16_variant(int v) {
+  const int old = g_deep_bf16_dbg;
+  g_deep_bf16_dbg = v;
+  return old;
+}
+
+namespace {
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight shadows.  down: D[cs][cb/8][kh*4+kw][8] (M = cs);  up: U[cb][cs/8][phase][th*2+tw][8] (M = cb), phase = 2ph+pw,
+// taps kh = ph + 2th, kw = pw + 2tw.  One thread = (cs, channel group of 8 cb, kernel row): 8 x 16-byte reads, 4 x 16-byte
+// writes of the down shadow; the up shadow is written by the thread that owns (cb, group of 8 cs, kernel row).
+__global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restrict__ w, int CS, int CB,
+                                                        u16* __restrict__ down, u16* __restrict__ up) {
+  const int items = CS * (CB / 8) * 4;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int kh = it & 3, g = (it >> 2) % (CB / 8), cs = (it >> 2) / (CB / 8);
+    f32x4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const f32x4*>(w + ((size_t)(cs * CB + g * 8 + c) * 16 + kh * 4));
+    u32x4* dst = reinterpret_cast<u32x4*>(down + ((size_t)(cs * (CB / 8) + g) * 16 + kh * 4) * 8);
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+      dst[kw] = u32x4{pack_bf16x2(v[0][kw], v[1][kw]), pack_bf16x2(v[2][kw], v[3][kw]), pack_bf16x2(v[4][kw], v[5][kw]),
+                      pack_bf16x2(v[6][kw], v[7][kw])};
+  }
+  if (!up) return;
+  const int items_u = CB * (CS / 8) * 4;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items_u; it += gridDim.x * 256) {
+    const int kh = it & 3, cb = (it >> 2) % CB, g = (it >> 2) / CB;   // cb fastest: the reads of a wave are 64-byte pieces
+    f32x4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const f32x4*>(w + ((size_t)((g * 8 + c) * CB + cb) * 16 + kh * 4));
+    const int ph = kh & 1, th = kh >> 1;
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int pw = kw & 1, tw = kw >> 1;
+      u32x4* dst = reinterpret_cast<u32x4*>(up + ((size_t)((cb * (CS / 8) + g) * 4 + 2 * ph + pw) * 4 + 2 * th + tw) * 8);
+      *dst = u32x4{pack_bf16x2(v[0][kw], v[1][kw]), pack_bf16x2(v[2][kw], v[3][kw]), pack_bf16x2(v[4][kw], v[5][kw]),
+                   pack_bf16x2(v[6][kw], v[7][kw])};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
+template <int H_, int W_, int NS_>
+struct DownB {
+  static constexpr int H = H_, W = W_, NS = NS_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W, HP = 2 * Hs + 2;
+  // image pixels (rows / columns -2 .. 2Hs-1 / 2Ws-1) and plane strides in pixels: scratch/deep_bf16_strides.py - no bank
+  // conflicts on the 5x7 planes, 0.11 / 0.14 extra LDS cycles per fragment read on 9x12 / 17x23
+  static constexpr int WP = (H == 5 && W == 7) ? 12 : (H == 9 && W == 12) ? 23 : (H == 17 && W == 23) ? 28 : 2 * Ws + 2;
+  static constexpr int PLANE = (H == 5 && W == 7) ? 104 : (H == 9 && W == 12) ? 278 : HP * WP;
+  static_assert(WP >= 2 * Ws + 2 && PLANE >= HP * WP, "padded plane");
+  static constexpr int N = NS * P, NT = (N + 15) / 16;
+  static constexpr int CK = 16;                            // channels per slab = two groups of 8
+  static constexpr int A_ROW = 2 * 256 + 32;               // bytes per weight row of a slab: conflict-free fragment reads
+  static constexpr int A_BYTES = 64 * A_ROW;
+  static constexpr int B_BYTES = NS * PLANE * 32;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int QA = 64 * 32 / 512;                 // 16-byte weight pieces per thread and slab
+  static constexpr int QUADS = (HW + 3) / 4;               // pixel quads of a plane (the last one shifted back)
+  static constexpr int ITEMS = NS * 8 * QUADS;             // (sample, channel pair, quad)
+  static constexpr int QB = (ITEMS + 511) / 512;
+  static constexpr int RED_BYTES = 8 * NT * 1024, OUT_BYTES = NS * 64 * P * 4;
+  static_assert(STAGE % 16 == 0 && HW >= 4, "alignment");
+  static_assert(RED_BYTES + OUT_BYTES <= 2 * STAGE, "reduction and output tile fit the stages");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift,
+                                                             const u16* __restrict__ wsh, const float* __restrict__ bias,
+                                                             int act, float slope, float* __restrict__ out,
+                                                             double* __restrict__ stats, int groups, int stat_stride,
+                                                             pgv_bn_src in_bn, int dbg,
+                                                             unsigned long long* __restrict__ stamps) {
+  constexpr int NT = G::NT, HW = G::HW, P = G::P, NS = G::NS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*CB]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cbg = wave >> 2, kh = wave & 3;
+  int mb, grp;
+  deep_block(CS / 64, groups, mb, grp);
+  const int cs0 = mb * 64, b0 = grp * NS;
+  BSTAMP(0);
+
+  // zero both stages' images once (the data pixels are rewritten every slab, the padding never)
+  for (int i = tid; i < G::B_BYTES / 16; i += 512) {
+    reinterpret_cast<u32x4*>(ldsb + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+    reinterpret_cast<u32x4*>(ldsb + G::STAGE + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+  }
+  for (int i = tid; i < CB; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CB, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CB + i] = sh;
+  }
+
+  // ---- loader coordinates (identical for every slab)
+  const int cbgs = CB / 8;
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 512 * i, row = q >> 5, f = q & 31;
+    a_src[i] = ((cs0 + row) * cbgs) * 256 + f * 16;   // bytes into the shadow (+ 512 per slab)
+    a_dst[i] = row * G::A_ROW + f * 16;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int si = q / (8 * G::QUADS), rem = q - si * (8 * G::QUADS), cp = rem / G::QUADS, qi = rem - cp * G::QUADS;
+    const int p0 = min(4 * qi, HW - 4);
+    const int bs = min(b0 + si, B - 1);   // partial last group: duplicate the last sample (masked at the store)
+    b_src[i] = (bs * CB + 2 * cp) * HW + p0;
+    b_cp[i] = cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pe = p0 + e, r = pe / G::W, c = pe - r * G::W;
+      const int px = si * G::PLANE + (r + 2) * G::WP + c + 2;
+      b_dst[i][e] = px * 32 + (((cp >> 2) ^ ((px >> 3) & 1)) * 16) + (cp & 3) * 4;
+    }
+  }
+  // ---- fragment coordinates (bytes)
+  const int a_frag = m * G::A_ROW + cbg * 256 + kh * 64 + kq * 16;   // M tile t: + t * 16 rows
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = min(t * 16 + m, G::N - 1);
+    const int si = n / P, pix = n - si * P, oh = pix / G::Ws, ow = pix - oh * G::Ws;
+    const int px = si * G::PLANE + (2 * oh + kh) * G::WP + 2 * ow + kq;
+    boff[t] = G::A_BYTES + px * 32 + ((cbg ^ ((px >> 3) & 1)) * 16);
+  }
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[G::QA];
+  f4u rb[G::QB][2];
+  auto issue = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i)
+      ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + a_src[i] + slab * 512);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const float* p = big + b_src[i] + slab * (16 * HW);
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + HW);
+    }
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<u32x4*>(st + a_dst[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = slab * 16 + 2 * b_cp[i];
+      const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[CB + c], h1 = aff[CB + c + 1];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<unsigned*>(st + G::A_BYTES + b_dst[i][e]) =
+              pack_bf16x2(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1));
+      }
+    }
+  };
+
+  const int nslab = CB / 16;
+  BSTAMP(1);
+  issue(0);
+  __syncthreads();   // images zeroed, affine staged
+  BSTAMP(2);
+  commit(ldsb, 0);
+  if (nslab > 1) issue(1);
+  __syncthreads();
+  BSTAMP(3);
+#pragma unroll 1
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned char* st = ldsb + (s & 1) * G::STAGE;
+    u32x4 af[4], bf[NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(st + a_frag + mt * 16 * G::A_ROW);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const u32x4*>(st + boff[t]);
+    if (!(dbg & 1)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
+    }
+    if (s + 1 < nslab) {   // the next slab goes to the other stage under the running matrix pipe
+      if (!(dbg & 4)) commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
+      if (s + 2 < nslab && !(dbg & 2)) issue(s + 2);
+    }
+    if (!(dbg & 1)) {
+#pragma unroll
+      for (int mt = 2; mt < 4; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
+    }
+    __syncthreads();
+  }
+
+  // ---- the 8 K groups' partial tiles are added up M tile by M tile (a round: every wave stores its 16 x N partial tile,
+  // wave w sums the N tiles t = w, w + 8 in the fixed order of the waves - deterministic - and finishes them: bias,
+  // activation, into the [sample][channel][P] output tile); the stages are free after the last slab's barrier
+  BSTAMP(4);
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  f32x4* red = reinterpret_cast<f32x4*>(ldsb);
+  float* otile = reinterpret_cast<float*>(ldsb + G::RED_BYTES);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[mt][t];
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < (NT + 7) / 8; ++tt) {
+      const int t = wave + 8 * tt;
+      if (t < NT) {
+        f32x4 v = red[t * 64 + lane];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) v += red[(u * NT + t) * 64 + lane];
+        const int n = t * 16 + m, si = n / P, pix = n - si * P, cl = mt * 16 + 4 * kq;
+        if (n < G::N) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            otile[(si * 64 + cl + i) * P + pix] = pgv_act_apply(v[i] + (bias ? bias[cs0 + cl + i] : 0.f), ap);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  BSTAMP(5);
+  // ---- BatchNorm statistics of the written outputs: 8 lanes per channel over the tile, one pair of atomics per channel
+  if (stats) {
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
+    const int ch = tid >> 3, part = tid & 7;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+      if (b0 + si < B)
+        for (int i = part; i < P; i += 8) {
+          const float v = otile[(si * 64 + ch) * P + i];
+          s1 += v;
+          s2 += v * v;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (part == 0) {
+      atomicAdd(&stats[cs0 + ch], (double)s1);
+      atomicAdd(&stats[CS + cs0 + ch], (double)s2);
+    }
+  }
+  BSTAMP(6);
+#pragma unroll
+  for (int si = 0; si < NS; ++si) {
+    if (b0 + si < B) {
+      float* dst = out + ((int64_t)(b0 + si) * CS + cs0) * P;
+      const float* src = otile + si * 64 * P;
+      for (int i = tid; i < 64 * P; i += 512) dst[i] = src[i];
+    }
+  }
+  BSTAMP(7);
+}
+
+template <int H, int W, int NS>
+int launch_deep_down_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                          const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                          const pgv_bn_src* bn) {
+  using G = DownB<H, W, NS>;
+  if (d->Cs % 64 || d->Cb % 16 || !d->w_shadow) return 0;
+  if ((int64_t)d->B * d->Cb * G::HW * 4 >= (int64_t)1 << 31 || (int64_t)d->Cs * d->Cb * 32 >= (int64_t)1 << 31) return 0;
+  const size_t bytes = 2 * (size_t)G::STAGE + sizeof(float) * (2 * (size_t)d->Cb + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = deep_down_bf16_kernel<G>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_down_deep_bf16");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_deep_bf16: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big, in_scale,
+                     in_shift, (const u16*)d->w_shadow, bias, act, slope, out, stats, groups,
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0, bn ? *bn : pgv_no_bn(), g_deep_bf16_dbg,
+                     g_deep_bf16_stamps);
+  PGV_CHECK_LAUNCH("conv_down_deep_bf16");
+  return 1;
+}
+
+bool deep_bf16_shape(const pgv_conv_desc* d) {
+  return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
+         ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
+}
+
+}  // namespace
+
+// bytes of the bf16 weight shadow of a layer (down + up layouts), 0: the layer has no bf16-native kernels
+int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
+  return deep_bf16_shape(d) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
+}
+
+int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
+  if (!deep_bf16_shape(d)) return 0;
+  u16* down = (u16*)shadow;
+  u16* up = down + (size_t)d->Cs * d->Cb * 16;
+  const int items = d->Cs * (d->Cb / 8) * 4;
+  hipLaunchKernelGGL(deep_shadow_kernel, dim3((unsigned)min((items + 255) / 256, 2048)), dim3(256), 0, st, w, d->Cs, d->Cb,
+                     down, up);
+  PGV_CHECK_LAUNCH("conv_weight_shadow");
+  return 1;
+}
+
+// 1 = launched, 0 = not this kernel family's case (no shadow in the descriptor, shape not covered)
+int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                            const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                            const pgv_bn_src* bn) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down_bf16<5, 7, 8>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  return 0;
+}

@@ -39,6 +39,10 @@ int pgv_conv_wgrad_band(const pgv_conv_desc* d, const float* big, const float* b
 int pgv_conv_wgrad_band_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                                 const float* small_in, const float* small_scale, const float* small_shift, float* partial,
                                 int64_t partial_bytes, int* nparts, hipStream_t st);
+// bf16-native weight gradient (conv_wgrad_bf16.hip): same workspace layout, the three stride-2 k=4 layers of the stack
+int pgv_conv_wgrad_bf16_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                                const float* small_in, const float* small_scale, const float* small_shift, float* partial,
+                                int64_t partial_bytes, int* nparts, hipStream_t st);
 
 // Second-generation kernels (conv_v2.hip): one workgroup per CU, waves split M, weights from registers; tried first.
 // (bn != null: in_scale / in_shift are bn->scale / bn->shift, not yet computed - the kernel finalizes the BatchNorm in its
@@ -120,3 +124,10 @@ int pgv_act_bwd_coef_impl(const float* g, const float* a, const float* coef, int
                           float* g_y, float* gbias, hipStream_t st);
 // cls[C][4] += sums of gy[B,C,H,W] by (row parity, column parity): pgv_bwd_fuse.cls for kernels without that by-product
 int pgv_class_sums2_impl(const float* gy, int B, int C, int H, int W, float* cls, hipStream_t st);
+
+// bf16-native kernels of the deep layers (conv_deep_bf16.hip); weights come from pgv_conv_desc.w_shadow
+int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d);
+int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st);
+int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                            const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                            const pgv_bn_src* bn);

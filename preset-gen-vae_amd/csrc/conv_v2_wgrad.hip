@@ -743,6 +743,14 @@ int pgv_bias_finish(const pgv_bias_req* bias, hipStream_t st) {
   return PGV_OK;
 }
 
+// debugging / A-B knob: bit 0 = bf16 operand mode stays on the band kernels (conv_band.hip) instead of conv_wgrad_bf16.hip
+static int g_wgrad_bf16_variant = 0;
+extern "C" int pgv_dbg_set_wgrad_bf16_variant(int v) {
+  const int old = g_wgrad_bf16_variant;
+  g_wgrad_bf16_variant = v;
+  return old;
+}
+
 int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                       void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias,
@@ -757,8 +765,13 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
     // and the reduce launch of this file adds them up - with the tap sums / bias roles the fp32 step folds into it
     if (!workspace || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
     int nparts = 0;
-    int rc = pgv_conv_wgrad_band_partial(d, big, big_scale, big_shift, small_in, small_scale, small_shift, (float*)workspace,
-                                         workspace_bytes, &nparts, st);
+    int rc = (g_wgrad_bf16_variant & 1) ? 0
+                                        : pgv_conv_wgrad_bf16_partial(d, big, big_scale, big_shift, small_in, small_scale,
+                                                                      small_shift, (float*)workspace, workspace_bytes,
+                                                                      &nparts, st);
+    if (rc == 0)
+      rc = pgv_conv_wgrad_band_partial(d, big, big_scale, big_shift, small_in, small_scale, small_shift, (float*)workspace,
+                                       workspace_bytes, &nparts, st);
     if (rc <= 0) return rc;
     const int n4 = d->Cs * d->Cb * 16 / 4;
     if (req) {

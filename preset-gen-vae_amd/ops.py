@@ -67,15 +67,29 @@ class ConvGeom:
         self.Hs = (Hb + 2 * pad - k) // stride + 1
         self.Ws = (Wb + 2 * pad - k) // stride + 1
         self._descs = {}
+        self._shadow_bytes = None
 
-    def desc(self, B, flags=0):
+    def desc(self, B, flags=0, w_shadow=None):
+        """``w_shadow``: the tensor ``conv_weight_shadow`` returned for the call's weight (``pgv_conv_desc.w_shadow``)."""
         flags |= _COMPUTE_FLAGS
+        if w_shadow is not None:   # per call: the descriptor carries a pointer
+            return ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
+                            self.pad, flags, w_shadow.data_ptr())
         d = self._descs.get((B, flags))
         if d is None:
             d = ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
-                         self.pad, flags)
+                         self.pad, flags, None)
             self._descs[(B, flags)] = d
         return d
+
+    def shadow_bytes(self):
+        """Bytes of the bf16 weight shadow of this layer in the current compute mode (0: none)."""
+        if not (_COMPUTE_FLAGS & PGV_COMPUTE_BF16):
+            return 0
+        n = self._shadow_bytes
+        if n is None:
+            n = self._shadow_bytes = int(_lib.load().pgv_conv_weight_shadow_bytes(ctypes.byref(self.desc(1))))
+        return n
 
 
 def _fuse_arg(bwd_fuse, out):
@@ -124,8 +138,21 @@ def bn_src_finalize(src):
     _lib.check(_lib.load().pgv_bn_finalize_src(ctypes.byref(src), C, _stream()), "pgv_bn_finalize_src")
 
 
+def conv_weight_shadow(geom, w):
+    """The bf16 shadow of weight ``w`` of layer ``geom`` (``pgv_conv_weight_shadow``) for ``w_shadow=`` of the conv calls
+    that multiply by ``w`` until it changes, or None: fp32 mode, or the layer has no bf16-native kernels."""
+    n = geom.shadow_bytes()
+    if n == 0:
+        return None
+    _chk(w)
+    sh = torch.empty(n, device=w.device, dtype=torch.uint8)
+    _lib.check(_lib.load().pgv_conv_weight_shadow(ctypes.byref(geom.desc(1)), _p(w), _p(sh), _stream()),
+               "pgv_conv_weight_shadow")
+    return sh
+
+
 def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-              bwd_fuse=None, in_bn=None, stats_copies=False):
+              bwd_fuse=None, in_bn=None, stats_copies=False, w_shadow=None):
     """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it.
     ``in_bn`` (a ``bn_src``): the input's BatchNorm, finalized by this call (``pgv_conv_down_bn``).  ``stats_copies``:
     ``stats`` is CLS_COPIES zeroed partial copies of [2C] (PGV_STATS_COPIES)."""
@@ -139,18 +166,18 @@ def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stat
     if in_bn is not None:
         if bwd_fuse is not None or in_scale is not None:
             raise ValueError("conv_down: in_bn excludes in_scale / bwd_fuse")
-        _lib.check(lib.pgv_conv_down_bn(ctypes.byref(geom.desc(B, fl)), _p(big), ctypes.byref(in_bn), _p(w),
+        _lib.check(lib.pgv_conv_down_bn(ctypes.byref(geom.desc(B, fl, w_shadow)), _p(big), ctypes.byref(in_bn), _p(w),
                                         _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_down_bn")
         return out
     f = _fuse_arg(bwd_fuse, out)
-    _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, fl)), _p(big), _p(in_scale),
+    _lib.check(lib.pgv_conv_down_fused(ctypes.byref(geom.desc(B, fl, w_shadow)), _p(big), _p(in_scale),
                                        _p(in_shift), _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                        None if f is None else ctypes.byref(f), _stream()), "pgv_conv_down")
     return out
 
 
 def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
-            bwd_fuse=None, in_bn=None, stats_copies=False):
+            bwd_fuse=None, in_bn=None, stats_copies=False, w_shadow=None):
     B = small.shape[0]
     fl = int(prezeroed) | (PGV_STATS_COPIES if stats_copies else 0)
     if out is None:
@@ -161,11 +188,11 @@ def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stat
     if in_bn is not None:
         if bwd_fuse is not None or in_scale is not None:
             raise ValueError("conv_up: in_bn excludes in_scale / bwd_fuse")
-        _lib.check(lib.pgv_conv_up_bn(ctypes.byref(geom.desc(B, fl)), _p(small), ctypes.byref(in_bn), _p(w),
+        _lib.check(lib.pgv_conv_up_bn(ctypes.byref(geom.desc(B, fl, w_shadow)), _p(small), ctypes.byref(in_bn), _p(w),
                                       _p(bias), act, slope, _p(out), _p(stats), _stream()), "pgv_conv_up_bn")
         return out
     f = _fuse_arg(bwd_fuse, out)
-    _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, fl)), _p(small), _p(in_scale), _p(in_shift),
+    _lib.check(lib.pgv_conv_up_fused(ctypes.byref(geom.desc(B, fl, w_shadow)), _p(small), _p(in_scale), _p(in_shift),
                                      _p(w), _p(bias), act, slope, _p(out), _p(stats),
                                      None if f is None else ctypes.byref(f), _stream()), "pgv_conv_up")
     return out
