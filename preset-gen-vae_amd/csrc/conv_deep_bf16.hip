@@ -334,6 +334,258 @@ int launch_deep_down_bf16(const pgv_conv_desc* d, const float* big, const float*
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// UP: out[b,cb,ih,iw] = act(bias[cb] + sum_{cs,kh,kw} w[cs,cb,kh,kw] * s'[b,cs,oh,ow]),  ih = 2oh-2+kh, iw = 2ow-2+kw.
+// Output pixel (ih,iw) = (2u+ph, 2v+pw) only meets the taps kh = ph+2th, kw = pw+2tw (th,tw in {0,1}) at oh = u+1-th,
+// ow = v+1-tw: four 2x2-tap convolutions, one per output phase.  GEMM per phase: M = cb (32 per workgroup: the layers have
+// 64..256 big channels, and every sample group streams the whole weight), K = (cs, 4 taps), N = the phase's output pixels
+// of NS samples.  The K = 32 of one instruction is 8 small channels x the 4 taps of the phase (lane group kq = 2th+tw), the
+// B fragment the quarter-pixel (32 channels per pixel) at (u+1-th, v+1-tw) of the zero-padded small image.  The 8 waves
+// split N - wave = (phase, half of the phase's tiles), every wave runs the whole K: no reduction between waves.
+template <int H_, int W_, int NS_>
+struct UpB {
+  static constexpr int H = H_, W = W_, NS = NS_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
+  // small image with a zero row below / column right; strides in pixels (scratch/deep_bf16_strides.py: about one extra
+  // LDS cycle per fragment read remains on every layer - the phases' short pixel rows do not tile the 16 slots)
+  static constexpr int SWP = (H == 5 && W == 7) ? 5 : (H == 9 && W == 12) ? 11 : (H == 17 && W == 23) ? 14 : Ws + 1;
+  static constexpr int SPLANE = (H == 5 && W == 7) ? 23 : (H == 9 && W == 12) ? 70 : (H == 17 && W == 23) ? 141 : (Hs + 1) * SWP;
+  static_assert(SWP >= Ws + 1 && SPLANE >= (Hs + 1) * SWP, "padded plane");
+  static constexpr int hu(int p) { return (p >> 1) ? H / 2 : (H + 1) / 2; }
+  static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
+  static constexpr int cnt(int p) { return NS * hu(p) * wu(p); }
+  static constexpr int ntp(int p) { return (cnt(p) + 15) / 16; }
+  static constexpr int TMAX = (ntp(0) + 1) / 2;            // tiles of one wave (phase 0 has the most pixels)
+  static constexpr int CK = 32;                            // small channels per slab = four groups of 8
+  static constexpr int MT = 32;                            // big channels per workgroup
+  static constexpr int A_ROW = 4 * 256 + 32;               // bytes per weight row of a slab
+  static constexpr int A_BYTES = MT * A_ROW;
+  static constexpr int B_BYTES = NS * SPLANE * 64;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int QA = MT * 64 / 512;
+  static constexpr int QUADS = (P + 3) / 4;
+  static constexpr int ITEMS = NS * 16 * QUADS;            // (sample, channel pair, pixel quad)
+  static constexpr int QB = (ITEMS + 511) / 512;
+  static constexpr int OUT_BYTES = NS * MT * HW * 4;
+  static_assert(STAGE % 16 == 0 && P >= 4, "alignment");
+  static_assert(OUT_BYTES <= 2 * STAGE, "output tile fits the stages");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void deep_up_bf16_kernel(int B, int CB, int CS, const float* __restrict__ small_in,
+                                                           const float* __restrict__ in_scale,
+                                                           const float* __restrict__ in_shift,
+                                                           const u16* __restrict__ wsh, const float* __restrict__ bias,
+                                                           int act, float slope, float* __restrict__ out,
+                                                           double* __restrict__ stats, int groups, int stat_stride,
+                                                           pgv_bn_src in_bn) {
+  constexpr int HW = G::HW, P = G::P, NS = G::NS, TMAX = G::TMAX, MT = G::MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*CS]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // phases 0..3 have decreasing pixel counts: the two waves of a SIMD (w, w + 4) take phases p and 3 - p
+  const int ph = wave < 4 ? wave : 7 - wave, half = wave >> 2;
+  int mb, grp;
+  deep_block(CB / MT, groups, mb, grp);
+  const int cb0 = mb * MT, b0 = grp * NS;
+
+  for (int i = tid; i < G::B_BYTES / 16; i += 512) {
+    reinterpret_cast<u32x4*>(ldsb + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+    reinterpret_cast<u32x4*>(ldsb + G::STAGE + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+  }
+  for (int i = tid; i < CS; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CS, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CS + i] = sh;
+  }
+
+  // ---- loader coordinates
+  const int csgs = CS / 8;
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 512 * i, row = q >> 6, f = q & 63;
+    a_src[i] = ((cb0 + row) * csgs) * 256 + f * 16;   // bytes into the up shadow (+ 1024 per slab)
+    a_dst[i] = row * G::A_ROW + f * 16;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int si = q / (16 * G::QUADS), rem = q - si * (16 * G::QUADS), cp = rem / G::QUADS, qi = rem - cp * G::QUADS;
+    const int p0 = min(4 * qi, P - 4);
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = (bs * CS + 2 * cp) * P + p0;
+    b_cp[i] = cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pe = p0 + e, oh = pe / G::Ws, ow = pe - oh * G::Ws;
+      const int px = si * G::SPLANE + oh * G::SWP + ow;
+      b_dst[i][e] = px * 64 + (((cp >> 2) ^ ((px >> 2) & 3)) * 16) + (cp & 3) * 4;
+    }
+  }
+  // ---- this wave's tiles: pixels [16 (t0 + t), +16) of phase ph's list (sample, u, v)
+  const int phh = ph >> 1, pww = ph & 1;
+  const int hu = phh ? G::H / 2 : (G::H + 1) / 2, wu = pww ? G::W / 2 : (G::W + 1) / 2;
+  const int cnt = NS * hu * wu, ntp = (cnt + 15) >> 4;
+  const int t0 = half ? (ntp + 1) >> 1 : 0, ntl = half ? ntp >> 1 : (ntp + 1) >> 1;
+  const int th = kq >> 1, tw = kq & 1;
+  const int a_frag = m * G::A_ROW + ph * 64 + kq * 16;   // + 256 per channel group, + 16 rows for the second M tile
+  int boff[TMAX][4], opix[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    const int n = (t0 + t) * 16 + m, nn = min(n, cnt - 1);
+    const int si = nn / (hu * wu), rem = nn - si * (hu * wu), u = rem / wu, v = rem - u * wu;
+    const int px = si * G::SPLANE + (u + 1 - th) * G::SWP + (v + 1 - tw);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) boff[t][g] = G::A_BYTES + px * 64 + ((g ^ ((px >> 2) & 3)) * 16);
+    opix[t] = (t < ntl && n < cnt) ? si * MT * HW + (2 * u + phh) * G::W + 2 * v + pww : -1;
+  }
+  float bv[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[mt][i] = bias ? bias[cb0 + mt * 16 + 4 * kq + i] : 0.f;
+  f32x4 acc[2][TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[G::QA];
+  f4u rb[G::QB][2];
+  auto issue = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i)
+      ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + a_src[i] + slab * 1024);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const float* p = small_in + b_src[i] + slab * (32 * P);
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + P);
+    }
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<u32x4*>(st + a_dst[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = slab * 32 + 2 * b_cp[i];
+      const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[CS + c], h1 = aff[CS + c + 1];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<unsigned*>(st + G::A_BYTES + b_dst[i][e]) =
+              pack_bf16x2(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1));
+      }
+    }
+  };
+
+  const int nslab = CS / 32;
+  issue(0);
+  __syncthreads();
+  commit(ldsb, 0);
+  if (nslab > 1) issue(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned char* st = ldsb + (s & 1) * G::STAGE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + a_frag + g * 256);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + a_frag + g * 256 + 16 * G::A_ROW);
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < ntl) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(st + boff[t][g]);
+          acc[0][t] = mfma_bf16_k32(a0, b, acc[0][t]);
+          acc[1][t] = mfma_bf16_k32(a1, b, acc[1][t]);
+        }
+      }
+      if (g == 1 && s + 1 < nslab) {   // the next slab goes to the other stage under the running matrix pipe
+        commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
+        if (s + 2 < nslab) issue(s + 2);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, activation, into the [sample][channel][H*W] output tile (the stages are free)
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float* otile = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (opix[t] >= 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          otile[opix[t] + (mt * 16 + 4 * kq + i) * HW] = pgv_act_apply(acc[mt][t][i] + bv[mt][i], ap);
+    }
+  }
+  __syncthreads();
+  if (stats) {   // 16 lanes per channel over the tile, one pair of atomics per channel
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;
+    const int ch = tid >> 4, part = tid & 15;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+      if (b0 + si < B)
+        for (int i = part; i < HW; i += 16) {
+          const float v = otile[(si * MT + ch) * HW + i];
+          s1 += v;
+          s2 += v * v;
+        }
+    }
+    s1 = group16_sum(s1);
+    s2 = group16_sum(s2);
+    if (part == 0) {
+      atomicAdd(&stats[cb0 + ch], (double)s1);
+      atomicAdd(&stats[CB + cb0 + ch], (double)s2);
+    }
+  }
+#pragma unroll
+  for (int si = 0; si < NS; ++si) {
+    if (b0 + si < B) {
+      float* dst = out + ((int64_t)(b0 + si) * CB + cb0) * HW;
+      const float* src = otile + si * MT * HW;
+      for (int i = tid; i < MT * HW; i += 512) dst[i] = src[i];
+    }
+  }
+}
+
+template <int H, int W, int NS>
+int launch_deep_up_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                        const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                        const pgv_bn_src* bn) {
+  using G = UpB<H, W, NS>;
+  if (d->Cb % G::MT || d->Cs % 32 || !d->w_shadow) return 0;
+  if ((int64_t)d->B * d->Cs * G::P * 4 >= (int64_t)1 << 31 || (int64_t)d->Cs * d->Cb * 32 >= (int64_t)1 << 31) return 0;
+  const size_t bytes = 2 * (size_t)G::STAGE + sizeof(float) * (2 * (size_t)d->Cs + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = deep_up_bf16_kernel<G>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_up_deep_bf16");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_deep_bf16: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + NS - 1) / NS;
+  const u16* up = (const u16*)d->w_shadow + (size_t)d->Cs * d->Cb * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / G::MT))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, small_in,
+                     in_scale, in_shift, up, bias, act, slope, out, stats, groups,
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn());
+  PGV_CHECK_LAUNCH("conv_up_deep_bf16");
+  return 1;
+}
+
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -365,5 +617,15 @@ int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const floa
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 5 && d->Wb == 7) return launch_deep_down_bf16<5, 7, 8>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  return 0;
+}
+
+int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                          const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                          const pgv_bn_src* bn) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_bf16<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_bf16<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up_bf16<5, 7, 8>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   return 0;
 }

@@ -131,3 +131,6 @@ int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* sh
 int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                             const pgv_bn_src* bn);
+int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                          const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                          const pgv_bn_src* bn);

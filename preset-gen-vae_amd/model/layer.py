@@ -208,14 +208,17 @@ class ConvStackFn(torch.autograd.Function):
                 stats = arena[a_off:a_off + SC * 2 * C]
                 a_off += SC * 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
+            # bf16 operand mode, deep layers: the weight rounded once per step into the layouts the bf16-native kernels
+            # stream (ops.conv_weight_shadow); None otherwise.  The backward pass multiplies by the same weight.
+            w_sh = ops.conv_weight_shadow(g, w)
             # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
             if pending is not None:
                 a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending,
-                       stats_copies=stats is not None and SC > 1)
+                       stats_copies=stats is not None and SC > 1, w_shadow=w_sh)
                 pending = None
             else:
                 a = fn(g, cur, w, b, blk.act, blk.slope, in_scale=cur_scale, in_shift=cur_shift, stats=stats,
-                       prezeroed=stats is not None, stats_copies=stats is not None and SC > 1)
+                       prezeroed=stats is not None, stats_copies=stats is not None and SC > 1, w_shadow=w_sh)
             scale = shift = mean = rstd = None
             if has_bn:
                 vec = torch.empty(4 * C, device=dev, dtype=torch.float32)
@@ -236,7 +239,7 @@ class ConvStackFn(torch.autograd.Function):
                 else:
                     ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
                     mean = rstd = None
-            saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g))
+            saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g, w_sh))
             cur, cur_scale, cur_shift = a, scale, shift
         ctx.drop = None
         if out_dropout is not None:
@@ -348,7 +351,7 @@ class ConvStackFn(torch.autograd.Function):
         gb_is_copies = False
         for li in range(nb - 1, -1, -1):
             blk = blocks[li]
-            inp, in_scale, in_shift, a, scale, mean, rstd, geom = saved[li]
+            inp, in_scale, in_shift, a, scale, mean, rstd, geom, w_sh = saved[li]
             has_bn = blk.bn is not None
             pi = pis[li]
             w = params[pi]
@@ -398,7 +401,7 @@ class ConvStackFn(torch.autograd.Function):
             coef_req = None
             if need_dx and li > 0 and passfree[li - 1]:
                 low = blocks[li - 1]
-                _, _, _, a_low, _, mean_low, rstd_low, _ = saved[li - 1]
+                _, _, _, a_low, _, mean_low, rstd_low, _, _ = saved[li - 1]
                 pl = pis[li - 1]
                 Cl = low.c_out
                 if low.bn is not None and mean_low is not None:
@@ -448,9 +451,9 @@ class ConvStackFn(torch.autograd.Function):
             _grad_done(params[pi + 1], w)
             if need_dx:
                 if blk.up:
-                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+                    g_o = ops.conv_down(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse, w_shadow=w_sh)
                 else:
-                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse)
+                    g_o = ops.conv_up(geom, g_y, w, None, PGV_ACT_NONE, 0.0, bwd_fuse=fuse, w_shadow=w_sh)
                 if fuse is not None:
                     g_y_fused, g_o = g_o, None
                     gb_cur, cls_cur = fuse[2], fuse[5]

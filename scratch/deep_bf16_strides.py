@@ -30,3 +30,34 @@ for (H, W, NS) in [(5, 7, 8), (9, 12, 4), (17, 23, 1), (17, 23, 2)]:
             best.append((c, PLANE, WP, n))
     best.sort()
     print((H, W, NS), 'HP', HP, 'min WP', 2 * Ws + 2, best[:4])
+
+print('--- up: 64-byte pixels (32 channels), quarter of channel group g at g ^ ((px >> 2) & 3)')
+def cost_up(H, W, NS, SWP, SPLANE):
+    Hs, Ws = H // 2 + 1, W // 2 + 1
+    tot = cnt = 0
+    for ph in range(4):
+        hu = H // 2 if ph >> 1 else (H + 1) // 2
+        wu = W // 2 if ph & 1 else (W + 1) // 2
+        npx = NS * hu * wu
+        for t in range((npx + 15) // 16):
+            for g in range(4):
+                for grp in GROUPS:
+                    slots = {}
+                    for lane in grp:
+                        n = min(t * 16 + (lane & 15), npx - 1); kq = lane >> 4; th, tw = kq >> 1, kq & 1
+                        si, rem = divmod(n, hu * wu); u, v = divmod(rem, wu)
+                        px = si * SPLANE + (u + 1 - th) * SWP + v + 1 - tw
+                        addr = px * 64 + ((g ^ ((px >> 2) & 3)) * 16)
+                        slots.setdefault((addr // 16) % 16, set()).add(addr)
+                    tot += max(len(v) for v in slots.values()) - 1
+                    cnt += 1
+    return tot, cnt
+for (H, W, NS) in [(5, 7, 8), (9, 12, 4), (17, 23, 2)]:
+    Hs, Ws = H // 2 + 1, W // 2 + 1
+    best = []
+    for SWP in range(Ws + 1, Ws + 12):
+        for SPLANE in range((Hs + 1) * SWP, (Hs + 1) * SWP + 20):
+            c, n = cost_up(H, W, NS, SWP, SPLANE)
+            best.append((c, SPLANE, SWP, n))
+    best.sort()
+    print((H, W, NS), 'rows', Hs + 1, 'min SWP', Ws + 1, best[:4])

@@ -330,6 +330,61 @@ def test_deep_kernels_many_units(ops, case, mode):
         ops.set_compute_dtype('fp32')
 
 
+@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9),
+                                  (256, 512, 4, 2, 2, 5, 7, 16), (128, 192, 4, 2, 2, 9, 12, 3)])
+def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
+    """conv_deep_bf16.hip: the bf16-native kernels of the deep layers behind ``pgv_conv_desc.w_shadow`` (bf16 weight shadow
+    written by pgv_conv_weight_shadow), several sample groups with a partial last one: against float64 convolutions of the
+    rounded operands, and bit-for-bit deterministic.  Forward form (lazy normalisation, bias, activation, BatchNorm
+    statistics) and the input-gradient form (plain product) of both directions."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    assert ops.conv_weight_shadow(geom, dev(w)) is None            # fp32 mode: no shadow
+    ops.set_compute_dtype('bf16')
+    try:
+        sh = ops.conv_weight_shadow(geom, dev(w))
+        assert sh is not None and sh.numel() == 4 * w.numel()      # two bf16 layouts
+        big_n, small_n = _bf16(_affine_fma(big, sc_b, sh_b)), _bf16(_affine_fma(small, sc_s, sh_s))
+        ref = F.leaky_relu(F.conv2d(big_n, _bf16(w), bias_s.float().double(), stride=s, padding=p), 0.1)
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats, w_shadow=sh)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        old = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b))
+        assert rel_l2(got, old) < 2e-6                             # same products, another summation order
+        again = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                              in_shift=dev(sh_b), w_shadow=sh)
+        assert torch.equal(got, again)
+        got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        assert rel_l2(got, F.conv2d(_bf16(big), _bf16(w), None, stride=s, padding=p)) < 1e-5
+        oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+        ref = F.leaky_relu(F.conv_transpose2d(small_n, _bf16(w), bias_b.float().double(), stride=s, padding=p,
+                                              output_padding=(oph, opw)), 0.1)
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats, w_shadow=sh)
+        assert rel_l2(got, ref) < 1e-5
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        again = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                            in_shift=dev(sh_s), w_shadow=sh)
+        assert torch.equal(got, again)
+        got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        ref = F.conv_transpose2d(_bf16(small), _bf16(w), None, stride=s, padding=p, output_padding=(oph, opw))
+        assert rel_l2(got, ref) < 1e-5
+        # PGV_STATS_COPIES: the statistics may land in any of the partial copies
+        C8 = ops.CLS_COPIES
+        stc = torch.zeros(C8 * 2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, stats=stc, prezeroed=True,
+                            stats_copies=True, w_shadow=sh)
+        assert rel_l2(stc.view(C8, -1).sum(0), torch.cat([got.double().sum(dim=(0, 2, 3)),
+                                                          (got.double() ** 2).sum(dim=(0, 2, 3))])) < 2e-5
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 2), (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3),
                                   (3, 5, 4, 2, 2, 10, 13, 2)])
 def test_conv_prezeroed_outputs_accumulate(ops, case):
