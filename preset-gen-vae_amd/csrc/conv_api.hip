@@ -250,7 +250,8 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small_in, const float* in_s
 int64_t pgv_conv_wgrad_workspace(const pgv_conv_desc* d) {
   if (!d) return 0;
   const int64_t a = pgv_conv_wgrad_tuned_workspace(d), b = pgv_conv_wgrad_v2_workspace(d);
-  return a > b ? a : b;
+  const int64_t c = pgv_conv_wgrad_deep_bf16_workspace(d);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 int pgv_conv_wgrad(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
@@ -306,6 +307,9 @@ int pgv_conv_wgrad_ex(const pgv_conv_desc* d, const float* big, const float* big
                                    pgv_tap_replicas(req->lower_is_big ? d->Cs : d->Cb, d->kh * d->kw), req->scale,
                                    req->shift, req->mean, req->rstd, req->n, req->coef, req->ggamma, req->gbeta, st);
     }
+    if (rc == 0 && g_policy == 0 && d->B > 0)   // bf16 operand mode, deep layers: the bf16-native kernel
+      rc = pgv_conv_wgrad_deep_bf16(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace,
+                                    workspace_bytes, st);
     if (rc == 0 && g_policy == 0)
       rc = pgv_conv_wgrad_band(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, st);
     if (rc == 0 && g_policy == 0)

@@ -21,7 +21,7 @@ extern "C" void pgv_dbg_set_deep_bf16_stamps(void* p) { g_deep_bf16_stamps = (un
   do {                                                                                              \
     if (stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 77)) stamps[(blockIdx.x ? 16 : 0) + (k)] = clock64(); \
   } while (0)
-static int g_deep_bf16_dbg = 0;   // ablation knob of the timing scripts: 1 no matrix instructions, 2 no loads, 4 no commits
+static int g_deep_bf16_dbg = 0;   // A/B knob of the timing scripts: 8 = the weight gradient stays on the fp32-image kernels
 extern "C" int pgv_dbg_set_deep_bf16_variant(int v) {
   const int old = g_deep_bf16_dbg;
   g_deep_bf16_dbg = v;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int 
                                                              const u16* __restrict__ wsh, const float* __restrict__ bias,
                                                              int act, float slope, float* __restrict__ out,
                                                              double* __restrict__ stats, int groups, int stat_stride,
-                                                             pgv_bn_src in_bn, int dbg,
+                                                             pgv_bn_src in_bn,
                                                              unsigned long long* __restrict__ stamps) {
   constexpr int NT = G::NT, HW = G::HW, P = G::P, NS = G::NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -223,22 +223,18 @@ __global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int 
     for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(st + a_frag + mt * 16 * G::A_ROW);
 #pragma unroll
     for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const u32x4*>(st + boff[t]);
-    if (!(dbg & 1)) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
-    }
+      for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
     if (s + 1 < nslab) {   // the next slab goes to the other stage under the running matrix pipe
-      if (!(dbg & 4)) commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
-      if (s + 2 < nslab && !(dbg & 2)) issue(s + 2);
+      commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
+      if (s + 2 < nslab) issue(s + 2);
     }
-    if (!(dbg & 1)) {
 #pragma unroll
-      for (int mt = 2; mt < 4; ++mt)
+    for (int mt = 2; mt < 4; ++mt)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
-    }
+      for (int t = 0; t < NT; ++t) acc[mt][t] = mfma_bf16_k32(af[mt], bf[t], acc[mt][t]);
     __syncthreads();
   }
 
@@ -328,8 +324,7 @@ int launch_deep_down_bf16(const pgv_conv_desc* d, const float* big, const float*
   const int groups = (d->B + NS - 1) / NS;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cs / 64))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big, in_scale,
                      in_shift, (const u16*)d->w_shadow, bias, act, slope, out, stats, groups,
-                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0, bn ? *bn : pgv_no_bn(), g_deep_bf16_dbg,
-                     g_deep_bf16_stamps);
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0, bn ? *bn : pgv_no_bn(), g_deep_bf16_stamps);
   PGV_CHECK_LAUNCH("conv_down_deep_bf16");
   return 1;
 }
@@ -586,6 +581,286 @@ int launch_deep_up_bf16(const pgv_conv_desc* d, const float* small_in, const flo
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD: gw[cs,cb,kh,kw] = sum_{b,oh,ow} s'[b,cs,oh,ow] * x'[b,cb,2oh-2+kh,2ow-2+kw]
+// GEMM: M = cs (64 per workgroup), N = (cb, 16 taps): one 16-column tile per big channel, 8 big channels per workgroup,
+// K = (sample, output pixel).  The contraction index inside a fragment is the SAMPLE: both images sit in LDS
+// sample-innermost - pixel -> channel -> 16 samples of a block = two 16-byte halves - so the K = 32 of one instruction is
+// 16 samples x 2 consecutive output pixels (lane group kq = 2 * pixel + half), the A fragment the half-row
+// S[pixel][cs][half] and the B fragment of column (cb, tap) the half-row X[input pixel of (pixel, tap)][cb][half]: the
+// im2col gather is the fragment ADDRESS, every read 16 aligned bytes.  A unit of work = (block of 16 samples, band of R
+// output rows); a workgroup sweeps a range of units (double-buffered stages, register prefetch) with its 64 x 128
+// accumulator tile in registers and stores it once: to gw, or - when the units of a tile are split over several
+// workgroups (the layers with few tiles) - to a partial gradient that deep_wgrad_reduce_kernel adds up.
+template <int H_, int W_, int R_, int WP_>
+struct WgradB {
+  static constexpr int H = H_, W = W_, R = R_, WP = WP_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, BANDS = Hs / R;
+  static_assert(Hs % R == 0, "bands of whole output rows");
+  static constexpr int SPX = R * Ws, SPX2 = (SPX + 1) / 2 * 2, STEPS = SPX2 / 2;   // pixels of a band, padded to pairs
+  static constexpr int XR = 2 * R + 2;                       // input rows of a band
+  static constexpr int XROWS = XR + (SPX2 > SPX ? 2 : 0);    // + the rows the pad pixel's fragment addresses touch (zeros)
+  static_assert(WP >= 2 * Ws + 2 && (WP % 16 == 4 || WP % 16 == 12), "row stride: the 16 taps of a pixel on 16 distinct slots");
+  static constexpr int S_BYTES = SPX2 * 64 * 32;             // [pixel][64 cs][16 samples] bf16
+  static constexpr int X_BYTES = XROWS * WP * 256;           // [input pixel][8 cb][16 samples] bf16
+  static constexpr int STAGE = S_BYTES + X_BYTES;
+  static constexpr int QS = (SPX + 3) / 4, S_HALF = 64 * QS;       // items of one half of the block: (cs, quad)
+  static constexpr int QX = (W + 3) / 4, X_HALF = 8 * XR * QX;     // (cb, row, quad)
+  static_assert(SPX >= 4 && W >= 4, "shifted last quads");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void deep_wgrad_bf16_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                              const float* __restrict__ big_scale,
+                                                              const float* __restrict__ big_shift,
+                                                              const float* __restrict__ small_in,
+                                                              const float* __restrict__ small_scale,
+                                                              const float* __restrict__ small_shift,
+                                                              float* __restrict__ outp, int nsplit, int add,
+                                                              unsigned long long* __restrict__ stamps) {
+  constexpr int H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, WP = G::WP, STEPS = G::STEPS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mh = wave & 1, nq = wave >> 1;
+  // (cs block, split) share the small operand, the CB/8 workgroups of one such combination sit on one XCD
+  const int NB = CB / 8, ncombo = (CS / 64) * nsplit;
+  int combo, nb;
+  if (ncombo % 8 == 0) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    combo = x + 8 * (q / NB);
+    nb = q - (q / NB) * NB;
+  } else {
+    combo = blockIdx.x / NB;
+    nb = blockIdx.x - combo * NB;
+  }
+  const int mb = combo / nsplit, ks = combo - mb * nsplit;
+  const int cs0 = mb * 64, cb0 = nb * 8;
+  const int units = ((B + 15) >> 4) * G::BANDS, per = (units + nsplit - 1) / nsplit;
+  const int u0 = ks * per, u1 = min(units, u0 + per);
+  BSTAMP(0);
+
+  // ---- loader coordinates.  An item = the 8 samples of one HALF of the block x one channel x four pixels: 8 loads (one per
+  // sample; across the lanes of an instruction the addresses run over channels and quads of ONE sample - coalesced) and
+  // 4 ds_write_b128 (one per pixel: the 8 samples of a half are the 16 contiguous bytes a fragment reads).  The half is
+  // wave-uniform (threads 0-255 / 256-511), so the sample bases are scalars and a load is base + per-item offset.
+  static_assert(G::S_HALF <= 256 && G::X_HALF <= 256, "one item of each operand per thread");
+  const int hf = __builtin_amdgcn_readfirstlane(tid >> 8), it = tid & 255;
+  const bool s_ok = it < G::S_HALF, x_ok = it < G::X_HALF;
+  int s_off, s_dst, x_off, x_row, x_dst[4];
+  float s_sc, s_sh, x_sc, x_sh;
+  {
+    const int q = min(it, G::S_HALF - 1), cs = q / G::QS, qi = q - cs * G::QS, p0 = min(4 * qi, G::SPX - 4);
+    s_off = ((cs0 + cs) * (Hs * Ws) + p0) * 4;   // bytes; + sample * CS * P + band * SPX
+    s_sc = small_scale ? small_scale[cs0 + cs] : 1.f;
+    s_sh = small_scale ? small_shift[cs0 + cs] : 0.f;
+    s_dst = p0 * 2048 + cs * 32 + hf * 16;       // + 2048 per pixel
+  }
+  {
+    const int q = min(it, G::X_HALF - 1), cb = q / (G::XR * G::QX), rem = q - cb * (G::XR * G::QX);
+    const int r = rem / G::QX, qi = rem - r * G::QX, c0 = min(4 * qi, W - 4);
+    x_row = r;
+    x_off = ((cb0 + cb) * (H * W) + c0) * 4;     // bytes; + sample * CB * H * W + image row * W
+    x_sc = big_scale ? big_scale[cb0 + cb] : 1.f;
+    x_sh = big_scale ? big_shift[cb0 + cb] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int px = r * WP + c0 + e + 2;
+      x_dst[e] = G::S_BYTES + px * 256 + ((((cb * 2 + hf) ^ px) & 15) * 16);
+    }
+  }
+  const bool s_aff = small_scale != nullptr, x_aff = big_scale != nullptr;
+
+  // Loads run TWO units ahead of the matrix loop in two register sets (the units are short - 4 to 6 instructions of K per
+  // wave - against ~2 us of L2 latency under load): inline asm with manual s_waitcnt, because the compiler's counter model
+  // merges the in-flight sets at the loop header and would wait for both at every commit (conv_deep.hip does the same).
+  struct RegSet {
+    f4u rs[8], rx[8];
+    float x_m;        // 0: the X item's values are zeros this unit (row outside the image)
+    unsigned live;    // bit j: sample j of the half exists - all ones except in a partial last block
+  };
+  RegSet r0, r1;
+  auto issue = [&](int u, RegSet& r) {
+    const int sb = u / G::BANDS, band = u - sb * G::BANDS;
+    const int b = sb * 16 + 8 * hf;
+    r.live = (1u << min(max(B - b, 0), 8)) - 1u;
+    const int ih = 2 * band * G::R - 2 + x_row;
+    const bool in = (unsigned)ih < (unsigned)H;
+    r.x_m = in ? 1.f : 0.f;
+    const int so = s_off + band * (G::SPX * 4), xo = x_off + (in ? ih : 0) * (W * 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bj = min(b + j, B - 1);   // (uniform: scalar bases)
+      const unsigned char* ps = reinterpret_cast<const unsigned char*>(small_in) + (size_t)bj * CS * (Hs * Ws) * 4;
+      const unsigned char* px = reinterpret_cast<const unsigned char*>(big) + (size_t)bj * CB * (H * W) * 4;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.rs[j]) : "v"(so), "s"(ps) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.rx[j]) : "v"(xo), "s"(px) : "memory");
+    }
+  };
+  // `younger`: the other set has been requested after this one and may stay in flight
+  auto wait_set = [&](RegSet& r, bool younger) {
+    if (younger)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("" : "+v"(r.rs[j]));   // the values exist from here on
+      asm volatile("" : "+v"(r.rx[j]));
+    }
+  };
+  auto pack8 = [&](const f4u (&r)[8], int e, bool aff, float sc, float sh, float msk, unsigned live) -> u32x4 {
+    float v[8];
+    if (live != 0xFFu) {      // partial last block (uniform): per-sample masks
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float mj = ((live >> j) & 1u) ? msk : 0.f;
+        v[j] = fmaf(r[j][e], sc * mj, sh * mj);
+      }
+    } else if (aff) {         // (uniform)
+      const float a = sc * msk, c = sh * msk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(r[j][e], a, c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = r[j][e] * msk;
+    }
+    return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  };
+  auto commit = [&](unsigned char* st, const RegSet& r) {
+    if (s_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<u32x4*>(st + s_dst + e * 2048) = pack8(r.rs, e, s_aff, s_sc, s_sh, 1.f, r.live);
+    }
+    if (x_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(st + x_dst[e]) = pack8(r.rx, e, x_aff, x_sc, x_sh, r.x_m, r.live);
+    }
+  };
+  if (u0 < u1) issue(u0, r0);   // in flight while the stages are cleared
+  if (u0 + 1 < u1) issue(u0 + 1, r1);
+
+  for (int i = tid; i < 2 * G::STAGE / 16; i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
+
+  // ---- fragment coordinates (bytes into a stage, identical for every unit).  A: row cs = (2 mh + t) * 16 + m, half
+  // sg = kq & 1, pixel 2 step + (kq >> 1); rows 32 bytes apart, no swizzle: in a 16-lane group of ds_read_b128 rows m and
+  // m + 8 always come with opposite halves (lanes {0-3, 12-15} of one kq, lanes {4-11} of the next), so its 16 fragments
+  // fall on 16 distinct slots.  B: column tap n = m = (kh, kw) of big channel 2 nq + t at input pixel
+  // (2 ohl + kh) * WP + 2 ow + kw, its half of channel cb stored at slot (2 cb + sg) ^ (pixel & 15).
+  const int sg = kq & 1, pp = kq >> 1;
+  const int a_frag = pp * 2048 + ((2 * mh) * 16 + m) * 32 + sg * 16;   // second M tile: + 512; step: + 4096
+  int b_frag[STEPS][2];
+#pragma unroll
+  for (int sp = 0; sp < STEPS; ++sp) {
+    const int p = 2 * sp + pp;
+    const int px = (m >> 2) * WP + (m & 3) + 2 * (p / Ws) * WP + 2 * (p % Ws);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b_frag[sp][t] = G::S_BYTES + px * 256 + (((((2 * nq + t) * 2 + sg) ^ px) & 15) * 16);
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  BSTAMP(1);
+  __syncthreads();   // stages zeroed
+  BSTAMP(2);
+  if (u0 < u1) {
+    wait_set(r0, u0 + 1 < u1);
+    commit(ldsb, r0);
+  }
+  if (u0 + 2 < u1) issue(u0 + 2, r0);
+  __syncthreads();
+  BSTAMP(3);
+  // one unit: matrix loop over stage (u - u0) & 1; half way, unit u + 1 (in `rn`) goes to the other stage and unit u + 3
+  // is requested into the registers it frees
+  auto unit_step = [&](int u, RegSet& rn) {
+    const unsigned char* st = ldsb + ((u - u0) & 1) * G::STAGE;
+#pragma unroll
+    for (int sp = 0; sp < STEPS; ++sp) {
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096 + 512);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 b = *reinterpret_cast<const u32x4*>(st + b_frag[sp][t]);
+        acc[0][t] = mfma_bf16_k32(a0, b, acc[0][t]);
+        acc[1][t] = mfma_bf16_k32(a1, b, acc[1][t]);
+      }
+      if (sp == STEPS / 2 && u + 1 < u1) {
+        wait_set(rn, u + 2 < u1);
+        commit(ldsb + ((u + 1 - u0) & 1) * G::STAGE, rn);
+        if (u + 3 < u1) issue(u + 3, rn);
+      }
+    }
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int u = u0; u < u1; u += 2) {
+    unit_step(u, r1);
+    if (u + 1 < u1) unit_step(u + 1, r0);
+  }
+  BSTAMP(4);
+  // ---- store: D row 4 kq + i of M tile (2 mh + t), column tap m of big channel cb0 + 2 nq + t2
+  float* o = outp + (nsplit > 1 ? (size_t)ks * CS * CB * 16 : 0);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t idx = ((size_t)(cs0 + (2 * mh + t) * 16 + 4 * kq + i) * CB + cb0 + 2 * nq + t2) * 16 + m;
+        o[idx] = acc[t][t2][i] + ((add && nsplit == 1) ? o[idx] : 0.f);
+      }
+  BSTAMP(5);
+}
+
+// gw = (add ? gw : 0) + sum of the partial gradients (fixed order: deterministic)
+__global__ __launch_bounds__(256) void deep_wgrad_reduce_kernel(const f32x4* __restrict__ partial, int nparts, int n4,
+                                                                f32x4* __restrict__ gw, int add) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = add ? gw[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nparts; ++s) v += partial[(size_t)s * n4 + i];
+  gw[i] = v;
+}
+
+template <int H, int W, int R, int WP>
+int launch_deep_wgrad_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                           const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                           void* workspace, int64_t workspace_bytes, int nsplit, hipStream_t st) {
+  using G = WgradB<H, W, R, WP>;
+  if (d->Cs % 64 || d->Cb % 8 || d->B <= 0) return 0;
+  const int64_t gw_bytes = (int64_t)d->Cs * d->Cb * 64;
+  const int units = ((d->B + 15) / 16) * G::BANDS;
+  nsplit = max(1, min(nsplit, units));
+  if (nsplit > 1 && (!workspace || workspace_bytes < nsplit * gw_bytes || ((uintptr_t)workspace & 15) || ((uintptr_t)gw & 15)))
+    nsplit = 1;   // no room for partial gradients: one workgroup per tile
+  const size_t bytes = 2 * (size_t)G::STAGE;
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = deep_wgrad_bf16_kernel<G>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_wgrad_deep_bf16");
+  if (rc) return rc;
+  const int add = (d->flags & PGV_PREZEROED) ? 1 : 0;
+  const int grid = (d->Cs / 64) * (d->Cb / 8) * nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), bytes, st, d->B, d->Cb, d->Cs, big, big_scale, big_shift, small_in,
+                     small_scale, small_shift, nsplit > 1 ? (float*)workspace : gw, nsplit, add, g_deep_bf16_stamps);
+  PGV_CHECK_LAUNCH("conv_wgrad_deep_bf16");
+  if (nsplit > 1) {
+    const int n4 = (int)(gw_bytes / 16);
+    hipLaunchKernelGGL(deep_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       (const f32x4*)workspace, nsplit, n4, (f32x4*)gw, add);
+    PGV_CHECK_LAUNCH("conv_wgrad_deep_bf16 reduce");
+  }
+  return 1;
+}
+
+// tiles of 64 x 8 channels over 256 CUs: how many workgroups share the units of a tile
+int deep_wgrad_bf16_split(const pgv_conv_desc* d) {
+  const int tiles = (d->Cs / 64) * (d->Cb / 8);
+  return tiles >= 192 ? 1 : max(1, 256 / max(1, tiles));
+}
+
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -627,5 +902,25 @@ int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const f
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_bf16<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_bf16<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 5 && d->Wb == 7) return launch_deep_up_bf16<5, 7, 8>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  return 0;
+}
+
+int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || d->Cb % 8) return 0;
+  const int ns = deep_wgrad_bf16_split(d);
+  return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 64 : 0;
+}
+
+int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                             const float* small_in, const float* small_scale, const float* small_shift, float* gw,
+                             void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || (g_deep_bf16_dbg & 8)) return 0;
+  const int ns = deep_wgrad_bf16_split(d);
+  if (d->Hb == 17 && d->Wb == 23)
+    return launch_deep_wgrad_bf16<17, 23, 1, 28>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
+  if (d->Hb == 9 && d->Wb == 12)
+    return launch_deep_wgrad_bf16<9, 12, 1, 20>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
+  if (d->Hb == 5 && d->Wb == 7)
+    return launch_deep_wgrad_bf16<5, 7, 3, 12>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
   return 0;
 }

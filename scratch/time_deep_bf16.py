@@ -67,3 +67,30 @@ for which, (Cb, Cs, Hb, Wb) in {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9
             serr = ((st - torch.cat([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])).norm() / ref.pow(2).sum().sqrt()).item()
             t = timeit(lambda: ops.conv_up(g, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=ssc, in_shift=ssh, **kw))
             print(f'up   {which} {name}: {t:7.1f} us  err {err:.2e} stats {serr:.2e}', flush=True)
+    if 'wgrad' in WHAT:
+        for form in ('big', 'small'):
+            kw = dict(big_scale=sc, big_shift=sh) if form == 'big' else dict(small_scale=ssc, small_shift=ssh)
+            bb = torch.addcmul(sh.view(1, -1, 1, 1), big[:nb], sc.view(1, -1, 1, 1)) if form == 'big' else big[:nb]
+            ss = torch.addcmul(ssh.view(1, -1, 1, 1), small[:nb], ssc.view(1, -1, 1, 1)) if form == 'small' else small[:nb]
+            wv = w.double().clone().requires_grad_(True)
+            F.conv2d(bf(bb), wv, None, stride=2, padding=2).backward(bf(ss))
+            for name, v in (('old', 8), ('new', 0)):
+                lib.pgv_dbg_set_deep_bf16_variant(v)
+                gs = torch.empty_like(w)
+                ops.conv_wgrad(g, big[:nb].contiguous(), small[:nb].contiguous(), gs, **kw)
+                err = ((gs.double() - wv.grad).norm() / wv.grad.norm()).item()
+                gw = torch.empty_like(w)
+                t = timeit(lambda: ops.conv_wgrad(g, big, small, gw, **kw))
+                if name == 'new' and os.environ.get('STAMPS') and form == 'big':
+                    import ctypes
+                    stb = torch.zeros(32, device='cuda', dtype=torch.int64)
+                    lib.pgv_dbg_set_deep_bf16_stamps.argtypes = [ctypes.c_void_p]
+                    lib.pgv_dbg_set_deep_bf16_stamps(ctypes.c_void_p(stb.data_ptr()))
+                    ops.conv_wgrad(g, big, small, gw, **kw)
+                    torch.cuda.synchronize()
+                    lib.pgv_dbg_set_deep_bf16_stamps(None)
+                    vv = stb.cpu().tolist()
+                    for o in (0, 16):
+                        print('   stamps', [vv[o + i] - vv[o] for i in range(6)])
+                print(f'wgrad {which} {form:5s} {name}: {t:7.1f} us  err {err:.2e}', flush=True)
+            lib.pgv_dbg_set_deep_bf16_variant(0)
