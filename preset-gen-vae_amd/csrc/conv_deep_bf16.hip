@@ -861,6 +861,206 @@ int deep_wgrad_bf16_split(const pgv_conv_desc* d) {
   return tiles >= 192 ? 1 : max(1, 256 / max(1, tiles));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 layers on 3x4 planes (enc8 / dec1: 512 <-> 2048 channels, model/encoder.py:256-258, model/decoder.py:199-201):
+// out[b,m,p] = act(bias[m] + sum_k Wt[m][k] * in'[b,k,p]) - both directions are this one product (forward: m = cs, k = cb,
+// Wt = the weight; transposed: m = cb, k = cs, Wt = its transpose), the shadow holds both as [m][k] bf16.  One workgroup =
+// 128 output channels (16 per wave) x 4 samples (48 pixels = 3 tiles): every wave runs the whole K, no reduction.  Images
+// are channel-innermost, 64 channels = 128 bytes per pixel, the 16-byte group g of a pixel stored at g ^ (pixel & 7).
+__global__ __launch_bounds__(256) void k1_shadow_kernel(const float* __restrict__ w, int CS, int CB, u16* __restrict__ down,
+                                                        u16* __restrict__ up) {
+  const int n8 = CS * CB / 8;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < n8; it += gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8), b = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8 + 4);
+    *reinterpret_cast<u32x4*>(down + (size_t)it * 8) =
+        u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    // transposed: up[cb][8 consecutive cs]; cb fastest across the lanes (coalesced reads of 8 weight rows)
+    const int cb = it % CB, g = it / CB;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = w[(size_t)(g * 8 + c) * CB + cb];
+    *reinterpret_cast<u32x4*>(up + (size_t)cb * CS + g * 8) =
+        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  }
+}
+
+struct K1B {
+  static constexpr int P = 12, NS = 4, NPX = NS * P, NT = NPX / 16, MT = 128, CK = 64;
+  static constexpr int A_ROW = 128 + 32, A_BYTES = MT * A_ROW, B_BYTES = NPX * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int OUT_BYTES = NS * MT * P * 4;
+  static_assert(NPX % 16 == 0 && OUT_BYTES <= 2 * STAGE && STAGE % 16 == 0, "tile shapes");
+};
+
+__global__ __launch_bounds__(512) void k1_fwd_bf16_kernel(int B, int M, int K, const float* __restrict__ in,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, const u16* __restrict__ wsh,
+                                                          const float* __restrict__ bias, int act, float slope,
+                                                          float* __restrict__ out, double* __restrict__ stats, int groups,
+                                                          int stat_stride) {
+  using G = K1B;
+  constexpr int P = G::P, NS = G::NS, NT = G::NT, MT = G::MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*K]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int mb, grp;
+  deep_block(M / MT, groups, mb, grp);
+  const int m0 = mb * MT, b0 = grp * NS;
+
+  for (int i = tid; i < K; i += 512) {
+    aff[i] = in_scale ? in_scale[i] : 1.f;
+    aff[K + i] = in_scale ? in_shift[i] : 0.f;
+  }
+  // ---- loader coordinates: weights 2 x 16 bytes per thread and slab; image: (sample, channel pair, pixel quad)
+  int a_src[2], a_dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 512 * i, row = q >> 3, f = q & 7;
+    a_src[i] = ((m0 + row) * K) * 2 + f * 16;   // bytes into the shadow (+ 128 per slab)
+    a_dst[i] = row * G::A_ROW + f * 16;
+  }
+  const bool b_ok = tid < NS * 32 * 3;
+  const int q = min(tid, NS * 32 * 3 - 1), si = q / 96, rem = q - si * 96, cp = rem / 3, qi = rem - cp * 3;
+  const int bs = min(b0 + si, B - 1);
+  const int b_src = (bs * K + 2 * cp) * P + 4 * qi;
+  int b_dst[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int px = si * P + 4 * qi + e;
+    b_dst[e] = G::A_BYTES + px * 128 + (((cp >> 2) ^ (px & 7)) * 16) + (cp & 3) * 4;
+  }
+  // ---- fragment coordinates
+  const int a_frag = (wave * 16 + m) * G::A_ROW + kq * 16;   // + 64 for the second step of a slab
+  int b_frag[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int px = t * 16 + m;
+      b_frag[t][st] = G::A_BYTES + px * 128 + (((st * 4 + kq) ^ (px & 7)) * 16);
+    }
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[m0 + wave * 16 + 4 * kq + i] : 0.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[2];
+  f4u rb[2];
+  auto issue = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + a_src[i] + slab * 128);
+    const float* p = in + b_src + slab * (64 * P);
+    rb[0] = *reinterpret_cast<const f4u*>(p);
+    rb[1] = *reinterpret_cast<const f4u*>(p + P);
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(st + a_dst[i]) = ra[i];
+    const int c = slab * 64 + 2 * cp;
+    const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[K + c], h1 = aff[K + c + 1];
+    if (b_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<unsigned*>(st + b_dst[e]) = pack_bf16x2(fmaf(rb[0][e], s0, h0), fmaf(rb[1][e], s1, h1));
+    }
+  };
+  const int nslab = K / 64;
+  issue(0);
+  __syncthreads();   // affine staged
+  commit(ldsb, 0);
+  if (nslab > 1) issue(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned char* st = ldsb + (s & 1) * G::STAGE;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(st + a_frag + k2 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16_k32(a, *reinterpret_cast<const u32x4*>(st + b_frag[t][k2]), acc[t]);
+      if (k2 == 0 && s + 1 < nslab) {
+        commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
+        if (s + 2 < nslab) issue(s + 2);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: bias, activation, into the [sample][channel][P] output tile
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float* otile = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 16 + m, s2 = n / P, pix = n - s2 * P;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) otile[(s2 * MT + wave * 16 + 4 * kq + i) * P + pix] = pgv_act_apply(acc[t][i] + bv[i], ap);
+  }
+  __syncthreads();
+  if (stats) {   // 4 lanes per channel over the tile, one pair of atomics per channel
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;
+    const int ch = tid >> 2, part = tid & 3;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s3 = 0; s3 < NS; ++s3) {
+      if (b0 + s3 < B) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float v = otile[(s3 * MT + ch) * P + part * 3 + i];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 1);
+    s2 += __shfl_xor(s2, 1);
+    s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 2);
+    if (part == 0) {
+      atomicAdd(&stats[m0 + ch], (double)s1);
+      atomicAdd(&stats[M + m0 + ch], (double)s2);
+    }
+  }
+#pragma unroll
+  for (int s3 = 0; s3 < NS; ++s3) {
+    if (b0 + s3 < B) {
+      float* dst = out + ((int64_t)(b0 + s3) * M + m0) * P;
+      const float* src = otile + s3 * MT * P;
+      for (int i = tid; i < MT * P; i += 512) dst[i] = src[i];
+    }
+  }
+}
+
+bool k1_bf16_shape(const pgv_conv_desc* d) {
+  return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->Hb == 3 && d->Wb == 4 && d->Cb % 128 == 0 &&
+         d->Cs % 128 == 0;
+}
+
+// up = false: out = small (m = cs, k = cb); up = true: out = big (m = cb, k = cs)
+int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const float* in_scale, const float* in_shift,
+                       const float* bias, int act, float slope, float* out, double* stats, hipStream_t st) {
+  using G = K1B;
+  const int M = up ? d->Cb : d->Cs, K = up ? d->Cs : d->Cb;
+  if ((int64_t)d->B * K * G::P * 4 >= (int64_t)1 << 31 || (int64_t)M * K * 2 >= (int64_t)1 << 31) return 0;
+  const size_t bytes = 2 * (size_t)G::STAGE + sizeof(float) * (2 * (size_t)K + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(k1_fwd_bf16_kernel, &attr_done, "conv_k1_bf16");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * M, st) != hipSuccess) {
+    pgv_set_error("conv_k1_bf16: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + G::NS - 1) / G::NS;
+  const u16* wsh = (const u16*)d->w_shadow + (up ? (size_t)d->Cs * d->Cb : 0);
+  hipLaunchKernelGGL(k1_fwd_bf16_kernel, dim3((unsigned)(groups * (M / G::MT))), dim3(512), bytes, st, d->B, M, K, in, in_scale,
+                     in_shift, wsh, bias, act, slope, out, stats, groups, (d->flags & PGV_STATS_COPIES) ? 2 * M : 0);
+  PGV_CHECK_LAUNCH("conv_k1_bf16");
+  return 1;
+}
+
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -870,10 +1070,18 @@ bool deep_bf16_shape(const pgv_conv_desc* d) {
 
 // bytes of the bf16 weight shadow of a layer (down + up layouts), 0: the layer has no bf16-native kernels
 int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
+  if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
   return deep_bf16_shape(d) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
 }
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
+  if (k1_bf16_shape(d)) {
+    u16* down = (u16*)shadow;
+    hipLaunchKernelGGL(k1_shadow_kernel, dim3((unsigned)min((d->Cs * d->Cb / 8 + 255) / 256, 2048)), dim3(256), 0, st, w, d->Cs,
+                       d->Cb, down, down + (size_t)d->Cs * d->Cb);
+    PGV_CHECK_LAUNCH("conv_weight_shadow");
+    return 1;
+  }
   if (!deep_bf16_shape(d)) return 0;
   u16* down = (u16*)shadow;
   u16* up = down + (size_t)d->Cs * d->Cb * 16;
@@ -888,6 +1096,8 @@ int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* sh
 int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                             const pgv_bn_src* bn) {
+  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && !bn && k1_bf16_shape(d))
+    return launch_k1_fwd_bf16(d, false, big, in_scale, in_shift, bias, act, slope, out, stats, st);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
@@ -898,6 +1108,8 @@ int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const floa
 int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                           const pgv_bn_src* bn) {
+  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && !bn && k1_bf16_shape(d))
+    return launch_k1_fwd_bf16(d, true, small_in, in_scale, in_shift, bias, act, slope, out, stats, st);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_bf16<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_bf16<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);

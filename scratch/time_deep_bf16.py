@@ -18,10 +18,13 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1000
-for which, (Cb, Cs, Hb, Wb) in {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9, 12), '5x7': (256, 512, 5, 7)}.items():
-    g = ops.ConvGeom(Cb, Cs, 4, 2, 2, Hb, Wb)
+CASES = {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9, 12), '5x7': (256, 512, 5, 7), 'k1': (512, 2048, 3, 4)}
+for which, (Cb, Cs, Hb, Wb) in CASES.items():
+    if os.environ.get('ONLY') and which not in os.environ['ONLY'].split(','): continue
+    KK, ST, PD = (1, 1, 0) if which == 'k1' else (4, 2, 2)
+    g = ops.ConvGeom(Cb, Cs, KK, ST, PD, Hb, Wb)
     torch.manual_seed(1)
-    big = torch.randn(B, Cb, Hb, Wb, device='cuda'); w = torch.randn(Cs, Cb, 4, 4, device='cuda') * 0.05
+    big = torch.randn(B, Cb, Hb, Wb, device='cuda'); w = torch.randn(Cs, Cb, KK, KK, device='cuda') * 0.05
     small = torch.randn(B, Cs, g.Hs, g.Ws, device='cuda')
     bias_s = torch.randn(Cs, device='cuda') * 0.1; bias_b = torch.randn(Cb, device='cuda') * 0.1
     sc = torch.rand(Cb, device='cuda') + 0.5; sh = torch.randn(Cb, device='cuda') * 0.1
@@ -31,7 +34,7 @@ for which, (Cb, Cs, Hb, Wb) in {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9
     nb = min(B, 19)
     if 'down' in WHAT:
         xin = torch.addcmul(sh.view(1, -1, 1, 1), big[:nb], sc.view(1, -1, 1, 1))
-        ref = F.leaky_relu(F.conv2d(bf(xin), bf(w), bias_s.double(), stride=2, padding=2), 0.1)
+        ref = F.leaky_relu(F.conv2d(bf(xin), bf(w), bias_s.double(), stride=ST, padding=PD), 0.1)
         for name, kw in (('old', {}), ('new', dict(w_shadow=shadow))):
             st = torch.zeros(2 * Cs, device='cuda', dtype=torch.float64)
             got = ops.conv_down(g, big[:nb].contiguous(), w, bias_s, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=sc, in_shift=sh, stats=st, **kw)
@@ -58,8 +61,8 @@ for which, (Cb, Cs, Hb, Wb) in {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9
             print(f'down {which} {name}: {t:7.1f} us  err {err:.2e} stats {serr:.2e}   (shadow {t_sh:.1f} us)', flush=True)
     if 'up' in WHAT:
         sin = torch.addcmul(ssh.view(1, -1, 1, 1), small[:nb], ssc.view(1, -1, 1, 1))
-        oph, opw = Hb - ((g.Hs - 1) * 2 - 4 + 4), Wb - ((g.Ws - 1) * 2 - 4 + 4)
-        ref = F.leaky_relu(F.conv_transpose2d(bf(sin), bf(w), bias_b.double(), stride=2, padding=2, output_padding=(oph, opw)), 0.1)
+        oph, opw = Hb - ((g.Hs - 1) * ST - 2 * PD + KK), Wb - ((g.Ws - 1) * ST - 2 * PD + KK)
+        ref = F.leaky_relu(F.conv_transpose2d(bf(sin), bf(w), bias_b.double(), stride=ST, padding=PD, output_padding=(oph, opw)), 0.1)
         for name, kw in (('old', {}), ('new', dict(w_shadow=shadow))):
             st = torch.zeros(2 * Cb, device='cuda', dtype=torch.float64)
             got = ops.conv_up(g, small[:nb].contiguous(), w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=ssc, in_shift=ssh, stats=st, **kw)
@@ -73,7 +76,7 @@ for which, (Cb, Cs, Hb, Wb) in {'17x23': (64, 128, 17, 23), '9x12': (128, 256, 9
             bb = torch.addcmul(sh.view(1, -1, 1, 1), big[:nb], sc.view(1, -1, 1, 1)) if form == 'big' else big[:nb]
             ss = torch.addcmul(ssh.view(1, -1, 1, 1), small[:nb], ssc.view(1, -1, 1, 1)) if form == 'small' else small[:nb]
             wv = w.double().clone().requires_grad_(True)
-            F.conv2d(bf(bb), wv, None, stride=2, padding=2).backward(bf(ss))
+            F.conv2d(bf(bb), wv, None, stride=ST, padding=PD).backward(bf(ss))
             for name, v in (('old', 8), ('new', 0)):
                 lib.pgv_dbg_set_deep_bf16_variant(v)
                 gs = torch.empty_like(w)
