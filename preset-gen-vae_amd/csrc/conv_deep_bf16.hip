@@ -824,6 +824,123 @@ __global__ __launch_bounds__(256) void deep_wgrad_reduce_kernel(const f32x4* __r
   gw[i] = v;
 }
 
+// 1x1 layers on 3x4 planes: gw[cs][cb] = sum_{b,p} s'[b,cs,p] * x'[b,cb,p].  M = cs, N = cb, 128 x 128 per workgroup, the
+// contraction index inside a fragment is the sample again: images [pixel][channel][8 samples] (16 bytes), the K = 32 of one
+// instruction = 8 samples x 4 pixels (lane group kq = pixel); a unit = a block of 8 samples.
+struct K1W {
+  static constexpr int P = 12, T = 128, IMG = P * T * 16, STAGE = 2 * IMG, ITEMS = T * 3;   // items: (channel, pixel quad)
+};
+
+__global__ __launch_bounds__(512) void k1_wgrad_bf16_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                            const float* __restrict__ big_scale,
+                                                            const float* __restrict__ big_shift,
+                                                            const float* __restrict__ small_in,
+                                                            const float* __restrict__ small_scale,
+                                                            const float* __restrict__ small_shift,
+                                                            float* __restrict__ outp, int nsplit, int add) {
+  using G = K1W;
+  constexpr int P = G::P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mh = wave & 1, nq = wave >> 1;
+  const int NBc = CB / G::T, tiles = (CS / G::T) * NBc;
+  const int tile = blockIdx.x % tiles, ks = blockIdx.x / tiles;
+  const int cs0 = (tile / NBc) * G::T, cb0 = (tile % NBc) * G::T;
+  const int units = (B + 7) >> 3, per = (units + nsplit - 1) / nsplit;
+  const int u0 = ks * per, u1 = min(units, u0 + per);
+
+  const bool ok = tid < G::ITEMS;
+  const int q = min(tid, G::ITEMS - 1), ch = q / 3, qi = q - ch * 3;
+  const int s_off = ((cs0 + ch) * P + 4 * qi) * 4, x_off = ((cb0 + ch) * P + 4 * qi) * 4;   // bytes; + sample * C * P
+  const int dst = (4 * qi) * (G::T * 16) + ch * 16;                                        // + T * 16 per pixel
+  const float s_sc = small_scale ? small_scale[cs0 + ch] : 1.f, s_sh = small_scale ? small_shift[cs0 + ch] : 0.f;
+  const float x_sc = big_scale ? big_scale[cb0 + ch] : 1.f, x_sh = big_scale ? big_shift[cb0 + ch] : 0.f;
+  const bool s_aff = small_scale != nullptr, x_aff = big_scale != nullptr;
+
+  f4u rs[8], rx[8];
+  unsigned live;
+  auto issue = [&](int u) {
+    const int b = u * 8;
+    live = (1u << min(max(B - b, 0), 8)) - 1u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bj = min(b + j, B - 1);
+      rs[j] = *reinterpret_cast<const f4u*>(reinterpret_cast<const unsigned char*>(small_in) + (size_t)bj * CS * P * 4 + s_off);
+      rx[j] = *reinterpret_cast<const f4u*>(reinterpret_cast<const unsigned char*>(big) + (size_t)bj * CB * P * 4 + x_off);
+    }
+  };
+  auto pack8 = [&](const f4u (&r)[8], int e, bool aff, float sc, float sh) -> u32x4 {
+    float v[8];
+    if (live != 0xFFu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float mj = ((live >> j) & 1u) ? 1.f : 0.f;
+        v[j] = fmaf(r[j][e], sc * mj, sh * mj);
+      }
+    } else if (aff) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(r[j][e], sc, sh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = r[j][e];
+    }
+    return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  };
+  auto commit = [&](unsigned char* st) {
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<u32x4*>(st + dst + e * (G::T * 16)) = pack8(rs, e, s_aff, s_sc, s_sh);
+        *reinterpret_cast<u32x4*>(st + G::IMG + dst + e * (G::T * 16)) = pack8(rx, e, x_aff, x_sc, x_sh);
+      }
+    }
+  };
+  // fragments: A rows cs = (4 mh + t) * 16 + m, B columns cb = (2 nq + t) * 16 + m; pixel 4 step + kq
+  const int a_frag = kq * (G::T * 16) + (4 * mh * 16 + m) * 16;             // + 256 per M tile, + 4 pixels per step
+  const int b_frag = G::IMG + kq * (G::T * 16) + (2 * nq * 16 + m) * 16;   // + 256 per N tile
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (u0 < u1) {
+    issue(u0);
+    commit(ldsb);
+  }
+  if (u0 + 1 < u1) issue(u0 + 1);
+  __syncthreads();
+#pragma unroll 1
+  for (int u = u0; u < u1; ++u) {
+    const unsigned char* st = ldsb + ((u - u0) & 1) * G::STAGE;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      u32x4 a[4], b[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4 * (G::T * 16) + t * 256);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const u32x4*>(st + b_frag + sp * 4 * (G::T * 16) + t * 256);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) acc[t][t2] = mfma_bf16_k32(a[t], b[t2], acc[t][t2]);
+      if (sp == 1 && u + 1 < u1) {
+        commit(ldsb + ((u + 1 - u0) & 1) * G::STAGE);
+        if (u + 2 < u1) issue(u + 2);
+      }
+    }
+    __syncthreads();
+  }
+  float* o = outp + (nsplit > 1 ? (size_t)ks * CS * CB : 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t idx = (size_t)(cs0 + (4 * mh + t) * 16 + 4 * kq + i) * CB + cb0 + (2 * nq + t2) * 16 + m;
+        o[idx] = acc[t][t2][i] + ((add && nsplit == 1) ? o[idx] : 0.f);
+      }
+}
+
 template <int H, int W, int R, int WP>
 int launch_deep_wgrad_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                            const float* small_in, const float* small_scale, const float* small_shift, float* gw,
@@ -1117,7 +1234,16 @@ int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const f
   return 0;
 }
 
+static int k1_wgrad_split(const pgv_conv_desc* d) {
+  const int tiles = (d->Cs / 128) * (d->Cb / 128);
+  return tiles >= 192 ? 1 : max(1, min(8, 256 / max(1, tiles)));
+}
+
 int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d) {
+  if ((d->flags & PGV_COMPUTE_BF16) && k1_bf16_shape(d)) {
+    const int ns = k1_wgrad_split(d);
+    return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 4 : 0;
+  }
   if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || d->Cb % 8) return 0;
   const int ns = deep_wgrad_bf16_split(d);
   return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 64 : 0;
@@ -1126,6 +1252,27 @@ int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d) {
 int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                              const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                              void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if ((d->flags & PGV_COMPUTE_BF16) && k1_bf16_shape(d) && !(g_deep_bf16_dbg & 8) && d->B > 0) {
+    const int64_t gw_bytes = (int64_t)d->Cs * d->Cb * 4;
+    int nsplit = min(k1_wgrad_split(d), (d->B + 7) / 8);
+    if (nsplit > 1 && (!workspace || workspace_bytes < nsplit * gw_bytes || ((uintptr_t)workspace & 15) || ((uintptr_t)gw & 15)))
+      nsplit = 1;
+    static bool attr_done = false;
+    int rc = raise_lds_limit(k1_wgrad_bf16_kernel, &attr_done, "conv_wgrad_k1_bf16");
+    if (rc) return rc;
+    const int add = (d->flags & PGV_PREZEROED) ? 1 : 0;
+    const int grid = (d->Cs / 128) * (d->Cb / 128) * nsplit;
+    hipLaunchKernelGGL(k1_wgrad_bf16_kernel, dim3((unsigned)grid), dim3(512), 2 * (size_t)K1W::STAGE, st, d->B, d->Cb, d->Cs, big,
+                       big_scale, big_shift, small_in, small_scale, small_shift, nsplit > 1 ? (float*)workspace : gw, nsplit, add);
+    PGV_CHECK_LAUNCH("conv_wgrad_k1_bf16");
+    if (nsplit > 1) {
+      const int n4 = (int)(gw_bytes / 16);
+      hipLaunchKernelGGL(deep_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                         (const f32x4*)workspace, nsplit, n4, (f32x4*)gw, add);
+      PGV_CHECK_LAUNCH("conv_wgrad_k1_bf16 reduce");
+    }
+    return 1;
+  }
   if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || (g_deep_bf16_dbg & 8)) return 0;
   const int ns = deep_wgrad_bf16_split(d);
   if (d->Hb == 17 && d->Wb == 23)
