@@ -89,8 +89,8 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scal
                 const float* w, const float* bias, int act, float slope, float* big, double* stats,
                 void* stream);
 
-/* bf16 weight shadow (PGV_COMPUTE_BF16; nn.Conv2d / nn.ConvTranspose2d weights of the deep layers, model/encoder.py:249-255,
- * model/decoder.py:205-210): the weight tensor rounded to bfloat16 and laid out channel-innermost, once for the forward
+/* bf16 weight shadow (PGV_COMPUTE_BF16; nn.Conv2d / nn.ConvTranspose2d weights of the deep layers, model/encoder.py:64-69,249-255,
+ * model/decoder.py:72-75,205-210): the weight tensor rounded to bfloat16 and laid out channel-innermost, once for the forward
  * and once for the transposed direction, so that the kernels stream half the bytes and copy weight slabs to LDS as they
  * are.  pgv_conv_weight_shadow_bytes: bytes of the shadow of this layer, 0 when the layer has no bf16-native kernels
  * (every call then behaves as without a shadow).  pgv_conv_weight_shadow writes it (16-byte aligned, caller-owned; one

@@ -980,7 +980,7 @@ int deep_wgrad_bf16_split(const pgv_conv_desc* d) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// 1x1 layers on 3x4 planes (enc8 / dec1: 512 <-> 2048 channels, model/encoder.py:256-258, model/decoder.py:199-201):
+// 1x1 layers on 3x4 planes (enc8 / dec1: 512 <-> 2048 channels, model/encoder.py:64-69, model/decoder.py:72-75):
 // out[b,m,p] = act(bias[m] + sum_k Wt[m][k] * in'[b,k,p]) - both directions are this one product (forward: m = cs, k = cb,
 // Wt = the weight; transposed: m = cb, k = cs, Wt = its transpose), the shadow holds both as [m][k] bf16.  One workgroup =
 // 128 output channels (16 per wave) x 4 samples (48 pixels = 3 tiles): every wave runs the whole K, no reduction.  Images
