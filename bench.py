@@ -300,23 +300,24 @@ def launch_table(ae, B, device, frontend=None):
 
         def mk(kind, geom=geom, big=big, small=small, w=w, gw=gw, sc_b=sc_b, sh_b=sh_b, sc_s=sc_s, sh_s=sh_s,
                bias_b=bias_b, bias_s=bias_s, out_s=out_s, out_b=out_b, fs=fwd_stats_s, fb=fwd_stats_b, is_up=is_up,
-               fuse=fuse, in_bn=in_bn, coef_req=coef_req, sck=nsc > 1, bias_fin=bias_fin):
+               fuse=fuse, in_bn=in_bn, coef_req=coef_req, sck=nsc > 1, bias_fin=bias_fin,
+               w_sh=ops.conv_weight_shadow(geom, w)):   # (bf16 operand mode, deep layers: as ConvStackFn passes it)
             if kind == 'conv_down':
                 if is_up:
-                    return lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse)
+                    return lambda: ops.conv_down(geom, big, w, None, 0, 0.0, out=out_s, bwd_fuse=fuse, w_shadow=w_sh)
                 if in_bn is not None:
                     return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, in_bn=in_bn,
-                                                 prezeroed=fs is not None, stats_copies=sck and fs is not None)
+                                                 prezeroed=fs is not None, stats_copies=sck and fs is not None, w_shadow=w_sh)
                 return lambda: ops.conv_down(geom, big, w, bias_s, 1, 0.1, stats=fs, out=out_s, prezeroed=fs is not None,
-                                             stats_copies=sck and fs is not None)
+                                             stats_copies=sck and fs is not None, w_shadow=w_sh)
             if kind == 'conv_up':
                 if not is_up:
-                    return lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse)
+                    return lambda: ops.conv_up(geom, small, w, None, 0, 0.0, out=out_b, bwd_fuse=fuse, w_shadow=w_sh)
                 if in_bn is not None:
                     return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, in_bn=in_bn,
-                                               prezeroed=fb is not None, stats_copies=sck and fb is not None)
+                                               prezeroed=fb is not None, stats_copies=sck and fb is not None, w_shadow=w_sh)
                 return lambda: ops.conv_up(geom, small, w, bias_b, 1, 0.1, stats=fb, out=out_b, prezeroed=fb is not None,
-                                           stats_copies=sck and fb is not None)
+                                           stats_copies=sck and fb is not None, w_shadow=w_sh)
             return (lambda: ops.conv_wgrad(geom, big, small, gw, big_scale=sc_b, big_shift=sh_b, coef_req=coef_req,
                                            bias_finish=bias_fin)) \
                 if not is_up else \

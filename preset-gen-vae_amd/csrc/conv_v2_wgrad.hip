@@ -468,7 +468,9 @@ struct Wgrad5Cfg {
   static_assert(R == 4 && CS == 8 && SPR % 2 == 0 && WP >= W + 2 && 2 * WsP <= WP, "tiling");
 };
 
-template <int CS, int W, int H, int R, bool AFF_S>
+// BF16: PGV_COMPUTE_BF16 - both operands rounded to bfloat16 where the loader commits them (products of rounded operands
+// are exact on the fp32 matrix pipe; this 1-channel layer has little matrix work)
+template <int CS, int W, int H, int R, bool AFF_S, bool BF16 = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const float* __restrict__ big,
                                                               const float* __restrict__ small_in,
                                                               const float* __restrict__ small_scale,
@@ -545,14 +547,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
       band_of(it, b, band);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NPS) : "memory");  // the older item has landed
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NPB>([&](auto j) { StageB::template commit_slot<decltype(j)::value, false, false>(geoB, bx, dst, ltid, 0u); });
+      static_for<0, NPB>([&](auto j) { StageB::template commit_slot<decltype(j)::value, false, false, BF16>(geoB, bx, dst, ltid, 0u); });
       if (AFF_S && band == BANDS - 1) {
         static_for<0, NPS>([&](auto j) {
-          StageS::template commit_slot<decltype(j)::value, true, AFF_S>(geoS, sx, dst + PLANE_B, ltid, geoS.bot_bad);
+          StageS::template commit_slot<decltype(j)::value, true, AFF_S, BF16>(geoS, sx, dst + PLANE_B, ltid, geoS.bot_bad);
         });
       } else {
         static_for<0, NPS>([&](auto j) {
-          StageS::template commit_slot<decltype(j)::value, false, AFF_S>(geoS, sx, dst + PLANE_B, ltid, 0u);
+          StageS::template commit_slot<decltype(j)::value, false, AFF_S, BF16>(geoS, sx, dst + PLANE_B, ltid, 0u);
         });
       }
     };
@@ -669,8 +671,11 @@ int launch_wgrad5_v2(const pgv_conv_desc* d, const float* big, const float* smal
   const int64_t need = (int64_t)nparts * 8 * G::NTAP * sizeof(float);
   if (!workspace || workspace_bytes < need || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, float*);
-  kern_t kern = small_scale ? (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, true>
-                            : (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, false>;
+  const bool bf16 = (d->flags & PGV_COMPUTE_BF16) != 0;
+  kern_t kern = small_scale ? (bf16 ? (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, true, true>
+                                    : (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, true>)
+                            : (bf16 ? (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, false, true>
+                                    : (kern_t)conv_wgrad5_ws_kernel<8, 347, 257, R, false>);
   if (int rc = raise_lds_once((const void*)kern, "conv_wgrad5_v2")) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), bytes, st, d->B, big, small_in, small_scale, small_shift, (float*)workspace);
   PGV_CHECK_LAUNCH("conv_wgrad5_v2");
@@ -723,7 +728,7 @@ int launch_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big_s
 
 // workspace: one partial gradient per workgroup
 int64_t pgv_conv_wgrad_v2_workspace(const pgv_conv_desc* d) {
-  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->Cb == 1 &&
+  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && d->Cb == 1 &&
       d->Cs == 8 && d->Hb == 257 && d->Wb == 347)
     return (int64_t)4 * 256 * 8 * 25 * sizeof(float);  // one partial gradient per MFMA wave
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
@@ -755,7 +760,7 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
                       const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                       void* workspace, int64_t workspace_bytes, const pgv_coef_req* req, const pgv_bias_req* bias,
                       hipStream_t st) {
-  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && !(d->flags & PGV_COMPUTE_BF16) && d->B > 0 &&
+  if (d->stride == 2 && d->pad == 2 && d->kh == 5 && d->kw == 5 && d->B > 0 &&
       d->Cb == 1 && d->Cs == 8 && d->Hb == 257 && d->Wb == 347 && !big_scale)
     return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, bias, st);
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
