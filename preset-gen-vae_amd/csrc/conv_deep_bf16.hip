@@ -1178,6 +1178,288 @@ int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const f
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// UP on a LARGE plane: the 64 -> 32 channel transposed convolution onto 33x45 (dec5 forward, enc4 input gradient;
+// model/decoder.py:211-212, model/encoder.py:247-248) - 2 x 100 us of the bf16 step on the fp32-MFMA kernel with rounded
+// operands, against 12-20 us of HBM time.  Same product as deep_up_bf16 (K = 32: 8 small channels x the 4 taps of an
+// output phase; channel-innermost image, 64 channels = 128 bytes per pixel; waves = phases x halves, no reduction), but
+// the plane does not fit LDS: a unit of work = (sample, band of 8 output rows), PERSISTENT workgroups sweep the units with
+// the layer's whole weight shadow (64 KB) resident in LDS, the small band double-buffered (register prefetch one unit
+// ahead) and the 32 x 8 x 45 output tile staged through LDS, from where 16 lanes per channel move it out - with the
+// BatchNorm statistics (forward) or the BatchNorm + activation backward of the block below (pgv_bwd_fuse) on the way.
+template <int CB_, int CS_, int H_, int W_>
+struct UpBig {
+  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws;
+  static constexpr int UB = 4, RB = 2 * UB, BANDS = (Hs + UB - 1) / UB;     // u rows / output rows of a band
+  static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;      // small band image (+ zero column right)
+  static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
+  static constexpr int ntp(int p) { return (UB * wu(p) + 15) / 16; }
+  static constexpr int TMAX = (ntp(0) + 1) / 2;
+  static constexpr int A_ROW = (CS / 8) * 256 + 32, A_BYTES = CB * A_ROW;
+  static constexpr int S_BYTES = SPX * (CS * 2);                             // one stage
+  static constexpr int O_FLOATS = CB * RB * W, O_BYTES = O_FLOATS * 4;
+  static constexpr int S_RUN = SROWS * Ws, QUADS = (S_RUN + 3) / 4, ITEMS = (CS / 2) * QUADS, QB = (ITEMS + 511) / 512;
+  static constexpr int QA = CB * (CS / 8) * 16 / 512;                        // 16-byte weight pieces per thread
+  static constexpr int O4 = RB * W / 4, QO = (O4 + 15) / 16;                 // float4 groups of a channel's band per lane
+  static constexpr size_t LDS_BYTES = (size_t)A_BYTES + 2 * S_BYTES + O_BYTES + sizeof(float) * (2 * CS + 8);
+  static_assert(CB == 32 && CS == 64, "two M tiles, 128-byte pixels");
+  static_assert((RB * W) % 4 == 0 && (CB * (CS / 8) * 16) % 512 == 0 && S_BYTES % 16 == 0, "tile shapes");
+};
+
+template <class G, bool FUSE>
+__global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __restrict__ small_in,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, const u16* __restrict__ wsh,
+                                                          const float* __restrict__ bias, int act, float slope,
+                                                          float* __restrict__ out, double* __restrict__ stats,
+                                                          int stat_stride, pgv_bn_src in_bn, pgv_bwd_fuse fuse) {
+  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, RB = G::RB, UB = G::UB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* lds_a = ldsb;
+  unsigned char* lds_s = ldsb + G::A_BYTES;
+  float* otile = reinterpret_cast<float*>(ldsb + G::A_BYTES + 2 * G::S_BYTES);
+  float* aff = otile + G::O_FLOATS;   // [2*CS]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave < 4 ? wave : 7 - wave, half = wave >> 2, phh = ph >> 1, pww = ph & 1;
+  const int units = B * G::BANDS;
+
+  for (int i = tid; i < 2 * G::S_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_s)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < CS; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CS, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CS + i] = sh;
+  }
+  // the whole weight shadow of the layer: [cb][cs/8][phase][tap][8] -> rows of A_ROW bytes
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 512 * i, row = q / ((CS / 8) * 16), f = q - row * ((CS / 8) * 16);
+    *reinterpret_cast<u32x4*>(lds_a + row * G::A_ROW + f * 16) =
+        *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
+  }
+  // ---- small-band loader: an item = a channel pair x 4 consecutive floats of the band's rows (contiguous in the plane)
+  int b_off[G::QB], b_dst[G::QB][4], b_e0[G::QB], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int cp = q / G::QUADS, qi = q - cp * G::QUADS, e0 = min(4 * qi, G::S_RUN - 4);
+    b_cp[i] = cp;
+    b_e0[i] = e0;
+    b_off[i] = (2 * cp) * G::P + e0;   // + sample * CS * P + first row * Ws
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = (e0 + e) / Ws, cc = (e0 + e) - rr * Ws, px = rr * G::SWP + cc;
+      b_dst[i][e] = px * 128 + (((cp >> 2) ^ ((px >> 1) & 7)) * 16) + (cp & 3) * 4;
+    }
+  }
+  // ---- this wave's tiles: pixels [16 (t0 + t), +16) of phase ph's list (ul, v) of the band
+  const int wu = pww ? W / 2 : (W + 1) / 2, cnt = UB * wu, ntp = (cnt + 15) >> 4;
+  const int t0 = half ? (ntp + 1) >> 1 : 0, ntl = half ? ntp >> 1 : (ntp + 1) >> 1;
+  const int th = kq >> 1, tw = kq & 1;
+  const int a_frag = m * G::A_ROW + ph * 64 + kq * 16;
+  int boff[TMAX], bsw[TMAX], opix[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    const int n = (t0 + t) * 16 + m, nn = min(n, cnt - 1), ul = nn / wu, v = nn - ul * wu;
+    const int px = (ul + 1 - th) * G::SWP + (v + 1 - tw);
+    boff[t] = px * 128;
+    bsw[t] = (px >> 1) & 7;
+    opix[t] = (t < ntl && n < cnt) ? (2 * ul + phh) * W + 2 * v + pww : -1;
+  }
+  float bv[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[mt][i] = (!FUSE && bias) ? bias[mt * 16 + 4 * kq + i] : 0.f;
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  // copy-out roles: 16 lanes per channel
+  const int och = tid >> 4, part = tid & 15;
+  float ka = 1.f, kb = 0.f, kc = 0.f;
+  pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
+  if (FUSE) {
+    ka = fuse.coef[och], kb = fuse.coef[CB + och], kc = fuse.coef[2 * CB + och];
+    actd = pgv_actd_setup(fuse.act, fuse.slope);
+  }
+  float s1 = 0.f, s2 = 0.f;   // forward: sum / sum of squares of the outputs; fused: sum of g_y (bias gradient)
+
+  f4u rb[G::QB][2];
+  unsigned rb_n[G::QB];   // valid floats of the item's quad (rows beyond the plane are zeros)
+  auto issue = [&](int u) {
+    const int b = u / G::BANDS, band = u - b * G::BANDS, oh0 = band * UB;
+    const int nvalid = (min(Hs, oh0 + G::SROWS) - oh0) * Ws;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int e0 = min(b_e0[i], max(nvalid - 4, 0));   // keep the load inside the plane
+      rb_n[i] = (unsigned)(((b_e0[i] - e0) << 8) | max(0, min(4, nvalid - b_e0[i])));
+      const float* p = small_in + (size_t)b * CS * G::P + b_off[i] - b_e0[i] + e0 + oh0 * Ws;
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + G::P);
+    }
+  };
+  auto commit = [&](unsigned char* st) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = 2 * b_cp[i];
+      const float s0 = aff[c], s1c = aff[c + 1], h0 = aff[CS + c], h1 = aff[CS + c + 1];
+      const int shft = (int)(rb_n[i] >> 8), nv = (int)(rb_n[i] & 255);
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // (the last band: the quad was shifted back into the plane by shft floats; floats behind the plane are zeros)
+          float x0, x1;
+          if (shft == 0) {
+            x0 = rb[i][0][e], x1 = rb[i][1][e];
+          } else {
+            const int k = min(e + shft, 3);
+            x0 = k == 1 ? rb[i][0][1] : (k == 2 ? rb[i][0][2] : rb[i][0][3]);
+            x1 = k == 1 ? rb[i][1][1] : (k == 2 ? rb[i][1][2] : rb[i][1][3]);
+          }
+          const bool on = e < nv;
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) =
+              pack_bf16x2(on ? fmaf(x0, s0, h0) : 0.f, on ? fmaf(x1, s1c, h1) : 0.f);
+        }
+      }
+    }
+  };
+
+  int u = pgv_xcd_block();
+  if (u < units) issue(u);
+  __syncthreads();   // stages zeroed, affine and weights staged
+  if (u < units) commit(lds_s);
+  __syncthreads();
+  int stage = 0;
+#pragma unroll 1
+  for (; u < units; u += gridDim.x, stage ^= 1) {
+    const int b = u / G::BANDS, band = u - b * G::BANDS, y0 = band * RB, nrow = min(RB, H - y0), nfl = nrow * W;
+    const int un = u + gridDim.x;
+    if (un < units) issue(un);
+    // the saved activation of the fused epilogue: requested before the matrix loop, used after it
+    f4u av[G::QO];
+    const float* a_p = FUSE ? fuse.a + ((size_t)b * CB + och) * (H * W) + y0 * W : nullptr;
+    if (FUSE) {
+#pragma unroll
+      for (int i = 0; i < G::QO; ++i) {
+        const int q4 = part + 16 * i;
+        if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
+      }
+    }
+    const unsigned char* st = lds_s + stage * G::S_BYTES;
+    f32x4 acc[2][TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < CS / 8; ++g) {
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + 16 * G::A_ROW);
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < ntl) {
+          const u32x4 bfr = *reinterpret_cast<const u32x4*>(st + boff[t] + ((g ^ bsw[t]) * 16));
+          acc[0][t] = mfma_bf16_k32(a0, bfr, acc[0][t]);
+          acc[1][t] = mfma_bf16_k32(a1, bfr, acc[1][t]);
+        }
+      }
+    }
+    // ---- this wave's pixels into the [channel][8 rows][W] output tile
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (opix[t] >= 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[mt][t][i];
+            otile[(mt * 16 + 4 * kq + i) * (RB * W) + opix[t]] = FUSE ? v : pgv_act_apply(v + bv[mt][i], ap);
+          }
+      }
+    }
+    if (un < units) commit(lds_s + (stage ^ 1) * G::S_BYTES);   // (nobody reads that stage during this unit)
+    __syncthreads();
+    // ---- move the band out: 16 lanes per channel, 16 bytes per lane and step
+    {
+      float* o_p = out + ((size_t)b * CB + och) * (H * W) + y0 * W;
+      const float* t_p = otile + och * (RB * W);
+#pragma unroll
+      for (int i = 0; i < G::QO; ++i) {
+        const int q4 = part + 16 * i;
+        if (4 * q4 + 4 <= nfl) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
+          if (FUSE) {
+            v = f32x4{pgv_bwd_apply(v[0], av[i][0], ka, kb, kc, actd), pgv_bwd_apply(v[1], av[i][1], ka, kb, kc, actd),
+                      pgv_bwd_apply(v[2], av[i][2], ka, kb, kc, actd), pgv_bwd_apply(v[3], av[i][3], ka, kb, kc, actd)};
+          } else {
+            s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
+          s1 += (v[0] + v[1]) + (v[2] + v[3]);
+          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
+        }
+      }
+      const int tail0 = nfl & ~3;   // (the last band: 45 floats = 11 groups + 1)
+      if (part < nfl - tail0) {
+        float v = t_p[tail0 + part];
+        if (FUSE)
+          v = pgv_bwd_apply(v, a_p[tail0 + part], ka, kb, kc, actd);
+        else
+          s2 += v * v;
+        s1 += v;
+        o_p[tail0 + part] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- per-channel sums of the workgroup: BatchNorm statistics (forward) or the bias gradient (fused backward)
+  s1 = group16_sum(s1);
+  s2 = group16_sum(s2);
+  if (part == 0) {
+    const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
+    if (FUSE) {
+      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CB : 0) + och, s1);
+    } else if (stats) {
+      double* sp = stats + (size_t)copy * stat_stride;
+      atomicAdd(&sp[och], (double)s1);
+      atomicAdd(&sp[CB + och], (double)s2);
+    }
+  }
+}
+
+bool up_big_bf16_shape(const pgv_conv_desc* d) {
+  return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64;
+}
+
+int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                       const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                       hipStream_t st, const pgv_bn_src* bn) {
+  using G = UpBig<32, 64, 33, 45>;
+  if (fuse && (fuse->cls || stats || bias)) return 0;   // (class sums: not a case of this layer in the train step)
+  if ((int64_t)d->B * d->Cs * G::P * 4 >= (int64_t)1 << 31 || G::LDS_BYTES > (size_t)kMaxLds || d->B <= 0) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const u16*, const float*, int, float, float*, double*,
+                         int, pgv_bn_src, pgv_bwd_fuse);
+  kern_t kern = fuse ? (kern_t)up_big_bf16_kernel<G, true> : (kern_t)up_big_bf16_kernel<G, false>;
+  static bool attr_done[2] = {false, false};
+  int rc = raise_lds_limit(kern, &attr_done[fuse ? 1 : 0], "conv_up_big_bf16");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_big_bf16: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  pgv_bwd_fuse f = {};
+  if (fuse) f = *fuse;
+  const int units = d->B * G::BANDS;
+  const u16* up = (const u16*)d->w_shadow + (size_t)d->Cs * d->Cb * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
+                     bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(), f);
+  PGV_CHECK_LAUNCH("conv_up_big_bf16");
+  return 1;
+}
+
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -1188,7 +1470,7 @@ bool deep_bf16_shape(const pgv_conv_desc* d) {
 // bytes of the bf16 weight shadow of a layer (down + up layouts), 0: the layer has no bf16-native kernels
 int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
   if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
-  return deep_bf16_shape(d) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
+  return (deep_bf16_shape(d) || up_big_bf16_shape(d)) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
 }
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
@@ -1199,7 +1481,7 @@ int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* sh
     PGV_CHECK_LAUNCH("conv_weight_shadow");
     return 1;
   }
-  if (!deep_bf16_shape(d)) return 0;
+  if (!deep_bf16_shape(d) && !up_big_bf16_shape(d)) return 0;
   u16* down = (u16*)shadow;
   u16* up = down + (size_t)d->Cs * d->Cb * 16;
   const int items = d->Cs * (d->Cb / 8) * 4;
@@ -1282,4 +1564,12 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
   if (d->Hb == 5 && d->Wb == 7)
     return launch_deep_wgrad_bf16<5, 7, 3, 12>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
   return 0;
+}
+
+// the 64 -> 32 channel transposed convolution onto 33x45 (1 = launched; the fused epilogue is applied when `fuse` is given)
+int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                         const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                         hipStream_t st, const pgv_bn_src* bn) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
+  return launch_up_big_bf16(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }

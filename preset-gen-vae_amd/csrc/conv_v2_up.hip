@@ -832,6 +832,8 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                    const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  // bf16 operand mode with a weight shadow: the bf16-native kernel of the 33x45 layer (conv_deep_bf16.hip)
+  if (int rc = pgv_conv_up_big_bf16(d, small_in, in_scale, in_shift, bias, act, slope, big_out, stats, fuse, st, bn)) return rc;
   // bf16 operand mode: only the 33x45 layer comes here (operands rounded at the LDS commit / weight load, fp32 MFMA: 95 us
   // against 157 us for the band kernel's bf16 loop at this shape; the other shapes' band kernels are faster than this form)
   // (and the fused 129x174 input gradient: 204 us on the band kernel's bf16 loop)

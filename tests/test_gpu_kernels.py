@@ -332,7 +332,8 @@ def test_deep_kernels_many_units(ops, case, mode):
 
 @pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9),
                                   (256, 512, 4, 2, 2, 5, 7, 16), (128, 192, 4, 2, 2, 9, 12, 3),
-                                  (512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4)])
+                                  (512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4),
+                                  (32, 64, 4, 2, 2, 33, 45, 5), (32, 64, 4, 2, 2, 33, 45, 70)])
 def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
     """conv_deep_bf16.hip: the bf16-native kernels of the deep layers behind ``pgv_conv_desc.w_shadow`` (bf16 weight shadow
     written by pgv_conv_weight_shadow), several sample groups with a partial last one: against float64 convolutions of the
@@ -510,6 +511,17 @@ def test_conv_bwd_fuse_bf16_operand_mode(ops, case):
             assert rel_l2(out, ref) < 1e-5, (out_is_big, rel_l2(out, ref))
             l1 = ref.abs().sum(dim=(0, 2, 3))
             assert ((gb.double() - ref.sum(dim=(0, 2, 3))).abs() <= 1e-5 * l1 + 1e-12).all()
+            # with the bf16 weight shadow (the 33x45 transposed product then runs conv_deep_bf16.hip's persistent kernel),
+            # the bias gradient kept as per-XCD partial copies as in the train step
+            sh = ops.conv_weight_shadow(geom, w)
+            if sh is not None:
+                gbc = torch.zeros(ops.CLS_COPIES * C, device='cuda')
+                fzc = (a, coef, gbc, ops.PGV_ACT_LEAKY_RELU, 0.1, None, ops.CLS_COPIES)
+                out2 = (ops.conv_up(geom, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fzc, w_shadow=sh) if out_is_big else
+                        ops.conv_down(geom, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fzc, w_shadow=sh))
+                assert rel_l2(out2, ref) < 1e-5, (out_is_big, rel_l2(out2, ref))
+                gsum = gbc.view(ops.CLS_COPIES, C).double().sum(0)
+                assert ((gsum - ref.sum(dim=(0, 2, 3))).abs() <= 1e-5 * l1 + 1e-12).all()
     finally:
         ops.set_compute_dtype('fp32')
 
