@@ -1188,24 +1188,27 @@ int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const f
 // the layer's whole weight shadow (64 KB) resident in LDS, the small band double-buffered (register prefetch one unit
 // ahead) and the 32 x 8 x 45 output tile staged through LDS, from where 16 lanes per channel move it out - with the
 // BatchNorm statistics (forward) or the BatchNorm + activation backward of the block below (pgv_bwd_fuse) on the way.
-template <int CB_, int CS_, int H_, int W_>
+template <int CB_, int CS_, int H_, int W_, int UB_ = 4>
 struct UpBig {
   static constexpr int CB = CB_, CS = CS_, H = H_, W = W_;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws;
-  static constexpr int UB = 4, RB = 2 * UB, BANDS = (Hs + UB - 1) / UB;     // u rows / output rows of a band
+  static constexpr int UB = UB_, RB = 2 * UB, BANDS = (Hs + UB - 1) / UB;   // u rows / output rows of a band
   static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;      // small band image (+ zero column right)
   static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
   static constexpr int ntp(int p) { return (UB * wu(p) + 15) / 16; }
   static constexpr int TMAX = (ntp(0) + 1) / 2;
-  static constexpr int A_ROW = (CS / 8) * 256 + 32, A_BYTES = CB * A_ROW;
-  static constexpr int S_BYTES = SPX * (CS * 2);                             // one stage
+  static constexpr int MTN = (CB + 15) / 16;                                 // M tiles (a layer with 8 big channels: rows 8-15 zero)
+  static constexpr int NG = CS / 8, PB = CS * 2;                             // 16-byte channel groups / bytes of a pixel
+  static constexpr int SH = NG == 8 ? 1 : (NG == 4 ? 2 : 3);                 // group g of pixel px sits at g ^ ((px >> SH) & (NG - 1))
+  static constexpr int A_ROW = NG * 256 + 32, A_BYTES = MTN * 16 * A_ROW;
+  static constexpr int S_BYTES = (SPX * PB + 15) / 16 * 16;                  // one stage
   static constexpr int O_FLOATS = CB * RB * W, O_BYTES = O_FLOATS * 4;
   static constexpr int S_RUN = SROWS * Ws, QUADS = (S_RUN + 3) / 4, ITEMS = (CS / 2) * QUADS, QB = (ITEMS + 511) / 512;
-  static constexpr int QA = CB * (CS / 8) * 16 / 512;                        // 16-byte weight pieces per thread
-  static constexpr int O4 = RB * W / 4, QO = (O4 + 15) / 16;                 // float4 groups of a channel's band per lane
+  static constexpr int LPC = 512 / CB;                                       // copy-out lanes per channel
+  static constexpr int O4 = RB * W / 4, QO = (O4 + LPC - 1) / LPC;           // float4 groups of a channel's band per lane
   static constexpr size_t LDS_BYTES = (size_t)A_BYTES + 2 * S_BYTES + O_BYTES + sizeof(float) * (2 * CS + 8);
-  static_assert(CB == 32 && CS == 64, "two M tiles, 128-byte pixels");
-  static_assert((RB * W) % 4 == 0 && (CB * (CS / 8) * 16) % 512 == 0 && S_BYTES % 16 == 0, "tile shapes");
+  static_assert((NG == 8 || NG == 4 || NG == 2) && (CB == 32 || CB == 16 || CB == 8), "channel counts of the stack");
+  static_assert((RB * W) % 4 == 0 && LPC <= 64 && LDS_BYTES <= 160 * 1024, "tile shapes");
 };
 
 template <class G, bool FUSE>
@@ -1236,10 +1239,12 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
     aff[i] = sc;
     aff[CS + i] = sh;
   }
-  // the whole weight shadow of the layer: [cb][cs/8][phase][tap][8] -> rows of A_ROW bytes
-#pragma unroll
-  for (int i = 0; i < G::QA; ++i) {
-    const int q = tid + 512 * i, row = q / ((CS / 8) * 16), f = q - row * ((CS / 8) * 16);
+  // the whole weight shadow of the layer: [cb][cs/8][phase][tap][8] -> rows of A_ROW bytes (rows beyond CB: zeros)
+  if (CB < G::MTN * 16)
+    for (int i = tid; i < G::A_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_a)[i] = u32x4{0, 0, 0, 0};
+  if (CB < G::MTN * 16) __syncthreads();
+  for (int q = tid; q < CB * G::NG * 16; q += 512) {
+    const int row = q / (G::NG * 16), f = q - row * (G::NG * 16);
     *reinterpret_cast<u32x4*>(lds_a + row * G::A_ROW + f * 16) =
         *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
   }
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rr = (e0 + e) / Ws, cc = (e0 + e) - rr * Ws, px = rr * G::SWP + cc;
-      b_dst[i][e] = px * 128 + (((cp >> 2) ^ ((px >> 1) & 7)) * 16) + (cp & 3) * 4;
+      b_dst[i][e] = px * G::PB + (((cp >> 2) ^ ((px >> G::SH) & (G::NG - 1))) * 16) + (cp & 3) * 4;
     }
   }
   // ---- this wave's tiles: pixels [16 (t0 + t), +16) of phase ph's list (ul, v) of the band
@@ -1270,18 +1275,18 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
   for (int t = 0; t < TMAX; ++t) {
     const int n = (t0 + t) * 16 + m, nn = min(n, cnt - 1), ul = nn / wu, v = nn - ul * wu;
     const int px = (ul + 1 - th) * G::SWP + (v + 1 - tw);
-    boff[t] = px * 128;
-    bsw[t] = (px >> 1) & 7;
+    boff[t] = px * G::PB;
+    bsw[t] = (px >> G::SH) & (G::NG - 1);
     opix[t] = (t < ntl && n < cnt) ? (2 * ul + phh) * W + 2 * v + pww : -1;
   }
-  float bv[2][4];
+  float bv[G::MTN][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < G::MTN; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[mt][i] = (!FUSE && bias) ? bias[mt * 16 + 4 * kq + i] : 0.f;
+    for (int i = 0; i < 4; ++i) bv[mt][i] = (!FUSE && bias && mt * 16 + 4 * kq + i < CB) ? bias[mt * 16 + 4 * kq + i] : 0.f;
   const pgv_act_params ap = pgv_act_setup(act, slope);
-  // copy-out roles: 16 lanes per channel
-  const int och = tid >> 4, part = tid & 15;
+  // copy-out roles: LPC lanes per channel
+  const int och = tid / G::LPC, part = tid % G::LPC;
   float ka = 1.f, kb = 0.f, kc = 0.f;
   pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
   if (FUSE) {
@@ -1347,24 +1352,27 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
     if (FUSE) {
 #pragma unroll
       for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + 16 * i;
+        const int q4 = part + G::LPC * i;
         if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
       }
     }
     const unsigned char* st = lds_s + stage * G::S_BYTES;
-    f32x4 acc[2][TMAX];
+    f32x4 acc[G::MTN][TMAX];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < G::MTN; ++mt)
 #pragma unroll
-    for (int g = 0; g < CS / 8; ++g) {
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256);
-      const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + 16 * G::A_ROW);
+      for (int t = 0; t < TMAX; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G::NG; ++g) {
+      u32x4 af[G::MTN];
+#pragma unroll
+      for (int mt = 0; mt < G::MTN; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + mt * 16 * G::A_ROW);
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) {
         if (t < ntl) {
           const u32x4 bfr = *reinterpret_cast<const u32x4*>(st + boff[t] + ((g ^ bsw[t]) * 16));
-          acc[0][t] = mfma_bf16_k32(a0, bfr, acc[0][t]);
-          acc[1][t] = mfma_bf16_k32(a1, bfr, acc[1][t]);
+#pragma unroll
+          for (int mt = 0; mt < G::MTN; ++mt) acc[mt][t] = mfma_bf16_k32(af[mt], bfr, acc[mt][t]);
         }
       }
     }
@@ -1373,23 +1381,24 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
     for (int t = 0; t < TMAX; ++t) {
       if (opix[t] >= 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < G::MTN; ++mt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float v = acc[mt][t][i];
-            otile[(mt * 16 + 4 * kq + i) * (RB * W) + opix[t]] = FUSE ? v : pgv_act_apply(v + bv[mt][i], ap);
+            if (mt * 16 + 4 * kq + i < CB)
+              otile[(mt * 16 + 4 * kq + i) * (RB * W) + opix[t]] = FUSE ? v : pgv_act_apply(v + bv[mt][i], ap);
           }
       }
     }
     if (un < units) commit(lds_s + (stage ^ 1) * G::S_BYTES);   // (nobody reads that stage during this unit)
     __syncthreads();
-    // ---- move the band out: 16 lanes per channel, 16 bytes per lane and step
+    // ---- move the band out: LPC lanes per channel, 16 bytes per lane and step
     {
       float* o_p = out + ((size_t)b * CB + och) * (H * W) + y0 * W;
       const float* t_p = otile + och * (RB * W);
 #pragma unroll
       for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + 16 * i;
+        const int q4 = part + G::LPC * i;
         if (4 * q4 + 4 <= nfl) {
           f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
           if (FUSE) {
@@ -1416,8 +1425,11 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
     __syncthreads();
   }
   // ---- per-channel sums of the workgroup: BatchNorm statistics (forward) or the bias gradient (fused backward)
-  s1 = group16_sum(s1);
-  s2 = group16_sum(s2);
+#pragma unroll
+  for (int o = 1; o < G::LPC; o <<= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
   if (part == 0) {
     const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
     if (FUSE) {
@@ -1431,19 +1443,22 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
 }
 
 bool up_big_bf16_shape(const pgv_conv_desc* d) {
-  return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64;
+  if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
+  // (16 -> 8 channels onto 129x174 stays on the band kernel: 62 us there, 75 us here with bands of 4 rows and two
+  // workgroups per CU, 89 us with bands of 8 rows - half-empty M tiles and a 44 KB output tile per 1.4 k pixels)
+  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32);
 }
 
+template <class G>
 int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                        const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                        hipStream_t st, const pgv_bn_src* bn) {
-  using G = UpBig<32, 64, 33, 45>;
-  if (fuse && (fuse->cls || stats || bias)) return 0;   // (class sums: not a case of this layer in the train step)
+  if (fuse && (fuse->cls || stats || bias)) return 0;   // (class sums: the band kernels' epilogue keeps those calls)
   if ((int64_t)d->B * d->Cs * G::P * 4 >= (int64_t)1 << 31 || G::LDS_BYTES > (size_t)kMaxLds || d->B <= 0) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const u16*, const float*, int, float, float*, double*,
                          int, pgv_bn_src, pgv_bwd_fuse);
   kern_t kern = fuse ? (kern_t)up_big_bf16_kernel<G, true> : (kern_t)up_big_bf16_kernel<G, false>;
-  static bool attr_done[2] = {false, false};
+  static bool attr_done[2] = {false, false};   // (per instantiation of the template)
   int rc = raise_lds_limit(kern, &attr_done[fuse ? 1 : 0], "conv_up_big_bf16");
   if (rc) return rc;
   if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
@@ -1454,7 +1469,8 @@ int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const floa
   if (fuse) f = *fuse;
   const int units = d->B * G::BANDS;
   const u16* up = (const u16*)d->w_shadow + (size_t)d->Cs * d->Cb * 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
+  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / G::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256 * per_cu)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
                      bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(), f);
   PGV_CHECK_LAUNCH("conv_up_big_bf16");
   return 1;
@@ -1571,5 +1587,6 @@ int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const fl
                          const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                          hipStream_t st, const pgv_bn_src* bn) {
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
-  return launch_up_big_bf16(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }

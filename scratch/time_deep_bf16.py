@@ -18,7 +18,7 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1000
-CASES = {'33x45': (32, 64, 33, 45), '17x23': (64, 128, 17, 23), '9x12': (128, 256, 9, 12), '5x7': (256, 512, 5, 7), 'k1': (512, 2048, 3, 4)}
+CASES = {'129x174': (8, 16, 129, 174), '65x88': (16, 32, 65, 88), '33x45': (32, 64, 33, 45), '17x23': (64, 128, 17, 23), '9x12': (128, 256, 9, 12), '5x7': (256, 512, 5, 7), 'k1': (512, 2048, 3, 4)}
 for which, (Cb, Cs, Hb, Wb) in CASES.items():
     if os.environ.get('ONLY') and which not in os.environ['ONLY'].split(','): continue
     KK, ST, PD = (1, 1, 0) if which == 'k1' else (4, 2, 2)

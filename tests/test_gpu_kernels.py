@@ -333,7 +333,8 @@ def test_deep_kernels_many_units(ops, case, mode):
 @pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9),
                                   (256, 512, 4, 2, 2, 5, 7, 16), (128, 192, 4, 2, 2, 9, 12, 3),
                                   (512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4),
-                                  (32, 64, 4, 2, 2, 33, 45, 5), (32, 64, 4, 2, 2, 33, 45, 70)])
+                                  (32, 64, 4, 2, 2, 33, 45, 5), (32, 64, 4, 2, 2, 33, 45, 70), (16, 32, 4, 2, 2, 65, 88, 5),
+                                  (16, 32, 4, 2, 2, 65, 88, 40)])
 def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
     """conv_deep_bf16.hip: the bf16-native kernels of the deep layers behind ``pgv_conv_desc.w_shadow`` (bf16 weight shadow
     written by pgv_conv_weight_shadow), several sample groups with a partial last one: against float64 convolutions of the
