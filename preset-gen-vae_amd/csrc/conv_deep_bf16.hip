@@ -1476,6 +1476,289 @@ int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const floa
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN on a LARGE plane: the stride-2 k4 convolutions 32 -> 64 channels from 33x45 and 16 -> 32 from 65x88 (enc4 / enc3
+// forward, dec5 / dec6 input gradient; model/encoder.py:245-248, model/decoder.py:211-214).  The persistent form of
+// deep_down_bf16: the layer's whole weight shadow resident in LDS, a unit = (sample, band of R output rows), the big band
+// channel-innermost and double-buffered, every wave one M tile x up to 3 pixel tiles over the whole K (no reduction), the
+// CS x R x Ws output tile staged through LDS and moved out by 512 / CS lanes per channel - with the BatchNorm statistics
+// (forward) or the fused BatchNorm + activation backward of the block below including its class sums (pgv_bwd_fuse).
+template <int CB_, int CS_, int H_, int W_, int R_, int WPX_, int SH_>
+struct DownBig {
+  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, R = R_, WPX = WPX_, SH = SH_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, BANDS = (Hs + R - 1) / R;
+  static constexpr int XR = 2 * R + 2;                                        // big rows of a band
+  static constexpr int NG = CB / 8, PB = CB * 2;                              // channel groups / bytes of a pixel
+  static constexpr int MTN = CS / 16, NW = 8 / MTN;                           // M tiles; waves that split the pixels
+  static constexpr int NPX = R * Ws, NT = (NPX + 15) / 16, TMAX = (NT + NW - 1) / NW;
+  static constexpr int A_ROW = NG * 256 + 32, A_BYTES = CS * A_ROW;
+  static constexpr int X_BYTES = (XR * WPX * PB + 15) / 16 * 16;              // one stage
+  static constexpr int O_FLOATS = CS * NPX, O_BYTES = O_FLOATS * 4;
+  static constexpr int QX = (W + 3) / 4, ITEMS = (CB / 2) * XR * QX, QB = (ITEMS + 511) / 512;   // (channel pair, row, quad)
+  static constexpr int LPC = 512 / CS, QO = ((NPX + 3) / 4 + LPC - 1) / LPC;
+  static constexpr size_t LDS_BYTES = (size_t)A_BYTES + 2 * X_BYTES + O_BYTES + sizeof(float) * (2 * CB + 8);
+  static_assert(WPX >= 2 * Ws + 2 && CS % 16 == 0 && 8 % MTN == 0 && W >= 4 && LPC <= 64, "tile shapes");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class G, bool FUSE>
+__global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* __restrict__ big,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift, const u16* __restrict__ wsh,
+                                                            const float* __restrict__ bias, int act, float slope,
+                                                            float* __restrict__ out, double* __restrict__ stats,
+                                                            int stat_stride, pgv_bn_src in_bn, pgv_bwd_fuse fuse) {
+  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, R = G::R, NPX = G::NPX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* lds_a = ldsb;
+  unsigned char* lds_x = ldsb + G::A_BYTES;
+  float* otile = reinterpret_cast<float*>(ldsb + G::A_BYTES + 2 * G::X_BYTES);
+  float* aff = otile + G::O_FLOATS;   // [2*CB]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mt = wave % G::MTN, nw = wave / G::MTN;
+  const int units = B * G::BANDS;
+
+  for (int i = tid; i < 2 * G::X_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_x)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < CB; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CB, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CB + i] = sh;
+  }
+  // the whole weight shadow of the layer: [cs][cb/8][16 taps][8] -> rows of A_ROW bytes
+  for (int q = tid; q < CS * G::NG * 16; q += 512) {
+    const int row = q / (G::NG * 16), f = q - row * (G::NG * 16);
+    *reinterpret_cast<u32x4*>(lds_a + row * G::A_ROW + f * 16) =
+        *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
+  }
+  // ---- big-band loader: an item = a channel pair x one band row x 4 columns (the last quad of a row shifted back)
+  int b_off[G::QB], b_row[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int cp = q / (G::XR * G::QX), rem = q - cp * (G::XR * G::QX), r = rem / G::QX, qi = rem - r * G::QX;
+    const int c0 = min(4 * qi, W - 4);
+    b_cp[i] = cp;
+    b_row[i] = r;
+    b_off[i] = (2 * cp) * (H * W) + c0;   // + sample * CB * H * W + image row * W
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int px = r * G::WPX + c0 + e + 2;
+      b_dst[i][e] = px * G::PB + (((cp >> 2) ^ ((px >> G::SH) & (G::NG - 1))) * 16) + (cp & 3) * 4;
+    }
+  }
+  // ---- this wave: M tile mt, pixel tiles nw, nw + NW, ... of the band's R * Ws pixels
+  const int a_frag = (mt * 16 + m) * G::A_ROW + kq * 16;   // + 256 per channel group, + 64 per kernel row
+  int boff[TMAX], bsw[TMAX];
+  bool t_on[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    const int tile = nw + G::NW * t;
+    t_on[t] = tile < G::NT;
+    const int n = min(tile * 16 + m, NPX - 1), ohl = n / Ws, ow = n - ohl * Ws;
+    const int px = (2 * ohl) * G::WPX + 2 * ow + kq;   // + WPX per kernel row
+    boff[t] = px * G::PB;
+    bsw[t] = px;                                         // (the swizzle bits are taken per kernel row)
+  }
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = (!FUSE && bias) ? bias[mt * 16 + 4 * kq + i] : 0.f;
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  const int och = tid / G::LPC, part = tid % G::LPC;
+  float ka = 1.f, kb = 0.f, kc = 0.f;
+  pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
+  if (FUSE) {
+    ka = fuse.coef[och], kb = fuse.coef[CS + och], kc = fuse.coef[2 * CS + och];
+    actd = pgv_actd_setup(fuse.act, fuse.slope);
+  }
+  // forward: s[0] / s[1] = sum / sum of squares of the outputs; fused: s[k] = sum of g_y in (row, column) parity class k
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f4u rb[G::QB][2];
+  float rb_m[G::QB];
+  auto issue = [&](int u) {
+    const int b = u / G::BANDS, band = u - b * G::BANDS, ih0 = 2 * band * R - 2;
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int ih = ih0 + b_row[i];
+      const bool in = (unsigned)ih < (unsigned)H;
+      rb_m[i] = in ? 1.f : 0.f;
+      const float* p = big + (size_t)b * CB * (H * W) + b_off[i] + (in ? ih : 0) * W;
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + H * W);
+    }
+  };
+  auto commit = [&](unsigned char* st) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = 2 * b_cp[i];
+      const float s0 = aff[c] * rb_m[i], s1c = aff[c + 1] * rb_m[i], h0 = aff[CB + c] * rb_m[i], h1 = aff[CB + c + 1] * rb_m[i];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1c, h1));
+      }
+    }
+  };
+
+  int u = pgv_xcd_block();
+  if (u < units) issue(u);
+  __syncthreads();   // stages zeroed, affine and weights staged
+  if (u < units) commit(lds_x);
+  __syncthreads();
+  int stage = 0;
+#pragma unroll 1
+  for (; u < units; u += gridDim.x, stage ^= 1) {
+    const int b = u / G::BANDS, band = u - b * G::BANDS, oh0 = band * R, nfl = min(R, Hs - oh0) * Ws;
+    const int un = u + gridDim.x;
+    if (un < units) issue(un);
+    f4u av[G::QO];
+    const float* a_p = FUSE ? fuse.a + ((size_t)b * CS + och) * G::P + oh0 * Ws : nullptr;
+    if (FUSE) {
+#pragma unroll
+      for (int i = 0; i < G::QO; ++i) {
+        const int q4 = part + G::LPC * i;
+        if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
+      }
+    }
+    const unsigned char* st = lds_x + stage * G::X_BYTES;
+    f32x4 acc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+#pragma unroll
+      for (int g = 0; g < G::NG; ++g) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + kh * 64);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+          if (t_on[t]) {
+            const int sw = ((bsw[t] + kh * G::WPX) >> G::SH) & (G::NG - 1);
+            const u32x4 bfr = *reinterpret_cast<const u32x4*>(st + boff[t] + kh * (G::WPX * G::PB) + ((g ^ sw) * 16));
+            acc[t] = mfma_bf16_k32(af, bfr, acc[t]);
+          }
+        }
+      }
+    }
+    // ---- this wave's pixels into the [channel][R * Ws] output tile
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      const int n = (nw + G::NW * t) * 16 + m;
+      if (t_on[t] && n < NPX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[t][i];
+          otile[(mt * 16 + 4 * kq + i) * NPX + n] = FUSE ? v : pgv_act_apply(v + bv[i], ap);
+        }
+      }
+    }
+    if (un < units) commit(lds_x + (stage ^ 1) * G::X_BYTES);   // (nobody reads that stage during this unit)
+    __syncthreads();
+    // ---- move the band out: LPC lanes per channel, 16 bytes per lane and step
+    {
+      float* o_p = out + ((size_t)b * CS + och) * G::P + oh0 * Ws;
+      const float* t_p = otile + och * NPX;
+#pragma unroll
+      for (int i = 0; i < G::QO; ++i) {
+        const int q4 = part + G::LPC * i;
+        if (4 * q4 + 4 <= nfl) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
+          if (FUSE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
+              const int idx = 4 * q4 + e, rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * ((oh0 + rr) & 1) + (cc & 1);
+              s[0] += cls == 0 ? v[e] : 0.f;
+              s[1] += cls == 1 ? v[e] : 0.f;
+              s[2] += cls == 2 ? v[e] : 0.f;
+              s[3] += cls == 3 ? v[e] : 0.f;
+            }
+          } else {
+            s[0] += (v[0] + v[1]) + (v[2] + v[3]);
+            s[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
+          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
+        }
+      }
+      const int tail0 = nfl & ~3;   // (a last band of one row: Ws floats)
+      if (part < nfl - tail0) {
+        const int idx = tail0 + part;
+        float v = t_p[idx];
+        if (FUSE) {
+          v = pgv_bwd_apply(v, a_p[idx], ka, kb, kc, actd);
+          const int rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * ((oh0 + rr) & 1) + (cc & 1);
+          s[0] += cls == 0 ? v : 0.f;
+          s[1] += cls == 1 ? v : 0.f;
+          s[2] += cls == 2 ? v : 0.f;
+          s[3] += cls == 3 ? v : 0.f;
+        } else {
+          s[0] += v;
+          s[1] += v * v;
+        }
+        o_p[idx] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- per-channel sums of the workgroup
+#pragma unroll
+  for (int o = 1; o < G::LPC; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], o);
+  if (part == 0) {
+    const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
+    if (FUSE) {
+      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CS : 0) + och, (s[0] + s[1]) + (s[2] + s[3]));
+      if (fuse.cls) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(fuse.cls + ((size_t)copy * CS + och) * 4 + k, s[k]);
+      }
+    } else if (stats) {
+      double* sp = stats + (size_t)copy * stat_stride;
+      atomicAdd(&sp[och], (double)s[0]);
+      atomicAdd(&sp[CS + och], (double)s[1]);
+    }
+  }
+}
+
+bool down_big_bf16_shape(const pgv_conv_desc* d) {
+  if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
+  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32);
+}
+
+template <class G>
+int launch_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                         const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                         hipStream_t st, const pgv_bn_src* bn) {
+  if (fuse && (stats || bias)) return 0;
+  if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || d->B <= 0) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const u16*, const float*, int, float, float*, double*,
+                         int, pgv_bn_src, pgv_bwd_fuse);
+  kern_t kern = fuse ? (kern_t)down_big_bf16_kernel<G, true> : (kern_t)down_big_bf16_kernel<G, false>;
+  static bool attr_done[2] = {false, false};   // (per instantiation of the template)
+  int rc = raise_lds_limit(kern, &attr_done[fuse ? 1 : 0], "conv_down_big_bf16");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
+    pgv_set_error("conv_down_big_bf16: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  pgv_bwd_fuse f = {};
+  if (fuse) f = *fuse;
+  const int units = d->B * G::BANDS;
+  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / G::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256 * per_cu)), dim3(512), G::LDS_BYTES, st, d->B, big, in_scale, in_shift,
+                     (const u16*)d->w_shadow, bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0,
+                     bn ? *bn : pgv_no_bn(), f);
+  PGV_CHECK_LAUNCH("conv_down_big_bf16");
+  return fuse && fuse->cls ? 3 : 1;   // (3: the class sums of the fused result are done)
+}
+
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -1589,4 +1872,18 @@ int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const fl
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
   if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+}
+
+// the stride-2 convolutions from 33x45 and 65x88 (1 / 3 = launched; 3: with the class sums of the fused epilogue)
+int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                           const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                           hipStream_t st, const pgv_bn_src* bn) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !down_big_bf16_shape(d) || (g_deep_bf16_dbg & 32)) return 0;
+  if (d->Hb == 33) {
+    // (the plain forward form stays on the band kernel's bf16 loop: 32 us there, 38 us here; the fused input gradient with
+    // class sums: 58 us in three launches there, 43 us here)
+    if (!fuse) return 0;
+    return launch_down_big_bf16<DownBig<32, 64, 33, 45, 4, 48, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  }
+  return launch_down_big_bf16<DownBig<16, 32, 65, 88, 2, 93, 3>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }

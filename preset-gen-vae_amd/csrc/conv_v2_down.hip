@@ -735,6 +735,8 @@ int pgv_conv_down_v2(const pgv_conv_desc* d, const float* big, const float* in_s
                      const float* w, const float* bias, int act, float slope, float* small_out, double* stats,
                      const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
+  // bf16 operand mode with a weight shadow: the bf16-native kernels of the 33x45 / 65x88 layers (conv_deep_bf16.hip)
+  if (int rc = pgv_conv_down_big_bf16(d, big, in_scale, in_shift, bias, act, slope, small_out, stats, fuse, st, bn)) return rc;
   // (bf16 operand mode: only the fused 129x174 input gradient has an operand-rounding instantiation, see launch_down_v2)
   if ((d->flags & PGV_COMPUTE_BF16) && !(d->Hb == 129 && d->Wb == 174 && fuse)) return 0;
   if (d->Hb == 33 && d->Wb == 45)   // 32 -> 64 channels, 17x23 outputs: the whole sample per unit, M split 4 ways

@@ -97,3 +97,17 @@ for which, (Cb, Cs, Hb, Wb) in CASES.items():
                         print('   stamps', [vv[o + i] - vv[o] for i in range(6)])
                 print(f'wgrad {which} {form:5s} {name}: {t:7.1f} us  err {err:.2e}', flush=True)
             lib.pgv_dbg_set_deep_bf16_variant(0)
+    if 'dfuse' in WHAT:   # input-gradient form with the fused BatchNorm + activation backward of the block below
+        for direction in ('down', 'up'):
+            C = Cs if direction == 'down' else Cb
+            a = (small if direction == 'down' else big) * 1.3 + 0.1
+            coef = torch.cat([1.0 + 0.3 * torch.rand(C, device='cuda'), 0.05 * torch.randn(C, device='cuda'), 0.02 * torch.randn(C, device='cuda')])
+            for name, kw in (('old', {}), ('new', dict(w_shadow=shadow))):
+                gbc = torch.zeros(ops.CLS_COPIES * C, device='cuda')
+                cls = torch.zeros(ops.CLS_COPIES * 4 * C, device='cuda') if direction == 'down' else None
+                fz = (a, coef, gbc, ops.PGV_ACT_LEAKY_RELU, 0.1, cls, ops.CLS_COPIES)
+                fn = (lambda: ops.conv_down(g, big, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz, **kw)) if direction == 'down' else \
+                     (lambda: ops.conv_up(g, small, w, None, ops.PGV_ACT_NONE, 0.0, bwd_fuse=fz, **kw))
+                o = fn()
+                t = timeit(fn)
+                print(f'dfuse {direction} {which} {name}: {t:7.1f} us  checksum {o.double().sum().item():.6e}', flush=True)
