@@ -1577,8 +1577,16 @@ __global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* 
     ka = fuse.coef[och], kb = fuse.coef[CS + och], kc = fuse.coef[2 * CS + och];
     actd = pgv_actd_setup(fuse.act, fuse.slope);
   }
-  // forward: s[0] / s[1] = sum / sum of squares of the outputs; fused: s[k] = sum of g_y in (row, column) parity class k
+  // forward: s[0] / s[1] = sum / sum of squares of the outputs; fused: s[k] = sum of g_y in (row, column) parity class k.
+  // (fused: an element of the band tile has the same class in every unit - the bands start at even rows - so the sums are
+  // kept per (group, element) slot of this lane and sorted into the classes at the end)
+  static_assert(R % 2 == 0, "bands start at even output rows");
   float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float slot[G::QO][4];
+#pragma unroll
+  for (int i = 0; i < G::QO; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slot[i][e] = 0.f;
 
   f4u rb[G::QB][2];
   float rb_m[G::QB];
@@ -1673,11 +1681,7 @@ __global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-              const int idx = 4 * q4 + e, rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * ((oh0 + rr) & 1) + (cc & 1);
-              s[0] += cls == 0 ? v[e] : 0.f;
-              s[1] += cls == 1 ? v[e] : 0.f;
-              s[2] += cls == 2 ? v[e] : 0.f;
-              s[3] += cls == 3 ? v[e] : 0.f;
+              slot[i][e] += v[e];   // (sorted into the parity classes once, after the last unit)
             }
           } else {
             s[0] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -1707,6 +1711,18 @@ __global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* 
     __syncthreads();
   }
   // ---- per-channel sums of the workgroup
+  if (FUSE) {
+#pragma unroll
+    for (int i = 0; i < G::QO; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = 4 * (part + G::LPC * i) + e, rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
+        s[0] += cls == 0 ? slot[i][e] : 0.f;
+        s[1] += cls == 1 ? slot[i][e] : 0.f;
+        s[2] += cls == 2 ? slot[i][e] : 0.f;
+        s[3] += cls == 3 ? slot[i][e] : 0.f;
+      }
+  }
 #pragma unroll
   for (int o = 1; o < G::LPC; o <<= 1)
 #pragma unroll
