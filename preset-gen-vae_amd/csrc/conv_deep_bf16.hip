@@ -10,8 +10,9 @@
 //   * weights come from a bf16 SHADOW of the layer's weight, [cs][cb/8][16 taps][8 channels] (pgv_conv_weight_shadow, one
 //     launch per layer and step): a slab of a weight row is 512 contiguous bytes, copied to LDS as it is.  The shadow
 //     halves the weight stream, the bound of these layers (every sample group streams the whole weight through L2).
-// One workgroup = 64 output channels x NS samples; 8 waves = 8 K groups (2 channel groups x 4 kernel rows of a 16-channel
-// slab), each with the full 64 x N register tile: (4 + NT) fragment reads per 4 NT instructions.
+// One workgroup = 64 output channels x NS samples; 8 waves = 4 M tiles x 2 halves of the pixel tiles, every wave over the
+// whole K: no reduction between waves (a first version split K over the waves, 0.42 KB of fragments per instruction
+// instead of 1.3, and paid 3.6 us of LDS reduction rounds per workgroup for it).
 #include "conv_tile.h"
 #include "conv_deep_common.h"
 
@@ -75,9 +76,12 @@ __global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
+// DOWN, K split over the waves (the 5x7 and 17x23 layers): 8 waves = 8 K groups (2 channel groups x 4 kernel rows of a
+// 16-channel slab), each with the full 64 x N register tile - (4 + NT) fragment reads per 4 NT instructions - and LDS
+// reduction rounds before the epilogue.  Measured against the N-split form below: 27 / 27 us against 54 / 46 us on 5x7 /
+// 17x23, 34 against 28 us on 9x12 (whose 9-tile accumulator spills here).
 template <int H_, int W_, int NS_>
-struct DownB {
+struct DownBK {
   static constexpr int H = H_, W = W_, NS = NS_;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W, HP = 2 * Hs + 2;
   // image pixels (rows / columns -2 .. 2Hs-1 / 2Ws-1) and plane strides in pixels: scratch/deep_bf16_strides.py - no bank
@@ -101,7 +105,7 @@ struct DownB {
 };
 
 template <class G>
-__global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int CS, const float* __restrict__ big,
+__global__ __launch_bounds__(512) void deep_down_bf16_ksplit_kernel(int B, int CB, int CS, const float* __restrict__ big,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
                                                              const u16* __restrict__ wsh, const float* __restrict__ bias,
@@ -304,16 +308,242 @@ __global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int 
   BSTAMP(7);
 }
 
-template <int H, int W, int NS>
+// ---------------------------------------------------------------------------------------------------------------
+// DOWN: out[b,cs,oh,ow] = act(bias[cs] + sum_{cb,kh,kw} w[cs,cb,kh,kw] * x'[b,cb,2oh-2+kh,2ow-2+kw])
+template <int H_, int W_, int NS_>
+struct DownB {
+  static constexpr int H = H_, W = W_, NS = NS_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W, HP = 2 * Hs + 2;
+  // image pixels (rows / columns -2 .. 2Hs-1 / 2Ws-1) and plane strides in pixels: scratch/deep_bf16_strides.py - no bank
+  // conflicts on the 5x7 planes, 0.11 / 0.14 extra LDS cycles per fragment read on 9x12 / 17x23
+  static constexpr int WP = (H == 5 && W == 7) ? 12 : (H == 9 && W == 12) ? 23 : (H == 17 && W == 23) ? 28 : 2 * Ws + 2;
+  static constexpr int PLANE = (H == 5 && W == 7) ? 104 : (H == 9 && W == 12) ? 278 : HP * WP;
+  static_assert(WP >= 2 * Ws + 2 && PLANE >= HP * WP, "padded plane");
+  static constexpr int N = NS * P, NT = (N + 15) / 16;
+  static constexpr int CK = 16;                            // channels per slab = two groups of 8
+  static constexpr int A_ROW = 2 * 256 + 32;               // bytes per weight row of a slab: conflict-free fragment reads
+  static constexpr int A_BYTES = 64 * A_ROW;
+  static constexpr int B_BYTES = NS * PLANE * 32;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int QA = 64 * 32 / 512;                 // 16-byte weight pieces per thread and slab
+  static constexpr int QUADS = (HW + 3) / 4;               // pixel quads of a plane (the last one shifted back)
+  static constexpr int ITEMS = NS * 8 * QUADS;             // (sample, channel pair, quad)
+  static constexpr int QB = (ITEMS + 511) / 512;
+  static constexpr int TH = (NT + 1) / 2;                  // pixel tiles of a wave
+  static constexpr int OUT_BYTES = NS * 64 * P * 4;
+  static_assert(STAGE % 16 == 0 && HW >= 4, "alignment");
+  static_assert(OUT_BYTES <= 2 * STAGE, "the output tile fits the stages");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void deep_down_bf16_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift,
+                                                             const u16* __restrict__ wsh, const float* __restrict__ bias,
+                                                             int act, float slope, float* __restrict__ out,
+                                                             double* __restrict__ stats, int groups, int stat_stride,
+                                                             pgv_bn_src in_bn,
+                                                             unsigned long long* __restrict__ stamps) {
+  constexpr int NT = G::NT, HW = G::HW, P = G::P, NS = G::NS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*CB]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  // 8 waves = 4 M tiles x 2 halves of the pixel tiles; every wave runs the whole K of its tiles: no reduction between waves
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mt = wave & 3, nh = wave >> 2;
+  int mb, grp;
+  deep_block(CS / 64, groups, mb, grp);
+  const int cs0 = mb * 64, b0 = grp * NS;
+  BSTAMP(0);
+
+  // zero both stages' images once (the data pixels are rewritten every slab, the padding never)
+  for (int i = tid; i < G::B_BYTES / 16; i += 512) {
+    reinterpret_cast<u32x4*>(ldsb + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+    reinterpret_cast<u32x4*>(ldsb + G::STAGE + G::A_BYTES)[i] = u32x4{0, 0, 0, 0};
+  }
+  for (int i = tid; i < CB; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CB, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CB + i] = sh;
+  }
+
+  // ---- loader coordinates (identical for every slab)
+  const int cbgs = CB / 8;
+  int a_src[G::QA], a_dst[G::QA];
+#pragma unroll
+  for (int i = 0; i < G::QA; ++i) {
+    const int q = tid + 512 * i, row = q >> 5, f = q & 31;
+    a_src[i] = ((cs0 + row) * cbgs) * 256 + f * 16;   // bytes into the shadow (+ 512 per slab)
+    a_dst[i] = row * G::A_ROW + f * 16;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int si = q / (8 * G::QUADS), rem = q - si * (8 * G::QUADS), cp = rem / G::QUADS, qi = rem - cp * G::QUADS;
+    const int p0 = min(4 * qi, HW - 4);
+    const int bs = min(b0 + si, B - 1);   // partial last group: duplicate the last sample (masked at the store)
+    b_src[i] = (bs * CB + 2 * cp) * HW + p0;
+    b_cp[i] = cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pe = p0 + e, r = pe / G::W, c = pe - r * G::W;
+      const int px = si * G::PLANE + (r + 2) * G::WP + c + 2;
+      b_dst[i][e] = px * 32 + (((cp >> 2) ^ ((px >> 3) & 1)) * 16) + (cp & 3) * 4;
+    }
+  }
+  // ---- fragment coordinates (bytes): this wave's tiles nh * TH + tt; per kernel row kh and channel group g
+  constexpr int TH = G::TH;
+  const int a_frag = (mt * 16 + m) * G::A_ROW + kq * 16;   // + 256 per channel group, + 64 per kernel row
+  int boff[TH][4][2];
+#pragma unroll
+  for (int tt = 0; tt < TH; ++tt) {
+    const int n = min((nh * TH + tt) * 16 + m, G::N - 1);
+    const int si = n / P, pix = n - si * P, oh = pix / G::Ws, ow = pix - oh * G::Ws;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const int px = si * G::PLANE + (2 * oh + kh) * G::WP + 2 * ow + kq;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) boff[tt][kh][g] = G::A_BYTES + px * 32 + ((g ^ ((px >> 3) & 1)) * 16);
+    }
+  }
+  const int ntl = min(TH, NT - nh * TH);   // tiles of this wave
+  f32x4 acc[TH];
+#pragma unroll
+  for (int tt = 0; tt < TH; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[cs0 + mt * 16 + 4 * kq + i] : 0.f;
+
+  u32x4 ra[G::QA];
+  f4u rb[G::QB][2];
+  auto issue = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i)
+      ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + a_src[i] + slab * 512);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const float* p = big + b_src[i] + slab * (16 * HW);
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + HW);
+    }
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QA; ++i) *reinterpret_cast<u32x4*>(st + a_dst[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = slab * 16 + 2 * b_cp[i];
+      const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[CB + c], h1 = aff[CB + c + 1];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<unsigned*>(st + G::A_BYTES + b_dst[i][e]) =
+              pack_bf16x2(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1));
+      }
+    }
+  };
+
+  const int nslab = CB / 16;
+  BSTAMP(1);
+  issue(0);
+  __syncthreads();   // images zeroed, affine staged
+  BSTAMP(2);
+  commit(ldsb, 0);
+  if (nslab > 1) issue(1);
+  __syncthreads();
+  BSTAMP(3);
+#pragma unroll 1
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned char* st = ldsb + (s & 1) * G::STAGE;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(st + a_frag + g * 256 + kh * 64);
+#pragma unroll
+        for (int tt = 0; tt < TH; ++tt) {
+          if (tt < ntl) acc[tt] = mfma_bf16_k32(af, *reinterpret_cast<const u32x4*>(st + boff[tt][kh][g]), acc[tt]);
+        }
+      }
+      if (g == 0 && s + 1 < nslab) {   // the next slab goes to the other stage under the running matrix pipe
+        commit(ldsb + ((s + 1) & 1) * G::STAGE, s + 1);
+        if (s + 2 < nslab) issue(s + 2);
+      }
+    }
+    __syncthreads();
+  }
+  BSTAMP(4);
+  // ---- epilogue: bias, activation, into the [sample][channel][P] output tile (the stages are free after the last barrier)
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float* otile = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int tt = 0; tt < TH; ++tt) {
+    const int n = (nh * TH + tt) * 16 + m, si = n / P, pix = n - si * P, cl = mt * 16 + 4 * kq;
+    if (tt < ntl && n < G::N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) otile[(si * 64 + cl + i) * P + pix] = pgv_act_apply(acc[tt][i] + bv[i], ap);
+    }
+  }
+  __syncthreads();
+  BSTAMP(5);
+  // ---- BatchNorm statistics of the written outputs: 8 lanes per channel over the tile, one pair of atomics per channel
+  if (stats) {
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;   // PGV_STATS_COPIES: this XCD's partial copy
+    const int ch = tid >> 3, part = tid & 7;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+      if (b0 + si < B)
+        for (int i = part; i < P; i += 8) {
+          const float v = otile[(si * 64 + ch) * P + i];
+          s1 += v;
+          s2 += v * v;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (part == 0) {
+      atomicAdd(&stats[cs0 + ch], (double)s1);
+      atomicAdd(&stats[CS + cs0 + ch], (double)s2);
+    }
+  }
+  BSTAMP(6);
+#pragma unroll
+  for (int si = 0; si < NS; ++si) {
+    if (b0 + si < B) {
+      float* dst = out + ((int64_t)(b0 + si) * CS + cs0) * P;
+      const float* src = otile + si * 64 * P;
+      for (int i = tid; i < 64 * P; i += 512) dst[i] = src[i];
+    }
+  }
+  BSTAMP(7);
+}
+
+template <int H, int W, int NS, bool KSPLIT>
 int launch_deep_down_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                           const pgv_bn_src* bn) {
-  using G = DownB<H, W, NS>;
+  using G = typename std::conditional<KSPLIT, DownBK<H, W, NS>, DownB<H, W, NS>>::type;
   if (d->Cs % 64 || d->Cb % 16 || !d->w_shadow) return 0;
   if ((int64_t)d->B * d->Cb * G::HW * 4 >= (int64_t)1 << 31 || (int64_t)d->Cs * d->Cb * 32 >= (int64_t)1 << 31) return 0;
   const size_t bytes = 2 * (size_t)G::STAGE + sizeof(float) * (2 * (size_t)d->Cb + 8);
   if (bytes > (size_t)kMaxLds) return 0;
-  auto kern = deep_down_bf16_kernel<G>;
+  typedef void (*kern_t)(int, int, int, const float*, const float*, const float*, const u16*, const float*, int, float, float*,
+                         double*, int, int, pgv_bn_src, unsigned long long*);
+  kern_t kern;
+  if constexpr (KSPLIT)
+    kern = deep_down_bf16_ksplit_kernel<G>;
+  else
+    kern = deep_down_bf16_kernel<G>;
   static bool attr_done = false;
   int rc = raise_lds_limit(kern, &attr_done, "conv_down_deep_bf16");
   if (rc) return rc;
@@ -1813,9 +2043,9 @@ int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const floa
   if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && !bn && k1_bf16_shape(d))
     return launch_k1_fwd_bf16(d, false, big, in_scale, in_shift, bias, act, slope, out, stats, st);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
-  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
-  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
-  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down_bf16<5, 7, 8>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1, true>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4, false>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_down_bf16<5, 7, 8, true>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   return 0;
 }
 
