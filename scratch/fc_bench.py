@@ -9,15 +9,18 @@ if os.environ.get('FC_TILES'):
     _lib.load().pgv_dbg_set_gemm_tiles(int(os.environ['FC_TILES']))
 if os.environ.get('FC_BF16'):
     ops.set_compute_dtype('bf16')
+FEAT = int(os.environ.get('FC_FEAT', 25024))
 for dz in (64, 512):
-    x = torch.randn(B, 25024, device='cuda'); We = torch.randn(2 * dz, 25024, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
+    x = torch.randn(B, FEAT, device='cuda'); We = torch.randn(2 * dz, FEAT, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
     gye = torch.randn(B, 2 * dz, device='cuda'); gWe = torch.empty_like(We)
-    z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(25024, dz, device='cuda') * 0.01; bd = torch.zeros(25024, device='cuda')
-    gyd = torch.randn(B, 25024, device='cuda'); gWd = torch.empty_like(Wd)
+    z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(FEAT, dz, device='cuda') * 0.01; bd = torch.zeros(FEAT, device='cuda')
+    gyd = torch.randn(B, FEAT, device='cuda'); gWd = torch.empty_like(Wd)
     for pol in (0, 0, 1):
+        if os.environ.get('FC_BF16') and pol == 1:
+            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(4096)   # third line: gemm.hip's bf16 MFMA tiles
         _lib.load().pgv_set_kernel_policy(pol)
         ts = [bench.time_kernel(f, iters=5) * 1e3 for f in (
             lambda: ops.linear_fwd(x, We, be), lambda: ops.linear_dgrad(gye, We), lambda: ops.linear_wgrad(gye, x, gWe),
             lambda: ops.linear_fwd(z, Wd, bd), lambda: ops.linear_dgrad(gyd, Wd), lambda: ops.linear_wgrad(gyd, z, gWd))]
         print(f"dz={dz} policy {pol}: enc fwd/dgrad/wgrad {ts[0]:.1f} {ts[1]:.1f} {ts[2]:.1f} | dec {ts[3]:.1f} {ts[4]:.1f} {ts[5]:.1f} | sum {sum(ts):.1f} us")
-    _lib.load().pgv_set_kernel_policy(0)
+    _lib.load().pgv_set_kernel_policy(0); _lib.load().pgv_dbg_set_gemm_variant(0)
