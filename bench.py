@@ -428,12 +428,11 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
         achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, matrix_peak, 'TFLOP/s'
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation: the file is measured on
-    # the fp32 4-layer model at batch 256, so it only speaks for launches of that configuration (same labels on the
-    # 8-layer / bf16 models are other kernels or other fusions)
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation and THIS configuration at batch
+    # 256 (the same labels on another model / operand mode are other kernels or other fusions)
     traffic = None
     try:
-        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r3_traffic.json')) as f:
+        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r4_traffic.json')) as f:
             entry = json.load(f).get(worst['launch'])
         if entry and B == 256 and traffic_ok:
             traffic = entry['hbm_bytes_per_launch']
@@ -644,9 +643,13 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     if rank == 0 and world == 1 and with_cpu and frontend is None:
         h2d = h2d_inclusive(step, x)
     if rank == 0 and with_roofline:
+        # the PMC passes exist for three configurations (profiles/README.md); other configurations report traffic null
+        tfile = {('speccnn4l1_bn', 'fp32', 64): 'r4_traffic.json', ('speccnn8l1_bn', 'fp32', 64): 'r4_traffic_8l.json',
+                 ('speccnn8l1_bn', 'bf16', 512): 'r4_traffic_8l_bf16.json'}.get((args.arch, args.dtype, args.dim_z))
         roof, table = measure_roofline(ae, args.batch, device, ms, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
                                        else F32_MATRIX_PEAK_TFLOPS, frontend=frontend,
-                                       traffic_ok=(args.arch == 'speccnn4l1_bn' and args.dtype == 'fp32'))
+                                       traffic_file=os.path.join(ROOT, 'profiles', tfile) if tfile else None,
+                                       traffic_ok=tfile is not None)
     if rank == 0 and world == 1 and with_cpu:
         cpu = cpu_baseline(args.arch, args.dim_z, args.cpu_batch)
     if world > 1:
