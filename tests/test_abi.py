@@ -51,3 +51,33 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b"inconsistent" in lib.pgv_last_error()
     assert lib.pgv_stft_mel(16, 1, 1000, 512, 256, 4, 16, 1.0, None, None, None, 0, 1e-6, 1.0, 0.0, 16, None) == -1
     assert b"n_fft=1024" in lib.pgv_last_error()
+
+
+def test_weight_shadow_sizes_and_descriptor_layout_do_not_need_a_gpu():
+    """ABI v11: ``pgv_conv_desc`` ends in the ``w_shadow`` pointer (twelve int32 then one pointer: 56 bytes), and
+    ``pgv_conv_weight_shadow_bytes`` answers from the descriptor alone - two bf16 layouts (4 bytes per weight) for the
+    layers that have bf16-native kernels in bf16 operand mode, 0 for every other layer."""
+    import ctypes
+    from preset_gen_vae_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpgv_hip.so not built")
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.ConvDesc) == 56 and _lib.ConvDesc.w_shadow.offset == 48
+    BF16 = 2   # PGV_COMPUTE_BF16
+
+    def nbytes(Cb, Cs, k, s, p, Hb, Wb, flags=BF16):
+        Hs, Ws = (Hb + 2 * p - k) // s + 1, (Wb + 2 * p - k) // s + 1
+        d = _lib.ConvDesc(1, Cb, Hb, Wb, Cs, Hs, Ws, k, k, s, p, flags, None)
+        return lib.pgv_conv_weight_shadow_bytes(ctypes.byref(d))
+
+    for Cb, Cs, k, s, p, Hb, Wb in [(64, 128, 4, 2, 2, 17, 23), (128, 256, 4, 2, 2, 9, 12), (256, 512, 4, 2, 2, 5, 7),
+                                    (512, 2048, 1, 1, 0, 3, 4), (32, 64, 4, 2, 2, 33, 45), (16, 32, 4, 2, 2, 65, 88)]:
+        assert nbytes(Cb, Cs, k, s, p, Hb, Wb) == 4 * Cb * Cs * k * k
+    # the 129x174 and 1-channel layers keep their band / direct kernels; no layer has a shadow for the deep layers' shapes
+    # at other plane sizes
+    for case in [(8, 16, 4, 2, 2, 129, 174), (1, 8, 5, 2, 2, 257, 347), (64, 128, 4, 2, 2, 19, 23), (3, 5, 4, 2, 2, 10, 13)]:
+        assert nbytes(*case) == 0
+    # writing a shadow for a layer that has none is an argument error, reported before any launch
+    d = _lib.ConvDesc(1, 8, 129, 174, 16, 65, 88, 4, 4, 2, 2, BF16, None)
+    assert lib.pgv_conv_weight_shadow(ctypes.byref(d), 16, 16, None) == -1
+    assert b"no weight shadow" in lib.pgv_last_error()
