@@ -97,6 +97,10 @@ int pgv_conv_up(const pgv_conv_desc* d, const float* small, const float* in_scal
  * launch, to be repeated whenever w changes: once per optimizer step); calls pass it in pgv_conv_desc.w_shadow. */
 int64_t pgv_conv_weight_shadow_bytes(const pgv_conv_desc* d);
 int pgv_conv_weight_shadow(const pgv_conv_desc* d, const float* w, void* shadow, void* stream);
+/* The shadows of n <= 8 layers in one launch (the layers of one conv stack: a launch per layer costs 4-6 us of latency each);
+ * every layer must have a shadow (pgv_conv_weight_shadow_bytes > 0).  ABI v12. */
+int pgv_conv_weight_shadows(int n, const pgv_conv_desc* const* descs, const float* const* ws, void* const* shadows,
+                            void* stream);
 
 /* Optional fusion for input-gradient calls (backward of model/layer.py:21-26 under train.py:246).  The product of the
  * call is g, the gradient w.r.t. the BatchNorm output o of the next-lower block; with a pgv_bwd_fuse it is never

@@ -90,6 +90,7 @@ SIGNATURES = {
     "pgv_conv_up_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_weight_shadow_bytes": (c_int64, [_DESC]),
     "pgv_conv_weight_shadow": (c_int, [_DESC, _P, _P, _P]),
+    "pgv_conv_weight_shadows": (c_int, [c_int, POINTER(_DESC), POINTER(c_void_p), POINTER(c_void_p), _P]),
     "pgv_conv_wgrad_workspace": (c_int64, [_DESC]),
     "pgv_conv_wgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "pgv_conv_wgrad_coef": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _COEF, _P]),

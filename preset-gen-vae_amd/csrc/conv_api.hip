@@ -31,7 +31,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 11; }
+int pgv_abi_version(void) { return 12; }
 const char* pgv_last_error(void) { return g_err; }
 static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {
@@ -73,6 +73,21 @@ int pgv_conv_weight_shadow(const pgv_conv_desc* d, const float* w, void* shadow,
                 "pgv_conv_weight_shadow: null or misaligned pointer");
   PGV_CHECK_ARG(pgv_conv_weight_shadow_bytes_impl(d) > 0, "pgv_conv_weight_shadow: this layer has no weight shadow");
   rc = pgv_conv_weight_shadow_impl(d, w, shadow, pgv_stream(stream));
+  return rc < 0 ? rc : PGV_OK;
+}
+
+int pgv_conv_weight_shadows(int n, const pgv_conv_desc* const* descs, const float* const* ws, void* const* shadows,
+                            void* stream) {
+  PGV_CHECK_ARG(n >= 0 && n <= 8 && (n == 0 || (descs && ws && shadows)), "pgv_conv_weight_shadows: 0 <= n <= 8 layers");
+  for (int i = 0; i < n; ++i) {
+    int rc = check_desc(descs[i], "pgv_conv_weight_shadows");
+    if (rc) return rc;
+    PGV_CHECK_ARG(ws[i] && shadows[i] && ((uintptr_t)shadows[i] & 15) == 0 && ((uintptr_t)ws[i] & 15) == 0,
+                  "pgv_conv_weight_shadows: null or misaligned pointer");
+    PGV_CHECK_ARG(pgv_conv_weight_shadow_bytes_impl(descs[i]) > 0, "pgv_conv_weight_shadows: layer %d has no weight shadow", i);
+  }
+  if (n == 0) return PGV_OK;
+  const int rc = pgv_conv_weight_shadows_impl(n, descs, ws, shadows, pgv_stream(stream));
   return rc < 0 ? rc : PGV_OK;
 }
 

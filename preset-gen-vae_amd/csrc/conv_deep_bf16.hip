@@ -43,10 +43,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 // Weight shadows.  down: D[cs][cb/8][kh*4+kw][8] (M = cs);  up: U[cb][cs/8][phase][th*2+tw][8] (M = cb), phase = 2ph+pw,
 // taps kh = ph + 2th, kw = pw + 2tw.  One thread = (cs, channel group of 8 cb, kernel row): 8 x 16-byte reads, 4 x 16-byte
 // writes of the down shadow; the up shadow is written by the thread that owns (cb, group of 8 cs, kernel row).
-__global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restrict__ w, int CS, int CB,
-                                                        u16* __restrict__ down, u16* __restrict__ up) {
-  const int items = CS * (CB / 8) * 4;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+__device__ __forceinline__ void shadow_k4_item(int it, const float* __restrict__ w, int CS, int CB, u16* __restrict__ down,
+                                               u16* __restrict__ up) {
+  {
     const int kh = it & 3, g = (it >> 2) % (CB / 8), cs = (it >> 2) / (CB / 8);
     f32x4 v[8];
 #pragma unroll
@@ -58,8 +57,7 @@ __global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restric
                       pack_bf16x2(v[6][kw], v[7][kw])};
   }
   if (!up) return;
-  const int items_u = CB * (CS / 8) * 4;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < items_u; it += gridDim.x * 256) {
+  {
     const int kh = it & 3, cb = (it >> 2) % CB, g = (it >> 2) / CB;   // cb fastest: the reads of a wave are 64-byte pieces
     f32x4 v[8];
 #pragma unroll
@@ -73,6 +71,11 @@ __global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restric
                    pack_bf16x2(v[6][kw], v[7][kw])};
     }
   }
+}
+__global__ __launch_bounds__(256) void deep_shadow_kernel(const float* __restrict__ w, int CS, int CB,
+                                                        u16* __restrict__ down, u16* __restrict__ up) {
+  const int items = CS * (CB / 8) * 4;   // (= CB * (CS / 8) * 4: the same item count serves both layouts)
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) shadow_k4_item(it, w, CS, CB, down, up);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1215,21 +1218,43 @@ int deep_wgrad_bf16_split(const pgv_conv_desc* d) {
 // Wt = the weight; transposed: m = cb, k = cs, Wt = its transpose), the shadow holds both as [m][k] bf16.  One workgroup =
 // 128 output channels (16 per wave) x 4 samples (48 pixels = 3 tiles): every wave runs the whole K, no reduction.  Images
 // are channel-innermost, 64 channels = 128 bytes per pixel, the 16-byte group g of a pixel stored at g ^ (pixel & 7).
+__device__ __forceinline__ void shadow_k1_item(int it, const float* __restrict__ w, int CS, int CB, u16* __restrict__ down,
+                                               u16* __restrict__ up) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8), b = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8 + 4);
+  *reinterpret_cast<u32x4*>(down + (size_t)it * 8) =
+      u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  // transposed: up[cb][8 consecutive cs]; cb fastest across the lanes (coalesced reads of 8 weight rows)
+  const int cb = it % CB, g = it / CB;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = w[(size_t)(g * 8 + c) * CB + cb];
+  *reinterpret_cast<u32x4*>(up + (size_t)cb * CS + g * 8) =
+      u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+}
 __global__ __launch_bounds__(256) void k1_shadow_kernel(const float* __restrict__ w, int CS, int CB, u16* __restrict__ down,
                                                         u16* __restrict__ up) {
   const int n8 = CS * CB / 8;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < n8; it += gridDim.x * 256) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8), b = *reinterpret_cast<const f32x4*>(w + (size_t)it * 8 + 4);
-    *reinterpret_cast<u32x4*>(down + (size_t)it * 8) =
-        u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
-    // transposed: up[cb][8 consecutive cs]; cb fastest across the lanes (coalesced reads of 8 weight rows)
-    const int cb = it % CB, g = it / CB;
-    float v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = w[(size_t)(g * 8 + c) * CB + cb];
-    *reinterpret_cast<u32x4*>(up + (size_t)cb * CS + g * 8) =
-        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-  }
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < n8; it += gridDim.x * 256) shadow_k1_item(it, w, CS, CB, down, up);
+}
+
+// the shadows of several layers in ONE launch (a conv stack's forward pass: 4 - 6 us of launch latency per layer otherwise)
+struct ShadowTable {
+  static constexpr int MAXN = 8;
+  const float* w[MAXN];
+  u16* down[MAXN];
+  int CS[MAXN], CB[MAXN], k1[MAXN], items[MAXN], blk0[MAXN + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.blk0[e + 1]) ++e;
+  const int it = ((int)blockIdx.x - t.blk0[e]) * 256 + threadIdx.x;
+  if (it >= t.items[e]) return;
+  u16* up = t.down[e] + (size_t)t.CS[e] * t.CB[e] * (t.k1[e] ? 1 : 16);
+  if (t.k1[e])
+    shadow_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
+  else
+    shadow_k4_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
 }
 
 struct K1B {
@@ -2132,4 +2157,27 @@ int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float
     return launch_down_big_bf16<DownBig<32, 64, 33, 45, 4, 48, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   }
   return launch_down_big_bf16<DownBig<16, 32, 65, 88, 2, 93, 3>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+}
+
+// the shadows of n <= 8 layers in one launch (every descriptor must have a shadow: pgv_conv_weight_shadow_bytes > 0)
+int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const float* const* ws, void* const* shadows,
+                                 hipStream_t st) {
+  ShadowTable t;
+  t.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const pgv_conv_desc* d = descs[i];
+    const bool k1 = k1_bf16_shape(d);
+    if (!k1 && !deep_bf16_shape(d) && !up_big_bf16_shape(d)) return 0;
+    t.w[i] = ws[i];
+    t.down[i] = (u16*)shadows[i];
+    t.CS[i] = d->Cs, t.CB[i] = d->Cb, t.k1[i] = k1 ? 1 : 0;
+    t.items[i] = k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4;
+    t.blk0[i] = blocks;
+    blocks += (t.items[i] + 255) / 256;
+  }
+  t.blk0[n] = blocks;
+  hipLaunchKernelGGL(shadow_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t);
+  PGV_CHECK_LAUNCH("conv_weight_shadows");
+  return 1;
 }

@@ -144,3 +144,5 @@ int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const fl
 int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                            hipStream_t st, const pgv_bn_src* bn);
+int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const float* const* ws, void* const* shadows,
+                                 hipStream_t st);

@@ -192,7 +192,16 @@ class ConvStackFn(torch.autograd.Function):
                 n_stats += sc_b * 2 * blk.c_out
         arena = _step_zeros(params[0], n_stats, torch.float64, 'stats', dev) if n_stats else None
         a_off = 0
+        # bf16 operand mode: the weights of the layers with bf16-native kernels rounded once per step into the layouts those
+        # kernels stream (None otherwise) - one launch for the whole stack; the backward pass multiplies by the same weights
+        pairs, hh, ww, pj = [], x.shape[2], x.shape[3], 0
         for blk in blocks:
+            go = blk.geom(hh, ww)
+            pairs.append((go, params[pj]))
+            hh, ww = (go.Hb, go.Wb) if blk.up else (go.Hs, go.Ws)
+            pj += 2 + (2 if blk.bn is not None else 0)
+        shadows = ops.conv_weight_shadows(pairs) if ops.compute_dtype() == 'bf16' else [None] * len(pairs)
+        for bi, blk in enumerate(blocks):
             w, b = params[pi], params[pi + 1]
             pi += 2
             g = blk.geom(cur.shape[2], cur.shape[3])
@@ -208,9 +217,7 @@ class ConvStackFn(torch.autograd.Function):
                 stats = arena[a_off:a_off + SC * 2 * C]
                 a_off += SC * 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
-            # bf16 operand mode, deep layers: the weight rounded once per step into the layouts the bf16-native kernels
-            # stream (ops.conv_weight_shadow); None otherwise.  The backward pass multiplies by the same weight.
-            w_sh = ops.conv_weight_shadow(g, w)
+            w_sh = shadows[bi]
             # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
             if pending is not None:
                 a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending,

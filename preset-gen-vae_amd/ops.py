@@ -151,6 +151,32 @@ def conv_weight_shadow(geom, w):
     return sh
 
 
+def conv_weight_shadows(pairs):
+    """``conv_weight_shadow`` for the (geom, w) pairs of a conv stack in ONE launch (``pgv_conv_weight_shadows``): a list with
+    the shadow of every pair, None where the layer has none."""
+    todo = [(i, g, w) for i, (g, w) in enumerate(pairs) if g.shadow_bytes() > 0]
+    out = [None] * len(pairs)
+    if not todo:
+        return out
+    if len(todo) > 8:
+        for i, g, w in todo:
+            out[i] = conv_weight_shadow(g, w)
+        return out
+    sizes = [(g.shadow_bytes() + 255) // 256 * 256 for _, g, _ in todo]
+    buf = torch.empty(sum(sizes), device=todo[0][2].device, dtype=torch.uint8)
+    n, off = len(todo), 0
+    descs = (ctypes.POINTER(ConvDesc) * n)()
+    ws, shs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    for k, (i, g, w) in enumerate(todo):
+        _chk(w)
+        out[i] = buf[off:off + g.shadow_bytes()]
+        descs[k] = ctypes.pointer(g.desc(1))
+        ws[k], shs[k] = w.data_ptr(), out[i].data_ptr()
+        off += sizes[k]
+    _lib.check(_lib.load().pgv_conv_weight_shadows(n, descs, ws, shs, _stream()), "pgv_conv_weight_shadows")
+    return out
+
+
 def conv_down(geom, big, w, bias, act, slope, in_scale=None, in_shift=None, stats=None, out=None, prezeroed=False,
               bwd_fuse=None, in_bn=None, stats_copies=False, w_shadow=None):
     """``prezeroed``: ``stats`` already holds zeros (PGV_PREZEROED) - the call accumulates without clearing it.

@@ -388,6 +388,28 @@ def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
         ops.set_compute_dtype('fp32')
 
 
+def test_weight_shadows_of_a_stack_in_one_launch(ops):
+    """pgv_conv_weight_shadows (one launch for the layers of a conv stack) writes exactly what pgv_conv_weight_shadow writes
+    layer by layer; layers without a shadow come back as None; fp32 mode has none at all."""
+    shapes = [(8, 16, 4, 2, 2, 129, 174), (16, 32, 4, 2, 2, 65, 88), (32, 64, 4, 2, 2, 33, 45), (64, 128, 4, 2, 2, 17, 23),
+              (128, 256, 4, 2, 2, 9, 12), (256, 512, 4, 2, 2, 5, 7), (512, 2048, 1, 1, 0, 3, 4)]
+    pairs = []
+    for i, (Cb, Cs, k, s, p, Hb, Wb) in enumerate(shapes):
+        w = dev(synth_vec((Cs, Cb, k, k), 0.37 + i, 0.11 * i) * 0.05)
+        pairs.append((ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb), w))
+    assert ops.conv_weight_shadows(pairs) == [None] * len(pairs)
+    ops.set_compute_dtype('bf16')
+    try:
+        many = ops.conv_weight_shadows(pairs)
+        assert many[0] is None and all(m is not None for m in many[1:])
+        for (g, w), m in zip(pairs[1:], many[1:]):
+            one = ops.conv_weight_shadow(g, w)
+            assert m.numel() == one.numel() == 4 * w.numel() and torch.equal(m, one)
+            assert m.data_ptr() % 16 == 0
+    finally:
+        ops.set_compute_dtype('fp32')
+
+
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 2), (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3),
                                   (3, 5, 4, 2, 2, 10, 13, 2)])
 def test_conv_prezeroed_outputs_accumulate(ops, case):
@@ -925,7 +947,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 11
+    assert _lib.load().pgv_abi_version() == 12
 
 
 def test_empty_batch(ops):
