@@ -77,7 +77,7 @@ for which, (Cb, Cs, Hb, Wb) in CASES.items():
             ss = torch.addcmul(ssh.view(1, -1, 1, 1), small[:nb], ssc.view(1, -1, 1, 1)) if form == 'small' else small[:nb]
             wv = w.double().clone().requires_grad_(True)
             F.conv2d(bf(bb), wv, None, stride=ST, padding=PD).backward(bf(ss))
-            for name, v in (('old', 8), ('new', 0)):
+            for name, v in (('old', 8), ('new', 0)) + ((('alt64', 64),) if which == '9x12' else ()) + ((('alt128', 128),) if which == '17x23' else ()):
                 lib.pgv_dbg_set_deep_bf16_variant(v)
                 gs = torch.empty_like(w)
                 ops.conv_wgrad(g, big[:nb].contiguous(), small[:nb].contiguous(), gs, **kw)
