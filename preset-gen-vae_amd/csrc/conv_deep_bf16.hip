@@ -1936,9 +1936,8 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
 
 bool up_big_bf16_shape(const pgv_conv_desc* d) {
   if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
-  // (16 -> 8 channels onto 129x174 stays on the band kernel: 62 us there, 75 us here with bands of 4 rows and two
-  // workgroups per CU, 89 us with bands of 8 rows - half-empty M tiles and a 44 KB output tile per 1.4 k pixels)
-  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32);
+  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
+         (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16);   // (129x174: the shadow exists, the routing decides)
 }
 
 template <class G>
@@ -2237,7 +2236,8 @@ __global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* 
 
 bool down_big_bf16_shape(const pgv_conv_desc* d) {
   if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
-  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32);
+  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
+         (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16);
 }
 
 template <class G>
@@ -2384,7 +2384,11 @@ int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const fl
                          hipStream_t st, const pgv_bn_src* bn) {
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
   if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 65) return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // (16 -> 8 channels onto 129x174 stays on the band / wave-specialised kernels: 65 us plain and 112 us fused there, 78 / 166 us
+  // here - 8 output channels leave half of every M tile empty and a whole wave per channel moves the band out; A/B knob)
+  if (!(g_deep_bf16_dbg & 256)) return 0;
+  return launch_up_big_bf16<UpBig<8, 16, 129, 174, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
 
 // the stride-2 convolutions from 33x45 and 65x88 (1 / 3 = launched; 3: with the class sums of the fused epilogue)
@@ -2398,7 +2402,9 @@ int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float
     if (!fuse) return 0;
     return launch_down_big_bf16<DownBig<32, 64, 33, 45, 4, 48, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   }
-  return launch_down_big_bf16<DownBig<16, 32, 65, 88, 2, 93, 3>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 65) return launch_down_big_bf16<DownBig<16, 32, 65, 88, 2, 93, 3>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // 8 -> 16 channels from 129x174: 70 -> 62 us plain, 110 -> 81 us fused against the band / wave-specialised kernels
+  return launch_down_big_bf16<DownBig<8, 16, 129, 174, 2, 178, 0>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
 
 // the shadows of n <= 8 layers in one launch (every descriptor must have a shadow: pgv_conv_weight_shadow_bytes > 0)

@@ -10,6 +10,8 @@ lib = _lib.load()
 B = int(os.environ.get('B', 256))
 WHAT = os.environ.get('WHAT', 'down,up').split(',')
 ops.set_compute_dtype('bf16')
+if os.environ.get('KNOB'):
+    lib.pgv_dbg_set_deep_bf16_variant(int(os.environ['KNOB']))
 def bf(t): return t.float().bfloat16().double()
 def timeit(fn, n=30):
     for _ in range(5): fn()

@@ -71,13 +71,13 @@ def test_weight_shadow_sizes_and_descriptor_layout_do_not_need_a_gpu():
         return lib.pgv_conv_weight_shadow_bytes(ctypes.byref(d))
 
     for Cb, Cs, k, s, p, Hb, Wb in [(64, 128, 4, 2, 2, 17, 23), (128, 256, 4, 2, 2, 9, 12), (256, 512, 4, 2, 2, 5, 7),
-                                    (512, 2048, 1, 1, 0, 3, 4), (32, 64, 4, 2, 2, 33, 45), (16, 32, 4, 2, 2, 65, 88)]:
+                                    (512, 2048, 1, 1, 0, 3, 4), (32, 64, 4, 2, 2, 33, 45), (16, 32, 4, 2, 2, 65, 88),
+                                    (8, 16, 4, 2, 2, 129, 174)]:
         assert nbytes(Cb, Cs, k, s, p, Hb, Wb) == 4 * Cb * Cs * k * k
-    # the 129x174 and 1-channel layers keep their band / direct kernels; no layer has a shadow for the deep layers' shapes
-    # at other plane sizes
-    for case in [(8, 16, 4, 2, 2, 129, 174), (1, 8, 5, 2, 2, 257, 347), (64, 128, 4, 2, 2, 19, 23), (3, 5, 4, 2, 2, 10, 13)]:
+    # the 1-channel layers keep their direct kernels; no layer has a shadow for the deep layers' shapes at other plane sizes
+    for case in [(1, 8, 5, 2, 2, 257, 347), (64, 128, 4, 2, 2, 19, 23), (3, 5, 4, 2, 2, 10, 13), (8, 16, 4, 2, 2, 128, 174)]:
         assert nbytes(*case) == 0
     # writing a shadow for a layer that has none is an argument error, reported before any launch
-    d = _lib.ConvDesc(1, 8, 129, 174, 16, 65, 88, 4, 4, 2, 2, BF16, None)
+    d = _lib.ConvDesc(1, 1, 257, 347, 8, 129, 174, 5, 5, 2, 2, BF16, None)
     assert lib.pgv_conv_weight_shadow(ctypes.byref(d), 16, 16, None) == -1
     assert b"no weight shadow" in lib.pgv_last_error()

@@ -334,7 +334,7 @@ def test_deep_kernels_many_units(ops, case, mode):
                                   (256, 512, 4, 2, 2, 5, 7, 16), (128, 192, 4, 2, 2, 9, 12, 3),
                                   (512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4),
                                   (32, 64, 4, 2, 2, 33, 45, 5), (32, 64, 4, 2, 2, 33, 45, 70), (16, 32, 4, 2, 2, 65, 88, 5),
-                                  (16, 32, 4, 2, 2, 65, 88, 40)])
+                                  (16, 32, 4, 2, 2, 65, 88, 40), (8, 16, 4, 2, 2, 129, 174, 3), (8, 16, 4, 2, 2, 129, 174, 20)])
 def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
     """conv_deep_bf16.hip: the bf16-native kernels of the deep layers behind ``pgv_conv_desc.w_shadow`` (bf16 weight shadow
     written by pgv_conv_weight_shadow), several sample groups with a partial last one: against float64 convolutions of the
@@ -400,6 +400,7 @@ def test_weight_shadows_of_a_stack_in_one_launch(ops):
     assert ops.conv_weight_shadows(pairs) == [None] * len(pairs)
     ops.set_compute_dtype('bf16')
     try:
+        pairs.insert(0, (ops.ConvGeom(1, 8, 5, 2, 2, 257, 347), dev(synth_vec((8, 1, 5, 5), 0.2, 0.3))))
         many = ops.conv_weight_shadows(pairs)
         assert many[0] is None and all(m is not None for m in many[1:])
         for (g, w), m in zip(pairs[1:], many[1:]):
