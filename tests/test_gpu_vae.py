@@ -309,10 +309,17 @@ def test_train_step_bf16_operand_mode_vs_oracle(arch, dim_z):
         assert err < 3 * max(self_noise, 1e-4), (key, err, self_noise)
     # the latent code (4 / 8 blocks deep) is still far closer to the bf16 oracle than the fp32 mode is
     assert rel_l2(out['z_mu_logvar'], ora['z_mu_logvar']) < 0.5 * rel_l2(ora_fp32['z_mu_logvar'], ora['z_mu_logvar'])
+    # The scalar losses: |oracle64 - oracle32| is ONE sample of a scalar's noise and can be small by chance, so the scale
+    # also takes 1/16 of the self-noise of the tensor the loss is a mean over (measured, scratch/bf16_step_noise.py: the same
+    # step with the 129x174 layer on two kernel families - another summation order, nothing else - lands at -1.8e-5 and
+    # +4.2e-4 of the oracle's latent loss while z_mu_logvar stays at 4.0e-3 / 4.1e-3 against a self-noise of 3.4e-3)
+    tensor_noise = {'latent': rel_l2(ora64['z_mu_logvar'], ora['z_mu_logvar']), 'recons': rel_l2(ora64['x_out'], ora['x_out'])}
+    tensor_noise['total'] = max(tensor_noise.values())
     for key in ('recons', 'latent', 'total'):
         ref = ora[key].item()
         self_noise = abs(ora64[key].item() - ref) / abs(ref)
-        assert abs(out[key].item() - ref) <= 3 * max(self_noise, 1e-4) * abs(ref), (key, out[key].item(), ref)
+        bar = 3 * max(self_noise, 1e-4, tensor_noise[key] / 16)
+        assert abs(out[key].item() - ref) <= bar * abs(ref), (key, out[key].item(), ref, bar)
     params = dict(ae.named_parameters())
     errs, noises = [], []
     for k, gr in ora['grads'].items():
