@@ -22,7 +22,11 @@ extern "C" void pgv_dbg_set_deep_bf16_stamps(void* p) { g_deep_bf16_stamps = (un
   do {                                                                                              \
     if (stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 77)) stamps[(blockIdx.x ? 16 : 0) + (k)] = clock64(); \
   } while (0)
-static int g_deep_bf16_dbg = 0;   // A/B knob of the timing scripts: 8 = the weight gradient stays on the fp32-image kernels
+// A/B knobs of the timing scripts (scratch/time_deep_bf16.py, pgv_dbg_set_deep_bf16_variant; no effect on results beyond the
+// summation order): 8 = deep / 1x1 weight gradients stay on the fp32-image kernels, 16 / 32 = no up_big / down_big kernels,
+// 64 = 9x12 weight gradient on 16-sample blocks, 128 = 17x23 weight gradient on 8-sample blocks, 256 = 129x174 transposed
+// convolution on up_big
+static int g_deep_bf16_dbg = 0;
 extern "C" int pgv_dbg_set_deep_bf16_variant(int v) {
   const int old = g_deep_bf16_dbg;
   g_deep_bf16_dbg = v;
