@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--input", default="spectrograms", choices=["spectrograms", "audio"],
                     help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
                          "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
+    ap.add_argument("--fp32-products", default="native", choices=["native", "bf16x6"],
+                    help="fp32 mode only, opt-in: layers with a split-product kernel evaluate every fp32 product as six "
+                         "bf16 matrix instructions on exact three-way operand splits (DESIGN.md 3.11); default native")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--dist-mode", default="bucket-graphs", choices=["bucket-graphs", "eager", "two-graph"],
                     help="N > 1 launch mode: bucket-graphs = the captured step cut at the gradient-bucket boundaries "
@@ -574,6 +577,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.train_step import VAETrainStep
     ops.set_compute_dtype(args.dtype)
+    ops.set_fp32_products(args.fp32_products if args.dtype == 'fp32' else 'native')
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture, mc.dim_z = args.arch, args.dim_z
     tc.minibatch_size = args.batch
@@ -671,6 +675,9 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                               if args.input == "audio" else ""),
                "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": launch,
                "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
+        if ops.fp32_products() != 'native':
+            cfg["fp32_products"] = ("bf16x6 on the 65x88 transposed convolution (six bf16 matrix instructions per fp32 "
+                                    "product on exact three-way operand splits, fp32 accumulation; opt-in)")
         if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
@@ -691,6 +698,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         step.grad_sync.uninstall()
     del step, ae, x
     ops.set_compute_dtype('fp32')
+    ops.set_fp32_products('native')
     torch.cuda.empty_cache()
     return line
 

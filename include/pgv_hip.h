@@ -58,6 +58,13 @@ typedef struct pgv_conv_desc {
  * BatchNorm affine, weights, gradients) are rounded to bfloat16 (RNE) and multiplied on the bf16 matrix cores
  * (v_mfma_f32_16x16x16_bf16) with fp32 accumulation; tensors in HBM, BatchNorm, losses and Adam stay fp32. */
 #define PGV_COMPUTE_BF16 2
+/* fp32 products evaluated as SIX bf16 matrix instructions (opt-in, fp32 mode only; ignored together with PGV_COMPUTE_BF16):
+ * every operand value x is held as three bfloat16 terms x1 + x2 + x3 (exact), the product as the six largest cross terms
+ * with fp32 accumulation - the dropped terms are below 2^-23 of the product, the measured error against float64 is below
+ * that of v_mfma_f32_16x16x4_f32 (scratch/ubench/bf16x6.hip) - at 6 / 16 of the fp32 instruction time.  Only the layers
+ * with a kernel for it change (pgv_conv_weight_shadow_bytes > 0 under this flag: they need the weight shadow); every other
+ * call computes as without the flag. */
+#define PGV_COMPUTE_F32_SPLIT 8
 /* The BatchNorm statistics output of a forward conv call (`stats`) is PGV_CLS_COPIES partial copies [copies][2C] of
  * doubles, zeroed by the caller, and a workgroup may add into any of them (the wave-specialised kernels use the copy of
  * their XCD: 256 workgroups finishing together on ONE copy serialise on its 2C addresses, 7-8 us per launch); they are

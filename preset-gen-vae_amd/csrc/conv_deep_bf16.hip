@@ -1478,6 +1478,37 @@ __global__ __launch_bounds__(256) void k1_shadow_kernel(const float* __restrict_
   for (int it = blockIdx.x * 256 + threadIdx.x; it < n8; it += gridDim.x * 256) shadow_k1_item(it, w, CS, CB, down, up);
 }
 
+// PGV_COMPUTE_F32_SPLIT shadow: three bf16 planes (hi, mid, lo: w = w1 + w2 + w3 exactly) of the up layout [cb][cs/8][phase][tap][8]
+__device__ __forceinline__ void shadow_split_item(int it, const float* __restrict__ w, int CS, int CB, u16* __restrict__ up3) {
+  const int kh = it & 3, cb = (it >> 2) % CB, g = (it >> 2) / CB;
+  f32x4 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const f32x4*>(w + ((size_t)((g * 8 + c) * CB + cb) * 16 + kh * 4));
+  const int ph = kh & 1, th = kh >> 1;
+  const size_t plane = (size_t)CS * CB * 16;
+#pragma unroll
+  for (int kw = 0; kw < 4; ++kw) {
+    const int pw = kw & 1, tw = kw >> 1;
+    const size_t o = ((size_t)((cb * (CS / 8) + g) * 4 + 2 * ph + pw) * 4 + 2 * th + tw) * 8;
+    float hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float x = v[c][kw];
+      hi[c] = (float)(__bf16)x;
+      const float r = x - hi[c];
+      mid[c] = (float)(__bf16)r;
+      lo[c] = r - mid[c];
+    }
+    *reinterpret_cast<u32x4*>(up3 + o) = u32x4{pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]), pack_bf16x2(hi[4], hi[5]), pack_bf16x2(hi[6], hi[7])};
+    *reinterpret_cast<u32x4*>(up3 + plane + o) = u32x4{pack_bf16x2(mid[0], mid[1]), pack_bf16x2(mid[2], mid[3]), pack_bf16x2(mid[4], mid[5]), pack_bf16x2(mid[6], mid[7])};
+    *reinterpret_cast<u32x4*>(up3 + 2 * plane + o) = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(lo[4], lo[5]), pack_bf16x2(lo[6], lo[7])};
+  }
+}
+__global__ __launch_bounds__(256) void split_shadow_kernel(const float* __restrict__ w, int CS, int CB, u16* __restrict__ up3) {
+  const int items = CB * (CS / 8) * 4;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) shadow_split_item(it, w, CS, CB, up3);
+}
+
 // the shadows of several layers in ONE launch (a conv stack's forward pass: 4 - 6 us of launch latency per layer otherwise)
 struct ShadowTable {
   static constexpr int MAXN = 8;
@@ -1492,7 +1523,9 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
   const int it = ((int)blockIdx.x - t.blk0[e]) * 256 + threadIdx.x;
   if (it >= t.items[e]) return;
   u16* up = t.down[e] + (size_t)t.CS[e] * t.CB[e] * (t.k1[e] ? 1 : 16);
-  if (t.k1[e])
+  if (t.k1[e] == 2)
+    shadow_split_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
+  else if (t.k1[e])
     shadow_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
   else
     shadow_k4_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
@@ -1684,9 +1717,13 @@ int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const f
 // the layer's whole weight shadow (64 KB) resident in LDS, the small band double-buffered (register prefetch one unit
 // ahead) and the 32 x 8 x 45 output tile staged through LDS, from where 16 lanes per channel move it out - with the
 // BatchNorm statistics (forward) or the BatchNorm + activation backward of the block below (pgv_bwd_fuse) on the way.
-template <int CB_, int CS_, int H_, int W_, int UB_ = 4>
+// NP = 3 (PGV_COMPUTE_F32_SPLIT): an fp32 product as SIX bf16 instructions - every operand value kept as three bfloat16
+// planes x = x1 + x2 + x3 (exact: 3 x 8 significant bits), the product as x1 y1 + x1 y2 + x2 y1 + x2 y2 + x1 y3 + x3 y1 with the
+// fp32 accumulator of the matrix instruction (the dropped terms are below 2^-23 of the product; measured against float64,
+// scratch/ubench/bf16x6.hip: closer than v_mfma_f32_16x16x4_f32 itself) at 6 / 16 of the fp32 instruction time.
+template <int CB_, int CS_, int H_, int W_, int UB_ = 4, int NP_ = 1>
 struct UpBig {
-  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_;
+  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, NP = NP_;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws;
   static constexpr int UB = UB_, RB = 2 * UB, BANDS = (Hs + UB - 1) / UB;   // u rows / output rows of a band
   static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;      // small band image (+ zero column right)
@@ -1696,8 +1733,8 @@ struct UpBig {
   static constexpr int MTN = (CB + 15) / 16;                                 // M tiles (a layer with 8 big channels: rows 8-15 zero)
   static constexpr int NG = CS / 8, PB = CS * 2;                             // 16-byte channel groups / bytes of a pixel
   static constexpr int SH = NG == 8 ? 1 : (NG == 4 ? 2 : 3);                 // group g of pixel px sits at g ^ ((px >> SH) & (NG - 1))
-  static constexpr int A_ROW = NG * 256 + 32, A_BYTES = MTN * 16 * A_ROW;
-  static constexpr int S_BYTES = (SPX * PB + 15) / 16 * 16;                  // one stage
+  static constexpr int A_ROW = NG * 256 + 32, A_PLANE = MTN * 16 * A_ROW, A_BYTES = NP * A_PLANE;
+  static constexpr int S_PLANE = (SPX * PB + 15) / 16 * 16, S_BYTES = NP * S_PLANE;   // one stage
   static constexpr int O_FLOATS = CB * RB * W, O_BYTES = O_FLOATS * 4;
   static constexpr int S_RUN = SROWS * Ws, QUADS = (S_RUN + 3) / 4, ITEMS = (CS / 2) * QUADS, QB = (ITEMS + 511) / 512;
   static constexpr int LPC = 512 / CB;                                       // copy-out lanes per channel
@@ -1739,9 +1776,10 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
   if (CB < G::MTN * 16)
     for (int i = tid; i < G::A_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_a)[i] = u32x4{0, 0, 0, 0};
   if (CB < G::MTN * 16) __syncthreads();
-  for (int q = tid; q < CB * G::NG * 16; q += 512) {
-    const int row = q / (G::NG * 16), f = q - row * (G::NG * 16);
-    *reinterpret_cast<u32x4*>(lds_a + row * G::A_ROW + f * 16) =
+  for (int q = tid; q < G::NP * CB * G::NG * 16; q += 512) {   // (NP planes, each [cb][cs/8][phase][tap][8])
+    const int pl = q / (CB * G::NG * 16), qq = q - pl * (CB * G::NG * 16);
+    const int row = qq / (G::NG * 16), f = qq - row * (G::NG * 16);
+    *reinterpret_cast<u32x4*>(lds_a + pl * G::A_PLANE + row * G::A_ROW + f * 16) =
         *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
   }
   // ---- small-band loader: an item = a channel pair x 4 consecutive floats of the band's rows (contiguous in the plane)
@@ -1824,8 +1862,17 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
             x1 = k == 1 ? rb[i][1][1] : (k == 2 ? rb[i][1][2] : rb[i][1][3]);
           }
           const bool on = e < nv;
-          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) =
-              pack_bf16x2(on ? fmaf(x0, s0, h0) : 0.f, on ? fmaf(x1, s1c, h1) : 0.f);
+          const float y0 = on ? fmaf(x0, s0, h0) : 0.f, y1 = on ? fmaf(x1, s1c, h1) : 0.f;
+          if constexpr (G::NP == 1) {
+            *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(y0, y1);
+          } else {   // three bf16 planes: y = y_hi + y_mid + y_lo exactly
+            const float a0 = (float)(__bf16)y0, a1 = (float)(__bf16)y1;
+            const float r0 = y0 - a0, r1 = y1 - a1;
+            const float m0 = (float)(__bf16)r0, m1 = (float)(__bf16)r1;
+            *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(a0, a1);
+            *reinterpret_cast<unsigned*>(st + G::S_PLANE + b_dst[i][e]) = pack_bf16x2(m0, m1);
+            *reinterpret_cast<unsigned*>(st + 2 * G::S_PLANE + b_dst[i][e]) = pack_bf16x2(r0 - m0, r1 - m1);
+          }
         }
       }
     }
@@ -1860,15 +1907,34 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
       for (int t = 0; t < TMAX; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G::NG; ++g) {
-      u32x4 af[G::MTN];
+      u32x4 af[G::NP][G::MTN];
 #pragma unroll
-      for (int mt = 0; mt < G::MTN; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + mt * 16 * G::A_ROW);
+      for (int pl = 0; pl < G::NP; ++pl)
+#pragma unroll
+        for (int mt = 0; mt < G::MTN; ++mt)
+          af[pl][mt] = *reinterpret_cast<const u32x4*>(lds_a + pl * G::A_PLANE + a_frag + g * 256 + mt * 16 * G::A_ROW);
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) {
         if (t < ntl) {
-          const u32x4 bfr = *reinterpret_cast<const u32x4*>(st + boff[t] + ((g ^ bsw[t]) * 16));
+          const int bo = boff[t] + ((g ^ bsw[t]) * 16);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(st + bo);
+          if constexpr (G::NP == 1) {
 #pragma unroll
-          for (int mt = 0; mt < G::MTN; ++mt) acc[mt][t] = mfma_bf16_k32(af[mt], bfr, acc[mt][t]);
+            for (int mt = 0; mt < G::MTN; ++mt) acc[mt][t] = mfma_bf16_k32(af[0][mt], b1, acc[mt][t]);
+          } else {
+            const u32x4 b2 = *reinterpret_cast<const u32x4*>(st + G::S_PLANE + bo);
+            const u32x4 b3 = *reinterpret_cast<const u32x4*>(st + 2 * G::S_PLANE + bo);
+#pragma unroll
+            for (int mt = 0; mt < G::MTN; ++mt) {   // smallest terms first
+              f32x4 c = acc[mt][t];
+              c = mfma_bf16_k32(af[0][mt], b3, c);
+              c = mfma_bf16_k32(af[2][mt], b1, c);
+              c = mfma_bf16_k32(af[1][mt], b2, c);
+              c = mfma_bf16_k32(af[0][mt], b2, c);
+              c = mfma_bf16_k32(af[1][mt], b1, c);
+              acc[mt][t] = mfma_bf16_k32(af[0][mt], b1, c);
+            }
+          }
         }
       }
     }
@@ -1938,6 +2004,12 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
   }
 }
 
+// PGV_COMPUTE_F32_SPLIT: the 32 -> 16 channel transposed convolution onto 65x88 with fp32 products as six bf16 instructions
+bool up_big_split_shape(const pgv_conv_desc* d) {
+  return (d->flags & PGV_COMPUTE_F32_SPLIT) && !(d->flags & PGV_COMPUTE_BF16) && d->kh == 4 && d->kw == 4 && d->stride == 2 &&
+         d->pad == 2 && d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32;
+}
+
 bool up_big_bf16_shape(const pgv_conv_desc* d) {
   if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
   return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
@@ -1963,7 +2035,7 @@ int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const floa
   pgv_bwd_fuse f = {};
   if (fuse) f = *fuse;
   const int units = d->B * G::BANDS;
-  const u16* up = (const u16*)d->w_shadow + (size_t)d->Cs * d->Cb * 16;
+  const u16* up = (const u16*)d->w_shadow + (G::NP == 1 ? (size_t)d->Cs * d->Cb * 16 : 0);   // (split mode: three up planes)
   const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / G::LDS_BYTES));
   hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256 * per_cu)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
                      bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(), f);
@@ -2280,11 +2352,19 @@ bool deep_bf16_shape(const pgv_conv_desc* d) {
 
 // bytes of the bf16 weight shadow of a layer (down + up layouts), 0: the layer has no bf16-native kernels
 int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
+  if (!(d->flags & PGV_COMPUTE_BF16)) return up_big_split_shape(d) ? (int64_t)6 * d->Cs * d->Cb * 16 : 0;   // (3 bf16 planes)
   if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
   return (deep_bf16_shape(d) || up_big_bf16_shape(d)) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
 }
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
+  if (!(d->flags & PGV_COMPUTE_BF16)) {
+    if (!up_big_split_shape(d)) return 0;
+    hipLaunchKernelGGL(split_shadow_kernel, dim3((unsigned)((d->Cb * (d->Cs / 8) * 4 + 255) / 256)), dim3(256), 0, st, w, d->Cs,
+                       d->Cb, (u16*)shadow);
+    PGV_CHECK_LAUNCH("conv_weight_shadow");
+    return 1;
+  }
   if (k1_bf16_shape(d)) {
     u16* down = (u16*)shadow;
     hipLaunchKernelGGL(k1_shadow_kernel, dim3((unsigned)min((d->Cs * d->Cb / 8 + 255) / 256, 2048)), dim3(256), 0, st, w, d->Cs,
@@ -2386,6 +2466,8 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
 int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                          const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                          hipStream_t st, const pgv_bn_src* bn) {
+  if (d->w_shadow && up_big_split_shape(d))   // fp32 products as six bf16 instructions
+    return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2, 3>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
   if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65) return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
@@ -2419,12 +2501,13 @@ int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
     const pgv_conv_desc* d = descs[i];
-    const bool k1 = k1_bf16_shape(d);
-    if (!k1 && !deep_bf16_shape(d) && !up_big_bf16_shape(d)) return 0;
+    const bool bf = (d->flags & PGV_COMPUTE_BF16) != 0, split = up_big_split_shape(d);
+    const bool k1 = bf && k1_bf16_shape(d);
+    if (!split && !(bf && (k1 || deep_bf16_shape(d) || up_big_bf16_shape(d)))) return 0;
     t.w[i] = ws[i];
     t.down[i] = (u16*)shadows[i];
-    t.CS[i] = d->Cs, t.CB[i] = d->Cb, t.k1[i] = k1 ? 1 : 0;
-    t.items[i] = k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4;
+    t.CS[i] = d->Cs, t.CB[i] = d->Cb, t.k1[i] = split ? 2 : (k1 ? 1 : 0);   // (kind: 0 k4 bf16, 1 1x1 bf16, 2 split up planes)
+    t.items[i] = split ? d->Cb * (d->Cs / 8) * 4 : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
     t.blk0[i] = blocks;
     blocks += (t.items[i] + 255) / 256;
   }

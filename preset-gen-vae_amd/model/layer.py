@@ -200,7 +200,7 @@ class ConvStackFn(torch.autograd.Function):
             pairs.append((go, params[pj]))
             hh, ww = (go.Hb, go.Wb) if blk.up else (go.Hs, go.Ws)
             pj += 2 + (2 if blk.bn is not None else 0)
-        shadows = ops.conv_weight_shadows(pairs) if ops.compute_dtype() == 'bf16' else [None] * len(pairs)
+        shadows = ops.conv_weight_shadows(pairs)   # (all None in plain fp32 mode, without a launch)
         for bi, blk in enumerate(blocks):
             w, b = params[pi], params[pi + 1]
             pi += 2

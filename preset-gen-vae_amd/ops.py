@@ -59,6 +59,29 @@ def compute_dtype():
     return 'bf16' if _COMPUTE_FLAGS & PGV_COMPUTE_BF16 else 'fp32'
 
 
+PGV_COMPUTE_F32_SPLIT = 8
+_F32_SPLIT = False
+
+
+def set_fp32_products(mode):
+    """How fp32-mode products are evaluated by the layers that have a kernel for both: 'native' (default:
+    v_mfma_f32_16x16x4_f32) or 'bf16x6' (PGV_COMPUTE_F32_SPLIT: every operand as three exact bfloat16 terms, six bf16 matrix
+    instructions per product with fp32 accumulation - fp32-level error).  Opt-in; no effect in bf16 mode."""
+    global _F32_SPLIT
+    if mode not in ('native', 'bf16x6'):
+        raise ValueError(f"unknown fp32 product mode {mode!r}")
+    _F32_SPLIT = mode == 'bf16x6'
+
+
+def fp32_products():
+    return 'bf16x6' if _F32_SPLIT else 'native'
+
+
+def _flags():
+    """Compute-mode bits of every descriptor built now."""
+    return _COMPUTE_FLAGS | (PGV_COMPUTE_F32_SPLIT if (_F32_SPLIT and not (_COMPUTE_FLAGS & PGV_COMPUTE_BF16)) else 0)
+
+
 class ConvGeom:
     """Geometry of one strided convolution between a big [B,Cb,Hb,Wb] and a small [B,Cs,Hs,Ws] tensor."""
 
@@ -67,11 +90,11 @@ class ConvGeom:
         self.Hs = (Hb + 2 * pad - k) // stride + 1
         self.Ws = (Wb + 2 * pad - k) // stride + 1
         self._descs = {}
-        self._shadow_bytes = None
+        self._shadow_bytes = {}
 
     def desc(self, B, flags=0, w_shadow=None):
         """``w_shadow``: the tensor ``conv_weight_shadow`` returned for the call's weight (``pgv_conv_desc.w_shadow``)."""
-        flags |= _COMPUTE_FLAGS
+        flags |= _flags()
         if w_shadow is not None:   # per call: the descriptor carries a pointer
             return ConvDesc(B, self.Cb, self.Hb, self.Wb, self.Cs, self.Hs, self.Ws, self.k, self.k, self.stride,
                             self.pad, flags, w_shadow.data_ptr())
@@ -83,12 +106,13 @@ class ConvGeom:
         return d
 
     def shadow_bytes(self):
-        """Bytes of the bf16 weight shadow of this layer in the current compute mode (0: none)."""
-        if not (_COMPUTE_FLAGS & PGV_COMPUTE_BF16):
+        """Bytes of the weight shadow of this layer in the current compute mode (0: none)."""
+        fl = _flags()
+        if fl == 0:
             return 0
-        n = self._shadow_bytes
+        n = self._shadow_bytes.get(fl)
         if n is None:
-            n = self._shadow_bytes = int(_lib.load().pgv_conv_weight_shadow_bytes(ctypes.byref(self.desc(1))))
+            n = self._shadow_bytes[fl] = int(_lib.load().pgv_conv_weight_shadow_bytes(ctypes.byref(self.desc(1))))
         return n
 
 

@@ -388,6 +388,53 @@ def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
         ops.set_compute_dtype('fp32')
 
 
+@pytest.mark.parametrize("B", [3, 40])
+def test_conv_up_65x88_fp32_products_as_six_bf16_instructions(ops, B):
+    """PGV_COMPUTE_F32_SPLIT: the fp32 transposed convolution onto 65x88 with every product as six bf16 matrix instructions on
+    exact three-way splits of both operands (up_big, NP = 3) - against float64 at fp32 tolerances, no further from it than the
+    native fp32 kernel is, forward form (lazy normalisation, bias, activation, statistics) and fused input-gradient form."""
+    case = (16, 32, 4, 2, 2, 65, 88, B)
+    Cb, Cs, k, s, p, Hb, Wb, _ = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    assert ops.conv_weight_shadow(geom, dev(w)) is None          # native fp32 products: no shadow
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    ref = F.leaky_relu(F.conv_transpose2d(_affine_fma(small, sc_s, sh_s).double(), w.double(), bias_b.double(), stride=s,
+                                          padding=p, output_padding=(oph, opw)), 0.1)
+    native = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
+    C8 = ops.CLS_COPIES
+    ops.set_fp32_products('bf16x6')
+    try:
+        sh = ops.conv_weight_shadow(geom, dev(w))
+        assert sh is not None and sh.numel() == 6 * w.numel()     # three bf16 planes
+        # the planes add up to the weight exactly
+        planes = sh.view(torch.bfloat16).view(3, 16, 4, 2, 2, 2, 2, 8).float().sum(0)     # [cb][csg][ph][pw][th][tw][8]
+        for ph, pw, th, tw in ((0, 1, 1, 0), (1, 1, 0, 1)):
+            assert torch.equal(planes[:, :, ph, pw, th, tw, :].reshape(16, 32), dev(w)[:, :, ph + 2 * th, pw + 2 * tw].t())
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, ref), rel_l2(native, ref)
+        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        again = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                            in_shift=dev(sh_s), w_shadow=sh)
+        assert torch.equal(got, again)
+        prod = F.conv_transpose2d(small.double(), w.double(), None, stride=s, padding=p, output_padding=(oph, opw))
+        a = (dev(big) * 1.3 + 0.1).contiguous()
+        coef = dev(torch.cat([1.0 + 0.3 * synth_vec((Cb,), 4.1, 0.2), 0.05 * synth_vec((Cb,), 4.7, 0.3),
+                              0.02 * synth_vec((Cb,), 5.3, 0.8)]))
+        gbc = torch.zeros(C8 * Cb, device='cuda')
+        out = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0,
+                          bwd_fuse=(a, coef, gbc, ops.PGV_ACT_LEAKY_RELU, 0.1, None, C8), w_shadow=sh)
+        refb = _bwd_apply_ref(prod.cuda(), a, coef, ops.PGV_ACT_LEAKY_RELU, 0.1)
+        assert rel_l2(out, refb) < 2e-6
+        l1 = refb.abs().sum(dim=(0, 2, 3))
+        assert ((gbc.view(C8, Cb).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+    finally:
+        ops.set_fp32_products('native')
+
+
 def test_weight_shadows_of_a_stack_in_one_launch(ops):
     """pgv_conv_weight_shadows (one launch for the layers of a conv stack) writes exactly what pgv_conv_weight_shadow writes
     layer by layer; layers without a shadow come back as None; fp32 mode has none at all."""

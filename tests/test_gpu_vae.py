@@ -269,6 +269,20 @@ def test_train_step_dz512_vs_oracle():
         assert r < max(5e-3, 4 * noise), (k, r, noise)
 
 
+@pytest.mark.parametrize("name", ["vae4l_b16_outbn.npz", "vae4l_b2.npz"])
+def test_train_step_parity_with_fp32_products_as_six_bf16_instructions(name):
+    """PGV_COMPUTE_F32_SPLIT (opt-in, ops.set_fp32_products('bf16x6')): the layers with a split-product kernel - the 65x88
+    transposed convolution, forward and fused input gradient - evaluate every fp32 product as six bf16 matrix instructions on
+    exact three-way operand splits.  The arithmetic is fp32-accurate, so the STRICT fp32 parity test must pass unchanged."""
+    from preset_gen_vae_amd import ops
+    ops.set_fp32_products('bf16x6')
+    try:
+        assert ops.fp32_products() == 'bf16x6' and ops.compute_dtype() == 'fp32'
+        test_train_step_parity(name)
+    finally:
+        ops.set_fp32_products('native')
+
+
 @pytest.mark.parametrize("arch,dim_z", [('speccnn8l1_bn', 512), ('speccnn4l1_bn', 64)])
 def test_train_step_bf16_operand_mode_vs_oracle(arch, dim_z):
     """BASELINE config 2 arithmetic: bf16 matrix-core products (operands rounded to bfloat16, fp32 accumulation),
