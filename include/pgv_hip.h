@@ -295,6 +295,15 @@ int pgv_bn_bwd_reduce(const float* g_o, const float* a, const float* mean, const
 int pgv_act_bn_bwd(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd,
                    const double* red, int B, int C, int HW, int act, float slope, float* g_y, float* gbias,
                    float* ggamma, float* gbeta, int flags, void* stream);
+/* pgv_bn_bwd_reduce followed by pgv_act_bn_bwd (train-mode BatchNorm) as ONE launch for small planes - a workgroup per
+ * channel keeps the channel's values in registers between the reduction and the application: same results (the sums are
+ * float64 across the workgroup), 3 instead of 5 passes over the tensors.  pgv_bn_act_bwd_fusable: 1 when (B, C, HW) is
+ * served (the deepest blocks of the 8-layer stack: at most 8 k values per channel, at least 96 channels), else the two
+ * calls above are the way.  In place allowed (g_y == g_o); gbias as in pgv_act_bn_bwd.  ABI v13. */
+int pgv_bn_act_bwd_fusable(int B, int C, int HW);
+int pgv_bn_act_bwd_fused(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd, int B,
+                         int C, int HW, int act, float slope, float* g_y, float* gbias, float* ggamma, float* gbeta,
+                         int flags, void* stream);
 /* Output block under a squared-error criterion, backward in one pass: with g = 2 * scale * g_loss[0] * (a - x) (the
  * gradient of scale * sum (a - x)^2, train.py:222 / loss.py:15-43, never materialised) it writes
  * g_y = act'(a) * g and accumulates gbias[c] += sum g_y - pgv_sqerr_bwd followed by pgv_act_bn_bwd without BatchNorm.

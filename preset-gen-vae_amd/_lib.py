@@ -109,6 +109,8 @@ SIGNATURES = {
     "pgv_conv_class_sums": (c_int, [_DESC, c_int, _P, _P, c_int, _P]),
     "pgv_act_bwd_coef": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
     "pgv_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "pgv_bn_act_bwd_fusable": (c_int, [c_int, c_int, c_int]),
+    "pgv_bn_act_bwd_fused": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int, _P]),
     "pgv_act_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int,
                                _P]),
     "pgv_gemm_workspace": (c_int64, [c_int, c_int, c_int]),

@@ -934,6 +934,125 @@ int zero_async(void* p, size_t bytes, hipStream_t st, const char* who) {
   return PGV_OK;
 }
 
+// pgv_bn_bwd_reduce + pgv_act_bn_bwd as ONE launch for small planes: one workgroup per channel holds the channel's gradient
+// and activation in registers (16-byte groups of a plane, flattened over (sample, group): NR per thread, plus the planes'
+// tails), sums them (float per thread, float64 across the workgroup, as the reduce pass does), then applies the backward to
+// the values it holds - 3 tensor passes over HBM and one launch instead of 5 and two (the deep blocks of the 8-layer stack:
+// 6-14 MB tensors, where the two launches cost more than their traffic).
+template <int ACT, int NR>
+__global__ __launch_bounds__(512) void bn_act_bwd_fused_kernel(const float* __restrict__ g_o, const float* __restrict__ a,
+                                        const float* __restrict__ scale, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, int B, int C, int HW, float slope,
+                                        float* __restrict__ g_y, float* __restrict__ gbias, float* __restrict__ ggamma,
+                                        float* __restrict__ gbeta) {
+  __shared__ double redd[2][16];
+  __shared__ double tot[2];
+  __shared__ float redf[16];
+  const int c = blockIdx.x, nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
+  const int HW4 = HW >> 2, T = HW - 4 * HW4, groups = B * HW4, tails = B * T;
+  const float mu = mean[c], rs = rstd[c], sc = scale[c];
+  f4u gv[NR], av[NR];
+  int off[NR];
+  float gt[2] = {0.f, 0.f}, at[2] = {0.f, 0.f};
+  int offt[2] = {-1, -1};
+  double s0 = 0.0, d0 = 0.0;   // (float partials per 16-byte group, float64 from there on: as pgv_bn_bwd_reduce)
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int e = tid + j * nt;
+    off[j] = -1;
+    if (e < groups) {
+      const int bi = e / HW4, i = e - bi * HW4;
+      off[j] = (bi * C + c) * HW + 4 * i;
+      gv[j] = *reinterpret_cast<const f4u*>(g_o + off[j]);
+      av[j] = *reinterpret_cast<const f4u*>(a + off[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * nt;
+    if (e < tails) {
+      const int bi = e / T, i = e - bi * T;
+      offt[j] = (bi * C + c) * HW + 4 * HW4 + i;
+      gt[j] = g_o[offt[j]];
+      at[j] = a[offt[j]];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    if (off[j] >= 0) {
+      const f4u g = gv[j], v = av[j];
+      const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+      s0 += (double)((g.x + g.y) + (g.z + g.w));
+      d0 += (double)fmaf(g.x, h0, fmaf(g.y, h1, fmaf(g.z, h2, g.w * h3)));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (offt[j] >= 0) {
+      s0 += (double)gt[j];
+      d0 += (double)(gt[j] * ((at[j] - mu) * rs));
+    }
+  }
+  const double ws = pgv_wave_sum_d(s0), wd = pgv_wave_sum_d(d0);
+  if (lane == 0) redd[0][wave] = ws, redd[1][wave] = wd;
+  __syncthreads();
+  if (wave == 0) {
+    double r0 = lane < nw ? redd[0][lane] : 0.0, r1 = lane < nw ? redd[1][lane] : 0.0;
+    r0 = pgv_wave_sum_d(r0);
+    r1 = pgv_wave_sum_d(r1);
+    if (lane == 0) tot[0] = r0, tot[1] = r1;
+  }
+  __syncthreads();
+  const double inv_n = 1.0 / ((double)B * HW);
+  const float c1 = (float)(tot[0] * inv_n), c2 = (float)(tot[1] * inv_n);
+  if (tid == 0) {
+    if (ggamma) ggamma[c] = (float)tot[1];
+    if (gbeta) gbeta[c] = (float)tot[0];
+  }
+  auto one = [&](float g, float av_) -> float {
+    g = sc * (g - c1 - (av_ - mu) * rs * c2);
+    if (ACT == PGV_ACT_LEAKY_RELU)
+      g = av_ > 0.f ? g : slope * g;
+    else if (ACT == PGV_ACT_HARDTANH)
+      g = (av_ > -1.f && av_ < 1.f) ? g : 0.f;
+    return g;
+  };
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    if (off[j] >= 0) {
+      f4u r;
+      r.x = one(gv[j].x, av[j].x);
+      r.y = one(gv[j].y, av[j].y);
+      r.z = one(gv[j].z, av[j].z);
+      r.w = one(gv[j].w, av[j].w);
+      *reinterpret_cast<f4u*>(g_y + off[j]) = r;
+      acc += (r.x + r.y) + (r.z + r.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (offt[j] >= 0) {
+      const float r = one(gt[j], at[j]);
+      g_y[offt[j]] = r;
+      acc += r;
+    }
+  }
+  if (gbias) {
+    const float s = pgv_block_sum(acc, redf);
+    if (tid == 0) atomicAdd(&gbias[c], s);
+  }
+}
+
+// shapes the fused launch serves: a channel's values fit the registers of one workgroup and there are enough channels
+static bool bn_act_bwd_fusable(int B, int C, int HW) {
+  const int64_t groups = (int64_t)B * (HW >> 2), tails = (int64_t)B * (HW & 3);
+  // (at most 4 groups per thread of 512: with 8 groups per thread of 1024 - the 9x12 planes of a 256-sample batch - the
+  // kernel took 111 us against 20 us for the two passes: 128 workgroups, a 128-register budget and 16 loads per thread)
+  return B > 0 && C >= 96 && groups > 0 && groups <= 2048 && tails <= 2 * 256 * (groups <= 768 ? 1 : 2) &&
+         (int64_t)B * C * HW < ((int64_t)1 << 31);
+}
+
 }  // namespace
 
 int pgv_bn_stats_impl(const float* a, int B, int C, int HW, double* stats, hipStream_t st) {
@@ -1069,6 +1188,35 @@ int pgv_dropout_bwd_bn_reduce(const uint64_t* saved_state, uint64_t stream_id, f
   hipLaunchKernelGGL(dropout_bwd_bn_reduce_kernel, dim3(C, s.nsplit), dim3(256), 0, st, saved_state, stream_id, p,
                      1.0f / (1.0f - p), g_d, a, mean, rstd, B, C, HW, s.per, gx, red);
   PGV_CHECK_LAUNCH("dropout_bwd_bn_reduce");
+  return PGV_OK;
+}
+
+int pgv_bn_act_bwd_fusable(int B, int C, int HW) { return bn_act_bwd_fusable(B, C, HW) ? 1 : 0; }
+
+int pgv_bn_act_bwd_fused(const float* g_o, const float* a, const float* scale, const float* mean, const float* rstd, int B,
+                         int C, int HW, int act, float slope, float* g_y, float* gbias, float* ggamma, float* gbeta,
+                         int flags, void* stream) {
+  PGV_CHECK_ARG(g_o && a && g_y && scale && mean && rstd && B >= 0 && C > 0 && HW > 0, "pgv_bn_act_bwd_fused: bad argument");
+  PGV_CHECK_ARG(bn_act_bwd_fusable(B, C, HW), "pgv_bn_act_bwd_fused: shape not served (pgv_bn_act_bwd_fusable)");
+  PGV_CHECK_ARG(act == PGV_ACT_LEAKY_RELU || act == PGV_ACT_HARDTANH || act == PGV_ACT_NONE, "pgv_bn_act_bwd_fused: activation");
+  hipStream_t st = pgv_stream(stream);
+  if (gbias && !(flags & PGV_PREZEROED)) {
+    int rc = zero_async(gbias, sizeof(float) * C, st, "pgv_bn_act_bwd_fused");
+    if (rc) return rc;
+  }
+  const int groups = B * (HW >> 2);
+  const int threads = groups <= 768 ? 256 : 512;
+  typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, int, int, int, float, float*,
+                         float*, float*, float*);
+  kern_t kern;
+  if (act == PGV_ACT_LEAKY_RELU)
+    kern = (kern_t)bn_act_bwd_fused_kernel<PGV_ACT_LEAKY_RELU, 4>;
+  else if (act == PGV_ACT_HARDTANH)
+    kern = (kern_t)bn_act_bwd_fused_kernel<PGV_ACT_HARDTANH, 4>;
+  else
+    kern = (kern_t)bn_act_bwd_fused_kernel<PGV_ACT_NONE, 4>;
+  hipLaunchKernelGGL(kern, dim3(C), dim3(threads), 0, st, g_o, a, scale, mean, rstd, B, C, HW, slope, g_y, gbias, ggamma, gbeta);
+  PGV_CHECK_LAUNCH("bn_act_bwd_fused");
   return PGV_OK;
 }
 

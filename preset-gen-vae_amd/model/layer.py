@@ -368,6 +368,7 @@ class ConvStackFn(torch.autograd.Function):
                 g_y, g_y_fused = g_y_fused, None
             else:
                 red = ggamma = gbeta = None
+                fused_bn = False   # BatchNorm-backward reduce + apply as one launch (small planes: ops.bn_act_bwd_fused)
                 if drop_pending and not (has_bn and mean is not None):
                     g_o = ops.dropout_bwd(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o)
                     drop_pending = False
@@ -378,6 +379,8 @@ class ConvStackFn(torch.autograd.Function):
                         g_o = ops.dropout_bwd_bn_reduce(ctx.drop[0], ctx.drop[1], ctx.drop[2], g_o.reshape(a.shape), a,
                                                         mean, rstd, red, prezeroed=True)
                         drop_pending = False
+                    elif not (fused_sq and li == nb - 1) and ops.bn_act_bwd_fusable(a.shape[0], C, a.shape[2] * a.shape[3]):
+                        fused_bn = True
                     else:
                         ops.bn_bwd_reduce(g_o, a, mean, rstd, red, prezeroed=True)
                     ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
@@ -395,8 +398,12 @@ class ConvStackFn(torch.autograd.Function):
                                       prezeroed=gb_zero, loss_acc=ctx.sq_deferred, cls=cls_cur)
                 else:
                     g_y = g_o if li != nb - 1 else torch.empty_like(g_o)
-                    ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
-                                   ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
+                    if fused_bn:
+                        ops.bn_act_bwd_fused(g_o.reshape(a.shape), a, scale, mean, rstd, blk.act, blk.slope, g_y, gb,
+                                             ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
+                    else:
+                        ops.act_bn_bwd(g_o, a, scale if has_bn else None, mean, rstd, red, blk.act, blk.slope, g_y, gb,
+                                       ggamma=ggamma, gbeta=gbeta, prezeroed=gb_zero)
                 grads[pi + 1] = gb_ret
                 gb_cur = gb
                 if ggamma is not None:

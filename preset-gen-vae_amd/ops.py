@@ -467,6 +467,21 @@ def act_bn_bwd(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, ggamma=No
                "pgv_act_bn_bwd")
 
 
+def bn_act_bwd_fusable(B, C, HW):
+    """Whether ``bn_act_bwd_fused`` serves this shape (else: ``bn_bwd_reduce`` + ``act_bn_bwd``)."""
+    return bool(_lib.load().pgv_bn_act_bwd_fusable(int(B), int(C), int(HW)))
+
+
+def bn_act_bwd_fused(g_o, a, scale, mean, rstd, act, slope, g_y, gbias, ggamma=None, gbeta=None, prezeroed=False):
+    """``bn_bwd_reduce`` + ``act_bn_bwd`` of a train-mode BatchNorm as one launch (``pgv_bn_act_bwd_fused``, small planes)."""
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // max(1, B * C)
+    _chk(g_o, a, scale, mean, rstd, g_y, gbias, ggamma, gbeta)
+    _lib.check(_lib.load().pgv_bn_act_bwd_fused(_p(g_o), _p(a), _p(scale), _p(mean), _p(rstd), B, C, HW, act, slope, _p(g_y),
+                                                _p(gbias), _p(ggamma), _p(gbeta), int(prezeroed), _stream()),
+               "pgv_bn_act_bwd_fused")
+
+
 def sqerr_act_bwd(a, x, g_loss, scale, act, slope, g_y, gbias, prezeroed=False, loss_acc=None, cls=None):
     """g_y = act'(a) * 2 scale g_loss (a - x), gbias += sum over (batch, pixels): squared-error criterion + output
     activation of a block without BatchNorm, backward in one pass.  ``loss_acc`` (zeroed scalar) += the criterion.

@@ -435,6 +435,52 @@ def test_conv_up_65x88_fp32_products_as_six_bf16_instructions(ops, B):
         ops.set_fp32_products('native')
 
 
+@pytest.mark.parametrize("shape", [(256, 512, 3, 4), (19, 256, 5, 7), (256, 256, 5, 7), (37, 128, 9, 12), (2, 96, 5, 7)])
+@pytest.mark.parametrize("act", [1, 2, 0])
+def test_bn_act_bwd_fused_equals_the_two_passes(ops, shape, act):
+    """pgv_bn_act_bwd_fused (one launch, a workgroup per channel holding its values in registers) against
+    pgv_bn_bwd_reduce + pgv_act_bn_bwd on the same inputs - g_y, bias gradient, gamma / beta gradients - and against float64;
+    in place (g_y = g_o) as the backward pass calls it.  Shapes it does not serve are reported by pgv_bn_act_bwd_fusable."""
+    B, C, H, W = shape
+    HW = H * W
+    assert ops.bn_act_bwd_fusable(B, C, HW)
+    assert not ops.bn_act_bwd_fusable(256, 64, 17 * 23) and not ops.bn_act_bwd_fusable(256, 16, 12) and \
+        not ops.bn_act_bwd_fusable(256, 8, 129 * 174) and not ops.bn_act_bwd_fusable(256, 128, 9 * 12)
+    g = dev(synth_vec((B, C, H, W), 0.731, 0.2) + 0.03)
+    a = dev(synth_vec((B, C, H, W), 1.377, 0.9) * 1.5)
+    mean = a.mean(dim=(0, 2, 3)).contiguous()
+    rstd = (1.0 / torch.sqrt(a.var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+    scale = (dev(1.0 + 0.2 * synth_vec((C,), 2.1, 0.4)) * rstd).contiguous()
+    slope = 0.1
+    # two passes
+    red = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+    ops.bn_bwd_reduce(g, a, mean, rstd, red, prezeroed=True)
+    gy2, gb2, gg2, gbt2 = torch.empty_like(g), torch.zeros(C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ops.act_bn_bwd(g, a, scale, mean, rstd, red, act, slope, gy2, gb2, ggamma=gg2, gbeta=gbt2, prezeroed=True)
+    # fused, in place
+    gy1, gb1, gg1, gbt1 = g.clone(), torch.zeros(C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ops.bn_act_bwd_fused(gy1, a, scale, mean, rstd, act, slope, gy1, gb1, ggamma=gg1, gbeta=gbt1, prezeroed=True)
+    # float64 reference
+    gd, ad = g.double(), a.double()
+    ah = (ad - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
+    n = B * HW
+    s0, d0 = gd.sum(dim=(0, 2, 3)), (gd * ah).sum(dim=(0, 2, 3))
+    ga = scale.double().view(1, -1, 1, 1) * (gd - s0.view(1, -1, 1, 1) / n - ah * d0.view(1, -1, 1, 1) / n)
+    if act == 1:
+        ref = torch.where(ad > 0, ga, slope * ga)
+    elif act == 2:
+        ref = torch.where((ad > -1) & (ad < 1), ga, torch.zeros_like(ga))
+    else:
+        ref = ga
+    assert rel_l2(gy1, ref) < 2e-6 and rel_l2(gy2, ref) < 2e-6
+    assert rel_l2(gy1, gy2) < 5e-7
+    l1 = ref.abs().sum(dim=(0, 2, 3))
+    assert ((gb1.double() - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-9).all()
+    # (the projections are sums of fp32 products with cancellation: both forms sit a few 1e-6 from float64, and on each other)
+    assert rel_l2(gg1, d0) < 5e-6 and rel_l2(gbt1, s0) < 5e-6 and rel_l2(gg2, d0) < 5e-6
+    assert rel_l2(gg1, gg2) < 1e-6 and rel_l2(gbt1, gbt2) < 1e-6
+
+
 def test_weight_shadows_of_a_stack_in_one_launch(ops):
     """pgv_conv_weight_shadows (one launch for the layers of a conv stack) writes exactly what pgv_conv_weight_shadow writes
     layer by layer; layers without a shadow come back as None; fp32 mode has none at all."""
@@ -995,7 +1041,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 12
+    assert _lib.load().pgv_abi_version() == 13
 
 
 def test_empty_batch(ops):

@@ -64,6 +64,12 @@ def _record_activation_regions(run, arch):
             rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
         return orig(g_o, a, scale, mean, rstd, red, act, slope, g_y, gbias, **kw)
 
+    orig_fused = ops.bn_act_bwd_fused
+
+    def patched_fused(g_o, a, scale, mean, rstd, act, slope, g_y, gbias, **kw):   # small planes: reduce + apply in one launch
+        rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
+        return orig_fused(g_o, a, scale, mean, rstd, act, slope, g_y, gbias, **kw)
+
     orig_sq = ops.sqerr_act_bwd
 
     def patched_sq(a, x, g_loss, scale, act, slope, g_y, gbias, **kw):   # output block with the fused criterion
@@ -83,12 +89,14 @@ def _record_activation_regions(run, arch):
         return f
 
     ops.act_bn_bwd = patched
+    ops.bn_act_bwd_fused = patched_fused
     ops.sqerr_act_bwd = patched_sq
     ops.conv_down, ops.conv_up = fused(orig_down), fused(orig_up)
     try:
         out = run()
     finally:
         ops.act_bn_bwd = orig
+        ops.bn_act_bwd_fused = orig_fused
         ops.sqerr_act_bwd = orig_sq
         ops.conv_down, ops.conv_up = orig_down, orig_up
     names = _block_names(arch)
