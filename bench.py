@@ -349,6 +349,12 @@ def launch_table(ae, B, device, frontend=None):
             mean, rstd, scale = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
             red = torch.zeros(2 * C, device=device, dtype=torch.float64)
             gbias, gga, gbe = (torch.zeros(C, device=device) for _ in range(3))
+            if ops.bn_act_bwd_fusable(B, C, a.shape[2] * a.shape[3]):   # (the deepest blocks: one launch, as in the step)
+                table.append((f"bn_act_bwd_fused[{name}]",
+                              (lambda g_o=g_o, a=a, scale=scale, mean=mean, rstd=rstd, g_y=g_y, gbias=gbias, gga=gga, gbe=gbe:
+                               ops.bn_act_bwd_fused(g_o, a, scale, mean, rstd, 1, 0.1, g_y, gbias, ggamma=gga, gbeta=gbe)),
+                              3 * a.numel() * 4, 0.0))
+                continue
             table.append((f"act_bn_bwd[{name}]",
                           (lambda g_o=g_o, a=a, scale=scale, mean=mean, rstd=rstd, red=red, g_y=g_y, gbias=gbias, gga=gga,
                            gbe=gbe: ops.act_bn_bwd(g_o, a, scale, mean, rstd, red, 1, 0.1, g_y, gbias, ggamma=gga,
