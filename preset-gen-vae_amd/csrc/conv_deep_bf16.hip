@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(512) void k1_fwd_bf16_kernel(int B, int M, int K, c
                                                           const float* __restrict__ in_shift, const u16* __restrict__ wsh,
                                                           const float* __restrict__ bias, int act, float slope,
                                                           float* __restrict__ out, double* __restrict__ stats, int groups,
-                                                          int stat_stride) {
+                                                          int stat_stride, pgv_bn_src in_bn) {
   using G = K1B;
   constexpr int P = G::P, NS = G::NS, NT = G::NT, MT = G::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -1555,8 +1555,13 @@ __global__ __launch_bounds__(512) void k1_fwd_bf16_kernel(int B, int M, int K, c
   const int m0 = mb * MT, b0 = grp * NS;
 
   for (int i = tid; i < K; i += 512) {
-    aff[i] = in_scale ? in_scale[i] : 1.f;
-    aff[K + i] = in_scale ? in_shift[i] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)   // (the producer's BatchNorm finalized here instead of by a launch of its own: pgv_conv_*_bn)
+      pgv_bn_finalize_dev(in_bn, K, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[K + i] = sh;
   }
   // ---- loader coordinates: weights 2 x 16 bytes per thread and slab; image: (sample, channel pair, pixel quad)
   int a_src[2], a_dst[2];
@@ -1686,7 +1691,8 @@ bool k1_bf16_shape(const pgv_conv_desc* d) {
 
 // up = false: out = small (m = cs, k = cb); up = true: out = big (m = cb, k = cs)
 int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const float* in_scale, const float* in_shift,
-                       const float* bias, int act, float slope, float* out, double* stats, hipStream_t st) {
+                       const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                       const pgv_bn_src* bn) {
   using G = K1B;
   const int M = up ? d->Cb : d->Cs, K = up ? d->Cs : d->Cb;
   if ((int64_t)d->B * K * G::P * 4 >= (int64_t)1 << 31 || (int64_t)M * K * 2 >= (int64_t)1 << 31) return 0;
@@ -1702,7 +1708,8 @@ int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const f
   const int groups = (d->B + G::NS - 1) / G::NS;
   const u16* wsh = (const u16*)d->w_shadow + (up ? (size_t)d->Cs * d->Cb : 0);
   hipLaunchKernelGGL(k1_fwd_bf16_kernel, dim3((unsigned)(groups * (M / G::MT))), dim3(512), bytes, st, d->B, M, K, in, in_scale,
-                     in_shift, wsh, bias, act, slope, out, stats, groups, (d->flags & PGV_STATS_COPIES) ? 2 * M : 0);
+                     in_shift, wsh, bias, act, slope, out, stats, groups, (d->flags & PGV_STATS_COPIES) ? 2 * M : 0,
+                     bn ? *bn : pgv_no_bn());
   PGV_CHECK_LAUNCH("conv_k1_bf16");
   return 1;
 }
@@ -2386,8 +2393,8 @@ int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* sh
 int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                             const pgv_bn_src* bn) {
-  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && !bn && k1_bf16_shape(d))
-    return launch_k1_fwd_bf16(d, false, big, in_scale, in_shift, bias, act, slope, out, stats, st);
+  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && k1_bf16_shape(d))
+    return launch_k1_fwd_bf16(d, false, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_bf16<17, 23, 1, true>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_bf16<9, 12, 4, false>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
@@ -2398,8 +2405,8 @@ int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const floa
 int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                           const pgv_bn_src* bn) {
-  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && !bn && k1_bf16_shape(d))
-    return launch_k1_fwd_bf16(d, true, small_in, in_scale, in_shift, bias, act, slope, out, stats, st);
+  if ((d->flags & PGV_COMPUTE_BF16) && d->w_shadow && k1_bf16_shape(d))
+    return launch_k1_fwd_bf16(d, true, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !deep_bf16_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_bf16<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_bf16<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
