@@ -481,6 +481,30 @@ def test_bn_act_bwd_fused_equals_the_two_passes(ops, shape, act):
     assert rel_l2(gg1, gg2) < 1e-6 and rel_l2(gbt1, gbt2) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(256, 2048, 3, 4), (19, 2048, 3, 4), (7, 256, 4, 4), (3, 300, 5, 7)])
+@pytest.mark.parametrize("act", [1, 2, 0])
+def test_act_bwd_without_batchnorm_small_planes(ops, shape, act):
+    """pgv_act_bn_bwd with scale = NULL (a block without BatchNorm: enc8 of the 8-layer stack) - small planes whose size is a
+    multiple of 4 take the flat walk (act_bwd_flat_kernel), the others the channel walk: g_y = act'(a) g, bias gradient, in
+    place, and accumulation into a pre-zeroed bias gradient."""
+    B, C, H, W = shape
+    g = dev(synth_vec((B, C, H, W), 0.731, 0.2) + 0.03)
+    a = dev(synth_vec((B, C, H, W), 1.377, 0.9) * 1.5)
+    ref = g.double()
+    if act == 1:
+        ref = torch.where(a > 0, ref, 0.1 * ref)
+    elif act == 2:
+        ref = torch.where((a > -1) & (a < 1), ref, torch.zeros_like(ref))
+    gy, gb = g.clone(), torch.full((C,), float('nan'), device='cuda')
+    ops.act_bn_bwd(gy, a, None, None, None, None, act, 0.1, gy, gb)          # in place, gbias cleared by the call
+    assert rel_l2(gy, ref) < 1e-7 and torch.equal(gy == 0, ref == 0)
+    l1 = ref.abs().sum(dim=(0, 2, 3))
+    assert ((gb.double() - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-9).all()
+    gb2 = torch.ones(C, device='cuda')
+    ops.act_bn_bwd(g, a, None, None, None, None, act, 0.1, torch.empty_like(g), gb2, prezeroed=True)   # accumulates
+    assert ((gb2.double() - 1.0 - ref.sum(dim=(0, 2, 3))).abs() <= 2e-6 * (l1 + 1.0) + 1e-9).all()
+
+
 def test_weight_shadows_of_a_stack_in_one_launch(ops):
     """pgv_conv_weight_shadows (one launch for the layers of a conv stack) writes exactly what pgv_conv_weight_shadow writes
     layer by layer; layers without a shadow come back as None; fp32 mode has none at all."""
