@@ -1527,6 +1527,7 @@ int pgv_conv_down_deep(const pgv_conv_desc* d, const float* big, const float* in
                        const float* w, const float* bias, int act, float slope, float* out, double* stats,
                        hipStream_t st, const pgv_bn_src* bn) {
   if (int rc = pgv_conv_down_deep_bf16(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn)) return rc;
+  if (int rc = pgv_conv_down_deep_split(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn)) return rc;
   if (bn && shape_k1_3x4(d)) return 0;
   if (shape_k1_3x4(d) && d->Cs % 128 == 0)
     return launch_k1_down128<12, 16, 32>(d->B, d->Cb, d->Cs, d->flags, big, in_scale, in_shift, w, bias, act, slope, out,

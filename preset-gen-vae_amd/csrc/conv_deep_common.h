@@ -25,4 +25,38 @@ __device__ __forceinline__ void deep_block(int nmb, int groups, int& mb, int& gr
   }
 }
 
+// PGV_COMPUTE_F32_SPLIT: x = h + m + l exactly, three bfloat16 terms (8 + 8 + 8 significant bits cover fp32's 24)
+__device__ __forceinline__ void pgv_split3(float x, float& h, float& m, float& l) {
+  h = (float)(__bf16)x;
+  const float r = x - h;
+  m = (float)(__bf16)r;
+  l = r - m;   // (at most 8 significant bits: exact as bfloat16)
+}
+__device__ __forceinline__ unsigned pgv_pack_bf16x2(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// Split weight shadow of a deep k4 s2 p2 layer, DOWN layout = the fragment order of deep_down_split_kernel: the 16 bytes
+// (8 channels of slab s at kernel tap (kh, kq)) that lane (m, kq) of wave (half, kh) feeds the matrix instruction as the
+// A operand of rows mb*64 + half*32 + mt*16 + m, for plane p, at
+//   (((((mb * nslab + s) * 8 + wave) * 3 + p) * 2 + mt) * 64 + lane) * 16 bytes:
+// a wave's six fragments of a slab are 6 KB of contiguous memory, read straight into registers (no LDS copy: with K
+// split over the waves no two waves share a weight element).  One item = (mb, s, wave, mt, lane).
+__device__ __forceinline__ void shadow_split_down_item(int it, const float* __restrict__ w, int CS, int CB,
+                                                       unsigned short* __restrict__ down3) {
+  const int lane = it & 63, mt = (it >> 6) & 1, wave = (it >> 7) & 7, rest = it >> 10;
+  const int nslab = CB / 8, s = rest % nslab, mb = rest / nslab;
+  const int m = lane & 15, kq = lane >> 4, half = wave >> 2, kh = wave & 3;
+  const int cs = mb * 64 + half * 32 + mt * 16 + m;
+  float h[8], mid[8], l[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pgv_split3(w[((size_t)cs * CB + s * 8 + c) * 16 + kh * 4 + kq], h[c], mid[c], l[c]);
+  u32x4* dst = reinterpret_cast<u32x4*>(down3) + ((size_t)((rest * 8 + wave) * 3) * 2 + mt) * 64 + lane;
+  dst[0] = u32x4{pgv_pack_bf16x2(h[0], h[1]), pgv_pack_bf16x2(h[2], h[3]), pgv_pack_bf16x2(h[4], h[5]), pgv_pack_bf16x2(h[6], h[7])};
+  dst[128] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
+  dst[256] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+}
+
 }  // namespace

@@ -388,6 +388,53 @@ def test_deep_kernels_bf16_native_with_weight_shadow(ops, case):
         ops.set_compute_dtype('fp32')
 
 
+@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 5), (128, 256, 4, 2, 2, 9, 12, 9), (256, 512, 4, 2, 2, 5, 7, 9),
+                                  (256, 512, 4, 2, 2, 5, 7, 16), (128, 192, 4, 2, 2, 9, 12, 3)])
+def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
+    """conv_deep_split.hip (PGV_COMPUTE_F32_SPLIT): the deep layers with every fp32 product as six bf16 matrix instructions
+    on exact three-way splits of both operands - against float64 at fp32 tolerances and no further from it than the native
+    fp32 kernels are, several sample groups with a partial last one, bit-for-bit deterministic.  Forward form (lazy
+    normalisation, bias, activation, BatchNorm statistics) and the input-gradient form (plain product)."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    big_n = _affine_fma(big, sc_b, sh_b).double()
+    ref = F.leaky_relu(F.conv2d(big_n, w.double(), bias_s.double(), stride=s, padding=p), 0.1)
+    native = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b), in_shift=dev(sh_b))
+    native_plain = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+    ops.set_fp32_products('bf16x6')
+    try:
+        sh = ops.conv_weight_shadow(geom, dev(w))
+        assert sh is not None and sh.numel() == 12 * w.numel()    # three bf16 planes in two layouts
+        # the three planes of the down layout (fragment order) add up to the weight exactly
+        nslab = Cb // 8
+        planes = sh[:6 * w.numel()].view(torch.bfloat16).view(Cs // 64, nslab, 2, 4, 3, 2, 4, 16, 8).float().sum(4)
+        # [mb][slab][half][kh][mt][kq][m][8 channels] -> w[cs][cb][kh][kw]
+        back = planes.permute(0, 2, 4, 6, 1, 7, 3, 5).reshape(Cs, Cb, 4, 4)
+        assert torch.equal(back, dev(w))
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, ref), rel_l2(native, ref)
+        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        again = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                              in_shift=dev(sh_b), w_shadow=sh)
+        assert torch.equal(got, again)
+        got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        refp = F.conv2d(big.double(), w.double(), None, stride=s, padding=p)     # (structured inputs: the sums cancel)
+        e_split, e_native = rel_l2(got, refp), rel_l2(native_plain, refp)
+        assert e_split < 1e-5 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        C8 = ops.CLS_COPIES
+        stc = torch.zeros(C8 * 2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, stats=stc, prezeroed=True,
+                            stats_copies=True, w_shadow=sh)
+        assert rel_l2(stc.view(C8, -1).sum(0), torch.cat([got.double().sum(dim=(0, 2, 3)),
+                                                          (got.double() ** 2).sum(dim=(0, 2, 3))])) < 2e-5
+    finally:
+        ops.set_fp32_products('native')
+
+
 @pytest.mark.parametrize("B", [3, 40])
 def test_conv_up_65x88_fp32_products_as_six_bf16_instructions(ops, B):
     """PGV_COMPUTE_F32_SPLIT: the fp32 transposed convolution onto 65x88 with every product as six bf16 matrix instructions on
