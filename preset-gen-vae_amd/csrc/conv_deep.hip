@@ -1548,6 +1548,7 @@ int pgv_conv_up_deep(const pgv_conv_desc* d, const float* small_in, const float*
                      const float* w, const float* bias, int act, float slope, float* out, double* stats,
                      hipStream_t st, const pgv_bn_src* bn) {
   if (int rc = pgv_conv_up_deep_bf16(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn)) return rc;
+  if (int rc = pgv_conv_up_deep_split(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn)) return rc;
   if (bn && shape_k1_3x4(d)) return 0;
   if (shape_k1_3x4(d))
     return launch_k1_fwd<12, 4, 64, true>(d->B, d->Cs, d->Cb, d->flags, small_in, in_scale, in_shift, w, bias, act, slope,

@@ -1523,12 +1523,12 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
   const int it = ((int)blockIdx.x - t.blk0[e]) * 256 + threadIdx.x;
   if (it >= t.items[e]) return;
   u16* up = t.down[e] + (size_t)t.CS[e] * t.CB[e] * (t.k1[e] ? 1 : 16);
-  if (t.k1[e] == 3) {   // deep split: the down layout (fragment order), then the three planes of the up layout
+  if (t.k1[e] == 3) {   // deep split: the down layout, then the up layout (both in fragment order, three planes each)
     const int nd = t.CS[e] * t.CB[e] * 2;
     if (it < nd)
       shadow_split_down_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
     else
-      shadow_split_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
+      shadow_split_up_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
   } else if (t.k1[e] == 2)
     shadow_split_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
   else if (t.k1[e])
@@ -2530,7 +2530,7 @@ int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const
     t.down[i] = (u16*)shadows[i];
     t.CS[i] = d->Cs, t.CB[i] = d->Cb;
     t.k1[i] = dsplit ? 3 : split ? 2 : (k1 ? 1 : 0);   // (kind: 0 k4 bf16, 1 1x1 bf16, 2 split up planes, 3 split down + up planes)
-    t.items[i] = dsplit  ? d->Cs * d->Cb * 2 + d->Cb * (d->Cs / 8) * 4
+    t.items[i] = dsplit  ? d->Cs * d->Cb * 4
                  : split ? d->Cb * (d->Cs / 8) * 4
                          : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
     t.blk0[i] = blocks;

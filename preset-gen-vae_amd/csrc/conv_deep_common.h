@@ -59,4 +59,23 @@ __device__ __forceinline__ void shadow_split_down_item(int it, const float* __re
   dst[256] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
 }
 
+// UP layout of the split shadow = the fragment order of deep_up_split_kernel: big-channel blocks of 32, wave wv = 2 * phase +
+// M half; the 16 bytes (small channels g*8 .. g*8+7 at the phase's tap kq = 2 th + tw, i.e. kernel tap (ph + 2 th, pw + 2 tw))
+// of row mb*32 + half*16 + m, plane p, at ((((mb * (CS/8) + g) * 8 + wv) * 3 + p) * 64 + lane) * 16 bytes.
+// One item = (mb, g, wv, lane).
+__device__ __forceinline__ void shadow_split_up_item(int it, const float* __restrict__ w, int CS, int CB,
+                                                     unsigned short* __restrict__ up3) {
+  const int lane = it & 63, wv = (it >> 6) & 7, rest = it >> 9;
+  const int ng = CS / 8, g = rest % ng, mb = rest / ng;
+  const int m = lane & 15, kq = lane >> 4, phase = wv >> 1, half = wv & 1;
+  const int cb = mb * 32 + half * 16 + m, kh = (phase >> 1) + 2 * (kq >> 1), kw = (phase & 1) + 2 * (kq & 1);
+  float h[8], mid[8], l[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pgv_split3(w[((size_t)(g * 8 + c) * CB + cb) * 16 + kh * 4 + kw], h[c], mid[c], l[c]);
+  u32x4* dst = reinterpret_cast<u32x4*>(up3) + ((size_t)(rest * 8 + wv) * 3) * 64 + lane;
+  dst[0] = u32x4{pgv_pack_bf16x2(h[0], h[1]), pgv_pack_bf16x2(h[2], h[3]), pgv_pack_bf16x2(h[4], h[5]), pgv_pack_bf16x2(h[6], h[7])};
+  dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
+  dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+}
+
 }  // namespace

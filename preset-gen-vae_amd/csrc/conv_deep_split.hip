@@ -273,11 +273,259 @@ int launch_deep_down_split(const pgv_conv_desc* d, const float* big, const float
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// UP: out[b,cb,ih,iw] = act(bias[cb] + sum_{cs,kh,kw} w[cs,cb,kh,kw] * s'[b,cs,oh,ow]): four 2x2-tap convolutions, one per output
+// phase (conv_deep_bf16.hip, UpB).  One workgroup = 32 big channels x NS samples; 8 waves = 4 phases x 2 M halves of 16 rows,
+// every wave over the whole K and all pixel tiles of its phase: no weight element is shared between waves (fragments straight
+// from the split shadow's up layout) and nothing to reduce.  A slab = 16 small channels = two K = 32 steps per phase.
+template <int H_, int W_, int NS_>
+struct UpS3 {
+  static constexpr int H = H_, W = W_, NS = NS_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, HW = H * W;
+  static constexpr int SWP = (H == 5 && W == 7) ? 5 : (H == 9 && W == 12) ? 11 : (H == 17 && W == 23) ? 14 : Ws + 1;
+  static constexpr int SPLANE = (H == 5 && W == 7) ? 23 : (H == 9 && W == 12) ? 70 : (H == 17 && W == 23) ? 141 : (Hs + 1) * SWP;
+  static_assert(SWP >= Ws + 1 && SPLANE >= (Hs + 1) * SWP, "padded plane");
+  static constexpr int hu(int p) { return (p >> 1) ? H / 2 : (H + 1) / 2; }
+  static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
+  static constexpr int TMAX = (NS * hu(0) * wu(0) + 15) / 16;   // tiles of a wave (phase 0 has the most pixels)
+  static constexpr int MT = 32, KS = 2;
+  static constexpr int IMG = NS * SPLANE * 16;             // one image: 8 channels of one plane
+  static constexpr int STAGE = KS * 3 * IMG;               // [K step][plane]
+  static constexpr int QUADS = (P + 3) / 4;
+  static constexpr int ITEMS = NS * 4 * KS * QUADS;        // (sample, channel pair, pixel quad)
+  static constexpr int QB = (ITEMS + 511) / 512;
+  static constexpr int OUT_BYTES = NS * MT * HW * 4;
+  static constexpr int WORK = (2 * STAGE > OUT_BYTES) ? 2 * STAGE : OUT_BYTES;
+  static_assert(STAGE % 16 == 0 && P >= 4, "alignment");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void deep_up_split_kernel(int B, int CB, int CS, const float* __restrict__ small_in,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            const u32x4* __restrict__ wsh, const float* __restrict__ bias,
+                                                            int act, float slope, float* __restrict__ out,
+                                                            double* __restrict__ stats, int groups, int stat_stride,
+                                                            pgv_bn_src in_bn) {
+  constexpr int HW = G::HW, P = G::P, NS = G::NS, TMAX = G::TMAX, MT = G::MT, KS = G::KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + G::WORK);   // [2*CS]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // phases 0..3 have decreasing pixel counts: the two waves of a SIMD (w, w + 4) take phases p and 3 - p
+  const int ph = wave < 4 ? wave : 7 - wave, half = wave >> 2;
+  int mb, grp;
+  deep_block(CB / MT, groups, mb, grp);
+  const int cb0 = mb * MT, b0 = grp * NS;
+
+  for (int i = tid; i < 2 * G::STAGE / 16; i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < CS; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, CS, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[CS + i] = sh;
+  }
+
+  // ---- loader coordinates
+  int b_src[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int si = q / (4 * KS * G::QUADS), rem = q - si * (4 * KS * G::QUADS), cp = rem / G::QUADS, qi = rem - cp * G::QUADS;
+    const int p0 = min(4 * qi, P - 4);
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = (bs * CS + 2 * cp) * P + p0;
+    b_cp[i] = cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pe = p0 + e, oh = pe / G::Ws, ow = pe - oh * G::Ws;
+      b_dst[i][e] = (cp >> 2) * 3 * G::IMG + (si * G::SPLANE + oh * G::SWP + ow) * 16 + (cp & 3) * 4;
+    }
+  }
+  // ---- this wave's tiles: pixels [16 t, +16) of phase ph's list (sample, u, v)
+  const int phh = ph >> 1, pww = ph & 1;
+  const int hu = phh ? G::H / 2 : (G::H + 1) / 2, wu = pww ? G::W / 2 : (G::W + 1) / 2;
+  const int cnt = NS * hu * wu, ntl = (cnt + 15) >> 4;
+  const int th = kq >> 1, tw = kq & 1;
+  const int ng = CS / 8;
+  const u32x4* a_src = wsh + ((size_t)(mb * ng) * 8 + ph * 2 + half) * 192 + lane;   // + g * 8 * 192; + plane * 64
+  int boff[TMAX], opix[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    const int n = t * 16 + m, nn = min(n, cnt - 1);
+    const int si = nn / (hu * wu), rem = nn - si * (hu * wu), u = rem / wu, v = rem - u * wu;
+    boff[t] = (si * G::SPLANE + (u + 1 - th) * G::SWP + (v + 1 - tw)) * 16;
+    opix[t] = (t < ntl && n < cnt) ? si * MT * HW + (2 * u + phh) * G::W + 2 * v + pww : -1;
+  }
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[cb0 + half * 16 + 4 * kq + i] : 0.f;
+  f32x4 acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[2][KS * 3];   // [set][K step * 3 + plane]
+  f4u rb[G::QB][2];
+  auto issue_a = [&](int set, int slab) {
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ra[set][j * 3 + p] = a_src[(size_t)(slab * KS + j) * (8 * 192) + p * 64];
+  };
+  auto issue_b = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const float* p = small_in + b_src[i] + slab * (8 * KS * P);
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + P);
+    }
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = slab * 8 * KS + 2 * b_cp[i];
+      const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[CS + c], h1 = aff[CS + c + 1];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh, xm, xl, yh, ym, yl;
+          pgv_split3(fmaf(rb[i][0][e], s0, h0), xh, xm, xl);
+          pgv_split3(fmaf(rb[i][1][e], s1, h1), yh, ym, yl);
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pgv_pack_bf16x2(xh, yh);
+          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xm, ym);
+          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xl, yl);
+        }
+      }
+    }
+  };
+  auto kstep_products = [&](const u32x4 (&a)[KS * 3], int j, const unsigned char* st) {
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < ntl) {
+        u32x4 bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const u32x4*>(st + (j * 3 + p) * G::IMG + boff[t]);
+        f32x4 c = acc[t];   // the six products, smallest first
+        c = mfma_bf16_k32(a[j * 3 + 0], bf[2], c);
+        c = mfma_bf16_k32(a[j * 3 + 2], bf[0], c);
+        c = mfma_bf16_k32(a[j * 3 + 1], bf[1], c);
+        c = mfma_bf16_k32(a[j * 3 + 0], bf[1], c);
+        c = mfma_bf16_k32(a[j * 3 + 1], bf[0], c);
+        acc[t] = mfma_bf16_k32(a[j * 3 + 0], bf[0], c);
+      }
+    }
+  };
+
+  const int nslab = CS / (8 * KS);
+  issue_a(0, 0);
+  issue_b(0);
+  __syncthreads();
+  commit(ldsb, 0);
+  if (nslab > 1) issue_b(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < nslab; s += 2) {   // (two slabs per trip: the register sets of the weight fragments alternate)
+    {
+      const unsigned char* st = ldsb;
+      if (s + 1 < nslab) issue_a(1, s + 1);
+      kstep_products(ra[0], 0, st);
+      if (s + 1 < nslab) {   // the next slab goes to the other stage under the running matrix pipe
+        commit(ldsb + G::STAGE, s + 1);
+        if (s + 2 < nslab) issue_b(s + 2);
+      }
+      kstep_products(ra[0], 1, st);
+      __syncthreads();
+    }
+    if (s + 1 < nslab) {
+      const unsigned char* st = ldsb + G::STAGE;
+      if (s + 2 < nslab) issue_a(0, s + 2);
+      kstep_products(ra[1], 0, st);
+      if (s + 2 < nslab) {
+        commit(ldsb, s + 2);
+        if (s + 3 < nslab) issue_b(s + 3);
+      }
+      kstep_products(ra[1], 1, st);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, activation, into the [sample][channel][H*W] output tile (the stages are free)
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float* otile = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (opix[t] >= 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) otile[opix[t] + (half * 16 + 4 * kq + i) * HW] = pgv_act_apply(acc[t][i] + bv[i], ap);
+    }
+  }
+  __syncthreads();
+  if (stats) {   // 16 lanes per channel over the tile, one pair of atomics per channel
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;
+    const int ch = tid >> 4, part = tid & 15;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+      if (b0 + si < B)
+        for (int i = part; i < HW; i += 16) {
+          const float v = otile[(si * MT + ch) * HW + i];
+          s1 += v;
+          s2 += v * v;
+        }
+    }
+    s1 = group16_sum(s1);
+    s2 = group16_sum(s2);
+    if (part == 0) {
+      atomicAdd(&stats[cb0 + ch], (double)s1);
+      atomicAdd(&stats[CB + cb0 + ch], (double)s2);
+    }
+  }
+#pragma unroll
+  for (int si = 0; si < NS; ++si) {
+    if (b0 + si < B) {
+      float* dst = out + ((int64_t)(b0 + si) * CB + cb0) * HW;
+      const float* src = otile + si * MT * HW;
+      for (int i = tid; i < MT * HW; i += 512) dst[i] = src[i];
+    }
+  }
+}
+
+template <int H, int W, int NS>
+int launch_deep_up_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                         const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                         const pgv_bn_src* bn) {
+  using G = UpS3<H, W, NS>;
+  if (d->Cb % G::MT || d->Cs % (16 * G::KS) || !d->w_shadow) return 0;
+  if ((int64_t)d->B * d->Cs * G::P * 4 >= (int64_t)1 << 31 || (int64_t)d->Cs * d->Cb * 96 >= (int64_t)1 << 31) return 0;
+  const size_t bytes = (size_t)G::WORK + sizeof(float) * (2 * (size_t)d->Cs + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  auto kern = deep_up_split_kernel<G>;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(kern, &attr_done, "conv_up_deep_split");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
+    pgv_set_error("conv_up_deep_split: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + NS - 1) / NS;
+  const u32x4* up = (const u32x4*)d->w_shadow + (size_t)d->Cs * d->Cb * 6;   // (after the down layout: 96 bytes per weight)
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * (d->Cb / G::MT))), dim3(512), bytes, st, d->B, d->Cb, d->Cs, small_in,
+                     in_scale, in_shift, up, bias, act, slope, out, stats, groups,
+                     (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn());
+  PGV_CHECK_LAUNCH("conv_up_deep_split");
+  return 1;
+}
+
 }  // namespace
 
 bool pgv_deep_split_shape(const pgv_conv_desc* d) {
   return (d->flags & PGV_COMPUTE_F32_SPLIT) && !(d->flags & PGV_COMPUTE_BF16) && d->kh == 4 && d->kw == 4 && d->stride == 2 &&
-         d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
+         d->pad == 2 && d->Cb >= 64 && d->Cb % 32 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
 }
 
@@ -289,5 +537,15 @@ int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const flo
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_split<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_split<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 5 && d->Wb == 7) return launch_deep_down_split<5, 7, 8>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  return 0;
+}
+
+int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                           const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                           const pgv_bn_src* bn) {
+  if (!d->w_shadow || !pgv_deep_split_shape(d)) return 0;
+  if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_split<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_split<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  if (d->Hb == 5 && d->Wb == 7) return launch_deep_up_split<5, 7, 8>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   return 0;
 }

@@ -139,6 +139,9 @@ bool pgv_deep_split_shape(const pgv_conv_desc* d);
 int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                              const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                              const pgv_bn_src* bn);
+int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                           const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                           const pgv_bn_src* bn);
 int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d);
 int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                              const float* small_in, const float* small_scale, const float* small_shift, float* gw,

@@ -26,3 +26,32 @@ for (H, W, NS) in [(5, 7, 8), (5, 7, 4), (9, 12, 4), (9, 12, 2), (17, 23, 1), (1
             best.append((c, PLANE, WP, n))
     best.sort()
     print((H, W, NS), 'HP', HP, 'min WP', 2 * Ws + 2, best[:4])
+
+print('--- up: 16-byte pixels, waves = (phase, M half), tiles of the phase')
+def cost_up(H, W, NS, SWP, SPLANE):
+    Hs, Ws = H // 2 + 1, W // 2 + 1
+    tot = cnt = 0
+    for ph in range(4):
+        hu = H // 2 if ph >> 1 else (H + 1) // 2
+        wu = W // 2 if ph & 1 else (W + 1) // 2
+        npx = NS * hu * wu
+        for t in range((npx + 15) // 16):
+            for grp in GROUPS:
+                slots = {}
+                for lane in grp:
+                    n = min(t * 16 + (lane & 15), npx - 1); kq = lane >> 4; th, tw = kq >> 1, kq & 1
+                    si, rem = divmod(n, hu * wu); u, v = divmod(rem, wu)
+                    px = si * SPLANE + (u + 1 - th) * SWP + v + 1 - tw
+                    slots.setdefault(px % 16, set()).add(px)
+                tot += max(len(v) for v in slots.values()) - 1
+                cnt += 1
+    return tot, cnt
+for (H, W, NS) in [(5, 7, 8), (9, 12, 4), (17, 23, 2), (17, 23, 1)]:
+    Hs, Ws = H // 2 + 1, W // 2 + 1
+    best = []
+    for SWP in range(Ws + 1, Ws + 14):
+        for SPLANE in range((Hs + 1) * SWP, (Hs + 1) * SWP + 20):
+            c, n = cost_up(H, W, NS, SWP, SPLANE)
+            best.append((c, SPLANE, SWP, n))
+    best.sort()
+    print((H, W, NS), 'rows', Hs + 1, 'min SWP', Ws + 1, best[:4])

@@ -402,6 +402,9 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
     ref = F.leaky_relu(F.conv2d(big_n, w.double(), bias_s.double(), stride=s, padding=p), 0.1)
     native = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b), in_shift=dev(sh_b))
     native_plain = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+    oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
+    native_up = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
+    native_up_plain = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0)
     ops.set_fp32_products('bf16x6')
     try:
         sh = ops.conv_weight_shadow(geom, dev(w))
@@ -431,6 +434,26 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
                             stats_copies=True, w_shadow=sh)
         assert rel_l2(stc.view(C8, -1).sum(0), torch.cat([got.double().sum(dim=(0, 2, 3)),
                                                           (got.double() ** 2).sum(dim=(0, 2, 3))])) < 2e-5
+        # the up layout: [cb block of 32][cs group of 8][phase][M half][plane][kq = 2 th + tw][m][8 channels]
+        planes = sh[6 * w.numel():].view(torch.bfloat16).view(Cb // 32, Cs // 8, 2, 2, 2, 3, 2, 2, 16, 8).float().sum(5)
+        # -> [mb][g][ph][pw][half][th][tw][m][c]; w[cs = g*8+c][cb = mb*32+half*16+m][kh = ph+2th][kw = pw+2tw]
+        back = planes.permute(1, 8, 0, 4, 7, 5, 2, 6, 3).reshape(Cs, Cb, 4, 4)
+        assert torch.equal(back, dev(w))
+        refu = F.leaky_relu(F.conv_transpose2d(_affine_fma(small, sc_s, sh_s).double(), w.double(), bias_b.double(), stride=s,
+                                               padding=p, output_padding=(oph, opw)), 0.1)
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, refu), rel_l2(native_up, refu)
+        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
+        again = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                            in_shift=dev(sh_s), w_shadow=sh)
+        assert torch.equal(got, again)
+        got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        refp = F.conv_transpose2d(small.double(), w.double(), None, stride=s, padding=p, output_padding=(oph, opw))
+        e_split, e_native = rel_l2(got, refp), rel_l2(native_up_plain, refp)
+        assert e_split < 1e-5 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
     finally:
         ops.set_fp32_products('native')
 
