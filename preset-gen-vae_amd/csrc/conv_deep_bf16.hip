@@ -1055,9 +1055,11 @@ __global__ __launch_bounds__(512) void deep_wgrad_bf16_kernel(int B, int CB, int
 // 8 samples x 4 consecutive output pixels (lane group kq = pixel).  Half the LDS per pixel lets a unit be a whole 9x12 plane
 // (35 pixels) or three rows of a 17x23 plane: 9 instructions of K per wave and unit instead of 4 - 6, 30 % fewer bytes per
 // workgroup (no rows fetched twice at 9x12) and fewer, longer pipeline steps.
-template <int H_, int W_, int R_, int WP_>
+// NP = 3 (PGV_COMPUTE_F32_SPLIT): three plane images of each operand (x = x1 + x2 + x3 exactly, split at the commit) and six
+// instructions per fragment pair, smallest terms first - the fp32 product on the bf16 matrix pipe.
+template <int H_, int W_, int R_, int WP_, int NP_ = 1>
 struct Wgrad8 {
-  static constexpr int H = H_, W = W_, R = R_, WP = WP_;
+  static constexpr int H = H_, W = W_, R = R_, WP = WP_, NP = NP_;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, BANDS = Hs / R;
   static_assert(Hs % R == 0, "bands of whole output rows");
   static constexpr int SPX = R * Ws, SPX4 = (SPX + 3) / 4 * 4, STEPS = SPX4 / 4;   // pixels of a band, padded to quads
@@ -1066,10 +1068,13 @@ struct Wgrad8 {
   static_assert(WP >= 2 * Ws + 2 && (WP % 16 == 4 || WP % 16 == 12), "row stride: the 16 taps of a pixel on 16 distinct slots");
   static constexpr int S_BYTES = SPX4 * 64 * 16;             // [pixel][64 cs][8 samples] bf16
   static constexpr int X_BYTES = XROWS * WP * 128;           // [input pixel][8 cb][8 samples] bf16
-  static constexpr int STAGE = S_BYTES + X_BYTES;
+  static constexpr int PLANE_BYTES = S_BYTES + X_BYTES, STAGE = NP * PLANE_BYTES;
   static constexpr int QS = (SPX + 3) / 4, S_ITEMS = 64 * QS, QA = (S_ITEMS + 511) / 512;   // (cs, quad)
   static constexpr int QX = (W + 3) / 4, X_ITEMS = 8 * XR * QX;                             // (cb, row, quad)
   static constexpr int NLOADS = 8 * (QA + 1);                // per thread and unit
+  // first thread of the X items: behind the S items' waves when both fit the workgroup (the commit's conversions - three
+  // planes: ~250 VALU instructions per item - then spread over 5 - 6 waves instead of piling up on waves 0 - 2)
+  static constexpr int XT0 = (NP == 3 && QA == 1 && (S_ITEMS + 63) / 64 * 64 + X_ITEMS <= 512) ? (S_ITEMS + 63) / 64 * 64 : 0;
   static_assert(SPX >= 4 && W >= 4 && X_ITEMS <= 512 && NLOADS <= 63 && 2 * STAGE <= 160 * 1024, "tile shapes");
 };
 
@@ -1113,11 +1118,11 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
     s_sh[i] = small_scale ? small_shift[cs0 + cs] : 0.f;
     s_dst[i] = p0 * 1024 + cs * 16;                 // + 1024 per pixel
   }
-  const bool x_ok = tid < G::X_ITEMS;
+  const bool x_ok = (unsigned)(tid - G::XT0) < (unsigned)G::X_ITEMS;
   int x_off, x_row, x_dst[4];
   float x_sc, x_sh;
   {
-    const int q = min(tid, G::X_ITEMS - 1), cb = q / (G::XR * G::QX), rem = q - cb * (G::XR * G::QX);
+    const int q = min(max(tid - G::XT0, 0), G::X_ITEMS - 1), cb = q / (G::XR * G::QX), rem = q - cb * (G::XR * G::QX);
     const int r = rem / G::QX, qi = rem - r * G::QX, c0 = min(4 * qi, W - 4);
     x_row = r;
     x_off = ((cb0 + cb) * (H * W) + c0) * 4;
@@ -1185,18 +1190,49 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
     }
     return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
   };
+  // NP = 3: the 8 values as three planes (hi, mid, lo)
+  auto store8 = [&](unsigned char* dst, const f4u (&r)[8], int e, bool aff, float sc, float sh, float msk, unsigned live) {
+    if constexpr (G::NP == 1) {
+      *reinterpret_cast<u32x4*>(dst) = pack8(r, e, aff, sc, sh, msk, live);
+    } else {
+      float v[8];
+      if (live != 0xFFu) {      // partial last block (uniform): per-sample masks
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float mj = ((live >> j) & 1u) ? msk : 0.f;
+          v[j] = fmaf(r[j][e], sc * mj, sh * mj);
+        }
+      } else if (aff) {         // (uniform)
+        const float a = sc * msk, c = sh * msk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(r[j][e], a, c);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = r[j][e] * msk;
+      }
+      u32x4 ph, pm, pl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        pgv_split3_pair(v[2 * j], v[2 * j + 1], a, b, c);
+        ph[j] = a, pm[j] = b, pl[j] = c;
+      }
+      *reinterpret_cast<u32x4*>(dst) = ph;
+      *reinterpret_cast<u32x4*>(dst + G::PLANE_BYTES) = pm;
+      *reinterpret_cast<u32x4*>(dst + 2 * G::PLANE_BYTES) = pl;
+    }
+  };
   auto commit = [&](unsigned char* st, const RegSet& r) {
 #pragma unroll
     for (int i = 0; i < G::QA; ++i) {
       if (s_ok[i]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          *reinterpret_cast<u32x4*>(st + s_dst[i] + e * 1024) = pack8(r.rs[i], e, s_aff, s_sc[i], s_sh[i], 1.f, r.live);
+        for (int e = 0; e < 4; ++e) store8(st + s_dst[i] + e * 1024, r.rs[i], e, s_aff, s_sc[i], s_sh[i], 1.f, r.live);
       }
     }
     if (x_ok) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(st + x_dst[e]) = pack8(r.rx, e, x_aff, x_sc, x_sh, r.x_m, r.live);
+      for (int e = 0; e < 4; ++e) store8(st + x_dst[e], r.rx, e, x_aff, x_sc, x_sh, r.x_m, r.live);
     }
   };
   if (u0 < u1) issue(u0, r0);
@@ -1229,13 +1265,38 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
     const unsigned char* st = ldsb + ((u - u0) & 1) * G::STAGE;
 #pragma unroll
     for (int sp = 0; sp < STEPS; ++sp) {
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096);
-      const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096 + 256);
+      if constexpr (G::NP == 1) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + a_frag + sp * 4096 + 256);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const u32x4 b = *reinterpret_cast<const u32x4*>(st + b_frag[sp][t]);
-        acc[0][t] = mfma_bf16_k32(a0, b, acc[0][t]);
-        acc[1][t] = mfma_bf16_k32(a1, b, acc[1][t]);
+        for (int t = 0; t < 2; ++t) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(st + b_frag[sp][t]);
+          acc[0][t] = mfma_bf16_k32(a0, b, acc[0][t]);
+          acc[1][t] = mfma_bf16_k32(a1, b, acc[1][t]);
+        }
+      } else {
+        u32x4 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[0][p] = *reinterpret_cast<const u32x4*>(st + p * G::PLANE_BYTES + a_frag + sp * 4096);
+          a[1][p] = *reinterpret_cast<const u32x4*>(st + p * G::PLANE_BYTES + a_frag + sp * 4096 + 256);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          u32x4 b[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const u32x4*>(st + p * G::PLANE_BYTES + b_frag[sp][t]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {   // the six products, smallest first
+            f32x4 c = acc[mt][t];
+            c = mfma_bf16_k32(a[mt][0], b[2], c);
+            c = mfma_bf16_k32(a[mt][2], b[0], c);
+            c = mfma_bf16_k32(a[mt][1], b[1], c);
+            c = mfma_bf16_k32(a[mt][0], b[1], c);
+            c = mfma_bf16_k32(a[mt][1], b[0], c);
+            acc[mt][t] = mfma_bf16_k32(a[mt][0], b[0], c);
+          }
+        }
       }
       if (sp == STEPS / 2 && u + 1 < u1) {
         wait_set(rn);
@@ -1417,11 +1478,11 @@ int launch_deep_wgrad_bf16(const pgv_conv_desc* d, const float* big, const float
   return 1;
 }
 
-template <int H, int W, int R, int WP>
+template <int H, int W, int R, int WP, int NP = 1>
 int launch_deep_wgrad8_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                             const float* small_in, const float* small_scale, const float* small_shift, float* gw,
                             void* workspace, int64_t workspace_bytes, int nsplit, hipStream_t st) {
-  using G = Wgrad8<H, W, R, WP>;
+  using G = Wgrad8<H, W, R, WP, NP>;
   if (d->Cs % 64 || d->Cb % 8 || d->B <= 0) return 0;
   const int64_t gw_bytes = (int64_t)d->Cs * d->Cb * 64;
   const int units = ((d->B + 7) / 8) * G::BANDS;
@@ -2439,7 +2500,7 @@ int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d) {
     const int ns = k1_wgrad_split(d);
     return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 4 : 0;
   }
-  if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || d->Cb % 8) return 0;
+  if (!((d->flags & PGV_COMPUTE_BF16) ? deep_bf16_shape(d) : pgv_deep_split_shape(d)) || d->Cb % 8) return 0;
   const int ns = deep_wgrad_bf16_split(d);
   return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 64 : 0;
 }
@@ -2467,6 +2528,14 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
       PGV_CHECK_LAUNCH("conv_wgrad_k1_bf16 reduce");
     }
     return 1;
+  }
+  if (pgv_deep_split_shape(d)) {   // fp32 products as six bf16 instructions: blocks of 8 samples, three plane images
+    const int ns = deep_wgrad_bf16_split(d);
+    if (d->Hb == 17 && d->Wb == 23)
+      return launch_deep_wgrad8_bf16<17, 23, 1, 28, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
+    if (d->Hb == 9 && d->Wb == 12)
+      return launch_deep_wgrad8_bf16<9, 12, 1, 20, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
+    return launch_deep_wgrad8_bf16<5, 7, 3, 12, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, ns, st);
   }
   if (!(d->flags & PGV_COMPUTE_BF16) || !deep_bf16_shape(d) || (g_deep_bf16_dbg & 8)) return 0;
   const int ns = deep_wgrad_bf16_split(d);

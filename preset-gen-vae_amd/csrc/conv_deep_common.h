@@ -38,6 +38,16 @@ __device__ __forceinline__ unsigned pgv_pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// two values at once, as the packed bf16 pairs (low half = a) the images hold: 3 packed conversions, 4 mask / shift
+// instructions and 4 subtractions per pair (the conversion's result IS the packed pair; its halves, moved to the top of a
+// dword, are the terms as fp32)
+__device__ __forceinline__ void pgv_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+  H = pgv_pack_bf16x2(a, b);
+  const float ra = a - __builtin_bit_cast(float, H << 16), rb = b - __builtin_bit_cast(float, H & 0xffff0000u);
+  M = pgv_pack_bf16x2(ra, rb);
+  L = pgv_pack_bf16x2(ra - __builtin_bit_cast(float, M << 16), rb - __builtin_bit_cast(float, M & 0xffff0000u));
+}
+
 // Split weight shadow of a deep k4 s2 p2 layer, DOWN layout = the fragment order of deep_down_split_kernel: the 16 bytes
 // (8 channels of slab s at kernel tap (kh, kq)) that lane (m, kq) of wave (half, kh) feeds the matrix instruction as the
 // A operand of rows mb*64 + half*32 + mt*16 + m, for plane p, at

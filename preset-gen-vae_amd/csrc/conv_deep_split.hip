@@ -122,12 +122,11 @@ __global__ __launch_bounds__(512) void deep_down_split_kernel(int B, int CB, int
       if (b_ok[i]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float xh, xm, xl, yh, ym, yl;
-          pgv_split3(fmaf(rb[i][0][e], s0, h0), xh, xm, xl);
-          pgv_split3(fmaf(rb[i][1][e], s1, h1), yh, ym, yl);
-          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pgv_pack_bf16x2(xh, yh);
-          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xm, ym);
-          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xl, yl);
+          unsigned ph, pm, pl;
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
+          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
+          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
         }
       }
     }
@@ -393,12 +392,11 @@ __global__ __launch_bounds__(512) void deep_up_split_kernel(int B, int CB, int C
       if (b_ok[i]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float xh, xm, xl, yh, ym, yl;
-          pgv_split3(fmaf(rb[i][0][e], s0, h0), xh, xm, xl);
-          pgv_split3(fmaf(rb[i][1][e], s1, h1), yh, ym, yl);
-          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pgv_pack_bf16x2(xh, yh);
-          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xm, ym);
-          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pgv_pack_bf16x2(xl, yl);
+          unsigned ph, pm, pl;
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
+          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
+          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
         }
       }
     }

@@ -46,6 +46,14 @@ for (Cb, Cs, H, W) in [(64, 128, 17, 23), (128, 256, 9, 12), (256, 512, 5, 7)]:
             t = timeit(lambda: ops.conv_up(g, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=ssc, in_shift=ssh, stats=st, prezeroed=True, stats_copies=True, **kw))
             t2 = timeit(lambda: ops.conv_up(g, small, w, None, ops.PGV_ACT_NONE, 0.0, **kw))
             line += f'  up fwd {t:6.1f} us plain {t2:6.1f} us err {err:.2e}'
+        if WHAT in ('wgrad', 'all'):
+            gw = torch.empty_like(w)
+            wv = w.double().clone().requires_grad_(True)
+            F.conv2d(big[:24].double(), wv, None, stride=2, padding=2).backward(small[:24].double())
+            ops.conv_wgrad(g, big[:24].contiguous(), small[:24].contiguous(), gw)
+            err = ((gw.double() - wv.grad).norm() / wv.grad.norm()).item()
+            t = timeit(lambda: ops.conv_wgrad(g, big, small, gw, big_scale=bsc, big_shift=bsh))
+            line += f'  wgrad {t:6.1f} us err {err:.2e}'
         if sh is not None:
             ts = timeit(lambda: ops.conv_weight_shadow(g, w))
             line += f'  shadow {ts:5.1f} us'

@@ -454,6 +454,26 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         refp = F.conv_transpose2d(small.double(), w.double(), None, stride=s, padding=p, output_padding=(oph, opw))
         e_split, e_native = rel_l2(got, refp), rel_l2(native_up_plain, refp)
         assert e_split < 1e-5 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        # weight gradient (Wgrad8 with three plane images of both operands), lazy normalisation on either side
+        for kw_n, bigd, smalld in (({'big_scale': dev(sc_b), 'big_shift': dev(sh_b)}, big_n, small.double()),
+                                   ({'small_scale': dev(sc_s), 'small_shift': dev(sh_s)}, big.double(),
+                                    _affine_fma(small, sc_s, sh_s).double())):
+            wv = w.double().clone().requires_grad_(True)
+            F.conv2d(bigd, wv, None, stride=s, padding=p).backward(smalld)
+            gw = torch.empty((Cs, Cb, k, k), device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gw, **kw_n)
+            gw2 = torch.full((Cs, Cb, k, k), 7.0, device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gw2, **kw_n)
+            assert torch.equal(gw, gw2)
+            ops.set_fp32_products('native')
+            gwn = torch.empty((Cs, Cb, k, k), device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gwn, **kw_n)
+            ops.set_fp32_products('bf16x6')
+            e_split, e_native = rel_l2(gw, wv.grad), rel_l2(gwn, wv.grad)
+            assert e_split < 5e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        acc = torch.zeros((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), acc, prezeroed=True, small_scale=dev(sc_s), small_shift=dev(sh_s))
+        assert rel_l2(acc, gw) < 1e-6
     finally:
         ops.set_fp32_products('native')
 
