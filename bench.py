@@ -682,8 +682,9 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": launch,
                "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
         if ops.fp32_products() != 'native':
-            cfg["fp32_products"] = ("bf16x6 on the 65x88 transposed convolution (six bf16 matrix instructions per fp32 "
-                                    "product on exact three-way operand splits, fp32 accumulation; opt-in)")
+            cfg["fp32_products"] = ("bf16x6 on the deep k4 layers (17x23 / 9x12 / 5x7: forward, input and weight gradients), the "
+                                    "1x1 layers (forward, input gradient) and the 65x88 transposed convolution: six bf16 matrix "
+                                    "instructions per fp32 product on exact three-way operand splits, fp32 accumulation; opt-in")
         if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
@@ -712,6 +713,9 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
 # the other BASELINE.json configurations measured inside the same invocation (N = 1): fewer steps, live roofline each
 EXTRA_CONFIGS = [
     ("configs[1] on the reference-exact 8-layer stack", dict(arch='speccnn8l1_bn')),
+    ("configs[1] on the 8-layer stack, fp32 products of the deep and 1x1 layers as six bf16 instructions (opt-in "
+     "ops.set_fp32_products('bf16x6') / PGV_COMPUTE_F32_SPLIT: exact three-way operand splits, fp32 accumulation; same "
+     "parity tests and tolerances as the native fp32 kernels)", dict(arch='speccnn8l1_bn', fp32_products='bf16x6')),
     ("configs[2]: 8-layer z=512 bf16", dict(arch='speccnn8l1_bn', dim_z=512, dtype='bf16')),
     ("configs[4]: raw-audio minibatch, fused STFT->mel front-end", dict(input='audio')),
 ]

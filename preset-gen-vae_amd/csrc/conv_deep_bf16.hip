@@ -1590,7 +1590,9 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
       shadow_split_down_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
     else
       shadow_split_up_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
-  } else if (t.k1[e] == 2)
+  } else if (t.k1[e] == 4)
+    shadow_split_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
+  else if (t.k1[e] == 2)
     shadow_split_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
   else if (t.k1[e])
     shadow_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
@@ -2428,6 +2430,7 @@ bool deep_bf16_shape(const pgv_conv_desc* d) {
 int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
   if (!(d->flags & PGV_COMPUTE_BF16)) {   // PGV_COMPUTE_F32_SPLIT: 3 bf16 planes; the deep layers hold a down and an up layout
     if (pgv_deep_split_shape(d)) return (int64_t)12 * d->Cs * d->Cb * 16;
+    if (pgv_k1_split_shape(d)) return (int64_t)12 * d->Cs * d->Cb;
     return up_big_split_shape(d) ? (int64_t)6 * d->Cs * d->Cb * 16 : 0;
   }
   if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
@@ -2436,7 +2439,7 @@ int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
   if (!(d->flags & PGV_COMPUTE_BF16)) {
-    if (pgv_deep_split_shape(d)) {
+    if (pgv_deep_split_shape(d) || pgv_k1_split_shape(d)) {
       const pgv_conv_desc* one[1] = {d};
       const float* ws[1] = {w};
       void* sh[1] = {shadow};
@@ -2593,13 +2596,15 @@ int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const
   for (int i = 0; i < n; ++i) {
     const pgv_conv_desc* d = descs[i];
     const bool bf = (d->flags & PGV_COMPUTE_BF16) != 0, split = up_big_split_shape(d), dsplit = pgv_deep_split_shape(d);
-    const bool k1 = bf && k1_bf16_shape(d);
-    if (!split && !dsplit && !(bf && (k1 || deep_bf16_shape(d) || up_big_bf16_shape(d)))) return 0;
+    const bool k1 = bf && k1_bf16_shape(d), k1split = pgv_k1_split_shape(d);
+    if (!split && !dsplit && !k1split && !(bf && (k1 || deep_bf16_shape(d) || up_big_bf16_shape(d)))) return 0;
     t.w[i] = ws[i];
     t.down[i] = (u16*)shadows[i];
     t.CS[i] = d->Cs, t.CB[i] = d->Cb;
-    t.k1[i] = dsplit ? 3 : split ? 2 : (k1 ? 1 : 0);   // (kind: 0 k4 bf16, 1 1x1 bf16, 2 split up planes, 3 split down + up planes)
-    t.items[i] = dsplit  ? d->Cs * d->Cb * 4
+    // kind: 0 k4 bf16, 1 1x1 bf16, 2 split up planes, 3 split down + up fragments, 4 split 1x1 fragments
+    t.k1[i] = k1split ? 4 : dsplit ? 3 : split ? 2 : (k1 ? 1 : 0);
+    t.items[i] = k1split ? d->Cs * d->Cb / 4
+                 : dsplit  ? d->Cs * d->Cb * 4
                  : split ? d->Cb * (d->Cs / 8) * 4
                          : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
     t.blk0[i] = blocks;

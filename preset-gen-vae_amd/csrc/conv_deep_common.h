@@ -88,4 +88,25 @@ __device__ __forceinline__ void shadow_split_up_item(int it, const float* __rest
   dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
 }
 
+// Split shadow of a 1x1 layer, fragment order of k1_fwd_split_kernel: both directions are the product out[m] = sum_k Wt[m][k]
+// in[k] (forward: m = cs, k = cb; transposed: m = cb, k = cs).  The 16 bytes (k = ks*32 + kq*8 .. +7) of row r16*16 + m,
+// plane p, at (((r16 * (K/32) + ks) * 3 + p) * 64 + lane) * 16 bytes; the forward layout (Cs*Cb*6 bytes), then the transposed
+// one.  One item = (direction, r16, ks, lane): Cs*Cb/8 items per direction.
+__device__ __forceinline__ void shadow_split_k1_item(int it, const float* __restrict__ w, int CS, int CB,
+                                                     unsigned short* __restrict__ sh) {
+  const int per = CS * CB / 8, up = it >= per;
+  if (up) it -= per;
+  const int M = up ? CB : CS, K = up ? CS : CB, nks = K / 32;
+  const int lane = it & 63, rest = it >> 6, ks = rest % nks, r16 = rest / nks;
+  const int m = r16 * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+  (void)M;
+  float h[8], mid[8], l[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pgv_split3(up ? w[(size_t)(k0 + c) * CB + m] : w[(size_t)m * CB + k0 + c], h[c], mid[c], l[c]);
+  u32x4* dst = reinterpret_cast<u32x4*>(sh) + (up ? (size_t)CS * CB * 3 / 8 : 0) + ((size_t)(r16 * nks + ks) * 3) * 64 + lane;
+  dst[0] = u32x4{pgv_pack_bf16x2(h[0], h[1]), pgv_pack_bf16x2(h[2], h[3]), pgv_pack_bf16x2(h[4], h[5]), pgv_pack_bf16x2(h[6], h[7])};
+  dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
+  dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+}
+
 }  // namespace

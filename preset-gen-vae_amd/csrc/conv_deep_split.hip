@@ -519,6 +519,234 @@ int launch_deep_up_split(const pgv_conv_desc* d, const float* small_in, const fl
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 layers on 3x4 planes (enc8 / dec1: 512 <-> 2048 channels): out[b,m,p] = act(bias[m] + sum_k Wt[m][k] * in'[b,k,p]).
+// One workgroup = 128 output channels (16 per wave) x 8 samples (96 pixels = 6 tiles), every wave over the whole K: its
+// weight fragments come straight from the split shadow (fragment order, one slab ahead), the activation slab (64 channels,
+// 128 bytes per pixel, group g of a pixel at g ^ (pixel & 7), three planes) through LDS.
+template <int NS_>
+struct K1S3 {
+  static constexpr int P = 12, NS = NS_, NPX = NS * P, NT = NPX / 16, MT = 128, CK = 64;
+  static constexpr int IMG = NPX * 128, STAGE = 3 * IMG;
+  static constexpr int ITEMS = NS * 32 * 3, QB = (ITEMS + 511) / 512;   // (sample, channel pair, pixel quad)
+  static constexpr int OUT_BYTES = NS * MT * P * 4;
+  static_assert(NPX % 16 == 0 && OUT_BYTES <= 2 * STAGE, "tile shapes");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void k1_fwd_split_kernel(int B, int M, int K, const float* __restrict__ in,
+                                                           const float* __restrict__ in_scale,
+                                                           const float* __restrict__ in_shift, const u32x4* __restrict__ wsh,
+                                                           const float* __restrict__ bias, int act, float slope,
+                                                           float* __restrict__ out, double* __restrict__ stats, int groups,
+                                                           int stat_stride, pgv_bn_src in_bn) {
+  constexpr int P = G::P, NS = G::NS, NT = G::NT, MT = G::MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*K]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int mb, grp;
+  deep_block(M / MT, groups, mb, grp);
+  const int m0 = mb * MT, b0 = grp * NS;
+
+  for (int i = tid; i < K; i += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (in_bn.stats)
+      pgv_bn_finalize_dev(in_bn, K, i, blockIdx.x == 0, sc, sh);
+    else if (in_scale)
+      sc = in_scale[i], sh = in_shift[i];
+    aff[i] = sc;
+    aff[K + i] = sh;
+  }
+  int b_src[G::QB], b_dst[G::QB][4], b_cp[G::QB];
+  bool b_ok[G::QB];
+#pragma unroll
+  for (int i = 0; i < G::QB; ++i) {
+    const int q = min(tid + 512 * i, G::ITEMS - 1), si = q / 96, rem = q - si * 96, cp = rem / 3, qi = rem - cp * 3;
+    b_ok[i] = tid + 512 * i < G::ITEMS;
+    const int bs = min(b0 + si, B - 1);
+    b_src[i] = (bs * K + 2 * cp) * P + 4 * qi;
+    b_cp[i] = cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int px = si * P + 4 * qi + e;
+      b_dst[i][e] = px * 128 + (((cp >> 2) ^ (px & 7)) * 16) + (cp & 3) * 4;
+    }
+  }
+  const int nks = K / 32;
+  const u32x4* a_src = wsh + ((size_t)(m0 / 16 + wave) * nks) * 192 + lane;   // + K step * 192; + plane * 64
+  int b_frag[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int px = t * 16 + m;
+      b_frag[t][j] = px * 128 + (((j * 4 + kq) ^ (px & 7)) * 16);
+    }
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[m0 + wave * 16 + 4 * kq + i] : 0.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[2][6];   // [set][K step * 3 + plane]
+  f4u rb[G::QB][2];
+  auto issue_a = [&](int set, int slab) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ra[set][i] = a_src[(size_t)slab * 384 + i * 64];
+  };
+  auto issue_b = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const float* p = in + b_src[i] + slab * (64 * P);
+      rb[i][0] = *reinterpret_cast<const f4u*>(p);
+      rb[i][1] = *reinterpret_cast<const f4u*>(p + P);
+    }
+  };
+  auto commit = [&](unsigned char* st, int slab) {
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      const int c = slab * 64 + 2 * b_cp[i];
+      const float s0 = aff[c], s1 = aff[c + 1], h0 = aff[K + c], h1 = aff[K + c + 1];
+      if (b_ok[i]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned ph, pm, pl;
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
+          *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
+          *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
+        }
+      }
+    }
+  };
+  auto kstep_products = [&](const u32x4 (&a)[6], int j, const unsigned char* st) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      u32x4 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const u32x4*>(st + p * G::IMG + b_frag[t][j]);
+      f32x4 c = acc[t];   // the six products, smallest first
+      c = mfma_bf16_k32(a[j * 3 + 0], bf[2], c);
+      c = mfma_bf16_k32(a[j * 3 + 2], bf[0], c);
+      c = mfma_bf16_k32(a[j * 3 + 1], bf[1], c);
+      c = mfma_bf16_k32(a[j * 3 + 0], bf[1], c);
+      c = mfma_bf16_k32(a[j * 3 + 1], bf[0], c);
+      acc[t] = mfma_bf16_k32(a[j * 3 + 0], bf[0], c);
+    }
+  };
+  const int nslab = K / 64;
+  issue_a(0, 0);
+  issue_b(0);
+  __syncthreads();   // affine staged
+  commit(ldsb, 0);
+  if (nslab > 1) issue_b(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < nslab; s += 2) {
+    {
+      const unsigned char* st = ldsb;
+      if (s + 1 < nslab) issue_a(1, s + 1);
+      kstep_products(ra[0], 0, st);
+      if (s + 1 < nslab) {
+        commit(ldsb + G::STAGE, s + 1);
+        if (s + 2 < nslab) issue_b(s + 2);
+      }
+      kstep_products(ra[0], 1, st);
+      __syncthreads();
+    }
+    if (s + 1 < nslab) {
+      const unsigned char* st = ldsb + G::STAGE;
+      if (s + 2 < nslab) issue_a(0, s + 2);
+      kstep_products(ra[1], 0, st);
+      if (s + 2 < nslab) {
+        commit(ldsb, s + 2);
+        if (s + 3 < nslab) issue_b(s + 3);
+      }
+      kstep_products(ra[1], 1, st);
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: bias, activation, into the [sample][channel][P] output tile
+  const pgv_act_params ap = pgv_act_setup(act, slope);
+  float* otile = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 16 + m, s2 = n / P, pix = n - s2 * P;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) otile[(s2 * MT + wave * 16 + 4 * kq + i) * P + pix] = pgv_act_apply(acc[t][i] + bv[i], ap);
+  }
+  __syncthreads();
+  if (stats) {   // 4 lanes per channel over the tile, one pair of atomics per channel
+    stats += (size_t)(blockIdx.x & (PGV_CLS_COPIES - 1)) * stat_stride;
+    const int ch = tid >> 2, part = tid & 3;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s3 = 0; s3 < NS; ++s3) {
+      if (b0 + s3 < B) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float v = otile[(s3 * MT + ch) * P + part * 3 + i];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 1);
+    s2 += __shfl_xor(s2, 1);
+    s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 2);
+    if (part == 0) {
+      atomicAdd(&stats[m0 + ch], (double)s1);
+      atomicAdd(&stats[M + m0 + ch], (double)s2);
+    }
+  }
+#pragma unroll
+  for (int s3 = 0; s3 < NS; ++s3) {
+    if (b0 + s3 < B) {
+      float* dst = out + ((int64_t)(b0 + s3) * M + m0) * P;
+      const float* src = otile + s3 * MT * P;
+      for (int i = tid; i < MT * P; i += 512) dst[i] = src[i];
+    }
+  }
+}
+
+// up = false: out = small (m = cs, k = cb); up = true: out = big (m = cb, k = cs)
+template <int NS>
+int launch_k1_fwd_split_ns(const pgv_conv_desc* d, bool up, const float* in, const float* in_scale, const float* in_shift,
+                        const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                        const pgv_bn_src* bn) {
+  using G = K1S3<NS>;
+  const int M = up ? d->Cb : d->Cs, K = up ? d->Cs : d->Cb;
+  if ((int64_t)d->B * K * G::P * 4 >= (int64_t)1 << 31 || (int64_t)M * K * 12 >= (int64_t)1 << 31) return 0;
+  const size_t bytes = 2 * (size_t)G::STAGE + sizeof(float) * (2 * (size_t)K + 8);
+  if (bytes > (size_t)kMaxLds) return 0;
+  static bool attr_done = false;
+  int rc = raise_lds_limit(k1_fwd_split_kernel<G>, &attr_done, "conv_k1_split");
+  if (rc) return rc;
+  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * M, st) != hipSuccess) {
+    pgv_set_error("conv_k1_split: memset failed");
+    return PGV_E_LAUNCH;
+  }
+  const int groups = (d->B + G::NS - 1) / G::NS;
+  const u32x4* wsh = (const u32x4*)d->w_shadow + (up ? (size_t)d->Cs * d->Cb * 3 / 8 : 0);
+  hipLaunchKernelGGL(k1_fwd_split_kernel<G>, dim3((unsigned)(groups * (M / G::MT))), dim3(512), bytes, st, d->B, M, K, in, in_scale,
+                     in_shift, wsh, bias, act, slope, out, stats, groups, (d->flags & PGV_STATS_COPIES) ? 2 * M : 0,
+                     bn ? *bn : pgv_no_bn());
+  PGV_CHECK_LAUNCH("conv_k1_split");
+  return 1;
+}
+
+// (8 samples per workgroup halve the weight stream; 4 when 128-row blocks x sample groups would not fill the CUs)
+int launch_k1_fwd_split(const pgv_conv_desc* d, bool up, const float* in, const float* in_scale, const float* in_shift,
+                        const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                        const pgv_bn_src* bn) {
+  const int M = up ? d->Cb : d->Cs;
+  if ((M / 128) * ((d->B + 7) / 8) >= 256) return launch_k1_fwd_split_ns<8>(d, up, in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+  return launch_k1_fwd_split_ns<4>(d, up, in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
+}
+
 }  // namespace
 
 bool pgv_deep_split_shape(const pgv_conv_desc* d) {
@@ -527,10 +755,16 @@ bool pgv_deep_split_shape(const pgv_conv_desc* d) {
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
 }
 
+bool pgv_k1_split_shape(const pgv_conv_desc* d) {
+  return (d->flags & PGV_COMPUTE_F32_SPLIT) && !(d->flags & PGV_COMPUTE_BF16) && d->kh == 1 && d->kw == 1 && d->stride == 1 &&
+         d->pad == 0 && d->Hb == 3 && d->Wb == 4 && d->Cb % 128 == 0 && d->Cs % 128 == 0;
+}
+
 // 1 = launched, 0 = not this kernel family's case
 int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                              const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                              const pgv_bn_src* bn) {
+  if (d->w_shadow && pgv_k1_split_shape(d)) return launch_k1_fwd_split(d, false, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (!d->w_shadow || !pgv_deep_split_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_down_split<17, 23, 1>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_down_split<9, 12, 4>(d, big, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
@@ -541,6 +775,7 @@ int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const flo
 int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                            const pgv_bn_src* bn) {
+  if (d->w_shadow && pgv_k1_split_shape(d)) return launch_k1_fwd_split(d, true, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (!d->w_shadow || !pgv_deep_split_shape(d)) return 0;
   if (d->Hb == 17 && d->Wb == 23) return launch_deep_up_split<17, 23, 2>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);
   if (d->Hb == 9 && d->Wb == 12) return launch_deep_up_split<9, 12, 4>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, st, bn);

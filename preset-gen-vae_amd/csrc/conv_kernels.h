@@ -136,6 +136,7 @@ int pgv_conv_up_deep_bf16(const pgv_conv_desc* d, const float* small_in, const f
                           const pgv_bn_src* bn);
 // PGV_COMPUTE_F32_SPLIT kernels of the deep layers (conv_deep_split.hip): fp32 products as six bf16 matrix instructions
 bool pgv_deep_split_shape(const pgv_conv_desc* d);
+bool pgv_k1_split_shape(const pgv_conv_desc* d);
 int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                              const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                              const pgv_bn_src* bn);

@@ -16,17 +16,19 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1000
 torch.manual_seed(1)
-for (Cb, Cs, H, W) in [(64, 128, 17, 23), (128, 256, 9, 12), (256, 512, 5, 7)]:
-    g = ops.ConvGeom(Cb, Cs, 4, 2, 2, H, W)
+for (Cb, Cs, H, W) in [(64, 128, 17, 23), (128, 256, 9, 12), (256, 512, 5, 7), (512, 2048, 3, 4)]:
+    K1 = H == 3
+    if K1 and WHAT == 'wgrad': continue
+    g = ops.ConvGeom(Cb, Cs, 1, 1, 0, H, W) if K1 else ops.ConvGeom(Cb, Cs, 4, 2, 2, H, W)
     big = torch.randn(B, Cb, H, W, device='cuda'); small = torch.randn(B, Cs, g.Hs, g.Ws, device='cuda')
-    w = torch.randn(Cs, Cb, 4, 4, device='cuda') * 0.05
+    w = torch.randn(Cs, Cb, *((1, 1) if K1 else (4, 4)), device='cuda') * 0.05
     bias_s = torch.randn(Cs, device='cuda') * 0.1; bias_b = torch.randn(Cb, device='cuda') * 0.1
     bsc = torch.rand(Cb, device='cuda') + 0.5; bsh = torch.randn(Cb, device='cuda') * 0.1
     ssc = torch.rand(Cs, device='cuda') + 0.5; ssh = torch.randn(Cs, device='cuda') * 0.1
     nb = 8
-    refd = F.conv2d(big[:nb].double(), w.double(), None, stride=2, padding=2)
+    refd = F.conv2d(big[:nb].double(), w.double(), None) if K1 else F.conv2d(big[:nb].double(), w.double(), None, stride=2, padding=2)
     oph, opw = H - ((g.Hs - 1) * 2 - 4 + 4), W - ((g.Ws - 1) * 2 - 4 + 4)
-    refu = F.conv_transpose2d(small[:nb].double(), w.double(), None, stride=2, padding=2, output_padding=(oph, opw))
+    refu = F.conv_transpose2d(small[:nb].double(), w.double(), None) if K1 else F.conv_transpose2d(small[:nb].double(), w.double(), None, stride=2, padding=2, output_padding=(oph, opw))
     for mode in ('native', 'bf16x6'):
         ops.set_fp32_products(mode)
         sh = ops.conv_weight_shadow(g, w)
@@ -46,7 +48,7 @@ for (Cb, Cs, H, W) in [(64, 128, 17, 23), (128, 256, 9, 12), (256, 512, 5, 7)]:
             t = timeit(lambda: ops.conv_up(g, small, w, bias_b, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=ssc, in_shift=ssh, stats=st, prezeroed=True, stats_copies=True, **kw))
             t2 = timeit(lambda: ops.conv_up(g, small, w, None, ops.PGV_ACT_NONE, 0.0, **kw))
             line += f'  up fwd {t:6.1f} us plain {t2:6.1f} us err {err:.2e}'
-        if WHAT in ('wgrad', 'all'):
+        if WHAT in ('wgrad', 'all') and not K1:
             gw = torch.empty_like(w)
             wv = w.double().clone().requires_grad_(True)
             F.conv2d(big[:24].double(), wv, None, stride=2, padding=2).backward(small[:24].double())

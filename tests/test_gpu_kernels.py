@@ -478,6 +478,46 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         ops.set_fp32_products('native')
 
 
+@pytest.mark.parametrize("case", [(512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4)])
+def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
+    """conv_deep_split.hip, the 1x1 layers on 3x4 planes (enc8 / dec1) in PGV_COMPUTE_F32_SPLIT mode: both directions against
+    float64 at fp32 tolerances, no further from it than the native fp32 kernels, deterministic; the weight gradient of these
+    layers stays on the fp32 kernels."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    refd = F.leaky_relu(F.conv2d(_affine_fma(big, sc_b, sh_b).double(), w.double(), bias_s.double()), 0.1)
+    refu = F.leaky_relu(F.conv_transpose2d(_affine_fma(small, sc_s, sh_s).double(), w.double(), bias_b.double()), 0.1)
+    nat_d = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b), in_shift=dev(sh_b))
+    nat_u = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
+    ops.set_fp32_products('bf16x6')
+    try:
+        sh = ops.conv_weight_shadow(geom, dev(w))
+        assert sh is not None and sh.numel() == 12 * w.numel()    # three bf16 planes in two layouts
+        fw = sh[:6 * w.numel()].view(torch.bfloat16).view(Cs // 16, Cb // 32, 3, 4, 16, 8).float().sum(2)   # [r16][ks][kq][m][c]
+        assert torch.equal(fw.permute(0, 3, 1, 2, 4).reshape(Cs, Cb), dev(w).view(Cs, Cb))
+        tr = sh[6 * w.numel():].view(torch.bfloat16).view(Cb // 16, Cs // 32, 3, 4, 16, 8).float().sum(2)
+        assert torch.equal(tr.permute(0, 3, 1, 2, 4).reshape(Cb, Cs), dev(w).view(Cs, Cb).t())
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, refd), rel_l2(nat_d, refd)
+        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([refd.sum(dim=(0, 2, 3)), (refd * refd).sum(dim=(0, 2, 3))])) < 2e-5
+        assert torch.equal(got, ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1,
+                                              in_scale=dev(sc_b), in_shift=dev(sh_b), w_shadow=sh))
+        stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
+                          in_shift=dev(sh_s), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, refu), rel_l2(nat_u, refu)
+        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
+        got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        assert rel_l2(got, F.conv_transpose2d(small.double(), w.double(), None)) < 1e-5
+    finally:
+        ops.set_fp32_products('native')
+
+
 @pytest.mark.parametrize("B", [3, 40])
 def test_conv_up_65x88_fp32_products_as_six_bf16_instructions(ops, B):
     """PGV_COMPUTE_F32_SPLIT: the fp32 transposed convolution onto 65x88 with every product as six bf16 matrix instructions on
