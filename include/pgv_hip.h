@@ -62,8 +62,12 @@ typedef struct pgv_conv_desc {
  * every operand value x is held as three bfloat16 terms x1 + x2 + x3 (exact), the product as the six largest cross terms
  * with fp32 accumulation - the dropped terms are below 2^-23 of the product, the measured error against float64 is below
  * that of v_mfma_f32_16x16x4_f32 (scratch/ubench/bf16x6.hip) - at 6 / 16 of the fp32 instruction time.  Only the layers
- * with a kernel for it change (pgv_conv_weight_shadow_bytes > 0 under this flag: they need the weight shadow); every other
- * call computes as without the flag. */
+ * with a kernel for it change: the deep k4 s2 p2 layers on 17x23 / 9x12 / 5x7 planes (forward, input gradient, weight
+ * gradient), the 1x1 layers on 3x4 planes (forward, input gradient) and the 32 -> 16 channel transposed convolution onto
+ * 65x88 (conv_deep_split.hip, conv_deep_bf16.hip).  Forward / input-gradient calls need the layer's split weight shadow
+ * (pgv_conv_weight_shadow_bytes > 0 under this flag: three bf16 planes per direction, in the fragment order of the kernels)
+ * in pgv_conv_desc.w_shadow and compute natively without it; the weight gradient needs none (both operands are activations,
+ * split in the kernel's loader).  Every other call computes as without the flag. */
 #define PGV_COMPUTE_F32_SPLIT 8
 /* The BatchNorm statistics output of a forward conv call (`stats`) is PGV_CLS_COPIES partial copies [copies][2C] of
  * doubles, zeroed by the caller, and a workgroup may add into any of them (the wave-specialised kernels use the copy of

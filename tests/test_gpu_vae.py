@@ -277,11 +277,14 @@ def test_train_step_dz512_vs_oracle():
         assert r < max(5e-3, 4 * noise), (k, r, noise)
 
 
-@pytest.mark.parametrize("name", ["vae4l_b16_outbn.npz", "vae4l_b2.npz"])
+@pytest.mark.parametrize("name", ["vae4l_b16_outbn.npz", "vae4l_b2.npz", "vae8l_b2.npz", "vae8l_b16.npz", "vae8l_b16_outbn.npz"])
 def test_train_step_parity_with_fp32_products_as_six_bf16_instructions(name):
-    """PGV_COMPUTE_F32_SPLIT (opt-in, ops.set_fp32_products('bf16x6')): the layers with a split-product kernel - the 65x88
-    transposed convolution, forward and fused input gradient - evaluate every fp32 product as six bf16 matrix instructions on
-    exact three-way operand splits.  The arithmetic is fp32-accurate, so the STRICT fp32 parity test must pass unchanged."""
+    """PGV_COMPUTE_F32_SPLIT (opt-in, ops.set_fp32_products('bf16x6')): the layers with a split-product kernel - the deep
+    k4 layers of the 8-layer stack (forward, input gradient, weight gradient), its 1x1 layers (forward, input gradient) and
+    the 65x88 transposed convolution (forward and fused input gradient) - evaluate every fp32 product as six bf16 matrix
+    instructions on exact three-way operand splits.  The arithmetic is fp32-accurate, so the STRICT fp32 parity test (z at
+    fixed eps, losses, every gradient, post-Adam parameters, running statistics against the float64 goldens) must pass
+    unchanged."""
     from preset_gen_vae_amd import ops
     ops.set_fp32_products('bf16x6')
     try:
