@@ -37,6 +37,7 @@ def build_table():
     # PMC_ARCH / PMC_DZ / PMC_DTYPE select the configuration (round 4: the 8-layer and the bf16 z = 512 steps too)
     from preset_gen_vae_amd import ops
     ops.set_compute_dtype(os.environ.get('PMC_DTYPE', 'fp32'))
+    ops.set_fp32_products(os.environ.get('PMC_FP32_PRODUCTS', 'native'))   # 'bf16x6': PGV_COMPUTE_F32_SPLIT
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture = os.environ.get('PMC_ARCH', 'speccnn4l1_bn')
     mc.dim_z, mc.input_tensor_size = int(os.environ.get('PMC_DZ', 64)), (B, 1, 257, 347)
@@ -117,7 +118,7 @@ def traffic(fetch_dir, write_dir):
 def mfma(d):
     out = {'_about': 'matrix-pipe utilisation per launch: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / '
                      '(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); GRBM_GUI_ACTIVE is reported summed over the 8 XCDs '
-                     '(1.6 M for a 75 us kernel). profiles/pmc_launches.py, batch 256, configuration ' + os.environ.get('PMC_ARCH', 'speccnn4l1_bn') + ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32')}
+                     '(1.6 M for a 75 us kernel). profiles/pmc_launches.py, batch 256, configuration ' + os.environ.get('PMC_ARCH', 'speccnn4l1_bn') + ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32') + ' fp32 products ' + os.environ.get('PMC_FP32_PRODUCTS', 'native')}
     for lab, c, names in segments(d):
         if lab['algorithmic_flops'] <= 0:
             continue
@@ -133,7 +134,7 @@ def counters(dirs):
     ... behind DESIGN.md 3.9), plus two ratios: wave cycles parked (s_waitcnt / barrier) and VALU instructions per MFMA."""
     out = {'_about': 'SQ counters per launch (sum over the launch\'s kernels, per repetition), rocprofv3 --kernel-trace --pmc '
                      'passes of profiles/pmc_launches.py; configuration ' + os.environ.get('PMC_ARCH', 'speccnn4l1_bn') +
-                     ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32') +
+                     ' z=' + os.environ.get('PMC_DZ', '64') + ' ' + os.environ.get('PMC_DTYPE', 'fp32') + ' fp32 products ' + os.environ.get('PMC_FP32_PRODUCTS', 'native') +
                      '.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles '
                      '(MI355X_MICROARCH.md).'}
     merged = {}

@@ -12,7 +12,8 @@ if [ "$PART" = all ] || [ "$PART" = stats ]; then
     f=$(find $O/prof_${TAG}_$n -name '*kernel_stats.csv' | head -1); cp "$f" $O/$2_placeholder 2>/dev/null; echo "$f"
   }
   for spec in "07_4l:" "07_8l:--arch speccnn8l1_bn" "07_8l_bf16:--arch speccnn8l1_bn --dim-z 512 --dtype bf16" "07_audio:--input audio" \
-              "08_4l_step_only:--no-roofline" "08_8l_step_only:--no-roofline --arch speccnn8l1_bn" "08_8l_bf16_step_only:--no-roofline --arch speccnn8l1_bn --dim-z 512 --dtype bf16"; do
+              "08_4l_step_only:--no-roofline" "08_8l_step_only:--no-roofline --arch speccnn8l1_bn" "08_8l_bf16_step_only:--no-roofline --arch speccnn8l1_bn --dim-z 512 --dtype bf16" \
+              "09_8l_split_step_only:--no-roofline --arch speccnn8l1_bn --fp32-products bf16x6"; do
     n=${spec%%:*}; fl=${spec#*:}
     rm -rf $O/prof_tmp
     rocprofv3 --kernel-trace --stats -d $O/prof_tmp --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline $fl > $O/prof_${TAG}_$n.log 2>&1
@@ -22,9 +23,10 @@ if [ "$PART" = all ] || [ "$PART" = stats ]; then
   rm -rf $O/prof_tmp $O/*_placeholder
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
-  for cfg in "4l:speccnn4l1_bn:64:fp32" "8l:speccnn8l1_bn:64:fp32" "8l_bf16:speccnn8l1_bn:512:bf16"; do
-    IFS=: read name arch dz dt <<< "$cfg"
-    export PMC_ARCH=$arch PMC_DZ=$dz PMC_DTYPE=$dt PMC_LABELS=pmc_labels_$name.json
+  for cfg in "4l:speccnn4l1_bn:64:fp32:native" "8l:speccnn8l1_bn:64:fp32:native" "8l_bf16:speccnn8l1_bn:512:bf16:native" \
+             "8l_split:speccnn8l1_bn:64:fp32:bf16x6"; do
+    IFS=: read name arch dz dt prod <<< "$cfg"
+    export PMC_ARCH=$arch PMC_DZ=$dz PMC_DTYPE=$dt PMC_FP32_PRODUCTS=$prod PMC_LABELS=pmc_labels_$name.json
     rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 $R/profiles/pmc_launches.py run > $O/pmc_fetch_$name.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 $R/profiles/pmc_launches.py run > $O/pmc_write_$name.log 2>&1
