@@ -96,10 +96,9 @@ __device__ __forceinline__ void shadow_split_k1_item(int it, const float* __rest
                                                      unsigned short* __restrict__ sh) {
   const int per = CS * CB / 8, up = it >= per;
   if (up) it -= per;
-  const int M = up ? CB : CS, K = up ? CS : CB, nks = K / 32;
+  const int K = up ? CS : CB, nks = K / 32;
   const int lane = it & 63, rest = it >> 6, ks = rest % nks, r16 = rest / nks;
   const int m = r16 * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
-  (void)M;
   float h[8], mid[8], l[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) pgv_split3(up ? w[(size_t)(k0 + c) * CB + m] : w[(size_t)m * CB + k0 + c], h[c], mid[c], l[c]);
