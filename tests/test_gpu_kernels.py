@@ -919,6 +919,49 @@ def test_bf16_native_kernels_finalize_the_input_batchnorm(ops, case):
         ops.set_compute_dtype('fp32')
 
 
+@pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 19), (128, 256, 4, 2, 2, 9, 12, 19), (256, 512, 4, 2, 2, 5, 7, 21),
+                                  (512, 2048, 1, 1, 0, 3, 4, 19)])
+def test_split_product_kernels_finalize_the_input_batchnorm(ops, case):
+    """The PGV_COMPUTE_F32_SPLIT kernels take ``in_bn`` as well (the 1x1 ones too, unlike their native fp32 counterparts): bit
+    for bit the output, vectors and running statistics of pgv_bn_finalize + the plain call, ragged sample groups."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    ops.set_fp32_products('bf16x6')
+    try:
+        for up in (False, True):
+            C, H, W = (Cs, geom.Hs, geom.Ws) if up else (Cb, Hb, Wb)
+            Co = Cb if up else Cs
+            x = dev(synth_vec((B, C, H, W), 0.371, 0.2) * 1.3 + 0.1)
+            w = dev(synth_vec((Cs, Cb, k, k), 0.6180, 0.7) * (1.0 / np.sqrt(C * k * k)))
+            sh = ops.conv_weight_shadow(geom, w)
+            assert sh is not None
+            bias = dev(synth_vec((Co,), 1.1, 0.3) * 0.1)
+            gamma, beta = dev(1.0 + 0.3 * synth_vec((C,), 2.1, 0.1)), dev(0.3 * synth_vec((C,), 2.9, 0.6))
+            stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+            ops.bn_stats(x, stats)
+            fn = ops.conv_up if up else ops.conv_down
+            res = []
+            for fused in (False, True):
+                rm, rv = dev(synth_vec((C,), 0.5, 0.5)), dev(synth_vec((C,), 0.7, 0.1).abs() + 0.5)
+                nbt = torch.tensor(3, device='cuda', dtype=torch.int64)
+                vec = [torch.full((C,), float('nan'), device='cuda') for _ in range(4)]
+                src = ops.bn_src(stats, B * H * W, gamma, beta, 1e-5, 0.1, rm, rv, nbt, *vec)
+                if fused:
+                    y = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, in_bn=src, w_shadow=sh)
+                else:
+                    ops.bn_src_finalize(src)
+                    y = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=vec[0], in_shift=vec[1], w_shadow=sh)
+                res.append([y, rm, rv, nbt] + vec)
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+            assert res[1][3].item() == 4
+            # and without a shadow the call computes natively under the flag
+            y_native = fn(geom, x, w, bias, ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=res[0][4], in_shift=res[0][5])
+            assert rel_l2(y_native, res[0][0]) < 1e-5      # (structured inputs: the sums cancel)
+    finally:
+        ops.set_fp32_products('native')
+
+
 @pytest.mark.parametrize("policy", [0, 3])
 @pytest.mark.parametrize("case", [(8, 16, 4, 2, 2, 129, 174, 3), (16, 32, 4, 2, 2, 65, 88, 3), (32, 64, 4, 2, 2, 33, 45, 5),
                                   (1, 8, 5, 2, 2, 257, 347, 2), (64, 128, 4, 2, 2, 17, 23, 3), (3, 5, 4, 2, 2, 10, 13, 2),
