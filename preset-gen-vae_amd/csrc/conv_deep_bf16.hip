@@ -1539,37 +1539,6 @@ __global__ __launch_bounds__(256) void k1_shadow_kernel(const float* __restrict_
   for (int it = blockIdx.x * 256 + threadIdx.x; it < n8; it += gridDim.x * 256) shadow_k1_item(it, w, CS, CB, down, up);
 }
 
-// PGV_COMPUTE_F32_SPLIT shadow: three bf16 planes (hi, mid, lo: w = w1 + w2 + w3 exactly) of the up layout [cb][cs/8][phase][tap][8]
-__device__ __forceinline__ void shadow_split_item(int it, const float* __restrict__ w, int CS, int CB, u16* __restrict__ up3) {
-  const int kh = it & 3, cb = (it >> 2) % CB, g = (it >> 2) / CB;
-  f32x4 v[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const f32x4*>(w + ((size_t)((g * 8 + c) * CB + cb) * 16 + kh * 4));
-  const int ph = kh & 1, th = kh >> 1;
-  const size_t plane = (size_t)CS * CB * 16;
-#pragma unroll
-  for (int kw = 0; kw < 4; ++kw) {
-    const int pw = kw & 1, tw = kw >> 1;
-    const size_t o = ((size_t)((cb * (CS / 8) + g) * 4 + 2 * ph + pw) * 4 + 2 * th + tw) * 8;
-    float hi[8], mid[8], lo[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float x = v[c][kw];
-      hi[c] = (float)(__bf16)x;
-      const float r = x - hi[c];
-      mid[c] = (float)(__bf16)r;
-      lo[c] = r - mid[c];
-    }
-    *reinterpret_cast<u32x4*>(up3 + o) = u32x4{pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]), pack_bf16x2(hi[4], hi[5]), pack_bf16x2(hi[6], hi[7])};
-    *reinterpret_cast<u32x4*>(up3 + plane + o) = u32x4{pack_bf16x2(mid[0], mid[1]), pack_bf16x2(mid[2], mid[3]), pack_bf16x2(mid[4], mid[5]), pack_bf16x2(mid[6], mid[7])};
-    *reinterpret_cast<u32x4*>(up3 + 2 * plane + o) = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(lo[4], lo[5]), pack_bf16x2(lo[6], lo[7])};
-  }
-}
-__global__ __launch_bounds__(256) void split_shadow_kernel(const float* __restrict__ w, int CS, int CB, u16* __restrict__ up3) {
-  const int items = CB * (CS / 8) * 4;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) shadow_split_item(it, w, CS, CB, up3);
-}
-
 // the shadows of several layers in ONE launch (a conv stack's forward pass: 4 - 6 us of launch latency per layer otherwise)
 struct ShadowTable {
   static constexpr int MAXN = 8;
@@ -1590,10 +1559,14 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
       shadow_split_down_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
     else
       shadow_split_up_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
+  } else if (t.k1[e] == 5) {   // large-plane split (conv_big_split.hip): down fragments, then up fragments
+    const int nd = t.CS[e] * t.CB[e] * 2;
+    if (it < nd)
+      shadow_bigq_down_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
+    else
+      shadow_bigq_up_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
   } else if (t.k1[e] == 4)
     shadow_split_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
-  else if (t.k1[e] == 2)
-    shadow_split_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
   else if (t.k1[e])
     shadow_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e], up);
   else
@@ -2080,12 +2053,6 @@ __global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __
   }
 }
 
-// PGV_COMPUTE_F32_SPLIT: the 32 -> 16 channel transposed convolution onto 65x88 with fp32 products as six bf16 instructions
-bool up_big_split_shape(const pgv_conv_desc* d) {
-  return (d->flags & PGV_COMPUTE_F32_SPLIT) && !(d->flags & PGV_COMPUTE_BF16) && d->kh == 4 && d->kw == 4 && d->stride == 2 &&
-         d->pad == 2 && d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32;
-}
-
 bool up_big_bf16_shape(const pgv_conv_desc* d) {
   if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
   return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
@@ -2431,7 +2398,7 @@ int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
   if (!(d->flags & PGV_COMPUTE_BF16)) {   // PGV_COMPUTE_F32_SPLIT: 3 bf16 planes; the deep layers hold a down and an up layout
     if (pgv_deep_split_shape(d)) return (int64_t)12 * d->Cs * d->Cb * 16;
     if (pgv_k1_split_shape(d)) return (int64_t)12 * d->Cs * d->Cb;
-    return up_big_split_shape(d) ? (int64_t)6 * d->Cs * d->Cb * 16 : 0;
+    return pgv_big_split_shape(d) ? (int64_t)12 * d->Cs * d->Cb * 16 : 0;
   }
   if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
   return (deep_bf16_shape(d) || up_big_bf16_shape(d)) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
@@ -2439,17 +2406,13 @@ int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
   if (!(d->flags & PGV_COMPUTE_BF16)) {
-    if (pgv_deep_split_shape(d) || pgv_k1_split_shape(d)) {
+    if (pgv_deep_split_shape(d) || pgv_k1_split_shape(d) || pgv_big_split_shape(d)) {
       const pgv_conv_desc* one[1] = {d};
       const float* ws[1] = {w};
       void* sh[1] = {shadow};
       return pgv_conv_weight_shadows_impl(1, one, ws, sh, st);
     }
-    if (!up_big_split_shape(d)) return 0;
-    hipLaunchKernelGGL(split_shadow_kernel, dim3((unsigned)((d->Cb * (d->Cs / 8) * 4 + 255) / 256)), dim3(256), 0, st, w, d->Cs,
-                       d->Cb, (u16*)shadow);
-    PGV_CHECK_LAUNCH("conv_weight_shadow");
-    return 1;
+    return 0;
   }
   if (k1_bf16_shape(d)) {
     u16* down = (u16*)shadow;
@@ -2563,8 +2526,8 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
 int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                          const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                          hipStream_t st, const pgv_bn_src* bn) {
-  if (d->w_shadow && up_big_split_shape(d))   // fp32 products as six bf16 instructions
-    return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2, 3>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // fp32 products as six bf16 instructions (PGV_COMPUTE_F32_SPLIT): conv_big_split.hip
+  if (int rc = pgv_conv_up_big_split(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn)) return rc;
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
   if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65) return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
@@ -2578,6 +2541,7 @@ int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const fl
 int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                            hipStream_t st, const pgv_bn_src* bn) {
+  if (int rc = pgv_conv_down_big_split(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn)) return rc;
   if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !down_big_bf16_shape(d) || (g_deep_bf16_dbg & 32)) return 0;
   if (d->Hb == 33) {
     // (the plain forward form stays on the band kernel's bf16 loop: 32 us there, 38 us here; the fused input gradient with
@@ -2598,18 +2562,17 @@ int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
     const pgv_conv_desc* d = descs[i];
-    const bool bf = (d->flags & PGV_COMPUTE_BF16) != 0, split = up_big_split_shape(d), dsplit = pgv_deep_split_shape(d);
+    const bool bf = (d->flags & PGV_COMPUTE_BF16) != 0, split = pgv_big_split_shape(d), dsplit = pgv_deep_split_shape(d);
     const bool k1 = bf && k1_bf16_shape(d), k1split = pgv_k1_split_shape(d);
     if (!split && !dsplit && !k1split && !(bf && (k1 || deep_bf16_shape(d) || up_big_bf16_shape(d)))) return 0;
     t.w[i] = ws[i];
     t.down[i] = (u16*)shadows[i];
     t.CS[i] = d->Cs, t.CB[i] = d->Cb;
-    // kind: 0 k4 bf16, 1 1x1 bf16, 2 split up planes, 3 split down + up fragments, 4 split 1x1 fragments
-    t.k1[i] = k1split ? 4 : dsplit ? 3 : split ? 2 : (k1 ? 1 : 0);
+    // kind: 0 k4 bf16, 1 1x1 bf16, 3 deep split down + up fragments, 4 split 1x1 fragments, 5 large-plane split fragments
+    t.k1[i] = k1split ? 4 : dsplit ? 3 : split ? 5 : (k1 ? 1 : 0);
     t.items[i] = k1split ? d->Cs * d->Cb / 4
-                 : dsplit  ? d->Cs * d->Cb * 4
-                 : split ? d->Cb * (d->Cs / 8) * 4
-                         : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
+                 : (dsplit || split) ? d->Cs * d->Cb * 4
+                                     : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
     t.blk0[i] = blocks;
     blocks += (t.items[i] + 255) / 256;
   }

@@ -143,6 +143,15 @@ int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const flo
 int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                            const pgv_bn_src* bn);
+// ... and of the large-plane layers of the 4-layer stack (conv_big_split.hip): two teams of waves alternating between the
+// matrix pipe and the epilogue / staging work, weights in registers
+bool pgv_big_split_shape(const pgv_conv_desc* d);
+int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
+                            const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                            hipStream_t st, const pgv_bn_src* bn);
+int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                          const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
+                          hipStream_t st, const pgv_bn_src* bn);
 int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d);
 int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                              const float* small_in, const float* small_scale, const float* small_shift, float* gw,

@@ -668,7 +668,36 @@ def run_dataset_seam_case(out_dir):
     print('dataset seam ->', path, os.path.getsize(path) // 1024, 'KiB')
 
 
+def run_mel_basis_case(out_dir):
+    """Pin for the mel filterbank.  The reference calls librosa.feature.melspectrogram(S=.., n_mels=257,
+    norm=None) (utils/audio.py:85-86; librosa ~=0.8.0 is neither vendored nor installed in this image).  What the image
+    does have is ``transformers.audio_utils.mel_filter_bank``, an INDEPENDENT implementation that documents its
+    ``mel_scale="slaney", norm=None`` mode as reproducing ``librosa.filters.mel(htk=False, norm=None)``.  The golden is
+    that implementation's basis for the reference's parameters, stored as CSR (1016 non-zeros of 257 x 513) - not
+    librosa 0.8 itself, which this container cannot run."""
+    # (transformers probes optional packages with importlib.util.find_spec, which rejects the MagicMock stubs above)
+    stubs = {k: sys.modules.pop(k) for k in ('librosa', 'librosa.display', 'soundfile') if k in sys.modules}
+    try:
+        from transformers.audio_utils import mel_filter_bank
+    finally:
+        sys.modules.update(stubs)
+    fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=257, min_frequency=0.0, max_frequency=11025.0,
+                         sampling_rate=22050, norm=None, mel_scale="slaney")           # [513, 257]
+    fb = np.asarray(fb, dtype=np.float64).T                                            # [n_mels, n_bins]
+    rows, cols = np.nonzero(fb)
+    row_ptr = np.zeros(258, dtype=np.int32)
+    np.add.at(row_ptr, rows + 1, 1)
+    np.savez_compressed(os.path.join(out_dir, 'mel_basis.npz'), shape=np.array(fb.shape, dtype=np.int32),
+                        row_ptr=np.cumsum(row_ptr).astype(np.int32), col=cols.astype(np.int32), val=fb[rows, cols],
+                        row_sums=fb.sum(axis=1), source=np.array('transformers.audio_utils.mel_filter_bank '
+                                                                 '(norm=None, mel_scale="slaney")'))
+    print('mel_basis', fb.shape, 'nnz', len(rows), 'max taps per row', int(np.diff(np.cumsum(row_ptr)).max()))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'mel_basis':
+        run_mel_basis_case(HERE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'dataset_seam':
         run_dataset_seam_case(HERE)
         sys.exit(0)
@@ -710,3 +739,4 @@ if __name__ == '__main__':
     run_dataset_seam_case(HERE)
     run_probability_case(HERE)
     run_params_loss_case(HERE)
+    run_mel_basis_case(HERE)

@@ -518,49 +518,110 @@ def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
         ops.set_fp32_products('native')
 
 
-@pytest.mark.parametrize("B", [3, 40])
-def test_conv_up_65x88_fp32_products_as_six_bf16_instructions(ops, B):
-    """PGV_COMPUTE_F32_SPLIT: the fp32 transposed convolution onto 65x88 with every product as six bf16 matrix instructions on
-    exact three-way splits of both operands (up_big, NP = 3) - against float64 at fp32 tolerances, no further from it than the
-    native fp32 kernel is, forward form (lazy normalisation, bias, activation, statistics) and fused input-gradient form."""
-    case = (16, 32, 4, 2, 2, 65, 88, B)
-    Cb, Cs, k, s, p, Hb, Wb, _ = case
+BIG_SPLIT_CASES = [(8, 16, 4, 2, 2, 129, 174, 2), (8, 16, 4, 2, 2, 129, 174, 9), (16, 32, 4, 2, 2, 65, 88, 3),
+                   (16, 32, 4, 2, 2, 65, 88, 40), (32, 64, 4, 2, 2, 33, 45, 5), (32, 64, 4, 2, 2, 33, 45, 70)]
+
+
+@pytest.mark.parametrize("case", BIG_SPLIT_CASES)
+def test_big_plane_kernels_fp32_products_as_six_bf16_instructions(ops, case):
+    """conv_big_split.hip (PGV_COMPUTE_F32_SPLIT): the three large-plane k4 s2 p2 layers of the headline stack, both
+    directions, with every fp32 product as six bf16 matrix instructions on exact three-way splits - against float64 at fp32
+    tolerances and within 1.25 x the native fp32 kernels' own error; batches with fewer units than workgroups and with
+    several units per workgroup; bit-for-bit repeatable.  Forward form (lazy normalisation, bias, activation, BatchNorm
+    statistics, statistics copies) and the fused input-gradient form (pgv_bwd_fuse: bias-gradient copies, class sums)."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
     big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
     geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
     assert ops.conv_weight_shadow(geom, dev(w)) is None          # native fp32 products: no shadow
     oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
-    ref = F.leaky_relu(F.conv_transpose2d(_affine_fma(small, sc_s, sh_s).double(), w.double(), bias_b.double(), stride=s,
-                                          padding=p, output_padding=(oph, opw)), 0.1)
-    native = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
+    refd = F.leaky_relu(F.conv2d(_affine_fma(big, sc_b, sh_b).double(), w.double(), bias_s.double(), stride=s, padding=p), 0.1)
+    refu = F.leaky_relu(F.conv_transpose2d(_affine_fma(small, sc_s, sh_s).double(), w.double(), bias_b.double(), stride=s,
+                                           padding=p, output_padding=(oph, opw)), 0.1)
+    nat_d = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b), in_shift=dev(sh_b))
+    nat_u = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
     C8 = ops.CLS_COPIES
     ops.set_fp32_products('bf16x6')
     try:
         sh = ops.conv_weight_shadow(geom, dev(w))
-        assert sh is not None and sh.numel() == 6 * w.numel()     # three bf16 planes
-        # the planes add up to the weight exactly
-        planes = sh.view(torch.bfloat16).view(3, 16, 4, 2, 2, 2, 2, 8).float().sum(0)     # [cb][csg][ph][pw][th][tw][8]
-        for ph, pw, th, tw in ((0, 1, 1, 0), (1, 1, 0, 1)):
-            assert torch.equal(planes[:, :, ph, pw, th, tw, :].reshape(16, 32), dev(w)[:, :, ph + 2 * th, pw + 2 * tw].t())
+        assert sh is not None and sh.numel() == 12 * w.numel()    # three bf16 planes, fragment order, both directions
+        # down layout [M tile][K step = kh * (Cb/8) + g][plane][kq][m][kw][channel of pair 4g + kq]: the planes add up to
+        # the weight exactly
+        planes = sh[:6 * w.numel()].view(torch.bfloat16).view(Cs // 16, 4, Cb // 8, 3, 4, 16, 4, 2).float().sum(3)
+        back = planes.permute(0, 4, 2, 3, 6, 1, 5).reshape(Cs, Cb, 4, 4)     # [mt][m][g][kq][c][kh][kw]
+        assert torch.equal(back, dev(w))
+        # up layout [M tile][g][plane][kq = 2 th + tw][m][8 small channels], M rows r = (2 ph + pw) * Cb + cb
+        planes = sh[6 * w.numel():].view(torch.bfloat16).view(Cb // 4, Cs // 8, 3, 2, 2, 16, 8).float().sum(2)
+        rows = planes.permute(0, 4, 1, 5, 2, 3).reshape(2, 2, Cb, Cs, 2, 2)     # [ph][pw][cb][cs][th][tw]
+        back = rows.permute(3, 2, 4, 0, 5, 1).reshape(Cs, Cb, 4, 4)           # kh = 2 th + ph, kw = 2 tw + pw
+        assert torch.equal(back, dev(w))
+
+        # ---- convolution: forward form
+        stats = torch.empty(2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                            in_shift=dev(sh_b), stats=stats, w_shadow=sh)
+        e_split, e_native = rel_l2(got, refd), rel_l2(nat_d, refd)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([refd.sum(dim=(0, 2, 3)), (refd * refd).sum(dim=(0, 2, 3))])) < 2e-5
+        again = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
+                              in_shift=dev(sh_b), w_shadow=sh)
+        assert torch.equal(got, again)
+        stc = torch.zeros(C8 * 2 * Cs, device='cuda', dtype=torch.float64)
+        got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, stats=stc, prezeroed=True,
+                            stats_copies=True, w_shadow=sh)
+        assert rel_l2(stc.view(C8, -1).sum(0), torch.cat([got.double().sum(dim=(0, 2, 3)),
+                                                          (got.double() ** 2).sum(dim=(0, 2, 3))])) < 2e-5
+        # ---- convolution as the input gradient of a transposed convolution: plain and with the fused backward epilogue
+        prod = F.conv2d(big.double(), w.double(), None, stride=s, padding=p)     # (structured inputs: the sums cancel)
+        got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        nat = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+        e_split, e_native = rel_l2(got, prod), rel_l2(nat, prod)
+        assert e_split < 1e-5 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        for act in (ops.PGV_ACT_LEAKY_RELU, ops.PGV_ACT_NONE):
+            a = (dev(small) * 1.3 + 0.1).contiguous()
+            coef = dev(torch.cat([1.0 + 0.3 * synth_vec((Cs,), 4.1, 0.2), 0.05 * synth_vec((Cs,), 4.7, 0.3),
+                                  0.02 * synth_vec((Cs,), 5.3, 0.8)]))
+            gbc, cls = torch.zeros(C8 * Cs, device='cuda'), torch.zeros(C8 * 4 * Cs, device='cuda')
+            out = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0,
+                                bwd_fuse=(a, coef, gbc, act, 0.1, cls, C8), w_shadow=sh)
+            refb = _bwd_apply_ref(prod.cuda(), a, coef, act, 0.1)
+            assert rel_l2(out, refb) < 2e-6, rel_l2(out, refb)
+            l1 = refb.abs().sum(dim=(0, 2, 3))
+            assert ((gbc.view(C8, Cs).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+            ref_cls = torch.stack([refb[:, :, r::2, c::2].sum(dim=(0, 2, 3)) for r in range(2) for c in range(2)], dim=1)
+            assert ((cls.view(C8, Cs, 4).double().sum(0) - ref_cls).abs() <= 2e-6 * l1.view(-1, 1) + 1e-12).all()
+
+        # ---- transposed convolution: forward form
         stats = torch.empty(2 * Cb, device='cuda', dtype=torch.float64)
         got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                           in_shift=dev(sh_s), stats=stats, w_shadow=sh)
-        e_split, e_native = rel_l2(got, ref), rel_l2(native, ref)
-        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
-        assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
+        e_split, e_native = rel_l2(got, refu), rel_l2(nat_u, refu)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
         again = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                             in_shift=dev(sh_s), w_shadow=sh)
         assert torch.equal(got, again)
+        stc = torch.zeros(C8 * 2 * Cb, device='cuda', dtype=torch.float64)
+        got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, stats=stc, prezeroed=True,
+                          stats_copies=True, w_shadow=sh)
+        assert rel_l2(stc.view(C8, -1).sum(0), torch.cat([got.double().sum(dim=(0, 2, 3)),
+                                                          (got.double() ** 2).sum(dim=(0, 2, 3))])) < 2e-5
+        # ---- ... as the input gradient of a convolution: plain and fused (bias-gradient copies)
         prod = F.conv_transpose2d(small.double(), w.double(), None, stride=s, padding=p, output_padding=(oph, opw))
-        a = (dev(big) * 1.3 + 0.1).contiguous()
-        coef = dev(torch.cat([1.0 + 0.3 * synth_vec((Cb,), 4.1, 0.2), 0.05 * synth_vec((Cb,), 4.7, 0.3),
-                              0.02 * synth_vec((Cb,), 5.3, 0.8)]))
-        gbc = torch.zeros(C8 * Cb, device='cuda')
-        out = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0,
-                          bwd_fuse=(a, coef, gbc, ops.PGV_ACT_LEAKY_RELU, 0.1, None, C8), w_shadow=sh)
-        refb = _bwd_apply_ref(prod.cuda(), a, coef, ops.PGV_ACT_LEAKY_RELU, 0.1)
-        assert rel_l2(out, refb) < 2e-6
-        l1 = refb.abs().sum(dim=(0, 2, 3))
-        assert ((gbc.view(C8, Cb).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+        got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
+        nat = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0)
+        e_split, e_native = rel_l2(got, prod), rel_l2(nat, prod)
+        assert e_split < 1e-5 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        for act in (ops.PGV_ACT_LEAKY_RELU, ops.PGV_ACT_NONE):
+            a = (dev(big) * 1.3 + 0.1).contiguous()
+            coef = dev(torch.cat([1.0 + 0.3 * synth_vec((Cb,), 4.1, 0.2), 0.05 * synth_vec((Cb,), 4.7, 0.3),
+                                  0.02 * synth_vec((Cb,), 5.3, 0.8)]))
+            gbc = torch.zeros(C8 * Cb, device='cuda')
+            out = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0,
+                              bwd_fuse=(a, coef, gbc, act, 0.1, None, C8), w_shadow=sh)
+            refb = _bwd_apply_ref(prod.cuda(), a, coef, act, 0.1)
+            assert rel_l2(out, refb) < 2e-6
+            l1 = refb.abs().sum(dim=(0, 2, 3))
+            assert ((gbc.view(C8, Cb).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
     finally:
         ops.set_fp32_products('native')
 
@@ -920,7 +981,8 @@ def test_bf16_native_kernels_finalize_the_input_batchnorm(ops, case):
 
 
 @pytest.mark.parametrize("case", [(64, 128, 4, 2, 2, 17, 23, 19), (128, 256, 4, 2, 2, 9, 12, 19), (256, 512, 4, 2, 2, 5, 7, 21),
-                                  (512, 2048, 1, 1, 0, 3, 4, 19)])
+                                  (512, 2048, 1, 1, 0, 3, 4, 19), (8, 16, 4, 2, 2, 129, 174, 9), (16, 32, 4, 2, 2, 65, 88, 19),
+                                  (32, 64, 4, 2, 2, 33, 45, 31)])
 def test_split_product_kernels_finalize_the_input_batchnorm(ops, case):
     """The PGV_COMPUTE_F32_SPLIT kernels take ``in_bn`` as well (the 1x1 ones too, unlike their native fp32 counterparts): bit
     for bit the output, vectors and running statistics of pgv_bn_finalize + the plain call, ragged sample groups."""

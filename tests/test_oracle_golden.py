@@ -212,6 +212,34 @@ def test_mel_filterbank_known_answers():
     assert fb.sum(axis=0).max() <= 1.0 + 1e-6
 
 
+def _golden_mel_basis():
+    g = load_golden('mel_basis.npz')
+    fb = np.zeros(tuple(g['shape']), dtype=np.float64)
+    rp = g['row_ptr']
+    for r in range(fb.shape[0]):
+        fb[r, g['col'][rp[r]:rp[r + 1]]] = g['val'][rp[r]:rp[r + 1]]
+    return g, fb
+
+
+def test_mel_filterbank_matches_independent_implementation():
+    """The pin of SURVEY 8 a12: the oracle's Slaney basis AND the product's host-side basis (utils/audio.slaney_mel_basis,
+    the CSR the HIP kernel reads) against ``tests/golden/mel_basis.npz`` - the basis of
+    transformers.audio_utils.mel_filter_bank(norm=None, mel_scale="slaney"), an independent implementation documented to
+    reproduce librosa.filters.mel(htk=False, norm=None), generated in the build container by make_goldens.py (librosa 0.8
+    itself, the reference's dependency, is not obtainable here)."""
+    import importlib
+    g, ref = _golden_mel_basis()
+    assert ref.shape == (257, 513) and len(g['val']) == 1016
+    fb = ao.mel_filterbank()
+    assert np.array_equal(fb != 0, ref != 0)
+    assert np.abs(fb.astype(np.float64) - ref).max() < 1e-7
+    audio = importlib.import_module('preset_gen_vae_amd.utils.audio')
+    prod = audio.slaney_mel_basis(22050, 1024, 257)
+    assert prod.shape == (257, 513) and np.array_equal(prod != 0, ref != 0)
+    assert np.abs(prod.astype(np.float64) - ref).max() < 1e-7
+    np.testing.assert_allclose(prod.astype(np.float64).sum(axis=1), g['row_sums'], atol=2e-6)
+
+
 def test_minmax_normalisation():
     s = np.array([-120.0, -60.0, 0.0])
     np.testing.assert_allclose(ao.minmax_normalize(s, -120.0, 0.0), [-1.0, 0.0, 1.0])
