@@ -5,26 +5,29 @@
 // train step (BatchNorm finalize in the prologue, BatchNorm statistics, pgv_bwd_fuse incl. class sums and bias-gradient
 // copies).
 //
-// Structure ("two teams"): one 512-thread workgroup per CU, persistent over its units (sample, band of 2 output rows / 2
-// grid rows).  The 8 waves form two TEAMS of four (one wave per SIMD each).  A unit is computed in two halves - team 0's
-// and team 1's share of its outputs (the two channel halves of a convolution; the two output-row parities of a transposed
-// convolution) - in two consecutive SEGMENTS separated by one workgroup barrier: while team t multiplies (its SIMD's matrix
-// pipe streams v_mfma_f32_16x16x32_bf16), team 1 - t, on the same four SIMDs, runs everything else: moves its finished
-// half of the previous unit out (bias / activation / statistics or the fused backward), splits its share of the NEXT
-// unit's input band into the three plane images of the other LDS stage.  So every SIMD always holds one matrix wave and
-// one vector wave, the roles swap every segment, and nothing but the barrier joins them.
-//   * weights: the wave's A fragments for its (M tile, K range) of all three planes live in REGISTERS for the whole kernel
-//     (24 - 96 VGPRs), read once from a split shadow in fragment order (shadow_bigq_*_item below);
-//   * activations: three plane images per stage; two stages (unit j in stage j & 1: both teams read it, in consecutive
-//     segments, while the next unit is committed to the other one).  Convolution: channel-PAIR planar images [pair][row]
-//     [plane][column], a dword = the bf16 pair (channels 2p, 2p + 1) of one pixel, so that a loader item (two channels x 4
-//     consecutive pixels, 16-byte global loads) is ONE 16-byte LDS store per plane - conflict free, where pixel-major
-//     images gave 16- to 32-way conflicts on the 4-byte stores - and the B fragment of output pixel ow is the 4-dword
-//     window of input columns 2 ow - 2 .. 2 ow + 1 (the four kernel columns), read as two ds_read_b64 (windows start at
-//     even dwords).  Transposed convolution: pixel-major images (8 channels = 16 bytes, swizzled), a loader item = one
-//     pixel x 8 channels (coalesced 4-byte loads along the row) = one 16-byte store per plane;
-//   * outputs: per team a [channel][pixels] tile in LDS, written from the accumulators (two waves that split K write a tile
-//     each, added up in the move-out), moved out as contiguous 16-byte runs.
+// Structure: one 512-thread workgroup per CU, persistent over its units (sample, band of R output rows / UB grid rows).
+// Per unit all eight waves go through TWO PHASES, separated by workgroup barriers:
+//   matrix phase  - request the next unit's input band (global -> registers) and this unit's saved activations (fused
+//                   form), then the wave's share of the products: v_mfma_f32_16x16x32_bf16 x 6 per fragment pair, the B
+//                   fragments read from the LDS image PD steps ahead, the accumulators written to the output tile in LDS;
+//   vector phase  - split the next unit's band into its three bf16 plane images (the stage is free: everybody has left the
+//                   matrix phase), then move this unit's tile out (bias / activation / statistics or the fused backward).
+// The phases are NOT overlapped on purpose.  A first version ran two teams of four waves in opposite phases (one matrix
+// wave and one vector wave per SIMD at any time): v_mfma_f32_16x16x32_bf16 holds a SIMD's vector issue for 8 of its 16
+// cycles, the vector wave got one instruction through per ~10 clocks and the matrix wave ran at half rate beside it - both
+// phases took 3 - 4 k clocks per unit where 1.2 k of matrix time was the floor (in-kernel stamps, scratch/bigq_stamps.py).
+// With the phases in sequence the vector work issues from two waves per SIMD at full rate and the matrix pipe is shared by
+// two waves that hide each other's LDS latency.
+//   * weights: a wave's A fragments for its (M tiles, K range), all three planes, live in REGISTERS for the whole kernel
+//     (24 - 96 VGPRs), read once from a split shadow in fragment order (shadow_bigq_*_item, conv_deep_common.h);
+//   * activations: three plane images.  Convolution: channel-PAIR planar image [pair][row][plane][column], a dword = the
+//     bf16 pair (channels 2p, 2p + 1) of one pixel: a loader item (two channels x 4 consecutive pixels, 16-byte loads) is
+//     ONE 16-byte LDS store per plane - conflict free, where pixel-major images gave 16- to 32-way conflicts on 4-byte
+//     stores - and the B fragment of output pixel ow is the 4-dword window of input columns 2 ow - 2 .. 2 ow + 1 (the four
+//     kernel columns) at an 8-byte aligned address.  Transposed convolution: pixel-major image (8 channels = 16 bytes,
+//     swizzled), a loader item = one pixel x 8 channels (coalesced 4-byte loads along the row) = one 16-byte store per plane;
+//   * outputs: a [channel][pixels] tile in LDS per K group of waves (waves that split K write a tile each; LDS float atomics
+//     into one tile cost 3.5 k clocks per unit), added up in a fixed order and moved out as contiguous 16-byte runs.
 #include "conv_tile.h"
 #include "conv_deep_common.h"
 
@@ -33,9 +36,9 @@ static unsigned long long* g_bigq_stamps = nullptr;
 extern "C" void pgv_dbg_set_bigq_stamps(void* p) { g_bigq_stamps = (unsigned long long*)p; }
 #define QSTAMP_ARG , unsigned long long* __restrict__ stamps
 #define QSTAMP_PASS , g_bigq_stamps
-#define QSTAMP(j, k)                                                                                             \
-  do {                                                                                                           \
-    if (stamps && blockIdx.x == 0 && lane == 0 && tw == 0 && (j) < 60) stamps[(team * 64 + (j) + 2) * 16 + (k)] = clock64(); \
+#define QSTAMP(j, k)                                                                                                    \
+  do {                                                                                                                  \
+    if (stamps && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && (j) < 60) stamps[((wave >> 2) * 64 + (j) + 2) * 16 + (k)] = clock64(); \
   } while (0)
 #else
 #define QSTAMP_ARG
@@ -70,39 +73,35 @@ __device__ __forceinline__ f4u buffer_load_x4(__amdgpu_buffer_rsrc_t r, unsigned
   return __builtin_bit_cast(f4u, v);
 }
 
-// workgroup barrier between segments: this wave's LDS traffic complete, then s_barrier - without the vector-memory wait of
-// __syncthreads() (which would expose the latency of every segment's global loads and stores)
+// workgroup barrier between phases: this wave's LDS traffic complete, then s_barrier - without the vector-memory wait of
+// __syncthreads() (which would expose the latency of every unit's global loads and stores)
 __device__ __forceinline__ void ws_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // DOWN: small = conv_{s2,p2,k4}(big').  GEMM: M = small channels, K = (kernel row, 8 big channels) x 4 kernel columns,
-// N = output pixels.  ROWHALF = false: team t owns the channel half t (CS / 2 channels, all pixels of the band);
-// ROWHALF = true: team t owns output row t of the band, all channels (its waves then hold all M tiles' weights).
-// A wave owns MW M tiles (every B fragment it reads feeds 6 MW instructions), KW K steps and TMAX pixel tiles; PD = how many
-// steps ahead it requests fragments.
-template <int CB_, int CS_, int H_, int W_, bool ROWHALF_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1>
+// N = the band's output pixels.  A wave owns MW M tiles (every B fragment it reads feeds 6 MW instructions), KW K steps and
+// TMAX pixel tiles; PD = how many steps ahead it requests fragments.
+template <int CB_, int CS_, int H_, int W_, int R_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1>
 struct DownQ {
-  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_;
-  static constexpr bool ROWHALF = ROWHALF_;
-  static constexpr int R = 2, XR = 2 * R + 2;
+  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, R = R_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_;
+  static constexpr int XR = 2 * R + 2;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, BANDS = (Hs + R - 1) / R;
   static constexpr int NCP = CB / 2, NG = CB / 8;                     // channel pairs; K groups of 8 channels (4 pairs)
   // image: dword (pair, row, plane, column), column = input column + 4; rows of WPD dwords, pair planes CPS dwords apart with
-  // CPS = 32 (mod 64): the two 16-lane halves of a ds_read_b64 group (pairs kq, kq + 1) then sit on disjoint banks
+  // CPS = 32 (mod 64): the two 16-lane halves of a read group (pairs kq, kq + 1) then sit on disjoint banks
   static constexpr int WPD = (2 * Ws + 4 + 3) / 4 * 4;
   static constexpr int CPS = ((XR * 3 * WPD - 32 + 63) / 64) * 64 + 32;
   static constexpr int STAGE = NCP * CPS * 4;                         // bytes
   static constexpr int KSTEPS = 4 * NG, KHW = 4 / KSPLIT, KW = KHW * NG;   // K steps; kernel rows / K steps of a wave
-  static constexpr int MT_TEAM = ROWHALF ? CS / 16 : CS / 32, CT = MT_TEAM * 16;   // M tiles / channels of a team's tile
-  static constexpr int NPX = ROWHALF ? Ws : R * Ws;                   // pixels of a team's tile
-  static constexpr int NT = (NPX + 15) / 16, TMAX = (NT + NSPLIT - 1) / NSPLIT;
-  static constexpr int OSTR = (NPX + 3) / 4 * 4, O_SLICE = CT * OSTR, O_FLOATS = KSPLIT * O_SLICE;   // a team's tile(s)
-  static constexpr int QX = (W + 3) / 4, ITEMS = NCP * (XR / 2) * QX, QB = (ITEMS + 255) / 256;   // a team's loader items
-  static constexpr int LPC = 256 / CT, QO = ((NPX + 3) / 4 + LPC - 1) / LPC;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE + 2 * (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CB + 8);
-  static_assert((MT_TEAM / MW) * KSPLIT * NSPLIT == 4 && MT_TEAM % MW == 0 && 4 % KSPLIT == 0, "four waves per team");
-  static_assert(CPS >= XR * 3 * WPD && WPD >= 4 * QX + 4 && W >= 4 && LPC >= 1 && LPC <= 64 && CS % (ROWHALF ? 16 : 32) == 0, "tile shapes");
-  static_assert(LDS_BYTES <= 160 * 1024 && STAGE < 65536, "LDS budget / immediate offsets");
+  static constexpr int MTN = CS / 16, MG = MTN / MW;                  // M tiles; M groups over the waves
+  static constexpr int NPX = R * Ws, NT = (NPX + 15) / 16, TMAX = (NT + NSPLIT - 1) / NSPLIT;
+  static constexpr int OSTR = (NPX + 3) / 4 * 4, O_SLICE = CS * OSTR, O_FLOATS = KSPLIT * O_SLICE;
+  static constexpr int QX = (W + 3) / 4, ITEMS = NCP * XR * QX, QB = (ITEMS + 511) / 512;   // loader items
+  static constexpr int LPC = 512 / CS, QO = ((NPX + 3) / 4 + LPC - 1) / LPC;
+  static constexpr size_t LDS_BYTES = (size_t)STAGE + (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CB + 8);
+  static_assert(MG * KSPLIT * NSPLIT == 8 && MTN % MW == 0 && 4 % KSPLIT == 0, "eight waves");
+  static_assert(CPS >= XR * 3 * WPD && WPD >= 4 * QX + 4 && W >= 4 && LPC >= 1 && LPC <= 64 && R % 2 == 0, "tile shapes");
+  static_assert(LDS_BYTES <= 160 * 1024 && ((NG - 1) * 4 * CPS + 3 * 3 * WPD + 2 * WPD) * 4 + 16 < 65536, "LDS budget / immediate offsets");
 };
 
 template <class G, bool FUSE>
@@ -112,20 +111,17 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
                                                      float* __restrict__ out, double* __restrict__ stats, int stat_stride,
                                                      pgv_bn_src in_bn, pgv_bwd_fuse fuse QSTAMP_ARG) {
   constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, R = G::R, NPX = G::NPX;
-  constexpr int NG = G::NG, WPD = G::WPD, CPS = G::CPS, CT = G::CT, OSTR = G::OSTR, LPC = G::LPC, QO = G::QO;
+  constexpr int NG = G::NG, WPD = G::WPD, CPS = G::CPS, OSTR = G::OSTR, LPC = G::LPC, QO = G::QO, MW = G::MW;
   typedef unsigned u4a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-byte LDS load from an 8-byte aligned address
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* lds_x = ldsb;
-  float* otile_all = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);
-  float* aff = otile_all + 2 * G::O_FLOATS;   // [2*CB]
+  float* otile = reinterpret_cast<float*>(ldsb + G::STAGE);
+  float* aff = otile + G::O_FLOATS;   // [2*CB]
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), team = wave >> 2, tw = wave & 3, ttid = tid & 255;
-  constexpr int MW = G::MW, MG = G::MT_TEAM / MW;   // M tiles per wave / M groups of a team
-  const int mtl = (tw % MG) * MW, kg = (tw / MG) % G::KSPLIT, ng = tw / (MG * G::KSPLIT);
-  float* otile = otile_all + team * G::O_FLOATS;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
 
-  for (int i = tid; i < (int)((2 * G::STAGE + 2 * G::O_FLOATS * 4) / 16); i += 512)
-    reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   for (int i = tid; i < CB; i += 512) {
     float sc = 1.f, sh = 0.f;
     if (in_bn.stats)
@@ -135,47 +131,43 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     aff[i] = sc;
     aff[CB + i] = sh;
   }
-  // ---- this wave's weight fragments: M tiles mtg .. mtg + MW - 1, K steps [kg * KW, + KW), three planes
+  // ---- this wave's weight fragments: M tiles mtl .. mtl + MW - 1, K steps [kg * KW, + KW), three planes
   u32x4 af[MW][G::KW][3];
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw) {
-    const int mtg = (G::ROWHALF ? mtl : team * G::MT_TEAM + mtl) + mw;
-    const u32x4* a_src = wsh + ((size_t)(mtg * G::KSTEPS + kg * G::KW) * 3) * 64 + lane;
+    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * G::KSTEPS + kg * G::KW) * 3) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < G::KW; ++k)
 #pragma unroll
       for (int p = 0; p < 3; ++p) af[mw][k][p] = a_src[(k * 3 + p) * 64];
   }
   // ---- this wave's pixel tiles ng, ng + NSPLIT, ...: byte offset of the lane's window (pair kq, the wave's first kernel
-  // row, plane 0, image column 2 ow + 2): 16 bytes at an 8-byte aligned address, ONE ds_read_b128 (gfx950 reads LDS
-  // unaligned; as two ds_read_b64 the compiler fuses pairs of them into ds_read2_b64, which costs twice their LDS cycles)
+  // row, plane 0, image column 2 ow + 2): 16 bytes at an 8-byte aligned address (the compiler reads them as ds_read2_b64;
+  // a ds_read_b128 at such an address takes 64 LDS clocks instead of 8, scratch/ubench/lds_read_forms.hip)
   int blo[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
-    const int tile = ng + G::NSPLIT * t;
-    const int n = min(tile * 16 + m, NPX - 1);
-    const int ohl = G::ROWHALF ? team : n / Ws, ow = G::ROWHALF ? n : n - ohl * Ws;
+    const int n = min((ng + G::NSPLIT * t) * 16 + m, NPX - 1), ohl = n / Ws, ow = n - ohl * Ws;
     blo[t] = (kq * CPS + (2 * ohl + kg * G::KHW) * 3 * WPD + 2 * ow + 2) * 4;
   }
-  // ---- loader items of this team: rows [3 team, +3) of the band, (channel pair, row, quad of 4 columns)
+  // ---- loader items: (channel pair, band row, quad of 4 columns)
   int l_src[G::QB], l_dst[G::QB], l_cr[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
-    const int q = min(ttid + 256 * i, G::ITEMS - 1);
-    const int cp = q / ((G::XR / 2) * G::QX), rem = q - cp * ((G::XR / 2) * G::QX), rl = rem / G::QX, qi = rem - rl * G::QX;
-    const int r = (G::XR / 2) * team + rl;
+    const int q = min(tid + 512 * i, G::ITEMS - 1);
+    const int cp = q / (G::XR * G::QX), rem = q - cp * (G::XR * G::QX), r = rem / G::QX, qi = rem - r * G::QX;
     l_src[i] = (2 * cp) * (H * W) + 4 * qi;                       // + sample * CB * H * W + image row * W
     l_dst[i] = (cp * CPS + r * 3 * WPD + 4 * qi + 4) * 4;         // plane 0, byte offset
-    l_cr[i] = (cp << 8) | r | ((ttid + 256 * i < G::ITEMS) ? 0x8000 : 0) | ((4 * qi + 4 > W) ? 0x4000 : 0);   // (0x4000: ragged row end)
+    l_cr[i] = (cp << 8) | r | ((tid + 512 * i < G::ITEMS) ? 0x8000 : 0) | ((4 * qi + 4 > W) ? 0x4000 : 0);   // (0x4000: ragged row end)
   }
-  // ---- move-out role: LPC lanes per channel of the team's tile
-  const int och = ttid / LPC, part = ttid % LPC, ocg = G::ROWHALF ? och : team * CT + och;
+  // ---- move-out role: LPC lanes per channel
+  const int och = tid / LPC, part = tid % LPC;
   const pgv_act_params ap = pgv_act_setup(act, slope);
-  const float bv = (!FUSE && bias) ? bias[ocg] : 0.f;
+  const float bv = (!FUSE && bias) ? bias[och] : 0.f;
   float ka = 1.f, kb = 0.f, kc = 0.f;
   pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
   if (FUSE) {
-    ka = fuse.coef[ocg], kb = fuse.coef[CS + ocg], kc = fuse.coef[2 * CS + ocg];
+    ka = fuse.coef[och], kb = fuse.coef[CS + och], kc = fuse.coef[2 * CS + och];
     actd = pgv_actd_setup(fuse.act, fuse.slope);
   }
   // forward: s[0] / s[1] = sum / sum of squares; fused: s[k] = sum of g_y in (row, column) parity class k (bands start at
@@ -208,7 +200,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       rb[i][1] = buffer_load_x4(big_rs, o + (unsigned)(H * W * 4));
     }
   };
-  auto commit = [&](unsigned char* st) {
+  auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       const int c = 2 * ((l_cr[i] >> 8) & 63);
@@ -224,24 +216,19 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
           pgv_split3_pair(y0, y1, a1, a2, a3);
           ph[e] = a1, pm[e] = a2, pl[e] = a3;
         }
-        *reinterpret_cast<u32x4*>(st + l_dst[i]) = ph;
-        *reinterpret_cast<u32x4*>(st + l_dst[i] + WPD * 4) = pm;
-        *reinterpret_cast<u32x4*>(st + l_dst[i] + 2 * WPD * 4) = pl;
+        *reinterpret_cast<u32x4*>(lds_x + l_dst[i]) = ph;
+        *reinterpret_cast<u32x4*>(lds_x + l_dst[i] + WPD * 4) = pm;
+        *reinterpret_cast<u32x4*>(lds_x + l_dst[i] + 2 * WPD * 4) = pl;
       }
     }
   };
-  // the saved activation of the fused epilogue: requested in the matrix segment, used in the next one
+  // the saved activation of the fused epilogue: requested in the matrix phase, used in the vector phase
   f4u av[QO];
   float av_t = 0.f;
   auto tile_geom = [&](int j, int& nfl, size_t& goff) {
     const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, oh0 = band * R;
-    if (G::ROWHALF) {
-      nfl = oh0 + team < Hs ? Ws : 0;
-      goff = ((size_t)b * CS + ocg) * G::P + (oh0 + team) * Ws;
-    } else {
-      nfl = min(R, Hs - oh0) * Ws;
-      goff = ((size_t)b * CS + ocg) * G::P + oh0 * Ws;
-    }
+    nfl = min(R, Hs - oh0) * Ws;
+    goff = ((size_t)b * CS + och) * G::P + oh0 * Ws;
   };
   auto fetch_a = [&](int j) {
     int nfl;
@@ -257,68 +244,77 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     if (part < nfl - tail0) av_t = a_p[tail0 + part];
   };
 
-  // ---- prologue: unit 0 into stage 0 (both teams their rows); team 1 already holds its rows of unit 1
   if (J > 0) issue(0);
-  __syncthreads();   // images zeroed, affine staged
-  if (J > 0) commit(lds_x);
-  if (team == 1 && J > 1) issue(1);
+  __syncthreads();   // image zeroed, affine staged
+  if (J > 0) commit();
   __syncthreads();
+  // Everything the prologue loaded is READ here: the compiler may sink those loads (read-only data) below the barriers, and
+  // with any of them pending at the loop header its counter model waits for "them" inside the loop - s_waitcnt vmcnt(n)
+  // with n counting down through the matrix loop, i.e. for the band loads just issued, and vmcnt(0) in front of the next
+  // issue, i.e. for the stores of the vector phase (1.6 - 2.9 k clocks per unit).
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int k = 0; k < G::KW; ++k) asm volatile("" ::"v"(af[mw][k][0]), "v"(af[mw][k][1]), "v"(af[mw][k][2]));
+  asm volatile("" ::"v"(bv), "v"(ka), "v"(kb), "v"(kc));
 
-  // ================= matrix segment: this team's half of unit j =================
-  auto mphase = [&](int j) {
-    if (j + 1 + team < J) issue(j + 1 + team);   // committed in this team's NEXT vector segment
-    if (FUSE) fetch_a(j);
+#pragma unroll 1
+  for (int j = 0; j < J; ++j) {
+    // ================= matrix phase =================
+    QSTAMP(j, 0);
+    if (j + 1 < J) issue(j + 1);
     QSTAMP(j, 1);
-    const unsigned char* st = lds_x + (j & 1) * G::STAGE;
-    f32x4 acc[MW][TMAX];
+    {
+      f32x4 acc[MW][TMAX];
 #pragma unroll
-    for (int mw = 0; mw < MW; ++mw)
+      for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // steps (kh, g, t) in order; the fragments of step i + PD are requested before the products of step i are issued (an LDS
-    // round trip under load is ~200 clocks, the six instructions of a tile 96)
-    constexpr int NSTEP = G::KHW * NG * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
-    u32x4 bf[PD + 1][3];
-    auto frag = [&](int i, u32x4 (&f)[3]) {
-      const int t = i % TMAX, g = (i / TMAX) % NG, kh = i / (TMAX * NG);
-      const int off = (g * 4 * CPS + kh * 3 * WPD) * 4;
+        for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // steps (kh, g, t) in order; the fragments of step i + PD are requested before the products of step i are issued
+      constexpr int NSTEP = G::KHW * NG * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
+      u32x4 bf[PD + 1][3];
+      auto frag = [&](int i, u32x4 (&f)[3]) {
+        const int t = i % TMAX, g = (i / TMAX) % NG, kh = i / (TMAX * NG);
+        const int off = (g * 4 * CPS + kh * 3 * WPD) * 4;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u4a8*>(st + blo[t] + off + p * WPD * 4);
-    };
+        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
+      };
 #pragma unroll
-    for (int i = 0; i < PD; ++i) frag(i, bf[i]);
+      for (int i = 0; i < PD; ++i) frag(i, bf[i]);
 #pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-      const int t = i % TMAX, ks = i / TMAX;
-      if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
-      if (ng + G::NSPLIT * t < G::NT) {
+      for (int i = 0; i < NSTEP; ++i) {
+        const int t = i % TMAX, ks = i / TMAX;
+        if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
+        // (no branch on `tile < NT` here: a wave with a tile short of TMAX multiplies a clamped copy that is never written -
+        // with the wave-uniform branch in the unrolled loop the accumulators were copied from block to block, spilling)
 #pragma unroll
         for (int mw = 0; mw < MW; ++mw) acc[mw][t] = six_products(af[mw][ks], bf[i % (PD + 1)], acc[mw][t]);
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the fragment loads of many steps: registers)
+      }
+      QSTAMP(j, 2);
+      // (the saved activations of the fused epilogue are requested only now: their registers are not live across the matrix
+      // loop, and the tile write + the wait for the slowest wave at the barrier cover the latency)
+      if (FUSE) fetch_a(j);
+      float* ot = otile + kg * G::O_SLICE;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int n = (ng + G::NSPLIT * t) * 16 + m;
+        if (ng + G::NSPLIT * t < G::NT && n < NPX) {
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ot[((mtl + mw) * 16 + 4 * kq + i) * OSTR + n] = acc[mw][t][i];
+        }
       }
     }
-    QSTAMP(j, 2);
-    // (waves that split K write a tile each: the move-out adds them - LDS float atomics into one tile cost a pair of waves
-    // 3.5 k clocks per unit)
-    float* ot = otile + kg * G::O_SLICE;
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      const int n = (ng + G::NSPLIT * t) * 16 + m;
-      if (ng + G::NSPLIT * t < G::NT && n < NPX) {
-#pragma unroll
-        for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ot[((mtl + mw) * 16 + 4 * kq + i) * OSTR + n] = acc[mw][t][i];
-      }
-    }
-  };
-  // ========== vector segment: commit this team's rows of unit jc (the loads were issued in its previous matrix segment;
-  // FIRST: they are the youngest vector-memory operations then, and a wait for them does not wait for this segment's
-  // stores), then move unit je's half out ==========
-  auto ephase = [&](int je, int jc) {
-    // Every register the previous matrix segment loaded into is READ here, whether or not the unit exists: the compiler's
-    // vector-memory counter model then has nothing pending at the loop's back edge.  (With the loads consumed only under
-    // `jc < J`, it protected the registers' next overwrite with s_waitcnt vmcnt(0) in the matrix segment - after this
-    // segment's stores had been issued, i.e. every trip waited for its stores to complete: 5 us per segment.)
+    QSTAMP(j, 4);
+    ws_sync();
+    QSTAMP(j, 5);
+    // ================= vector phase =================
+    // Every register the matrix phase loaded into is READ here, whether or not the next unit exists: the compiler's
+    // vector-memory counter model then has nothing pending at the loop's back edge (with the loads consumed only under a
+    // condition it protected the registers' next overwrite with s_waitcnt vmcnt(0) - behind the stores of this phase).
+    // The commit comes first: the loads are the youngest vector-memory operations then.
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) asm volatile("" ::"v"(rb[i][0]), "v"(rb[i][1]));
     if (FUSE) {
@@ -326,95 +322,61 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       for (int i = 0; i < QO; ++i) asm volatile("" ::"v"(av[i]));
       asm volatile("" ::"v"(av_t));
     }
-    QSTAMP(je, 6);
-    if (jc < J) commit(lds_x + (jc & 1) * G::STAGE);
-    QSTAMP(je, 7);
-    if (je < 0) return;
-    int nfl;
-    size_t goff;
-    tile_geom(je, nfl, goff);
-    float* o_p = out + goff;
-    float* t_p = otile + och * OSTR;
-    const int tail0 = nfl & ~3;
-    const bool has_tail = part < nfl - tail0;
-    float vt = 0.f;
-    if (has_tail) {
-      vt = t_p[tail0 + part];
+    QSTAMP(j, 6);
+    if (j + 1 < J) commit();
+    QSTAMP(j, 7);
+    {
+      int nfl;
+      size_t goff;
+      tile_geom(j, nfl, goff);
+      float* o_p = out + goff;
+      const float* t_p = otile + och * OSTR;
+      const int tail0 = nfl & ~3;
 #pragma unroll
-      for (int k = 1; k < G::KSPLIT; ++k) vt += t_p[k * G::O_SLICE + tail0 + part];
-    }
+      for (int i = 0; i < QO; ++i) {
+        const int q4 = part + LPC * i;
+        if (4 * q4 + 4 <= nfl) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
 #pragma unroll
-    for (int i = 0; i < QO; ++i) {
-      const int q4 = part + LPC * i;
-      if (4 * q4 + 4 <= nfl) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
+          for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * q4);   // (fixed order)
+          if (FUSE) {
 #pragma unroll
-        for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * q4);   // (fixed order)
-        if (FUSE) {
+            for (int e = 0; e < 4; ++e) {
+              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
+              slot[i][e] += v[e];
+            }
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-            slot[i][e] += v[e];
+            for (int e = 0; e < 4; ++e) v[e] = pgv_act_apply(v[e] + bv, ap);
+            s[0] += (v[0] + v[1]) + (v[2] + v[3]);
+            s[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = pgv_act_apply(v[e] + bv, ap);
-          s[0] += (v[0] + v[1]) + (v[2] + v[3]);
-          s[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
         }
-        *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
+      }
+      if (part < nfl - tail0) {
+        const int idx = tail0 + part;
+        float vt = t_p[idx];
+#pragma unroll
+        for (int k = 1; k < G::KSPLIT; ++k) vt += t_p[k * G::O_SLICE + idx];
+        if (FUSE) {
+          vt = pgv_bwd_apply(vt, av_t, ka, kb, kc, actd);
+          const int rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
+          s[0] += cls == 0 ? vt : 0.f;
+          s[1] += cls == 1 ? vt : 0.f;
+          s[2] += cls == 2 ? vt : 0.f;
+          s[3] += cls == 3 ? vt : 0.f;
+        } else {
+          vt = pgv_act_apply(vt + bv, ap);
+          s[0] += vt;
+          s[1] += vt * vt;
+        }
+        o_p[idx] = vt;
       }
     }
-    if (has_tail) {
-      const int idx = tail0 + part;
-      if (FUSE) {
-        vt = pgv_bwd_apply(vt, av_t, ka, kb, kc, actd);
-        const int rr = G::ROWHALF ? team : idx / Ws, cc = G::ROWHALF ? idx : idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
-        s[0] += cls == 0 ? vt : 0.f;
-        s[1] += cls == 1 ? vt : 0.f;
-        s[2] += cls == 2 ? vt : 0.f;
-        s[3] += cls == 3 ? vt : 0.f;
-      } else {
-        vt = pgv_act_apply(vt + bv, ap);
-        s[0] += vt;
-        s[1] += vt * vt;
-      }
-      o_p[idx] = vt;
-    }
-  };
-  // Segment s: team 0 multiplies unit j in segment 2j and moves it out in 2j + 1 (committing its rows of unit j + 1);
-  // team 1 multiplies unit j in segment 2j + 1 and moves it out in 2j + 2 (committing its rows of unit j + 2; its rows of
-  // unit 1 in segment 0).  One loop per team, its two segments per trip in program order: the compiler's vector-memory
-  // counter model is then exact (one loop alternating on a flag made it wait for the stores of every segment).
-  if (team == 0) {
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-      QSTAMP(j, 0);
-      mphase(j);
-      QSTAMP(j, 4);
-      ws_sync();
-      QSTAMP(j, 5);
-      ephase(j, j + 1);
-      QSTAMP(j, 8);
-      ws_sync();
-      QSTAMP(j, 9);
-    }
+    QSTAMP(j, 8);
     ws_sync();
-  } else {
-    ephase(-1, 1);
-    ws_sync();
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-      QSTAMP(j, 0);
-      mphase(j);
-      QSTAMP(j, 4);
-      ws_sync();
-      QSTAMP(j, 5);
-      ephase(j, j + 2);
-      QSTAMP(j, 8);
-      ws_sync();
-      QSTAMP(j, 9);
-    }
+    QSTAMP(j, 9);
   }
 
   // ---- per-channel sums of the workgroup
@@ -423,8 +385,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     for (int i = 0; i < QO; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int idx = 4 * (part + LPC * i) + e;
-        const int rr = G::ROWHALF ? team : idx / Ws, cc = G::ROWHALF ? idx : idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
+        const int idx = 4 * (part + LPC * i) + e, rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
         s[0] += cls == 0 ? slot[i][e] : 0.f;
         s[1] += cls == 1 ? slot[i][e] : 0.f;
         s[2] += cls == 2 ? slot[i][e] : 0.f;
@@ -438,15 +399,15 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   if (part == 0) {
     const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
     if (FUSE) {
-      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CS : 0) + ocg, (s[0] + s[1]) + (s[2] + s[3]));
+      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CS : 0) + och, (s[0] + s[1]) + (s[2] + s[3]));
       if (fuse.cls) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(fuse.cls + ((size_t)copy * CS + ocg) * 4 + k, s[k]);
+        for (int k = 0; k < 4; ++k) atomicAdd(fuse.cls + ((size_t)copy * CS + och) * 4 + k, s[k]);
       }
     } else if (stats) {
       double* sp = stats + (size_t)copy * stat_stride;
-      atomicAdd(&sp[ocg], (double)s[0]);
-      atomicAdd(&sp[CS + ocg], (double)s[1]);
+      atomicAdd(&sp[och], (double)s[0]);
+      atomicAdd(&sp[CS + och], (double)s[1]);
     }
   }
 }
@@ -480,26 +441,25 @@ int launch_down_q(const pgv_conv_desc* d, const float* big, const float* in_scal
 // ---------------------------------------------------------------------------------------------------------------
 // UP: big = conv_transpose_{s2,p2,k4}(small').  Four 2x2-tap phase convolutions sharing ONE input gather: GEMM with
 // M = (output phase, big channel), K = (8 small channels) x the 4 taps of a phase, N = grid positions (u, v) of the band;
-// output (2u + ph, 2v + pw) takes taps kh = ph + 2 th, kw = pw + 2 tw at input (u + 1 - th, v + 1 - tw).  Team t owns the
-// output rows of parity ph = t (M rows (pw, channel)).
-template <int CB_, int CS_, int H_, int W_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1, int UB_ = 2>
+// output (2u + ph, 2v + pw) takes taps kh = ph + 2 th, kw = pw + 2 tw at input (u + 1 - th, v + 1 - tw).
+template <int CB_, int CS_, int H_, int W_, int UB_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1>
 struct UpQ {
-  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_, UB = UB_;
-  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws;
+  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, UB = UB_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_;
+  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, RB = 2 * UB;
   static constexpr int HU = (H + 1) / 2, WU = (W + 1) / 2, BANDS = (HU + UB - 1) / UB;   // grid rows / columns with an output
   static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;                  // small band image (+ zero column)
   static constexpr int NG = CS / 8, PB = CS * 2;
   static constexpr int SH = NG == 8 ? 1 : (NG == 4 ? 2 : 3);   // group g of pixel px sits at g ^ ((px >> SH) & (NG - 1))
   static constexpr int KSTEPS = NG, KW = NG / KSPLIT;
-  static constexpr int MT_TEAM = CB / 8;                        // M tiles of a team: rows (pw, channel)
+  static constexpr int MTN = CB / 4, MG = MTN / MW;             // M tiles: rows (phase, channel); M groups over the waves
   static constexpr int NPOS = UB * WU, NT = (NPOS + 15) / 16, TMAX = (NT + NSPLIT - 1) / NSPLIT;
-  static constexpr int WR = (W + 3) / 4 * 4, QW = WR / 4, OCH = UB * WR, O_SLICE = CB * OCH, O_FLOATS = KSPLIT * O_SLICE;   // a team's tile(s) [CB][UB][WR]
+  static constexpr int OCH = RB * W, O_SLICE = CB * OCH, O_FLOATS = KSPLIT * O_SLICE;   // tile [CB][RB rows][W]
   static constexpr int IMG = (SPX * PB + 15) / 16 * 16, STAGE = 3 * IMG;
-  static constexpr int S_RUN = SROWS * Ws, ITEMS = (NG / 2) * S_RUN, QB = (ITEMS + 255) / 256;   // a team's loader items: (group, pixel)
-  static constexpr int LPC = 256 / CB, QO = (UB * QW + LPC - 1) / LPC;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE + 2 * (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CS + 8);
-  static_assert((MT_TEAM / MW) * KSPLIT * NSPLIT == 4 && MT_TEAM % MW == 0 && NG % KSPLIT == 0, "four waves per team");
-  static_assert((NG == 8 || NG == 4 || NG == 2) && (CB == 32 || CB == 16 || CB == 8) && LPC <= 64, "channel counts of the stack");
+  static constexpr int S_RUN = SROWS * Ws, ITEMS = NG * S_RUN, QB = (ITEMS + 511) / 512;   // loader items: (group, pixel)
+  static constexpr int LPC = 512 / CB, O4 = OCH / 4, QO = (O4 + LPC - 1) / LPC;
+  static constexpr size_t LDS_BYTES = (size_t)STAGE + (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CS + 8);
+  static_assert(MG * KSPLIT * NSPLIT == 8 && MTN % MW == 0 && NG % KSPLIT == 0, "eight waves");
+  static_assert((NG == 8 || NG == 4 || NG == 2) && (CB == 32 || CB == 16 || CB == 8) && LPC <= 64 && OCH % 4 == 0, "channel counts of the stack");
   static_assert(LDS_BYTES <= 160 * 1024 && 2 * IMG + SPX * PB < 65536, "LDS budget / immediate offsets");
 };
 
@@ -509,20 +469,17 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
                                                    const float* __restrict__ bias, int act, float slope,
                                                    float* __restrict__ out, double* __restrict__ stats, int stat_stride,
                                                    pgv_bn_src in_bn, pgv_bwd_fuse fuse QSTAMP_ARG) {
-  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, UB = G::UB;
-  constexpr int NG = G::NG, PB = G::PB, SH = G::SH, SWP = G::SWP, WR = G::WR, QW = G::QW, OCH = G::OCH, LPC = G::LPC, QO = G::QO;
+  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, UB = G::UB, RB = G::RB;
+  constexpr int NG = G::NG, PB = G::PB, SH = G::SH, SWP = G::SWP, OCH = G::OCH, LPC = G::LPC, QO = G::QO, MW = G::MW;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* lds_s = ldsb;
-  float* otile_all = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);
-  float* aff = otile_all + 2 * G::O_FLOATS;   // [2*CS]
+  float* otile = reinterpret_cast<float*>(ldsb + G::STAGE);
+  float* aff = otile + G::O_FLOATS;   // [2*CS]
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), team = wave >> 2, tw = wave & 3, ttid = tid & 255;
-  constexpr int MW = G::MW, MG = G::MT_TEAM / MW;   // M tiles per wave / M groups of a team
-  const int mtl = (tw % MG) * MW, kg = (tw / MG) % G::KSPLIT, ng = tw / (MG * G::KSPLIT);
-  float* otile = otile_all + team * G::O_FLOATS;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
 
-  for (int i = tid; i < (int)((2 * G::STAGE + 2 * G::O_FLOATS * 4) / 16); i += 512)
-    reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   for (int i = tid; i < CS; i += 512) {
     float sc = 1.f, sh = 0.f;
     if (in_bn.stats)
@@ -532,47 +489,50 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     aff[i] = sc;
     aff[CS + i] = sh;
   }
-  // ---- this wave's weight fragments: M tiles team * MT_TEAM + mtl .. + MW - 1, K steps [kg * KW, + KW), three planes
+  // ---- this wave's weight fragments: M tiles mtl .. mtl + MW - 1, K steps [kg * KW, + KW), three planes
   u32x4 af[MW][G::KW][3];
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw) {
-    const u32x4* a_src = wsh + ((size_t)((team * G::MT_TEAM + mtl + mw) * NG + kg * G::KW) * 3) * 64 + lane;
+    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * NG + kg * G::KW) * 3) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < G::KW; ++k)
 #pragma unroll
       for (int p = 0; p < 3; ++p) af[mw][k][p] = a_src[(k * 3 + p) * 64];
   }
-  // ---- this lane's accumulator rows: (pw, channels c0 .. c0 + 3) of the team's row list, per M tile of the wave
-  int pw[MW], c0[MW];
+  // ---- this lane's accumulator rows: (phase, channels c0 .. c0 + 3) of the row list (phase, channel), per M tile of the wave
+  int ph_[MW], pw_[MW], c0[MW];
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw) {
-    const int rl0 = (mtl + mw) * 16 + 4 * kq;
-    pw[mw] = rl0 / CB;
-    c0[mw] = rl0 - pw[mw] * CB;
+    const int rl0 = (mtl + mw) * 16 + 4 * kq, phase = rl0 / CB;
+    ph_[mw] = phase >> 1;
+    pw_[mw] = phase & 1;
+    c0[mw] = rl0 - phase * CB;
   }
   const int th = kq >> 1, twp = kq & 1;
-  int boff[TMAX], bsw[TMAX], opos[TMAX];   // (opos: tile position at output column 2 v, -1 = no such position)
+  int boff[TMAX], bsw[TMAX], opos[TMAX];   // (opos: tile position of output (2 ul, 2 v), -1 = no such grid position)
+  bool oedge[TMAX];                        // (its column 2 v + 1 lies outside the row)
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     const int n = (ng + G::NSPLIT * t) * 16 + m, nn = min(n, G::NPOS - 1), ul = nn / G::WU, v = nn - ul * G::WU;
     const int px = (ul + 1 - th) * SWP + (v + 1 - twp);
     boff[t] = px * PB;
     bsw[t] = (px >> SH) & (NG - 1);
-    opos[t] = (ng + G::NSPLIT * t < G::NT && n < G::NPOS) ? ul * WR + 2 * v : -1;
+    opos[t] = (ng + G::NSPLIT * t < G::NT && n < G::NPOS) ? (2 * ul) * W + 2 * v : -1;
+    oedge[t] = 2 * v + 1 >= W;
   }
-  // ---- loader items of this team: channel groups [team * NG/2, + NG/2) x the pixels of the band's contiguous run; a lane
-  // loads the 8 channels of its pixel (4-byte loads, consecutive lanes = consecutive pixels) and stores 16 bytes per plane
+  // ---- loader items: channel groups x the pixels of the band's contiguous run; a lane loads the 8 channels of its pixel
+  // (4-byte loads, consecutive lanes = consecutive pixels) and stores 16 bytes per plane
   int l_src[G::QB], l_dst[G::QB], l_gi[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
-    const int q = min(ttid + 256 * i, G::ITEMS - 1), gl = q / G::S_RUN, idx = q - gl * G::S_RUN, g = team * (NG / 2) + gl;
+    const int q = min(tid + 512 * i, G::ITEMS - 1), g = q / G::S_RUN, idx = q - g * G::S_RUN;
     const int rr = idx / Ws, cc = idx - rr * Ws, px = rr * SWP + cc;
     l_src[i] = (8 * g) * G::P + idx;             // + sample * CS * P + first row * Ws; + c * P per channel
     l_dst[i] = px * PB + ((g ^ ((px >> SH) & (NG - 1))) * 16);
-    l_gi[i] = (g << 16) | idx | ((ttid + 256 * i < G::ITEMS) ? 0x8000 : 0);
+    l_gi[i] = (g << 16) | idx | ((tid + 512 * i < G::ITEMS) ? 0x8000 : 0);
   }
   // ---- move-out role: LPC lanes per channel
-  const int och = ttid / LPC, part = ttid % LPC;
+  const int och = tid / LPC, part = tid % LPC;
   const pgv_act_params ap = pgv_act_setup(act, slope);
   const float bv = (!FUSE && bias) ? bias[och] : 0.f;
   float ka = 1.f, kb = 0.f, kc = 0.f;
@@ -591,18 +551,18 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   auto issue = [&](int j) {
     const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, r0 = band * UB;
     const int nvalid = (min(Hs, r0 + G::SROWS) - r0) * Ws;   // floats of the run inside the plane (rows beyond it are zeros)
+    const float* bp = small_in + (size_t)b * CS * G::P + r0 * Ws;   // (wave-uniform)
     rb_on = 0;
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       const bool on = (l_gi[i] & 0x7fff) < nvalid;
       rb_on |= on ? (1u << i) : 0u;
-      const float* bp = small_in + (size_t)b * CS * G::P + r0 * Ws;   // (wave-uniform)
       const unsigned o = (unsigned)l_src[i];
 #pragma unroll
       for (int c = 0; c < 8; ++c) rb[i][c] = on ? bp[o + c * G::P] : 0.f;
     }
   };
-  auto commit = [&](unsigned char* st) {
+  auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       if (l_gi[i] & 0x8000) {
@@ -617,76 +577,98 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
           pgv_split3_pair(y0, y1, a1, a2, a3);
           ph[e] = a1, pm[e] = a2, pl[e] = a3;
         }
-        *reinterpret_cast<u32x4*>(st + l_dst[i]) = ph;
-        *reinterpret_cast<u32x4*>(st + G::IMG + l_dst[i]) = pm;
-        *reinterpret_cast<u32x4*>(st + 2 * G::IMG + l_dst[i]) = pl;
+        *reinterpret_cast<u32x4*>(lds_s + l_dst[i]) = ph;
+        *reinterpret_cast<u32x4*>(lds_s + G::IMG + l_dst[i]) = pm;
+        *reinterpret_cast<u32x4*>(lds_s + 2 * G::IMG + l_dst[i]) = pl;
       }
     }
   };
-  // move-out items of a lane: j = part + LPC * i -> (grid row ul, quad q) of its channel
   f4u av[QO];
-  const __amdgpu_buffer_rsrc_t a_rs = tensor_rsrc(FUSE ? fuse.a : small_in, (int64_t)B * CB * (H * W) * 4);
+  float av_t = 0.f;
+  auto tile_geom = [&](int j, int& nfl, size_t& goff) {
+    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, y0 = band * RB;
+    nfl = min(RB, H - y0) * W;
+    goff = ((size_t)b * CB + och) * (H * W) + y0 * W;
+  };
   auto fetch_a = [&](int j) {
-    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, y0 = 2 * band * UB + team;
-    const unsigned ch = ((unsigned)b * CB + och) * (unsigned)(H * W);
+    int nfl;
+    size_t goff;
+    tile_geom(j, nfl, goff);
+    const float* a_p = fuse.a + goff;
 #pragma unroll
     for (int i = 0; i < QO; ++i) {
-      const int it = part + LPC * i, ul = it / QW, q = it - ul * QW, y = y0 + 2 * ul;
-      // (a quad at the ragged end of a row reads on into the next row / zeros behind the tensor: masked where it is used)
-      if (it < UB * QW && y < H) av[i] = buffer_load_x4(a_rs, (ch + (unsigned)(y * W + 4 * q)) * 4u);
+      const int q4 = part + LPC * i;
+      if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
     }
+    const int tail0 = nfl & ~3;
+    if (part < nfl - tail0) av_t = a_p[tail0 + part];
   };
 
   if (J > 0) issue(0);
-  __syncthreads();   // images zeroed, affine staged
-  if (J > 0) commit(lds_s);
-  if (team == 1 && J > 1) issue(1);
+  __syncthreads();   // image zeroed, affine staged
+  if (J > 0) commit();
   __syncthreads();
+  // Everything the prologue loaded is READ here: the compiler may sink those loads (read-only data) below the barriers, and
+  // with any of them pending at the loop header its counter model waits for "them" inside the loop - s_waitcnt vmcnt(n)
+  // with n counting down through the matrix loop, i.e. for the band loads just issued, and vmcnt(0) in front of the next
+  // issue, i.e. for the stores of the vector phase (1.6 - 2.9 k clocks per unit).
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int k = 0; k < G::KW; ++k) asm volatile("" ::"v"(af[mw][k][0]), "v"(af[mw][k][1]), "v"(af[mw][k][2]));
+  asm volatile("" ::"v"(bv), "v"(ka), "v"(kb), "v"(kc));
 
-  auto mphase = [&](int j) {
-    if (j + 1 + team < J) issue(j + 1 + team);
-    if (FUSE) fetch_a(j);
+#pragma unroll 1
+  for (int j = 0; j < J; ++j) {
+    // ================= matrix phase =================
+    QSTAMP(j, 0);
+    if (j + 1 < J) issue(j + 1);
     QSTAMP(j, 1);
-    const unsigned char* st = lds_s + (j & 1) * G::STAGE;
-    f32x4 acc[MW][TMAX];
+    {
+      f32x4 acc[MW][TMAX];
 #pragma unroll
-    for (int mw = 0; mw < MW; ++mw)
+      for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NSTEP = G::KW * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
-    u32x4 bf[PD + 1][3];
-    auto frag = [&](int i, u32x4 (&f)[3]) {
-      const int t = i % TMAX, g = kg * G::KW + i / TMAX;
-      const unsigned char* bp = st + boff[t] + ((g ^ bsw[t]) * 16);
+        for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int NSTEP = G::KW * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
+      u32x4 bf[PD + 1][3];
+      auto frag = [&](int i, u32x4 (&f)[3]) {
+        const int t = i % TMAX, g = kg * G::KW + i / TMAX;
+        const unsigned char* bp = lds_s + boff[t] + ((g ^ bsw[t]) * 16);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
-    };
+        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
+      };
 #pragma unroll
-    for (int i = 0; i < PD; ++i) frag(i, bf[i]);
+      for (int i = 0; i < PD; ++i) frag(i, bf[i]);
 #pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-      const int t = i % TMAX, ks = i / TMAX;
-      if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
-      if (ng + G::NSPLIT * t < G::NT) {
+      for (int i = 0; i < NSTEP; ++i) {
+        const int t = i % TMAX, ks = i / TMAX;
+        if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
+        // (no branch on `tile < NT` here: a wave with a tile short of TMAX multiplies a clamped copy that is never written -
+        // with the wave-uniform branch in the unrolled loop the accumulators were copied from block to block, spilling)
 #pragma unroll
         for (int mw = 0; mw < MW; ++mw) acc[mw][t] = six_products(af[mw][ks], bf[i % (PD + 1)], acc[mw][t]);
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the fragment loads of many steps: registers)
       }
-    }
-    QSTAMP(j, 2);
-    float* ot = otile + kg * G::O_SLICE;   // (waves that split K write a tile each, added up in the move-out)
+      QSTAMP(j, 2);
+      if (FUSE) fetch_a(j);   // (requested only now: see down_q_kernel)
+      float* ot = otile + kg * G::O_SLICE;   // (waves that split K write a tile each, added up in the move-out)
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
+      for (int t = 0; t < TMAX; ++t) {
 #pragma unroll
-      for (int mw = 0; mw < MW; ++mw) {
-        if (opos[t] >= 0 && opos[t] % WR + pw[mw] < W) {
+        for (int mw = 0; mw < MW; ++mw) {
+          // (a position whose output column 2 v + pw lies outside the row is dropped; rows outside the plane are never moved out)
+          if (opos[t] >= 0 && !(oedge[t] && pw_[mw])) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ot[(c0[mw] + i) * OCH + opos[t] + pw[mw]] = acc[mw][t][i];
+            for (int i = 0; i < 4; ++i) ot[(c0[mw] + i) * OCH + opos[t] + ph_[mw] * W + pw_[mw]] = acc[mw][t][i];
+          }
         }
       }
     }
-  };
-  auto ephase = [&](int je, int jc) {
-    // (all loads of the previous matrix segment consumed here for the compiler's counter model: see down_q_kernel)
+    QSTAMP(j, 4);
+    ws_sync();
+    QSTAMP(j, 5);
+    // ================= vector phase ================= (see down_q_kernel)
 #pragma unroll
     for (int i = 0; i < G::QB; ++i)
 #pragma unroll
@@ -694,71 +676,56 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     if (FUSE) {
 #pragma unroll
       for (int i = 0; i < QO; ++i) asm volatile("" ::"v"(av[i]));
+      asm volatile("" ::"v"(av_t));
     }
-    QSTAMP(je, 6);
-    if (jc < J) commit(lds_s + (jc & 1) * G::STAGE);   // (first: see down_q_kernel)
-    QSTAMP(je, 7);
-    if (je < 0) return;
-    const int u = u0 + je * grid, b = u / G::BANDS, band = u - b * G::BANDS, y0 = 2 * band * UB + team;
-    float* o_p = out + ((size_t)b * CB + och) * (H * W);
-    const float* t_p = otile + och * OCH;
+    QSTAMP(j, 6);
+    if (j + 1 < J) commit();
+    QSTAMP(j, 7);
+    {
+      int nfl;
+      size_t goff;
+      tile_geom(j, nfl, goff);
+      float* o_p = out + goff;
+      const float* t_p = otile + och * OCH;
+      const int tail0 = nfl & ~3;
 #pragma unroll
-    for (int i = 0; i < QO; ++i) {
-      const int it = part + LPC * i, ul = it / QW, q = it - ul * QW, y = y0 + 2 * ul, nv = min(4, W - 4 * q);
-      if (it < UB * QW && y < H) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(t_p + ul * WR + 4 * q);
+      for (int i = 0; i < QO; ++i) {
+        const int q4 = part + LPC * i;
+        if (4 * q4 + 4 <= nfl) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
 #pragma unroll
-        for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + ul * WR + 4 * q);   // (fixed order)
+          for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * q4);   // (fixed order)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (FUSE)
-            v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-          else
-            v[e] = pgv_act_apply(v[e] + bv, ap);
-          if (e >= nv) v[e] = 0.f;
-          if (!FUSE) s2 += v[e] * v[e];
-          s1 += v[e];
-        }
-        float* p = o_p + y * W + 4 * q;
-        if (nv == 4) {
-          *reinterpret_cast<f4u*>(p) = f4u{v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) p[e] = v[e];
+          for (int e = 0; e < 4; ++e) {
+            if (FUSE) {
+              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
+            } else {
+              v[e] = pgv_act_apply(v[e] + bv, ap);
+              s2 += v[e] * v[e];
+            }
+            s1 += v[e];
+          }
+          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
         }
       }
+      if (part < nfl - tail0) {   // (a last band of an odd number of odd-width rows)
+        const int idx = tail0 + part;
+        float vt = t_p[idx];
+#pragma unroll
+        for (int k = 1; k < G::KSPLIT; ++k) vt += t_p[k * G::O_SLICE + idx];
+        if (FUSE) {
+          vt = pgv_bwd_apply(vt, av_t, ka, kb, kc, actd);
+        } else {
+          vt = pgv_act_apply(vt + bv, ap);
+          s2 += vt * vt;
+        }
+        s1 += vt;
+        o_p[idx] = vt;
+      }
     }
-  };
-  if (team == 0) {   // (the segment schedule of down_q_kernel)
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-      QSTAMP(j, 0);
-      mphase(j);
-      QSTAMP(j, 4);
-      ws_sync();
-      QSTAMP(j, 5);
-      ephase(j, j + 1);
-      QSTAMP(j, 8);
-      ws_sync();
-      QSTAMP(j, 9);
-    }
+    QSTAMP(j, 8);
     ws_sync();
-  } else {
-    ephase(-1, 1);
-    ws_sync();
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-      QSTAMP(j, 0);
-      mphase(j);
-      QSTAMP(j, 4);
-      ws_sync();
-      QSTAMP(j, 5);
-      ephase(j, j + 2);
-      QSTAMP(j, 8);
-      ws_sync();
-      QSTAMP(j, 9);
-    }
+    QSTAMP(j, 9);
   }
 
   // ---- per-channel sums of the workgroup: BatchNorm statistics (forward) or the bias gradient (fused backward)
@@ -799,7 +766,8 @@ int launch_up_q(const pgv_conv_desc* d, const float* small_in, const float* in_s
   const int units = d->B * G::BANDS;
   const u32x4* up = (const u32x4*)d->w_shadow + (size_t)d->Cs * d->Cb * 6;   // (after the down layout: 96 bytes per weight)
   hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
-                     bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(), f QSTAMP_PASS);
+                     bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(),
+                     f QSTAMP_PASS);
   PGV_CHECK_LAUNCH("conv_up_big_split");
   return 1;
 }
@@ -818,20 +786,26 @@ int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const floa
                             const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                             hipStream_t st, const pgv_bn_src* bn) {
   if (!d->w_shadow || !pgv_big_split_shape(d)) return 0;
-  if (d->Hb == 33)
-    return launch_down_q<DownQ<32, 64, 33, 45, false, 1, 2, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  if (d->Hb == 65)
-    return launch_down_q<DownQ<16, 32, 65, 88, true, 2, 4, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  return launch_down_q<DownQ<8, 16, 129, 174, true, 1, 2, 2, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 33)   // 32 -> 64 channels: bands of 2 rows (46 pixels = 3 tiles), waves = 2 M pairs x 4 kernel rows
+    return launch_down_q<DownQ<32, 64, 33, 45, 2, 2, 4, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 65)   // 16 -> 32 channels: bands of 4 rows (180 pixels = 12 tiles), waves = 2 K halves x 4 pixel groups
+    return launch_down_q<DownQ<16, 32, 65, 88, 4, 2, 2, 4, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // 8 -> 16 channels: bands of 4 rows (352 pixels = 22 tiles), one M tile, waves = 2 K halves x 4 pixel groups
+  return launch_down_q<DownQ<8, 16, 129, 174, 4, 1, 2, 4, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
 
 int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                           hipStream_t st, const pgv_bn_src* bn) {
   if (!d->w_shadow || !pgv_big_split_shape(d)) return 0;
-  if (d->Hb == 33)
-    return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  if (d->Hb == 65)
-    return launch_up_q<UpQ<16, 32, 65, 88, 2, 2, 2, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  return launch_up_q<UpQ<8, 16, 129, 174, 1, 1, 4, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  if (d->Hb == 33)   // 64 -> 32 channels: bands of 4 grid rows (92 positions = 6 tiles), waves = the 8 M tiles (M pairs x K halves spilled)
+  {
+    // (the fused form on bands of 2 grid rows: with 4 its six saved-activation quads per lane spill)
+    if (fuse) return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 2, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+    return launch_up_q<UpQ<32, 64, 33, 45, 4, 1, 1, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  }
+  if (d->Hb == 65)   // 32 -> 16 channels: bands of 4 grid rows (176 positions = 11 tiles), waves = 2 M pairs x 4 position groups
+    return launch_up_q<UpQ<16, 32, 65, 88, 4, 2, 1, 4, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // 16 -> 8 channels: bands of 4 grid rows (348 positions = 22 tiles), one M pair, waves = 8 position groups
+  return launch_up_q<UpQ<8, 16, 129, 174, 4, 2, 1, 8, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
