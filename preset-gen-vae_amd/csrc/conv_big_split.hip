@@ -61,6 +61,9 @@ __device__ __forceinline__ f32x4 six_products(const u32x4 (&a)[3], const u32x4 (
   return mfma_bf16_k32(a[0], b[0], c);
 }
 
+// the six terms in the order they are accumulated (smallest first): (plane of a, plane of b)
+__device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0}, kTermB[6] = {2, 0, 1, 1, 0, 0};
+
 // 16-byte global load through a buffer descriptor of the whole tensor: a quad at the ragged end of a row simply reads on
 // into the next row (masked where it is used), and one that crosses the end of the tensor reads zeros there (the range
 // check is per dword) - no divergent scalar-load branch, whose merge with the 16-byte path made the compiler wait for the
@@ -151,13 +154,12 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     blo[t] = (kq * CPS + (2 * ohl + kg * G::KHW) * 3 * WPD + 2 * ow + 2) * 4;
   }
   // ---- loader items: (channel pair, band row, quad of 4 columns)
-  int l_src[G::QB], l_dst[G::QB], l_cr[G::QB];
+  int l_src[G::QB], l_cr[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
     const int q = min(tid + 512 * i, G::ITEMS - 1);
     const int cp = q / (G::XR * G::QX), rem = q - cp * (G::XR * G::QX), r = rem / G::QX, qi = rem - r * G::QX;
     l_src[i] = (2 * cp) * (H * W) + 4 * qi;                       // + sample * CB * H * W + image row * W
-    l_dst[i] = (cp * CPS + r * 3 * WPD + 4 * qi + 4) * 4;         // plane 0, byte offset
     l_cr[i] = (cp << 8) | r | ((tid + 512 * i < G::ITEMS) ? 0x8000 : 0) | ((4 * qi + 4 > W) ? 0x4000 : 0);   // (0x4000: ragged row end)
   }
   // ---- move-out role: LPC lanes per channel
@@ -203,7 +205,9 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
-      const int c = 2 * ((l_cr[i] >> 8) & 63);
+      const int cp = (l_cr[i] >> 8) & 63, c = 2 * cp;
+      // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
+      const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
       const float mk = (rb_in >> i) & 1 ? 1.f : 0.f;
       const float s0 = aff[c] * mk, s1c = aff[c + 1] * mk, h0 = aff[CB + c] * mk, h1 = aff[CB + c + 1] * mk;
       if (l_cr[i] & 0x8000) {
@@ -216,9 +220,9 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
           pgv_split3_pair(y0, y1, a1, a2, a3);
           ph[e] = a1, pm[e] = a2, pl[e] = a3;
         }
-        *reinterpret_cast<u32x4*>(lds_x + l_dst[i]) = ph;
-        *reinterpret_cast<u32x4*>(lds_x + l_dst[i] + WPD * 4) = pm;
-        *reinterpret_cast<u32x4*>(lds_x + l_dst[i] + 2 * WPD * 4) = pl;
+        *reinterpret_cast<u32x4*>(lds_x + dst) = ph;
+        *reinterpret_cast<u32x4*>(lds_x + dst + WPD * 4) = pm;
+        *reinterpret_cast<u32x4*>(lds_x + dst + 2 * WPD * 4) = pl;
       }
     }
   };
@@ -270,26 +274,43 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // steps (kh, g, t) in order; the fragments of step i + PD are requested before the products of step i are issued
-      constexpr int NSTEP = G::KHW * NG * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
-      u32x4 bf[PD + 1][3];
-      auto frag = [&](int i, u32x4 (&f)[3]) {
-        const int t = i % TMAX, g = (i / TMAX) % NG, kh = i / (TMAX * NG);
+      // steps (kh, g, group of TP tiles) in order; the fragments of step i + PD are requested before the products of step i
+      // are issued.  A step multiplies MW x TP = 2 (M tile, pixel tile) pairs: two independent accumulation chains,
+      // interleaved term by term, with the LDS reads pinned in front of them (sched_group_barrier: left to itself the
+      // scheduler sinks the reads behind most of the previous step's instructions and the wave waits for LDS every step).
+      constexpr int TP = 2 / MW, TG = (TMAX + TP - 1) / TP;
+      constexpr int NSTEP = G::KHW * NG * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
+      static_assert(MW == 1 || MW == 2, "two chains per step");
+      u32x4 bf[PD + 1][TP][3];
+      auto frag = [&](int i, u32x4 (&f)[TP][3]) {
+        const int tg = i % TG, g = (i / TG) % NG, kh = i / (TG * NG);
         const int off = (g * 4 * CPS + kh * 3 * WPD) * 4;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
+        for (int q = 0; q < TP; ++q) {
+          const int t = min(tg * TP + q, TMAX - 1);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
+        }
       };
 #pragma unroll
       for (int i = 0; i < PD; ++i) frag(i, bf[i]);
 #pragma unroll
       for (int i = 0; i < NSTEP; ++i) {
-        const int t = i % TMAX, ks = i / TMAX;
+        const int tg = i % TG, ks = i / TG;
         if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
         // (no branch on `tile < NT` here: a wave with a tile short of TMAX multiplies a clamped copy that is never written -
         // with the wave-uniform branch in the unrolled loop the accumulators were copied from block to block, spilling)
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw) acc[mw][t] = six_products(af[mw][ks], bf[i % (PD + 1)], acc[mw][t]);
-        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the fragment loads of many steps: registers)
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
+            if (t < TMAX) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);   // the step's LDS reads ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);       // ... then its matrix instructions
+        __builtin_amdgcn_sched_barrier(0);
       }
       QSTAMP(j, 2);
       // (the saved activations of the fused epilogue are requested only now: their registers are not live across the matrix
@@ -630,25 +651,38 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int NSTEP = G::KW * TMAX, PD = G::PD < NSTEP ? G::PD : NSTEP;
-      u32x4 bf[PD + 1][3];
-      auto frag = [&](int i, u32x4 (&f)[3]) {
-        const int t = i % TMAX, g = kg * G::KW + i / TMAX;
-        const unsigned char* bp = lds_s + boff[t] + ((g ^ bsw[t]) * 16);
+      // (steps of two accumulation chains, reads pinned in front: see down_q_kernel)
+      constexpr int TP = 2 / MW, TG = (TMAX + TP - 1) / TP;
+      constexpr int NSTEP = G::KW * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
+      static_assert(MW == 1 || MW == 2, "two chains per step");
+      u32x4 bf[PD + 1][TP][3];
+      auto frag = [&](int i, u32x4 (&f)[TP][3]) {
+        const int tg = i % TG, g = kg * G::KW + i / TG;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
+        for (int q = 0; q < TP; ++q) {
+          const int t = min(tg * TP + q, TMAX - 1);
+          const unsigned char* bp = lds_s + boff[t] + ((g ^ bsw[t]) * 16);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
+        }
       };
 #pragma unroll
       for (int i = 0; i < PD; ++i) frag(i, bf[i]);
 #pragma unroll
       for (int i = 0; i < NSTEP; ++i) {
-        const int t = i % TMAX, ks = i / TMAX;
+        const int tg = i % TG, ks = i / TG;
         if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
-        // (no branch on `tile < NT` here: a wave with a tile short of TMAX multiplies a clamped copy that is never written -
-        // with the wave-uniform branch in the unrolled loop the accumulators were copied from block to block, spilling)
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw) acc[mw][t] = six_products(af[mw][ks], bf[i % (PD + 1)], acc[mw][t]);
-        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the fragment loads of many steps: registers)
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
+            if (t < TMAX) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       QSTAMP(j, 2);
       if (FUSE) fetch_a(j);   // (requested only now: see down_q_kernel)
@@ -798,12 +832,8 @@ int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const f
                           const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                           hipStream_t st, const pgv_bn_src* bn) {
   if (!d->w_shadow || !pgv_big_split_shape(d)) return 0;
-  if (d->Hb == 33)   // 64 -> 32 channels: bands of 4 grid rows (92 positions = 6 tiles), waves = the 8 M tiles (M pairs x K halves spilled)
-  {
-    // (the fused form on bands of 2 grid rows: with 4 its six saved-activation quads per lane spill)
-    if (fuse) return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 2, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-    return launch_up_q<UpQ<32, 64, 33, 45, 4, 1, 1, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  }
+  if (d->Hb == 33)   // 64 -> 32 channels: bands of 2 grid rows (46 positions = 3 tiles), waves = 4 M pairs x 2 K halves (bands of 4 spill)
+    return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 2, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65)   // 32 -> 16 channels: bands of 4 grid rows (176 positions = 11 tiles), waves = 2 M pairs x 4 position groups
     return launch_up_q<UpQ<16, 32, 65, 88, 4, 2, 1, 4, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   // 16 -> 8 channels: bands of 4 grid rows (348 positions = 22 tiles), one M pair, waves = 8 position groups
