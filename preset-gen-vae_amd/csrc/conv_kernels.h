@@ -152,6 +152,10 @@ int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const floa
 int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                           hipStream_t st, const pgv_bn_src* bn);
+// weight gradient of those layers (conv_wgrad_split.hip): per-workgroup partial gradients, same contract as the bf16 form
+int pgv_conv_wgrad_split_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                                 const float* small_in, const float* small_scale, const float* small_shift, float* partial,
+                                 int64_t partial_bytes, int* nparts, hipStream_t st);
 int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d);
 int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                              const float* small_in, const float* small_scale, const float* small_shift, float* gw,

@@ -1,0 +1,323 @@
+// Weight gradient of the LARGE-plane k4 s2 p2 layers with fp32 products as SIX bf16 matrix instructions
+// (PGV_COMPUTE_F32_SPLIT; model/layer.py:10-46 under train.py:246; conv_big_split.hip has the forward / input-gradient forms):
+//   gW[cs][cb][kh][kw] = sum_{b,oh,ow} S[b,cs,oh,ow] * X[b,cb,2oh-2+kh,2ow-2+kw]
+// Both operands are activations, so both are split into three exact bfloat16 planes on their way into LDS.  GEMM view (the
+// formulation of conv_wgrad_bf16.hip): M = cs, N = (cb, kh, kw), K = output pixels, eight consecutive pixels of a row per
+// lane and instruction.  The stride-2 column walk is contiguous in the EVEN / ODD column planes of X (Xp[j] = X[2j + p]):
+//   kw = 2 + p:  column 2 ow + p      -> sum_j S[j]     Xp[j]
+//   kw = p:      column 2 (ow-1) + p  -> sum_j S[j + 1] Xp[j]      (the A fragment one pixel on: a 16-byte read + the next
+//                                                                   dword, moved into place by four v_alignbit_b32 - a
+//                                                                   2-byte misaligned ds_read_b128 takes 64 LDS clocks)
+// so a column tile is (two big channels) x (4 kernel rows) x (2 parities) of ONE half h of the kernel columns, and a wave owns
+// column tiles of one half only (it needs one kind of A fragment).
+// Structure as in conv_big_split.hip: one 512-thread workgroup per CU, persistent over its units (sample, band of R output
+// rows); per unit a matrix phase (all waves multiply: MT x CTW tiles each, the K steps of a unit dealt over KWAYS waves)
+// and a vector phase (the next unit's two bands are split and committed), one barrier each; the band loads travel in
+// registers across the matrix phase.  The accumulators stay in registers over all units; at the end the K ways are added up
+// through LDS and the workgroup's partial gradient goes to the workspace (the reduce launch of conv_v2_wgrad.hip adds the
+// workgroups up, with the tap-sum / bias roles of the step).
+#include "conv_tile.h"
+#include "conv_deep_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const float* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4u buffer_load_x4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(f4u, v);
+}
+__device__ __forceinline__ void ws_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0}, kTermB[6] = {2, 0, 1, 1, 0, 0};   // (plane of a, plane of b), smallest first
+
+// strides in bf16 elements from scratch/wgrad_split_strides.py (conflict-free ds_read_b128 groups where the shape allows)
+template <int CB_, int CS_, int W_, int H_, int R_, int SCH_, int XCH_, int XPL_, int NQ_, int KWAYS_>
+struct WgQ {
+  static constexpr int CB = CB_, CS = CS_, W = W_, H = H_, R = R_, SCH = SCH_, XCH = XCH_, XPL = XPL_, NQ = NQ_, KWAYS = KWAYS_;
+  static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1, BANDS = (Hs + R - 1) / R, XR = 2 * R + 2;
+  static constexpr int GPR = (Ws + 7) / 8, XROW = GPR * 8, SROW = GPR * 8 + 8;   // 8-pixel groups per row; row strides (S: + 8 zeros)
+  static constexpr int NGRP = R * GPR, KS = (NGRP + 3) / 4, KSW = (KS + KWAYS - 1) / KWAYS;   // K steps of a unit / of a wave
+  static constexpr int MT = CS / 16, CTW = (CB / 2) / NQ;      // M tiles (all of them per wave); column tiles of a wave
+  static constexpr int S_PLANE = CS * SCH, X_PLANE = 2 * XPL;   // elements of one plane image
+  static constexpr int OX = (W + 7) / 8, X_ITEMS = CB * XR * OX, S_ITEMS = CS * R * GPR;
+  static constexpr int QX = (X_ITEMS + 511) / 512, QS = (S_ITEMS + 511) / 512;
+  static constexpr size_t IMG_BYTES = 3 * 2 * (size_t)(S_PLANE + X_PLANE);
+  static constexpr size_t LDS_BYTES = IMG_BYTES + sizeof(float) * 2 * (CB + CS);
+  static_assert(2 * NQ * KWAYS == 8 && (CB / 2) % NQ == 0 && CS % 16 == 0, "eight waves: kernel-column half x column groups x K ways");
+  static_assert(SCH >= R * SROW + 8 && XCH >= XR * XROW && XPL >= CB * XCH && SCH % 8 == 0 && XCH % 8 == 0 && XPL % 8 == 0, "plane strides");
+  static_assert(4 * OX <= XROW && LDS_BYTES <= 160 * 1024, "tile shapes / LDS budget");
+  static_assert(KWAYS == 1 || (size_t)(KWAYS - 1) * 2 * NQ * MT * CTW * 1024 <= IMG_BYTES, "K-way reduction fits the images");
+};
+
+template <class G, bool BIG_AFF, bool SMALL_AFF>
+__global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const float* __restrict__ big, const float* __restrict__ big_scale,
+                                                              const float* __restrict__ big_shift, const float* __restrict__ small_in,
+                                                              const float* __restrict__ small_scale,
+                                                              const float* __restrict__ small_shift, float* __restrict__ partial) {
+  constexpr int CB = G::CB, CS = G::CS, W = G::W, H = G::H, R = G::R, Ws = G::Ws, Hs = G::Hs, MT = G::MT, CTW = G::CTW;
+  constexpr int SCH = G::SCH, XCH = G::XCH, XPL = G::XPL, SROW = G::SROW, XROW = G::XROW, GPR = G::GPR, KSW = G::KSW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  u16* s_img = reinterpret_cast<u16*>(lds_raw);                     // [3][CS][SCH]
+  u16* x_img = s_img + 3 * G::S_PLANE;                              // [3][2 parities][XPL]
+  float* aff_b = reinterpret_cast<float*>(lds_raw + G::IMG_BYTES);   // [2][CB]
+  float* aff_s = aff_b + 2 * CB;                                    // [2][CS]
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave & 1, nq = (wave >> 1) % G::NQ, kw0 = (wave >> 1) / G::NQ;   // kernel-column half, column group, K way
+
+  for (int i = tid; i < (int)(G::IMG_BYTES / 16); i += 512) reinterpret_cast<u32x4*>(lds_raw)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < CB; i += 512) {
+    aff_b[i] = BIG_AFF ? big_scale[i] : 1.f;
+    aff_b[CB + i] = BIG_AFF ? big_shift[i] : 0.f;
+  }
+  for (int i = tid; i < CS; i += 512) {
+    aff_s[i] = SMALL_AFF ? small_scale[i] : 1.f;
+    aff_s[CS + i] = SMALL_AFF ? small_shift[i] : 0.f;
+  }
+  // ---- loader items.  X: (channel, band row, 8 columns) -> 4 even + 4 odd columns = 8 bytes per parity and plane;
+  // S: (channel, band row, 8 pixels) = 16 bytes per plane
+  int xl_src[G::QX], xl_cr[G::QX], sl_src[G::QS], sl_cr[G::QS];
+#pragma unroll
+  for (int i = 0; i < G::QX; ++i) {
+    const int q = min(tid + 512 * i, G::X_ITEMS - 1), c = q / (G::XR * G::OX), rem = q - c * (G::XR * G::OX), r = rem / G::OX, o = rem - r * G::OX;
+    xl_src[i] = c * (H * W) + 8 * o;                    // + sample * CB * H * W + image row * W
+    xl_cr[i] = (c << 16) | (r << 8) | o | ((tid + 512 * i < G::X_ITEMS) ? 0x8000 : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < G::QS; ++i) {
+    const int q = min(tid + 512 * i, G::S_ITEMS - 1), c = q / (R * GPR), rem = q - c * (R * GPR), r = rem / GPR, o = rem - r * GPR;
+    sl_src[i] = c * (Hs * Ws) + 8 * o;                  // + sample * CS * Hs * Ws + output row * Ws
+    sl_cr[i] = (c << 16) | (r << 8) | o | ((tid + 512 * i < G::S_ITEMS) ? 0x8000 : 0);
+  }
+  const int grid = (int)gridDim.x, u0 = pgv_xcd_block(), units = B * G::BANDS;
+  const int J = u0 < units ? (units - 1 - u0) / grid + 1 : 0;
+
+  f4u xb[G::QX][2], sb[G::QS][2];
+  unsigned x_in = 0, s_in = 0;   // bit i: the item's row lies inside the tensor
+  const __amdgpu_buffer_rsrc_t big_rs = tensor_rsrc(big, (int64_t)B * CB * (H * W) * 4);
+  const __amdgpu_buffer_rsrc_t small_rs = tensor_rsrc(small_in, (int64_t)B * CS * (Hs * Ws) * 4);
+  auto issue = [&](int j) {
+    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS;
+    const unsigned xs = (unsigned)b * (unsigned)(CB * H * W), ss = (unsigned)b * (unsigned)(CS * Hs * Ws);
+    x_in = s_in = 0;
+#pragma unroll
+    for (int i = 0; i < G::QX; ++i) {
+      const int ih = 2 * band * R - 2 + ((xl_cr[i] >> 8) & 63);
+      const bool in = (unsigned)ih < (unsigned)H;
+      x_in |= in ? (1u << i) : 0u;
+      const unsigned o = (xs + (unsigned)(xl_src[i] + (in ? ih : 0) * W)) * 4u;
+      xb[i][0] = buffer_load_x4(big_rs, o);        // (columns beyond the row: masked at the commit)
+      xb[i][1] = buffer_load_x4(big_rs, o + 16u);
+    }
+#pragma unroll
+    for (int i = 0; i < G::QS; ++i) {
+      const int oh = band * R + ((sl_cr[i] >> 8) & 63);
+      const bool in = oh < Hs;
+      s_in |= in ? (1u << i) : 0u;
+      const unsigned o = (ss + (unsigned)(sl_src[i] + (in ? oh : 0) * Ws)) * 4u;
+      sb[i][0] = buffer_load_x4(small_rs, o);
+      sb[i][1] = buffer_load_x4(small_rs, o + 16u);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::QX; ++i) {
+      const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
+      const float mk = (x_in >> i) & 1 ? 1.f : 0.f, sc = aff_b[c] * mk, sh = aff_b[CB + c] * mk;
+      if (xl_cr[i] & 0x8000) {
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = e < 4 ? xb[i][0][e] : xb[i][1][e - 4];
+          y[e] = 8 * o + e < W ? fmaf(v, sc, sh) : 0.f;   // (columns beyond the row stay zero under an affine too)
+        }
+        unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k]);       // even columns 8o + 4k, + 2
+          pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k]);   // odd columns
+        }
+        u16* dst = x_img + c * XCH + r * XROW + 4 * o;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dst) = u32x2{e1[0], e1[1]};
+        *reinterpret_cast<u32x2*>(dst + XPL) = u32x2{o1[0], o1[1]};
+        *reinterpret_cast<u32x2*>(dst + G::X_PLANE) = u32x2{e2[0], e2[1]};
+        *reinterpret_cast<u32x2*>(dst + G::X_PLANE + XPL) = u32x2{o2[0], o2[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE) = u32x2{e3[0], e3[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::QS; ++i) {
+      const int c = sl_cr[i] >> 16, r = (sl_cr[i] >> 8) & 63, o = sl_cr[i] & 255;
+      const float mk = (s_in >> i) & 1 ? 1.f : 0.f, sc = aff_s[c] * mk, sh = aff_s[CS + c] * mk;
+      if (sl_cr[i] & 0x8000) {
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
+          const float y0 = 8 * o + 2 * k < Ws ? fmaf(v0, sc, sh) : 0.f, y1 = 8 * o + 2 * k + 1 < Ws ? fmaf(v1, sc, sh) : 0.f;
+          unsigned a1, a2, a3;
+          pgv_split3_pair(y0, y1, a1, a2, a3);
+          p1[k] = a1, p2[k] = a2, p3[k] = a3;
+        }
+        u16* dst = s_img + c * SCH + r * SROW + 8 * o;
+        *reinterpret_cast<u32x4*>(dst) = p1;
+        *reinterpret_cast<u32x4*>(dst + G::S_PLANE) = p2;
+        *reinterpret_cast<u32x4*>(dst + 2 * G::S_PLANE) = p3;
+      }
+    }
+  };
+
+  // ---- fragment bases (elements) of this wave's K steps: lane group kq of step ks holds pixel group gi = 4 ks + kq
+  int offA[KSW], offB[KSW];
+#pragma unroll
+  for (int k = 0; k < KSW; ++k) {
+    const int ks = kw0 + G::KWAYS * k, gi = min(4 * ks + kq, G::NGRP - 1), row = gi / GPR, g8 = gi - row * GPR;
+    // (a lane group beyond the unit's last pixel group repeats the last group of the LAST row with an A offset into the
+    // zero padding behind it: its products vanish)
+    const bool pad = 4 * ks + kq >= G::NGRP;
+    offA[k] = n * SCH + row * SROW + (pad ? GPR * 8 : g8 * 8);
+    offB[k] = (n & 1) * XPL + (2 * nq * CTW + (n >> 3)) * XCH + (2 * row + ((n >> 1) & 3)) * XROW + g8 * 8;
+  }
+  f32x4 acc[MT][CTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (J > 0) issue(0);
+  __syncthreads();
+  if (J > 0) commit();
+  __syncthreads();
+
+#pragma unroll 1
+  for (int j = 0; j < J; ++j) {
+    if (j + 1 < J) issue(j + 1);
+    // ================= matrix phase =================
+#pragma unroll
+    for (int k = 0; k < KSW; ++k) {
+      {   // (a K way with a step less multiplies the zero padding: no wave-uniform branch around the accumulators)
+        u32x4 a[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u16* ap = s_img + p * G::S_PLANE + offA[k] + m * 16 * SCH;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(ap);
+            if (h) {   // kernel columns 2, 3: S itself
+              a[m][p] = w;
+            } else {   // kernel columns 0, 1: S one pixel on
+              const unsigned w4 = *reinterpret_cast<const unsigned*>(ap + 8);
+              a[m][p] = u32x4{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                              __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
+            }
+          }
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) {
+          u32x4 bfr[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(x_img + p * G::X_PLANE + offB[k] + 2 * t * XCH);
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16_k32(a[m][kTermA[term]], bfr[kTermB[term]], acc[m][t]);
+        }
+      }
+    }
+    ws_sync();
+    // ================= vector phase ================= (all loads of the matrix phase consumed for the compiler's counter model)
+#pragma unroll
+    for (int i = 0; i < G::QX; ++i) asm volatile("" ::"v"(xb[i][0]), "v"(xb[i][1]));
+#pragma unroll
+    for (int i = 0; i < G::QS; ++i) asm volatile("" ::"v"(sb[i][0]), "v"(sb[i][1]));
+    if (j + 1 < J) commit();
+    ws_sync();
+  }
+
+  // ---- the K ways of a tile are added up through LDS (the images are dead), then this workgroup's partial gradient, layout
+  // of gw: D row (lane >> 4) * 4 + reg = cs within the M tile, column n = (channel of the pair, kernel row, parity)
+  if (G::KWAYS > 1) {
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw);
+    const int slot0 = ((h * G::NQ + nq) * MT * CTW) * 64 + lane;
+    if (kw0 > 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) red[(size_t)(kw0 - 1) * (2 * G::NQ * MT * CTW * 64) + slot0 + (m * CTW + t) * 64] = acc[m][t];
+    }
+    ws_sync();
+    if (kw0 == 0) {
+#pragma unroll
+      for (int kx = 1; kx < G::KWAYS; ++kx)   // (fixed order)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < CTW; ++t) acc[m][t] += red[(size_t)(kx - 1) * (2 * G::NQ * MT * CTW * 64) + slot0 + (m * CTW + t) * 64];
+    }
+  }
+  if (kw0 == 0) {
+    float* pw = partial + (size_t)blockIdx.x * ((size_t)CS * CB * 16);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < CTW; ++t) {
+        const int cb = 2 * (nq * CTW + t) + (n >> 3), kh = (n >> 1) & 3, kw = 2 * h + (n & 1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cs = m * 16 + kq * 4 + reg;
+          pw[(cs * CB + cb) * 16 + kh * 4 + kw] = acc[m][t][reg];
+        }
+      }
+  }
+}
+
+template <class G>
+int launch_wgq(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift, const float* small_in,
+               const float* small_scale, const float* small_shift, float* partial, int64_t partial_bytes, int* nparts,
+               hipStream_t st) {
+  if (d->Cb != G::CB || d->Cs != G::CS || d->B <= 0) return 0;
+  if (big_scale && small_scale) return 0;   // not a case of the train step
+  if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || (int64_t)d->B * d->Cs * G::Hs * G::Ws * 4 >= (int64_t)1 << 31) return 0;
+  const int units = d->B * G::BANDS, grid = min(units, 256);
+  if ((int64_t)grid * G::CS * G::CB * 16 * (int64_t)sizeof(float) > partial_bytes) return 0;
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
+  kern_t kern = big_scale ? (kern_t)conv_wgrad_split_kernel<G, true, false>
+                          : (small_scale ? (kern_t)conv_wgrad_split_kernel<G, false, true>
+                                         : (kern_t)conv_wgrad_split_kernel<G, false, false>);
+  static const void* raised[3];
+  const int slot = big_scale ? 0 : (small_scale ? 1 : 2);
+  if (raised[slot] != (const void*)kern) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+      pgv_set_error("conv_wgrad_split: cannot raise the dynamic LDS limit");
+      return PGV_E_LAUNCH;
+    }
+    raised[slot] = (const void*)kern;
+  }
+  *nparts = grid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, d->B, big, big_scale, big_shift, small_in, small_scale, small_shift,
+                     partial);
+  PGV_CHECK_LAUNCH("conv_wgrad_split");
+  return 1;
+}
+
+}  // namespace
+
+// 1 = launched (*nparts partial gradients in ``partial``, one per workgroup, layout of gw), 0 = shape / mode not covered
+int pgv_conv_wgrad_split_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
+                                 const float* small_in, const float* small_scale, const float* small_shift, float* partial,
+                                 int64_t partial_bytes, int* nparts, hipStream_t st) {
+  if (!pgv_big_split_shape(d) || !partial) return 0;
+  if (d->Hb == 129)
+    return launch_wgq<WgQ<8, 16, 174, 129, 4, 400, 896, 7232, 1, 4>>(d, big, big_scale, big_shift, small_in, small_scale, small_shift,
+                                                                     partial, partial_bytes, nparts, st);
+  if (d->Hb == 65)
+    return launch_wgq<WgQ<16, 32, 88, 65, 4, 240, 512, 8256, 2, 2>>(d, big, big_scale, big_shift, small_in, small_scale, small_shift,
+                                                                    partial, partial_bytes, nparts, st);
+  return launch_wgq<WgQ<32, 64, 45, 33, 4, 144, 256, 8256, 4, 1>>(d, big, big_scale, big_shift, small_in, small_scale, small_shift,
+                                                                  partial, partial_bytes, nparts, st);
+}

@@ -67,3 +67,23 @@ for Cb, Cs, Hb, Wb in ((8, 16, 129, 174), (16, 32, 65, 88), (32, 64, 33, 45)):
         print(f'{Hb}x{Wb} {Cb}<->{Cs} {mode:7s}: down fwd {t_df:6.1f} fused+cls {t_db:6.1f} | up fwd {t_uf:6.1f} fused {t_ub:6.1f} us'
               f' | rel L2 vs float64 down {ed:.2e} up {eu:.2e}', flush=True)
     ops.set_fp32_products('native')
+
+# ---- weight gradients
+for Cb, Cs, Hb, Wb in ((8, 16, 129, 174), (16, 32, 65, 88), (32, 64, 33, 45)):
+    g = ops.ConvGeom(Cb, Cs, 4, 2, 2, Hb, Wb)
+    torch.manual_seed(1)
+    big = torch.randn(B, Cb, Hb, Wb, device='cuda')
+    small = torch.randn(B, Cs, g.Hs, g.Ws, device='cuda')
+    bsc, bsh = torch.rand(Cb, device='cuda') + 0.5, torch.randn(Cb, device='cuda') * 0.1
+    nb = 4
+    wv = torch.zeros(Cs, Cb, 4, 4, dtype=torch.float64, device='cuda', requires_grad=True)
+    F.conv2d(big[:nb].double(), wv, None, stride=2, padding=2).backward(small[:nb].double())
+    for mode in ('native', 'bf16x6'):
+        ops.set_fp32_products(mode)
+        gw = torch.empty(Cs, Cb, 4, 4, device='cuda')
+        ops.conv_wgrad(g, big[:nb].contiguous(), small[:nb].contiguous(), gw)
+        err = ((gw.double() - wv.grad).norm() / wv.grad.norm()).item()
+        gwf = torch.zeros(Cs, Cb, 4, 4, device='cuda')
+        t = timeit(lambda: ops.conv_wgrad(g, big, small, gwf, big_scale=bsc, big_shift=bsh))
+        print(f'{Hb}x{Wb} {Cb}<->{Cs} {mode:7s}: weight gradient (+ reduce launch) {t:6.1f} us | rel L2 vs float64 {err:.2e}', flush=True)
+    ops.set_fp32_products('native')

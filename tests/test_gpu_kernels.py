@@ -622,6 +622,35 @@ def test_big_plane_kernels_fp32_products_as_six_bf16_instructions(ops, case):
             assert rel_l2(out, refb) < 2e-6
             l1 = refb.abs().sum(dim=(0, 2, 3))
             assert ((gbc.view(C8, Cb).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
+
+        # ---- weight gradient (conv_wgrad_split.hip: both operands split in the loader), lazy normalisation on either side
+        # seeded normal operands here (activations with a mean, zero-mean output gradient): the sinusoid vectors above
+        # cancel to ~1e-5 of the sum of magnitudes over a plane, which measures summation order (5e-6 .. 3e-5 for both
+        # forms), not the products
+        gen = torch.Generator().manual_seed(B)
+        big = (torch.randn(big.shape, generator=gen) + 0.5).to(big.dtype)
+        small = torch.randn(small.shape, generator=gen).to(small.dtype)
+        big_n = _affine_fma(big, sc_b, sh_b).double()
+        for kw_n, bigd, smalld in (({'big_scale': dev(sc_b), 'big_shift': dev(sh_b)}, big_n, small.double()),
+                                   ({'small_scale': dev(sc_s), 'small_shift': dev(sh_s)}, big.double(),
+                                    _affine_fma(small, sc_s, sh_s).double()),
+                                   ({}, big.double(), small.double())):
+            wv = w.double().clone().requires_grad_(True)
+            F.conv2d(bigd, wv, None, stride=s, padding=p).backward(smalld)
+            gw = torch.empty((Cs, Cb, k, k), device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gw, **kw_n)
+            gw2 = torch.full((Cs, Cb, k, k), 7.0, device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gw2, **kw_n)
+            assert torch.equal(gw, gw2)
+            ops.set_fp32_products('native')
+            gwn = torch.empty((Cs, Cb, k, k), device='cuda')
+            ops.conv_wgrad(geom, dev(big), dev(small), gwn, **kw_n)
+            ops.set_fp32_products('bf16x6')
+            e_split, e_native = rel_l2(gw, wv.grad), rel_l2(gwn, wv.grad)
+            assert e_split < 1e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        acc = torch.zeros((Cs, Cb, k, k), device='cuda')
+        ops.conv_wgrad(geom, dev(big), dev(small), acc, prezeroed=True)
+        assert rel_l2(acc, gw) < 1e-6
     finally:
         ops.set_fp32_products('native')
 
