@@ -44,9 +44,11 @@ def parse():
     ap.add_argument("--input", default="spectrograms", choices=["spectrograms", "audio"],
                     help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
                          "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
-    ap.add_argument("--fp32-products", default="native", choices=["native", "bf16x6"],
-                    help="fp32 mode only, opt-in: layers with a split-product kernel evaluate every fp32 product as six "
-                         "bf16 matrix instructions on exact three-way operand splits (DESIGN.md 3.11); default native")
+    ap.add_argument("--fp32-products", default="bf16x6", choices=["native", "bf16x6"],
+                    help="fp32 mode only: bf16x6 (default) = layers with a split-product kernel evaluate every fp32 "
+                         "product as six bf16 matrix instructions on exact three-way operand splits, fp32 accumulation "
+                         "(DESIGN.md 2.3; the strict fp32 parity tests run in this mode too); native = the fp32 matrix "
+                         "instruction everywhere (reported under 'extra')")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--dist-mode", default="bucket-graphs", choices=["bucket-graphs", "eager", "two-graph"],
                     help="N > 1 launch mode: bucket-graphs = the captured step cut at the gradient-bucket boundaries "
@@ -419,16 +421,25 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     """Time every kind of launch of the step standalone at the bench shapes and report the one FURTHEST BELOW ITS OWN
     ROOFLINE among the launches that take at least 2 % of the step (the kernel to fix next); the table of all launches
     goes to gpurun_out/bench_kernel_table.json."""
+    from preset_gen_vae_amd import ops
     rows = []
+    # six-instruction products: a conv launch of a layer with more than one input channel issues 6 bf16 instructions per
+    # fp32 product, so ITS matrix roofline is the dense bf16 peak / 6 (417 TFLOP/s of fp32 products) - not the fp32
+    # instruction's peak, which those kernels do not use
+    split_layers = set()
+    if ops.compute_dtype() == 'fp32' and ops.fp32_products() != 'native':
+        split_layers = {name for name, (Cb, Cs, k, s, p, Hb, Wb), _, _ in layer_ops(ae) if Cb > 1}
     for label, fn, bytes_, flops in launch_table(ae, B, device, frontend):
         # median of three 5-launch averages: one disturbed replay (another tenant of the box, a clock ramp) would otherwise
         # push a launch over the 2 % line AND to the bottom of the fractions at once (seen: conv_wgrad[dec8] 0.43 -> 0.25)
         ms = sorted(time_kernel(fn, iters=5) for _ in range(3))[1]
-        t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (matrix_peak * 1e12)
+        lname = label[label.index('[') + 1:label.index(']')] if '[' in label else ''
+        row_peak = BF16_MATRIX_PEAK_TFLOPS / 6.0 if (label.startswith('conv_') and lname in split_layers) else matrix_peak
+        t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (row_peak * 1e12)
         bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
         frac = max(t_hbm, t_mfma) * 1e3 / ms if ms > 0 else 0.0
         rows.append({'launch': label, 'ms': ms, 'flops': flops, 'bytes': bytes_, 'bound': bound, 'frac': frac,
-                     'share_of_step': ms / step_ms})
+                     'share_of_step': ms / step_ms, 'matrix_peak': row_peak})
     # (launch-latency-sized helpers with no algorithmic bytes / flops of their own have no roofline to stand against)
     priced = [r for r in rows if r['bytes'] > 0 or r['flops'] > 0]
     cands = [r for r in priced if r['share_of_step'] >= 0.02] or priced
@@ -436,12 +447,12 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     if worst['bound'] == 'hbm':
         achieved, peak, unit = worst['bytes'] / (worst['ms'] * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
     else:
-        achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, matrix_peak, 'TFLOP/s'
+        achieved, peak, unit = worst['flops'] / (worst['ms'] * 1e-3) / 1e12, round(worst['matrix_peak'], 1), 'TFLOP/s'
     # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel generation and THIS configuration at batch
     # 256 (the same labels on another model / operand mode are other kernels or other fusions)
     traffic = None
     try:
-        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r4_traffic.json')) as f:
+        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r5_traffic.json')) as f:
             entry = json.load(f).get(worst['launch'])
         if entry and B == 256 and traffic_ok:
             traffic = entry['hbm_bytes_per_launch']
@@ -450,10 +461,14 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     conv = [r for r in rows if r['launch'].startswith('conv_')]
     mp = measured_peaks(device)
     mpeak = mp['hbm_read_GBs'] if worst['bound'] == 'hbm' else \
-        (mp['mfma_bf16_TFLOPs'] if matrix_peak == BF16_MATRIX_PEAK_TFLOPS else mp['mfma_f32_TFLOPs'])
+        (mp['mfma_bf16_TFLOPs'] / 6.0 if worst['matrix_peak'] != matrix_peak else
+         (mp['mfma_bf16_TFLOPs'] if matrix_peak == BF16_MATRIX_PEAK_TFLOPS else mp['mfma_f32_TFLOPs']))
     # the same sum of per-launch rooflines, priced against what this box sustains instead of the data-sheet figures
     mpf = mp['mfma_bf16_TFLOPs'] if matrix_peak == BF16_MATRIX_PEAK_TFLOPS else mp['mfma_f32_TFLOPs']
-    conv_meas = sum(max(r['bytes'] / (mp['hbm_read_GBs'] * 1e9), r['flops'] / (mpf * 1e12)) for r in conv) * 1e3
+
+    def row_mpf(r):   # (a six-instruction launch: the measured bf16 rate / 6)
+        return mp['mfma_bf16_TFLOPs'] / 6.0 if r['matrix_peak'] not in (matrix_peak,) else mpf
+    conv_meas = sum(max(r['bytes'] / (mp['hbm_read_GBs'] * 1e9), r['flops'] / (row_mpf(r) * 1e12)) for r in conv) * 1e3
     roof = {'bound': worst['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
             'frac': round(achieved / peak, 5), 'measured_peak': mpeak, 'frac_of_measured_peak': round(achieved / mpeak, 5),
             'measured_peaks': mp, 'conv_launches_sum_measured_roofline_ms': round(conv_meas, 4),
@@ -654,8 +669,12 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         h2d = h2d_inclusive(step, x)
     if rank == 0 and with_roofline:
         # the PMC passes exist for three configurations (profiles/README.md); other configurations report traffic null
-        tfile = {('speccnn4l1_bn', 'fp32', 64): 'r4_traffic.json', ('speccnn8l1_bn', 'fp32', 64): 'r4_traffic_8l.json',
-                 ('speccnn8l1_bn', 'bf16', 512): 'r4_traffic_8l_bf16.json'}.get((args.arch, args.dtype, args.dim_z))
+        prod = ops.fp32_products() if args.dtype == 'fp32' else 'native'
+        tfile = {('speccnn4l1_bn', 'fp32', 64, 'bf16x6'): 'r5_traffic.json',
+                 ('speccnn8l1_bn', 'fp32', 64, 'bf16x6'): 'r5_traffic_8l.json',
+                 ('speccnn4l1_bn', 'fp32', 64, 'native'): 'r5_traffic_native.json',
+                 ('speccnn8l1_bn', 'fp32', 64, 'native'): 'r5_traffic_8l_native.json',
+                 ('speccnn8l1_bn', 'bf16', 512, 'native'): 'r5_traffic_8l_bf16.json'}.get((args.arch, args.dtype, args.dim_z, prod))
         roof, table = measure_roofline(ae, args.batch, device, ms, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
                                        else F32_MATRIX_PEAK_TFLOPS, frontend=frontend,
                                        traffic_file=os.path.join(ROOT, 'profiles', tfile) if tfile else None,
@@ -681,10 +700,13 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                               if args.input == "audio" else ""),
                "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": launch,
                "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
-        if ops.fp32_products() != 'native':
-            cfg["fp32_products"] = ("bf16x6 on the deep k4 layers (17x23 / 9x12 / 5x7: forward, input and weight gradients), the "
-                                    "1x1 layers (forward, input gradient) and the 65x88 transposed convolution: six bf16 matrix "
-                                    "instructions per fp32 product on exact three-way operand splits, fp32 accumulation; opt-in")
+        if args.dtype == 'fp32':
+            cfg["fp32_products"] = (
+                "bf16x6: the k4 s2 layers from 129x174 down to 5x7 (forward, fused input gradient, weight gradient) and the "
+                "1x1 layers (forward, input gradient) evaluate every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact "
+                "three-way operand splits with fp32 accumulation (error against float64 <= the native instruction's: "
+                "tests/test_gpu_kernels.py); the 1-channel 5x5 end layers and the fc GEMMs use the native fp32 instruction"
+                if ops.fp32_products() != 'native' else "native: v_mfma_f32_16x16x4_f32 / fp32 FMA everywhere")
         if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
@@ -712,10 +734,11 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
 
 # the other BASELINE.json configurations measured inside the same invocation (N = 1): fewer steps, live roofline each
 EXTRA_CONFIGS = [
+    ("configs[1] with the native fp32 matrix instruction everywhere (ops.set_fp32_products('native'))",
+     dict(fp32_products='native')),
     ("configs[1] on the reference-exact 8-layer stack", dict(arch='speccnn8l1_bn')),
-    ("configs[1] on the 8-layer stack, fp32 products of the deep and 1x1 layers as six bf16 instructions (opt-in "
-     "ops.set_fp32_products('bf16x6') / PGV_COMPUTE_F32_SPLIT: exact three-way operand splits, fp32 accumulation; same "
-     "parity tests and tolerances as the native fp32 kernels)", dict(arch='speccnn8l1_bn', fp32_products='bf16x6')),
+    ("configs[1] on the 8-layer stack with the native fp32 matrix instruction everywhere",
+     dict(arch='speccnn8l1_bn', fp32_products='native')),
     ("configs[2]: 8-layer z=512 bf16", dict(arch='speccnn8l1_bn', dim_z=512, dtype='bf16')),
     ("configs[4]: raw-audio minibatch, fused STFT->mel front-end", dict(input='audio')),
 ]

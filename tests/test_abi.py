@@ -78,16 +78,15 @@ def test_weight_shadow_sizes_and_descriptor_layout_do_not_need_a_gpu():
     for case in [(1, 8, 5, 2, 2, 257, 347), (64, 128, 4, 2, 2, 19, 23), (3, 5, 4, 2, 2, 10, 13), (8, 16, 4, 2, 2, 128, 174)]:
         assert nbytes(*case) == 0
     # PGV_COMPUTE_F32_SPLIT (fp32 products as six bf16 instructions): three bf16 planes per direction, 12 bytes per weight, for
-    # the deep k4 layers and the 1x1 layers; 6 bytes per weight (transposed direction only) for the 65x88 layer; ignored
-    # together with PGV_COMPUTE_BF16
+    # every k4 s2 layer of the stacks from 129x174 down to 5x7 and the 1x1 layers; ignored together with PGV_COMPUTE_BF16
     SPLIT = 8
     for Cb, Cs, k, s, p, Hb, Wb in [(64, 128, 4, 2, 2, 17, 23), (128, 256, 4, 2, 2, 9, 12), (256, 512, 4, 2, 2, 5, 7),
-                                    (512, 2048, 1, 1, 0, 3, 4)]:
+                                    (512, 2048, 1, 1, 0, 3, 4), (32, 64, 4, 2, 2, 33, 45), (16, 32, 4, 2, 2, 65, 88),
+                                    (8, 16, 4, 2, 2, 129, 174)]:
         assert nbytes(Cb, Cs, k, s, p, Hb, Wb, flags=SPLIT) == 12 * Cb * Cs * k * k
         assert nbytes(Cb, Cs, k, s, p, Hb, Wb, flags=SPLIT | BF16) == 4 * Cb * Cs * k * k
         assert nbytes(Cb, Cs, k, s, p, Hb, Wb, flags=0) == 0
-    assert nbytes(16, 32, 4, 2, 2, 65, 88, flags=SPLIT) == 6 * 16 * 32 * 16
-    assert nbytes(32, 64, 4, 2, 2, 33, 45, flags=SPLIT) == 0
+    assert nbytes(1, 8, 5, 2, 2, 257, 347, flags=SPLIT) == 0 and nbytes(16, 32, 4, 2, 2, 66, 88, flags=SPLIT) == 0
     # writing a shadow for a layer that has none is an argument error, reported before any launch
     d = _lib.ConvDesc(1, 1, 257, 347, 8, 129, 174, 5, 5, 2, 2, BF16, None)
     assert lib.pgv_conv_weight_shadow(ctypes.byref(d), 16, 16, None) == -1

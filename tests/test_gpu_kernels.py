@@ -54,6 +54,20 @@ def _conv_inputs(case):
     return big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws
 
 
+def _conv_inputs_normal(case):
+    """Seeded normal operands (activations with a mean, zero-mean output gradient, He-scaled weights) for the tests that
+    compare the ERROR of two kernel families against float64: the sinusoid vectors of _conv_inputs cancel to ~1e-5 of the sum
+    of magnitudes over a plane, so an error measured on them (5e-6 .. 3e-5 for a weight gradient, either family) is the
+    summation order of the partial sums, not the accuracy of the products."""
+    Cb, Cs, k, s, p, Hb, Wb, B = case
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    gen = torch.Generator().manual_seed(1000 * Cb + B)
+    big = (torch.randn(big.shape, generator=gen) + 0.5).to(big.dtype)
+    small = torch.randn(small.shape, generator=gen).to(small.dtype)
+    w = (torch.randn(w.shape, generator=gen) * (1.0 / np.sqrt(Cb * k * k / (s * s)))).to(w.dtype)
+    return big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws
+
+
 def _affine(t, sc, sh):
     return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
 
@@ -396,7 +410,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
     fp32 kernels are, several sample groups with a partial last one, bit-for-bit deterministic.  Forward form (lazy
     normalisation, bias, activation, BatchNorm statistics) and the input-gradient form (plain product)."""
     Cb, Cs, k, s, p, Hb, Wb, B = case
-    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs_normal(case)
     geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
     big_n = _affine_fma(big, sc_b, sh_b).double()
     ref = F.leaky_relu(F.conv2d(big_n, w.double(), bias_s.double(), stride=s, padding=p), 0.1)
@@ -419,7 +433,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
                             in_shift=dev(sh_b), stats=stats, w_shadow=sh)
         e_split, e_native = rel_l2(got, ref), rel_l2(native, ref)
-        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         assert rel_l2(stats, torch.cat([ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))])) < 2e-5
         again = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
                               in_shift=dev(sh_b), w_shadow=sh)
@@ -427,7 +441,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
         refp = F.conv2d(big.double(), w.double(), None, stride=s, padding=p)     # (structured inputs: the sums cancel)
         e_split, e_native = rel_l2(got, refp), rel_l2(native_plain, refp)
-        assert e_split < 1e-5 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 1e-5 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         C8 = ops.CLS_COPIES
         stc = torch.zeros(C8 * 2 * Cs, device='cuda', dtype=torch.float64)
         got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, stats=stc, prezeroed=True,
@@ -445,7 +459,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                           in_shift=dev(sh_s), stats=stats, w_shadow=sh)
         e_split, e_native = rel_l2(got, refu), rel_l2(native_up, refu)
-        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
         again = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                             in_shift=dev(sh_s), w_shadow=sh)
@@ -453,7 +467,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
         refp = F.conv_transpose2d(small.double(), w.double(), None, stride=s, padding=p, output_padding=(oph, opw))
         e_split, e_native = rel_l2(got, refp), rel_l2(native_up_plain, refp)
-        assert e_split < 1e-5 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 1e-5 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         # weight gradient (Wgrad8 with three plane images of both operands), lazy normalisation on either side
         for kw_n, bigd, smalld in (({'big_scale': dev(sc_b), 'big_shift': dev(sh_b)}, big_n, small.double()),
                                    ({'small_scale': dev(sc_s), 'small_shift': dev(sh_s)}, big.double(),
@@ -470,7 +484,7 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
             ops.conv_wgrad(geom, dev(big), dev(small), gwn, **kw_n)
             ops.set_fp32_products('bf16x6')
             e_split, e_native = rel_l2(gw, wv.grad), rel_l2(gwn, wv.grad)
-            assert e_split < 5e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+            assert e_split < 5e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         acc = torch.zeros((Cs, Cb, k, k), device='cuda')
         ops.conv_wgrad(geom, dev(big), dev(small), acc, prezeroed=True, small_scale=dev(sc_s), small_shift=dev(sh_s))
         assert rel_l2(acc, gw) < 1e-6
@@ -502,7 +516,7 @@ def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_b),
                             in_shift=dev(sh_b), stats=stats, w_shadow=sh)
         e_split, e_native = rel_l2(got, refd), rel_l2(nat_d, refd)
-        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         assert rel_l2(stats, torch.cat([refd.sum(dim=(0, 2, 3)), (refd * refd).sum(dim=(0, 2, 3))])) < 2e-5
         assert torch.equal(got, ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1,
                                               in_scale=dev(sc_b), in_shift=dev(sh_b), w_shadow=sh))
@@ -510,7 +524,7 @@ def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
         got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_LEAKY_RELU, 0.1, in_scale=dev(sc_s),
                           in_shift=dev(sh_s), stats=stats, w_shadow=sh)
         e_split, e_native = rel_l2(got, refu), rel_l2(nat_u, refu)
-        assert e_split < 2e-6 and e_split < 2 * e_native + 1e-7, (e_split, e_native)
+        assert e_split < 2e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
         assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
         got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
         assert rel_l2(got, F.conv_transpose2d(small.double(), w.double(), None)) < 1e-5
@@ -530,7 +544,7 @@ def test_big_plane_kernels_fp32_products_as_six_bf16_instructions(ops, case):
     several units per workgroup; bit-for-bit repeatable.  Forward form (lazy normalisation, bias, activation, BatchNorm
     statistics, statistics copies) and the fused input-gradient form (pgv_bwd_fuse: bias-gradient copies, class sums)."""
     Cb, Cs, k, s, p, Hb, Wb, B = case
-    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
+    big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs_normal(case)
     geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
     assert ops.conv_weight_shadow(geom, dev(w)) is None          # native fp32 products: no shadow
     oph, opw = Hb - ((Hs - 1) * s - 2 * p + k), Wb - ((Ws - 1) * s - 2 * p + k)
@@ -624,12 +638,6 @@ def test_big_plane_kernels_fp32_products_as_six_bf16_instructions(ops, case):
             assert ((gbc.view(C8, Cb).double().sum(0) - refb.sum(dim=(0, 2, 3))).abs() <= 2e-6 * l1 + 1e-12).all()
 
         # ---- weight gradient (conv_wgrad_split.hip: both operands split in the loader), lazy normalisation on either side
-        # seeded normal operands here (activations with a mean, zero-mean output gradient): the sinusoid vectors above
-        # cancel to ~1e-5 of the sum of magnitudes over a plane, which measures summation order (5e-6 .. 3e-5 for both
-        # forms), not the products
-        gen = torch.Generator().manual_seed(B)
-        big = (torch.randn(big.shape, generator=gen) + 0.5).to(big.dtype)
-        small = torch.randn(small.shape, generator=gen).to(small.dtype)
         big_n = _affine_fma(big, sc_b, sh_b).double()
         for kw_n, bigd, smalld in (({'big_scale': dev(sc_b), 'big_shift': dev(sh_b)}, big_n, small.double()),
                                    ({'small_scale': dev(sc_s), 'small_shift': dev(sh_s)}, big.double(),
