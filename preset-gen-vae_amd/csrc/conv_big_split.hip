@@ -184,46 +184,53 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   const int grid = (int)gridDim.x, u0 = pgv_xcd_block(), units = B * G::BANDS;
   const int J = u0 < units ? (units - 1 - u0) / grid + 1 : 0;   // this workgroup's units u0, u0 + grid, ...
 
+  // The band loads are software-pipelined ITEM BY ITEM through the vector phase: an item of unit j + 1 is converted and
+  // committed, and its registers are re-issued at once for the same item of unit j + 2, so loads are in flight through the
+  // rest of the vector phase and the whole next matrix phase.  (Issued in one burst at the start of the matrix phase, a
+  // unit's 56 - 78 KB were still arriving when the vector phase wanted them: a CU's fair share of HBM moves them in ~6 k
+  // clocks, a matrix phase lasts 3 - 4 k.)  A load for a unit beyond the workgroup's last gets an offset outside the buffer:
+  // it returns zeros without traffic, and no load sits under a branch the compiler's counter model would have to merge.
   f4u rb[G::QB][2];
-  unsigned rb_in = 0;   // bit i: item i's row lies inside the image
   const __amdgpu_buffer_rsrc_t big_rs = tensor_rsrc(big, (int64_t)B * CB * (H * W) * 4);
-  auto issue = [&](int j) {
-    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, ih0 = 2 * band * R - 2;
-    const unsigned sample = (unsigned)b * (unsigned)(CB * H * W);
-    rb_in = 0;
+  struct UnitPos { unsigned sample, kill; int ih0; };
+  auto unit_pos = [&](int j) {
+    const int u = min(u0 + j * grid, units - 1), b = u / G::BANDS, band = u - b * G::BANDS;
+    return UnitPos{(unsigned)b * (unsigned)(CB * H * W), j < J ? 0u : 0x80000000u, 2 * band * R - 2};
+  };
+  auto issue_item = [&](int i, const UnitPos& up) {
+    const int ih = up.ih0 + (l_cr[i] & 255);
+    const unsigned o = (up.sample + (unsigned)(l_src[i] + ((unsigned)ih < (unsigned)H ? ih : 0) * W)) * 4u;
+    // (a quad at the ragged end of a row reads on into the next row: masked at the commit)
+    rb[i][0] = buffer_load_x4(big_rs, o | up.kill);
+    rb[i][1] = buffer_load_x4(big_rs, (o + (unsigned)(H * W * 4)) | up.kill);
+  };
+  auto commit_item = [&](int i, const UnitPos& up) {
+    const int cp = (l_cr[i] >> 8) & 63, c = 2 * cp;
+    // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
+    const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
+    const float mk = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H ? 1.f : 0.f;   // (the row lies inside the image)
+    const float s0 = aff[c] * mk, s1c = aff[c + 1] * mk, h0 = aff[CB + c] * mk, h1 = aff[CB + c + 1] * mk;
+    if (l_cr[i] & 0x8000) {
+      u32x4 ph, pm, pl;
 #pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const int ih = ih0 + (l_cr[i] & 255);
-      const bool in = (unsigned)ih < (unsigned)H;
-      rb_in |= in ? (1u << i) : 0u;
-      const unsigned o = (sample + (unsigned)(l_src[i] + (in ? ih : 0) * W)) * 4u;
-      // (a quad at the ragged end of a row reads on into the next row: masked at the commit)
-      rb[i][0] = buffer_load_x4(big_rs, o);
-      rb[i][1] = buffer_load_x4(big_rs, o + (unsigned)(H * W * 4));
+      for (int e = 0; e < 4; ++e) {
+        const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (the padding stays zero under an affine too)
+        const float y0 = on ? fmaf(rb[i][0][e], s0, h0) : 0.f, y1 = on ? fmaf(rb[i][1][e], s1c, h1) : 0.f;
+        unsigned a1, a2, a3;
+        pgv_split3_pair(y0, y1, a1, a2, a3);
+        ph[e] = a1, pm[e] = a2, pl[e] = a3;
+      }
+      *reinterpret_cast<u32x4*>(lds_x + dst) = ph;
+      *reinterpret_cast<u32x4*>(lds_x + dst + WPD * 4) = pm;
+      *reinterpret_cast<u32x4*>(lds_x + dst + 2 * WPD * 4) = pl;
     }
   };
-  auto commit = [&]() {
+  auto vector_items = [&](int jc) {   // commit unit jc from the registers, re-issue them for unit jc + 1
+    const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
-      const int cp = (l_cr[i] >> 8) & 63, c = 2 * cp;
-      // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
-      const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
-      const float mk = (rb_in >> i) & 1 ? 1.f : 0.f;
-      const float s0 = aff[c] * mk, s1c = aff[c + 1] * mk, h0 = aff[CB + c] * mk, h1 = aff[CB + c + 1] * mk;
-      if (l_cr[i] & 0x8000) {
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (the padding stays zero under an affine too)
-          const float y0 = on ? fmaf(rb[i][0][e], s0, h0) : 0.f, y1 = on ? fmaf(rb[i][1][e], s1c, h1) : 0.f;
-          unsigned a1, a2, a3;
-          pgv_split3_pair(y0, y1, a1, a2, a3);
-          ph[e] = a1, pm[e] = a2, pl[e] = a3;
-        }
-        *reinterpret_cast<u32x4*>(lds_x + dst) = ph;
-        *reinterpret_cast<u32x4*>(lds_x + dst + WPD * 4) = pm;
-        *reinterpret_cast<u32x4*>(lds_x + dst + 2 * WPD * 4) = pl;
-      }
+      commit_item(i, uc);
+      issue_item(i, un);
     }
   };
   // the saved activation of the fused epilogue: requested in the matrix phase, used in the vector phase
@@ -234,23 +241,30 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     nfl = min(R, Hs - oh0) * Ws;
     goff = ((size_t)b * CS + och) * G::P + oh0 * Ws;
   };
+  // (buffer loads, a lane without an element reads outside the buffer: every lane issues them, so the compiler's counter
+  // model counts them exactly and the waits for the band loads issued before them do not wait for these)
+  const __amdgpu_buffer_rsrc_t a_rs = tensor_rsrc(FUSE ? fuse.a : nullptr, FUSE ? (int64_t)B * CS * G::P * 4 : 0);
   auto fetch_a = [&](int j) {
     int nfl;
     size_t goff;
     tile_geom(j, nfl, goff);
-    const float* a_p = fuse.a + goff;
+    const unsigned a_o = (unsigned)goff * 4u;
 #pragma unroll
     for (int i = 0; i < QO; ++i) {
       const int q4 = part + LPC * i;
-      if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
+      av[i] = buffer_load_x4(a_rs, (a_o + 16u * q4) | (4 * q4 + 4 <= nfl ? 0u : 0x80000000u));
     }
     const int tail0 = nfl & ~3;
-    if (part < nfl - tail0) av_t = a_p[tail0 + part];
+    av_t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, (int)((a_o + 4u * (tail0 + part)) | (part < nfl - tail0 ? 0u : 0x80000000u)), 0, 0));
   };
 
-  if (J > 0) issue(0);
+  if (J > 0) {
+    const UnitPos p0 = unit_pos(0);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) issue_item(i, p0);
+  }
   __syncthreads();   // image zeroed, affine staged
-  if (J > 0) commit();
+  if (J > 0) vector_items(0);
   __syncthreads();
   // Everything the prologue loaded is READ here: the compiler may sink those loads (read-only data) below the barriers, and
   // with any of them pending at the loop header its counter model waits for "them" inside the loop - s_waitcnt vmcnt(n)
@@ -265,9 +279,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #pragma unroll 1
   for (int j = 0; j < J; ++j) {
     // ================= matrix phase =================
-    QSTAMP(j, 0);
-    if (j + 1 < J) issue(j + 1);
-    QSTAMP(j, 1);
+    QSTAMP(j, 0);   // (the loads of unit j + 1 are in flight)
     {
       f32x4 acc[MW][TMAX];
 #pragma unroll
@@ -332,19 +344,10 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     ws_sync();
     QSTAMP(j, 5);
     // ================= vector phase =================
-    // Every register the matrix phase loaded into is READ here, whether or not the next unit exists: the compiler's
-    // vector-memory counter model then has nothing pending at the loop's back edge (with the loads consumed only under a
-    // condition it protected the registers' next overwrite with s_waitcnt vmcnt(0) - behind the stores of this phase).
-    // The commit comes first: the loads are the youngest vector-memory operations then.
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) asm volatile("" ::"v"(rb[i][0]), "v"(rb[i][1]));
-    if (FUSE) {
-#pragma unroll
-      for (int i = 0; i < QO; ++i) asm volatile("" ::"v"(av[i]));
-      asm volatile("" ::"v"(av_t));
-    }
+    // The items come first (commit unit j + 1, re-issue for unit j + 2), the move-out and its stores after them: the band
+    // loads waited for are then the OLDEST vector-memory operations in flight.
     QSTAMP(j, 6);
-    if (j + 1 < J) commit();
+    if (j + 1 < J) vector_items(j + 1);
     QSTAMP(j, 7);
     {
       int nfl;
@@ -567,41 +570,47 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   const int grid = (int)gridDim.x, u0 = pgv_xcd_block(), units = B * G::BANDS;
   const int J = u0 < units ? (units - 1 - u0) / grid + 1 : 0;
 
+  // (software-pipelined item by item through the vector phase, loads outside the run or beyond the last unit read outside
+  // the buffer: see down_q_kernel)
   float rb[G::QB][8];
-  unsigned rb_on = 0;   // bit i: item i's pixel lies inside the plane (a pixel outside stays zero under an affine too)
-  auto issue = [&](int j) {
-    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS, r0 = band * UB;
-    const int nvalid = (min(Hs, r0 + G::SROWS) - r0) * Ws;   // floats of the run inside the plane (rows beyond it are zeros)
-    const float* bp = small_in + (size_t)b * CS * G::P + r0 * Ws;   // (wave-uniform)
-    rb_on = 0;
+  const __amdgpu_buffer_rsrc_t small_rs = tensor_rsrc(small_in, (int64_t)B * CS * G::P * 4);
+  struct UnitPos { unsigned base, kill; int nvalid; };
+  auto unit_pos = [&](int j) {
+    const int u = min(u0 + j * grid, units - 1), b = u / G::BANDS, band = u - b * G::BANDS, r0 = band * UB;
+    // nvalid: floats of the band's run inside the plane (rows beyond it are zeros - and stay zero under an affine)
+    return UnitPos{((unsigned)b * (unsigned)(CS * G::P) + (unsigned)(r0 * Ws)) * 4u, j < J ? 0u : 0x80000000u,
+                   (min(Hs, r0 + G::SROWS) - r0) * Ws};
+  };
+  auto issue_item = [&](int i, const UnitPos& up) {
+    const unsigned o = (up.base + 4u * (unsigned)l_src[i]) | up.kill | ((l_gi[i] & 0x7fff) < up.nvalid ? 0u : 0x80000000u);
 #pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const bool on = (l_gi[i] & 0x7fff) < nvalid;
-      rb_on |= on ? (1u << i) : 0u;
-      const unsigned o = (unsigned)l_src[i];
+    for (int c = 0; c < 8; ++c)
+      rb[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(small_rs, (int)(o + (unsigned)(c * G::P * 4)), 0, 0));
+  };
+  auto commit_item = [&](int i, const UnitPos& up) {
+    if (l_gi[i] & 0x8000) {
+      const int c = 8 * (l_gi[i] >> 16);
+      const float mk = (l_gi[i] & 0x7fff) < up.nvalid ? 1.f : 0.f;
+      u32x4 ph, pm, pl;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) rb[i][c] = on ? bp[o + c * G::P] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const float y0 = fmaf(rb[i][2 * e], aff[c + 2 * e] * mk, aff[CS + c + 2 * e] * mk);
+        const float y1 = fmaf(rb[i][2 * e + 1], aff[c + 2 * e + 1] * mk, aff[CS + c + 2 * e + 1] * mk);
+        unsigned a1, a2, a3;
+        pgv_split3_pair(y0, y1, a1, a2, a3);
+        ph[e] = a1, pm[e] = a2, pl[e] = a3;
+      }
+      *reinterpret_cast<u32x4*>(lds_s + l_dst[i]) = ph;
+      *reinterpret_cast<u32x4*>(lds_s + G::IMG + l_dst[i]) = pm;
+      *reinterpret_cast<u32x4*>(lds_s + 2 * G::IMG + l_dst[i]) = pl;
     }
   };
-  auto commit = [&]() {
+  auto vector_items = [&](int jc) {
+    const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
-      if (l_gi[i] & 0x8000) {
-        const int c = 8 * (l_gi[i] >> 16);
-        const float mk = (rb_on >> i) & 1 ? 1.f : 0.f;
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y0 = fmaf(rb[i][2 * e], aff[c + 2 * e] * mk, aff[CS + c + 2 * e] * mk);
-          const float y1 = fmaf(rb[i][2 * e + 1], aff[c + 2 * e + 1] * mk, aff[CS + c + 2 * e + 1] * mk);
-          unsigned a1, a2, a3;
-          pgv_split3_pair(y0, y1, a1, a2, a3);
-          ph[e] = a1, pm[e] = a2, pl[e] = a3;
-        }
-        *reinterpret_cast<u32x4*>(lds_s + l_dst[i]) = ph;
-        *reinterpret_cast<u32x4*>(lds_s + G::IMG + l_dst[i]) = pm;
-        *reinterpret_cast<u32x4*>(lds_s + 2 * G::IMG + l_dst[i]) = pl;
-      }
+      commit_item(i, uc);
+      issue_item(i, un);
     }
   };
   f4u av[QO];
@@ -611,23 +620,30 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     nfl = min(RB, H - y0) * W;
     goff = ((size_t)b * CB + och) * (H * W) + y0 * W;
   };
+  // (buffer loads, a lane without an element reads outside the buffer: every lane issues them, so the compiler's counter
+  // model counts them exactly and the waits for the band loads issued before them do not wait for these)
+  const __amdgpu_buffer_rsrc_t a_rs = tensor_rsrc(FUSE ? fuse.a : nullptr, FUSE ? (int64_t)B * CB * (H * W) * 4 : 0);
   auto fetch_a = [&](int j) {
     int nfl;
     size_t goff;
     tile_geom(j, nfl, goff);
-    const float* a_p = fuse.a + goff;
+    const unsigned a_o = (unsigned)goff * 4u;
 #pragma unroll
     for (int i = 0; i < QO; ++i) {
       const int q4 = part + LPC * i;
-      if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
+      av[i] = buffer_load_x4(a_rs, (a_o + 16u * q4) | (4 * q4 + 4 <= nfl ? 0u : 0x80000000u));
     }
     const int tail0 = nfl & ~3;
-    if (part < nfl - tail0) av_t = a_p[tail0 + part];
+    av_t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, (int)((a_o + 4u * (tail0 + part)) | (part < nfl - tail0 ? 0u : 0x80000000u)), 0, 0));
   };
 
-  if (J > 0) issue(0);
+  if (J > 0) {
+    const UnitPos p0 = unit_pos(0);
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) issue_item(i, p0);
+  }
   __syncthreads();   // image zeroed, affine staged
-  if (J > 0) commit();
+  if (J > 0) vector_items(0);
   __syncthreads();
   // Everything the prologue loaded is READ here: the compiler may sink those loads (read-only data) below the barriers, and
   // with any of them pending at the loop header its counter model waits for "them" inside the loop - s_waitcnt vmcnt(n)
@@ -642,9 +658,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #pragma unroll 1
   for (int j = 0; j < J; ++j) {
     // ================= matrix phase =================
-    QSTAMP(j, 0);
-    if (j + 1 < J) issue(j + 1);
-    QSTAMP(j, 1);
+    QSTAMP(j, 0);   // (the loads of unit j + 1 are in flight)
     {
       f32x4 acc[MW][TMAX];
 #pragma unroll
@@ -702,18 +716,9 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     QSTAMP(j, 4);
     ws_sync();
     QSTAMP(j, 5);
-    // ================= vector phase ================= (see down_q_kernel)
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i)
-#pragma unroll
-      for (int c = 0; c < 8; c += 2) asm volatile("" ::"v"(rb[i][c]), "v"(rb[i][c + 1]));
-    if (FUSE) {
-#pragma unroll
-      for (int i = 0; i < QO; ++i) asm volatile("" ::"v"(av[i]));
-      asm volatile("" ::"v"(av_t));
-    }
+    // ================= vector phase ================= (items first, then the move-out: see down_q_kernel)
     QSTAMP(j, 6);
-    if (j + 1 < J) commit();
+    if (j + 1 < J) vector_items(j + 1);
     QSTAMP(j, 7);
     {
       int nfl;

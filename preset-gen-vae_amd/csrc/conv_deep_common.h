@@ -38,14 +38,23 @@ __device__ __forceinline__ unsigned pgv_pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-// two values at once, as the packed bf16 pairs (low half = a) the images hold: 3 packed conversions, 4 mask / shift
-// instructions and 4 subtractions per pair (the conversion's result IS the packed pair; its halves, moved to the top of a
-// dword, are the terms as fp32)
+// two values at once, as the packed bf16 pairs (low half = a) the images hold: 3 packed conversions and 4 residuals per
+// pair.  A residual x - bf16(x) is ONE v_dot2c_f32_bf16 on the packed pair itself (x + pair . {-1, 0} for the low half,
+// {0, -1} for the high half: one exact product, one exactly representable sum - bit-identical to the subtraction from the
+// unpacked term for every finite input below 2^127.99, scratch/ubench/dot2_residual.hip), instead of a shift / mask that
+// moves the half to the top of a dword plus a subtraction.  The selectors live in scalar registers: written as literals the
+// packed {-1.0, 0} becomes the inline constant "-1.0", which the hardware reads as the fp32 pattern, i.e. as {0, -1.0}.
 __device__ __forceinline__ void pgv_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
+  asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+  const bf2 lo1 = __builtin_bit_cast(bf2, sel_lo), hi1 = __builtin_bit_cast(bf2, sel_hi);
   H = pgv_pack_bf16x2(a, b);
-  const float ra = a - __builtin_bit_cast(float, H << 16), rb = b - __builtin_bit_cast(float, H & 0xffff0000u);
+  const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, H), lo1, a, false);
+  const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, H), hi1, b, false);
   M = pgv_pack_bf16x2(ra, rb);
-  L = pgv_pack_bf16x2(ra - __builtin_bit_cast(float, M << 16), rb - __builtin_bit_cast(float, M & 0xffff0000u));
+  L = pgv_pack_bf16x2(__builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, M), lo1, ra, false),
+                      __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, M), hi1, rb, false));
 }
 
 // Split weight shadow of a deep k4 s2 p2 layer, DOWN layout = the fragment order of deep_down_split_kernel: the 16 bytes

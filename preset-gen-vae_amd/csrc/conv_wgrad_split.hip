@@ -97,79 +97,88 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   const int J = u0 < units ? (units - 1 - u0) / grid + 1 : 0;
 
   f4u xb[G::QX][2], sb[G::QS][2];
-  unsigned x_in = 0, s_in = 0;   // bit i: the item's row lies inside the tensor
   const __amdgpu_buffer_rsrc_t big_rs = tensor_rsrc(big, (int64_t)B * CB * (H * W) * 4);
   const __amdgpu_buffer_rsrc_t small_rs = tensor_rsrc(small_in, (int64_t)B * CS * (Hs * Ws) * 4);
-  auto issue = [&](int j) {
-    const int u = u0 + j * grid, b = u / G::BANDS, band = u - b * G::BANDS;
-    const unsigned xs = (unsigned)b * (unsigned)(CB * H * W), ss = (unsigned)b * (unsigned)(CS * Hs * Ws);
-    x_in = s_in = 0;
+  // The band loads are software-pipelined ITEM BY ITEM through the vector phase: an item of unit j + 1 is converted and
+  // committed, and its registers are re-issued at once for the same item of unit j + 2 - loads stay in flight through the
+  // vector phase and the next matrix phase (issued in one burst at the start of the matrix phase, a unit's 78 KB were
+  // still arriving when the vector phase wanted them: a CU's fair share of HBM moves them in ~6 k clocks, the matrix
+  // phase lasts ~3.5 k).  A load for a unit beyond this workgroup's last one gets an offset beyond the buffer: no traffic.
+  struct UnitPos { unsigned xs, ss, kill; int band; };
+  auto unit_pos = [&](int j) {
+    const int u = min(u0 + j * grid, units - 1), b = u / G::BANDS;
+    return UnitPos{(unsigned)b * (unsigned)(CB * H * W), (unsigned)b * (unsigned)(CS * Hs * Ws), j < J ? 0u : 0x80000000u, u - b * G::BANDS};
+  };
+  auto issue_x = [&](int i, const UnitPos& up) {
+    const int ih = 2 * up.band * R - 2 + ((xl_cr[i] >> 8) & 63);
+    const bool in = (unsigned)ih < (unsigned)H;
+    const unsigned o = ((up.xs + (unsigned)(xl_src[i] + (in ? ih : 0) * W)) * 4u) | up.kill;
+    xb[i][0] = buffer_load_x4(big_rs, o);        // (columns beyond the row: masked at the commit)
+    xb[i][1] = buffer_load_x4(big_rs, o + 16u);
+  };
+  auto issue_s = [&](int i, const UnitPos& up) {
+    const int oh = up.band * R + ((sl_cr[i] >> 8) & 63);
+    const unsigned o = ((up.ss + (unsigned)(sl_src[i] + (oh < Hs ? oh : 0) * Ws)) * 4u) | up.kill;
+    sb[i][0] = buffer_load_x4(small_rs, o);
+    sb[i][1] = buffer_load_x4(small_rs, o + 16u);
+  };
+  auto commit_x = [&](int i, const UnitPos& up) {
+    const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
+    const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = aff_b[c] * mk, sh = aff_b[CB + c] * mk;
+    if (xl_cr[i] & 0x8000) {
+      float y[8];
 #pragma unroll
-    for (int i = 0; i < G::QX; ++i) {
-      const int ih = 2 * band * R - 2 + ((xl_cr[i] >> 8) & 63);
-      const bool in = (unsigned)ih < (unsigned)H;
-      x_in |= in ? (1u << i) : 0u;
-      const unsigned o = (xs + (unsigned)(xl_src[i] + (in ? ih : 0) * W)) * 4u;
-      xb[i][0] = buffer_load_x4(big_rs, o);        // (columns beyond the row: masked at the commit)
-      xb[i][1] = buffer_load_x4(big_rs, o + 16u);
-    }
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? xb[i][0][e] : xb[i][1][e - 4];
+        y[e] = 8 * o + e < W ? fmaf(v, sc, sh) : 0.f;   // (columns beyond the row stay zero under an affine too)
+      }
+      unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
 #pragma unroll
-    for (int i = 0; i < G::QS; ++i) {
-      const int oh = band * R + ((sl_cr[i] >> 8) & 63);
-      const bool in = oh < Hs;
-      s_in |= in ? (1u << i) : 0u;
-      const unsigned o = (ss + (unsigned)(sl_src[i] + (in ? oh : 0) * Ws)) * 4u;
-      sb[i][0] = buffer_load_x4(small_rs, o);
-      sb[i][1] = buffer_load_x4(small_rs, o + 16u);
+      for (int k = 0; k < 2; ++k) {
+        pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k]);       // even columns 8o + 4k, + 2
+        pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k]);   // odd columns
+      }
+      u16* dst = x_img + c * XCH + r * XROW + 4 * o;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2*>(dst) = u32x2{e1[0], e1[1]};
+      *reinterpret_cast<u32x2*>(dst + XPL) = u32x2{o1[0], o1[1]};
+      *reinterpret_cast<u32x2*>(dst + G::X_PLANE) = u32x2{e2[0], e2[1]};
+      *reinterpret_cast<u32x2*>(dst + G::X_PLANE + XPL) = u32x2{o2[0], o2[1]};
+      *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE) = u32x2{e3[0], e3[1]};
+      *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
     }
   };
-  auto commit = [&]() {
+  auto commit_s = [&](int i, const UnitPos& up) {
+    const int c = sl_cr[i] >> 16, r = (sl_cr[i] >> 8) & 63, o = sl_cr[i] & 255;
+    const float mk = up.band * R + r < Hs ? 1.f : 0.f, sc = aff_s[c] * mk, sh = aff_s[CS + c] * mk;
+    if (sl_cr[i] & 0x8000) {
+      u32x4 p1, p2, p3;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
+        const float y0 = 8 * o + 2 * k < Ws ? fmaf(v0, sc, sh) : 0.f, y1 = 8 * o + 2 * k + 1 < Ws ? fmaf(v1, sc, sh) : 0.f;
+        unsigned a1, a2, a3;
+        pgv_split3_pair(y0, y1, a1, a2, a3);
+        p1[k] = a1, p2[k] = a2, p3[k] = a3;
+      }
+      u16* dst = s_img + c * SCH + r * SROW + 8 * o;
+      *reinterpret_cast<u32x4*>(dst) = p1;
+      *reinterpret_cast<u32x4*>(dst + G::S_PLANE) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * G::S_PLANE) = p3;
+    }
+  };
+  // commit unit jc from the registers, re-issue them for unit jc + 1
+  auto vector_phase = [&](int jc) {
+    const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
 #pragma unroll
     for (int i = 0; i < G::QX; ++i) {
-      const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
-      const float mk = (x_in >> i) & 1 ? 1.f : 0.f, sc = aff_b[c] * mk, sh = aff_b[CB + c] * mk;
-      if (xl_cr[i] & 0x8000) {
-        float y[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = e < 4 ? xb[i][0][e] : xb[i][1][e - 4];
-          y[e] = 8 * o + e < W ? fmaf(v, sc, sh) : 0.f;   // (columns beyond the row stay zero under an affine too)
-        }
-        unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k]);       // even columns 8o + 4k, + 2
-          pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k]);   // odd columns
-        }
-        u16* dst = x_img + c * XCH + r * XROW + 4 * o;
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(dst) = u32x2{e1[0], e1[1]};
-        *reinterpret_cast<u32x2*>(dst + XPL) = u32x2{o1[0], o1[1]};
-        *reinterpret_cast<u32x2*>(dst + G::X_PLANE) = u32x2{e2[0], e2[1]};
-        *reinterpret_cast<u32x2*>(dst + G::X_PLANE + XPL) = u32x2{o2[0], o2[1]};
-        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE) = u32x2{e3[0], e3[1]};
-        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
-      }
+      commit_x(i, uc);
+      issue_x(i, un);
     }
 #pragma unroll
     for (int i = 0; i < G::QS; ++i) {
-      const int c = sl_cr[i] >> 16, r = (sl_cr[i] >> 8) & 63, o = sl_cr[i] & 255;
-      const float mk = (s_in >> i) & 1 ? 1.f : 0.f, sc = aff_s[c] * mk, sh = aff_s[CS + c] * mk;
-      if (sl_cr[i] & 0x8000) {
-        u32x4 p1, p2, p3;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
-          const float y0 = 8 * o + 2 * k < Ws ? fmaf(v0, sc, sh) : 0.f, y1 = 8 * o + 2 * k + 1 < Ws ? fmaf(v1, sc, sh) : 0.f;
-          unsigned a1, a2, a3;
-          pgv_split3_pair(y0, y1, a1, a2, a3);
-          p1[k] = a1, p2[k] = a2, p3[k] = a3;
-        }
-        u16* dst = s_img + c * SCH + r * SROW + 8 * o;
-        *reinterpret_cast<u32x4*>(dst) = p1;
-        *reinterpret_cast<u32x4*>(dst + G::S_PLANE) = p2;
-        *reinterpret_cast<u32x4*>(dst + 2 * G::S_PLANE) = p3;
-      }
+      commit_s(i, uc);
+      issue_s(i, un);
     }
   };
 
@@ -190,15 +199,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
 #pragma unroll
     for (int t = 0; t < CTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (J > 0) issue(0);
+  if (J > 0) {
+    const UnitPos u0p = unit_pos(0);
+#pragma unroll
+    for (int i = 0; i < G::QX; ++i) issue_x(i, u0p);
+#pragma unroll
+    for (int i = 0; i < G::QS; ++i) issue_s(i, u0p);
+  }
   __syncthreads();
-  if (J > 0) commit();
+  if (J > 0) vector_phase(0);
   __syncthreads();
 
 #pragma unroll 1
   for (int j = 0; j < J; ++j) {
-    if (j + 1 < J) issue(j + 1);
-    // ================= matrix phase =================
+    // ================= matrix phase ================= (the loads of unit j + 1 are in flight)
 #pragma unroll
     for (int k = 0; k < KSW; ++k) {
       {   // (a K way with a step less multiplies the zero padding: no wave-uniform branch around the accumulators)
@@ -230,12 +244,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
       }
     }
     ws_sync();
-    // ================= vector phase ================= (all loads of the matrix phase consumed for the compiler's counter model)
-#pragma unroll
-    for (int i = 0; i < G::QX; ++i) asm volatile("" ::"v"(xb[i][0]), "v"(xb[i][1]));
-#pragma unroll
-    for (int i = 0; i < G::QS; ++i) asm volatile("" ::"v"(sb[i][0]), "v"(sb[i][1]));
-    if (j + 1 < J) commit();
+    // ================= vector phase =================
+    if (j + 1 < J) vector_phase(j + 1);
     ws_sync();
   }
 
