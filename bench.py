@@ -617,9 +617,12 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     sync = None
     if dist_on:
         sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=args.buckets))
-    step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
-                        beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=use_graph,
-                        graph_buckets=args.dist_mode == 'bucket-graphs')
+    def make_step(graph):
+        return VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
+                            beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=graph,
+                            graph_buckets=args.dist_mode == 'bucket-graphs')
+    step = make_step(use_graph)
+    launch_fallback = None
 
     frontend = None
     if args.input == "audio":
@@ -636,8 +639,25 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
             frontend.batch(wav, out=xin)
         return step.step(xin)
 
-    for _ in range(args.warmup):
-        out = one_step(x)
+    try:
+        for _ in range(args.warmup):
+            out = one_step(x)
+    except RuntimeError as e:
+        # N > 1 only: the captured launch modes have run over gloo and over a 1-rank RCCL communicator, never over RCCL on
+        # several GPUs.  A capture that fails there fails on every rank alike (same program, same order); the line is then
+        # measured with eager launches and says so, instead of the scaling run ending without a number.
+        if not (dist_on and use_graph):
+            raise
+        launch_fallback = f"{args.dist_mode} failed ({str(e).splitlines()[0][:160]}); eager launches instead"
+        print(f"[bench rank {rank}] {launch_fallback}", file=sys.stderr, flush=True)
+        if step.grad_sync is not None:
+            step.grad_sync.uninstall()
+        del step
+        torch.cuda.synchronize()
+        use_graph = False
+        step = make_step(False)
+        for _ in range(max(1, args.warmup)):
+            out = one_step(x)
     if step.static_input is not None:
         # the minibatch lives in the captured step's input buffer (where the on-GPU front-end / the H2D copy of a real
         # loader would put it): inputs are resident in HBM when the timed region starts, no device-to-device copy
@@ -707,6 +727,8 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                 "three-way operand splits with fp32 accumulation (error against float64 <= the native instruction's: "
                 "tests/test_gpu_kernels.py); the 1-channel 5x5 end layers and the fc GEMMs use the native fp32 instruction"
                 if ops.fp32_products() != 'native' else "native: v_mfma_f32_16x16x4_f32 / fp32 FMA everywhere")
+        if launch_fallback:
+            cfg["launch_fallback"] = launch_fallback
         if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()

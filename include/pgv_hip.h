@@ -44,9 +44,12 @@ typedef struct pgv_conv_desc {
   int32_t kh, kw;          /* kernel */
   int32_t stride, pad;     /* same on both axes (reference uses [2,2]/2 or [1,1]/0) */
   int32_t flags;           /* PGV_PREZEROED: the accumulated outputs of the call (stats / gw) already hold zeros */
-  const void* w_shadow;    /* optional (may be NULL): the bf16 shadow of the call's weight tensor, written by
-                              pgv_conv_weight_shadow for this descriptor's layer and still current - PGV_COMPUTE_BF16
-                              calls of the deep layers then run their bf16-native kernels (ABI v11) */
+  const void* w_shadow;    /* optional (may be NULL): the weight shadow of the call's weight tensor for THIS descriptor's
+                              flags, written by pgv_conv_weight_shadow and still current.  PGV_COMPUTE_BF16: the rounded
+                              weights, channel-innermost - the deep layers then run their bf16-native kernels (ABI v11).
+                              PGV_COMPUTE_F32_SPLIT: three bf16 planes per direction in the kernels' fragment order -
+                              forward / input-gradient calls of the layers listed at the flag run the six-instruction
+                              kernels with it and the native fp32 kernels without it (ABI v13, large planes v14) */
 } pgv_conv_desc;
 
 /* Reduction outputs (BN statistics, weight / bias gradients, BN-backward projections) are accumulated with atomics.
@@ -56,18 +59,26 @@ typedef struct pgv_conv_desc {
 #define PGV_PREZEROED 1
 /* bf16 compute / fp32 storage (BASELINE config 2): the operands of every product (activations after the folded
  * BatchNorm affine, weights, gradients) are rounded to bfloat16 (RNE) and multiplied on the bf16 matrix cores
- * (v_mfma_f32_16x16x16_bf16) with fp32 accumulation; tensors in HBM, BatchNorm, losses and Adam stay fp32. */
+ * (v_mfma_f32_16x16x32_bf16) with fp32 accumulation; tensors in HBM, BatchNorm, losses and Adam stay fp32. */
 #define PGV_COMPUTE_BF16 2
-/* fp32 products evaluated as SIX bf16 matrix instructions (opt-in, fp32 mode only; ignored together with PGV_COMPUTE_BF16):
+/* fp32 products evaluated as SIX bf16 matrix instructions (fp32 mode only; ignored together with PGV_COMPUTE_BF16):
  * every operand value x is held as three bfloat16 terms x1 + x2 + x3 (exact), the product as the six largest cross terms
- * with fp32 accumulation - the dropped terms are below 2^-23 of the product, the measured error against float64 is below
- * that of v_mfma_f32_16x16x4_f32 (scratch/ubench/bf16x6.hip) - at 6 / 16 of the fp32 instruction time.  Only the layers
- * with a kernel for it change: the deep k4 s2 p2 layers on 17x23 / 9x12 / 5x7 planes (forward, input gradient, weight
- * gradient), the 1x1 layers on 3x4 planes (forward, input gradient) and the 32 -> 16 channel transposed convolution onto
- * 65x88 (conv_deep_split.hip, conv_deep_bf16.hip).  Forward / input-gradient calls need the layer's split weight shadow
- * (pgv_conv_weight_shadow_bytes > 0 under this flag: three bf16 planes per direction, in the fragment order of the kernels)
- * in pgv_conv_desc.w_shadow and compute natively without it; the weight gradient needs none (both operands are activations,
- * split in the kernel's loader).  Every other call computes as without the flag. */
+ * (v_mfma_f32_16x16x32_bf16, smallest term first) with fp32 accumulation - the dropped terms are below 2^-23 of the
+ * product, the measured error against float64 is at or below that of v_mfma_f32_16x16x4_f32 (tests/test_gpu_kernels.py:
+ * within 1.25 x + 1e-7 of it on every kernel).  Only the layers with a kernel for it change - every k4 s2 p2 layer of the
+ * reference stacks with more than one input channel:
+ *   8 <-> 16 channels on 129x174, 16 <-> 32 on 65x88, 32 <-> 64 on 33x45   forward, fused input gradient (pgv_bwd_fuse;
+ *                                                                          the transposed direction without class sums),
+ *                                                                          weight gradient
+ *                                                                          (conv_big_split.hip, conv_wgrad_split.hip)
+ *   64 <-> 128 on 17x23, 128 <-> 256 on 9x12, 256 <-> 512 on 5x7           forward, input gradient, weight gradient
+ *   1x1 layers on 3x4 planes                                               forward, input gradient
+ *                                                                          (conv_deep_split.hip, conv_deep_bf16.hip)
+ * Forward / input-gradient calls need the layer's split weight shadow (pgv_conv_weight_shadow_bytes > 0 under this flag:
+ * 12 bytes per weight) in pgv_conv_desc.w_shadow and compute natively without it; the weight gradient needs none (both
+ * operands are activations, split in the kernel's loader) but needs the workspace of pgv_conv_wgrad_workspace_bytes.
+ * Every other call computes as without the flag.  The library default is off (native fp32 instruction); bench.py times
+ * the step with it on and says so in its config. */
 #define PGV_COMPUTE_F32_SPLIT 8
 /* The BatchNorm statistics output of a forward conv call (`stats`) is PGV_CLS_COPIES partial copies [copies][2C] of
  * doubles, zeroed by the caller, and a workgroup may add into any of them (the wave-specialised kernels use the copy of
@@ -503,6 +514,18 @@ int pgv_copy(const float* src, float* dst, int64_t n, void* stream);
  * float that is never written in practice. */
 int pgv_probe_mfma(int bf16, int iters, float* sink, int64_t* flops, void* stream);
 int pgv_probe_read(const float* buf, int64_t n, float* sink, void* stream);
+
+/* ---- tuning knobs ----------------------------------------------------------------------------------------
+ * NOT part of the interface a binding should use: process-wide A/B switches of the timing scripts under scratch/ (and of
+ * one test that covers a kept-alive alternative path).  None changes a result beyond summation order; each returns the
+ * previous value.  pgv_dbg_set_deep_bf16_stamps takes a device buffer for in-kernel clock stamps of the bf16-native deep
+ * kernels (NULL = off, the default). */
+int pgv_dbg_set_gemm_tiles(int v);          /* gemm.hip: 1 = the bf16 MFMA tile kernels instead of gemm_frag.hip */
+int pgv_dbg_set_gemm_variant(int v);        /* gemm_frag.hip: pipeline stages / grid cap / split-K selection */
+int pgv_dbg_set_v2_down_variant(int v);     /* conv_v2_down.hip */
+int pgv_dbg_set_wgrad_bf16_variant(int v);  /* conv_v2_wgrad.hip: bit 0 = band partial kernels instead of conv_wgrad_bf16.hip */
+int pgv_dbg_set_deep_bf16_variant(int v);   /* conv_deep_bf16.hip */
+void pgv_dbg_set_deep_bf16_stamps(void* device_buf);
 
 #ifdef __cplusplus
 }

@@ -153,6 +153,13 @@ SIGNATURES = {
     "pgv_copy": (c_int, [_P, _P, c_int64, _P]),
     "pgv_probe_mfma": (c_int, [c_int, c_int, _P, POINTER(c_int64), _P]),
     "pgv_probe_read": (c_int, [_P, c_int64, _P, _P]),
+    # tuning knobs of the timing scripts (pgv_hip.h, last section)
+    "pgv_dbg_set_gemm_tiles": (c_int, [c_int]),
+    "pgv_dbg_set_gemm_variant": (c_int, [c_int]),
+    "pgv_dbg_set_v2_down_variant": (c_int, [c_int]),
+    "pgv_dbg_set_wgrad_bf16_variant": (c_int, [c_int]),
+    "pgv_dbg_set_deep_bf16_variant": (c_int, [c_int]),
+    "pgv_dbg_set_deep_bf16_stamps": (None, [_P]),
 }
 
 _lib = None

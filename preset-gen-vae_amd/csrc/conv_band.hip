@@ -635,8 +635,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(int B, int Cb, 
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // bf16 compute: 16 output pixels per v_mfma_f32_16x16x16_bf16 - the lane group keeps its pixel offset k and
-      // supplies pixels k, k+4, k+8, k+12 of the 16-pixel step (the operands of four fp32 steps), rounded while packing
+      // bf16 compute: 32 output pixels per v_mfma_f32_16x16x32_bf16 (two 16-pixel steps paired in one operand, conv_tile.h) -
+      // the lane group keeps its pixel offset k and supplies pixels k, k+4, k+8, k+12 of each 16-pixel step (the operands
+      // of four fp32 steps), rounded while packing
       constexpr int SPR4 = SPR / 4;
       static_assert(SPR % 4 == 0, "bf16 rows are padded to 16 pixels");
       constexpr int S = RW * SPR4;
@@ -989,8 +990,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_band_kernel(int B, int Cb, int
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // bf16 compute: one v_mfma_f32_16x16x16_bf16 per (4 input channels, m, t): the lane group keeps its tap (th, tw)
-      // and supplies it for channels 4s..4s+3 (the operands of four fp32 steps), rounded to bf16 while packing
+      // bf16 compute: one v_mfma_f32_16x16x32_bf16 per (8 input channels, m, t) - two 4-channel steps paired in one operand
+      // (conv_tile.h): the lane group keeps its tap (th, tw) and supplies it for channels 4s..4s+3 of each step (the operands
+      // of four fp32 steps), rounded to bf16 while packing
       constexpr int S = CK / 4;
       static_assert(CK % 8 == 0, "channel chunk must hold an even number of 4-channel steps");
       u32x4 a0[MT], b0[NT];

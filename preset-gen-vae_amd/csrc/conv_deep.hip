@@ -13,7 +13,7 @@
 //   * the MFMA k index is the kernel tap: lane group j = lane>>4 holds kernel row kh = j, so one ds_read_b128 of the
 //     weight row gives the A operands of the four k-steps (kw = 0..3) of a channel.
 // PGV_COMPUTE_BF16: the same tiles, operands packed to bf16 while they are read (v_cvt_pk_bf16_f32), one
-// v_mfma_f32_16x16x16_bf16 per (channel, tile) instead of four fp32 steps.
+// v_mfma_f32_16x16x32_bf16 per (channel pair, tile) instead of eight fp32 steps (two 16-deep steps per operand, conv_tile.h).
 #include "conv_tile.h"
 #include "conv_deep_common.h"
 

@@ -80,7 +80,10 @@ def _config_attr(cfg, attr):
 
 def check_configs_on_resume_from_checkpoint(new_model_config, new_train_config, config_json_checkpoint):
     """Refuse to resume a run whose saved configuration disagrees with the current one on a field that shapes the
-    model, the data or the optimizer (the fields of ``_RESUME_LOCKED``).
+    model, the data or the optimizer (the fields of ``_RESUME_LOCKED``: the ones reference build.py:90-122 checks, same
+    exception type).  Two deliberate differences from the reference, recorded in INTEGRATION.md section 3: lists and
+    tuples compare equal at ANY nesting depth (the reference converts the top level only, so a nested tuple such as
+    ``stft_args`` inside a list fails its check after a JSON round trip), and the message names both values.
 
     :raises: ValueError naming the first field that differs"""
     current = {'model': new_model_config, 'train': new_train_config}

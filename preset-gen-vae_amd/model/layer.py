@@ -246,7 +246,7 @@ class ConvStackFn(torch.autograd.Function):
                 else:
                     ops.bn_eval_affine(gamma, beta, blk.bn.running_mean, blk.bn.running_var, blk.bn.eps, scale, shift)
                     mean = rstd = None
-            saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g, w_sh))
+            saved.append((cur, cur_scale, cur_shift, a, scale, mean, rstd, g, (w_sh, ops.compute_mode())))
             cur, cur_scale, cur_shift = a, scale, shift
         ctx.drop = None
         if out_dropout is not None:
@@ -358,7 +358,10 @@ class ConvStackFn(torch.autograd.Function):
         gb_is_copies = False
         for li in range(nb - 1, -1, -1):
             blk = blocks[li]
-            inp, in_scale, in_shift, a, scale, mean, rstd, geom, w_sh = saved[li]
+            inp, in_scale, in_shift, a, scale, mean, rstd, geom, (w_sh, sh_mode) = saved[li]
+            if sh_mode != ops.compute_mode():
+                w_sh = None   # (the operand mode changed between forward and backward: the saved shadow has the other
+                #               mode's layout - without one the call computes from w itself)
             has_bn = blk.bn is not None
             pi = pis[li]
             w = params[pi]

@@ -66,7 +66,8 @@ _F32_SPLIT = False
 def set_fp32_products(mode):
     """How fp32-mode products are evaluated by the layers that have a kernel for both: 'native' (default:
     v_mfma_f32_16x16x4_f32) or 'bf16x6' (PGV_COMPUTE_F32_SPLIT: every operand as three exact bfloat16 terms, six bf16 matrix
-    instructions per product with fp32 accumulation - fp32-level error).  Opt-in; no effect in bf16 mode."""
+    instructions per product with fp32 accumulation - fp32-level error).  No effect in bf16 mode.  The library
+    default is 'native'; bench.py times the step with 'bf16x6' and labels its line."""
     global _F32_SPLIT
     if mode not in ('native', 'bf16x6'):
         raise ValueError(f"unknown fp32 product mode {mode!r}")
@@ -75,6 +76,12 @@ def set_fp32_products(mode):
 
 def fp32_products():
     return 'bf16x6' if _F32_SPLIT else 'native'
+
+
+def compute_mode():
+    """(compute dtype, fp32 product form): what a weight shadow was laid out for (model/layer.py keeps it next to the
+    shadows it saves for the backward pass)."""
+    return (compute_dtype(), fp32_products())
 
 
 def _flags():

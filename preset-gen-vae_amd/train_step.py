@@ -254,8 +254,10 @@ class VAETrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        # (capture_error_mode 'thread_local': another thread of the process - a data-loader worker pinning memory, a logger
+        # calling into the runtime - must not invalidate the capture)
         if self.grad_sync is None:
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
                 self._out = self._step_body(self._static_x, self._static_v)
             return
         if self.graph_buckets:
@@ -263,10 +265,10 @@ class VAETrainStep:
             return
         # N ranks: [zero_grad + forward + backward] | eager exchange | [Adam]; the capture itself leaves the parameters
         # untouched (captured work does not run), so every rank still holds identical replicas afterwards
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
             self._out = self._forward_backward(self._static_x, self._static_v)
         self._graph_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_update):
+        with torch.cuda.graph(self._graph_update, capture_error_mode='thread_local'):
             self._optimizer_step(self._out)
 
     def _capture_bucket_graphs(self):
@@ -307,13 +309,26 @@ class VAETrainStep:
                 begin()
                 self._out = self._forward_backward(self._static_x, self._static_v, hooks=True)
                 cut()
+                state['graph'] = self._graph_update = torch.cuda.CUDAGraph()
+                self._graph_update.capture_begin(pool=graphs[0][0].pool(), capture_error_mode='thread_local')
+                self._optimizer_step(self._out)
+                self._graph_update.capture_end()
+                state['graph'] = None
+            except BaseException:
+                # a failure inside the step body leaves the stream capturing: end the running capture (its graph is
+                # dropped) so the caller's error is the step's, not "operation not permitted when stream is capturing" on
+                # the next unrelated call
+                g = state.get('graph')
+                if g is not None and torch.cuda.is_current_stream_capturing():
+                    try:
+                        g.capture_end()
+                    except RuntimeError:
+                        pass
+                self._graph = self._graph_update = self._bucket_graphs = None
+                raise
             finally:
                 layer.GRAD_READY_HOOK = prev_hook
                 sync.capture_cuts(None)
-            self._graph_update = torch.cuda.CUDAGraph()
-            self._graph_update.capture_begin(pool=graphs[0][0].pool(), capture_error_mode='thread_local')
-            self._optimizer_step(self._out)
-            self._graph_update.capture_end()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         self._bucket_graphs = graphs
