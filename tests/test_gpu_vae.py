@@ -604,6 +604,45 @@ def _batch_tiling_b256(g, arch, dim_z, B0, output_bn, reps):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("arch,dim_z,mode", [('speccnn8l1_bn', 64, 'bf16x6'), ('speccnn4l1_bn', 64, 'bf16x6'),
+                                             ('speccnn8l1_bn', 512, 'bf16')])
+@pytest.mark.parametrize("B", [1, 3, 19, 33, 257])
+def test_train_step_odd_batch_sizes_in_the_bench_modes(arch, dim_z, mode, B):
+    """The whole train step at batch sizes that leave partial sample groups, ragged last units and fewer units than
+    workgroups in every kernel of the two operand modes bench.py times besides the native fp32 instruction: it runs, is
+    finite, and agrees with the native fp32 step on the same inputs - six-instruction products: losses to 1e-6, the
+    gradient norm to 1e-3 (two fp32 evaluations with different summation orders put a few pre-activations on different
+    sides of a LeakyReLU kink, which moves gradients by 4e-4 .. 5e-3 - the strict tests pin the regions, this one does
+    not; measured 3e-6 .. 4.8e-4); bf16 operand mode: everything to 2e-2."""
+    from preset_gen_vae_amd import ops
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    res = {}
+    for m in ('native', mode):
+        ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
+        _load_closed_form(ae, arch, dim_z, False, 4321)
+        ae = ae.cuda().train()
+        x = synth_input(B)
+        eps = torch.sin(torch.arange(B * dim_z, dtype=torch.float64) * 0.37 + 0.2).reshape(B, dim_z) * 1.1
+        ops.set_compute_dtype('bf16' if m == 'bf16' else 'fp32')
+        ops.set_fp32_products('bf16x6' if m == 'bf16x6' else 'native')
+        try:
+            step = VAETrainStep(ae, lr=2e-4, weight_decay=1e-4, beta=0.2, normalize_losses=True)
+            out = step.step(_cuda32(x), inject={'eps': _cuda32(eps)})
+            torch.cuda.synchronize()
+        finally:
+            ops.set_compute_dtype('fp32')
+            ops.set_fp32_products('native')
+        gn = sum(float(p.grad.double().pow(2).sum()) for p in ae.parameters() if p.grad is not None) ** 0.5
+        res[m] = (out['recons'].item(), out['latent'].item(), gn)
+    a, b = res['native'], res[mode]
+    assert all(v == v and abs(v) < 1e30 for v in b), b
+    if mode == 'bf16x6':
+        assert all(abs(u - v) <= 1e-6 * abs(u) + 1e-7 for u, v in zip(a[:2], b[:2])), (a, b)
+        assert abs(a[2] - b[2]) <= 1e-3 * a[2], (a, b)
+    else:
+        assert all(abs(u - v) <= 2e-2 * abs(u) + 1e-6 for u, v in zip(a, b)), (a, b)
+
+
 def test_graph_replay_equals_eager():
     """hipGraph-captured step == eager step (same kernels, same order); RNG advances across replays."""
     from preset_gen_vae_amd.train_step import VAETrainStep
