@@ -204,12 +204,14 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     rb[i][0] = buffer_load_x4(big_rs, o | up.kill);
     rb[i][1] = buffer_load_x4(big_rs, (o + (unsigned)(H * W * 4)) | up.kill);
   };
-  auto commit_item = [&](int i, const UnitPos& up) {
-    const int cp = (l_cr[i] >> 8) & 63, c = 2 * cp;
+  // (the affine of an item's channel pair is read from LDS for ALL items before the first one is committed: read inside
+  // the item, the wait for it - lgkmcnt counts in order - was also a wait for the previous item's three image stores)
+  auto commit_item = [&](int i, const UnitPos& up, const float (&af2)[4]) {
+    const int cp = (l_cr[i] >> 8) & 63;
     // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
     const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
     const float mk = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H ? 1.f : 0.f;   // (the row lies inside the image)
-    const float s0 = aff[c] * mk, s1c = aff[c + 1] * mk, h0 = aff[CB + c] * mk, h1 = aff[CB + c + 1] * mk;
+    const float s0 = af2[0] * mk, s1c = af2[1] * mk, h0 = af2[2] * mk, h1 = af2[3] * mk;
     if (l_cr[i] & 0x8000) {
       u32x4 ph, pm, pl;
 #pragma unroll
@@ -217,7 +219,11 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
         const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (the padding stays zero under an affine too)
         const float y0 = on ? fmaf(rb[i][0][e], s0, h0) : 0.f, y1 = on ? fmaf(rb[i][1][e], s1c, h1) : 0.f;
         unsigned a1, a2, a3;
+#ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
+        a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
+#else
         pgv_split3_pair(y0, y1, a1, a2, a3);
+#endif
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }
       *reinterpret_cast<u32x4*>(lds_x + dst) = ph;
@@ -227,9 +233,16 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   };
   auto vector_items = [&](int jc) {   // commit unit jc from the registers, re-issue them for unit jc + 1
     const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
+    float af2[G::QB][4];
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
-      commit_item(i, uc);
+      const int c = 2 * ((l_cr[i] >> 8) & 63);
+      af2[i][0] = aff[c], af2[i][1] = aff[c + 1], af2[i][2] = aff[CB + c], af2[i][3] = aff[CB + c + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      commit_item(i, uc, af2[i]);
+      if (i < 3) QSTAMP(jc - 1, 10 + i);
       issue_item(i, un);
     }
   };
@@ -587,17 +600,20 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     for (int c = 0; c < 8; ++c)
       rb[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(small_rs, (int)(o + (unsigned)(c * G::P * 4)), 0, 0));
   };
-  auto commit_item = [&](int i, const UnitPos& up) {
+  auto commit_item = [&](int i, const UnitPos& up, const f32x4 (&af4)[4]) {   // af4: scale[c .. c+7], shift[c .. c+7]
     if (l_gi[i] & 0x8000) {
-      const int c = 8 * (l_gi[i] >> 16);
       const float mk = (l_gi[i] & 0x7fff) < up.nvalid ? 1.f : 0.f;
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float y0 = fmaf(rb[i][2 * e], aff[c + 2 * e] * mk, aff[CS + c + 2 * e] * mk);
-        const float y1 = fmaf(rb[i][2 * e + 1], aff[c + 2 * e + 1] * mk, aff[CS + c + 2 * e + 1] * mk);
+        const float y0 = fmaf(rb[i][2 * e], af4[e >> 1][2 * (e & 1)] * mk, af4[2 + (e >> 1)][2 * (e & 1)] * mk);
+        const float y1 = fmaf(rb[i][2 * e + 1], af4[e >> 1][2 * (e & 1) + 1] * mk, af4[2 + (e >> 1)][2 * (e & 1) + 1] * mk);
         unsigned a1, a2, a3;
+#ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
+        a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
+#else
         pgv_split3_pair(y0, y1, a1, a2, a3);
+#endif
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }
       *reinterpret_cast<u32x4*>(lds_s + l_dst[i]) = ph;
@@ -607,9 +623,16 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   };
   auto vector_items = [&](int jc) {
     const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
+    f32x4 af4[G::QB][4];   // (read for all items before the first commit: see down_q_kernel)
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
-      commit_item(i, uc);
+      const int c = 8 * (l_gi[i] >> 16);
+      af4[i][0] = *reinterpret_cast<const f32x4*>(aff + c), af4[i][1] = *reinterpret_cast<const f32x4*>(aff + c + 4);
+      af4[i][2] = *reinterpret_cast<const f32x4*>(aff + CS + c), af4[i][3] = *reinterpret_cast<const f32x4*>(aff + CS + c + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < G::QB; ++i) {
+      commit_item(i, uc, af4[i]);
       issue_item(i, un);
     }
   };

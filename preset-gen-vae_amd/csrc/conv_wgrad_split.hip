@@ -122,9 +122,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
     sb[i][0] = buffer_load_x4(small_rs, o);
     sb[i][1] = buffer_load_x4(small_rs, o + 16u);
   };
-  auto commit_x = [&](int i, const UnitPos& up) {
+  auto commit_x = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
     const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
-    const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = aff_b[c] * mk, sh = aff_b[CB + c] * mk;
+    const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = a_sc * mk, sh = a_sh * mk;
     if (xl_cr[i] & 0x8000) {
       float y[8];
 #pragma unroll
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
       *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
     }
   };
-  auto commit_s = [&](int i, const UnitPos& up) {
+  auto commit_s = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
     const int c = sl_cr[i] >> 16, r = (sl_cr[i] >> 8) & 63, o = sl_cr[i] & 255;
-    const float mk = up.band * R + r < Hs ? 1.f : 0.f, sc = aff_s[c] * mk, sh = aff_s[CS + c] * mk;
+    const float mk = up.band * R + r < Hs ? 1.f : 0.f, sc = a_sc * mk, sh = a_sh * mk;
     if (sl_cr[i] & 0x8000) {
       u32x4 p1, p2, p3;
 #pragma unroll
@@ -170,14 +170,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   // commit unit jc from the registers, re-issue them for unit jc + 1
   auto vector_phase = [&](int jc) {
     const UnitPos uc = unit_pos(jc), un = unit_pos(jc + 1);
+    // (the items' affines are read from LDS before the first commit: read inside an item, the in-order lgkmcnt wait for them
+    // was also a wait for the previous item's image stores)
+    float axs[G::QX][2], ass[G::QS][2];
+#pragma unroll
+    for (int i = 0; i < G::QX; ++i) axs[i][0] = aff_b[xl_cr[i] >> 16], axs[i][1] = aff_b[CB + (xl_cr[i] >> 16)];
+#pragma unroll
+    for (int i = 0; i < G::QS; ++i) ass[i][0] = aff_s[sl_cr[i] >> 16], ass[i][1] = aff_s[CS + (sl_cr[i] >> 16)];
 #pragma unroll
     for (int i = 0; i < G::QX; ++i) {
-      commit_x(i, uc);
+      commit_x(i, uc, axs[i][0], axs[i][1]);
       issue_x(i, un);
     }
 #pragma unroll
     for (int i = 0; i < G::QS; ++i) {
-      commit_s(i, uc);
+      commit_s(i, uc, ass[i][0], ass[i][1]);
       issue_s(i, un);
     }
   };

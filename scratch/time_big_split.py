@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 import preset_gen_vae_amd  # noqa
+if os.environ.get('PGV_LIB'):
+    from preset_gen_vae_amd import _lib
+    _lib.LIB_PATH = os.environ['PGV_LIB']
 from preset_gen_vae_amd import ops
 
 B = int(os.environ.get('B', 256))
