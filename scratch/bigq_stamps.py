@@ -51,7 +51,7 @@ for Cb, Cs, Hb, Wb in ((8, 16, 129, 174), (16, 32, 65, 88), (32, 64, 33, 45)):
         for j in range(2, 8):
             r = s[team, j + 2]
             if r[0] == 0: continue
-            d = [int(r[k] - r[0]) for k in (10, 11, 12, 2, 4, 5, 6, 7, 8, 9)]
+            d = [int(r[k] - r[0]) if r[k] else -1 for k in (10, 11, 12, 2, 4, 5, 6, 7, 8, 9)]
             rows.append(d)
         names = ['item0', 'item1', 'item2', 'mfma', 'tile', 'bar', 'arrived', 'commit', 'out', 'bar']
         for d in rows[:4]:
