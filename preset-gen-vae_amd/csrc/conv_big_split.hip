@@ -28,6 +28,7 @@
 //     swizzled), a loader item = one pixel x 8 channels (coalesced 4-byte loads along the row) = one 16-byte store per plane;
 //   * outputs: a [channel][pixels] tile in LDS per K group of waves (waves that split K write a tile each; LDS float atomics
 //     into one tile cost 3.5 k clocks per unit), added up in a fixed order and moved out as contiguous 16-byte runs.
+#include <type_traits>
 #include "conv_tile.h"
 #include "conv_deep_common.h"
 
@@ -293,17 +294,22 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   for (int j = 0; j < J; ++j) {
     // ================= matrix phase =================
     QSTAMP(j, 0);   // (the loads of unit j + 1 are in flight)
-    {
-      f32x4 acc[MW][TMAX];
+    // TN = the pixel tiles this wave really has: TMAX, or one less for the last pixel groups when the band's tiles do not
+    // divide by NSPLIT (a wave-uniform choice between two complete loops - a branch on `tile < NT` INSIDE the unrolled loop
+    // made the compiler copy the accumulators from block to block, spilling; multiplying a clamped copy instead, as before,
+    // cost 1 / 12 of the matrix instructions of the 129x174 and 65x88 layers, and matrix time is not hidden by anything)
+    auto matrix_phase = [&](auto tn_c) {
+      constexpr int TN = decltype(tn_c)::value;
+      f32x4 acc[MW][TN];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TN; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       // steps (kh, g, group of TP tiles) in order; the fragments of step i + PD are requested before the products of step i
       // are issued.  A step multiplies MW x TP = 2 (M tile, pixel tile) pairs: two independent accumulation chains,
       // interleaved term by term, with the LDS reads pinned in front of them (sched_group_barrier: left to itself the
       // scheduler sinks the reads behind most of the previous step's instructions and the wave waits for LDS every step).
-      constexpr int TP = 2 / MW, TG = (TMAX + TP - 1) / TP;
+      constexpr int TP = 2 / MW, TG = (TN + TP - 1) / TP;
       constexpr int NSTEP = G::KHW * NG * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
       static_assert(MW == 1 || MW == 2, "two chains per step");
       u32x4 bf[PD + 1][TP][3];
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
         const int off = (g * 4 * CPS + kh * 3 * WPD) * 4;
 #pragma unroll
         for (int q = 0; q < TP; ++q) {
-          const int t = min(tg * TP + q, TMAX - 1);
+          const int t = min(tg * TP + q, TN - 1);
 #pragma unroll
           for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
         }
@@ -323,14 +329,12 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       for (int i = 0; i < NSTEP; ++i) {
         const int tg = i % TG, ks = i / TG;
         if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
-        // (no branch on `tile < NT` here: a wave with a tile short of TMAX multiplies a clamped copy that is never written -
-        // with the wave-uniform branch in the unrolled loop the accumulators were copied from block to block, spilling)
 #pragma unroll
         for (int term = 0; term < 6; ++term) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
-            if (t < TMAX) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
           }
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);   // the step's LDS reads ...
@@ -343,16 +347,21 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       if (FUSE) fetch_a(j);
       float* ot = otile + kg * G::O_SLICE;
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
+      for (int t = 0; t < TN; ++t) {
         const int n = (ng + G::NSPLIT * t) * 16 + m;
-        if (ng + G::NSPLIT * t < G::NT && n < NPX) {
+        if (n < NPX) {
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
             for (int i = 0; i < 4; ++i) ot[((mtl + mw) * 16 + 4 * kq + i) * OSTR + n] = acc[mw][t][i];
         }
       }
-    }
+    };
+    constexpr int NFULL = G::NT - G::NSPLIT * (TMAX - 1);   // pixel groups with TMAX tiles (the others have TMAX - 1)
+    if (NFULL == G::NSPLIT || ng < NFULL)
+      matrix_phase(std::integral_constant<int, TMAX>());
+    else
+      matrix_phase(std::integral_constant<int, (TMAX > 1 ? TMAX - 1 : 1)>());
     QSTAMP(j, 4);
     ws_sync();
     QSTAMP(j, 5);
@@ -682,14 +691,15 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   for (int j = 0; j < J; ++j) {
     // ================= matrix phase =================
     QSTAMP(j, 0);   // (the loads of unit j + 1 are in flight)
-    {
-      f32x4 acc[MW][TMAX];
+    auto matrix_phase = [&](auto tn_c) {   // (TN = the position tiles this wave really has: see down_q_kernel)
+      constexpr int TN = decltype(tn_c)::value;
+      f32x4 acc[MW][TN];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TN; ++t) acc[mw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       // (steps of two accumulation chains, reads pinned in front: see down_q_kernel)
-      constexpr int TP = 2 / MW, TG = (TMAX + TP - 1) / TP;
+      constexpr int TP = 2 / MW, TG = (TN + TP - 1) / TP;
       constexpr int NSTEP = G::KW * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
       static_assert(MW == 1 || MW == 2, "two chains per step");
       u32x4 bf[PD + 1][TP][3];
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
         const int tg = i % TG, g = kg * G::KW + i / TG;
 #pragma unroll
         for (int q = 0; q < TP; ++q) {
-          const int t = min(tg * TP + q, TMAX - 1);
+          const int t = min(tg * TP + q, TN - 1);
           const unsigned char* bp = lds_s + boff[t] + ((g ^ bsw[t]) * 16);
 #pragma unroll
           for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
-            if (t < TMAX) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
           }
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       if (FUSE) fetch_a(j);   // (requested only now: see down_q_kernel)
       float* ot = otile + kg * G::O_SLICE;   // (waves that split K write a tile each, added up in the move-out)
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
+      for (int t = 0; t < TN; ++t) {
 #pragma unroll
         for (int mw = 0; mw < MW; ++mw) {
           // (a position whose output column 2 v + pw lies outside the row is dropped; rows outside the plane are never moved out)
@@ -735,7 +745,12 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
           }
         }
       }
-    }
+    };
+    constexpr int NFULL = G::NT - G::NSPLIT * (TMAX - 1);
+    if (NFULL == G::NSPLIT || ng < NFULL)
+      matrix_phase(std::integral_constant<int, TMAX>());
+    else
+      matrix_phase(std::integral_constant<int, (TMAX > 1 ? TMAX - 1 : 1)>());
     QSTAMP(j, 4);
     ws_sync();
     QSTAMP(j, 5);
