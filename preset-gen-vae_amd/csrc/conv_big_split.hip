@@ -125,7 +125,6 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
 
-  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   for (int i = tid; i < CB; i += 512) {
     float sc = 1.f, sh = 0.f;
     if (in_bn.stats)
@@ -277,6 +276,8 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) issue_item(i, p0);
   }
+  // (the image is cleared behind the first unit's loads: their latency covers it)
+  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   __syncthreads();   // image zeroed, affine staged
   if (J > 0) vector_items(0);
   __syncthreads();
@@ -298,9 +299,14 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     // divide by NSPLIT (a wave-uniform choice between two complete loops - a branch on `tile < NT` INSIDE the unrolled loop
     // made the compiler copy the accumulators from block to block, spilling; multiplying a clamped copy instead, as before,
     // cost 1 / 12 of the matrix instructions of the 129x174 and 65x88 layers, and matrix time is not hidden by anything)
-    auto matrix_phase = [&](auto tn_c) {
+    auto matrix_phase = [&](auto tn_c) __attribute__((always_inline)) {
       constexpr int TN = decltype(tn_c)::value;
-      f32x4 acc[MW][TN];
+      if constexpr (TN == 0) {   // (a wave without a tile in a sample's last band)
+        QSTAMP(j, 2);
+        if (FUSE) fetch_a(j);
+        return;
+      }
+      f32x4 acc[MW][TN > 0 ? TN : 1];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
@@ -357,11 +363,26 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
         }
       }
     };
-    constexpr int NFULL = G::NT - G::NSPLIT * (TMAX - 1);   // pixel groups with TMAX tiles (the others have TMAX - 1)
-    if (NFULL == G::NSPLIT || ng < NFULL)
-      matrix_phase(std::integral_constant<int, TMAX>());
-    else
-      matrix_phase(std::integral_constant<int, (TMAX > 1 ? TMAX - 1 : 1)>());
+    // The NT tiles of a band are dealt over the NSPLIT pixel groups: a wave has C0 or C0 - 1 of them.  A sample's LAST band
+    // has VRL < R valid rows (1 at all three sizes): only its NTL tiles that hold valid pixels are multiplied.  (The four
+    // calls are written out: wrapped in a second generic lambda the same dispatch cost the 129x174 kernel 30 registers.)
+    constexpr int C0 = TMAX, NF0 = G::NT - G::NSPLIT * (C0 - 1);
+    constexpr int VRL = Hs - (G::BANDS - 1) * R, NTL = (VRL * Ws + 15) / 16;
+    constexpr int CL = (NTL + G::NSPLIT - 1) / G::NSPLIT, NFL = NTL - G::NSPLIT * (CL - 1);
+    // (not in the fused 129x174 and 33x45 kernels: the extra loop bodies make them spill 3 - 11 registers, for 2 - 4 % of
+    // their matrix instructions)
+    constexpr bool LAST_BAND_TILES = NTL < G::NT && !(FUSE && (MW == 1 || CS == 64));
+    if (LAST_BAND_TILES && (u0 + j * grid) % G::BANDS == G::BANDS - 1) {
+      if (NFL == G::NSPLIT || ng < NFL)
+        matrix_phase(std::integral_constant<int, CL>());
+      else
+        matrix_phase(std::integral_constant<int, CL - 1>());
+    } else {
+      if (NF0 == G::NSPLIT || ng < NF0)
+        matrix_phase(std::integral_constant<int, C0>());
+      else
+        matrix_phase(std::integral_constant<int, (C0 > 1 ? C0 - 1 : 1)>());
+    }
     QSTAMP(j, 4);
     ws_sync();
     QSTAMP(j, 5);
@@ -525,7 +546,6 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
 
-  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   for (int i = tid; i < CS; i += 512) {
     float sc = 1.f, sh = 0.f;
     if (in_bn.stats)
@@ -674,6 +694,8 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) issue_item(i, p0);
   }
+  // (the image is cleared behind the first unit's loads: their latency covers it)
+  for (int i = tid; i < (int)((G::STAGE + G::O_FLOATS * 4) / 16); i += 512) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
   __syncthreads();   // image zeroed, affine staged
   if (J > 0) vector_items(0);
   __syncthreads();
@@ -691,9 +713,14 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   for (int j = 0; j < J; ++j) {
     // ================= matrix phase =================
     QSTAMP(j, 0);   // (the loads of unit j + 1 are in flight)
-    auto matrix_phase = [&](auto tn_c) {   // (TN = the position tiles this wave really has: see down_q_kernel)
+    auto matrix_phase = [&](auto tn_c) __attribute__((always_inline)) {   // (TN = the position tiles this wave really has: see down_q_kernel)
       constexpr int TN = decltype(tn_c)::value;
-      f32x4 acc[MW][TN];
+      if constexpr (TN == 0) {
+        QSTAMP(j, 2);
+        if (FUSE) fetch_a(j);
+        return;
+      }
+      f32x4 acc[MW][TN > 0 ? TN : 1];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
@@ -746,11 +773,21 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
         }
       }
     };
-    constexpr int NFULL = G::NT - G::NSPLIT * (TMAX - 1);
-    if (NFULL == G::NSPLIT || ng < NFULL)
-      matrix_phase(std::integral_constant<int, TMAX>());
-    else
-      matrix_phase(std::integral_constant<int, (TMAX > 1 ? TMAX - 1 : 1)>());
+    // (tiles of this wave, a sample's last band: see down_q_kernel)
+    constexpr int C0 = TMAX, NF0 = G::NT - G::NSPLIT * (C0 - 1);
+    constexpr int VRL = G::HU - (G::BANDS - 1) * UB, NTL = (VRL * G::WU + 15) / 16;   // valid grid rows / tiles of the last band
+    constexpr int CL = (NTL + G::NSPLIT - 1) / G::NSPLIT, NFL = NTL - G::NSPLIT * (CL - 1);
+    if (NTL < G::NT && (u0 + j * grid) % G::BANDS == G::BANDS - 1) {
+      if (NFL == G::NSPLIT || ng < NFL)
+        matrix_phase(std::integral_constant<int, CL>());
+      else
+        matrix_phase(std::integral_constant<int, CL - 1>());
+    } else {
+      if (NF0 == G::NSPLIT || ng < NF0)
+        matrix_phase(std::integral_constant<int, C0>());
+      else
+        matrix_phase(std::integral_constant<int, (C0 > 1 ? C0 - 1 : 1)>());
+    }
     QSTAMP(j, 4);
     ws_sync();
     QSTAMP(j, 5);

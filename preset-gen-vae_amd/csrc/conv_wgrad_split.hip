@@ -19,6 +19,23 @@
 #include "conv_tile.h"
 #include "conv_deep_common.h"
 
+#ifdef PGV_BIGQ_STAMPS   // scratch builds only (scratch/wgq_stamps.py): clock64() of workgroup 0, wave 0
+static unsigned long long* g_wgq_stamps = nullptr;
+extern "C" void pgv_dbg_set_wgq_stamps(void* p) { g_wgq_stamps = (unsigned long long*)p; }
+#define WSTAMP_ARG , unsigned long long* __restrict__ stamps
+#define WSTAMP_PASS , g_wgq_stamps
+#define WSTAMP(k)                                                                                  \
+  do {                                                                                             \
+    if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && (k) < 64) stamps[k] = clock64();          \
+  } while (0)
+#else
+#define WSTAMP_ARG
+#define WSTAMP_PASS
+#define WSTAMP(k) \
+  do {            \
+  } while (0)
+#endif
+
 namespace {
 
 typedef unsigned short u16;
@@ -57,7 +74,7 @@ template <class G, bool BIG_AFF, bool SMALL_AFF>
 __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const float* __restrict__ big, const float* __restrict__ big_scale,
                                                               const float* __restrict__ big_shift, const float* __restrict__ small_in,
                                                               const float* __restrict__ small_scale,
-                                                              const float* __restrict__ small_shift, float* __restrict__ partial) {
+                                                              const float* __restrict__ small_shift, float* __restrict__ partial WSTAMP_ARG) {
   constexpr int CB = G::CB, CS = G::CS, W = G::W, H = G::H, R = G::R, Ws = G::Ws, Hs = G::Hs, MT = G::MT, CTW = G::CTW;
   constexpr int SCH = G::SCH, XCH = G::XCH, XPL = G::XPL, SROW = G::SROW, XROW = G::XROW, GPR = G::GPR, KSW = G::KSW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -69,15 +86,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave & 1, nq = (wave >> 1) % G::NQ, kw0 = (wave >> 1) / G::NQ;   // kernel-column half, column group, K way
 
-  for (int i = tid; i < (int)(G::IMG_BYTES / 16); i += 512) reinterpret_cast<u32x4*>(lds_raw)[i] = u32x4{0, 0, 0, 0};
-  for (int i = tid; i < CB; i += 512) {
-    aff_b[i] = BIG_AFF ? big_scale[i] : 1.f;
-    aff_b[CB + i] = BIG_AFF ? big_shift[i] : 0.f;
-  }
-  for (int i = tid; i < CS; i += 512) {
-    aff_s[i] = SMALL_AFF ? small_scale[i] : 1.f;
-    aff_s[CS + i] = SMALL_AFF ? small_shift[i] : 0.f;
-  }
+  WSTAMP(0);
   // ---- loader items.  X: (channel, band row, 8 columns) -> 4 even + 4 odd columns = 8 bytes per parity and plane;
   // S: (channel, band row, 8 pixels) = 16 bytes per plane
   int xl_src[G::QX], xl_cr[G::QX], sl_src[G::QS], sl_cr[G::QS];
@@ -213,16 +222,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
 #pragma unroll
     for (int i = 0; i < G::QS; ++i) issue_s(i, u0p);
   }
+  // (the images are cleared and the affines staged behind the first unit's loads: their latency covers it)
+  for (int i = tid; i < (int)(G::IMG_BYTES / 16); i += 512) reinterpret_cast<u32x4*>(lds_raw)[i] = u32x4{0, 0, 0, 0};
+  for (int i = tid; i < CB; i += 512) {
+    aff_b[i] = BIG_AFF ? big_scale[i] : 1.f;
+    aff_b[CB + i] = BIG_AFF ? big_shift[i] : 0.f;
+  }
+  for (int i = tid; i < CS; i += 512) {
+    aff_s[i] = SMALL_AFF ? small_scale[i] : 1.f;
+    aff_s[CS + i] = SMALL_AFF ? small_shift[i] : 0.f;
+  }
   __syncthreads();
   if (J > 0) vector_phase(0);
   __syncthreads();
 
+  WSTAMP(1);
 #pragma unroll 1
   for (int j = 0; j < J; ++j) {
+    WSTAMP(2 + 3 * j);
     // ================= matrix phase ================= (the loads of unit j + 1 are in flight)
+    // K steps whose four pixel groups all lie in rows beyond the plane (a sample's last band: 1 valid row of R at all three
+    // sizes) are skipped - 2 of 3 steps of such a unit on 33x45, where they were 13 % of the kernel's matrix instructions
+    const int nvalid_groups = min(R, Hs - (min(u0 + j * grid, units - 1) % G::BANDS) * R) * GPR;
 #pragma unroll
     for (int k = 0; k < KSW; ++k) {
-      {   // (a K way with a step less multiplies the zero padding: no wave-uniform branch around the accumulators)
+      if (k == 0 || 4 * (kw0 + G::KWAYS * k) < nvalid_groups) {   // (wave-uniform; the steps of a wave are in row order)
         u32x4 a[MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -250,11 +274,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
         }
       }
     }
+    WSTAMP(3 + 3 * j);
     ws_sync();
+    WSTAMP(4 + 3 * j);
     // ================= vector phase =================
     if (j + 1 < J) vector_phase(j + 1);
     ws_sync();
   }
+  WSTAMP(60);
 
   // ---- the K ways of a tile are added up through LDS (the images are dead), then this workgroup's partial gradient, layout
   // of gw: D row (lane >> 4) * 4 + reg = cs within the M tile, column n = (channel of the pair, kernel row, parity)
@@ -291,6 +318,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
         }
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WSTAMP(61);
 }
 
 template <class G>
@@ -302,7 +331,7 @@ int launch_wgq(const pgv_conv_desc* d, const float* big, const float* big_scale,
   if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || (int64_t)d->B * d->Cs * G::Hs * G::Ws * 4 >= (int64_t)1 << 31) return 0;
   const int units = d->B * G::BANDS, grid = min(units, 256);
   if ((int64_t)grid * G::CS * G::CB * 16 * (int64_t)sizeof(float) > partial_bytes) return 0;
-  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
+  typedef void (*kern_t)(int, const float*, const float*, const float*, const float*, const float*, const float*, float* WSTAMP_ARG);
   kern_t kern = big_scale ? (kern_t)conv_wgrad_split_kernel<G, true, false>
                           : (small_scale ? (kern_t)conv_wgrad_split_kernel<G, false, true>
                                          : (kern_t)conv_wgrad_split_kernel<G, false, false>);
@@ -317,7 +346,7 @@ int launch_wgq(const pgv_conv_desc* d, const float* big, const float* big_scale,
   }
   *nparts = grid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, d->B, big, big_scale, big_shift, small_in, small_scale, small_shift,
-                     partial);
+                     partial WSTAMP_PASS);
   PGV_CHECK_LAUNCH("conv_wgrad_split");
   return 1;
 }
