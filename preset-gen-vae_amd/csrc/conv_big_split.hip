@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
+  const pgv_split_sel sel = pgv_split_sel_make();
 
   for (int i = tid; i < CB; i += 512) {
     float sc = 1.f, sh = 0.f;
@@ -154,12 +155,13 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     blo[t] = (kq * CPS + (2 * ohl + kg * G::KHW) * 3 * WPD + 2 * ow + 2) * 4;
   }
   // ---- loader items: (channel pair, band row, quad of 4 columns)
-  int l_src[G::QB], l_cr[G::QB];
+  int l_src[G::QB], l_cr[G::QB], l_row[G::QB];
 #pragma unroll
   for (int i = 0; i < G::QB; ++i) {
     const int q = min(tid + 512 * i, G::ITEMS - 1);
     const int cp = q / (G::XR * G::QX), rem = q - cp * (G::XR * G::QX), r = rem / G::QX, qi = rem - r * G::QX;
     l_src[i] = (2 * cp) * (H * W) + 4 * qi;                       // + sample * CB * H * W + image row * W
+    l_row[i] = r * W;                                             // (the item's row within the band, in floats)
     l_cr[i] = (cp << 8) | r | ((tid + 512 * i < G::ITEMS) ? 0x8000 : 0) | ((4 * qi + 4 > W) ? 0x4000 : 0);   // (0x4000: ragged row end)
   }
   // ---- move-out role: LPC lanes per channel
@@ -198,11 +200,13 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     return UnitPos{(unsigned)b * (unsigned)(CB * H * W), j < J ? 0u : 0x80000000u, 2 * band * R - 2};
   };
   auto issue_item = [&](int i, const UnitPos& up) {
-    const int ih = up.ih0 + (l_cr[i] & 255);
-    const unsigned o = (up.sample + (unsigned)(l_src[i] + ((unsigned)ih < (unsigned)H ? ih : 0) * W)) * 4u;
-    // (a quad at the ragged end of a row reads on into the next row: masked at the commit)
-    rb[i][0] = buffer_load_x4(big_rs, o | up.kill);
-    rb[i][1] = buffer_load_x4(big_rs, (o + (unsigned)(H * W * 4)) | up.kill);
+    // (row offset = scalar band part + the item's constant: no vector multiply; a row outside the image reads outside the
+    // buffer like a unit beyond the last one; a quad at the ragged end of a row reads on into the next row - masked at the
+    // commit)
+    const unsigned rk = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H ? up.kill : 0x80000000u;
+    const unsigned o = (up.sample + (unsigned)(l_src[i] + l_row[i] + up.ih0 * W)) * 4u;
+    rb[i][0] = buffer_load_x4(big_rs, o | rk);
+    rb[i][1] = buffer_load_x4(big_rs, (o + (unsigned)(H * W * 4)) | rk);
   };
   // (the affine of an item's channel pair is read from LDS for ALL items before the first one is committed: read inside
   // the item, the wait for it - lgkmcnt counts in order - was also a wait for the previous item's three image stores)
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
         a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
 #else
-        pgv_split3_pair(y0, y1, a1, a2, a3);
+        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
 #endif
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtl = (wave % G::MG) * MW, kg = (wave / G::MG) % G::KSPLIT, ng = wave / (G::MG * G::KSPLIT);
+  const pgv_split_sel sel = pgv_split_sel_make();
 
   for (int i = tid; i < CS; i += 512) {
     float sc = 1.f, sh = 0.f;
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
         a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
 #else
-        pgv_split3_pair(y0, y1, a1, a2, a3);
+        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
 #endif
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }

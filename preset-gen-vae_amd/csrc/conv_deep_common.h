@@ -44,17 +44,27 @@ __device__ __forceinline__ unsigned pgv_pack_bf16x2(float a, float b) {
 // unpacked term for every finite input below 2^127.99, scratch/ubench/dot2_residual.hip), instead of a shift / mask that
 // moves the half to the top of a dword plus a subtraction.  The selectors live in scalar registers: written as literals the
 // packed {-1.0, 0} becomes the inline constant "-1.0", which the hardware reads as the fp32 pattern, i.e. as {0, -1.0}.
-__device__ __forceinline__ void pgv_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+struct pgv_split_sel {
+  unsigned lo, hi;   // packed bf16 {-1, 0} and {0, -1}, in scalar registers
+};
+__device__ __forceinline__ pgv_split_sel pgv_split_sel_make() {
   unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
   asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
-  const bf2 lo1 = __builtin_bit_cast(bf2, sel_lo), hi1 = __builtin_bit_cast(bf2, sel_hi);
+  return pgv_split_sel{sel_lo, sel_hi};
+}
+// (sel: made ONCE per kernel - made inside, every call costs two s_mov)
+__device__ __forceinline__ void pgv_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L, const pgv_split_sel& sel) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 lo1 = __builtin_bit_cast(bf2, sel.lo), hi1 = __builtin_bit_cast(bf2, sel.hi);
   H = pgv_pack_bf16x2(a, b);
   const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, H), lo1, a, false);
   const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, H), hi1, b, false);
   M = pgv_pack_bf16x2(ra, rb);
   L = pgv_pack_bf16x2(__builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, M), lo1, ra, false),
                       __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, M), hi1, rb, false));
+}
+__device__ __forceinline__ void pgv_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+  pgv_split3_pair(a, b, H, M, L, pgv_split_sel_make());
 }
 
 // Split weight shadow of a deep k4 s2 p2 layer, DOWN layout = the fragment order of deep_down_split_kernel: the 16 bytes

@@ -85,21 +85,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave & 1, nq = (wave >> 1) % G::NQ, kw0 = (wave >> 1) / G::NQ;   // kernel-column half, column group, K way
+  const pgv_split_sel sel = pgv_split_sel_make();
 
   WSTAMP(0);
   // ---- loader items.  X: (channel, band row, 8 columns) -> 4 even + 4 odd columns = 8 bytes per parity and plane;
   // S: (channel, band row, 8 pixels) = 16 bytes per plane
-  int xl_src[G::QX], xl_cr[G::QX], sl_src[G::QS], sl_cr[G::QS];
+  int xl_src[G::QX], xl_cr[G::QX], xl_row[G::QX], sl_src[G::QS], sl_cr[G::QS], sl_row[G::QS];
 #pragma unroll
   for (int i = 0; i < G::QX; ++i) {
     const int q = min(tid + 512 * i, G::X_ITEMS - 1), c = q / (G::XR * G::OX), rem = q - c * (G::XR * G::OX), r = rem / G::OX, o = rem - r * G::OX;
     xl_src[i] = c * (H * W) + 8 * o;                    // + sample * CB * H * W + image row * W
+    xl_row[i] = r * W;
     xl_cr[i] = (c << 16) | (r << 8) | o | ((tid + 512 * i < G::X_ITEMS) ? 0x8000 : 0);
   }
 #pragma unroll
   for (int i = 0; i < G::QS; ++i) {
     const int q = min(tid + 512 * i, G::S_ITEMS - 1), c = q / (R * GPR), rem = q - c * (R * GPR), r = rem / GPR, o = rem - r * GPR;
     sl_src[i] = c * (Hs * Ws) + 8 * o;                  // + sample * CS * Hs * Ws + output row * Ws
+    sl_row[i] = r * Ws;
     sl_cr[i] = (c << 16) | (r << 8) | o | ((tid + 512 * i < G::S_ITEMS) ? 0x8000 : 0);
   }
   const int grid = (int)gridDim.x, u0 = pgv_xcd_block(), units = B * G::BANDS;
@@ -119,15 +122,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
     return UnitPos{(unsigned)b * (unsigned)(CB * H * W), (unsigned)b * (unsigned)(CS * Hs * Ws), j < J ? 0u : 0x80000000u, u - b * G::BANDS};
   };
   auto issue_x = [&](int i, const UnitPos& up) {
-    const int ih = 2 * up.band * R - 2 + ((xl_cr[i] >> 8) & 63);
-    const bool in = (unsigned)ih < (unsigned)H;
-    const unsigned o = ((up.xs + (unsigned)(xl_src[i] + (in ? ih : 0) * W)) * 4u) | up.kill;
+    // (row offset = scalar band part + the item's constant; a row outside the plane reads outside the buffer)
+    const int ih0 = 2 * up.band * R - 2;
+    const unsigned rk = (unsigned)(ih0 + ((xl_cr[i] >> 8) & 63)) < (unsigned)H ? up.kill : 0x80000000u;
+    const unsigned o = ((up.xs + (unsigned)(xl_src[i] + xl_row[i] + ih0 * W)) * 4u) | rk;
     xb[i][0] = buffer_load_x4(big_rs, o);        // (columns beyond the row: masked at the commit)
     xb[i][1] = buffer_load_x4(big_rs, o + 16u);
   };
   auto issue_s = [&](int i, const UnitPos& up) {
-    const int oh = up.band * R + ((sl_cr[i] >> 8) & 63);
-    const unsigned o = ((up.ss + (unsigned)(sl_src[i] + (oh < Hs ? oh : 0) * Ws)) * 4u) | up.kill;
+    const unsigned rk = up.band * R + ((sl_cr[i] >> 8) & 63) < Hs ? up.kill : 0x80000000u;
+    const unsigned o = ((up.ss + (unsigned)(sl_src[i] + sl_row[i] + up.band * (R * Ws))) * 4u) | rk;
     sb[i][0] = buffer_load_x4(small_rs, o);
     sb[i][1] = buffer_load_x4(small_rs, o + 16u);
   };
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
       unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k]);       // even columns 8o + 4k, + 2
-        pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k]);   // odd columns
+        pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k], sel);       // even columns 8o + 4k, + 2
+        pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k], sel);   // odd columns
       }
       u16* dst = x_img + c * XCH + r * XROW + 4 * o;
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
         const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
         const float y0 = 8 * o + 2 * k < Ws ? fmaf(v0, sc, sh) : 0.f, y1 = 8 * o + 2 * k + 1 < Ws ? fmaf(v1, sc, sh) : 0.f;
         unsigned a1, a2, a3;
-        pgv_split3_pair(y0, y1, a1, a2, a3);
+        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
         p1[k] = a1, p2[k] = a2, p3[k] = a3;
       }
       u16* dst = s_img + c * SCH + r * SROW + 8 * o;
