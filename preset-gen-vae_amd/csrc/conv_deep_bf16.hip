@@ -1089,6 +1089,7 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
   constexpr int H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, WP = G::WP, STEPS = G::STEPS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const pgv_split_sel sel = pgv_split_sel_make();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mh = wave & 1, nq = wave >> 1;
   const int NB = CB / 8, ncombo = (CS / 64) * nsplit;
   int combo, nb;
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned a, b, c;
-        pgv_split3_pair(v[2 * j], v[2 * j + 1], a, b, c);
+        pgv_split3_pair(v[2 * j], v[2 * j + 1], a, b, c, sel);
         ph[j] = a, pm[j] = b, pl[j] = c;
       }
       *reinterpret_cast<u32x4*>(dst) = ph;

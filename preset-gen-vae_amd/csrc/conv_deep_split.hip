@@ -49,6 +49,7 @@ __global__ __launch_bounds__(512) void deep_down_split_kernel(int B, int CB, int
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   float* aff = reinterpret_cast<float*>(ldsb + G::WORK);   // [2*CB]
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const pgv_split_sel sel = pgv_split_sel_make();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = wave >> 2, kh = wave & 3;
   int mb, grp;
   deep_block(CS / 64, groups, mb, grp);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void deep_down_split_kernel(int B, int CB, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned ph, pm, pl;
-          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl, sel);
           *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
           *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
           *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(512) void deep_up_split_kernel(int B, int CB, int C
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   float* aff = reinterpret_cast<float*>(ldsb + G::WORK);   // [2*CS]
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const pgv_split_sel sel = pgv_split_sel_make();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // phases 0..3 have decreasing pixel counts: the two waves of a SIMD (w, w + 4) take phases p and 3 - p
   const int ph = wave < 4 ? wave : 7 - wave, half = wave >> 2;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(512) void deep_up_split_kernel(int B, int CB, int C
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned ph, pm, pl;
-          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl, sel);
           *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
           *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
           *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(512) void k1_fwd_split_kernel(int B, int M, int K, 
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   float* aff = reinterpret_cast<float*>(ldsb + 2 * G::STAGE);   // [2*K]
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const pgv_split_sel sel = pgv_split_sel_make();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int mb, grp;
   deep_block(M / MT, groups, mb, grp);
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(512) void k1_fwd_split_kernel(int B, int M, int K, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned ph, pm, pl;
-          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl);
+          pgv_split3_pair(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1, h1), ph, pm, pl, sel);
           *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = ph;
           *reinterpret_cast<unsigned*>(st + G::IMG + b_dst[i][e]) = pm;
           *reinterpret_cast<unsigned*>(st + 2 * G::IMG + b_dst[i][e]) = pl;
