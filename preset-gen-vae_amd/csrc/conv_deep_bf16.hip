@@ -1305,7 +1305,10 @@ __global__ __launch_bounds__(512) void deep_wgrad8_bf16_kernel(int B, int CB, in
         if (u + 2 < u1) issue(u + 2, rn);
       }
     }
-    __syncthreads();
+    // (LDS traffic complete + barrier, WITHOUT the vector-memory wait of __syncthreads(): the loads of unit u + 2, issued
+    // half a unit ago, stay in flight until wait_set() of the next unit asks for them - with the wait here every unit
+    // exposed their latency)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 #pragma unroll 1
   for (int u = u0; u < u1; ++u) unit_step(u, r0);
