@@ -214,14 +214,17 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     const int cp = (l_cr[i] >> 8) & 63;
     // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
     const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
-    const float mk = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H ? 1.f : 0.f;   // (the row lies inside the image)
-    const float s0 = af2[0] * mk, s1c = af2[1] * mk, h0 = af2[2] * mk, h1 = af2[3] * mk;
+    // (a row outside the image arrived as zeros: only the SHIFT has to vanish there - the padding stays zero under an
+    // affine too.  FUSE = an input-gradient call: no affine at all, the launcher refuses one)
+    const bool in = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H;
+    const float s0 = af2[0], s1c = af2[1], h0 = in ? af2[2] : 0.f, h1 = in ? af2[3] : 0.f;
     if (l_cr[i] & 0x8000) {
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (the padding stays zero under an affine too)
-        const float y0 = on ? fmaf(rb[i][0][e], s0, h0) : 0.f, y1 = on ? fmaf(rb[i][1][e], s1c, h1) : 0.f;
+        const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (a quad at the ragged end of a row)
+        const float x0 = rb[i][0][e], x1 = rb[i][1][e];
+        const float y0 = on ? (FUSE ? x0 : fmaf(x0, s0, h0)) : 0.f, y1 = on ? (FUSE ? x1 : fmaf(x1, s1c, h1)) : 0.f;
         unsigned a1, a2, a3;
 #ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
         a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       const int c = 2 * ((l_cr[i] >> 8) & 63);
-      af2[i][0] = aff[c], af2[i][1] = aff[c + 1], af2[i][2] = aff[CB + c], af2[i][3] = aff[CB + c + 1];
+      if (!FUSE) af2[i][0] = aff[c], af2[i][1] = aff[c + 1], af2[i][2] = aff[CB + c], af2[i][3] = aff[CB + c + 1];
     }
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
@@ -487,7 +490,7 @@ template <class G>
 int launch_down_q(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift, const float* bias,
                   int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse, hipStream_t st,
                   const pgv_bn_src* bn) {
-  if (fuse && (stats || bias)) return 0;
+  if (fuse && (stats || bias || in_scale || (bn && bn->stats))) return 0;   // (the fused form multiplies a gradient: no input affine)
   if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || d->B <= 0) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const u32x4*, const float*, int, float, float*, double*,
                          int, pgv_bn_src, pgv_bwd_fuse QSTAMP_ARG);
@@ -636,12 +639,14 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   };
   auto commit_item = [&](int i, const UnitPos& up, const f32x4 (&af4)[4]) {   // af4: scale[c .. c+7], shift[c .. c+7]
     if (l_gi[i] & 0x8000) {
+      // (a pixel outside the plane arrived as zeros: only the shift has to vanish there; FUSE: no affine, see down_q_kernel)
       const float mk = (l_gi[i] & 0x7fff) < up.nvalid ? 1.f : 0.f;
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float y0 = fmaf(rb[i][2 * e], af4[e >> 1][2 * (e & 1)] * mk, af4[2 + (e >> 1)][2 * (e & 1)] * mk);
-        const float y1 = fmaf(rb[i][2 * e + 1], af4[e >> 1][2 * (e & 1) + 1] * mk, af4[2 + (e >> 1)][2 * (e & 1) + 1] * mk);
+        const float y0 = FUSE ? rb[i][2 * e] : fmaf(rb[i][2 * e], af4[e >> 1][2 * (e & 1)], af4[2 + (e >> 1)][2 * (e & 1)] * mk);
+        const float y1 = FUSE ? rb[i][2 * e + 1]
+                              : fmaf(rb[i][2 * e + 1], af4[e >> 1][2 * (e & 1) + 1], af4[2 + (e >> 1)][2 * (e & 1) + 1] * mk);
         unsigned a1, a2, a3;
 #ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
         a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
@@ -661,8 +666,10 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
       const int c = 8 * (l_gi[i] >> 16);
-      af4[i][0] = *reinterpret_cast<const f32x4*>(aff + c), af4[i][1] = *reinterpret_cast<const f32x4*>(aff + c + 4);
-      af4[i][2] = *reinterpret_cast<const f32x4*>(aff + CS + c), af4[i][3] = *reinterpret_cast<const f32x4*>(aff + CS + c + 4);
+      if (!FUSE) {
+        af4[i][0] = *reinterpret_cast<const f32x4*>(aff + c), af4[i][1] = *reinterpret_cast<const f32x4*>(aff + c + 4);
+        af4[i][2] = *reinterpret_cast<const f32x4*>(aff + CS + c), af4[i][3] = *reinterpret_cast<const f32x4*>(aff + CS + c + 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < G::QB; ++i) {
@@ -868,7 +875,8 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 template <class G>
 int launch_up_q(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift, const float* bias,
                 int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn) {
-  if (fuse && (fuse->cls || stats || bias)) return 0;   // (class sums of a big-tensor result: the band kernels keep those calls)
+  // (class sums of a big-tensor result: the band kernels keep those calls; the fused form has no input affine)
+  if (fuse && (fuse->cls || stats || bias || in_scale || (bn && bn->stats))) return 0;
   if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || d->B <= 0) return 0;
   typedef void (*kern_t)(int, const float*, const float*, const float*, const u32x4*, const float*, int, float, float*, double*,
                          int, pgv_bn_src, pgv_bwd_fuse QSTAMP_ARG);

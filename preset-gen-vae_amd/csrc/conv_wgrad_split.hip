@@ -137,13 +137,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   };
   auto commit_x = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
     const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
-    const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = a_sc * mk, sh = a_sh * mk;
+    const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = a_sc, sh = a_sh * mk;
     if (xl_cr[i] & 0x8000) {
       float y[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = e < 4 ? xb[i][0][e] : xb[i][1][e - 4];
-        y[e] = 8 * o + e < W ? fmaf(v, sc, sh) : 0.f;   // (columns beyond the row stay zero under an affine too)
+        // (columns beyond the row stay zero under an affine too; an operand without an affine is taken as it arrived -
+        // rows outside the plane arrived as zeros)
+        y[e] = 8 * o + e < W ? (BIG_AFF ? fmaf(v, sc, sh) : v) : 0.f;
       }
       unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
 #pragma unroll
@@ -163,13 +165,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   };
   auto commit_s = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
     const int c = sl_cr[i] >> 16, r = (sl_cr[i] >> 8) & 63, o = sl_cr[i] & 255;
-    const float mk = up.band * R + r < Hs ? 1.f : 0.f, sc = a_sc * mk, sh = a_sh * mk;
+    const float mk = up.band * R + r < Hs ? 1.f : 0.f, sc = a_sc, sh = a_sh * mk;
     if (sl_cr[i] & 0x8000) {
       u32x4 p1, p2, p3;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
-        const float y0 = 8 * o + 2 * k < Ws ? fmaf(v0, sc, sh) : 0.f, y1 = 8 * o + 2 * k + 1 < Ws ? fmaf(v1, sc, sh) : 0.f;
+        const float y0 = 8 * o + 2 * k < Ws ? (SMALL_AFF ? fmaf(v0, sc, sh) : v0) : 0.f;
+        const float y1 = 8 * o + 2 * k + 1 < Ws ? (SMALL_AFF ? fmaf(v1, sc, sh) : v1) : 0.f;
         unsigned a1, a2, a3;
         pgv_split3_pair(y0, y1, a1, a2, a3, sel);
         p1[k] = a1, p2[k] = a2, p3[k] = a3;
