@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   // (buffer loads, a lane without an element reads outside the buffer: every lane issues them, so the compiler's counter
   // model counts them exactly and the waits for the band loads issued before them do not wait for these)
   const __amdgpu_buffer_rsrc_t a_rs = tensor_rsrc(FUSE ? fuse.a : nullptr, FUSE ? (int64_t)B * CS * G::P * 4 : 0);
+  const __amdgpu_buffer_rsrc_t out_rs = tensor_rsrc(out, (int64_t)B * CS * G::P * 4);
   auto fetch_a = [&](int j) {
     int nfl;
     size_t goff;
@@ -406,27 +407,34 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       float* o_p = out + goff;
       const float* t_p = otile + och * OSTR;
       const int tail0 = nfl & ~3;
+      // (every lane reads all of its quads - a lane without one reads a clamped quad and stores outside the buffer - so the
+      // LDS reads of all quads are in flight together instead of one exec-masked block after the other)
+      f32x4 v[QO];
+#pragma unroll
+      for (int i = 0; i < QO; ++i) v[i] = *reinterpret_cast<const f32x4*>(t_p + 4 * min(part + LPC * i, OSTR / 4 - 1));
+#pragma unroll
+      for (int k = 1; k < G::KSPLIT; ++k)   // (fixed order)
+#pragma unroll
+        for (int i = 0; i < QO; ++i) v[i] += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * min(part + LPC * i, OSTR / 4 - 1));
 #pragma unroll
       for (int i = 0; i < QO; ++i) {
         const int q4 = part + LPC * i;
-        if (4 * q4 + 4 <= nfl) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
+        const bool on = 4 * q4 + 4 <= nfl;
+        const float onf = on ? 1.f : 0.f;
+        if (FUSE) {
 #pragma unroll
-          for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * q4);   // (fixed order)
-          if (FUSE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-              slot[i][e] += v[e];
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pgv_act_apply(v[e] + bv, ap);
-            s[0] += (v[0] + v[1]) + (v[2] + v[3]);
-            s[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          for (int e = 0; e < 4; ++e) {
+            v[i][e] = pgv_bwd_apply(v[i][e], av[i][e], ka, kb, kc, actd);
+            slot[i][e] = fmaf(v[i][e], onf, slot[i][e]);
           }
-          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = pgv_act_apply(v[i][e] + bv, ap);
+          s[0] = fmaf((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]), onf, s[0]);
+          s[1] = fmaf((v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]), onf, s[1]);
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), out_rs,
+                                               (int)(((unsigned)goff * 4u + 16u * (unsigned)q4) | (on ? 0u : 0x80000000u)), 0, 0);
       }
       if (part < nfl - tail0) {
         const int idx = tail0 + part;
@@ -687,6 +695,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
   // (buffer loads, a lane without an element reads outside the buffer: every lane issues them, so the compiler's counter
   // model counts them exactly and the waits for the band loads issued before them do not wait for these)
   const __amdgpu_buffer_rsrc_t a_rs = tensor_rsrc(FUSE ? fuse.a : nullptr, FUSE ? (int64_t)B * CB * (H * W) * 4 : 0);
+  const __amdgpu_buffer_rsrc_t out_rs = tensor_rsrc(out, (int64_t)B * CB * (H * W) * 4);
   auto fetch_a = [&](int j) {
     int nfl;
     size_t goff;
@@ -814,25 +823,33 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       float* o_p = out + goff;
       const float* t_p = otile + och * OCH;
       const int tail0 = nfl & ~3;
+      f32x4 v[QO];   // (all quads read before the first is processed: see down_q_kernel)
+#pragma unroll
+      for (int i = 0; i < QO; ++i) v[i] = *reinterpret_cast<const f32x4*>(t_p + 4 * min(part + LPC * i, G::O4 - 1));
+#pragma unroll
+      for (int k = 1; k < G::KSPLIT; ++k)   // (fixed order)
+#pragma unroll
+        for (int i = 0; i < QO; ++i) v[i] += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * min(part + LPC * i, G::O4 - 1));
 #pragma unroll
       for (int i = 0; i < QO; ++i) {
         const int q4 = part + LPC * i;
-        if (4 * q4 + 4 <= nfl) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
+        const bool on = 4 * q4 + 4 <= nfl;
+        const float onf = on ? 1.f : 0.f;
+        float q1 = 0.f, q2 = 0.f;
 #pragma unroll
-          for (int k = 1; k < G::KSPLIT; ++k) v += *reinterpret_cast<const f32x4*>(t_p + k * G::O_SLICE + 4 * q4);   // (fixed order)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (FUSE) {
-              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-            } else {
-              v[e] = pgv_act_apply(v[e] + bv, ap);
-              s2 += v[e] * v[e];
-            }
-            s1 += v[e];
+        for (int e = 0; e < 4; ++e) {
+          if (FUSE) {
+            v[i][e] = pgv_bwd_apply(v[i][e], av[i][e], ka, kb, kc, actd);
+          } else {
+            v[i][e] = pgv_act_apply(v[i][e] + bv, ap);
+            q2 += v[i][e] * v[i][e];
           }
-          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
+          q1 += v[i][e];
         }
+        s1 = fmaf(q1, onf, s1);
+        if (!FUSE) s2 = fmaf(q2, onf, s2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), out_rs,
+                                               (int)(((unsigned)goff * 4u + 16u * (unsigned)q4) | (on ? 0u : 0x80000000u)), 0, 0);
       }
       if (part < nfl - tail0) {   // (a last band of an odd number of odd-width rows)
         const int idx = tail0 + part;
