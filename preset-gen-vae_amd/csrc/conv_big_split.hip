@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     // affine too.  FUSE = an input-gradient call: no affine at all, the launcher refuses one)
     const bool in = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H;
     const float s0 = af2[0], s1c = af2[1], h0 = in ? af2[2] : 0.f, h1 = in ? af2[3] : 0.f;
-    if (l_cr[i] & 0x8000) {
+    if (l_cr[i] & 0x8000) {   // (kept under the lane mask for full slots too: without it the 129x174 / 65x88 kernels lost 1 - 2 us)
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -312,9 +312,8 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       if constexpr (TN == 0) {   // (a wave without a tile in a sample's last band)
         QSTAMP(j, 2);
         if (FUSE) fetch_a(j);
-        return;
-      }
-      f32x4 acc[MW][TN > 0 ? TN : 1];
+      } else {
+      f32x4 acc[MW][TN];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
@@ -370,6 +369,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
             for (int i = 0; i < 4; ++i) ot[((mtl + mw) * 16 + 4 * kq + i) * OSTR + n] = acc[mw][t][i];
         }
       }
+      }   // (TN > 0)
     };
     // The NT tiles of a band are dealt over the NSPLIT pixel groups: a wave has C0 or C0 - 1 of them.  A sample's LAST band
     // has VRL < R valid rows (1 at all three sizes): only its NTL tiles that hold valid pixels are multiplied.  (The four
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       rb[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(small_rs, (int)(o + (unsigned)(c * G::P * 4)), 0, 0));
   };
   auto commit_item = [&](int i, const UnitPos& up, const f32x4 (&af4)[4]) {   // af4: scale[c .. c+7], shift[c .. c+7]
-    if (l_gi[i] & 0x8000) {
+    if (512 * (i + 1) <= G::ITEMS || (l_gi[i] & 0x8000)) {   // (a full slot of items needs no lane mask)
       // (a pixel outside the plane arrived as zeros: only the shift has to vanish there; FUSE: no affine, see down_q_kernel)
       const float mk = (l_gi[i] & 0x7fff) < up.nvalid ? 1.f : 0.f;
       u32x4 ph, pm, pl;
@@ -739,9 +739,8 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       if constexpr (TN == 0) {
         QSTAMP(j, 2);
         if (FUSE) fetch_a(j);
-        return;
-      }
-      f32x4 acc[MW][TN > 0 ? TN : 1];
+      } else {
+      f32x4 acc[MW][TN];
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
@@ -793,6 +792,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
           }
         }
       }
+      }   // (TN > 0)
     };
     // (tiles of this wave, a sample's last band: see down_q_kernel)
     constexpr int C0 = TMAX, NF0 = G::NT - G::NSPLIT * (C0 - 1);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   auto commit_x = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
     const int c = xl_cr[i] >> 16, r = (xl_cr[i] >> 8) & 63, o = xl_cr[i] & 255;
     const float mk = (unsigned)(2 * up.band * R - 2 + r) < (unsigned)H ? 1.f : 0.f, sc = a_sc, sh = a_sh * mk;
-    if (xl_cr[i] & 0x8000) {
+    if (xl_cr[i] & 0x8000) {   // (kept under the lane mask for full slots too: without it the kernel lost 2 - 4 us)
       float y[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
