@@ -643,6 +643,43 @@ def test_train_step_odd_batch_sizes_in_the_bench_modes(arch, dim_z, mode, B):
         assert all(abs(u - v) <= 2e-2 * abs(u) + 1e-6 for u, v in zip(a, b)), (a, b)
 
 
+def test_prefetched_minibatches_equal_direct_steps():
+    """VAETrainStep.prefetch_input / step_prefetched: minibatches that arrive from pinned host memory on the copy stream
+    while the previous step replays give the same losses, step for step, as the same minibatches passed to step() from
+    device memory (same seeds, same generator streams) - incl. a minibatch handed over while the step that still reads
+    the previous one is in flight."""
+    from preset_gen_vae_amd.train_step import VAETrainStep
+    B = 4
+    xs = [synth_input(B) * (1.0 + 0.1 * i) for i in range(4)]
+    losses = []
+    for mode in ('direct', 'prefetched'):
+        torch.manual_seed(11)
+        ae = _build('speccnn4l1_bn', 64, B, True).cuda().train()
+        step = VAETrainStep(ae, use_graph=True)
+        out = step.step(_cuda32(xs[0]))
+        ls = [out['total'].item()]
+        if mode == 'direct':
+            for x in xs[1:]:
+                ls.append(step.step(_cuda32(x))['total'].item())
+        else:
+            hosts = [x.float().contiguous().pin_memory() for x in xs[1:]]
+            step.prefetch_input(hosts[0])
+            for i in range(len(hosts)):
+                out = step.step_prefetched()
+                if i + 1 < len(hosts):
+                    step.prefetch_input(hosts[i + 1])     # (while the step above is still running)
+                ls.append(out['total'].item())
+            with pytest.raises(RuntimeError):
+                step.step_prefetched()
+        losses.append(ls)
+    # (two runs of the same steps agree to summation-order level - float atomics in the BatchNorm statistics - and drift apart
+    # by the Adam steps in between: 7e-8 on the first loss, up to 3e-5 on the fourth; a stale or torn minibatch would show
+    # at the 10 % level, the inputs differ by 10 % from step to step)
+    for i, (a, b) in enumerate(zip(*losses)):
+        assert abs(a - b) <= (1e-6 if i == 0 else 2e-4) * abs(a), (i, losses)
+    assert all(abs(losses[0][i + 1] - losses[0][i]) > 1e-2 * losses[0][i] for i in range(3)), losses
+
+
 def test_graph_replay_equals_eager():
     """hipGraph-captured step == eager step (same kernels, same order); RNG advances across replays."""
     from preset_gen_vae_amd.train_step import VAETrainStep
