@@ -934,8 +934,9 @@ int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const floa
     return launch_down_q<DownQ<32, 64, 33, 45, 2, 2, 4, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65)   // 16 -> 32 channels: bands of 4 rows (180 pixels = 12 tiles), waves = 2 K halves x 4 pixel groups
     return launch_down_q<DownQ<16, 32, 65, 88, 4, 2, 2, 4, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  // 8 -> 16 channels: bands of 4 rows (352 pixels = 22 tiles), one M tile, waves = 2 K halves x 4 pixel groups
-  return launch_down_q<DownQ<8, 16, 129, 174, 4, 1, 2, 4, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  // 8 -> 16 channels: bands of 4 rows (352 pixels = 22 tiles), one M tile, waves = 8 pixel groups over the whole K (one
+  // tile slice to write and move out instead of two K halves: -1 us)
+  return launch_down_q<DownQ<8, 16, 129, 174, 4, 1, 1, 8, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
 
 int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
