@@ -741,8 +741,8 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                "latent_flow_input_regularization": args.latent_reg, "final_loss": round(loss, 6)}
         if args.dtype == 'fp32':
             cfg["fp32_products"] = (
-                "bf16x6: the k4 s2 layers from 129x174 down to 5x7 (forward, fused input gradient, weight gradient) and the "
-                "1x1 layers (forward, input gradient) evaluate every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact "
+                "bf16x6: the k4 s2 layers from 129x174 down to 5x7 and the 1x1 layers (forward, fused input gradient, weight "
+                "gradient) evaluate every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact "
                 "three-way operand splits with fp32 accumulation (error against float64 <= the native instruction's: "
                 "tests/test_gpu_kernels.py); the 1-channel 5x5 end layers and the fc GEMMs use the native fp32 instruction"
                 if ops.fp32_products() != 'native' else "native: v_mfma_f32_16x16x4_f32 / fp32 FMA everywhere")

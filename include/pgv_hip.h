@@ -72,7 +72,7 @@ typedef struct pgv_conv_desc {
  *                                                                          weight gradient
  *                                                                          (conv_big_split.hip, conv_wgrad_split.hip)
  *   64 <-> 128 on 17x23, 128 <-> 256 on 9x12, 256 <-> 512 on 5x7           forward, input gradient, weight gradient
- *   1x1 layers on 3x4 planes                                               forward, input gradient
+ *   1x1 layers on 3x4 planes                                               forward, input gradient, weight gradient
  *                                                                          (conv_deep_split.hip, conv_deep_bf16.hip)
  * Forward / input-gradient calls need the layer's split weight shadow (pgv_conv_weight_shadow_bytes > 0 under this flag:
  * 12 bytes per weight) in pgv_conv_desc.w_shadow and compute natively without it; the weight gradient needs none (both

@@ -1451,6 +1451,163 @@ __global__ __launch_bounds__(512) void k1_wgrad_bf16_kernel(int B, int CB, int C
       }
 }
 
+// The 1x1 weight gradient with fp32 products as SIX bf16 instructions (PGV_COMPUTE_F32_SPLIT): the 128 x 128 tile of
+// k1_wgrad_bf16_kernel with THREE plane images of both operands (x = x1 + x2 + x3 exactly, split where a block of 8 samples
+// is committed) - 144 KB, so ONE stage: a matrix phase (3 K steps of 8 samples x 4 pixels; a wave multiplies 4 x 2 tiles:
+// 18 fragment reads per 48 instructions) and a vector phase (the next block is converted and committed; its loads were
+// issued before the matrix phase) with a barrier each that does not wait for vector memory.  The S items sit on threads
+// 0 .. 383, the X items on threads 128 .. 511: three items per SIMD.
+struct K1WS {
+  // PS: pixel stride of an image, [pixel][128 channels][8 samples] + one 16-byte slot: the three items of a channel (pixel
+  // quads 0, 4, 8) then start 64 bytes apart modulo the bank period instead of on the same banks (3-way conflicts on every store)
+  static constexpr int P = 12, T = 128, PS = T * 16 + 16, IMG = P * PS, OPER = 3 * IMG, STAGE = 2 * OPER, ITEMS = T * 3;
+};
+
+__global__ __launch_bounds__(512) void k1_wgrad_split_kernel(int B, int CB, int CS, const float* __restrict__ big,
+                                                             const float* __restrict__ big_scale,
+                                                             const float* __restrict__ big_shift,
+                                                             const float* __restrict__ small_in,
+                                                             const float* __restrict__ small_scale,
+                                                             const float* __restrict__ small_shift,
+                                                             float* __restrict__ outp, int nsplit, int add,
+                                                             unsigned long long* __restrict__ stamps) {
+  using G = K1WS;
+  constexpr int P = G::P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const pgv_split_sel sel = pgv_split_sel_make();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mh = wave & 1, nq = wave >> 1;
+  const int NBc = CB / G::T, tiles = (CS / G::T) * NBc;
+  const int tile = blockIdx.x % tiles, ks = blockIdx.x / tiles;
+  const int cs0 = (tile / NBc) * G::T, cb0 = (tile % NBc) * G::T;
+  const int units = (B + 7) >> 3, per = (units + nsplit - 1) / nsplit;
+  const int u0 = ks * per, u1 = min(units, u0 + per);
+
+  const bool s_ok = tid < G::ITEMS, x_ok = tid >= 512 - G::ITEMS;
+  const int qs = min(tid, G::ITEMS - 1), sch = qs / 3, sqi = qs - sch * 3;
+  const int qx = max(tid - (512 - G::ITEMS), 0), xch = qx / 3, xqi = qx - xch * 3;
+  const int s_off = ((cs0 + sch) * P + 4 * sqi) * 4, x_off = ((cb0 + xch) * P + 4 * xqi) * 4;   // bytes; + sample * C * P
+  const int s_dst = (4 * sqi) * G::PS + sch * 16;                                        // + T * 16 per pixel
+  const int x_dst = G::OPER + (4 * xqi) * G::PS + xch * 16;
+  const float s_sc = small_scale ? small_scale[cs0 + sch] : 1.f, s_sh = small_scale ? small_shift[cs0 + sch] : 0.f;
+  const float x_sc = big_scale ? big_scale[cb0 + xch] : 1.f, x_sh = big_scale ? big_shift[cb0 + xch] : 0.f;
+  const bool s_aff = small_scale != nullptr, x_aff = big_scale != nullptr;
+
+  f4u rs[8], rx[8];
+  unsigned live = 0xFFu;
+  auto issue = [&](int u) {
+    const int b = u * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bj = min(b + j, B - 1);
+      rs[j] = *reinterpret_cast<const f4u*>(reinterpret_cast<const unsigned char*>(small_in) + (size_t)bj * CS * P * 4 + s_off);
+      rx[j] = *reinterpret_cast<const f4u*>(reinterpret_cast<const unsigned char*>(big) + (size_t)bj * CB * P * 4 + x_off);
+    }
+  };
+  // the 8 samples of pixel e of an item -> three 16-byte entries (one per plane)
+  auto store8 = [&](unsigned char* dst, const f4u (&r)[8], int e, bool aff, float sc, float sh) {
+    float v[8];
+    if (live != 0xFFu) {      // partial last block (uniform): per-sample masks
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float mj = ((live >> j) & 1u) ? 1.f : 0.f;
+        v[j] = fmaf(r[j][e], sc * mj, sh * mj);
+      }
+    } else if (aff) {         // (uniform)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(r[j][e], sc, sh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = r[j][e];
+    }
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned a, b, c;
+      pgv_split3_pair(v[2 * j], v[2 * j + 1], a, b, c, sel);
+      ph[j] = a, pm[j] = b, pl[j] = c;
+    }
+    *reinterpret_cast<u32x4*>(dst) = ph;
+    *reinterpret_cast<u32x4*>(dst + G::IMG) = pm;
+    *reinterpret_cast<u32x4*>(dst + 2 * G::IMG) = pl;
+  };
+  auto commit = [&](int u) {
+    live = (1u << min(max(B - u * 8, 0), 8)) - 1u;
+    if (s_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) store8(ldsb + s_dst + e * G::PS, rs, e, s_aff, s_sc, s_sh);
+    }
+    if (x_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) store8(ldsb + x_dst + e * G::PS, rx, e, x_aff, x_sc, x_sh);
+    }
+  };
+  auto sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // fragments: A rows cs = (4 mh + t) * 16 + m, B columns cb = (2 nq + t) * 16 + m; pixel 4 step + kq
+  const int a_frag = kq * G::PS + (4 * mh * 16 + m) * 16;                // + 256 per M tile, + 4 pixels per step
+  const int b_frag = G::OPER + kq * G::PS + (2 * nq * 16 + m) * 16;     // + 256 per N tile
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  BSTAMP(0);
+  if (u0 < u1) {
+    issue(u0);
+    commit(u0);
+  }
+  if (u0 + 1 < u1) issue(u0 + 1);
+  sync();
+  BSTAMP(1);
+#pragma unroll 1
+  for (int u = u0; u < u1; ++u) {
+    // ---- matrix phase
+    if (u == u0 + 2) BSTAMP(2);
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      u32x4 a[4][3], b[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t][p] = *reinterpret_cast<const u32x4*>(ldsb + p * G::IMG + a_frag + sp * 4 * G::PS + t * 256);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t][p] = *reinterpret_cast<const u32x4*>(ldsb + p * G::IMG + b_frag + sp * 4 * G::PS + t * 256);
+      }
+      // the six products, smallest first, over eight independent accumulators
+      constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) acc[t][t2] = mfma_bf16_k32(a[t][TA[term]], b[t2][TB[term]], acc[t][t2]);
+    }
+    if (u == u0 + 2) BSTAMP(3);
+    sync();
+    if (u == u0 + 2) BSTAMP(4);
+    // ---- vector phase: the next block of samples
+    if (u + 1 < u1) {
+      commit(u + 1);
+      if (u + 2 < u1) issue(u + 2);
+    }
+    if (u == u0 + 2) BSTAMP(5);
+    sync();
+    if (u == u0 + 2) BSTAMP(6);
+  }
+  BSTAMP(7);
+  float* o = outp + (nsplit > 1 ? (size_t)ks * CS * CB : 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t idx = (size_t)(cs0 + (4 * mh + t) * 16 + 4 * kq + i) * CB + cb0 + (2 * nq + t2) * 16 + m;
+        o[idx] = acc[t][t2][i] + ((add && nsplit == 1) ? o[idx] : 0.f);
+      }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BSTAMP(8);
+}
+
 template <int H, int W, int R, int WP>
 int launch_deep_wgrad_bf16(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                            const float* small_in, const float* small_scale, const float* small_shift, float* gw,
@@ -2466,7 +2623,7 @@ static int k1_wgrad_split(const pgv_conv_desc* d) {
 }
 
 int64_t pgv_conv_wgrad_deep_bf16_workspace(const pgv_conv_desc* d) {
-  if ((d->flags & PGV_COMPUTE_BF16) && k1_bf16_shape(d)) {
+  if (((d->flags & PGV_COMPUTE_BF16) && k1_bf16_shape(d)) || pgv_k1_split_shape(d)) {
     const int ns = k1_wgrad_split(d);
     return ns > 1 ? (int64_t)ns * d->Cs * d->Cb * 4 : 0;
   }
@@ -2496,6 +2653,28 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
       hipLaunchKernelGGL(deep_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                          (const f32x4*)workspace, nsplit, n4, (f32x4*)gw, add);
       PGV_CHECK_LAUNCH("conv_wgrad_k1_bf16 reduce");
+    }
+    return 1;
+  }
+  if (pgv_k1_split_shape(d) && d->B > 0) {   // the 1x1 weight gradient with six-instruction products
+    const int64_t gw_bytes = (int64_t)d->Cs * d->Cb * 4;
+    int nsplit = min(k1_wgrad_split(d), (d->B + 7) / 8);
+    if (nsplit > 1 && (!workspace || workspace_bytes < nsplit * gw_bytes || ((uintptr_t)workspace & 15) || ((uintptr_t)gw & 15)))
+      nsplit = 1;
+    static bool attr_done = false;
+    int rc = raise_lds_limit(k1_wgrad_split_kernel, &attr_done, "conv_wgrad_k1_split");
+    if (rc) return rc;
+    const int add = (d->flags & PGV_PREZEROED) ? 1 : 0;
+    const int grid = (d->Cs / 128) * (d->Cb / 128) * nsplit;
+    hipLaunchKernelGGL(k1_wgrad_split_kernel, dim3((unsigned)grid), dim3(512), (size_t)K1WS::STAGE, st, d->B, d->Cb, d->Cs, big,
+                       big_scale, big_shift, small_in, small_scale, small_shift, nsplit > 1 ? (float*)workspace : gw, nsplit, add,
+                       g_deep_bf16_stamps);
+    PGV_CHECK_LAUNCH("conv_wgrad_k1_split");
+    if (nsplit > 1) {
+      const int n4 = (int)(gw_bytes / 16);
+      hipLaunchKernelGGL(deep_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                         (const f32x4*)workspace, nsplit, n4, (f32x4*)gw, add);
+      PGV_CHECK_LAUNCH("conv_wgrad_k1_split reduce");
     }
     return 1;
   }

@@ -495,8 +495,8 @@ def test_deep_kernels_fp32_products_as_six_bf16_instructions(ops, case):
 @pytest.mark.parametrize("case", [(512, 2048, 1, 1, 0, 3, 4, 19), (128, 256, 1, 1, 0, 3, 4, 4)])
 def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
     """conv_deep_split.hip, the 1x1 layers on 3x4 planes (enc8 / dec1) in PGV_COMPUTE_F32_SPLIT mode: both directions against
-    float64 at fp32 tolerances, no further from it than the native fp32 kernels, deterministic; the weight gradient of these
-    layers stays on the fp32 kernels."""
+    float64 at fp32 tolerances, no further from it than the native fp32 kernels, deterministic; and their weight gradient
+    (k1_wgrad_split_kernel in conv_deep_bf16.hip)."""
     Cb, Cs, k, s, p, Hb, Wb, B = case
     big, small, w, bias_s, bias_b, sc_b, sh_b, sc_s, sh_s, Hs, Ws = _conv_inputs(case)
     geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
@@ -528,6 +528,32 @@ def test_k1_layers_fp32_products_as_six_bf16_instructions(ops, case):
         assert rel_l2(stats, torch.cat([refu.sum(dim=(0, 2, 3)), (refu * refu).sum(dim=(0, 2, 3))])) < 2e-5
         got = ops.conv_up(geom, dev(small), dev(w), None, ops.PGV_ACT_NONE, 0.0, w_shadow=sh)
         assert rel_l2(got, F.conv_transpose2d(small.double(), w.double(), None)) < 1e-5
+
+        # ---- weight gradient (k1_wgrad_split_kernel: both operands split where a block of 8 samples is committed) on seeded
+        # normal operands, either side lazily normalised, partial last block of samples, accumulate into a zeroed gradient
+        gen = torch.Generator().manual_seed(B)
+        bign = (torch.randn(big.shape, generator=gen) + 0.5).to(big.dtype)
+        smalln = torch.randn(small.shape, generator=gen).to(small.dtype)
+        for kw_n, bigd, smalld in (({'big_scale': dev(sc_b), 'big_shift': dev(sh_b)}, _affine_fma(bign, sc_b, sh_b).double(), smalln.double()),
+                                   ({'small_scale': dev(sc_s), 'small_shift': dev(sh_s)}, bign.double(),
+                                    _affine_fma(smalln, sc_s, sh_s).double()),
+                                   ({}, bign.double(), smalln.double())):
+            wv = w.double().clone().requires_grad_(True)
+            F.conv2d(bigd, wv, None).backward(smalld)
+            gw = torch.empty((Cs, Cb, 1, 1), device='cuda')
+            ops.conv_wgrad(geom, dev(bign), dev(smalln), gw, **kw_n)
+            gw2 = torch.full((Cs, Cb, 1, 1), 7.0, device='cuda')
+            ops.conv_wgrad(geom, dev(bign), dev(smalln), gw2, **kw_n)
+            assert torch.equal(gw, gw2)
+            ops.set_fp32_products('native')
+            gwn = torch.empty((Cs, Cb, 1, 1), device='cuda')
+            ops.conv_wgrad(geom, dev(bign), dev(smalln), gwn, **kw_n)
+            ops.set_fp32_products('bf16x6')
+            e_split, e_native = rel_l2(gw, wv.grad), rel_l2(gwn, wv.grad)
+            assert e_split < 1e-6 and e_split < 1.25 * e_native + 1e-7, (e_split, e_native)
+        acc = torch.zeros((Cs, Cb, 1, 1), device='cuda')
+        ops.conv_wgrad(geom, dev(bign), dev(smalln), acc, prezeroed=True)
+        assert rel_l2(acc, gw) < 1e-6
     finally:
         ops.set_fp32_products('native')
 
