@@ -1456,7 +1456,9 @@ __global__ __launch_bounds__(512) void k1_wgrad_bf16_kernel(int B, int CB, int C
 // is committed) - 144 KB, so ONE stage: a matrix phase (3 K steps of 8 samples x 4 pixels; a wave multiplies 4 x 2 tiles:
 // 18 fragment reads per 48 instructions) and a vector phase (the next block is converted and committed; its loads were
 // issued before the matrix phase) with a barrier each that does not wait for vector memory.  The S items sit on threads
-// 0 .. 383, the X items on threads 128 .. 511: three items per SIMD.
+// 0 .. 383, the X items on threads 128 .. 511: three items per SIMD.  (Tried: half-quad items with 8-byte loads, exactly
+// three per thread - the commit fell from 3.7 k to 2.5 k clocks per block, but 24 load instructions per thread instead of 16
+// cost more than that wherever they were issued: 61.8 / 65.1 us against 61.3.)
 struct K1WS {
   // PS: pixel stride of an image, [pixel][128 channels][8 samples] + one 16-byte slot: the three items of a channel (pixel
   // quads 0, 4, 8) then start 64 bytes apart modulo the bank period instead of on the same banks (3-way conflicts on every store)
