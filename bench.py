@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--input", default="spectrograms", choices=["spectrograms", "audio"],
                     help="audio = BASELINE config 5: every step starts from a raw-audio minibatch [B, 88576] in HBM, the "
                          "fused STFT -> mel -> dB -> min-max kernel writes the step's input buffer (timed with the step)")
-    ap.add_argument("--fp32-products", default="bf16x6", choices=["native", "bf16x6"],
-                    help="fp32 mode only: bf16x6 (default) = layers with a split-product kernel evaluate every fp32 "
+    ap.add_argument("--fp32-products", default=None, choices=["native", "bf16x6"],
+                    help="fp32 mode only; default = the library's own default (ops.DEFAULT_FP32_PRODUCTS = bf16x6, what "
+                         "config.train.fp32_products = None and VAETrainStep() run): bf16x6 = layers with a split-product kernel evaluate every fp32 "
                          "product as six bf16 matrix instructions on exact three-way operand splits, fp32 accumulation "
                          "(DESIGN.md 2.3; the strict fp32 parity tests run in this mode too); native = the fp32 matrix "
                          "instruction everywhere (reported under 'extra')")
@@ -617,8 +618,10 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.train_step import VAETrainStep
     ops.set_compute_dtype(args.dtype)
+    # (None = the library default: the headline line times exactly what the training path runs by default)
     ops.set_fp32_products(args.fp32_products if args.dtype == 'fp32' else 'native')
     mc, tc = copy.copy(config.model), copy.copy(config.train)
+    tc.fp32_products = ops.fp32_products() if args.dtype == 'fp32' else None   # (the config field build_ae_model reads)
     mc.encoder_architecture, mc.dim_z = args.arch, args.dim_z
     tc.minibatch_size = args.batch
     mc.input_tensor_size = (args.batch, 1, 257, 347)
@@ -768,7 +771,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         step.grad_sync.uninstall()
     del step, ae, x
     ops.set_compute_dtype('fp32')
-    ops.set_fp32_products('native')
+    ops.set_fp32_products(None)
     torch.cuda.empty_cache()
     return line
 

@@ -58,6 +58,10 @@ train.reg_fc_dropout = 0.4                     # config.py:112
 train.beta = 0.2                               # config.py:114
 train.beta_start_value = 0.1                   # config.py:115
 train.beta_warmup_epochs = 25                  # config.py:117
+# not a reference field: how fp32 products are evaluated on the matrix cores (ops.set_fp32_products).  None = the library
+# default ('bf16x6': six bf16 instructions on exact three-way operand splits, fp32 accumulation; what bench.py times);
+# 'native' = v_mfma_f32_16x16x4_f32 everywhere.  Read by model.build.build_ae_model.
+train.fp32_products = None
 
 
 def update_dynamic_config_params():

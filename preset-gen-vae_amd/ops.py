@@ -60,15 +60,22 @@ def compute_dtype():
 
 
 PGV_COMPUTE_F32_SPLIT = 8
-_F32_SPLIT = False
+# The product's default form of fp32 products: what ``config.train.fp32_products = None`` / ``VAETrainStep()`` run and what
+# bench.py times on its headline line (one default for library, training path and benchmark).
+DEFAULT_FP32_PRODUCTS = 'bf16x6'
+_F32_SPLIT = DEFAULT_FP32_PRODUCTS == 'bf16x6'
 
 
 def set_fp32_products(mode):
-    """How fp32-mode products are evaluated by the layers that have a kernel for both: 'native' (default:
-    v_mfma_f32_16x16x4_f32) or 'bf16x6' (PGV_COMPUTE_F32_SPLIT: every operand as three exact bfloat16 terms, six bf16 matrix
-    instructions per product with fp32 accumulation - fp32-level error).  No effect in bf16 mode.  The library
-    default is 'native'; bench.py times the step with 'bf16x6' and labels its line."""
+    """How fp32-mode products are evaluated by the layers that have a kernel for both: 'bf16x6' (the default,
+    ``DEFAULT_FP32_PRODUCTS``; PGV_COMPUTE_F32_SPLIT: every operand as three exact bfloat16 terms, six bf16 matrix
+    instructions per product with fp32 accumulation - fp32-level error) or 'native'
+    (v_mfma_f32_16x16x4_f32 everywhere).  ``None`` restores the default.  No effect in bf16 mode.  Reachable from the training
+    path as ``config.train.fp32_products`` (model/build.py) and ``VAETrainStep(fp32_products=...)``; bench.py times the
+    default and reports the other form under 'extra'."""
     global _F32_SPLIT
+    if mode is None:
+        mode = DEFAULT_FP32_PRODUCTS
     if mode not in ('native', 'bf16x6'):
         raise ValueError(f"unknown fp32 product mode {mode!r}")
     _F32_SPLIT = mode == 'bf16x6'

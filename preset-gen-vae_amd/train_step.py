@@ -30,13 +30,18 @@ from .model import loss as loss_mod
 class VAETrainStep:
     def __init__(self, ae_model, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, beta=0.2, normalize_losses=True,
                  reg_model=None, grad_sync=None, use_graph=False, controls_criterion=None, monitors=None,
-                 graph_buckets=True):
-        """``controls_criterion``: callable(v_out, v_in) -> 0-d loss, the backprop criterion of the preset-regression
+                 graph_buckets=True, fp32_products=None):
+        """``fp32_products``: 'bf16x6' / 'native' selects the form of the fp32 products for the whole process
+        (``ops.set_fp32_products``; None keeps the current setting, whose default is 'bf16x6' - the mode bench.py times).
+        ``controls_criterion``: callable(v_out, v_in) -> 0-d loss, the backprop criterion of the preset-regression
         output (train.py:108-116: ``model.params_loss.SynthParamsLoss``; default: MSE over all columns, the numeric branch
         of that loss on an all-numerical representation).  ``monitors``: {name: callable(v_out, v_in)} evaluated under
         ``no_grad`` on every minibatch BEFORE the controls criterion, as train.py:229-233 does with
         ``QuantizedNumericalParamsLoss`` / ``CategoricalParamsAccuracy``; their values come back as
         ``out['monitors'][name]`` (device tensors, no host synchronisation; captured with the rest of the step)."""
+        if fp32_products is not None:
+            from . import ops
+            ops.set_fp32_products(fp32_products)
         self.model = ae_model
         self.reg_model = reg_model
         self.beta = float(beta)

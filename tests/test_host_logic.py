@@ -40,6 +40,38 @@ def test_state_dict_keys_match_reference(arch, output_bn, golden):
         assert n_params == 12440017 + (256 if output_bn else 0)      # SURVEY.md §2.2 [probed]
 
 
+def test_fp32_products_default_is_what_bench_times_and_is_reachable_from_the_training_path():
+    """the library default, ``config.train.fp32_products`` and bench.py's default are ONE setting
+    (``ops.DEFAULT_FP32_PRODUCTS``); the builders and VAETrainStep can select either form."""
+    import bench
+    from preset_gen_vae_amd import config, ops
+    from preset_gen_vae_amd.model import build
+    import sys
+    before = ops.fp32_products()
+    try:
+        ops.set_fp32_products(None)
+        assert ops.fp32_products() == ops.DEFAULT_FP32_PRODUCTS == 'bf16x6'
+        assert config.train.fp32_products is None                       # = "the library default"
+        argv, sys.argv = sys.argv, ['bench.py']
+        try:
+            assert bench.parse().fp32_products is None                  # bench.py times the library default
+        finally:
+            sys.argv = argv
+        mc, tc = _cfg('speccnn4l1_bn')
+        build.build_ae_model(mc, tc)
+        assert ops.fp32_products() == 'bf16x6'                          # None leaves the default alone
+        tc.fp32_products = 'native'
+        build.build_ae_model(mc, tc)
+        assert ops.fp32_products() == 'native' and not (ops._flags() & ops.PGV_COMPUTE_F32_SPLIT)
+        tc.fp32_products = 'bf16x6'
+        build.build_ae_model(mc, tc)
+        assert ops._flags() & ops.PGV_COMPUTE_F32_SPLIT
+        with pytest.raises(ValueError):
+            ops.set_fp32_products('tf32')
+    finally:
+        ops.set_fp32_products(before)
+
+
 def test_builder_surface_and_errors():
     from preset_gen_vae_amd.model import VAE, build, extendedAE, regression
 
