@@ -440,8 +440,10 @@ inline int launch_wgrad_reduce_taps(const pgv_conv_desc* d, const pgv_coef_req* 
 // ---------------------------------------------------------------------------------------------------------------
 // WGRAD of the 1 <-> 8 channel 5x5 layers (enc1 / dec8: big = [B,1,257,347], small = [B,8,129,174]), same structure as
 // conv_wgrad_ws_kernel:  gw[cs][kh][kw] = sum_{b,oh,ow} small[b,cs,oh,ow] * big[b,0,2oh-2+kh,2ow-2+kw].
-// M = cs (8 of the tile's 16 rows; lanes 8-15 duplicate 0-7 and are not stored), N = 25 taps in two tiles (lanes past
-// tap 24 duplicate it), K = output pixels.  There are only two (M, N) tiles, so the four MFMA waves split K: wave w
+// M = (cs, column shift s) = 16 rows, N = (kh, kernel column 2..4) = 15 of 16 columns, K = output pixels: the shifted copy
+// of the small operand turns kernel columns 2..4 into 0..2, so ONE 16x16 tile holds the 200 gradients (round 6; before:
+// M = cs in 8 of 16 rows, N = 25 taps in two tiles - twice the matrix instructions, whose issue starved the loader
+// wave of the same SIMD).  The four MFMA waves split K: wave w
 // multiplies output row w of the unit (R = 4 rows) and keeps its own accumulators; every wave's partial sum goes to the
 // workspace (4 per workgroup) and the reduce pass adds them.  The band kernel this replaces spends 37 % of a
 // workgroup's time in its MFMA phase (commit 1.4 us + issue 1.0 us against 1.6 us of MFMAs per item).
@@ -584,21 +586,24 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
   }
   // ==================================================== MFMA waves ===================================================
   __builtin_amdgcn_s_setprio(PGV_V2_PRIO_MFMA);
-  // wave w multiplies output row w of the unit.  A: lane (m = cs = lane & 7, k = pixel lane>>4) reads
-  // small[cs][w][4i + k]; B: lane (tap = 16 n + (lane & 15), k) reads big[2w + kh][2(4i + k) + kw - 2]
-  const int offA = PLANE_B + (lane & 7) * PLANE_S + wave * WsP + (lane >> 4);
-  int offB[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int tap = min(16 * n + (lane & 15), G::NTAP - 1);
-    offB[n] = (2 * wave + tap / G::KS) * WP + tap % G::KS - 2 + 2 * (lane >> 4);
-  }
-  // operand lanes of the last k-step of a row that lie behind the end of the row (the loader does not clean them)
-  const bool keepA = 4 * (SPR - 1) + (lane >> 4) < Ws;
-  bool keepB[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) keepB[n] = 8 * (SPR - 1) + 2 * (lane >> 4) + min(16 * n + (lane & 15), G::NTAP - 1) % G::KS - 2 < W;
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // ONE 16x16 tile holds all 200 gradients: wave w multiplies output row w of the unit with
+  //   M row m = (cs = m & 7, s = m >> 3):  A[m][k] = small[cs][w][v + s]            (the same pixel row, one column on)
+  //   N col n = (kh = n / 3, kwn = 2 + n % 3), n < 15:  B[k][n] = big[2w + kh][2v + kwn - 2]
+  // so that D[(cs, s)][(kh, kwn)] = sum_v small[cs][w][v + s] * big[2w + kh][2(v + s) - 2 + (kwn - 2s)] is the gradient of
+  // tap (kh, kw = kwn - 2s): s = 0 gives kernel columns 2..4, s = 1 columns 0..2 (column 2 twice: the s = 1 copy is not
+  // stored).  One MFMA per 4 pixels instead of two with half-empty tiles (M = 8 channels, N = 25 taps in two tiles).
+  // K slot k = lane >> 4 of step i is pixel v = 4i + k.  The s = 1 rows see pixels 1 .. Ws of the row; pixel 0 (v = -1)
+  // rides in the last step's slot k = 3, whose own pixel (4 SPR - 1) lies behind the row end.
+  const int kq = lane >> 4, sh = (lane >> 3) & 1;
+  const int tapn = min(lane & 15, 14), khn = tapn / 3, kwn = 2 + tapn % 3;
+  const int offA = PLANE_B + (lane & 7) * PLANE_S + wave * WsP + kq + sh;
+  const int offB = (2 * wave + khn) * WP + kwn - 2 + 2 * kq;
+  static_assert(4 * (SPR - 1) + 3 >= Ws, "slot 3 of the last step is free for pixel -1");
+  // last step: which operand lanes hold real pixels (the loader does not clean the floats behind a row end)
+  const bool keepA = 4 * (SPR - 1) + kq + sh < Ws, keepB = 8 * (SPR - 1) + 2 * kq + kwn - 2 < W;
+  const int offA_m1 = PLANE_B + (lane & 7) * PLANE_S + wave * WsP;         // pixel v + s = 0 of the row
+  const int offB_m1 = (2 * wave + khn) * WP + kwn - 4;                      // columns -2 .. 0 (left zero padding)
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   if (my_items > 0) {
     ws_barrier();  // item 0 committed
 #pragma unroll 1
@@ -611,19 +616,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
 #else
       if (wave < nrows) {
 #endif
-        float av[3][2], bv[3][2][2];
-        auto load_pair = [&](int ps, float (&a)[2], float (&b)[2][2]) {
+        float av[3][2], bv[3][2];
+        auto load_pair = [&](int ps, float (&a)[2], float (&b)[2]) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             a[h] = cur[offA + 4 * (2 * ps + h)];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) b[h][n] = cur[offB[n] + 8 * (2 * ps + h)];
+            b[h] = cur[offB + 8 * (2 * ps + h)];
           }
           if (2 * ps + 1 == SPR - 1) {
-            if (Ws % 4 != 0) a[1] = keepA ? a[1] : 0.f;
-            if (W % 4 != 0)
-#pragma unroll
-              for (int n = 0; n < 2; ++n) b[1][n] = keepB[n] ? b[1][n] : 0.f;
+            const float a0 = cur[offA_m1], b0 = cur[offB_m1];
+            a[1] = kq == 3 ? (sh ? a0 : 0.f) : (keepA ? a[1] : 0.f);
+            b[1] = kq == 3 ? b0 : (keepB ? b[1] : 0.f);
           }
         };
         load_pair(0, av[0], bv[0]);
@@ -633,13 +636,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (pn < PPR) load_pair(pn, av[pn % 3], bv[pn % 3]);
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[n] = PGV_MFMA4(av[ps % 3][h], bv[ps % 3][h][n], acc[n]);
-          // 3 operand reads (one per operand: the two k-steps of a pair come from one ds_read2) under 4 MFMAs
-          static_for<0, 4>([&](auto kc) {
+          for (int h = 0; h < 2; ++h) acc = PGV_MFMA4(av[ps % 3][h], bv[ps % 3][h], acc);
+          // 2 operand reads (one per operand: the two k-steps of a pair come from one ds_read2) under 2 MFMAs
+          static_for<0, 2>([&](auto kc) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (pn < PPR && decltype(kc)::value < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (pn < PPR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           });
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -647,15 +648,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad5_ws_kernel(int B, const flo
       ws_barrier();
     }
   }
-  // ---- this wave's partial gradient: D column = lane & 15 = tap - 16 n, rows (lane>>4)*4 + reg = cs (0..7 are real)
+  // ---- this wave's partial gradient: D column = lane & 15 = (kh, kwn), rows (lane>>4)*4 + reg = (cs, s)
   float* pw = partial + ((size_t)blockIdx.x * 4 + wave) * (CS * G::NTAP);
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int cs = (lane >> 4) * 4 + reg, tap = 16 * n + (lane & 15);
-      if (cs < CS && tap < G::NTAP) pw[cs * G::NTAP + tap] = acc[n][reg];
-    }
+  for (int reg = 0; reg < 4; ++reg) {
+    const int m = (lane >> 4) * 4 + reg, cs = m & 7, s1 = m >> 3;
+    if ((lane & 15) < 15 && !(s1 && kwn == 4)) pw[cs * G::NTAP + khn * G::KS + kwn - 2 * s1] = acc[reg];
+  }
 }
 
 template <int R>
