@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, (R * ((W + 1) / 2 + 3) / 4 <= 256) ? 3 : 2) vo
           float* o = ob + (int64_t)(oh + ph) * W + ow;
           float y[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) y[i] = pgv_act_apply(acc[ps][ph][i >> 1][i & 1], actp);
+          for (int i = 0; i < 8; ++i) y[i] = pgv_act_apply_nan(acc[ps][ph][i >> 1][i & 1], actp);
           if (n >= 8) {
             f4u a, c;
             a.x = y[0], a.y = y[1], a.z = y[2], a.w = y[3];
@@ -420,6 +420,11 @@ int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const flo
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
   if (d->Hb != 257 || d->Wb != 347 || d->B <= 0) return 0;
   if (bn && !in_scale) return 0;
+#ifndef PGV_NO_C1_RING
+  // fp32: the ring kernel (conv_c1_ring.hip: rows by LDS-DMA, affine folded into the weights); bf16 operand mode rounds the
+  // operand AFTER the affine and stays here
+  if (int rc = pgv_conv_up_ring(d, small_in, in_scale, in_shift, w, bias, act, slope, out, stats, st, bn)) return rc;
+#endif
   // 11 grid rows per unit: since the units of neighbouring bands share an XCD's L2 (pgv_xcd_block) the larger unit no
   // longer pays for its halo and its longer multiply phase hides more of the next unit's loads (88 -> 83 us)
   return launch_up_c1<11>(d, small_in, in_scale, in_shift, w, bias, act, slope, out, bn, st);

@@ -55,6 +55,10 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
                    const float* w, const float* bias, int act, float slope, float* big_out, double* stats,
                    const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn = nullptr);
 
+// Third-generation kernels of the same layers (conv_c1_ring.hip): LDS ring of image rows filled by LDS-DMA, fp32 only.
+int pgv_conv_up_ring(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
+                     const float* w, const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
+                     const pgv_bn_src* bn);
 // Second-generation direct kernels (conv_direct2.hip): four pixels per lane, 16-byte LDS reads and stores.
 int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* out, double* stats,

@@ -149,6 +149,13 @@ __device__ __forceinline__ float pgv_act_apply(float y, const pgv_act_params& p)
   const float r = y > 0.f ? y : p.ns * y;
   return fminf(p.hi, fmaxf(p.lo, r));
 }
+// The same with torch's NaN behaviour at a clamp: Hardtanh(NaN) = NaN (fminf / fmaxf return the other operand).  For the
+// output layer's kernels: a NaN there must reach the reconstruction loss, where the reference's harness looks for it
+// (utils/exception.py:13-23, train.py:245).  Behind a LeakyReLU the plain form leaves NaN as -inf: still not finite.
+__device__ __forceinline__ float pgv_act_apply_nan(float y, const pgv_act_params& p) {
+  const float r = pgv_act_apply(y, p);
+  return y != y ? y : r;
+}
 
 // Operand precision of a product (PGV_COMPUTE_BF16): kernels without a bf16 MFMA loop round their operands to bfloat16
 // (RNE) and keep multiplying on the fp32 pipe - products of bf16 values are exact in fp32, so the result differs from
@@ -157,6 +164,6 @@ __device__ __forceinline__ float pgv_opnd(float x, bool bf16) { return bf16 ? (f
 
 __device__ __forceinline__ float pgv_act(float y, int act, float slope) {
   if (act == PGV_ACT_LEAKY_RELU) return y > 0.f ? y : slope * y;
-  if (act == PGV_ACT_HARDTANH) return fminf(1.f, fmaxf(-1.f, y));
+  if (act == PGV_ACT_HARDTANH) return y != y ? y : fminf(1.f, fmaxf(-1.f, y));   // (NaN stays NaN, as torch)
   return y;
 }

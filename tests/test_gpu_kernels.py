@@ -72,6 +72,59 @@ def _affine(t, sc, sh):
     return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
 
 
+@pytest.mark.parametrize("B", [1, 40, 300])
+def test_end_layer_ring_kernels_all_batch_regimes(ops, B):
+    """conv_c1_ring.hip (round 6): the 1 <-> 8 channel 5x5 end layers walk a sample in segments of steps with the rows of
+    the next step in flight.  B = 2 (CONV_CASES) gives one step per workgroup - prologue only; here B = 40 (13 segments of 2
+    steps), B = 300 (2 segments of 13 steps, 600 units on 512 workgroups: the persistent loop) and B = 1.  The producer's
+    BatchNorm affine is folded into weights + a border-aware constant: checked against the un-folded float64 convolution,
+    with large shifts so that a wrong border term would show."""
+    case = (1, 8, 5, 2, 2, 257, 347, B)
+    Cb, Cs, k, s, p, Hb, Wb, _ = case
+    geom = ops.ConvGeom(Cb, Cs, k, s, p, Hb, Wb)
+    gen = torch.Generator().manual_seed(77 + B)
+    small = torch.randn((B, Cs, geom.Hs, geom.Ws), generator=gen)
+    w = torch.randn((Cs, Cb, k, k), generator=gen) * 0.15
+    bias_b = torch.tensor([0.05])
+    sc_s = 1.0 + 0.3 * torch.randn(Cs, generator=gen)
+    sh_s = 0.7 * torch.randn(Cs, generator=gen)
+    ref = F.conv_transpose2d(_affine(small, sc_s, sh_s).double(), w.double(), bias_b.double(), stride=s, padding=p)
+    assert ref.shape[-2:] == (Hb, Wb)
+    got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_NONE, 0.0, in_scale=dev(sc_s), in_shift=dev(sh_s))
+    err = (got.double().cpu() - ref).abs()
+    assert rel_l2(got, ref) < 2e-6
+    # the border rows / columns on their own (where the shift term differs from the interior's)
+    for sl in (np.s_[:, :, :2], np.s_[:, :, -2:], np.s_[:, :, :, :2], np.s_[:, :, :, -2:]):
+        assert err[sl].max().item() < 2e-5 * ref.abs().max().item()
+    got = ops.conv_up(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_HARDTANH, 0.0)     # no affine
+    ref = F.hardtanh(F.conv_transpose2d(small.double(), w.double(), bias_b.double(), stride=s, padding=p))
+    assert rel_l2(got, ref) < 2e-6
+    # the stride-2 convolution of the 1-channel image (enc1 forward; ring of input rows)
+    big = torch.randn((B, Cb, Hb, Wb), generator=gen)
+    bias_s = 0.1 * torch.randn(Cs, generator=gen)
+    ref = F.leaky_relu(F.conv2d(big.double(), w.double(), bias_s.double(), stride=s, padding=p), 0.1)
+    got = ops.conv_down(geom, dev(big), dev(w), dev(bias_s), ops.PGV_ACT_LEAKY_RELU, 0.1)
+    assert rel_l2(got, ref) < 2e-6
+    # ... and as the output layer's input gradient with the lower block's BatchNorm + activation backward, class sums and
+    # bias gradient in its epilogue (pgv_bwd_fuse)
+    a = torch.randn(ref.shape, generator=gen)
+    coef = torch.cat([1.0 + 0.2 * torch.randn(Cs, generator=gen), 0.05 * torch.randn(2 * Cs, generator=gen)])
+    gb = torch.zeros(ops.CLS_COPIES * Cs, device='cuda')
+    cls = torch.zeros(ops.CLS_COPIES * 4 * Cs, device='cuda')
+    g = F.conv2d(big.double(), w.double(), None, stride=s, padding=p)
+    ka, kb, kc = (coef[i * Cs:(i + 1) * Cs].double().view(1, -1, 1, 1) for i in range(3))
+    t = ka * g + kb * a.double() + kc
+    ref = torch.where(a.double() > 0, t, 0.1 * t)
+    got = ops.conv_down(geom, dev(big), dev(w), None, ops.PGV_ACT_NONE, 0.0,
+                        bwd_fuse=(dev(a), dev(coef), gb, ops.PGV_ACT_LEAKY_RELU, 0.1, cls, ops.CLS_COPIES))
+    assert rel_l2(got, ref) < 2e-6
+    ref_cls = torch.stack([ref[:, :, r::2, c::2].sum(dim=(0, 2, 3)) for r in (0, 1) for c in (0, 1)], dim=1)   # [C][4]
+    got_cls = cls.view(ops.CLS_COPIES, Cs, 4).sum(0).double().cpu()
+    assert (got_cls - ref_cls).abs().max().item() < 2e-5 * ref.abs().sum(dim=(0, 2, 3)).max().item()
+    got_gb = gb.view(ops.CLS_COPIES, Cs).sum(0).double().cpu()
+    assert (got_gb - ref.sum(dim=(0, 2, 3))).abs().max().item() < 2e-5 * ref.abs().sum(dim=(0, 2, 3)).max().item()
+
+
 # kernel policies (pgv_set_kernel_policy): 0 = tuned (wave-specialised, then band kernels), 3 = the same without the
 # wave-specialised generation (band kernels at the reference shapes: the no-workspace wgrad fallback and the bf16 path),
 # 2 = runtime-stride MFMA kernels, 1 = generic
