@@ -428,10 +428,13 @@ int pgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
 int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* stream);
 /* pgv_adam_tick plus the rest of a train step's single-thread bookkeeping in the same launch: the generator offset
  * rng_state[1] += rng_inc (pgv_rng_advance; rng_state nullable) and the reported loss total[0] = loss_a[0] +
- * loss_b[0] * weight_b[0] (+ loss_c[0]) (train.py:227,246; total / loss_c nullable).  Placed in front of pgv_adam_step. */
+ * loss_b[0] * weight_b[0] (+ loss_c[0]) (train.py:227,246; total / loss_c nullable).  finite (nullable, ABI v15): finite[0]
+ * = 1 if every loss term and the total are finite, else 0 - the harness's check_nan_values / ModelConvergenceError test
+ * (utils/exception.py:13-23, train.py:245) as a device flag that costs no launch and no synchronisation of its own.
+ * Placed in front of pgv_adam_step. */
 int pgv_step_tick(double* pows, float* hyper, float beta1, float beta2, uint64_t* rng_state, uint64_t rng_inc,
                   const float* loss_a, const float* loss_b, const float* weight_b, const float* loss_c, float* total,
-                  void* stream);
+                  float* finite, void* stream);
 
 /* ---- STFT -> mel -> dB front-end (utils/audio.py:20-92, data/abstractbasedataset.py:129-131) -------- */
 /* wav[B][n_samples] fp32 -> out[B][n_mels][n_frames]; n_fft=1024 only, hop any, centre zero padding.

@@ -141,7 +141,7 @@ SIGNATURES = {
     "pgv_sqerr_bwd": (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P, _P]),
     "pgv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, _P]),
     "pgv_adam_tick": (c_int, [_P, _P, c_float, c_float, _P]),
-    "pgv_step_tick": (c_int, [_P, _P, c_float, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
+    "pgv_step_tick": (c_int, [_P, _P, c_float, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "pgv_stft_mel": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_float,
                              c_float, c_float, _P, _P]),
     "pgv_stft": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_int, c_int, c_float,

@@ -31,7 +31,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 14; }
+int pgv_abi_version(void) { return 15; }
 const char* pgv_last_error(void) { return g_err; }
 static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {

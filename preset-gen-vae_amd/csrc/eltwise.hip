@@ -572,7 +572,7 @@ __global__ void adam_tick_kernel(double* __restrict__ pows, float* __restrict__ 
 __global__ void step_tick_kernel(double* __restrict__ pows, float* __restrict__ hyper, double beta1, double beta2,
                                  uint64_t* __restrict__ rng_state, uint64_t rng_inc, const float* __restrict__ la,
                                  const float* __restrict__ lb, const float* __restrict__ wb,
-                                 const float* __restrict__ lc, float* __restrict__ total) {
+                                 const float* __restrict__ lc, float* __restrict__ total, float* __restrict__ finite) {
   if (blockIdx.x != 0) return;
   if (threadIdx.x == 0) {
     const double p1 = pows[0] * beta1, p2 = pows[1] * beta2;
@@ -584,7 +584,12 @@ __global__ void step_tick_kernel(double* __restrict__ pows, float* __restrict__ 
   } else if (threadIdx.x == 1) {
     if (rng_state) rng_state[1] += rng_inc;
   } else if (threadIdx.x == 2) {
-    if (total) total[0] = fmaf(lb[0], wb[0], la[0]) + (lc ? lc[0] : 0.f);
+    if (total) {
+      const float a = la[0], b = lb[0], c = lc ? lc[0] : 0.f, t = fmaf(b, wb[0], a) + c;
+      total[0] = t;
+      // (x - x is 0 for a finite x and NaN for NaN / +-Inf)
+      if (finite) finite[0] = ((a - a) + (b - b) + (c - c) + (t - t)) == 0.f ? 1.f : 0.f;
+    }
   }
 }
 
@@ -885,10 +890,10 @@ int pgv_adam_tick(double* pows, float* hyper, float beta1, float beta2, void* st
 
 int pgv_step_tick(double* pows, float* hyper, float beta1, float beta2, uint64_t* rng_state, uint64_t rng_inc,
                   const float* loss_a, const float* loss_b, const float* weight_b, const float* loss_c, float* total,
-                  void* stream) {
+                  float* finite, void* stream) {
   PGV_CHECK_ARG(pows && hyper && (!total || (loss_a && loss_b && weight_b)), "pgv_step_tick: bad argument");
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, pgv_stream(stream), pows, hyper, (double)beta1,
-                     (double)beta2, rng_state, rng_inc, loss_a, loss_b, weight_b, loss_c, total);
+                     (double)beta2, rng_state, rng_inc, loss_a, loss_b, weight_b, loss_c, total, finite);
   PGV_CHECK_LAUNCH("step_tick");
   return PGV_OK;
 }

@@ -145,9 +145,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, rng_advance=None, loss_total=None):
-        """``rng_advance`` = (state tensor, increment) and ``loss_total`` = (a, b, weight_b, c or None, total): bookkeeping
-        of the train step that rides in the step-counter launch (``pgv_step_tick``): the generator offset and the
-        reported total = a + b * weight_b (+ c)."""
+        """``rng_advance`` = (state tensor, increment) and ``loss_total`` = (a, b, weight_b, c or None, total[, finite]):
+        bookkeeping of the train step that rides in the step-counter launch (``pgv_step_tick``): the generator offset, the
+        reported total = a + b * weight_b (+ c) and the all-losses-finite flag."""
         g = self.param_groups[0]
         self.sync_lr()
         b1, b2 = g['betas']
@@ -157,10 +157,10 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.check(lib.pgv_adam_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2, st), "pgv_adam_tick")
         else:
             rs, inc = rng_advance if rng_advance is not None else (None, 0)
-            la, lb, wb, lc, tot = loss_total if loss_total is not None else (None,) * 5
+            la, lb, wb, lc, tot, fin = (tuple(loss_total) + (None,))[:6] if loss_total is not None else (None,) * 6
             ptr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
             _lib.check(lib.pgv_step_tick(self.pows.data_ptr(), self.hyper.data_ptr(), b1, b2, ptr(rs), int(inc), ptr(la),
-                                         ptr(lb), ptr(wb), ptr(lc), ptr(tot), st), "pgv_step_tick")
+                                         ptr(lb), ptr(wb), ptr(lc), ptr(tot), ptr(fin), st), "pgv_step_tick")
         f = self.flat
         ops.adam_step(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, self.hyper, b1, b2, g['eps'],
                       g['weight_decay'])

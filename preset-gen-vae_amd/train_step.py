@@ -142,10 +142,15 @@ class VAETrainStep:
         # recons may be a deferred value that the backward kernels deliver)
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
             total = torch.empty((), device=x.device, dtype=torch.float32)   # (written by the captured optimizer launch)
+            finite = torch.empty((), device=x.device, dtype=torch.float32)
         else:   # NaN until _optimizer_step has run: a caller of _forward_backward alone never reads garbage
             total = torch.full((), float('nan'), device=x.device, dtype=torch.float32)
-        terms = (recons.detach(), lat.detach(), beta_t, None if cont is None else cont.detach(), total)
-        return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total, '_total_terms': terms,
+            finite = torch.zeros((), device=x.device, dtype=torch.float32)
+        # 'finite': 1.0 when every loss term of the step is finite (pgv_step_tick) - what the reference's harness tests with
+        # utils.exception.check_nan_values before it raises ModelConvergenceError (train.py:245), here without a launch or a
+        # synchronisation of its own: a harness reads it when it logs (``if not out['finite']: raise ...``)
+        terms = (recons.detach(), lat.detach(), beta_t, None if cont is None else cont.detach(), total, finite)
+        return {'recons': recons.detach(), 'latent': lat.detach(), 'total': total, 'finite': finite, '_total_terms': terms,
                 'controls': None if cont is None else cont.detach(), 'z_mu_logvar': z_mu_logvar.detach(),
                 'x_out': x_out.detach(), 'monitors': mon}
 
