@@ -234,9 +234,12 @@ def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, 
             return torch.where(act_masks['dec8' + tag], y, y.detach().clamp(-1.0, 1.0))
         return F.hardtanh(y)                                             # decoder.py:98,219
 
-    n_ch = 1
+    n_ch, width = 1, 512
     if arch == 'speccnn8l1_bn':
-        n_ch = _find(sd, 'dec1tconv.weight', 'decoder.').shape[1] // 512  # un-mixer: 2048 -> C*512 (decoder.py:72-75)
+        # un-mixer: 2048 -> C * last_4x4conv_ch (decoder.py:72-75; 512, or 1800 under force_bigger_network: decoder.py:70),
+        # split into chunks of that width (decoder.py:85-86) = the input channels of the first 4x4 block
+        width = _find(sd, 'dec2tconv.weight', 'decoder.').shape[0]
+        n_ch = _find(sd, 'dec1tconv.weight', 'decoder.').shape[1] // width
     if n_ch == 1:
         for row in dec_rows:
             h = tconv_block(h, sd, row, 'decoder.', training, new_buffers, taps, act_masks)
@@ -244,7 +247,7 @@ def decoder_forward(sd, z, arch, training, dropout_mask=None, new_buffers=None, 
     # stacked spectrograms (decoder.py:85-92): un-mix, split along channels, the shared stack once per chunk
     h = tconv_block(h, sd, dec_rows[0], 'decoder.', training, new_buffers, taps, act_masks)
     outs = []
-    for ch, chunk in enumerate(torch.split(h, 512, dim=1)):
+    for ch, chunk in enumerate(torch.split(h, width, dim=1)):
         tag = '' if ch == 0 else f'#{ch}'
         for row in dec_rows[1:]:
             chunk = tconv_block(chunk, sd, row, 'decoder.', training, new_buffers, taps, act_masks, tag=tag)

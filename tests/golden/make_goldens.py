@@ -143,12 +143,12 @@ class FourLayerDecoder(nn.Module):
         return self.single_ch_cnn.dec_nn(self.mlp(z).view(-1, 64, 17, 23))
 
 
-def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False, n_ch=1):
+def build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=False, n_ch=1, force_bigger=False):
     size = (B, n_ch, 257, 347)
     if arch == 'speccnn8l1_bn':
         enc = ref_encoder.SpectrogramEncoder(arch, dim_z, size, 0.3, output_bn=output_bn,
-                                             deepest_features_mix=deepest_mix)
-        dec = ref_decoder.SpectrogramDecoder(arch, dim_z, size, 0.3)
+                                             deepest_features_mix=deepest_mix, force_bigger_network=force_bigger)
+        dec = ref_decoder.SpectrogramDecoder(arch, dim_z, size, 0.3, force_bigger_network=force_bigger)
     else:
         enc, dec = FourLayerEncoder(dim_z, output_bn), FourLayerDecoder(dim_z)
     return ref_VAE.BasicVAE(enc, dim_z, dec, True, 'Dkl')
@@ -159,8 +159,8 @@ def stack_channels(x1, n_ch):
     return torch.cat([x1] + [torch.roll(x1, shifts=37 * c, dims=3) * (1.0 - 0.2 * c) for c in range(1, n_ch)], dim=1)
 
 
-def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir, n_ch=1, deepest_mix=False):
-    vae = build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=deepest_mix, n_ch=n_ch).double()
+def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir, n_ch=1, deepest_mix=False, force_bigger=False):
+    vae = build_reference_vae(arch, dim_z, B, output_bn, deepest_mix=deepest_mix, n_ch=n_ch, force_bigger=force_bigger).double()
     template = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
     sd = vo.closed_form_state_dict(template, seed=1234, dtype=torch.float64)
     vae.load_state_dict(sd)
@@ -176,6 +176,7 @@ def run_vae_case(arch, dim_z, B, output_bn, tag, out_dir, n_ch=1, deepest_mix=Fa
     out = {'meta/arch': np.array(arch), 'meta/dim_z': np.array(dim_z), 'meta/B': np.array(B),
            'meta/output_bn': np.array(output_bn), 'meta/seed': np.array(1234), 'meta/beta': np.array(0.2),
            'meta/lr': np.array(2e-4), 'meta/weight_decay': np.array(1e-4), 'meta/n_ch': np.array(n_ch),
+           'meta/deepest_mix': np.array(deepest_mix), 'meta/force_bigger': np.array(force_bigger),
            'meta/keys': np.array(list(template.keys())),
            'meta/shapes': np.array([' '.join(str(d) for d in v) for v in template.values()]),
            'in/eps': eps.numpy(), 'in/enc_mask_bits': np.packbits((enc_mask > 0).numpy()),
@@ -430,6 +431,42 @@ def run_regstep_case(out_dir):
     np.savez_compressed(path, **out)
     print('regstep recons', recons.item(), 'lat', lat.item(), 'cont', cont.item(), '->', path,
           os.path.getsize(path) // 1024, 'KiB')
+
+
+def run_extended_keys_case(out_dir):
+    """What a checkpoint of the reference holds (logs/logger.py:199-202: ``extended_ae_model.state_dict()`` and
+    ``optimizer.state_dict()``): key names, registration order and shapes of the reference's OWN ``ExtendedAE`` around its
+    BasicVAE + MLPRegression (prefixes ``ae_model.`` / ``reg_model.``), for both latent regularisations, and the layout of
+    an Adam ``state_dict()`` over ``extended_ae_model.parameters()`` after one step (train.py:166-167) - data, no source."""
+    from model import extendedAE as ref_extendedAE
+    out = {}
+    for tag, output_bn in (('none', False), ('bn', True)):
+        vae = build_reference_vae('speccnn8l1_bn', 64, 2, output_bn)
+        helper = _AllNumericalHelper()
+        reg = ref_regression.MLPRegression('3l1024', 64, helper, dropout_p=0.4, cat_softmax_activation=False)
+        ext = ref_extendedAE.ExtendedAE(vae, reg, helper, 0.3)
+        sd = ext.state_dict()
+        out[f'{tag}/keys'] = np.array(list(sd.keys()))
+        out[f'{tag}/shapes'] = np.array([' '.join(str(d) for d in v.shape) for v in sd.values()])
+        out[f'{tag}/dtypes'] = np.array([str(v.dtype) for v in sd.values()])
+        out[f'{tag}/param_names'] = np.array([k for k, _ in ext.named_parameters()])
+        if tag == 'none':
+            opt = torch.optim.Adam(ext.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+            for p_ in ext.parameters():
+                p_.grad = torch.zeros_like(p_)
+            opt.step()
+            osd = opt.state_dict()
+            out['adam/top_keys'] = np.array(sorted(osd.keys()))
+            out['adam/group_keys'] = np.array(sorted(k for k in osd['param_groups'][0].keys()))
+            out['adam/n_params'] = np.array(len(osd['param_groups'][0]['params']))
+            out['adam/param_ids'] = np.array(osd['param_groups'][0]['params'])
+            out['adam/state_entry_keys'] = np.array(sorted(osd['state'][0].keys()))
+            out['adam/state_shapes'] = np.array([' '.join(str(d) for d in osd['state'][i]['exp_avg'].shape)
+                                                 for i in range(len(osd['state']))])
+            out['adam/step_after_one'] = np.array(float(osd['state'][0]['step']))
+    path = os.path.join(out_dir, 'extended_keys.npz')
+    np.savez_compressed(path, **out)
+    print('extended_keys', len(out['none/keys']), 'keys ->', path, os.path.getsize(path) // 1024, 'KiB')
 
 
 def run_regstep_cat_case(out_dir):
@@ -722,6 +759,15 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'stacked':
         run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        # the reference's other encoder variants (encoder.py:54-70): stacked channels mixed by the deepest 1x1 layer
+        # (512 * n_ch -> 1024), and the 1800-channel 4x4 layer of force_bigger_network (decoder.py:36,70 mirror it)
+        run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2_mix', HERE, n_ch=2, deepest_mix=True)
+        run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_big', HERE, force_bigger=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'extended_keys':
+        run_extended_keys_case(HERE)
+        sys.exit(0)
     run_regression_case(HERE)
     run_layer_cases(HERE)
     run_stft_cases(HERE)
@@ -729,6 +775,9 @@ if __name__ == '__main__':
     run_vae_case('speccnn8l1_bn', 64, 2, True, 'vae8l_b2_outbn', HERE)
     run_vae_case('speccnn4l1_bn', 64, 2, False, 'vae4l_b2', HERE)
     run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2', HERE, n_ch=2, deepest_mix=False)
+    run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_c2_mix', HERE, n_ch=2, deepest_mix=True)
+    run_vae_case('speccnn8l1_bn', 64, 2, False, 'vae8l_b2_big', HERE, force_bigger=True)
+    run_extended_keys_case(HERE)
     run_vae_case('speccnn8l1_bn', 64, 16, False, 'vae8l_b16', HERE)       # B = 16 capture
     run_vae_case('speccnn4l1_bn', 64, 16, False, 'vae4l_b16', HERE)
     # the reference's DEFAULT regularisation ('bn': BatchNorm1d on the encoder output, config.py:92) at the capture size

@@ -481,9 +481,13 @@ def test_fused_reconstruction_criterion_matches_separate(normalize):
         assert rel_l2(g1[k], g2[k]) < 1e-4, k
 
 
-def test_train_step_stacked_channels_f3():
+@pytest.mark.parametrize("golden", ['vae8l_b2_c2.npz', 'vae8l_b2_c2_mix.npz', 'vae8l_b2_big.npz'])
+def test_train_step_stacked_channels_f3(golden):
     """two stacked spectrogram channels (the shared per-channel stacks applied once per channel, 1x1
-    features mixer / un-mixer with channel split) against the reference golden and the float64 oracle."""
+    features mixer / un-mixer with channel split) against the reference golden and the float64 oracle - mixed by the 4x4 +
+    1x1 pair (``deepest_features_mix=False``) and by the deepest 1x1 layer alone (512 * 2 -> 1024, encoder.py:54-58) - and
+    the single-channel ``force_bigger_network`` stack (1800-channel 4x4 layers, encoder.py:62-63, decoder.py:36,70), built
+    through the config fields that select them in the reference (build.py:13-16)."""
     from oracle import vae_oracle as vo
     from preset_gen_vae_amd.train_step import VAETrainStep
     import copy
@@ -491,11 +495,15 @@ def test_train_step_stacked_channels_f3():
     from preset_gen_vae_amd.model import build
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
-    g = load_golden('vae8l_b2_c2.npz')
+    g = load_golden(golden)
     arch, dim_z, B, n_ch = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B']), int(g['meta/n_ch'])
     mc, tc = copy.copy(config.model), copy.copy(config.train)
     mc.encoder_architecture, mc.dim_z, mc.input_tensor_size = arch, dim_z, (B, n_ch, 257, 347)
-    mc.midi_notes, mc.stack_spectrograms = ((60, 85), (72, 100)), True
+    # several MIDI notes: stacked as channels, or (force_bigger_network, build.py:16) fed one at a time to a wider network
+    mc.midi_notes, mc.stack_spectrograms = ((60, 85), (72, 100)), n_ch > 1
+    mc.concat_midi_to_z = False
+    mc.stack_specs_deepest_features_mix = bool(g['meta/deepest_mix']) if 'meta/deepest_mix' in g.files else False
+    assert (n_ch == 1) == (bool(g['meta/force_bigger']) if 'meta/force_bigger' in g.files else False)
     tc.minibatch_size, tc.latent_flow_input_regularization = B, 'none'
     _, _, ae = build.build_ae_model(mc, tc)
     tpl = template_from_meta(g)
@@ -529,12 +537,23 @@ def test_train_step_stacked_channels_f3():
         ref = float(g['train/' + key])
         assert abs(out[key].item() - ref) <= max(1e-5, 4 * abs(ora32[key].item() - ora[key].item()) / abs(ref)) * abs(ref)
     params = dict(ae.named_parameters())
+    ratios, over = [], []
     for k, gr in ora['grads'].items():
         if gr.abs().max().item() < 1e-9:
             continue
-        # (no activation-region pinning here: allow for one flipped LeakyReLU element, see test_train_step_parity)
+        # (no activation-region pinning here - the recorder of test_train_step_parity follows single-channel stacks - so
+        # LeakyReLU elements within float32 rounding of their kink may take the other slope, differently from run to run
+        # (BatchNorm statistics are float atomics): at B = 2 one such element moves ONE parameter's gradient by 1 - 3e-2
+        # (seen: enc2conv.weight 1.3e-2 on the deepest-mixer golden, dec3tconv.bias 2.5e-2 on the 1800-channel one, in one
+        # run of three), the rest stay below 3e-3.  A wrong backward product lifts EVERY gradient upstream of it: at most two
+        # parameters may exceed SURVEY 8c's 1e-2, none 5e-2, and the median must stay below 2e-3)
         r, noise = rel_l2(params[k].grad, gr), rel_l2(ora32['grads'][k], gr)
-        assert r < max(1e-2, 4 * noise), (k, r, noise)
+        ratios.append(r)
+        if r >= max(1e-2, 4 * noise):
+            over.append((k, r, noise))
+        assert r < max(5e-2, 4 * noise), (k, r, noise)
+    assert len(over) <= 2, over
+    assert sorted(ratios)[len(ratios) // 2] < 2e-3, sorted(ratios)
     sd_new = ae.state_dict()
     for k, v in ora['new_sd'].items():
         if 'running' in k:

@@ -72,6 +72,40 @@ def test_fp32_products_default_is_what_bench_times_and_is_reachable_from_the_tra
         ops.set_fp32_products(before)
 
 
+def test_extended_model_checkpoint_layout_matches_the_reference():
+    """What the reference writes into a checkpoint (logs/logger.py:199-202: ``extended_ae_model.state_dict()`` +
+    ``optimizer.state_dict()``) against tests/golden/extended_keys.npz, recorded from the reference's own ExtendedAE
+    around its BasicVAE + MLPRegression: key names, registration order, shapes and dtypes of the extended model for both
+    latent regularisations, and the layout of Adam's state dict over its parameters."""
+    from preset_gen_vae_amd.model import build
+    from preset_gen_vae_amd import optim as optim_mod
+    g = load_golden('extended_keys.npz')
+
+    class Helper:
+        learnable_preset_size = 144
+
+    for tag, output_bn in (('none', False), ('bn', True)):
+        mc, tc = _cfg('speccnn8l1_bn', B=2, output_bn=output_bn)
+        _, _, _, ext = build.build_extended_ae_model(mc, tc, Helper())
+        sd = ext.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g[f'{tag}/keys']]
+        assert [' '.join(str(d) for d in v.shape) for v in sd.values()] == [str(x) for x in g[f'{tag}/shapes']]
+        assert [str(v.dtype) for v in sd.values()] == [str(x) for x in g[f'{tag}/dtypes']]
+        assert [k for k, _ in ext.named_parameters()] == [str(k) for k in g[f'{tag}/param_names']]
+    assert any(k.startswith('ae_model.encoder.') for k in sd) and any(k.startswith('reg_model.reg_model.') for k in sd)
+    # optimizer.state_dict() (recorded on the 'none' variant): same top-level / group / per-parameter entries, one entry per
+    # parameter in registration order
+    mc, tc = _cfg('speccnn8l1_bn', B=2, output_bn=False)
+    params = list(build.build_extended_ae_model(mc, tc, Helper())[3].parameters())
+    assert len(params) == int(g['adam/n_params']) and list(range(len(params))) == [int(i) for i in g['adam/param_ids']]
+    assert [' '.join(str(d) for d in p.shape) for p in params] == [str(x) for x in g['adam/state_shapes']]
+    assert [str(k) for k in g['adam/top_keys']] == ['param_groups', 'state']
+    assert {'exp_avg', 'exp_avg_sq', 'step'} <= {str(k) for k in g['adam/state_entry_keys']}
+    assert {'lr', 'betas', 'eps', 'weight_decay', 'amsgrad', 'params'} <= {str(k) for k in g['adam/group_keys']}
+    assert float(g['adam/step_after_one']) == 1.0
+    assert hasattr(optim_mod.FusedAdam, 'state_dict') and hasattr(optim_mod.FusedAdam, 'load_state_dict')
+
+
 def test_builder_surface_and_errors():
     from preset_gen_vae_amd.model import VAE, build, extendedAE, regression
 

@@ -32,13 +32,16 @@ def reference_template(g):
 
 
 @pytest.mark.parametrize("name", ["vae8l_b2.npz", "vae8l_b2_outbn.npz", "vae4l_b2.npz", "vae8l_b2_c2.npz",
+                                  "vae8l_b2_c2_mix.npz", "vae8l_b2_big.npz",
                                   "vae8l_b16.npz", "vae4l_b16.npz", "vae8l_b16_outbn.npz", "vae4l_b16_outbn.npz"])
 def test_train_step_matches_reference(name):
     g = load_golden(name)
     arch, dim_z, B = str(g['meta/arch']), int(g['meta/dim_z']), int(g['meta/B'])
     n_ch = int(g['meta/n_ch']) if 'meta/n_ch' in g.files else 1
-    # stacked spectrograms: the template travels with the golden (mixer shapes depend on the channels)
-    tpl = template_from_meta(g) if n_ch > 1 else reference_template(g)
+    variant = n_ch > 1 or ('meta/force_bigger' in g.files and bool(g['meta/force_bigger']))
+    # stacked spectrograms and the reference's other encoder variants (encoder.py:54-70: deepest 1x1 mixer,
+    # force_bigger_network): the template travels with the golden (mixer shapes depend on the variant)
+    tpl = template_from_meta(g) if variant else reference_template(g)
     sd = vo.closed_form_state_dict(tpl, seed=int(g['meta/seed']), dtype=torch.float64)
     x = stack_channels(synth_input(B), n_ch)
     eps = torch.tensor(g['in/eps'])
