@@ -493,6 +493,43 @@ def _cpu_model():
     return None
 
 
+def _frontend_cpu_worker(job):
+    """One worker process of the all-cores CPU front-end baseline: per-item loop for ``seconds``, returns the item count."""
+    seed, seconds = job
+    from oracle import audio_oracle as ao   # CPU baseline leg only
+    from preset_gen_vae_amd.utils.synthetic import fm_voice
+    waves = [fm_voice(idx=seed * 4 + i) for i in range(4)]
+    ao.minmax_normalize(ao.mel_spectrogram_db(waves[0], dtype=np.float32), -120.0, 0.0)   # (warm-up: plans, basis)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        ao.minmax_normalize(ao.mel_spectrogram_db(waves[n % 4], dtype=np.float32), -120.0, 0.0)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+_FRONTEND_ALL_CORES = None
+
+
+def frontend_cpu_all_cores(seconds=5.0):
+    """BASELINE.md section 4 asks for the front-end's CPU baseline on all host cores as well as on one: the reference's
+    DataLoader runs its per-item ``__getitem__`` loop (data/abstractbasedataset.py:126-134) in worker processes, so this leg
+    does the same - one forked worker per core, each looping over items for ``seconds``.  It runs at the very start of
+    bench.py, BEFORE this process makes its first GPU call (a process that has initialised HIP must not fork workers)."""
+    global _FRONTEND_ALL_CORES
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    try:
+        with mp.get_context('fork').Pool(cores) as pool:
+            res = pool.map(_frontend_cpu_worker, [(i, seconds) for i in range(cores)])
+        _FRONTEND_ALL_CORES = {'value': round(sum(n / t for n, t in res), 2), 'unit': 'waveforms/s', 'cores': cores,
+                               'kind': 'port',
+                               'sample': f'{sum(n for n, _ in res)} items over {cores} worker processes x {seconds:.0f} s, numpy '
+                                         f'float32, per-item loop as data/abstractbasedataset.py:126-134'}
+    except (OSError, ValueError) as e:   # (no fork / no semaphores in a sandbox: report why instead of a number)
+        _FRONTEND_ALL_CORES = {'value': None, 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port', 'sample': f'not measured: {e}'}
+    return _FRONTEND_ALL_CORES
+
+
 def frontend_figures(device, B=256, iters=10, cpu_seconds=6.0):
     """the STFT -> mel -> dB -> min-max front-end on its own - GPU waveforms/s (HIP events over replays
     of the batched kernel, inputs resident) against its HBM roofline (0.711 MB per spectrogram), and the CPU restatement
@@ -518,7 +555,8 @@ def frontend_figures(device, B=256, iters=10, cpu_seconds=6.0):
             'roofline': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(gbs / HBM_PEAK_GBS, 5)},
             'cpu_baseline': {'value': round(cpu, 2), 'unit': 'waveforms/s', 'cores': 1, 'kind': 'port',
-                             'sample': f'{n} items, numpy float32, per-item loop as data/abstractbasedataset.py:126-134'}}
+                             'sample': f'{n} items, numpy float32, per-item loop as data/abstractbasedataset.py:126-134'},
+            'cpu_baseline_all_cores': _FRONTEND_ALL_CORES}
 
 
 def h2d_inclusive(step, x, steps=10):
@@ -639,11 +677,6 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     sync = None
     if dist_on:
         sync = (lambda flat: parallel.GradAllReduce(flat, n_buckets=args.buckets))
-    def make_step(graph):
-        return VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
-                            beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=graph,
-                            graph_buckets=args.dist_mode == 'bucket-graphs')
-    step = make_step(use_graph)
     launch_fallback = None
 
     frontend = None
@@ -661,25 +694,48 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
             frontend.batch(wav, out=xin)
         return step.step(xin)
 
-    try:
-        for _ in range(args.warmup):
-            out = one_step(x)
-    except RuntimeError as e:
-        # N > 1 only: the captured launch modes have run over gloo and over a 1-rank RCCL communicator, never over RCCL on
-        # several GPUs.  A capture that fails there fails on every rank alike (same program, same order); the line is then
-        # measured with eager launches and says so, instead of the scaling run ending without a number.
-        if not (dist_on and use_graph):
-            raise
-        launch_fallback = f"{args.dist_mode} failed ({str(e).splitlines()[0][:160]}); eager launches instead"
-        print(f"[bench rank {rank}] {launch_fallback}", file=sys.stderr, flush=True)
-        if step.grad_sync is not None:
+    # N > 1: the captured launch modes have run over gloo and over a 1-rank RCCL communicator, never over RCCL on several
+    # GPUs (no SCALE record exists).  So the launch mode is chosen by a LADDER - the requested mode, then two-graph (the same
+    # kernels, one eager exchange between two replays), then eager - and every rung is tried with at least one protected
+    # warm-up step (also with --warmup 0: the capture never happens inside the timed loop), after which the ranks AGREE on
+    # the outcome (MAX all-reduce of a failure flag) before any of them goes on: a rank whose capture failed never leaves
+    # the others waiting in a collective of a mode it has abandoned.
+    ladder = [args.dist_mode] + [m for m in ('two-graph', 'eager') if m != args.dist_mode] if (dist_on and use_graph) \
+        else [args.dist_mode if dist_on else 'single']
+    step, failures = None, []
+    for mode in ladder:
+        graph = use_graph and mode != 'eager'
+        err = None
+        try:
+            step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
+                                beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=graph,
+                                graph_buckets=mode == 'bucket-graphs')
+            for _ in range(max(1, args.warmup) if dist_on else args.warmup):
+                out = one_step(x)
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            if not (dist_on and graph):
+                raise
+            err = str(e).splitlines()[0][:160]
+        failed = torch.tensor([1.0 if err else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if failed.item() == 0.0:
+            args = copy.copy(args)
+            args.dist_mode, use_graph = (mode if dist_on else args.dist_mode), graph
+            break
+        failures.append(f"{mode} failed ({err or 'on another rank'})")
+        print(f"[bench rank {rank}] {failures[-1]}; trying the next launch mode", file=sys.stderr, flush=True)
+        if step is not None and step.grad_sync is not None:
             step.grad_sync.uninstall()
-        del step
+        step = None
         torch.cuda.synchronize()
-        use_graph = False
-        step = make_step(False)
-        for _ in range(max(1, args.warmup)):
-            out = one_step(x)
+    if step is None:
+        raise SystemExit("bench.py: no launch mode of the N > 1 step worked: " + "; ".join(failures))
+    if failures:
+        launch_fallback = "; ".join(failures) + f"; measured with {args.dist_mode} launches instead"
+    if step.grad_sync is not None and dist_on:
+        step.grad_sync.time_buckets(True)      # event pairs around every bucket's collective (reported per bucket)
     if step.static_input is not None:
         # the minibatch lives in the captured step's input buffer (where the on-GPU front-end / the H2D copy of a real
         # loader would put it): inputs are resident in HBM when the timed region starts, no device-to-device copy
@@ -694,6 +750,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         out = one_step(x)
     torch.cuda.synchronize()
     n_coll = (step.grad_sync.n_collectives - n_coll0) if step.grad_sync is not None else 0
+    bucket_ms = step.grad_sync.bucket_times_ms() if (step.grad_sync is not None and dist_on) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -734,7 +791,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
             if dist_on and args.dist_mode == 'two-graph':
                 launch = "2 hipGraphs + eager all-reduce"
             elif dist_on:
-                launch = (f"{len(step._bucket_graphs) + 1} hipGraphs cut at the gradient buckets, all-reduce of a bucket "
+                launch = (f"{sum(1 for g_, _ in step._bucket_graphs if g_ is not None) + 1} hipGraphs cut at the gradient buckets, all-reduce of a bucket "
                           f"launched between two replays (overlaps the rest of backward)")
         cfg = {"workload": f"{args.arch} conv-VAE dz={args.dim_z} {args.dtype} full train step "
                            f"(fwd, MSE+0.2*KL, bwd, Adam), batch {args.batch}/GPU, 1x257x347 log-mel"
@@ -751,11 +808,15 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
                 if ops.fp32_products() != 'native' else "native: v_mfma_f32_16x16x4_f32 / fp32 FMA everywhere")
         if launch_fallback:
             cfg["launch_fallback"] = launch_fallback
+            cfg["launch"] = launch + " - FALLBACK: " + launch_fallback
         if dist_on:
             cfg["rccl_ranks"] = dist.get_world_size()
             cfg["backend"] = dist.get_backend()
             cfg["grad_buckets_bytes"] = [4 * (hi - lo) for lo, hi in step.grad_sync.ranges]
             cfg["collective_launches_per_step"] = n_coll / max(1, args.steps)
+            cfg["collective_ms_per_bucket"] = bucket_ms      # (events on the communication stream, timed steps only)
+            cfg["multi_gpu_status"] = ("measured on %d ranks in this run" % world) if world > 1 else \
+                "UNMEASURED on more than one GPU: the N > 1 launch path run over a 1-rank communicator (--force-dist)"
         line = {
             "metric": "spectrograms/sec per VAE train step (batch 256, 1x257x347)", "value": round(value, 2),
             "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -816,6 +877,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}, or without a launcher (bench.py then starts its own ranks)")
+    if world == 1 and not args.no_cpu_baseline and not args.force_dist:
+        frontend_cpu_all_cores()   # (forks worker processes: before the first GPU call of this process)
     import torch.distributed as dist
     from preset_gen_vae_amd import _lib
     _lib.load()   # fails loudly if the HIP library is missing

@@ -784,16 +784,21 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
         rc = pgv_conv_wgrad_band_partial(d, big, big_scale, big_shift, small_in, small_scale, small_shift, (float*)workspace,
                                          workspace_bytes, &nparts, st);
     }
-    if (rc <= 0) return rc;
-    const int n4 = d->Cs * d->Cb * 16 / 4;
-    if (req) {
-      rc = launch_wgrad_reduce_taps(d, req, bias, big, small_in, (const float*)workspace, nparts, n4, gw, st);
-      if (rc) return rc < 0 ? rc : 3;
+    if (rc < 0) return rc;
+    if (rc > 0) {
+      const int n4 = d->Cs * d->Cb * 16 / 4;
+      if (req) {
+        rc = launch_wgrad_reduce_taps(d, req, bias, big, small_in, (const float*)workspace, nparts, n4, gw, st);
+        if (rc) return rc < 0 ? rc : 3;
+      }
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8 + bias_blocks(bias)), dim3(256), 0, st, (const float*)workspace,
+                         nparts, n4, gw, (d->flags & PGV_PREZEROED) ? 1 : 0, bias_fin(bias), (n4 + 7) / 8);
+      PGV_CHECK_LAUNCH("conv_wgrad_band reduce");
+      return 1;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 7) / 8 + bias_blocks(bias)), dim3(256), 0, st, (const float*)workspace,
-                       nparts, n4, gw, (d->flags & PGV_PREZEROED) ? 1 : 0, bias_fin(bias), (n4 + 7) / 8);
-    PGV_CHECK_LAUNCH("conv_wgrad_band reduce");
-    return 1;
+    if (d->flags & PGV_COMPUTE_BF16) return 0;
+    // fp32, six-instruction form not applicable to this call (workspace smaller than one partial gradient per workgroup, or a
+    // tensor of 2 GB and more - B >= ~3000 on 129x174): the native wave-specialised kernels below, not the generic fallbacks
   }
   if (d->Hb == 33 && d->Wb == 45)
     return launch_wgrad_v2<32, 64, 45, 33, 3>(d, big, big_scale, big_shift, small_in, small_scale, small_shift, gw,

@@ -41,6 +41,10 @@ class GradAllReduce:
         self._works = []
         self._on_bucket = None
         self.n_collectives = 0     # bucket launches so far (also counted on one rank, where the collective is skipped)
+        # optional timing of every bucket's collective with events on the communication stream (``time_buckets(True)``;
+        # bench.py reports the averages): [(bucket, start event, end event)], read by ``bucket_times_ms``
+        self._time = False
+        self._timed = []
 
     # -- hooks ---------------------------------------------------------------------------------------------
     def install(self):
@@ -91,9 +95,30 @@ class GradAllReduce:
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self._time:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                if self._time:
+                    e1.record(self.comm_stream)
+                    self._timed.append((bi, e0, e1))
         else:  # gloo / CPU tests
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def time_buckets(self, on=True):
+        """Record an event pair around every bucket's all-reduce on the communication stream from now on."""
+        self._time, self._timed = bool(on), []
+
+    def bucket_times_ms(self):
+        """Average device time of each bucket's collective since ``time_buckets(True)`` (synchronises; None for a bucket
+        that was never launched - always on one rank, where no collective is issued)."""
+        if self.use_cuda:
+            torch.cuda.synchronize()
+        sums, counts = [0.0] * len(self.ranges), [0] * len(self.ranges)
+        for bi, e0, e1 in self._timed:
+            sums[bi] += e0.elapsed_time(e1)
+            counts[bi] += 1
+        return [round(s_ / c, 4) if c else None for s_, c in zip(sums, counts)]
 
     def exchange(self):
         """All buckets at once, after everything already queued on the compute stream (the graph launch mode: the

@@ -198,7 +198,8 @@ class VAETrainStep:
         if self._bucket_graphs is not None:
             self.grad_sync.start_step()
             for graph, ready in self._bucket_graphs:
-                graph.replay()
+                if graph is not None:
+                    graph.replay()
                 for bi in ready:                 # behind an event of the compute stream, on the communication stream
                     self.grad_sync.launch_bucket(bi)
             self.grad_sync.wait()                # (buckets nobody announced + join of the two streams)
@@ -228,9 +229,23 @@ class VAETrainStep:
         moves it into the captured step's input buffer with one device-to-device copy (91 MB: ~35 us) in front of the
         replay.  The captured step reads its input until the end of backward (the first layer's weight gradient), so a
         loader that wrote into ``static_input`` directly would have to wait for the whole step - 1.7 ms of PCIe time in
-        series with 1.9 ms of step; this way the two overlap.  One minibatch in flight at a time."""
+        series with 1.9 ms of step; this way the two overlap.  One minibatch in flight at a time.
+
+        ``host_x``: same shape and dtype as the captured input, pinned.  The caller must leave it untouched until the copy
+        has been made: ``stage_ready`` (a ``torch.cuda.Event`` recorded behind the copy) tells - ``stage_ready.synchronize()``
+        or ``.query()`` before the loader reuses the buffer; ``step_prefetched`` waits for it on the device."""
+        if not self.use_graph:
+            raise RuntimeError("prefetch_input / step_prefetched belong to the graph mode (use_graph=True): an eager step "
+                               "reads the tensor it is given, there is no captured input buffer to stage into")
         if self._static_x is None:
             raise RuntimeError("prefetch_input: run one step first (the captured step's input buffer does not exist yet)")
+        if tuple(host_x.shape) != tuple(self._static_x.shape) or host_x.dtype != self._static_x.dtype:
+            raise ValueError(f"prefetch_input: expected a {tuple(self._static_x.shape)} {self._static_x.dtype} minibatch (the "
+                             f"captured step's shape; a short last batch must be padded or stepped eagerly), got "
+                             f"{tuple(host_x.shape)} {host_x.dtype}")
+        if not host_x.is_cuda and not host_x.is_pinned():
+            raise ValueError("prefetch_input: the host minibatch must be in pinned memory (torch.Tensor.pin_memory / "
+                             "DataLoader(pin_memory=True)): a pageable source makes the copy synchronous - no overlap")
         if self._stage_x is None:
             self._stage_x = torch.empty_like(self._static_x)
             self._copy_stream = torch.cuda.Stream(device=self._static_x.device)
@@ -253,6 +268,12 @@ class VAETrainStep:
         self._stage_free.record(cur)
         self._stage_pending = False
         return self.step(self._static_x, v_in)
+
+    @property
+    def stage_ready(self):
+        """Event recorded behind the last ``prefetch_input`` copy (None before the first): the host buffer handed to
+        ``prefetch_input`` may be reused once it has completed."""
+        return getattr(self, '_stage_ready', None)
 
     @property
     def static_input(self):
@@ -334,8 +355,18 @@ class VAETrainStep:
             state['graph'], state['ready'] = g, []
 
         def cut():
-            state['graph'].capture_end()
-            graphs.append((state['graph'], state['ready']))
+            # (a capture that recorded no launch - the tail behind the last bucket: backward ends with the gradient that
+            # completes it - is not kept: replaying an empty graph every step costs a launch for nothing; torch reports
+            # such a capture with a warning, which is the only way to tell)
+            import warnings
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
+                state['graph'].capture_end()
+            empty = any('empty' in str(w.message).lower() for w in caught)
+            if not empty or not graphs:
+                graphs.append((state['graph'], state['ready']))
+            elif state['ready']:
+                graphs.append((None, state['ready']))
 
         def on_bucket(bi):                       # called by GradAllReduce in place of the collective launch
             state['ready'].append(bi)

@@ -428,10 +428,12 @@ def test_two_graph_launch_mode_matches_single_graph():
         torch.cuda.synchronize()
         assert (step._graph_update is not None) == two_graphs
         if mode == 'bucket-graphs':
-            # the step was cut where each of the 3 buckets became complete: 3 graphs that end with a bucket + the rest of
-            # backward (+ the optimizer graph); every bucket is launched once per step, between two replays
+            # the step was cut where each of the 3 buckets became complete: 3 graphs that end with a bucket (+ the optimizer
+            # graph); the capture behind the last bucket records no launch and is not kept (round 5 replayed that empty
+            # graph every step); every bucket is launched once per step, between two replays
             # (2 capture warm-ups + 3 replayed steps, 3 buckets each)
-            assert [r for _, r in step._bucket_graphs] == [[0], [1], [2], []]
+            assert [r for _, r in step._bucket_graphs] == [[0], [1], [2]]
+            assert all(g_ is not None for g_, _ in step._bucket_graphs)
             assert step.grad_sync.n_collectives == 15
         # (conv biases in front of a BatchNorm have a mathematically zero gradient: Adam turns their float noise into
         # +-lr updates, so they are not comparable between any two runs)
@@ -737,6 +739,16 @@ def test_prefetched_minibatches_equal_direct_steps():
                 ls.append(out['total'].item())
             with pytest.raises(RuntimeError):
                 step.step_prefetched()
+            # what a loader can get wrong is refused with a message, not broadcast or copied synchronously:
+            # a short last batch, another dtype, pageable memory; the event behind the copy says when the buffer is free
+            assert step.stage_ready is not None
+            step.stage_ready.synchronize()
+            with pytest.raises(ValueError, match="expected a"):
+                step.prefetch_input(hosts[0][:1].contiguous().pin_memory())
+            with pytest.raises(ValueError, match="expected a"):
+                step.prefetch_input(hosts[0].double().pin_memory())
+            with pytest.raises(ValueError, match="pinned"):
+                step.prefetch_input(xs[1].float().contiguous())
         losses.append(ls)
     # (two runs of the same steps agree to summation-order level - float atomics in the BatchNorm statistics - and drift apart
     # by the Adam steps in between: 7e-8 on the first loss, up to 3e-5 on the fourth; a stale or torn minibatch would show
@@ -744,6 +756,10 @@ def test_prefetched_minibatches_equal_direct_steps():
     for i, (a, b) in enumerate(zip(*losses)):
         assert abs(a - b) <= (1e-6 if i == 0 else 2e-4) * abs(a), (i, losses)
     assert all(abs(losses[0][i + 1] - losses[0][i]) > 1e-2 * losses[0][i] for i in range(3)), losses
+    eager = VAETrainStep(_build('speccnn4l1_bn', 64, B, True).cuda().train(), use_graph=False)
+    eager.step(_cuda32(xs[0]))
+    with pytest.raises(RuntimeError, match="graph mode"):
+        eager.prefetch_input(xs[1].float().contiguous().pin_memory())
 
 
 def test_graph_replay_equals_eager():
