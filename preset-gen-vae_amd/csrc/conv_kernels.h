@@ -147,8 +147,9 @@ int pgv_conv_down_deep_split(const pgv_conv_desc* d, const float* big, const flo
 int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
                            const pgv_bn_src* bn);
-// ... and of the large-plane layers of the 4-layer stack (conv_big_split.hip): two teams of waves alternating between the
-// matrix pipe and the epilogue / staging work, weights in registers
+// ... and of the large-plane layers of the 4-layer stack (conv_big_split.hip): one 512-thread workgroup per CU, persistent
+// over (sample, band) units; per unit a matrix phase in which all eight waves multiply (weights in registers, in fragment
+// order) and a vector phase in which they split and commit the next unit's band and move the output tile out
 bool pgv_big_split_shape(const pgv_conv_desc* d);
 int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
