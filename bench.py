@@ -453,7 +453,7 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     # 256 (the same labels on another model / operand mode are other kernels or other fusions)
     traffic = None
     try:
-        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r5_traffic.json')) as f:
+        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r6_traffic.json')) as f:
             entry = json.load(f).get(worst['launch'])
         if entry and B == 256 and traffic_ok:
             traffic = entry['hbm_bytes_per_launch']
@@ -479,6 +479,15 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
             'selection': 'lowest roofline fraction among launches >= 2 % of the step',
             'conv_launches_sum_roofline_ms': round(sum(r['ms'] * r['frac'] for r in conv), 4),
             'conv_launches_sum_ms': round(sum(r['ms'] for r in conv), 4)}
+    # the WHOLE step against its roofline: sum over every launch of the table of its own bound - max(algorithmic
+    # bytes / 8 TB/s, flops / matrix peak of the instruction it uses) - divided by the measured time of a step; 'hbm_frac' =
+    # the step's algorithmic bytes / step time against 8 TB/s alone
+    t_roof = sum(r['ms'] * r['frac'] for r in priced)
+    all_bytes = sum(r['bytes'] for r in priced)
+    roof['step'] = {'sum_of_launch_rooflines_ms': round(t_roof, 4), 'ms_per_step': round(step_ms, 4),
+                    'frac': round(t_roof / step_ms, 5), 'algorithmic_bytes': int(all_bytes),
+                    'hbm_frac': round(all_bytes / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5),
+                    'sum_of_launch_times_ms': round(sum(r['ms'] for r in rows), 4)}
     return roof, rows
 
 
@@ -769,11 +778,11 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     if rank == 0 and with_roofline:
         # the PMC passes exist for three configurations (profiles/README.md); other configurations report traffic null
         prod = ops.fp32_products() if args.dtype == 'fp32' else 'native'
-        tfile = {('speccnn4l1_bn', 'fp32', 64, 'bf16x6'): 'r5_traffic.json',
-                 ('speccnn8l1_bn', 'fp32', 64, 'bf16x6'): 'r5_traffic_8l.json',
-                 ('speccnn4l1_bn', 'fp32', 64, 'native'): 'r5_traffic_native.json',
-                 ('speccnn8l1_bn', 'fp32', 64, 'native'): 'r5_traffic_8l_native.json',
-                 ('speccnn8l1_bn', 'bf16', 512, 'native'): 'r5_traffic_8l_bf16.json'}.get((args.arch, args.dtype, args.dim_z, prod))
+        tfile = {('speccnn4l1_bn', 'fp32', 64, 'bf16x6'): 'r6_traffic.json',
+                 ('speccnn8l1_bn', 'fp32', 64, 'bf16x6'): 'r6_traffic_8l.json',
+                 ('speccnn4l1_bn', 'fp32', 64, 'native'): 'r6_traffic_native.json',
+                 ('speccnn8l1_bn', 'fp32', 64, 'native'): 'r6_traffic_8l_native.json',
+                 ('speccnn8l1_bn', 'bf16', 512, 'native'): 'r6_traffic_8l_bf16.json'}.get((args.arch, args.dtype, args.dim_z, prod))
         roof, table = measure_roofline(ae, args.batch, device, ms, BF16_MATRIX_PEAK_TFLOPS if args.dtype == 'bf16'
                                        else F32_MATRIX_PEAK_TFLOPS, frontend=frontend,
                                        traffic_file=os.path.join(ROOT, 'profiles', tfile) if tfile else None,

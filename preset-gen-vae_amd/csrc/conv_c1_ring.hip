@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256, 2) void up_c1_ring_kernel(int B, int nseg, con
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
           if (oh + ph < H) {
+#ifdef PGV_RING_EXP_ALIGNED   // timing experiment (wrong addresses): what 16-byte aligned row starts would be worth
+            float* o = out + ((int64_t)b * H * W) / 352 * 352 + (int64_t)min(oh + ph, 250) * 352 + ow;
+#else
             float* o = ob + (int64_t)(oh + ph) * W + ow;
+#endif
             float y[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = pgv_act_apply_nan(acc[ph][i >> 1][i & 1], actp);
