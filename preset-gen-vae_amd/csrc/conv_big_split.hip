@@ -85,16 +85,20 @@ __device__ __forceinline__ void ws_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n
 // DOWN: small = conv_{s2,p2,k4}(big').  GEMM: M = small channels, K = (kernel row, 8 big channels) x 4 kernel columns,
 // N = the band's output pixels.  A wave owns MW M tiles (every B fragment it reads feeds 6 MW instructions), KW K steps and
 // TMAX pixel tiles; PD = how many steps ahead it requests fragments.
-template <int CB_, int CS_, int H_, int W_, int R_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1>
+// NPL = operand planes: 3 = fp32 products as six instructions on exact three-way splits (PGV_COMPUTE_F32_SPLIT), 1 = bf16
+// operand mode (PGV_COMPUTE_BF16: one bf16 plane per operand, rounded to nearest, one instruction per fragment pair).
+template <int CB_, int CS_, int H_, int W_, int R_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1, int NPL_ = 3>
 struct DownQ {
   static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, R = R_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_;
+  static constexpr int NPL = NPL_, NTERM = NPL_ == 3 ? 6 : 1;
+  static_assert(NPL_ == 3 || NPL_ == 1, "three planes (six product terms) or one");
   static constexpr int XR = 2 * R + 2;
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, BANDS = (Hs + R - 1) / R;
   static constexpr int NCP = CB / 2, NG = CB / 8;                     // channel pairs; K groups of 8 channels (4 pairs)
   // image: dword (pair, row, plane, column), column = input column + 4; rows of WPD dwords, pair planes CPS dwords apart with
   // CPS = 32 (mod 64): the two 16-lane halves of a read group (pairs kq, kq + 1) then sit on disjoint banks
   static constexpr int WPD = (2 * Ws + 4 + 3) / 4 * 4;
-  static constexpr int CPS = ((XR * 3 * WPD - 32 + 63) / 64) * 64 + 32;
+  static constexpr int CPS = ((XR * NPL * WPD - 32 + 63) / 64) * 64 + 32;
   static constexpr int STAGE = NCP * CPS * 4;                         // bytes
   static constexpr int KSTEPS = 4 * NG, KHW = 4 / KSPLIT, KW = KHW * NG;   // K steps; kernel rows / K steps of a wave
   static constexpr int MTN = CS / 16, MG = MTN / MW;                  // M tiles; M groups over the waves
@@ -104,8 +108,8 @@ struct DownQ {
   static constexpr int LPC = 512 / CS, QO = ((NPX + 3) / 4 + LPC - 1) / LPC;
   static constexpr size_t LDS_BYTES = (size_t)STAGE + (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CB + 8);
   static_assert(MG * KSPLIT * NSPLIT == 8 && MTN % MW == 0 && 4 % KSPLIT == 0, "eight waves");
-  static_assert(CPS >= XR * 3 * WPD && WPD >= 4 * QX + 4 && W >= 4 && LPC >= 1 && LPC <= 64 && R % 2 == 0, "tile shapes");
-  static_assert(LDS_BYTES <= 160 * 1024 && ((NG - 1) * 4 * CPS + 3 * 3 * WPD + 2 * WPD) * 4 + 16 < 65536, "LDS budget / immediate offsets");
+  static_assert(CPS >= XR * NPL * WPD && WPD >= 4 * QX + 4 && W >= 4 && LPC >= 1 && LPC <= 64 && R % 2 == 0, "tile shapes");
+  static_assert(LDS_BYTES <= 160 * 1024 && ((NG - 1) * 4 * CPS + 3 * NPL * WPD + (NPL - 1) * WPD) * 4 + 16 < 65536, "LDS budget / immediate offsets");
 };
 
 template <class G, bool FUSE>
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
                                                      pgv_bn_src in_bn, pgv_bwd_fuse fuse QSTAMP_ARG) {
   constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, R = G::R, NPX = G::NPX;
   constexpr int NG = G::NG, WPD = G::WPD, CPS = G::CPS, OSTR = G::OSTR, LPC = G::LPC, QO = G::QO, MW = G::MW;
+  constexpr int NPL = G::NPL, NTERM = G::NTERM;
   typedef unsigned u4a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-byte LDS load from an 8-byte aligned address
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* lds_x = ldsb;
@@ -136,14 +141,14 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
     aff[CB + i] = sh;
   }
   // ---- this wave's weight fragments: M tiles mtl .. mtl + MW - 1, K steps [kg * KW, + KW), three planes
-  u32x4 af[MW][G::KW][3];
+  u32x4 af[MW][G::KW][NPL];
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw) {
-    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * G::KSTEPS + kg * G::KW) * 3) * 64 + lane;
+    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * G::KSTEPS + kg * G::KW) * NPL) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < G::KW; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[mw][k][p] = a_src[(k * 3 + p) * 64];
+      for (int p = 0; p < NPL; ++p) af[mw][k][p] = a_src[(k * NPL + p) * 64];
   }
   // ---- this wave's pixel tiles ng, ng + NSPLIT, ...: byte offset of the lane's window (pair kq, the wave's first kernel
   // row, plane 0, image column 2 ow + 2): 16 bytes at an 8-byte aligned address (the compiler reads them as ds_read2_b64;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     const int n = min((ng + G::NSPLIT * t) * 16 + m, NPX - 1), ohl = n / Ws, ow = n - ohl * Ws;
-    blo[t] = (kq * CPS + (2 * ohl + kg * G::KHW) * 3 * WPD + 2 * ow + 2) * 4;
+    blo[t] = (kq * CPS + (2 * ohl + kg * G::KHW) * NPL * WPD + 2 * ow + 2) * 4;
   }
   // ---- loader items: (channel pair, band row, quad of 4 columns)
   int l_src[G::QB], l_cr[G::QB], l_row[G::QB];
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
   auto commit_item = [&](int i, const UnitPos& up, const float (&af2)[4]) {
     const int cp = (l_cr[i] >> 8) & 63;
     // (image position: pair cp, band row, plane 0, column 4 qi + 4 - 4 qi recovered from the global offset)
-    const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (3 * WPD) + l_src[i] + 4) * 4;
+    const int dst = (cp * (CPS - 2 * H * W) + (l_cr[i] & 255) * (NPL * WPD) + l_src[i] + 4) * 4;
     // (a row outside the image arrived as zeros: only the SHIFT has to vanish there - the padding stays zero under an
     // affine too.  FUSE = an input-gradient call: no affine at all, the launcher refuses one)
     const bool in = (unsigned)(up.ih0 + (l_cr[i] & 255)) < (unsigned)H;
@@ -225,17 +230,18 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
         const bool on = W % 4 == 0 || !(l_cr[i] & 0x4000) || e < W % 4;   // (a quad at the ragged end of a row)
         const float x0 = rb[i][0][e], x1 = rb[i][1][e];
         const float y0 = on ? (FUSE ? x0 : fmaf(x0, s0, h0)) : 0.f, y1 = on ? (FUSE ? x1 : fmaf(x1, s1c, h1)) : 0.f;
-        unsigned a1, a2, a3;
-#ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
-        a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
-#else
-        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
-#endif
+        unsigned a1, a2 = 0, a3 = 0;
+        if constexpr (NPL == 3)
+          pgv_split3_pair(y0, y1, a1, a2, a3, sel);
+        else
+          a1 = pgv_pack_bf16x2(y0, y1);   // (bf16 operand mode: rounded to nearest, one plane)
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }
       *reinterpret_cast<u32x4*>(lds_x + dst) = ph;
-      *reinterpret_cast<u32x4*>(lds_x + dst + WPD * 4) = pm;
-      *reinterpret_cast<u32x4*>(lds_x + dst + 2 * WPD * 4) = pl;
+      if constexpr (NPL == 3) {
+        *reinterpret_cast<u32x4*>(lds_x + dst + WPD * 4) = pm;
+        *reinterpret_cast<u32x4*>(lds_x + dst + 2 * WPD * 4) = pl;
+      }
     }
   };
   auto vector_items = [&](int jc) {   // commit unit jc from the registers, re-issue them for unit jc + 1
@@ -296,7 +302,9 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-    for (int k = 0; k < G::KW; ++k) asm volatile("" ::"v"(af[mw][k][0]), "v"(af[mw][k][1]), "v"(af[mw][k][2]));
+    for (int k = 0; k < G::KW; ++k)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) asm volatile("" ::"v"(af[mw][k][p]));
   asm volatile("" ::"v"(bv), "v"(ka), "v"(kb), "v"(kc));
 
 #pragma unroll 1
@@ -325,15 +333,15 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
       constexpr int TP = 2 / MW, TG = (TN + TP - 1) / TP;
       constexpr int NSTEP = G::KHW * NG * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
       static_assert(MW == 1 || MW == 2, "two chains per step");
-      u32x4 bf[PD + 1][TP][3];
-      auto frag = [&](int i, u32x4 (&f)[TP][3]) {
+      u32x4 bf[PD + 1][TP][NPL];
+      auto frag = [&](int i, u32x4 (&f)[TP][NPL]) {
         const int tg = i % TG, g = (i / TG) % NG, kh = i / (TG * NG);
-        const int off = (g * 4 * CPS + kh * 3 * WPD) * 4;
+        const int off = (g * 4 * CPS + kh * NPL * WPD) * 4;
 #pragma unroll
         for (int q = 0; q < TP; ++q) {
           const int t = min(tg * TP + q, TN - 1);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
+          for (int p = 0; p < NPL; ++p) f[q][p] = *reinterpret_cast<const u4a8*>(lds_x + blo[t] + off + p * WPD * 4);
         }
       };
 #pragma unroll
@@ -343,15 +351,16 @@ __global__ __launch_bounds__(512) void down_q_kernel(int B, const float* __restr
         const int tg = i % TG, ks = i / TG;
         if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
+        for (int term = 0; term < NTERM; ++term) {
+          const int pa = NPL == 3 ? kTermA[term] : 0, pb = NPL == 3 ? kTermB[term] : 0;
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
-            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][pa], bf[i % (PD + 1)][q][pb], acc[mw][t]);
           }
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);   // the step's LDS reads ...
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);       // ... then its matrix instructions
+        __builtin_amdgcn_sched_group_barrier(0x100, NPL * TP, 0);    // the step's LDS reads ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTERM, 0);   // ... then its matrix instructions
         __builtin_amdgcn_sched_barrier(0);
       }
       QSTAMP(j, 2);
@@ -524,9 +533,11 @@ int launch_down_q(const pgv_conv_desc* d, const float* big, const float* in_scal
 // UP: big = conv_transpose_{s2,p2,k4}(small').  Four 2x2-tap phase convolutions sharing ONE input gather: GEMM with
 // M = (output phase, big channel), K = (8 small channels) x the 4 taps of a phase, N = grid positions (u, v) of the band;
 // output (2u + ph, 2v + pw) takes taps kh = ph + 2 th, kw = pw + 2 tw at input (u + 1 - th, v + 1 - tw).
-template <int CB_, int CS_, int H_, int W_, int UB_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1>
+template <int CB_, int CS_, int H_, int W_, int UB_, int MW_, int KSPLIT_, int NSPLIT_, int PD_ = 1, int NPL_ = 3>
 struct UpQ {
   static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, UB = UB_, MW = MW_, KSPLIT = KSPLIT_, NSPLIT = NSPLIT_, PD = PD_;
+  static constexpr int NPL = NPL_, NTERM = NPL_ == 3 ? 6 : 1;   // (operand planes / product terms: see DownQ)
+  static_assert(NPL_ == 3 || NPL_ == 1, "three planes (six product terms) or one");
   static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, RB = 2 * UB;
   static constexpr int HU = (H + 1) / 2, WU = (W + 1) / 2, BANDS = (HU + UB - 1) / UB;   // grid rows / columns with an output
   static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;                  // small band image (+ zero column)
@@ -536,13 +547,13 @@ struct UpQ {
   static constexpr int MTN = CB / 4, MG = MTN / MW;             // M tiles: rows (phase, channel); M groups over the waves
   static constexpr int NPOS = UB * WU, NT = (NPOS + 15) / 16, TMAX = (NT + NSPLIT - 1) / NSPLIT;
   static constexpr int OCH = RB * W, O_SLICE = CB * OCH, O_FLOATS = KSPLIT * O_SLICE;   // tile [CB][RB rows][W]
-  static constexpr int IMG = (SPX * PB + 15) / 16 * 16, STAGE = 3 * IMG;
+  static constexpr int IMG = (SPX * PB + 15) / 16 * 16, STAGE = NPL * IMG;
   static constexpr int S_RUN = SROWS * Ws, ITEMS = NG * S_RUN, QB = (ITEMS + 511) / 512;   // loader items: (group, pixel)
   static constexpr int LPC = 512 / CB, O4 = OCH / 4, QO = (O4 + LPC - 1) / LPC;
   static constexpr size_t LDS_BYTES = (size_t)STAGE + (size_t)O_FLOATS * 4 + sizeof(float) * (2 * CS + 8);
   static_assert(MG * KSPLIT * NSPLIT == 8 && MTN % MW == 0 && NG % KSPLIT == 0, "eight waves");
   static_assert((NG == 8 || NG == 4 || NG == 2) && (CB == 32 || CB == 16 || CB == 8) && LPC <= 64 && OCH % 4 == 0, "channel counts of the stack");
-  static_assert(LDS_BYTES <= 160 * 1024 && 2 * IMG + SPX * PB < 65536, "LDS budget / immediate offsets");
+  static_assert(LDS_BYTES <= 160 * 1024 && (NPL - 1) * IMG + SPX * PB < 65536, "LDS budget / immediate offsets");
 };
 
 template <class G, bool FUSE>
@@ -553,6 +564,7 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
                                                    pgv_bn_src in_bn, pgv_bwd_fuse fuse QSTAMP_ARG) {
   constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, UB = G::UB, RB = G::RB;
   constexpr int NG = G::NG, PB = G::PB, SH = G::SH, SWP = G::SWP, OCH = G::OCH, LPC = G::LPC, QO = G::QO, MW = G::MW;
+  constexpr int NPL = G::NPL, NTERM = G::NTERM;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* lds_s = ldsb;
   float* otile = reinterpret_cast<float*>(ldsb + G::STAGE);
@@ -572,14 +584,14 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
     aff[CS + i] = sh;
   }
   // ---- this wave's weight fragments: M tiles mtl .. mtl + MW - 1, K steps [kg * KW, + KW), three planes
-  u32x4 af[MW][G::KW][3];
+  u32x4 af[MW][G::KW][NPL];
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw) {
-    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * NG + kg * G::KW) * 3) * 64 + lane;
+    const u32x4* a_src = wsh + ((size_t)((mtl + mw) * NG + kg * G::KW) * NPL) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < G::KW; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[mw][k][p] = a_src[(k * 3 + p) * 64];
+      for (int p = 0; p < NPL; ++p) af[mw][k][p] = a_src[(k * NPL + p) * 64];
   }
   // ---- this lane's accumulator rows: (phase, channels c0 .. c0 + 3) of the row list (phase, channel), per M tile of the wave
   int ph_[MW], pw_[MW], c0[MW];
@@ -655,17 +667,18 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
         const float y0 = FUSE ? rb[i][2 * e] : fmaf(rb[i][2 * e], af4[e >> 1][2 * (e & 1)], af4[2 + (e >> 1)][2 * (e & 1)] * mk);
         const float y1 = FUSE ? rb[i][2 * e + 1]
                               : fmaf(rb[i][2 * e + 1], af4[e >> 1][2 * (e & 1) + 1], af4[2 + (e >> 1)][2 * (e & 1) + 1] * mk);
-        unsigned a1, a2, a3;
-#ifdef PGV_EXP_NOSPLIT   // scratch experiment: what the vector phase costs without the conversions (results are wrong)
-        a1 = __builtin_bit_cast(unsigned, y0), a2 = __builtin_bit_cast(unsigned, y1), a3 = 0;
-#else
-        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
-#endif
+        unsigned a1, a2 = 0, a3 = 0;
+        if constexpr (NPL == 3)
+          pgv_split3_pair(y0, y1, a1, a2, a3, sel);
+        else
+          a1 = pgv_pack_bf16x2(y0, y1);   // (bf16 operand mode: rounded to nearest, one plane)
         ph[e] = a1, pm[e] = a2, pl[e] = a3;
       }
       *reinterpret_cast<u32x4*>(lds_s + l_dst[i]) = ph;
-      *reinterpret_cast<u32x4*>(lds_s + G::IMG + l_dst[i]) = pm;
-      *reinterpret_cast<u32x4*>(lds_s + 2 * G::IMG + l_dst[i]) = pl;
+      if constexpr (NPL == 3) {
+        *reinterpret_cast<u32x4*>(lds_s + G::IMG + l_dst[i]) = pm;
+        *reinterpret_cast<u32x4*>(lds_s + 2 * G::IMG + l_dst[i]) = pl;
+      }
     }
   };
   auto vector_items = [&](int jc) {
@@ -727,7 +740,9 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-    for (int k = 0; k < G::KW; ++k) asm volatile("" ::"v"(af[mw][k][0]), "v"(af[mw][k][1]), "v"(af[mw][k][2]));
+    for (int k = 0; k < G::KW; ++k)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) asm volatile("" ::"v"(af[mw][k][p]));
   asm volatile("" ::"v"(bv), "v"(ka), "v"(kb), "v"(kc));
 
 #pragma unroll 1
@@ -749,15 +764,15 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
       constexpr int TP = 2 / MW, TG = (TN + TP - 1) / TP;
       constexpr int NSTEP = G::KW * TG, PD = G::PD < NSTEP ? G::PD : NSTEP;
       static_assert(MW == 1 || MW == 2, "two chains per step");
-      u32x4 bf[PD + 1][TP][3];
-      auto frag = [&](int i, u32x4 (&f)[TP][3]) {
+      u32x4 bf[PD + 1][TP][NPL];
+      auto frag = [&](int i, u32x4 (&f)[TP][NPL]) {
         const int tg = i % TG, g = kg * G::KW + i / TG;
 #pragma unroll
         for (int q = 0; q < TP; ++q) {
           const int t = min(tg * TP + q, TN - 1);
           const unsigned char* bp = lds_s + boff[t] + ((g ^ bsw[t]) * 16);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) f[q][p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
+          for (int p = 0; p < NPL; ++p) f[q][p] = *reinterpret_cast<const u32x4*>(bp + p * G::IMG);
         }
       };
 #pragma unroll
@@ -767,15 +782,16 @@ __global__ __launch_bounds__(512) void up_q_kernel(int B, const float* __restric
         const int tg = i % TG, ks = i / TG;
         if (i + PD < NSTEP) frag(i + PD, bf[(i + PD) % (PD + 1)]);
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
+        for (int term = 0; term < NTERM; ++term) {
+          const int pa = NPL == 3 ? kTermA[term] : 0, pb = NPL == 3 ? kTermB[term] : 0;
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int mw = MW == 2 ? c : 0, q = MW == 2 ? 0 : c, t = tg * TP + q;
-            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][kTermA[term]], bf[i % (PD + 1)][q][kTermB[term]], acc[mw][t]);
+            if (t < TN) acc[mw][t] = mfma_bf16_k32(af[mw][ks][pa], bf[i % (PD + 1)][q][pb], acc[mw][t]);
           }
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NPL * TP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTERM, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       QSTAMP(j, 2);
@@ -908,7 +924,8 @@ int launch_up_q(const pgv_conv_desc* d, const float* small_in, const float* in_s
   pgv_bwd_fuse f = {};
   if (fuse) f = *fuse;
   const int units = d->B * G::BANDS;
-  const u32x4* up = (const u32x4*)d->w_shadow + (size_t)d->Cs * d->Cb * 6;   // (after the down layout: 96 bytes per weight)
+  // (after the down layout: NPL planes x 16 taps x 2 bytes per weight = 96 bytes per weight with three planes, 32 with one)
+  const u32x4* up = (const u32x4*)d->w_shadow + (size_t)d->Cs * d->Cb * 2 * G::NPL;
   hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
                      bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(),
                      f QSTAMP_PASS);
@@ -918,18 +935,30 @@ int launch_up_q(const pgv_conv_desc* d, const float* small_in, const float* in_s
 
 }  // namespace
 
-bool pgv_big_split_shape(const pgv_conv_desc* d) {
-  if (!(d->flags & PGV_COMPUTE_F32_SPLIT) || (d->flags & PGV_COMPUTE_BF16)) return false;
+static bool big_plane_layer(const pgv_conv_desc* d) {
   if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
   return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
          (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16);
 }
+// fp32 mode, products as six bf16 instructions (three operand planes)
+bool pgv_big_split_shape(const pgv_conv_desc* d) {
+  return (d->flags & PGV_COMPUTE_F32_SPLIT) && !(d->flags & PGV_COMPUTE_BF16) && big_plane_layer(d);
+}
+// bf16 operand mode on the same kernels with ONE operand plane (round 6: the mode ran round-4 kernels that had become slower
+// than the six-instruction fp32 ones - 100.9 / 76 us against 90.5 / 83 us on 129x174 with a sixth of the matrix work)
+bool pgv_big_bf16q_shape(const pgv_conv_desc* d) { return (d->flags & PGV_COMPUTE_BF16) && big_plane_layer(d); }
 
 // 1 / 3 = launched (3: with the class sums of the fused epilogue), 0 = not this kernel family's case
 int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                             hipStream_t st, const pgv_bn_src* bn) {
-  if (!d->w_shadow || !pgv_big_split_shape(d)) return 0;
+  if (!d->w_shadow) return 0;
+  if (pgv_big_bf16q_shape(d)) {   // one operand plane (same tilings)
+    if (d->Hb == 33) return launch_down_q<DownQ<32, 64, 33, 45, 2, 2, 4, 1, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+    if (d->Hb == 65) return launch_down_q<DownQ<16, 32, 65, 88, 4, 2, 2, 4, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+    return launch_down_q<DownQ<8, 16, 129, 174, 4, 1, 1, 8, 2, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  }
+  if (!pgv_big_split_shape(d)) return 0;
   if (d->Hb == 33)   // 32 -> 64 channels: bands of 2 rows (46 pixels = 3 tiles), waves = 2 M pairs x 4 kernel rows
     return launch_down_q<DownQ<32, 64, 33, 45, 2, 2, 4, 1, 1>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65)   // 16 -> 32 channels: bands of 4 rows (180 pixels = 12 tiles), waves = 2 K halves x 4 pixel groups
@@ -942,7 +971,13 @@ int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const floa
 int pgv_conv_up_big_split(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                           const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                           hipStream_t st, const pgv_bn_src* bn) {
-  if (!d->w_shadow || !pgv_big_split_shape(d)) return 0;
+  if (!d->w_shadow) return 0;
+  if (pgv_big_bf16q_shape(d)) {   // one operand plane (same tilings)
+    if (d->Hb == 33) return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 2, 1, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+    if (d->Hb == 65) return launch_up_q<UpQ<16, 32, 65, 88, 4, 2, 1, 4, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+    return launch_up_q<UpQ<8, 16, 129, 174, 4, 2, 1, 8, 2, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  }
+  if (!pgv_big_split_shape(d)) return 0;
   if (d->Hb == 33)   // 64 -> 32 channels: bands of 2 grid rows (46 positions = 3 tiles), waves = 4 M pairs x 2 K halves (bands of 4 spill)
     return launch_up_q<UpQ<32, 64, 33, 45, 2, 2, 2, 1, 1>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
   if (d->Hb == 65)   // 32 -> 16 channels: bands of 4 grid rows (176 positions = 11 tiles), waves = 2 M pairs x 4 position groups

@@ -1728,6 +1728,12 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(ShadowTable t) {
       shadow_bigq_down_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
     else
       shadow_bigq_up_item(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)3 * t.CS[e] * t.CB[e] * 16);
+  } else if (t.k1[e] == 6) {   // bf16 operand mode on the large-plane kernels: the same fragment orders, one plane each
+    const int nd = t.CS[e] * t.CB[e] * 2;
+    if (it < nd)
+      shadow_bigq_down_item<1>(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
+    else
+      shadow_bigq_up_item<1>(it - nd, t.w[e], t.CS[e], t.CB[e], t.down[e] + (size_t)t.CS[e] * t.CB[e] * 16);
   } else if (t.k1[e] == 4)
     shadow_split_k1_item(it, t.w[e], t.CS[e], t.CB[e], t.down[e]);
   else if (t.k1[e])
@@ -1920,635 +1926,6 @@ int launch_k1_fwd_bf16(const pgv_conv_desc* d, bool up, const float* in, const f
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// UP on a LARGE plane: the 64 -> 32 channel transposed convolution onto 33x45 (dec5 forward, enc4 input gradient;
-// model/decoder.py:211-212, model/encoder.py:247-248) - 2 x 100 us of the bf16 step on the fp32-MFMA kernel with rounded
-// operands, against 12-20 us of HBM time.  Same product as deep_up_bf16 (K = 32: 8 small channels x the 4 taps of an
-// output phase; channel-innermost image, 64 channels = 128 bytes per pixel; waves = phases x halves, no reduction), but
-// the plane does not fit LDS: a unit of work = (sample, band of 8 output rows), PERSISTENT workgroups sweep the units with
-// the layer's whole weight shadow (64 KB) resident in LDS, the small band double-buffered (register prefetch one unit
-// ahead) and the 32 x 8 x 45 output tile staged through LDS, from where 16 lanes per channel move it out - with the
-// BatchNorm statistics (forward) or the BatchNorm + activation backward of the block below (pgv_bwd_fuse) on the way.
-// NP = 3 (PGV_COMPUTE_F32_SPLIT): an fp32 product as SIX bf16 instructions - every operand value kept as three bfloat16
-// planes x = x1 + x2 + x3 (exact: 3 x 8 significant bits), the product as x1 y1 + x1 y2 + x2 y1 + x2 y2 + x1 y3 + x3 y1 with the
-// fp32 accumulator of the matrix instruction (the dropped terms are below 2^-23 of the product; measured against float64,
-// scratch/ubench/bf16x6.hip: closer than v_mfma_f32_16x16x4_f32 itself) at 6 / 16 of the fp32 instruction time.
-template <int CB_, int CS_, int H_, int W_, int UB_ = 4, int NP_ = 1>
-struct UpBig {
-  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, NP = NP_;
-  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws;
-  static constexpr int UB = UB_, RB = 2 * UB, BANDS = (Hs + UB - 1) / UB;   // u rows / output rows of a band
-  static constexpr int SWP = Ws + 1, SROWS = UB + 1, SPX = SROWS * SWP;      // small band image (+ zero column right)
-  static constexpr int wu(int p) { return (p & 1) ? W / 2 : (W + 1) / 2; }
-  static constexpr int ntp(int p) { return (UB * wu(p) + 15) / 16; }
-  static constexpr int TMAX = (ntp(0) + 1) / 2;
-  static constexpr int MTN = (CB + 15) / 16;                                 // M tiles (a layer with 8 big channels: rows 8-15 zero)
-  static constexpr int NG = CS / 8, PB = CS * 2;                             // 16-byte channel groups / bytes of a pixel
-  static constexpr int SH = NG == 8 ? 1 : (NG == 4 ? 2 : 3);                 // group g of pixel px sits at g ^ ((px >> SH) & (NG - 1))
-  static constexpr int A_ROW = NG * 256 + 32, A_PLANE = MTN * 16 * A_ROW, A_BYTES = NP * A_PLANE;
-  static constexpr int S_PLANE = (SPX * PB + 15) / 16 * 16, S_BYTES = NP * S_PLANE;   // one stage
-  static constexpr int O_FLOATS = CB * RB * W, O_BYTES = O_FLOATS * 4;
-  static constexpr int S_RUN = SROWS * Ws, QUADS = (S_RUN + 3) / 4, ITEMS = (CS / 2) * QUADS, QB = (ITEMS + 511) / 512;
-  static constexpr int LPC = 512 / CB;                                       // copy-out lanes per channel
-  static constexpr int O4 = RB * W / 4, QO = (O4 + LPC - 1) / LPC;           // float4 groups of a channel's band per lane
-  static constexpr size_t LDS_BYTES = (size_t)A_BYTES + 2 * S_BYTES + O_BYTES + sizeof(float) * (2 * CS + 8);
-  static_assert((NG == 8 || NG == 4 || NG == 2) && (CB == 32 || CB == 16 || CB == 8), "channel counts of the stack");
-  static_assert((RB * W) % 4 == 0 && LPC <= 64 && LDS_BYTES <= 160 * 1024, "tile shapes");
-};
-
-template <class G, bool FUSE>
-__global__ __launch_bounds__(512) void up_big_bf16_kernel(int B, const float* __restrict__ small_in,
-                                                          const float* __restrict__ in_scale,
-                                                          const float* __restrict__ in_shift, const u16* __restrict__ wsh,
-                                                          const float* __restrict__ bias, int act, float slope,
-                                                          float* __restrict__ out, double* __restrict__ stats,
-                                                          int stat_stride, pgv_bn_src in_bn, pgv_bwd_fuse fuse) {
-  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, RB = G::RB, UB = G::UB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char* lds_a = ldsb;
-  unsigned char* lds_s = ldsb + G::A_BYTES;
-  float* otile = reinterpret_cast<float*>(ldsb + G::A_BYTES + 2 * G::S_BYTES);
-  float* aff = otile + G::O_FLOATS;   // [2*CS]
-  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ph = wave < 4 ? wave : 7 - wave, half = wave >> 2, phh = ph >> 1, pww = ph & 1;
-  const int units = B * G::BANDS;
-
-  for (int i = tid; i < 2 * G::S_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_s)[i] = u32x4{0, 0, 0, 0};
-  for (int i = tid; i < CS; i += 512) {
-    float sc = 1.f, sh = 0.f;
-    if (in_bn.stats)
-      pgv_bn_finalize_dev(in_bn, CS, i, blockIdx.x == 0, sc, sh);
-    else if (in_scale)
-      sc = in_scale[i], sh = in_shift[i];
-    aff[i] = sc;
-    aff[CS + i] = sh;
-  }
-  // the whole weight shadow of the layer: [cb][cs/8][phase][tap][8] -> rows of A_ROW bytes (rows beyond CB: zeros)
-  if (CB < G::MTN * 16)
-    for (int i = tid; i < G::A_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_a)[i] = u32x4{0, 0, 0, 0};
-  if (CB < G::MTN * 16) __syncthreads();
-  for (int q = tid; q < G::NP * CB * G::NG * 16; q += 512) {   // (NP planes, each [cb][cs/8][phase][tap][8])
-    const int pl = q / (CB * G::NG * 16), qq = q - pl * (CB * G::NG * 16);
-    const int row = qq / (G::NG * 16), f = qq - row * (G::NG * 16);
-    *reinterpret_cast<u32x4*>(lds_a + pl * G::A_PLANE + row * G::A_ROW + f * 16) =
-        *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
-  }
-  // ---- small-band loader: an item = a channel pair x 4 consecutive floats of the band's rows (contiguous in the plane)
-  int b_off[G::QB], b_dst[G::QB][4], b_e0[G::QB], b_cp[G::QB];
-  bool b_ok[G::QB];
-#pragma unroll
-  for (int i = 0; i < G::QB; ++i) {
-    const int q = min(tid + 512 * i, G::ITEMS - 1);
-    b_ok[i] = tid + 512 * i < G::ITEMS;
-    const int cp = q / G::QUADS, qi = q - cp * G::QUADS, e0 = min(4 * qi, G::S_RUN - 4);
-    b_cp[i] = cp;
-    b_e0[i] = e0;
-    b_off[i] = (2 * cp) * G::P + e0;   // + sample * CS * P + first row * Ws
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int rr = (e0 + e) / Ws, cc = (e0 + e) - rr * Ws, px = rr * G::SWP + cc;
-      b_dst[i][e] = px * G::PB + (((cp >> 2) ^ ((px >> G::SH) & (G::NG - 1))) * 16) + (cp & 3) * 4;
-    }
-  }
-  // ---- this wave's tiles: pixels [16 (t0 + t), +16) of phase ph's list (ul, v) of the band
-  const int wu = pww ? W / 2 : (W + 1) / 2, cnt = UB * wu, ntp = (cnt + 15) >> 4;
-  const int t0 = half ? (ntp + 1) >> 1 : 0, ntl = half ? ntp >> 1 : (ntp + 1) >> 1;
-  const int th = kq >> 1, tw = kq & 1;
-  const int a_frag = m * G::A_ROW + ph * 64 + kq * 16;
-  int boff[TMAX], bsw[TMAX], opix[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    const int n = (t0 + t) * 16 + m, nn = min(n, cnt - 1), ul = nn / wu, v = nn - ul * wu;
-    const int px = (ul + 1 - th) * G::SWP + (v + 1 - tw);
-    boff[t] = px * G::PB;
-    bsw[t] = (px >> G::SH) & (G::NG - 1);
-    opix[t] = (t < ntl && n < cnt) ? (2 * ul + phh) * W + 2 * v + pww : -1;
-  }
-  float bv[G::MTN][4];
-#pragma unroll
-  for (int mt = 0; mt < G::MTN; ++mt)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bv[mt][i] = (!FUSE && bias && mt * 16 + 4 * kq + i < CB) ? bias[mt * 16 + 4 * kq + i] : 0.f;
-  const pgv_act_params ap = pgv_act_setup(act, slope);
-  // copy-out roles: LPC lanes per channel
-  const int och = tid / G::LPC, part = tid % G::LPC;
-  float ka = 1.f, kb = 0.f, kc = 0.f;
-  pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
-  if (FUSE) {
-    ka = fuse.coef[och], kb = fuse.coef[CB + och], kc = fuse.coef[2 * CB + och];
-    actd = pgv_actd_setup(fuse.act, fuse.slope);
-  }
-  float s1 = 0.f, s2 = 0.f;   // forward: sum / sum of squares of the outputs; fused: sum of g_y (bias gradient)
-
-  f4u rb[G::QB][2];
-  unsigned rb_n[G::QB];   // valid floats of the item's quad (rows beyond the plane are zeros)
-  auto issue = [&](int u) {
-    const int b = u / G::BANDS, band = u - b * G::BANDS, oh0 = band * UB;
-    const int nvalid = (min(Hs, oh0 + G::SROWS) - oh0) * Ws;
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const int e0 = min(b_e0[i], max(nvalid - 4, 0));   // keep the load inside the plane
-      rb_n[i] = (unsigned)(((b_e0[i] - e0) << 8) | max(0, min(4, nvalid - b_e0[i])));
-      const float* p = small_in + (size_t)b * CS * G::P + b_off[i] - b_e0[i] + e0 + oh0 * Ws;
-      rb[i][0] = *reinterpret_cast<const f4u*>(p);
-      rb[i][1] = *reinterpret_cast<const f4u*>(p + G::P);
-    }
-  };
-  auto commit = [&](unsigned char* st) {
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const int c = 2 * b_cp[i];
-      const float s0 = aff[c], s1c = aff[c + 1], h0 = aff[CS + c], h1 = aff[CS + c + 1];
-      const int shft = (int)(rb_n[i] >> 8), nv = (int)(rb_n[i] & 255);
-      if (b_ok[i]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // (the last band: the quad was shifted back into the plane by shft floats; floats behind the plane are zeros)
-          float x0, x1;
-          if (shft == 0) {
-            x0 = rb[i][0][e], x1 = rb[i][1][e];
-          } else {
-            const int k = min(e + shft, 3);
-            x0 = k == 1 ? rb[i][0][1] : (k == 2 ? rb[i][0][2] : rb[i][0][3]);
-            x1 = k == 1 ? rb[i][1][1] : (k == 2 ? rb[i][1][2] : rb[i][1][3]);
-          }
-          const bool on = e < nv;
-          const float y0 = on ? fmaf(x0, s0, h0) : 0.f, y1 = on ? fmaf(x1, s1c, h1) : 0.f;
-          if constexpr (G::NP == 1) {
-            *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(y0, y1);
-          } else {   // three bf16 planes: y = y_hi + y_mid + y_lo exactly
-            const float a0 = (float)(__bf16)y0, a1 = (float)(__bf16)y1;
-            const float r0 = y0 - a0, r1 = y1 - a1;
-            const float m0 = (float)(__bf16)r0, m1 = (float)(__bf16)r1;
-            *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(a0, a1);
-            *reinterpret_cast<unsigned*>(st + G::S_PLANE + b_dst[i][e]) = pack_bf16x2(m0, m1);
-            *reinterpret_cast<unsigned*>(st + 2 * G::S_PLANE + b_dst[i][e]) = pack_bf16x2(r0 - m0, r1 - m1);
-          }
-        }
-      }
-    }
-  };
-
-  int u = pgv_xcd_block();
-  if (u < units) issue(u);
-  __syncthreads();   // stages zeroed, affine and weights staged
-  if (u < units) commit(lds_s);
-  __syncthreads();
-  int stage = 0;
-#pragma unroll 1
-  for (; u < units; u += gridDim.x, stage ^= 1) {
-    const int b = u / G::BANDS, band = u - b * G::BANDS, y0 = band * RB, nrow = min(RB, H - y0), nfl = nrow * W;
-    const int un = u + gridDim.x;
-    if (un < units) issue(un);
-    // the saved activation of the fused epilogue: requested before the matrix loop, used after it
-    f4u av[G::QO];
-    const float* a_p = FUSE ? fuse.a + ((size_t)b * CB + och) * (H * W) + y0 * W : nullptr;
-    if (FUSE) {
-#pragma unroll
-      for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + G::LPC * i;
-        if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
-      }
-    }
-    const unsigned char* st = lds_s + stage * G::S_BYTES;
-    f32x4 acc[G::MTN][TMAX];
-#pragma unroll
-    for (int mt = 0; mt < G::MTN; ++mt)
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < G::NG; ++g) {
-      u32x4 af[G::NP][G::MTN];
-#pragma unroll
-      for (int pl = 0; pl < G::NP; ++pl)
-#pragma unroll
-        for (int mt = 0; mt < G::MTN; ++mt)
-          af[pl][mt] = *reinterpret_cast<const u32x4*>(lds_a + pl * G::A_PLANE + a_frag + g * 256 + mt * 16 * G::A_ROW);
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        if (t < ntl) {
-          const int bo = boff[t] + ((g ^ bsw[t]) * 16);
-          const u32x4 b1 = *reinterpret_cast<const u32x4*>(st + bo);
-          if constexpr (G::NP == 1) {
-#pragma unroll
-            for (int mt = 0; mt < G::MTN; ++mt) acc[mt][t] = mfma_bf16_k32(af[0][mt], b1, acc[mt][t]);
-          } else {
-            const u32x4 b2 = *reinterpret_cast<const u32x4*>(st + G::S_PLANE + bo);
-            const u32x4 b3 = *reinterpret_cast<const u32x4*>(st + 2 * G::S_PLANE + bo);
-#pragma unroll
-            for (int mt = 0; mt < G::MTN; ++mt) {   // smallest terms first
-              f32x4 c = acc[mt][t];
-              c = mfma_bf16_k32(af[0][mt], b3, c);
-              c = mfma_bf16_k32(af[2][mt], b1, c);
-              c = mfma_bf16_k32(af[1][mt], b2, c);
-              c = mfma_bf16_k32(af[0][mt], b2, c);
-              c = mfma_bf16_k32(af[1][mt], b1, c);
-              acc[mt][t] = mfma_bf16_k32(af[0][mt], b1, c);
-            }
-          }
-        }
-      }
-    }
-    // ---- this wave's pixels into the [channel][8 rows][W] output tile
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      if (opix[t] >= 0) {
-#pragma unroll
-        for (int mt = 0; mt < G::MTN; ++mt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = acc[mt][t][i];
-            if (mt * 16 + 4 * kq + i < CB)
-              otile[(mt * 16 + 4 * kq + i) * (RB * W) + opix[t]] = FUSE ? v : pgv_act_apply(v + bv[mt][i], ap);
-          }
-      }
-    }
-    if (un < units) commit(lds_s + (stage ^ 1) * G::S_BYTES);   // (nobody reads that stage during this unit)
-    __syncthreads();
-    // ---- move the band out: LPC lanes per channel, 16 bytes per lane and step
-    {
-      float* o_p = out + ((size_t)b * CB + och) * (H * W) + y0 * W;
-      const float* t_p = otile + och * (RB * W);
-#pragma unroll
-      for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + G::LPC * i;
-        if (4 * q4 + 4 <= nfl) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
-          if (FUSE) {
-            v = f32x4{pgv_bwd_apply(v[0], av[i][0], ka, kb, kc, actd), pgv_bwd_apply(v[1], av[i][1], ka, kb, kc, actd),
-                      pgv_bwd_apply(v[2], av[i][2], ka, kb, kc, actd), pgv_bwd_apply(v[3], av[i][3], ka, kb, kc, actd)};
-          } else {
-            s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-          }
-          s1 += (v[0] + v[1]) + (v[2] + v[3]);
-          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
-        }
-      }
-      const int tail0 = nfl & ~3;   // (the last band: 45 floats = 11 groups + 1)
-      if (part < nfl - tail0) {
-        float v = t_p[tail0 + part];
-        if (FUSE)
-          v = pgv_bwd_apply(v, a_p[tail0 + part], ka, kb, kc, actd);
-        else
-          s2 += v * v;
-        s1 += v;
-        o_p[tail0 + part] = v;
-      }
-    }
-    __syncthreads();
-  }
-  // ---- per-channel sums of the workgroup: BatchNorm statistics (forward) or the bias gradient (fused backward)
-#pragma unroll
-  for (int o = 1; o < G::LPC; o <<= 1) {
-    s1 += __shfl_xor(s1, o);
-    s2 += __shfl_xor(s2, o);
-  }
-  if (part == 0) {
-    const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
-    if (FUSE) {
-      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CB : 0) + och, s1);
-    } else if (stats) {
-      double* sp = stats + (size_t)copy * stat_stride;
-      atomicAdd(&sp[och], (double)s1);
-      atomicAdd(&sp[CB + och], (double)s2);
-    }
-  }
-}
-
-bool up_big_bf16_shape(const pgv_conv_desc* d) {
-  if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
-  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
-         (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16);   // (129x174: the shadow exists, the routing decides)
-}
-
-template <class G>
-int launch_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
-                       const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
-                       hipStream_t st, const pgv_bn_src* bn) {
-  if (fuse && (fuse->cls || stats || bias)) return 0;   // (class sums: the band kernels' epilogue keeps those calls)
-  if ((int64_t)d->B * d->Cs * G::P * 4 >= (int64_t)1 << 31 || G::LDS_BYTES > (size_t)kMaxLds || d->B <= 0) return 0;
-  typedef void (*kern_t)(int, const float*, const float*, const float*, const u16*, const float*, int, float, float*, double*,
-                         int, pgv_bn_src, pgv_bwd_fuse);
-  kern_t kern = fuse ? (kern_t)up_big_bf16_kernel<G, true> : (kern_t)up_big_bf16_kernel<G, false>;
-  static bool attr_done[2] = {false, false};   // (per instantiation of the template)
-  int rc = raise_lds_limit(kern, &attr_done[fuse ? 1 : 0], "conv_up_big_bf16");
-  if (rc) return rc;
-  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cb, st) != hipSuccess) {
-    pgv_set_error("conv_up_big_bf16: memset failed");
-    return PGV_E_LAUNCH;
-  }
-  pgv_bwd_fuse f = {};
-  if (fuse) f = *fuse;
-  const int units = d->B * G::BANDS;
-  const u16* up = (const u16*)d->w_shadow + (G::NP == 1 ? (size_t)d->Cs * d->Cb * 16 : 0);   // (split mode: three up planes)
-  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / G::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256 * per_cu)), dim3(512), G::LDS_BYTES, st, d->B, small_in, in_scale, in_shift, up,
-                     bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cb : 0, bn ? *bn : pgv_no_bn(), f);
-  PGV_CHECK_LAUNCH("conv_up_big_bf16");
-  return 1;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// DOWN on a LARGE plane: the stride-2 k4 convolutions 32 -> 64 channels from 33x45 and 16 -> 32 from 65x88 (enc4 / enc3
-// forward, dec5 / dec6 input gradient; model/encoder.py:245-248, model/decoder.py:211-214).  The persistent form of
-// deep_down_bf16: the layer's whole weight shadow resident in LDS, a unit = (sample, band of R output rows), the big band
-// channel-innermost and double-buffered, every wave one M tile x up to 3 pixel tiles over the whole K (no reduction), the
-// CS x R x Ws output tile staged through LDS and moved out by 512 / CS lanes per channel - with the BatchNorm statistics
-// (forward) or the fused BatchNorm + activation backward of the block below including its class sums (pgv_bwd_fuse).
-template <int CB_, int CS_, int H_, int W_, int R_, int WPX_, int SH_>
-struct DownBig {
-  static constexpr int CB = CB_, CS = CS_, H = H_, W = W_, R = R_, WPX = WPX_, SH = SH_;
-  static constexpr int Hs = H / 2 + 1, Ws = W / 2 + 1, P = Hs * Ws, BANDS = (Hs + R - 1) / R;
-  static constexpr int XR = 2 * R + 2;                                        // big rows of a band
-  static constexpr int NG = CB / 8, PB = CB * 2;                              // channel groups / bytes of a pixel
-  static constexpr int MTN = CS / 16, NW = 8 / MTN;                           // M tiles; waves that split the pixels
-  static constexpr int NPX = R * Ws, NT = (NPX + 15) / 16, TMAX = (NT + NW - 1) / NW;
-  static constexpr int A_ROW = NG * 256 + 32, A_BYTES = CS * A_ROW;
-  static constexpr int X_BYTES = (XR * WPX * PB + 15) / 16 * 16;              // one stage
-  static constexpr int O_FLOATS = CS * NPX, O_BYTES = O_FLOATS * 4;
-  static constexpr int QX = (W + 3) / 4, ITEMS = (CB / 2) * XR * QX, QB = (ITEMS + 511) / 512;   // (channel pair, row, quad)
-  static constexpr int LPC = 512 / CS, QO = ((NPX + 3) / 4 + LPC - 1) / LPC;
-  static constexpr size_t LDS_BYTES = (size_t)A_BYTES + 2 * X_BYTES + O_BYTES + sizeof(float) * (2 * CB + 8);
-  static_assert(WPX >= 2 * Ws + 2 && CS % 16 == 0 && 8 % MTN == 0 && W >= 4 && LPC <= 64, "tile shapes");
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-template <class G, bool FUSE>
-__global__ __launch_bounds__(512) void down_big_bf16_kernel(int B, const float* __restrict__ big,
-                                                            const float* __restrict__ in_scale,
-                                                            const float* __restrict__ in_shift, const u16* __restrict__ wsh,
-                                                            const float* __restrict__ bias, int act, float slope,
-                                                            float* __restrict__ out, double* __restrict__ stats,
-                                                            int stat_stride, pgv_bn_src in_bn, pgv_bwd_fuse fuse) {
-  constexpr int CB = G::CB, CS = G::CS, H = G::H, W = G::W, Hs = G::Hs, Ws = G::Ws, TMAX = G::TMAX, R = G::R, NPX = G::NPX;
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char* lds_a = ldsb;
-  unsigned char* lds_x = ldsb + G::A_BYTES;
-  float* otile = reinterpret_cast<float*>(ldsb + G::A_BYTES + 2 * G::X_BYTES);
-  float* aff = otile + G::O_FLOATS;   // [2*CB]
-  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mt = wave % G::MTN, nw = wave / G::MTN;
-  const int units = B * G::BANDS;
-
-  for (int i = tid; i < 2 * G::X_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(lds_x)[i] = u32x4{0, 0, 0, 0};
-  for (int i = tid; i < CB; i += 512) {
-    float sc = 1.f, sh = 0.f;
-    if (in_bn.stats)
-      pgv_bn_finalize_dev(in_bn, CB, i, blockIdx.x == 0, sc, sh);
-    else if (in_scale)
-      sc = in_scale[i], sh = in_shift[i];
-    aff[i] = sc;
-    aff[CB + i] = sh;
-  }
-  // the whole weight shadow of the layer: [cs][cb/8][16 taps][8] -> rows of A_ROW bytes
-  for (int q = tid; q < CS * G::NG * 16; q += 512) {
-    const int row = q / (G::NG * 16), f = q - row * (G::NG * 16);
-    *reinterpret_cast<u32x4*>(lds_a + row * G::A_ROW + f * 16) =
-        *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsh) + (size_t)q * 16);
-  }
-  // ---- big-band loader: an item = a channel pair x one band row x 4 columns (the last quad of a row shifted back)
-  int b_off[G::QB], b_row[G::QB], b_dst[G::QB][4], b_cp[G::QB];
-  bool b_ok[G::QB];
-#pragma unroll
-  for (int i = 0; i < G::QB; ++i) {
-    const int q = min(tid + 512 * i, G::ITEMS - 1);
-    b_ok[i] = tid + 512 * i < G::ITEMS;
-    const int cp = q / (G::XR * G::QX), rem = q - cp * (G::XR * G::QX), r = rem / G::QX, qi = rem - r * G::QX;
-    const int c0 = min(4 * qi, W - 4);
-    b_cp[i] = cp;
-    b_row[i] = r;
-    b_off[i] = (2 * cp) * (H * W) + c0;   // + sample * CB * H * W + image row * W
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int px = r * G::WPX + c0 + e + 2;
-      b_dst[i][e] = px * G::PB + (((cp >> 2) ^ ((px >> G::SH) & (G::NG - 1))) * 16) + (cp & 3) * 4;
-    }
-  }
-  // ---- this wave: M tile mt, pixel tiles nw, nw + NW, ... of the band's R * Ws pixels
-  const int a_frag = (mt * 16 + m) * G::A_ROW + kq * 16;   // + 256 per channel group, + 64 per kernel row
-  int boff[TMAX], bsw[TMAX];
-  bool t_on[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    const int tile = nw + G::NW * t;
-    t_on[t] = tile < G::NT;
-    const int n = min(tile * 16 + m, NPX - 1), ohl = n / Ws, ow = n - ohl * Ws;
-    const int px = (2 * ohl) * G::WPX + 2 * ow + kq;   // + WPX per kernel row
-    boff[t] = px * G::PB;
-    bsw[t] = px;                                         // (the swizzle bits are taken per kernel row)
-  }
-  float bv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) bv[i] = (!FUSE && bias) ? bias[mt * 16 + 4 * kq + i] : 0.f;
-  const pgv_act_params ap = pgv_act_setup(act, slope);
-  const int och = tid / G::LPC, part = tid % G::LPC;
-  float ka = 1.f, kb = 0.f, kc = 0.f;
-  pgv_actd_params actd = pgv_actd_setup(PGV_ACT_NONE, 0.f);
-  if (FUSE) {
-    ka = fuse.coef[och], kb = fuse.coef[CS + och], kc = fuse.coef[2 * CS + och];
-    actd = pgv_actd_setup(fuse.act, fuse.slope);
-  }
-  // forward: s[0] / s[1] = sum / sum of squares of the outputs; fused: s[k] = sum of g_y in (row, column) parity class k.
-  // (fused: an element of the band tile has the same class in every unit - the bands start at even rows - so the sums are
-  // kept per (group, element) slot of this lane and sorted into the classes at the end)
-  static_assert(R % 2 == 0, "bands start at even output rows");
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  float slot[G::QO][4];
-#pragma unroll
-  for (int i = 0; i < G::QO; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) slot[i][e] = 0.f;
-
-  f4u rb[G::QB][2];
-  float rb_m[G::QB];
-  auto issue = [&](int u) {
-    const int b = u / G::BANDS, band = u - b * G::BANDS, ih0 = 2 * band * R - 2;
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const int ih = ih0 + b_row[i];
-      const bool in = (unsigned)ih < (unsigned)H;
-      rb_m[i] = in ? 1.f : 0.f;
-      const float* p = big + (size_t)b * CB * (H * W) + b_off[i] + (in ? ih : 0) * W;
-      rb[i][0] = *reinterpret_cast<const f4u*>(p);
-      rb[i][1] = *reinterpret_cast<const f4u*>(p + H * W);
-    }
-  };
-  auto commit = [&](unsigned char* st) {
-#pragma unroll
-    for (int i = 0; i < G::QB; ++i) {
-      const int c = 2 * b_cp[i];
-      const float s0 = aff[c] * rb_m[i], s1c = aff[c + 1] * rb_m[i], h0 = aff[CB + c] * rb_m[i], h1 = aff[CB + c + 1] * rb_m[i];
-      if (b_ok[i]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          *reinterpret_cast<unsigned*>(st + b_dst[i][e]) = pack_bf16x2(fmaf(rb[i][0][e], s0, h0), fmaf(rb[i][1][e], s1c, h1));
-      }
-    }
-  };
-
-  int u = pgv_xcd_block();
-  if (u < units) issue(u);
-  __syncthreads();   // stages zeroed, affine and weights staged
-  if (u < units) commit(lds_x);
-  __syncthreads();
-  int stage = 0;
-#pragma unroll 1
-  for (; u < units; u += gridDim.x, stage ^= 1) {
-    const int b = u / G::BANDS, band = u - b * G::BANDS, oh0 = band * R, nfl = min(R, Hs - oh0) * Ws;
-    const int un = u + gridDim.x;
-    if (un < units) issue(un);
-    f4u av[G::QO];
-    const float* a_p = FUSE ? fuse.a + ((size_t)b * CS + och) * G::P + oh0 * Ws : nullptr;
-    if (FUSE) {
-#pragma unroll
-      for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + G::LPC * i;
-        if (4 * q4 + 4 <= nfl) av[i] = *reinterpret_cast<const f4u*>(a_p + 4 * q4);
-      }
-    }
-    const unsigned char* st = lds_x + stage * G::X_BYTES;
-    f32x4 acc[TMAX];
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kh = 0; kh < 4; ++kh) {
-#pragma unroll
-      for (int g = 0; g < G::NG; ++g) {
-        const u32x4 af = *reinterpret_cast<const u32x4*>(lds_a + a_frag + g * 256 + kh * 64);
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-          if (t_on[t]) {
-            const int sw = ((bsw[t] + kh * G::WPX) >> G::SH) & (G::NG - 1);
-            const u32x4 bfr = *reinterpret_cast<const u32x4*>(st + boff[t] + kh * (G::WPX * G::PB) + ((g ^ sw) * 16));
-            acc[t] = mfma_bf16_k32(af, bfr, acc[t]);
-          }
-        }
-      }
-    }
-    // ---- this wave's pixels into the [channel][R * Ws] output tile
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      const int n = (nw + G::NW * t) * 16 + m;
-      if (t_on[t] && n < NPX) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[t][i];
-          otile[(mt * 16 + 4 * kq + i) * NPX + n] = FUSE ? v : pgv_act_apply(v + bv[i], ap);
-        }
-      }
-    }
-    if (un < units) commit(lds_x + (stage ^ 1) * G::X_BYTES);   // (nobody reads that stage during this unit)
-    __syncthreads();
-    // ---- move the band out: LPC lanes per channel, 16 bytes per lane and step
-    {
-      float* o_p = out + ((size_t)b * CS + och) * G::P + oh0 * Ws;
-      const float* t_p = otile + och * NPX;
-#pragma unroll
-      for (int i = 0; i < G::QO; ++i) {
-        const int q4 = part + G::LPC * i;
-        if (4 * q4 + 4 <= nfl) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(t_p + 4 * q4);
-          if (FUSE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = pgv_bwd_apply(v[e], av[i][e], ka, kb, kc, actd);
-              slot[i][e] += v[e];   // (sorted into the parity classes once, after the last unit)
-            }
-          } else {
-            s[0] += (v[0] + v[1]) + (v[2] + v[3]);
-            s[1] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-          }
-          *reinterpret_cast<f4u*>(o_p + 4 * q4) = f4u{v[0], v[1], v[2], v[3]};
-        }
-      }
-      const int tail0 = nfl & ~3;   // (a last band of one row: Ws floats)
-      if (part < nfl - tail0) {
-        const int idx = tail0 + part;
-        float v = t_p[idx];
-        if (FUSE) {
-          v = pgv_bwd_apply(v, a_p[idx], ka, kb, kc, actd);
-          const int rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * ((oh0 + rr) & 1) + (cc & 1);
-          s[0] += cls == 0 ? v : 0.f;
-          s[1] += cls == 1 ? v : 0.f;
-          s[2] += cls == 2 ? v : 0.f;
-          s[3] += cls == 3 ? v : 0.f;
-        } else {
-          s[0] += v;
-          s[1] += v * v;
-        }
-        o_p[idx] = v;
-      }
-    }
-    __syncthreads();
-  }
-  // ---- per-channel sums of the workgroup
-  if (FUSE) {
-#pragma unroll
-    for (int i = 0; i < G::QO; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = 4 * (part + G::LPC * i) + e, rr = idx / Ws, cc = idx - rr * Ws, cls = 2 * (rr & 1) + (cc & 1);
-        s[0] += cls == 0 ? slot[i][e] : 0.f;
-        s[1] += cls == 1 ? slot[i][e] : 0.f;
-        s[2] += cls == 2 ? slot[i][e] : 0.f;
-        s[3] += cls == 3 ? slot[i][e] : 0.f;
-      }
-  }
-#pragma unroll
-  for (int o = 1; o < G::LPC; o <<= 1)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], o);
-  if (part == 0) {
-    const int copy = blockIdx.x & (PGV_CLS_COPIES - 1);
-    if (FUSE) {
-      if (fuse.gbias) atomicAdd(fuse.gbias + (fuse.gbias_copies ? copy * CS : 0) + och, (s[0] + s[1]) + (s[2] + s[3]));
-      if (fuse.cls) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(fuse.cls + ((size_t)copy * CS + och) * 4 + k, s[k]);
-      }
-    } else if (stats) {
-      double* sp = stats + (size_t)copy * stat_stride;
-      atomicAdd(&sp[och], (double)s[0]);
-      atomicAdd(&sp[CS + och], (double)s[1]);
-    }
-  }
-}
-
-bool down_big_bf16_shape(const pgv_conv_desc* d) {
-  if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 2) return false;
-  return (d->Hb == 33 && d->Wb == 45 && d->Cb == 32 && d->Cs == 64) || (d->Hb == 65 && d->Wb == 88 && d->Cb == 16 && d->Cs == 32) ||
-         (d->Hb == 129 && d->Wb == 174 && d->Cb == 8 && d->Cs == 16);
-}
-
-template <class G>
-int launch_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
-                         const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
-                         hipStream_t st, const pgv_bn_src* bn) {
-  if (fuse && (stats || bias)) return 0;
-  if ((int64_t)d->B * d->Cb * G::H * G::W * 4 >= (int64_t)1 << 31 || d->B <= 0) return 0;
-  typedef void (*kern_t)(int, const float*, const float*, const float*, const u16*, const float*, int, float, float*, double*,
-                         int, pgv_bn_src, pgv_bwd_fuse);
-  kern_t kern = fuse ? (kern_t)down_big_bf16_kernel<G, true> : (kern_t)down_big_bf16_kernel<G, false>;
-  static bool attr_done[2] = {false, false};   // (per instantiation of the template)
-  int rc = raise_lds_limit(kern, &attr_done[fuse ? 1 : 0], "conv_down_big_bf16");
-  if (rc) return rc;
-  if (stats && !(d->flags & PGV_PREZEROED) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cs, st) != hipSuccess) {
-    pgv_set_error("conv_down_big_bf16: memset failed");
-    return PGV_E_LAUNCH;
-  }
-  pgv_bwd_fuse f = {};
-  if (fuse) f = *fuse;
-  const int units = d->B * G::BANDS;
-  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)kMaxLds / G::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3((unsigned)min(units, 256 * per_cu)), dim3(512), G::LDS_BYTES, st, d->B, big, in_scale, in_shift,
-                     (const u16*)d->w_shadow, bias, act, slope, out, stats, (d->flags & PGV_STATS_COPIES) ? 2 * d->Cs : 0,
-                     bn ? *bn : pgv_no_bn(), f);
-  PGV_CHECK_LAUNCH("conv_down_big_bf16");
-  return fuse && fuse->cls ? 3 : 1;   // (3: the class sums of the fused result are done)
-}
-
 bool deep_bf16_shape(const pgv_conv_desc* d) {
   return d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 2 && d->Cb >= 64 && d->Cb % 16 == 0 && d->Cs % 64 == 0 &&
          ((d->Hb == 17 && d->Wb == 23) || (d->Hb == 9 && d->Wb == 12) || (d->Hb == 5 && d->Wb == 7));
@@ -2564,12 +1941,12 @@ int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d) {
     return pgv_big_split_shape(d) ? (int64_t)12 * d->Cs * d->Cb * 16 : 0;
   }
   if (k1_bf16_shape(d)) return (int64_t)4 * d->Cs * d->Cb;
-  return (deep_bf16_shape(d) || up_big_bf16_shape(d)) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
+  return (deep_bf16_shape(d) || pgv_big_bf16q_shape(d)) ? (int64_t)4 * d->Cs * d->Cb * 16 : 0;
 }
 
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st) {
-  if (!(d->flags & PGV_COMPUTE_BF16)) {
-    if (pgv_deep_split_shape(d) || pgv_k1_split_shape(d) || pgv_big_split_shape(d)) {
+  if (!(d->flags & PGV_COMPUTE_BF16) || pgv_big_bf16q_shape(d)) {
+    if (pgv_deep_split_shape(d) || pgv_k1_split_shape(d) || pgv_big_split_shape(d) || pgv_big_bf16q_shape(d)) {
       const pgv_conv_desc* one[1] = {d};
       const float* ws[1] = {w};
       void* sh[1] = {shadow};
@@ -2584,7 +1961,7 @@ int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* sh
     PGV_CHECK_LAUNCH("conv_weight_shadow");
     return 1;
   }
-  if (!deep_bf16_shape(d) && !up_big_bf16_shape(d)) return 0;
+  if (!deep_bf16_shape(d)) return 0;
   u16* down = (u16*)shadow;
   u16* up = down + (size_t)d->Cs * d->Cb * 16;
   const int items = d->Cs * (d->Cb / 8) * 4;
@@ -2707,36 +2084,20 @@ int pgv_conv_wgrad_deep_bf16(const pgv_conv_desc* d, const float* big, const flo
   return 0;
 }
 
-// the 64 -> 32 channel transposed convolution onto 33x45 (1 = launched; the fused epilogue is applied when `fuse` is given)
+// The large-plane k4 s2 p2 layers with a weight shadow in the descriptor (1 / 3 = launched, 3: with the class sums of the fused
+// epilogue): conv_big_split.hip - fp32 products as six bf16 instructions (PGV_COMPUTE_F32_SPLIT, three operand planes) and,
+// since round 6, bf16 operand mode on the same kernels with one plane (the round-4 bf16 kernels of these layers, up_big_bf16 /
+// down_big_bf16, are gone: slower than the six-instruction kernels at a sixth of their matrix work, and their shadow layout
+// with them).  0 = not this family's case: the callers (conv_v2_down / conv_v2_up) go on to kernels that read the weights.
 int pgv_conv_up_big_bf16(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                          const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                          hipStream_t st, const pgv_bn_src* bn) {
-  // fp32 products as six bf16 instructions (PGV_COMPUTE_F32_SPLIT): conv_big_split.hip
-  if (int rc = pgv_conv_up_big_split(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn)) return rc;
-  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !up_big_bf16_shape(d) || (g_deep_bf16_dbg & 16)) return 0;
-  if (d->Hb == 33) return launch_up_big_bf16<UpBig<32, 64, 33, 45>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  if (d->Hb == 65) return launch_up_big_bf16<UpBig<16, 32, 65, 88, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  // (16 -> 8 channels onto 129x174 stays on the band / wave-specialised kernels: 65 us plain and 112 us fused there, 78 / 166 us
-  // here - 8 output channels leave half of every M tile empty and a whole wave per channel moves the band out; A/B knob)
-  if (!(g_deep_bf16_dbg & 256)) return 0;
-  return launch_up_big_bf16<UpBig<8, 16, 129, 174, 2>>(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  return pgv_conv_up_big_split(d, small_in, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
-
-// the stride-2 convolutions from 33x45 and 65x88 (1 / 3 = launched; 3: with the class sums of the fused epilogue)
 int pgv_conv_down_big_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                            const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                            hipStream_t st, const pgv_bn_src* bn) {
-  if (int rc = pgv_conv_down_big_split(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn)) return rc;
-  if (!(d->flags & PGV_COMPUTE_BF16) || !d->w_shadow || !down_big_bf16_shape(d) || (g_deep_bf16_dbg & 32)) return 0;
-  if (d->Hb == 33) {
-    // (the plain forward form stays on the band kernel's bf16 loop: 32 us there, 38 us here; the fused input gradient with
-    // class sums: 58 us in three launches there, 43 us here)
-    if (!fuse) return 0;
-    return launch_down_big_bf16<DownBig<32, 64, 33, 45, 4, 48, 2>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  }
-  if (d->Hb == 65) return launch_down_big_bf16<DownBig<16, 32, 65, 88, 2, 93, 3>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
-  // 8 -> 16 channels from 129x174: 70 -> 62 us plain, 110 -> 81 us fused against the band / wave-specialised kernels
-  return launch_down_big_bf16<DownBig<8, 16, 129, 174, 2, 178, 0>>(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
+  return pgv_conv_down_big_split(d, big, in_scale, in_shift, bias, act, slope, out, stats, fuse, st, bn);
 }
 
 // the shadows of n <= 8 layers in one launch (every descriptor must have a shadow: pgv_conv_weight_shadow_bytes > 0)
@@ -2748,15 +2109,16 @@ int pgv_conv_weight_shadows_impl(int n, const pgv_conv_desc* const* descs, const
   for (int i = 0; i < n; ++i) {
     const pgv_conv_desc* d = descs[i];
     const bool bf = (d->flags & PGV_COMPUTE_BF16) != 0, split = pgv_big_split_shape(d), dsplit = pgv_deep_split_shape(d);
-    const bool k1 = bf && k1_bf16_shape(d), k1split = pgv_k1_split_shape(d);
-    if (!split && !dsplit && !k1split && !(bf && (k1 || deep_bf16_shape(d) || up_big_bf16_shape(d)))) return 0;
+    const bool k1 = bf && k1_bf16_shape(d), k1split = pgv_k1_split_shape(d), bfq = pgv_big_bf16q_shape(d);
+    if (!split && !dsplit && !k1split && !bfq && !(bf && (k1 || deep_bf16_shape(d)))) return 0;
     t.w[i] = ws[i];
     t.down[i] = (u16*)shadows[i];
     t.CS[i] = d->Cs, t.CB[i] = d->Cb;
-    // kind: 0 k4 bf16, 1 1x1 bf16, 3 deep split down + up fragments, 4 split 1x1 fragments, 5 large-plane split fragments
-    t.k1[i] = k1split ? 4 : dsplit ? 3 : split ? 5 : (k1 ? 1 : 0);
+    // kind: 0 k4 bf16, 1 1x1 bf16, 3 deep split down + up fragments, 4 split 1x1 fragments, 5 large-plane split fragments,
+    // 6 large-plane fragments with one plane (bf16 operand mode)
+    t.k1[i] = k1split ? 4 : dsplit ? 3 : split ? 5 : bfq ? 6 : (k1 ? 1 : 0);
     t.items[i] = k1split ? d->Cs * d->Cb / 4
-                 : (dsplit || split) ? d->Cs * d->Cb * 4
+                 : (dsplit || split || bfq) ? d->Cs * d->Cb * 4
                                      : (k1 ? d->Cs * d->Cb / 8 : d->Cs * (d->Cb / 8) * 4);
     t.blk0[i] = blocks;
     blocks += (t.items[i] + 255) / 256;

@@ -133,6 +133,8 @@ __device__ __forceinline__ void shadow_split_k1_item(int it, const float* __rest
 // channel pair p = 4g + kq at kernel row kh - the order in which the B window of the channel-pair planar activation image
 // holds them (4 consecutive dwords = 4 input columns, a dword = the pair's two channels).  One item = (mt, ks, lane):
 // CS * CB * 2 items.
+// NPL = 3: the three planes of the exact split; NPL = 1 (bf16 operand mode): the weight rounded to nearest, one plane.
+template <int NPL = 3>
 __device__ __forceinline__ void shadow_bigq_down_item(int it, const float* __restrict__ w, int CS, int CB,
                                                       unsigned short* __restrict__ sh) {
   const int lane = it & 63, rest = it >> 6, ksteps = CB / 2, ng = CB / 8;
@@ -141,14 +143,17 @@ __device__ __forceinline__ void shadow_bigq_down_item(int it, const float* __res
   float h[8], mid[8], l[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) pgv_split3(w[((size_t)cs * CB + 2 * cp + (c & 1)) * 16 + kh * 4 + (c >> 1)], h[c], mid[c], l[c]);
-  u32x4* dst = reinterpret_cast<u32x4*>(sh) + ((size_t)rest * 3) * 64 + lane;
+  u32x4* dst = reinterpret_cast<u32x4*>(sh) + ((size_t)rest * NPL) * 64 + lane;
   dst[0] = u32x4{pgv_pack_bf16x2(h[0], h[1]), pgv_pack_bf16x2(h[2], h[3]), pgv_pack_bf16x2(h[4], h[5]), pgv_pack_bf16x2(h[6], h[7])};
-  dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
-  dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+  if constexpr (NPL == 3) {
+    dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
+    dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+  }
 }
 // UP layout [M tile][K step g = group of 8 small channels][plane][lane], M rows r = phase * CB + cb (phase = 2 ph + pw of the
 // output pixel): the 16 bytes (small channels g*8 .. +7 at the phase's tap kq = 2 th + tw, i.e. kernel tap (ph + 2 th, pw + 2 tw))
 // of row r = mt*16 + m.  One item = (mt, g, lane): CS * CB * 2 items.
+template <int NPL = 3>
 __device__ __forceinline__ void shadow_bigq_up_item(int it, const float* __restrict__ w, int CS, int CB,
                                                     unsigned short* __restrict__ sh) {
   const int lane = it & 63, rest = it >> 6, ng = CS / 8, g = rest % ng, mt = rest / ng;
@@ -157,10 +162,12 @@ __device__ __forceinline__ void shadow_bigq_up_item(int it, const float* __restr
   float h[8], mid[8], l[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) pgv_split3(w[((size_t)(g * 8 + c) * CB + cb) * 16 + kh * 4 + kw], h[c], mid[c], l[c]);
-  u32x4* dst = reinterpret_cast<u32x4*>(sh) + ((size_t)rest * 3) * 64 + lane;
+  u32x4* dst = reinterpret_cast<u32x4*>(sh) + ((size_t)rest * NPL) * 64 + lane;
   dst[0] = u32x4{pgv_pack_bf16x2(h[0], h[1]), pgv_pack_bf16x2(h[2], h[3]), pgv_pack_bf16x2(h[4], h[5]), pgv_pack_bf16x2(h[6], h[7])};
-  dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
-  dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+  if constexpr (NPL == 3) {
+    dst[64] = u32x4{pgv_pack_bf16x2(mid[0], mid[1]), pgv_pack_bf16x2(mid[2], mid[3]), pgv_pack_bf16x2(mid[4], mid[5]), pgv_pack_bf16x2(mid[6], mid[7])};
+    dst[128] = u32x4{pgv_pack_bf16x2(l[0], l[1]), pgv_pack_bf16x2(l[2], l[3]), pgv_pack_bf16x2(l[4], l[5]), pgv_pack_bf16x2(l[6], l[7])};
+  }
 }
 
 }  // namespace

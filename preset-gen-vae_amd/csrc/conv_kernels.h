@@ -151,6 +151,7 @@ int pgv_conv_up_deep_split(const pgv_conv_desc* d, const float* small_in, const 
 // over (sample, band) units; per unit a matrix phase in which all eight waves multiply (weights in registers, in fragment
 // order) and a vector phase in which they split and commit the next unit's band and move the output tile out
 bool pgv_big_split_shape(const pgv_conv_desc* d);
+bool pgv_big_bf16q_shape(const pgv_conv_desc* d);   // the same kernels with one operand plane: bf16 operand mode
 int pgv_conv_down_big_split(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
                             const float* bias, int act, float slope, float* out, double* stats, const pgv_bwd_fuse* fuse,
                             hipStream_t st, const pgv_bn_src* bn);

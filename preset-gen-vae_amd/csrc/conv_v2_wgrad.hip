@@ -764,8 +764,9 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
     return launch_wgrad5_v2<4>(d, big, small_in, small_scale, small_shift, gw, workspace, workspace_bytes, req, bias, st);
   if (d->stride != 2 || d->pad != 2 || d->kh != 4 || d->kw != 4) return 0;
   if (d->B <= 0) return 0;
-  const bool split = pgv_big_split_shape(d) && workspace && !((uintptr_t)gw & 15) && !((uintptr_t)workspace & 15) &&
-                     !(big_scale && small_scale);
+  // (the large-plane kernels of conv_wgrad_split.hip: fp32 products as six bf16 instructions, or bf16 operand mode with one plane)
+  const bool split = (pgv_big_split_shape(d) || pgv_big_bf16q_shape(d)) && workspace && !((uintptr_t)gw & 15) &&
+                     !((uintptr_t)workspace & 15) && !(big_scale && small_scale);
   if ((d->flags & PGV_COMPUTE_BF16) || split) {
     // bf16 operand mode: the band kernels (v_mfma_f32_16x16x32_bf16) leave per-workgroup partial gradients in the workspace
     // and the reduce launch of this file adds them up - with the tap sums / bias roles the fp32 step folds into it.
@@ -773,10 +774,10 @@ int pgv_conv_wgrad_v2(const pgv_conv_desc* d, const float* big, const float* big
     if (!workspace || ((uintptr_t)gw & 15) || ((uintptr_t)workspace & 15)) return 0;
     int nparts = 0;
     int rc = 0;
-    if (split) {
+    if (split)
       rc = pgv_conv_wgrad_split_partial(d, big, big_scale, big_shift, small_in, small_scale, small_shift, (float*)workspace,
                                         workspace_bytes, &nparts, st);
-    } else {
+    if (rc == 0 && (d->flags & PGV_COMPUTE_BF16)) {   // (bf16 operand mode: the round-4 kernels, for what the above did not take)
       rc = (g_wgrad_bf16_variant & 1) ? 0
                                       : pgv_conv_wgrad_bf16_partial(d, big, big_scale, big_shift, small_in, small_scale,
                                                                     small_shift, (float*)workspace, workspace_bytes, &nparts, st);

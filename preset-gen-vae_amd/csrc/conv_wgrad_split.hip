@@ -52,9 +52,13 @@ __device__ __forceinline__ void ws_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n
 __device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0}, kTermB[6] = {2, 0, 1, 1, 0, 0};   // (plane of a, plane of b), smallest first
 
 // strides in bf16 elements from scratch/wgrad_split_strides.py (conflict-free ds_read_b128 groups where the shape allows)
-template <int CB_, int CS_, int W_, int H_, int R_, int SCH_, int XCH_, int XPL_, int NQ_, int KWAYS_>
+// NPL = operand planes: 3 = six-instruction fp32 products on exact three-way splits, 1 = bf16 operand mode (PGV_COMPUTE_BF16:
+// both operands rounded to nearest where they are committed, one instruction per fragment pair) - as in conv_big_split.hip
+template <int CB_, int CS_, int W_, int H_, int R_, int SCH_, int XCH_, int XPL_, int NQ_, int KWAYS_, int NPL_ = 3>
 struct WgQ {
   static constexpr int CB = CB_, CS = CS_, W = W_, H = H_, R = R_, SCH = SCH_, XCH = XCH_, XPL = XPL_, NQ = NQ_, KWAYS = KWAYS_;
+  static constexpr int NPL = NPL_, NTERM = NPL_ == 3 ? 6 : 1;
+  static_assert(NPL_ == 3 || NPL_ == 1, "three planes (six product terms) or one");
   static constexpr int Ws = W / 2 + 1, Hs = H / 2 + 1, BANDS = (Hs + R - 1) / R, XR = 2 * R + 2;
   static constexpr int GPR = (Ws + 7) / 8, XROW = GPR * 8, SROW = GPR * 8 + 8;   // 8-pixel groups per row; row strides (S: + 8 zeros)
   static constexpr int NGRP = R * GPR, KS = (NGRP + 3) / 4, KSW = (KS + KWAYS - 1) / KWAYS;   // K steps of a unit / of a wave
@@ -62,7 +66,7 @@ struct WgQ {
   static constexpr int S_PLANE = CS * SCH, X_PLANE = 2 * XPL;   // elements of one plane image
   static constexpr int OX = (W + 7) / 8, X_ITEMS = CB * XR * OX, S_ITEMS = CS * R * GPR;
   static constexpr int QX = (X_ITEMS + 511) / 512, QS = (S_ITEMS + 511) / 512;
-  static constexpr size_t IMG_BYTES = 3 * 2 * (size_t)(S_PLANE + X_PLANE);
+  static constexpr size_t IMG_BYTES = NPL * 2 * (size_t)(S_PLANE + X_PLANE);
   static constexpr size_t LDS_BYTES = IMG_BYTES + sizeof(float) * 2 * (CB + CS);
   static_assert(2 * NQ * KWAYS == 8 && (CB / 2) % NQ == 0 && CS % 16 == 0, "eight waves: kernel-column half x column groups x K ways");
   static_assert(SCH >= R * SROW + 8 && XCH >= XR * XROW && XPL >= CB * XCH && SCH % 8 == 0 && XCH % 8 == 0 && XPL % 8 == 0, "plane strides");
@@ -78,8 +82,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
   constexpr int CB = G::CB, CS = G::CS, W = G::W, H = G::H, R = G::R, Ws = G::Ws, Hs = G::Hs, MT = G::MT, CTW = G::CTW;
   constexpr int SCH = G::SCH, XCH = G::XCH, XPL = G::XPL, SROW = G::SROW, XROW = G::XROW, GPR = G::GPR, KSW = G::KSW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  u16* s_img = reinterpret_cast<u16*>(lds_raw);                     // [3][CS][SCH]
-  u16* x_img = s_img + 3 * G::S_PLANE;                              // [3][2 parities][XPL]
+  constexpr int NPL = G::NPL, NTERM = G::NTERM;
+  u16* s_img = reinterpret_cast<u16*>(lds_raw);                     // [NPL][CS][SCH]
+  u16* x_img = s_img + NPL * G::S_PLANE;                            // [NPL][2 parities][XPL]
   float* aff_b = reinterpret_cast<float*>(lds_raw + G::IMG_BYTES);   // [2][CB]
   float* aff_s = aff_b + 2 * CB;                                    // [2][CS]
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
@@ -147,20 +152,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
         // rows outside the plane arrived as zeros)
         y[e] = 8 * o + e < W ? (BIG_AFF ? fmaf(v, sc, sh) : v) : 0.f;
       }
-      unsigned e1[2], e2[2], e3[2], o1[2], o2[2], o3[2];
+      unsigned e1[2], e2[2] = {0, 0}, e3[2] = {0, 0}, o1[2], o2[2] = {0, 0}, o3[2] = {0, 0};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k], sel);       // even columns 8o + 4k, + 2
-        pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k], sel);   // odd columns
+        if constexpr (NPL == 3) {
+          pgv_split3_pair(y[4 * k], y[4 * k + 2], e1[k], e2[k], e3[k], sel);       // even columns 8o + 4k, + 2
+          pgv_split3_pair(y[4 * k + 1], y[4 * k + 3], o1[k], o2[k], o3[k], sel);   // odd columns
+        } else {   // bf16 operand mode: rounded to nearest, one plane
+          e1[k] = pgv_pack_bf16x2(y[4 * k], y[4 * k + 2]);
+          o1[k] = pgv_pack_bf16x2(y[4 * k + 1], y[4 * k + 3]);
+        }
       }
       u16* dst = x_img + c * XCH + r * XROW + 4 * o;
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(dst) = u32x2{e1[0], e1[1]};
       *reinterpret_cast<u32x2*>(dst + XPL) = u32x2{o1[0], o1[1]};
-      *reinterpret_cast<u32x2*>(dst + G::X_PLANE) = u32x2{e2[0], e2[1]};
-      *reinterpret_cast<u32x2*>(dst + G::X_PLANE + XPL) = u32x2{o2[0], o2[1]};
-      *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE) = u32x2{e3[0], e3[1]};
-      *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
+      if constexpr (NPL == 3) {
+        *reinterpret_cast<u32x2*>(dst + G::X_PLANE) = u32x2{e2[0], e2[1]};
+        *reinterpret_cast<u32x2*>(dst + G::X_PLANE + XPL) = u32x2{o2[0], o2[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE) = u32x2{e3[0], e3[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * G::X_PLANE + XPL) = u32x2{o3[0], o3[1]};
+      }
     }
   };
   auto commit_s = [&](int i, const UnitPos& up, float a_sc, float a_sh) {
@@ -173,14 +185,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
         const float v0 = k < 2 ? sb[i][0][2 * k] : sb[i][1][2 * k - 4], v1 = k < 2 ? sb[i][0][2 * k + 1] : sb[i][1][2 * k - 3];
         const float y0 = 8 * o + 2 * k < Ws ? (SMALL_AFF ? fmaf(v0, sc, sh) : v0) : 0.f;
         const float y1 = 8 * o + 2 * k + 1 < Ws ? (SMALL_AFF ? fmaf(v1, sc, sh) : v1) : 0.f;
-        unsigned a1, a2, a3;
-        pgv_split3_pair(y0, y1, a1, a2, a3, sel);
+        unsigned a1, a2 = 0, a3 = 0;
+        if constexpr (NPL == 3)
+          pgv_split3_pair(y0, y1, a1, a2, a3, sel);
+        else
+          a1 = pgv_pack_bf16x2(y0, y1);
         p1[k] = a1, p2[k] = a2, p3[k] = a3;
       }
       u16* dst = s_img + c * SCH + r * SROW + 8 * o;
       *reinterpret_cast<u32x4*>(dst) = p1;
-      *reinterpret_cast<u32x4*>(dst + G::S_PLANE) = p2;
-      *reinterpret_cast<u32x4*>(dst + 2 * G::S_PLANE) = p3;
+      if constexpr (NPL == 3) {
+        *reinterpret_cast<u32x4*>(dst + G::S_PLANE) = p2;
+        *reinterpret_cast<u32x4*>(dst + 2 * G::S_PLANE) = p3;
+      }
     }
   };
   // commit unit jc from the registers, re-issue them for unit jc + 1
@@ -254,11 +271,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
 #pragma unroll
     for (int k = 0; k < KSW; ++k) {
       if (k == 0 || 4 * (kw0 + G::KWAYS * k) < nvalid_groups) {   // (wave-uniform; the steps of a wave are in row order)
-        u32x4 a[MT][3];
+        u32x4 a[MT][NPL];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
             const u16* ap = s_img + p * G::S_PLANE + offA[k] + m * 16 * SCH;
             const u32x4 w = *reinterpret_cast<const u32x4*>(ap);
             if (h) {   // kernel columns 2, 3: S itself
@@ -271,13 +288,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(int B, const floa
           }
 #pragma unroll
         for (int t = 0; t < CTW; ++t) {
-          u32x4 bfr[3];
+          u32x4 bfr[NPL];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(x_img + p * G::X_PLANE + offB[k] + 2 * t * XCH);
+          for (int p = 0; p < NPL; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(x_img + p * G::X_PLANE + offB[k] + 2 * t * XCH);
 #pragma unroll
-          for (int term = 0; term < 6; ++term)
+          for (int term = 0; term < NTERM; ++term) {
+            const int pa = NPL == 3 ? kTermA[term] : 0, pb = NPL == 3 ? kTermB[term] : 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16_k32(a[m][kTermA[term]], bfr[kTermB[term]], acc[m][t]);
+            for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16_k32(a[m][pa], bfr[pb], acc[m][t]);
+          }
         }
       }
     }
@@ -364,7 +383,18 @@ int launch_wgq(const pgv_conv_desc* d, const float* big, const float* big_scale,
 int pgv_conv_wgrad_split_partial(const pgv_conv_desc* d, const float* big, const float* big_scale, const float* big_shift,
                                  const float* small_in, const float* small_scale, const float* small_shift, float* partial,
                                  int64_t partial_bytes, int* nparts, hipStream_t st) {
-  if (!pgv_big_split_shape(d) || !partial) return 0;
+  if (!partial) return 0;
+  if (pgv_big_bf16q_shape(d)) {   // bf16 operand mode: one plane per operand, the same tilings
+    if (d->Hb == 129)
+      return launch_wgq<WgQ<8, 16, 174, 129, 4, 400, 896, 7232, 1, 4, 1>>(d, big, big_scale, big_shift, small_in, small_scale,
+                                                                          small_shift, partial, partial_bytes, nparts, st);
+    if (d->Hb == 65)
+      return launch_wgq<WgQ<16, 32, 88, 65, 4, 240, 512, 8256, 2, 2, 1>>(d, big, big_scale, big_shift, small_in, small_scale,
+                                                                         small_shift, partial, partial_bytes, nparts, st);
+    return launch_wgq<WgQ<32, 64, 45, 33, 4, 144, 256, 8256, 4, 1, 1>>(d, big, big_scale, big_shift, small_in, small_scale,
+                                                                       small_shift, partial, partial_bytes, nparts, st);
+  }
+  if (!pgv_big_split_shape(d)) return 0;
   if (d->Hb == 129)
     return launch_wgq<WgQ<8, 16, 174, 129, 4, 400, 896, 7232, 1, 4>>(d, big, big_scale, big_shift, small_in, small_scale, small_shift,
                                                                      partial, partial_bytes, nparts, st);

@@ -708,7 +708,12 @@ def test_train_step_odd_batch_sizes_in_the_bench_modes(arch, dim_z, mode, B):
         assert all(abs(u - v) <= 1e-6 * abs(u) + 1e-7 for u, v in zip(a[:2], b[:2])), (a, b)
         assert abs(a[2] - b[2]) <= 1e-3 * a[2], (a, b)
     else:
-        assert all(abs(u - v) <= 2e-2 * abs(u) + 1e-6 for u, v in zip(a, b)), (a, b)
+        # (bf16 operand arithmetic really differs from fp32 by this much: the float64 oracle run with rounded operands
+        # - oracle.vae_oracle.operand_precision('bf16') - gives a gradient norm 2.48 % above the fp32 one at B = 1 (2.6335
+        # against 2.5697; the device's 2.6315 is within 0.1 % of it) and 1.3 % below at B = 3: one sample per BatchNorm
+        # statistic.  The losses stay within 0.3 %.)
+        assert all(abs(u - v) <= 2e-2 * abs(u) + 1e-6 for u, v in zip(a[:2], b[:2])), (a, b)
+        assert abs(a[2] - b[2]) <= (3.5e-2 if B == 1 else 2e-2) * a[2], (a, b)
 
 
 def test_prefetched_minibatches_equal_direct_steps():
