@@ -505,6 +505,13 @@ def _cpu_model():
 def _frontend_cpu_worker(job):
     """One worker process of the all-cores CPU front-end baseline: per-item loop for ``seconds``, returns the item count."""
     seed, seconds = job
+    try:   # one BLAS / OpenMP thread per worker process: the workers ARE the parallelism (256 processes x a threaded BLAS
+        #    each gave 148 waveforms/s on a 256-thread host against 121 on one core)
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except ImportError:
+        pass
+    torch.set_num_threads(1)
     from oracle import audio_oracle as ao   # CPU baseline leg only
     from preset_gen_vae_amd.utils.synthetic import fm_voice
     waves = [fm_voice(idx=seed * 4 + i) for i in range(4)]
@@ -526,7 +533,11 @@ def frontend_cpu_all_cores(seconds=5.0):
     bench.py, BEFORE this process makes its first GPU call (a process that has initialised HIP must not fork workers)."""
     global _FRONTEND_ALL_CORES
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 128))   # (one worker per core up to 128: beyond that the fork + import cost eats the sample)
     try:
         with mp.get_context('fork').Pool(cores) as pool:
             res = pool.map(_frontend_cpu_worker, [(i, seconds) for i in range(cores)])
