@@ -91,7 +91,8 @@ int pgv_abi_version(void);
 const char* pgv_last_error(void);
 /* 0 = prefer tuned kernels (default), 1 = force the generic one-thread-per-output kernels, 2 = tuned kernels but
  * without the shape-specialised band kernels of the reference layer shapes, 3 = policy 0 without the wave-specialised
- * second-generation kernels (1-3 are test / A-B timing aids; process-wide). */
+ * second-generation kernels (1-3 are test / A-B timing aids; process-wide).  1-3 also keep the first-generation front-end
+ * kernel in pgv_stft / pgv_stft_mel (0 runs the 16-frame-group kernel for hop 256 with a mel projection). */
 int pgv_set_kernel_policy(int policy);
 
 /* ---- convolutions (layer.Conv2D / layer.TConv2D bodies, model/layer.py:10-46) -------------------- */

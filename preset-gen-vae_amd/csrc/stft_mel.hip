@@ -58,6 +58,11 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// the value of another lane (byte address = 4 x lane)
+__device__ __forceinline__ float lane_fetch(int lane4, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(lane4, __float_as_int(v)));
+}
+
 // forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
 __device__ __forceinline__ void bfly4(c32& a, c32& b, c32& c, c32& d) {
   const c32 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
@@ -331,6 +336,210 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation (round 6) for the configuration the model is trained on: hop = 256, mel projection, dB or linear
+// output.  Same arithmetic as stft_mel_kernel (same dft16 / twiddle tables / magnitude formulas, the mel sums in the same
+// tap order), reorganised around what the first kernel waits for (phase toggles: skeleton 40 us + FFT 53 + magnitudes 17 +
+// mel gather 51 + output 19 = 181 us, all in series at two waves per SIMD):
+//   * FOUR waves per SIMD: a 512-thread workgroup = 8 waves = the 8 frame pairs of a 16-frame group, two workgroups per
+//     CU.  LDS per workgroup is the eight 8.7 KB exchange buffers plus 7 KB of tables; the magnitude array of the group
+//     ALIASES the exchange buffers (the magnitudes cross the barrier in registers).  No signal window in LDS: a pair's
+//     samples are 20 coalesced 256-byte buffer loads per lane (frame b is frame a shifted by four 64-sample rows),
+//     re-issued for the next group as soon as they are consumed - in flight across a whole group; out-of-range
+//     samples = the buffer's bounds check = the centre zero padding.  128 VGPRs (pass-B twiddles come from LDS).
+//   * the conjugate partner Z[1024 - k] lives in lane 64 - lane: 16 ds_bpermute_b32 instead of writing the spectrum to
+//     LDS in natural order and reading both halves back (16 + 18 + 9 LDS instructions, 3 dependent round trips).
+//   * the mel projection runs on the whole group with lanes ALONG FRAMES: a wave instruction handles 4 rows x 16 frames,
+//     a tap is one ds_read_b32 of mags[bin][frame] (64 contiguous bytes per row) + one broadcast weight + one FMA, with
+//     immediate offsets (the taps of a Slaney filter are contiguous bins: the plan is checked in the kernel's prologue, any
+//     other CSR takes a gather loop).  Weights are re-laid per 4-row group, zero-padded to the group's widest row, so the
+//     tap loop has a wave-uniform trip count and no masks.  One lane = one output element: dB + affine + a store that is
+//     64 contiguous bytes per row - no output tile in LDS, no copy-out phase.
+constexpr int G8_WAVES = 8, G8_MS = 17;        // frame pairs per group; row stride of mags[bin][frame] (floats)
+constexpr int G8_PADROWS = 16;                 // zero rows behind the last bin (padded taps read them)
+
+__global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
+    const float* __restrict__ wav, int64_t n_samples, int n_frames, const float* __restrict__ window, float inv_norm,
+    const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
+    float floor_lin, float aff_a, float aff_b, float* __restrict__ out, int pval_cap, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  c32* xall = reinterpret_cast<c32*>(lds);                              // [8][XBUF]
+  float* mags = lds + 2 * G8_WAVES * XBUF - NBIN * G8_MS;               // [NBIN][17], the tail of the exchange region ...
+  float* zpad = lds + 2 * G8_WAVES * XBUF;                              // ... running into 16 rows that stay zero
+  c32* twb_t = reinterpret_cast<c32*>(zpad + G8_PADROWS * G8_MS);       // [16][4]  (17408 + 272 floats: 8-byte aligned)
+  int* row_lo = reinterpret_cast<int*>(twb_t + 64);                     // [n_rows]
+  const int NG = (n_rows + 3) >> 2;
+  int* grp_w = row_lo + n_rows;                                         // [NG]
+  int* grp_off = grp_w + NG;                                            // [NG]
+  int* plan_bad = grp_off + NG;                                         // [1]
+  float* pval = reinterpret_cast<float*>(plan_bad + 1);                 // [pval_cap]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  c32* xb = xall + wave * XBUF;
+
+  // ---- prologue: W_1024 (in the exchange region), the mel plan
+  for (int i = tid; i < NFFT; i += 512) {
+    float sn, cs;
+    sincospif(-2.0f * (float)i / (float)NFFT, &sn, &cs);
+    xall[i] = mk(cs, sn);
+  }
+  for (int i = tid; i < G8_PADROWS * G8_MS; i += 512) zpad[i] = 0.f;
+  if (tid == 0) *plan_bad = 0;
+  __syncthreads();
+  // rows: first bin and tap count; taps must be consecutive bins
+  for (int r = tid; r < n_rows; r += 512) {
+    const int e0 = row_ptr[r], e1 = row_ptr[r + 1], cnt = e1 - e0, lo = cnt > 0 ? col[e0] : 0;
+    bool ok = cnt >= 0 && cnt <= G8_PADROWS && lo >= 0 && lo + cnt <= NBIN;
+    for (int e = e0; ok && e < e1; ++e) ok = col[e] == lo + (e - e0);
+    if (!ok) atomicOr(plan_bad, 1);
+    row_lo[r] = lo;
+  }
+  __syncthreads();
+  for (int g = tid; g < NG; g += 512) {
+    int w = 2;
+    for (int j = 0; j < 4; ++j) {
+      const int r = min(4 * g + j, n_rows - 1);
+      w = max(w, row_ptr[r + 1] - row_ptr[r]);
+    }
+    grp_w[g] = (w + 1) & ~1;   // even: the tap loop runs two taps per trip
+  }
+  __syncthreads();
+  for (int g = tid; g < NG; g += 512) {
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += 4 * grp_w[i];
+    grp_off[g] = o;
+    if (g == NG - 1 && o + 4 * grp_w[g] > pval_cap) atomicOr(plan_bad, 1);
+  }
+  __syncthreads();
+  const bool plan_ok = *plan_bad == 0;
+  if (plan_ok)
+    for (int r = tid; r < 4 * NG; r += 512) {
+      const int g = r >> 2, w = grp_w[g], rr = min(r, n_rows - 1), e0 = row_ptr[rr], cnt = r < n_rows ? row_ptr[rr + 1] - e0 : 0;
+      float* d = pval + grp_off[g] + (r & 3) * w;
+      for (int e = 0; e < w; ++e) d[e] = e < cnt ? val[e0 + e] : 0.f;
+    }
+  c32 twA[16];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) twA[k] = xall[(lane * k) & (NFFT - 1)];
+  if (tid < 64) twb_t[tid] = xall[(16 * (tid & 3) * (tid >> 2)) & (NFFT - 1)];   // [j1 = tid >> 2][m2 = tid & 3]
+  __syncthreads();
+
+  // ---- the pair of this wave in group f0: 20 rows of 64 samples from sample (f0 + 2 wave) * 256 - 512
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(wav + (int64_t)b * n_samples), 0, (int)(n_samples * 4), 0x00020000);
+  // (the window rides with the samples - 16 more loads that hit the L1: held in registers for the whole kernel it was
+  // what the compiler spilled)
+  const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc((void*)window, 0, NFFT * 4, 0x00020000);
+  float sreg[20], wreg[16];
+  auto issue = [&](int f0) {
+    const int base = ((f0 + 2 * wave) * 256 - NFFT / 2 + lane) * 4;   // (negative = before the signal = beyond the buffer: zero)
+#pragma unroll
+    for (int j = 0; j < 20; ++j) sreg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, base + 256 * j, 0, 0));
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win_rs, (lane + 64 * n1) * 4, 0, 0));
+  };
+  const int f00 = blockIdx.x * FT;
+  if (f00 < n_frames) issue(f00);
+
+  for (int f0 = f00; f0 < n_frames; f0 += gridDim.x * FT) {
+    const int nf = min(FT, n_frames - f0), fp = 2 * wave;
+    c32 x[16];
+    // ---- pass A
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      // (two plain multiplies: the packed form wants (s[n1], s[n1 + 4]) and (w, w) as register PAIRS - 72 registers for
+      // the 36 prefetched values)
+      x[n1].x = sreg[n1] * wreg[n1];
+      x[n1].y = sreg[n1 + 4] * wreg[n1];
+    }
+    dft16(x);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) xb[k1 * XROW + lane] = k1 ? cmul(x[P16(k1)], twA[k1]) : x[P16(0)];
+    wave_sync();
+    // ---- pass B
+    {
+      const c32* src = xb + (lane >> 2) * XROW + (lane & 3);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) x[m1] = src[4 * m1];
+    }
+    wave_sync();
+    dft16(x);
+    {
+      c32* dst = xb + (lane >> 2) * XROW + (lane & 3);
+      const c32* tw = twb_t + (lane & 3);
+#pragma unroll
+      for (int j1 = 0; j1 < 16; ++j1) dst[4 * j1] = j1 ? cmul(x[P16(j1)], tw[4 * j1]) : x[P16(0)];
+    }
+    wave_sync();
+    // ---- pass C: lane = k1 + 16 jq; x[4 r + j2] = Z[lane + 64 (r + 4 j2)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const c32* src = xb + (lane & 15) * XROW + ((lane >> 4) + 4 * r) * 4;
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) x[4 * r + m2] = src[m2];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bfly4(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3]);
+    // ---- conjugate partners: Z[1024 - (lane + 64 q)] = Z[(64 - lane) + 64 (15 - q)] sits in lane 64 - lane, slot 15 - q
+    // (lane 0: in lane 0 itself, slot 16 - q; slots 0 and 8 of lane 0 are their own partners), then the two magnitudes
+    auto XQ = [&](int q) -> c32& { return x[4 * (q & 3) + (q >> 2)]; };
+    c32 mg[9];
+    const int src_lane4 = ((64 - lane) & 63) * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const c32 up = XQ(15 - q);
+      c32 zn = mk(lane_fetch(src_lane4, up.x), lane_fetch(src_lane4, up.y));
+      const c32 own = q ? XQ(16 - q) : XQ(0);
+      if (lane == 0) zn = own;
+      const c32 zk = XQ(q);
+      const float x1r = 0.5f * (zk.x + zn.x), x1i = 0.5f * (zk.y - zn.y);
+      const float x2r = 0.5f * (zk.y + zn.y), x2i = -0.5f * (zk.x - zn.x);
+      mg[q] = mk(__builtin_amdgcn_sqrtf(x1r * x1r + x1i * x1i) * inv_norm, __builtin_amdgcn_sqrtf(x2r * x2r + x2i * x2i) * inv_norm);
+    }
+    {
+      const c32 zk = XQ(8);   // bin 512 (lane 0 only)
+      mg[8] = mk(__builtin_amdgcn_sqrtf(zk.x * zk.x) * inv_norm, __builtin_amdgcn_sqrtf(zk.y * zk.y) * inv_norm);
+    }
+    __syncthreads();   // every wave is done with its exchange buffer: the magnitude array may overwrite them
+    {
+      float* d = mags + lane * G8_MS + fp;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[64 * q * G8_MS] = mg[q].x, d[64 * q * G8_MS + 1] = mg[q].y;
+      if (lane == 0) d[512 * G8_MS] = mg[8].x, d[512 * G8_MS + 1] = mg[8].y;
+    }
+    // the next group's samples and window: in flight across the mel phase (issued any earlier they are 36 more live
+    // registers next to the transform's or the magnitudes': 128 are all a wave has at four waves per SIMD)
+    if (f0 + gridDim.x * FT < n_frames) issue(f0 + gridDim.x * FT);
+    __syncthreads();
+    // ---- mel projection of the group: lane = (row of the 4-row group, frame)
+    {
+      const int f = lane & 15, j = lane >> 4;
+      float* o = out + (int64_t)b * n_rows * n_frames + f0 + f;
+      for (int g = wave; g < NG; g += G8_WAVES) {
+        const int r = 4 * g + j, rr = min(r, n_rows - 1);
+        float m = 0.f;
+        if (plan_ok) {
+          const int w = __builtin_amdgcn_readfirstlane(grp_w[g]);
+          const float* mp = mags + row_lo[rr] * G8_MS + f;
+          const float* wp = pval + __builtin_amdgcn_readfirstlane(grp_off[g]) + j * w;
+          for (int e = 0; e < w; e += 2) {
+            m = fmaf(wp[e], mp[e * G8_MS], m);
+            m = fmaf(wp[e + 1], mp[(e + 1) * G8_MS], m);
+          }
+        } else {
+          for (int e = row_ptr[rr]; e < row_ptr[rr + 1]; ++e) m = fmaf(val[e], mags[col[e] * G8_MS + f], m);
+        }
+        if (r < n_rows && f < nf)
+          o[(int64_t)r * n_frames] =
+              mode == PGV_STFT_LINEAR ? m : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m, floor_lin)), aff_b);
+      }
+    }
+    __syncthreads();   // the next group's transposes overwrite the magnitudes
+  }
+}
+
 }  // namespace
 
 extern "C" int pgv_stft_mel(const float* wav, int B, int64_t n_samples, int n_fft, int hop, int n_frames,
@@ -357,6 +566,28 @@ extern "C" int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, i
                 "pgv_stft_mel: n_frames=%d exceeds 1 + n_samples/hop (centre padding)", n_frames);
   if (B == 0) return PGV_OK;
   const int n_rows = n_mels > 0 ? n_mels : NBIN;
+  // the second-generation kernel: hop 256 with a mel projection (the trained configuration); kernel policies 1 - 3 keep the
+  // first kernel (the in-library cross-check of the tests), which also serves every other hop / output mode
+  if (pgv_kernel_policy() == 0 && n_mels > 0 && hop == 256 && out_mode != PGV_STFT_COMPLEX && n_samples < ((int64_t)1 << 29)) {
+    const int ng = (n_rows + 3) / 4;
+    const size_t fixed = 2 * (size_t)G8_WAVES * XBUF + G8_PADROWS * G8_MS + 128 + (size_t)n_rows + 2 * (size_t)ng + 1;
+    const size_t budget = 80 * 1024 / sizeof(float);
+    if (fixed + 8 * (size_t)ng <= budget) {   // (room for at least two taps per row; a plan that does not fit gathers instead)
+      const int pval_cap = (int)min((size_t)4 * G8_PADROWS * ng, budget - fixed);
+      static bool attr2_set = false;
+      if (!attr2_set) {
+        (void)hipFuncSetAttribute((const void*)stft_mel_g8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr2_set = true;
+      }
+      const int groups = (int)pgv_cdiv(n_frames, FT);
+      const int per_wave = (int)max((int64_t)1, min((int64_t)groups, pgv_cdiv(512, B)));
+      hipLaunchKernelGGL(stft_mel_g8_kernel, dim3((unsigned)per_wave, (unsigned)B), dim3(512), sizeof(float) * (fixed + pval_cap),
+                         pgv_stream(stream), wav, n_samples, n_frames, window, 1.0f / norm, mel_row_ptr, mel_col, mel_val, n_rows,
+                         floor_lin, affine_a, affine_b, out, pval_cap, out_mode);
+      PGV_CHECK_LAUNCH("stft_mel_g8");
+      return PGV_OK;
+    }
+  }
   const int sig_len = (FT - 1) * hop + NFFT;
   const size_t fixed_floats = 2 * (size_t)NWAVE * XBUF + ((sig_len + 3) & ~3) + (((size_t)n_rows * (FT + 1) + 3) & ~(size_t)3) +
                               (size_t)n_rows + 1 + 3;
