@@ -37,6 +37,13 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b) {
       : "=v"(r) : "v"(a), "v"(b), "v"(t));
   return r;
 }
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {
+  c32 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));        // (a.x b.x, -a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));   // + (a.y b.y, a.y b.x)
+  return r;
+}
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return a - b; }
 // a - i b = (a.x + b.y, a.y - b.x);  a + i b = (a.x - b.y, a.y + b.x)
@@ -339,109 +346,141 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Second generation (round 6) for the configuration the model is trained on: hop = 256, mel projection, dB or linear
-// output.  Same arithmetic as stft_mel_kernel (same dft16 / twiddle tables / magnitude formulas, the mel sums in the same
-// tap order), reorganised around what the first kernel waits for (phase toggles: skeleton 40 us + FFT 53 + magnitudes 17 +
-// mel gather 51 + output 19 = 181 us, all in series at two waves per SIMD):
+// output.  Same arithmetic as stft_mel_kernel (same dft16 / twiddle tables, the magnitudes rounded the same way, the mel
+// sums in the same tap order), reorganised around what the first kernel waits for (phase toggles: skeleton 40 us + FFT 53 +
+// magnitudes 17 + mel gather 51 + output 19 = 181 us, all in series at two waves per SIMD):
 //   * FOUR waves per SIMD: a 512-thread workgroup = 8 waves = the 8 frame pairs of a 16-frame group, two workgroups per
-//     CU.  LDS per workgroup is the eight 8.7 KB exchange buffers plus 7 KB of tables; the magnitude array of the group
+//     CU.  LDS per workgroup is the eight 8.7 KB exchange buffers plus 8 KB of tables; the magnitude array of the group
 //     ALIASES the exchange buffers (the magnitudes cross the barrier in registers).  No signal window in LDS: a pair's
 //     samples are 20 coalesced 256-byte buffer loads per lane (frame b is frame a shifted by four 64-sample rows),
-//     re-issued for the next group as soon as they are consumed - in flight across a whole group; out-of-range
-//     samples = the buffer's bounds check = the centre zero padding.  128 VGPRs (pass-B twiddles come from LDS).
+//     re-issued for the next group as soon as the magnitudes are out of the registers - in flight across the mel phase;
+//     out-of-range samples = the buffer's bounds check = the centre zero padding.  128 VGPRs (pass-B twiddles from LDS,
+//     the window rides with the samples).
 //   * the conjugate partner Z[1024 - k] lives in lane 64 - lane: 16 ds_bpermute_b32 instead of writing the spectrum to
 //     LDS in natural order and reading both halves back (16 + 18 + 9 LDS instructions, 3 dependent round trips).
-//   * the mel projection runs on the whole group with lanes ALONG FRAMES: a wave instruction handles 4 rows x 16 frames,
-//     a tap is one ds_read_b32 of mags[bin][frame] (64 contiguous bytes per row) + one broadcast weight + one FMA, with
-//     immediate offsets (the taps of a Slaney filter are contiguous bins: the plan is checked in the kernel's prologue, any
-//     other CSR takes a gather loop).  Weights are re-laid per 4-row group, zero-padded to the group's widest row, so the
-//     tap loop has a wave-uniform trip count and no masks.  One lane = one output element: dB + affine + a store that is
-//     64 contiguous bytes per row - no output tile in LDS, no copy-out phase.
-constexpr int G8_WAVES = 8, G8_MS = 17;        // frame pairs per group; row stride of mags[bin][frame] (floats)
+//   * the mel projection runs on the whole group with lanes ALONG FRAMES: a wave instruction handles 8 rows x 16 frames
+//     (two frames per lane), a tap is one ds_read_b64 of mags[bin][frame pair] + a broadcast weight + two FMAs, with
+//     immediate offsets (the taps of a Slaney filter are contiguous bins: checked in the kernel's prologue, any other CSR
+//     takes a gather loop).  Weights are re-laid per 8-row group, zero-padded to the group's widest row, so the tap loop has
+//     a wave-uniform trip count and no masks; the groups are dealt to the waves by estimated cost (longest first to the
+//     least loaded wave: the top rows have 14 taps, the bottom ones 1).  dB + affine + stores of 64 contiguous bytes per
+//     row straight from the registers - no output tile in LDS, no copy-out phase.
+constexpr int G8_WAVES = 8, G8_MS = 18;        // frame pairs per group; row stride of mags[bin][frame] (floats, even: b64 reads)
 constexpr int G8_PADROWS = 16;                 // zero rows behind the last bin (padded taps read them)
+__host__ __device__ constexpr int g8_groups(int n_rows) { return (n_rows + 7) >> 3; }
+__host__ __device__ constexpr int g8_lmax(int n_rows) { return (g8_groups(n_rows) + G8_WAVES - 1) / G8_WAVES; }   // groups of a wave
 
 __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
     const float* __restrict__ wav, int64_t n_samples, int n_frames, const float* __restrict__ window, float inv_norm,
     const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     float floor_lin, float aff_a, float aff_b, float* __restrict__ out, int pval_cap, int mode) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int EXF = 2 * G8_WAVES * XBUF;                              // floats of the exchange region
   c32* xall = reinterpret_cast<c32*>(lds);                              // [8][XBUF]
-  float* mags = lds + 2 * G8_WAVES * XBUF - NBIN * G8_MS;               // [NBIN][17], the tail of the exchange region ...
-  float* zpad = lds + 2 * G8_WAVES * XBUF;                              // ... running into 16 rows that stay zero
-  c32* twb_t = reinterpret_cast<c32*>(zpad + G8_PADROWS * G8_MS);       // [16][4]  (17408 + 272 floats: 8-byte aligned)
-  int* row_lo = reinterpret_cast<int*>(twb_t + 64);                     // [n_rows]
-  const int NG = (n_rows + 3) >> 2;
-  int* grp_w = row_lo + n_rows;                                         // [NG]
-  int* grp_off = grp_w + NG;                                            // [NG]
-  int* plan_bad = grp_off + NG;                                         // [1]
-  float* pval = reinterpret_cast<float*>(plan_bad + 1);                 // [pval_cap]
+  float* mags = lds + EXF - NBIN * G8_MS;                               // [NBIN][18], the tail of the exchange region ...
+  float* zpad = lds + EXF;                                              // ... running into 16 rows that stay zero
+  c32* twb_t = reinterpret_cast<c32*>(zpad + G8_PADROWS * G8_MS);       // [16][4]
+  float* pval = reinterpret_cast<float*>(twb_t + 64);                   // [pval_cap] (even: 8-byte aligned weight pairs)
+  int* row_lo = reinterpret_cast<int*>(pval + pval_cap);                // [n_rows]
+  const int NG = g8_groups(n_rows), LMAX = g8_lmax(n_rows);
+  int* grp_w = row_lo + n_rows;                                         // [NG]   groups count from the TOP: group G = rows
+  int* grp_off = grp_w + NG;                                            // [NG]   n_rows - 8 (G + 1) .. + 7 (negative rows: none)
+  int* lists = grp_off + NG;                                            // [8][LMAX][4] groups of a wave: (width, weight offset,
+  int* plan_bad = lists + 4 * G8_WAVES * LMAX;                          // [1]           first row, -)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   c32* xb = xall + wave * XBUF;
 
-  // ---- prologue: W_1024 (in the exchange region), the mel plan
+  // ---- prologue: W_1024 and a copy of the CSR in the exchange region, then the mel plan from LDS
+  int* rp_s = reinterpret_cast<int*>(lds + 2 * NFFT);                   // [n_rows + 1]
+  const int nnz = row_ptr[n_rows];
+  int* col_s = rp_s + n_rows + 1;                                       // [nnz]
+  float* val_s = reinterpret_cast<float*>(col_s + nnz);                 // [nnz]
+  const bool staged = nnz >= 0 && 2 * NFFT + (n_rows + 1) + 2 * (int64_t)nnz <= EXF;
   for (int i = tid; i < NFFT; i += 512) {
     float sn, cs;
     sincospif(-2.0f * (float)i / (float)NFFT, &sn, &cs);
     xall[i] = mk(cs, sn);
   }
   for (int i = tid; i < G8_PADROWS * G8_MS; i += 512) zpad[i] = 0.f;
-  if (tid == 0) *plan_bad = 0;
-  __syncthreads();
-  // rows: first bin and tap count; taps must be consecutive bins
-  for (int r = tid; r < n_rows; r += 512) {
-    const int e0 = row_ptr[r], e1 = row_ptr[r + 1], cnt = e1 - e0, lo = cnt > 0 ? col[e0] : 0;
-    bool ok = cnt >= 0 && cnt <= G8_PADROWS && lo >= 0 && lo + cnt <= NBIN;
-    for (int e = e0; ok && e < e1; ++e) ok = col[e] == lo + (e - e0);
-    if (!ok) atomicOr(plan_bad, 1);
-    row_lo[r] = lo;
+  if (staged) {
+    for (int i = tid; i <= n_rows; i += 512) rp_s[i] = row_ptr[i];
+    for (int i = tid; i < nnz; i += 512) col_s[i] = col[i], val_s[i] = val[i];
   }
+  if (tid == 0) *plan_bad = staged ? 0 : 1;
   __syncthreads();
-  for (int g = tid; g < NG; g += 512) {
-    int w = 2;
-    for (int j = 0; j < 4; ++j) {
-      const int r = min(4 * g + j, n_rows - 1);
-      w = max(w, row_ptr[r + 1] - row_ptr[r]);
+  if (staged) {
+    // rows: first bin; taps must be consecutive bins, at most 16
+    for (int r = tid; r < n_rows; r += 512) {
+      const int e0 = rp_s[r], e1 = rp_s[r + 1], cnt = e1 - e0, lo = cnt > 0 ? col_s[e0] : 0;
+      bool ok = e0 >= 0 && cnt >= 0 && e1 <= nnz && cnt <= G8_PADROWS && lo >= 0 && lo + cnt <= NBIN;
+      for (int e = e0; ok && e < e1; ++e) ok = col_s[e] == lo + (e - e0);
+      if (!ok) atomicOr(plan_bad, 1);
+      row_lo[r] = lo;
     }
-    grp_w[g] = (w + 1) & ~1;   // even: the tap loop runs two taps per trip
+    for (int g = tid; g < NG; g += 512) {
+      int w = 2;
+      for (int j = 0; j < 8; ++j) {
+        const int r = n_rows - 8 * (g + 1) + j;
+        if (r >= 0) w = max(w, rp_s[r + 1] - rp_s[r]);
+      }
+      grp_w[g] = min((w + 1) & ~1, G8_PADROWS);   // even: two taps per trip
+    }
   }
   __syncthreads();
-  for (int g = tid; g < NG; g += 512) {
-    int o = 0;
-    for (int i = 0; i < g; ++i) o += 4 * grp_w[i];
-    grp_off[g] = o;
-    if (g == NG - 1 && o + 4 * grp_w[g] > pval_cap) atomicOr(plan_bad, 1);
-  }
+  if (*plan_bad == 0)
+    for (int g = tid; g < NG; g += 512) {
+      // weight offsets; the groups dealt to the waves in snake order (0 .. 7, 7 .. 0, ...): they come in order of falling cost
+      // (the top rows have 14 taps, the bottom ones 1), so every wave gets one of each octave
+      int o = 0;
+      for (int i = 0; i < g; ++i) o += 8 * grp_w[i];
+      grp_off[g] = o;
+      if (g == NG - 1 && o + 8 * grp_w[g] > pval_cap) atomicOr(plan_bad, 1);
+      const int slot = g >> 3, w = (slot & 1) ? 7 - (g & 7) : (g & 7);
+      int* e = lists + 4 * (w * LMAX + slot);
+      e[0] = grp_w[g], e[1] = o, e[2] = n_rows - 8 * (g + 1), e[3] = 0;
+    }
   __syncthreads();
   const bool plan_ok = *plan_bad == 0;
   if (plan_ok)
-    for (int r = tid; r < 4 * NG; r += 512) {
-      const int g = r >> 2, w = grp_w[g], rr = min(r, n_rows - 1), e0 = row_ptr[rr], cnt = r < n_rows ? row_ptr[rr + 1] - e0 : 0;
-      float* d = pval + grp_off[g] + (r & 3) * w;
-      for (int e = 0; e < w; ++e) d[e] = e < cnt ? val[e0 + e] : 0.f;
+    for (int i = tid; i < 8 * NG; i += 512) {
+      const int g = i >> 3, w = grp_w[g], r = n_rows - 8 * (g + 1) + (i & 7);
+      const int e0 = r >= 0 ? rp_s[r] : 0, cnt = r >= 0 ? rp_s[r + 1] - e0 : 0;
+      float* d = pval + grp_off[g] + (i & 7) * w;
+      for (int e = 0; e < w; ++e) d[e] = e < cnt ? val_s[e0 + e] : 0.f;
     }
-  c32 twA[16];
+  // pass-A twiddles W^(lane k): k = 1 .. 8 in registers, W^(lane (16 - k)) = W^(16 lane) conj(W^(lane k)) formed when used
+  // (15 register pairs were 30 of the 128 registers; the extra 7 complex products are 1.4 % of the instructions)
+  c32 twA[9];
 #pragma unroll
-  for (int k = 1; k < 16; ++k) twA[k] = xall[(lane * k) & (NFFT - 1)];
+  for (int k = 1; k < 9; ++k) twA[k] = xall[(lane * k) & (NFFT - 1)];
+  const c32 tw16 = xall[(16 * lane) & (NFFT - 1)];
   if (tid < 64) twb_t[tid] = xall[(16 * (tid & 3) * (tid >> 2)) & (NFFT - 1)];   // [j1 = tid >> 2][m2 = tid & 3]
   __syncthreads();
 
   // ---- the pair of this wave in group f0: 20 rows of 64 samples from sample (f0 + 2 wave) * 256 - 512
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc((void*)(wav + (int64_t)b * n_samples), 0, (int)(n_samples * 4), 0x00020000);
-  // (the window rides with the samples - 16 more loads that hit the L1: held in registers for the whole kernel it was
-  // what the compiler spilled)
+  // (the window is re-read for every group - 16 loads that hit the L1, issued behind the mel phase: held in registers for
+  // the whole kernel, or across the mel phase, it was what the compiler spilled)
   const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc((void*)window, 0, NFFT * 4, 0x00020000);
   float sreg[20], wreg[16];
   auto issue = [&](int f0) {
     const int base = ((f0 + 2 * wave) * 256 - NFFT / 2 + lane) * 4;   // (negative = before the signal = beyond the buffer: zero)
 #pragma unroll
     for (int j = 0; j < 20; ++j) sreg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, base + 256 * j, 0, 0));
+  };
+  auto issue_window = [&]() {
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win_rs, (lane + 64 * n1) * 4, 0, 0));
   };
   const int f00 = blockIdx.x * FT;
-  if (f00 < n_frames) issue(f00);
+  if (f00 < n_frames) issue(f00), issue_window();
+  const float hscale = 0.5f * inv_norm;
+  // (groups of this wave: full snake rows, + 1 where the last, partial one reaches it)
+  const int last_n = NG & 7, last_slot = NG >> 3;
+  const int my_groups = !plan_ok ? 0 : last_slot + (((last_slot & 1) ? 7 - wave : wave) < last_n ? 1 : 0);
 
   for (int f0 = f00; f0 < n_frames; f0 += gridDim.x * FT) {
     const int nf = min(FT, n_frames - f0), fp = 2 * wave;
@@ -456,7 +495,8 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
     }
     dft16(x);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xb[k1 * XROW + lane] = k1 ? cmul(x[P16(k1)], twA[k1]) : x[P16(0)];
+    for (int k1 = 0; k1 < 16; ++k1)
+      xb[k1 * XROW + lane] = k1 == 0 ? x[P16(0)] : cmul(x[P16(k1)], k1 <= 8 ? twA[k1 <= 8 ? k1 : 0] : cmul_conj(tw16, twA[k1 <= 8 ? 0 : 16 - k1]));
     wave_sync();
     // ---- pass B
     {
@@ -483,7 +523,9 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) bfly4(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3]);
     // ---- conjugate partners: Z[1024 - (lane + 64 q)] = Z[(64 - lane) + 64 (15 - q)] sits in lane 64 - lane, slot 15 - q
-    // (lane 0: in lane 0 itself, slot 16 - q; slots 0 and 8 of lane 0 are their own partners), then the two magnitudes
+    // (lane 0: in lane 0 itself, slot 16 - q; slots 0 and 8 of lane 0 are their own partners), then the two magnitudes:
+    // with s = Z[k] + Z[N-k], d = Z[k] - Z[N-k]:  |Xa| = sqrt(s.x^2 + d.y^2) / 2,  |Xb| = sqrt(s.y^2 + d.x^2) / 2  (the squares
+    // added in the first kernel's order: fma(s, s, round(d^2)); the factor 1/2 is exact wherever it is applied)
     auto XQ = [&](int q) -> c32& { return x[4 * (q & 3) + (q >> 2)]; };
     c32 mg[9];
     const int src_lane4 = ((64 - lane) & 63) * 4;
@@ -493,47 +535,69 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
       c32 zn = mk(lane_fetch(src_lane4, up.x), lane_fetch(src_lane4, up.y));
       const c32 own = q ? XQ(16 - q) : XQ(0);
       if (lane == 0) zn = own;
-      const c32 zk = XQ(q);
-      const float x1r = 0.5f * (zk.x + zn.x), x1i = 0.5f * (zk.y - zn.y);
-      const float x2r = 0.5f * (zk.y + zn.y), x2i = -0.5f * (zk.x - zn.x);
-      mg[q] = mk(__builtin_amdgcn_sqrtf(x1r * x1r + x1i * x1i) * inv_norm, __builtin_amdgcn_sqrtf(x2r * x2r + x2i * x2i) * inv_norm);
+      const c32 zk = XQ(q), s = zk + zn, d = zk - zn;
+      c32 p, v;
+      asm("v_pk_mul_f32 %0, %1, %1 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(p) : "v"(d));                 // (d.y^2, d.x^2)
+      asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(v) : "v"(s), "v"(p));                                  // (s.x^2 + d.y^2, s.y^2 + d.x^2)
+      mg[q] = mk(__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)) * mk(hscale, hscale);
     }
     {
-      const c32 zk = XQ(8);   // bin 512 (lane 0 only)
+      const c32 zk = XQ(8);   // bin 512 (lane 0 only): its own partner
       mg[8] = mk(__builtin_amdgcn_sqrtf(zk.x * zk.x) * inv_norm, __builtin_amdgcn_sqrtf(zk.y * zk.y) * inv_norm);
     }
     __syncthreads();   // every wave is done with its exchange buffer: the magnitude array may overwrite them
     {
-      float* d = mags + lane * G8_MS + fp;
+      c32* d = reinterpret_cast<c32*>(mags + lane * G8_MS + fp);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) d[64 * q * G8_MS] = mg[q].x, d[64 * q * G8_MS + 1] = mg[q].y;
-      if (lane == 0) d[512 * G8_MS] = mg[8].x, d[512 * G8_MS + 1] = mg[8].y;
+      for (int q = 0; q < 8; ++q) d[32 * q * G8_MS] = mg[q];
+      if (lane == 0) d[256 * G8_MS] = mg[8];
     }
-    // the next group's samples and window: in flight across the mel phase (issued any earlier they are 36 more live
-    // registers next to the transform's or the magnitudes': 128 are all a wave has at four waves per SIMD)
-    if (f0 + gridDim.x * FT < n_frames) issue(f0 + gridDim.x * FT);
+    // the next group's samples: in flight across the mel phase (issued any earlier they are 20 more live registers next
+    // to the transform's or the magnitudes': 128 are all a wave has at four waves per SIMD)
+    if (f0 + gridDim.x * FT < n_frames) issue(f0 + gridDim.x * FT), issue_window();
     __syncthreads();
-    // ---- mel projection of the group: lane = (row of the 4-row group, frame)
+    // ---- mel projection of the group: lane = (row of the 8-row group, frame pair)
     {
-      const int f = lane & 15, j = lane >> 4;
-      float* o = out + (int64_t)b * n_rows * n_frames + f0 + f;
-      for (int g = wave; g < NG; g += G8_WAVES) {
-        const int r = 4 * g + j, rr = min(r, n_rows - 1);
-        float m = 0.f;
-        if (plan_ok) {
-          const int w = __builtin_amdgcn_readfirstlane(grp_w[g]);
-          const float* mp = mags + row_lo[rr] * G8_MS + f;
-          const float* wp = pval + __builtin_amdgcn_readfirstlane(grp_off[g]) + j * w;
-          for (int e = 0; e < w; e += 2) {
-            m = fmaf(wp[e], mp[e * G8_MS], m);
-            m = fmaf(wp[e + 1], mp[(e + 1) * G8_MS], m);
+      const int fl = 2 * (lane & 7), j = lane >> 3;
+      float* o = out + (int64_t)b * n_rows * n_frames + f0 + fl;
+      auto put = [&](int r, float m0, float m1) {
+        if (r >= 0 && r < n_rows) {
+          float* orow = o + (int64_t)r * n_frames;
+          if (mode != PGV_STFT_LINEAR) {
+            m0 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
+            m1 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
           }
-        } else {
-          for (int e = row_ptr[rr]; e < row_ptr[rr + 1]; ++e) m = fmaf(val[e], mags[col[e] * G8_MS + f], m);
+          if (fl < nf) orow[0] = m0;
+          if (fl + 1 < nf) orow[1] = m1;
         }
-        if (r < n_rows && f < nf)
-          o[(int64_t)r * n_frames] =
-              mode == PGV_STFT_LINEAR ? m : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m, floor_lin)), aff_b);
+      };
+      if (plan_ok) {
+        const int* desc = lists + 4 * wave * LMAX;
+        for (int i = 0; i < my_groups; ++i) {
+          const int w = __builtin_amdgcn_readfirstlane(desc[4 * i]), off = __builtin_amdgcn_readfirstlane(desc[4 * i + 1]);
+          const int r = __builtin_amdgcn_readfirstlane(desc[4 * i + 2]) + j;
+          const c32* mp = reinterpret_cast<const c32*>(mags + row_lo[max(r, 0)] * G8_MS + fl);
+          const c32* wp = reinterpret_cast<const c32*>(pval + off + j * w);
+          c32 m = mk(0.f, 0.f);
+#pragma unroll 2
+          for (int e = 0; e < w; e += 2) {
+            const c32 ww = wp[e >> 1];
+            m = mk(ww.x, ww.x) * mp[e * (G8_MS / 2)] + m;
+            m = mk(ww.y, ww.y) * mp[(e + 1) * (G8_MS / 2)] + m;
+          }
+          put(r, m.x, m.y);
+        }
+      } else {
+        for (int r = 8 * wave + j; r < n_rows; r += 8 * G8_WAVES) {   // any other CSR: gather
+          float m0 = 0.f, m1 = 0.f;
+          for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
+            const float v = val[e];
+            const int c = min(max(col[e], 0), NBIN - 1);
+            m0 = fmaf(v, mags[c * G8_MS + fl], m0);
+            m1 = fmaf(v, mags[c * G8_MS + fl + 1], m1);
+          }
+          put(r, m0, m1);
+        }
       }
     }
     __syncthreads();   // the next group's transposes overwrite the magnitudes
@@ -569,11 +633,12 @@ extern "C" int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, i
   // the second-generation kernel: hop 256 with a mel projection (the trained configuration); kernel policies 1 - 3 keep the
   // first kernel (the in-library cross-check of the tests), which also serves every other hop / output mode
   if (pgv_kernel_policy() == 0 && n_mels > 0 && hop == 256 && out_mode != PGV_STFT_COMPLEX && n_samples < ((int64_t)1 << 29)) {
-    const int ng = (n_rows + 3) / 4;
-    const size_t fixed = 2 * (size_t)G8_WAVES * XBUF + G8_PADROWS * G8_MS + 128 + (size_t)n_rows + 2 * (size_t)ng + 1;
+    const int ng = g8_groups(n_rows);
+    const size_t fixed = 2 * (size_t)G8_WAVES * XBUF + G8_PADROWS * G8_MS + 128 + (size_t)n_rows + 2 * (size_t)ng +
+                         4 * (size_t)G8_WAVES * g8_lmax(n_rows) + 1;
     const size_t budget = 80 * 1024 / sizeof(float);
-    if (fixed + 8 * (size_t)ng <= budget) {   // (room for at least two taps per row; a plan that does not fit gathers instead)
-      const int pval_cap = (int)min((size_t)4 * G8_PADROWS * ng, budget - fixed);
+    if (fixed + 16 * (size_t)ng <= budget) {   // (room for at least two taps per row; a plan that does not fit gathers instead)
+      const int pval_cap = (int)min((size_t)8 * G8_PADROWS * ng, budget - fixed) & ~1;
       static bool attr2_set = false;
       if (!attr2_set) {
         (void)hipFuncSetAttribute((const void*)stft_mel_g8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
