@@ -70,6 +70,9 @@ __device__ __forceinline__ float lane_fetch(int lane4, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(lane4, __float_as_int(v)));
 }
 
+// torch.maximum(x, floor) of Spectrogram.linear_to_log_scale (utils/audio.py:53): a NaN stays a NaN (fmaxf drops it)
+__device__ __forceinline__ float floor_nan(float x, float floor) { return x < floor ? floor : x; }
+
 // forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
 __device__ __forceinline__ void bfly4(c32& a, c32& b, c32& c, c32& d) {
   const c32 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
           tile[r * (FT + 1) + fp] =
             mode == PGV_STFT_LINEAR
                 ? m0
-                : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
+                : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m0, floor_lin)), aff_b);
         if (has2)
           tile[r * (FT + 1) + fp + 1] =
               mode == PGV_STFT_LINEAR
                   ? m1
-                  : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
+                  : fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m1, floor_lin)), aff_b);
       }
     }
     wave_sync();
@@ -564,8 +567,8 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
         if (r >= 0 && r < n_rows) {
           float* orow = o + (int64_t)r * n_frames;
           if (mode != PGV_STFT_LINEAR) {
-            m0 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m0, floor_lin)), aff_b);
-            m1 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(fmaxf(m1, floor_lin)), aff_b);
+            m0 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m0, floor_lin)), aff_b);
+            m1 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m1, floor_lin)), aff_b);
           }
           if (fl < nf) orow[0] = m0;
           if (fl + 1 < nf) orow[1] = m1;

@@ -70,6 +70,90 @@ def test_linear_spectrogram_matches_reference_golden():
     _compare_db(short, ao.spectrogram_db(ao.synth_fm_wave(n=700, idx=5)))
 
 
+def _stft_np(wav, window):
+    """float64 |STFT| / 1 of one waveform: centre zero padding, hop 256, n_fft 1024 -> [513, T]."""
+    n = len(wav)
+    pad = np.concatenate([np.zeros(512), wav.astype(np.float64), np.zeros(512)])
+    T = 1 + n // 256
+    frames = np.stack([pad[256 * t:256 * t + 1024] for t in range(T)])
+    return np.abs(np.fft.rfft(frames * window.astype(np.float64)[None], axis=1)).T
+
+
+@pytest.mark.parametrize("case", ["slaney257", "slaney64", "slaney400", "wide16", "scattered", "empty_rows"])
+def test_group_kernel_filterbanks_and_gather_path(case):
+    """The second-generation front-end kernel (hop 256 + mel projection: 16-frame groups, mel phase with lanes along
+    frames) against a float64 STFT + dense projection, for filterbanks that take its planned path (contiguous taps, <= 16 per
+    row: 257 / 64 / 400 Slaney rows) and its gather path (rows wider than 16 taps, scattered columns, empty rows), in the
+    linear and the dB output mode, at ragged lengths - and against the first-generation kernel (kernel policy 1), which
+    the repository's earlier rounds pinned to the reference's spectrograms."""
+    _need_gpu()
+    from preset_gen_vae_amd import ops, _lib
+    from preset_gen_vae_amd.utils.audio import slaney_mel_basis, dense_to_csr, Spectrogram
+    rng = np.random.default_rng(5)
+    if case.startswith("slaney"):
+        w = slaney_mel_basis(22050, 1024, int(case[6:]))
+    elif case == "wide16":
+        w = slaney_mel_basis(22050, 1024, 16)              # up to ~70 taps per row
+        assert (w > 0).sum(axis=1).max() > 16
+    elif case == "scattered":
+        w = np.zeros((96, 513), np.float32)
+        for r in range(96):
+            cols = rng.choice(513, size=rng.integers(1, 12), replace=False)
+            w[r, cols] = rng.uniform(0.1, 1.0, len(cols)).astype(np.float32)
+    else:
+        w = slaney_mel_basis(22050, 1024, 120)
+        w[[0, 7, 8, 63, 119]] = 0.0                        # rows without taps
+    rows = w.shape[0]
+    rp, col, val = (torch.tensor(a).cuda() for a in dense_to_csr(w))
+    window = Spectrogram(1024, 256, -120.0).window
+    win_d = window.cuda()
+    lib = _lib.load()
+    for n in (88576, 256 * 16 + 5, 256 * 47, 700):          # 347 frames; 17 (one full group + 1); 48 = 3 groups; 3
+        waves = np.stack([ao.synth_fm_wave(n=n, idx=i) for i in range(3)])
+        waves[1] += 0.05 * rng.standard_normal(n).astype(np.float32)
+        x = torch.tensor(waves).cuda()
+        T = 1 + n // 256
+        ref = np.stack([w.astype(np.float64) @ _stft_np(waves[i], window.numpy()) for i in range(3)]) / 300.0
+        for mode in (ops.STFT_LINEAR, ops.STFT_DB):
+            got = {}
+            for policy in (0, 1):
+                lib.pgv_set_kernel_policy(policy)
+                try:
+                    got[policy] = ops.stft_mel(x, 256, T, win_d, 300.0, (rp, col, val), rows, 1e-6, 1.0, 0.0, mode=mode).cpu().numpy()
+                finally:
+                    lib.pgv_set_kernel_policy(0)
+            assert got[0].shape == (3, rows, T)
+            if mode == ops.STFT_LINEAR:
+                scale = np.maximum(ref.max(axis=1, keepdims=True), 1e-6)
+                assert (np.abs(got[0] - ref) / scale).max() < 3e-6, (case, n)
+                assert (np.abs(got[0] - got[1]) / scale).max() < 1e-6, (case, n)
+            else:
+                _compare_db(got[0], 20 * np.log10(np.maximum(ref, 1e-6)))
+                lin0, lin1 = 10 ** (got[0].astype(np.float64) / 20), 10 ** (got[1].astype(np.float64) / 20)
+                # (through a float32 dB value: one ulp at 0 dB is 2e-7 dB, at -100 dB 8e-6 dB = 1e-6 relative)
+                assert (np.abs(lin0 - lin1) / np.maximum(lin1.max(axis=1, keepdims=True), 1e-6)).max() < 3e-6, (case, n)
+
+
+def test_group_kernel_non_finite_samples_stay_in_their_frames():
+    """A NaN sample reaches the output (torch.maximum of utils/audio.py:53 keeps a NaN; fmaxf would have put the floor there) and
+    poisons the frames that contain it - widened to whole frame PAIRS, since two real frames are transformed as one complex
+    signal (the reference: frames 39 .. 42 only) - and nothing else: the magnitude array of a 16-frame group is shared by its
+    frames, and padded taps multiply whatever lies behind a row's last bin by zero."""
+    _need_gpu()
+    from preset_gen_vae_amd.utils.audio import MelSpectrogram
+    mel = MelSpectrogram(1024, 256, -120.0, 257, 22050)
+    wav = torch.tensor(np.stack([ao.synth_fm_wave(idx=i) for i in range(2)])).cuda()
+    clean = mel.batch(wav).clone()
+    bad = wav.clone()
+    bad[1, 256 * 40 + 3] = float('nan')
+    out = mel.batch(bad)
+    hit = torch.isnan(out[1, 0]).any(dim=0).nonzero().flatten().tolist()
+    assert hit == [38, 39, 40, 41, 42, 43], hit
+    assert torch.isnan(out[1, 0][:, 38:44]).all()
+    keep = [t for t in range(347) if t not in hit]
+    assert torch.equal(out[1, 0][:, keep], clean[1, 0][:, keep]) and torch.equal(out[0], clean[0])
+
+
 def test_minmax_fused_and_odd_lengths():
     _need_gpu()
     from preset_gen_vae_amd.utils.audio import MelSpectrogram
