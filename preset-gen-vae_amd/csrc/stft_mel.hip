@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(
 constexpr int G8_WAVES = 8, G8_MS = 18;        // frame pairs per group; row stride of mags[bin][frame] (floats, even: b64 reads)
 constexpr int G8_PADROWS = 16;                 // zero rows behind the last bin (padded taps read them)
 __host__ __device__ constexpr int g8_groups(int n_rows) { return (n_rows + 7) >> 3; }
-__host__ __device__ constexpr int g8_lmax(int n_rows) { return (g8_groups(n_rows) + G8_WAVES - 1) / G8_WAVES; }   // groups of a wave
+constexpr int G8_LMAX = 8;                     // groups a wave can be dealt (8 x 8 x 8 = 512 rows take the planned path)
 
 __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
     const float* __restrict__ wav, int64_t n_samples, int n_frames, const float* __restrict__ window, float inv_norm,
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
   c32* twb_t = reinterpret_cast<c32*>(zpad + G8_PADROWS * G8_MS);       // [16][4]
   float* pval = reinterpret_cast<float*>(twb_t + 64);                   // [pval_cap] (even: 8-byte aligned weight pairs)
   int* row_lo = reinterpret_cast<int*>(pval + pval_cap);                // [n_rows]
-  const int NG = g8_groups(n_rows), LMAX = g8_lmax(n_rows);
+  const int NG = g8_groups(n_rows);
+  constexpr int LMAX = G8_LMAX;
   int* grp_w = row_lo + n_rows;                                         // [NG]   groups count from the TOP: group G = rows
   int* grp_off = grp_w + NG;                                            // [NG]   n_rows - 8 (G + 1) .. + 7 (negative rows: none)
   int* lists = grp_off + NG;                                            // [8][LMAX][4] groups of a wave: (width, weight offset,
@@ -395,23 +396,43 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
   const int b = blockIdx.y;
   c32* xb = xall + wave * XBUF;
 
+  // ---- the pair of this wave in group f0: 20 rows of 64 samples from sample (f0 + 2 wave) * 256 - 512 (the first group's are
+  // requested before the prologue: its global round trips and theirs overlap)
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(wav + (int64_t)b * n_samples), 0, (int)(n_samples * 4), 0x00020000);
+  // (the window is re-read for every group - 16 loads that hit the L1, issued behind the mel phase: held in registers for
+  // the whole kernel, or across the mel phase, it was what the compiler spilled)
+  const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc((void*)window, 0, NFFT * 4, 0x00020000);
+  float sreg[20], wreg[16];
+  auto issue = [&](int f0) {
+    const int base = ((f0 + 2 * wave) * 256 - NFFT / 2 + lane) * 4;   // (negative = before the signal = beyond the buffer: zero)
+#pragma unroll
+    for (int j = 0; j < 20; ++j) sreg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, base + 256 * j, 0, 0));
+  };
+  auto issue_window = [&]() {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win_rs, (lane + 64 * n1) * 4, 0, 0));
+  };
+  const int f00 = blockIdx.x * FT;
+  if (f00 < n_frames) issue(f00), issue_window();
   // ---- prologue: W_1024 and a copy of the CSR in the exchange region, then the mel plan from LDS
   int* rp_s = reinterpret_cast<int*>(lds + 2 * NFFT);                   // [n_rows + 1]
   const int nnz = row_ptr[n_rows];
   int* col_s = rp_s + n_rows + 1;                                       // [nnz]
   float* val_s = reinterpret_cast<float*>(col_s + nnz);                 // [nnz]
   const bool staged = nnz >= 0 && 2 * NFFT + (n_rows + 1) + 2 * (int64_t)nnz <= EXF;
+  if (staged) {
+    for (int i = tid; i <= n_rows; i += 512) rp_s[i] = row_ptr[i];
+    for (int i = tid; i < nnz; i += 512) col_s[i] = col[i], val_s[i] = val[i];
+  }
   for (int i = tid; i < NFFT; i += 512) {
     float sn, cs;
     sincospif(-2.0f * (float)i / (float)NFFT, &sn, &cs);
     xall[i] = mk(cs, sn);
   }
   for (int i = tid; i < G8_PADROWS * G8_MS; i += 512) zpad[i] = 0.f;
-  if (staged) {
-    for (int i = tid; i <= n_rows; i += 512) rp_s[i] = row_ptr[i];
-    for (int i = tid; i < nnz; i += 512) col_s[i] = col[i], val_s[i] = val[i];
-  }
-  if (tid == 0) *plan_bad = staged ? 0 : 1;
+  for (int i = tid; i < 4 * G8_WAVES * G8_LMAX; i += 512) lists[i] = (i & 3) == 2 ? -(1 << 20) : 0;   // (no taps, no row)
+  if (tid == 0) *plan_bad = staged && NG <= G8_WAVES * G8_LMAX ? 0 : 1;
   __syncthreads();
   if (staged) {
     // rows: first bin; taps must be consecutive bins, at most 16
@@ -462,24 +483,6 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
   if (tid < 64) twb_t[tid] = xall[(16 * (tid & 3) * (tid >> 2)) & (NFFT - 1)];   // [j1 = tid >> 2][m2 = tid & 3]
   __syncthreads();
 
-  // ---- the pair of this wave in group f0: 20 rows of 64 samples from sample (f0 + 2 wave) * 256 - 512
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(wav + (int64_t)b * n_samples), 0, (int)(n_samples * 4), 0x00020000);
-  // (the window is re-read for every group - 16 loads that hit the L1, issued behind the mel phase: held in registers for
-  // the whole kernel, or across the mel phase, it was what the compiler spilled)
-  const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc((void*)window, 0, NFFT * 4, 0x00020000);
-  float sreg[20], wreg[16];
-  auto issue = [&](int f0) {
-    const int base = ((f0 + 2 * wave) * 256 - NFFT / 2 + lane) * 4;   // (negative = before the signal = beyond the buffer: zero)
-#pragma unroll
-    for (int j = 0; j < 20; ++j) sreg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, base + 256 * j, 0, 0));
-  };
-  auto issue_window = [&]() {
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win_rs, (lane + 64 * n1) * 4, 0, 0));
-  };
-  const int f00 = blockIdx.x * FT;
-  if (f00 < n_frames) issue(f00), issue_window();
   const float hscale = 0.5f * inv_norm;
   // (groups of this wave: full snake rows, + 1 where the last, partial one reaches it)
   const int last_n = NG & 7, last_slot = NG >> 3;
@@ -570,26 +573,40 @@ __global__ __launch_bounds__(512, 4) void stft_mel_g8_kernel(
             m0 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m0, floor_lin)), aff_b);
             m1 = fmaf(aff_a, 6.02059991327962390f * __builtin_amdgcn_logf(floor_nan(m1, floor_lin)), aff_b);
           }
-          if (fl < nf) orow[0] = m0;
-          if (fl + 1 < nf) orow[1] = m1;
+          typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+          if (fl + 1 < nf)
+            *reinterpret_cast<f2u*>(orow) = f2u{m0, m1};   // (one 8-byte store: 8 lanes = the row's 64 contiguous bytes)
+          else if (fl < nf)
+            orow[0] = m0;
         }
       };
       if (plan_ok) {
-        const int* desc = lists + 4 * wave * LMAX;
-        for (int i = 0; i < my_groups; ++i) {
-          const int w = __builtin_amdgcn_readfirstlane(desc[4 * i]), off = __builtin_amdgcn_readfirstlane(desc[4 * i + 1]);
-          const int r = __builtin_amdgcn_readfirstlane(desc[4 * i + 2]) + j;
-          const c32* mp = reinterpret_cast<const c32*>(mags + row_lo[max(r, 0)] * G8_MS + fl);
-          const c32* wp = reinterpret_cast<const c32*>(pval + off + j * w);
-          c32 m = mk(0.f, 0.f);
-#pragma unroll 2
-          for (int e = 0; e < w; e += 2) {
-            const c32 ww = wp[e >> 1];
-            m = mk(ww.x, ww.x) * mp[e * (G8_MS / 2)] + m;
-            m = mk(ww.y, ww.y) * mp[(e + 1) * (G8_MS / 2)] + m;
-          }
-          put(r, m.x, m.y);
+        // the descriptors and first bins of all groups of this wave up front (read inside the loop they were two dependent
+        // LDS round trips at the head of every group)
+        const int* desc = lists + 4 * wave * G8_LMAX;
+        int dw[G8_LMAX], doff[G8_LMAX], dr[G8_LMAX], dlo[G8_LMAX];
+#pragma unroll
+        for (int i = 0; i < G8_LMAX; ++i) {
+          dw[i] = __builtin_amdgcn_readfirstlane(desc[4 * i]), doff[i] = __builtin_amdgcn_readfirstlane(desc[4 * i + 1]);
+          dr[i] = __builtin_amdgcn_readfirstlane(desc[4 * i + 2]) + j;
         }
+#pragma unroll
+        for (int i = 0; i < G8_LMAX; ++i) dlo[i] = row_lo[min(max(dr[i], 0), n_rows - 1)] * G8_MS;
+#pragma unroll
+        for (int i = 0; i < G8_LMAX; ++i)
+          if (i < my_groups) {
+            const int w = dw[i];
+            const c32* mp = reinterpret_cast<const c32*>(mags + dlo[i] + fl);
+            const c32* wp = reinterpret_cast<const c32*>(pval + doff[i] + j * w);
+            c32 m = mk(0.f, 0.f);
+#pragma unroll 2
+            for (int e = 0; e < w; e += 2) {
+              const c32 ww = wp[e >> 1];
+              m = mk(ww.x, ww.x) * mp[e * (G8_MS / 2)] + m;
+              m = mk(ww.y, ww.y) * mp[(e + 1) * (G8_MS / 2)] + m;
+            }
+            put(dr[i], m.x, m.y);
+          }
       } else {
         for (int r = 8 * wave + j; r < n_rows; r += 8 * G8_WAVES) {   // any other CSR: gather
           float m0 = 0.f, m1 = 0.f;
@@ -638,7 +655,7 @@ extern "C" int pgv_stft(const float* wav, int B, int64_t n_samples, int n_fft, i
   if (pgv_kernel_policy() == 0 && n_mels > 0 && hop == 256 && out_mode != PGV_STFT_COMPLEX && n_samples < ((int64_t)1 << 29)) {
     const int ng = g8_groups(n_rows);
     const size_t fixed = 2 * (size_t)G8_WAVES * XBUF + G8_PADROWS * G8_MS + 128 + (size_t)n_rows + 2 * (size_t)ng +
-                         4 * (size_t)G8_WAVES * g8_lmax(n_rows) + 1;
+                         4 * (size_t)G8_WAVES * G8_LMAX + 1;
     const size_t budget = 80 * 1024 / sizeof(float);
     if (fixed + 16 * (size_t)ng <= budget) {   // (room for at least two taps per row; a plan that does not fit gathers instead)
       const int pval_cap = (int)min((size_t)8 * G8_PADROWS * ng, budget - fixed) & ~1;
