@@ -28,6 +28,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
 template <int N>
 struct VecOf;
 template <>
@@ -68,12 +76,17 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 //          addresser handles one lane at a time - 1.4 TB/s for the encoder forward's operands with nothing but the loads.
 //   L = 0: the same rows loaded fragment-shaped (lane (i, piece) fetches its own 16 bytes; kept for A/B timing).
 //   L = 2 / 4: index-contiguous rows (element (i, k) at base[k * ld + i]) read L floats per lane.
-template <int L, int T>
+// KD = K indices of a chunk: 16 (fp32: four k-steps of v_mfma_f32_16x16x4_f32) or 32 (PGV_COMPUTE_BF16: ONE
+// v_mfma_f32_16x16x32_bf16 - the chunk is two 16-deep halves loaded exactly like two fp32 chunks, a lane's eight K indices are
+// 4 kq + e and 16 + 4 kq + e, rounded to bfloat16 and packed when the matrix instruction reads them).
+template <int L, int T, int KD = 16>
 struct Side {
   static constexpr bool KC = L == 0 || L == 1;
   static constexpr int IW = KC ? 4 : L;
-  static constexpr int NL = KC ? T : (T / IW) * 4;   // loads per 16-deep chunk
+  static constexpr int NL0 = KC ? T : (T / IW) * 4;   // loads per 16-deep half
+  static constexpr int NL = NL0 * (KD / 16);          // loads per chunk
   static_assert(KC || T % IW == 0, "interleaved groups");
+  static_assert(KD == 16 || KD == 32, "chunk depth");
   typedef typename VecOf<IW>::type vec;
   unsigned off[NL];
   int perm;   // byte address of the source lane for ds_bpermute (L == 1)
@@ -81,18 +94,20 @@ struct Side {
     const int l16 = lane & 15, kq = lane >> 4;
     perm = 4 * (4 * l16 + kq);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
+    for (int jj = 0; jj < NL; ++jj) {
+      const int j = jj % NL0;
+      const long long half = jj / NL0 ? (KC ? 16 : 16 * ld) : 0;   // the second 16 K indices of a 32-deep chunk
       if (L == 0)
-        off[j] = (unsigned)((((long long)(16 * j + l16)) * ld + 4 * kq) * 4);
+        off[jj] = (unsigned)((((long long)(16 * j + l16)) * ld + 4 * kq + half) * 4);
       else if (L == 1)
-        off[j] = (unsigned)((((long long)(16 * j + (lane >> 2))) * ld + 4 * (lane & 3)) * 4);
+        off[jj] = (unsigned)((((long long)(16 * j + (lane >> 2))) * ld + 4 * (lane & 3) + half) * 4);
       else
-        off[j] = (unsigned)((((long long)(4 * kq + (j & 3))) * ld + 16 * IW * (j >> 2) + IW * l16) * 4);
+        off[jj] = (unsigned)((((long long)(4 * kq + (j & 3))) * ld + 16 * IW * (j >> 2) + IW * l16 + half) * 4);
     }
   }
   // bytes from the operand's origin to (first index i0 of the macro tile, chunk kc)
   static __device__ __forceinline__ long long origin(long long i0, long long kc, long long ld) {
-    return KC ? (i0 * ld + 16 * kc) * 4 : (16 * kc * ld + i0) * 4;
+    return KC ? (i0 * ld + KD * kc) * 4 : (KD * kc * ld + i0) * 4;
   }
   // the chunk's registers as the MFMAs read them (L == 1: lane exchange; otherwise as loaded)
   __device__ __forceinline__ void arrange(vec (&r)[NL]) const {
@@ -104,10 +119,17 @@ struct Side {
           r[j][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm, __float_as_int(r[j][e])));
     }
   }
-  // value of tile t for k-step e out of the chunk's registers
+  // value of tile t for k-step e (KD = 32: K slot e = 0 .. 7 of the lane) out of the chunk's registers
   static __device__ __forceinline__ float val(const vec (&r)[NL], int t, int e) {
-    if (KC) return r[t][e];
-    return r[(t / IW) * 4 + e][t % IW];
+    const int h = (e >> 2) * NL0;
+    e &= 3;
+    if (KC) return r[h + t][e];
+    return r[h + (t / IW) * 4 + e][t % IW];
+  }
+  // the lane's eight K slots of tile t as packed bfloat16 (round to nearest even)
+  static __device__ __forceinline__ u32x4 frag_bf16(const vec (&r)[NL], int t) {
+    return u32x4{pack_bf16x2(val(r, t, 0), val(r, t, 1)), pack_bf16x2(val(r, t, 2), val(r, t, 3)),
+                 pack_bf16x2(val(r, t, 4), val(r, t, 5)), pack_bf16x2(val(r, t, 6), val(r, t, 7))};
   }
   // index (inside the macro tile) of MFMA index i of tile t
   static __device__ __forceinline__ int index(int t, int i) {
@@ -128,10 +150,10 @@ struct FragArgs {
   int dbg;             // tuning builds: 1 = no MFMAs, 2 = no stores
 };
 
-template <int PL, int QL, int TPW, int TQW, bool ATOMIC, int kStages>
+template <int PL, int QL, int TPW, int TQW, bool ATOMIC, int kStages, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
-  typedef Side<PL, TPW> SP;
-  typedef Side<QL, TQW> SQ;
+  typedef Side<PL, TPW, BF16 ? 32 : 16> SP;
+  typedef Side<QL, TQW, BF16 ? 32 : 16> SQ;
   constexpr int NLP = SP::NL, NLQ = SQ::NL, NLT = NLP + NLQ;
   constexpr int PEXT = 16 * TPW, QEXT = 16 * TQW, TROW = PEXT + 4;
   static_assert((kStages - 1) * NLT <= 63, "vmcnt range");
@@ -183,6 +205,20 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
         if (cc < kc1 && !(a.dbg & 1)) {
           sp.arrange(pf[s]);
           sq.arrange(qf[s]);
+          if constexpr (BF16) {
+            // one K = 32 instruction per tile pair and chunk: operands rounded to bfloat16 here, fp32 accumulation
+            u32x4 bq[TQW];
+#pragma unroll
+            for (int tq = 0; tq < TQW; ++tq) bq[tq] = SQ::frag_bf16(qf[s], tq);
+#pragma unroll
+            for (int tp = 0; tp < TPW; ++tp) {
+              const u32x4 ap = SP::frag_bf16(pf[s], tp);
+#pragma unroll
+              for (int tq = 0; tq < TQW; ++tq)
+                acc[tp][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bq[tq]),
+                                                                       acc[tp][tq], 0, 0, 0);
+            }
+          } else {
           // round-robin over the accumulators: the f32 MFMA issues every 32 cycles but feeds a dependent one after 40
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -192,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
               for (int tp = 0; tp < TPW; ++tp)
                 acc[tp][tq] = __builtin_amdgcn_mfma_f32_16x16x4f32(SP::val(pf[s], tp, e), SQ::val(qf[s], tq, e),
                                                                     acc[tp][tq], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -241,10 +278,10 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
 int g_frag_variant = 0;   // tuning knob (pgv_dbg_set_gemm_variant): bits 0-1 stages (3 / 4 / 5), bits 2-3 grid cap (1024 / 768 /
                           // 512 / 256), bits 4-5 split-K job target (1024 / 2048 / 4096), bit 6 no MFMAs, bit 7 no stores,
                           // bit 9 fragment-shaped loads of K-contiguous operands, bit 10 everything to
-                          // gemm.hip, bit 11 short-K forward products here too
+                          // gemm.hip, bit 11 short-K forward products here too, bit 12 every covered bf16 shape here
 
 // SPLITK: the tiling also exists in its split-K (atomic epilogue) form
-template <int PL, int QL, int TPW, int TQW, bool SPLITK>
+template <int PL, int QL, int TPW, int TQW, bool SPLITK, bool BF16 = false>
 int launch_frag(FragArgs a, hipStream_t st) {
   const int wgs = (a.njobs + 3) / 4;
   const int caps[4] = {1024, 768, 512, 256};
@@ -254,8 +291,15 @@ int launch_frag(FragArgs a, hipStream_t st) {
   a.dbg = (g_frag_variant >> 6) & 3;
   const int stages = 3 + (g_frag_variant & 3) % 3;
 #define PGV_FRAG_GO(AT, ST)                                                                                       \
-  hipLaunchKernelGGL((gemm_frag_kernel<PL, QL, TPW, TQW, AT, ST>), dim3(grid), dim3(256), 0, st, a)
-  if (a.atomic) {
+  hipLaunchKernelGGL((gemm_frag_kernel<PL, QL, TPW, TQW, AT, ST, BF16>), dim3(grid), dim3(256), 0, st, a)
+  if constexpr (BF16) {   // (one pipeline depth: three 32-deep chunks in flight)
+    if (a.atomic) {
+      if constexpr (SPLITK) PGV_FRAG_GO(true, 3);
+      else return 0;
+    } else
+      PGV_FRAG_GO(false, 3);
+    (void)stages;
+  } else if (a.atomic) {
     if constexpr (SPLITK) {
       if (stages == 3) PGV_FRAG_GO(true, 3);
       else if (stages == 4) PGV_FRAG_GO(true, 4);
@@ -286,9 +330,16 @@ extern "C" int pgv_dbg_set_gemm_variant(int v) {
 int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                   float* C, int64_t ldc, const float* bias_n, int flags, hipStream_t st,
                   int (*init_c)(float*, int, int, int64_t, const float*, hipStream_t)) {
-  if (flags & PGV_COMPUTE_BF16) return 0;
+  // PGV_COMPUTE_BF16 (round 6): the same jobs with 32-deep chunks and one bfloat16 matrix instruction per tile pair and chunk.
+  // Measured on the z = 512 products of BASELINE config 2 against gemm.hip's LDS tiles (us, same box): decoder forward
+  // [256 x 12 288, K = 512] 27.9 / 37.0 and decoder input gradient [256 x 512, K = 12 288] 25.8 / 38.6 - taken here; encoder
+  // forward 52.3 / 45.3 (47.3 with 64 x 32 macro tiles), encoder input gradient 44.5 / 44.5, weight gradients 63.4 / 34.1 and
+  // 27.9 / 20.6 - left there: 32 x 32 .. 64 x 32 macro tiles per wave re-read the operands 8 - 32 x out of L2 (800 MB for the
+  // encoder forward), which a 128 x 128 workgroup tile does not.  Bit 12 of the tuning variant sends every covered shape here.
+  const bool bf16 = (flags & PGV_COMPUTE_BF16) != 0;
+  const int CD = bf16 ? 32 : 16;
   if (g_frag_variant & 1024) return 0;   // (A/B timing: the LDS-tiled kernels of gemm.hip)
-  if (K % 16 != 0 || K < 32 || ldc % 4 != 0 || !al16(A) || !al16(B) || !al16(C) || (bias_n && !al16(bias_n))) return 0;
+  if (K % CD != 0 || K < 2 * CD || ldc % 4 != 0 || !al16(A) || !al16(B) || !al16(C) || (bias_n && !al16(bias_n))) return 0;
   const bool p_kc = sbk == 1, p_ic = sbn == 1 && !p_kc, q_kc = sak == 1, q_ic = sam == 1 && !q_kc;
   if (!(p_kc || p_ic) || !(q_kc || q_ic)) return 0;
   FragArgs a;
@@ -296,7 +347,7 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
   a.P = B, a.Q = A, a.C = C, a.bias = bias_n;
   a.ldp = p_kc ? sbn : sbk, a.ldq = q_kc ? sam : sak, a.ldc = ldc;
   if (a.ldp % 4 != 0 || a.ldq % 4 != 0) return 0;
-  a.nchunks = K / 16;
+  a.nchunks = K / CD;
   a.KS = 1, a.atomic = 0;
   // byte offsets of a macro tile's rows must fit the 32-bit lane offsets
   auto fits = [](int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 31); };
@@ -307,7 +358,7 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
     if (long_k) {
       // split K until ~job_target wave jobs exist (one or two per SIMD), at least 8 chunks per job
       int ks = (int)pgv_cdiv(job_target << ((g_frag_variant >> 4) & 3), (int64_t)a.MPw * a.MQw);
-      ks = (int)max((int64_t)1, min((int64_t)ks, (int64_t)a.nchunks / 8));
+      ks = (int)max((int64_t)1, min((int64_t)ks, (int64_t)a.nchunks / (bf16 ? 4 : 8)));
       a.KS = ks;
       if (ks > 1) a.atomic = (flags & PGV_PREZEROED) ? 2 : 1;
     }
@@ -319,29 +370,36 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
     if (N % 32 != 0 || M % 32 != 0 || !fits(32, a.ldp) || !fits(32, a.ldq)) return 0;
     // (same-box A/B, us: encoder forward [256 x 128, K = 25 024] 22.8 here with two jobs per SIMD against 27.5 for the
     // LDS-tiled kernel; the short-K decoder forward [256 x 25 024, K = 64] 18.0 against 16.4: that one stays there)
-    if (!long_k && !(g_frag_variant & 2048)) return 0;
+    // (bf16: the short-K forward product of z = 512 too, K >= 256: 27.9 us against 37.0 for the LDS tiles)
+    if (!long_k && !(bf16 && (K >= 256 || (g_frag_variant & 4096))) && !(g_frag_variant & 2048)) return 0;
     if (!long_k && N % 64 == 0 && (int64_t)(N / 64) * (M / 32) >= 1536) {
       finish(64, 32);
-      rc = (g_frag_variant & 512) ? launch_frag<0, 0, 4, 2, false>(a, st) : launch_frag<1, 1, 4, 2, false>(a, st);
+      rc = bf16 ? launch_frag<1, 1, 4, 2, false, true>(a, st)
+                : ((g_frag_variant & 512) ? launch_frag<0, 0, 4, 2, false>(a, st) : launch_frag<1, 1, 4, 2, false>(a, st));
     } else {
+      if (bf16 && !(g_frag_variant & 4096)) return 0;
       finish(32, 32, 2048);
       if (a.atomic == 1 && init_c(C, M, N, ldc, bias_n, st)) return PGV_E_LAUNCH;
-      rc = (g_frag_variant & 512) ? launch_frag<0, 0, 2, 2, true>(a, st) : launch_frag<1, 1, 2, 2, true>(a, st);
+      rc = bf16 ? launch_frag<1, 1, 2, 2, true, true>(a, st)
+                : ((g_frag_variant & 512) ? launch_frag<0, 0, 2, 2, true>(a, st) : launch_frag<1, 1, 2, 2, true>(a, st));
     }
   } else if (p_ic && q_kc) {
     // input-gradient products: gy[m][k] . W[k][n]
     if (N % 64 != 0 || M % 32 != 0 || !fits(32, a.ldq)) return 0;
+    if (bf16 && !(long_k && N >= 256) && !(g_frag_variant & 4096)) return 0;
     finish(64, 32);
     if (a.atomic == 1 && init_c(C, M, N, ldc, bias_n, st)) return PGV_E_LAUNCH;
-    rc = (g_frag_variant & 512) ? launch_frag<4, 0, 4, 2, true>(a, st) : launch_frag<4, 1, 4, 2, true>(a, st);
+    rc = bf16 ? launch_frag<4, 1, 4, 2, true, true>(a, st)
+              : ((g_frag_variant & 512) ? launch_frag<4, 0, 4, 2, true>(a, st) : launch_frag<4, 1, 4, 2, true>(a, st));
   } else if (p_ic && q_ic) {
     // weight-gradient products: gy[b][m]^T . x[b][n]
     if (N % 64 != 0 || long_k) return 0;
+    if (bf16 && !(g_frag_variant & 4096)) return 0;
     // (32 Q indices per job, read 2 at a time: twice the jobs of a 64 x 64 tiling - 782 instead of 391 for the decoder's
     // Linear, whose 25 024 rows otherwise fill 38 % of the chip: 14.7 against 21.5 us)
     if (M % 32 != 0) return 0;
     finish(64, 32);
-    rc = launch_frag<4, 2, 4, 2, false>(a, st);
+    rc = bf16 ? launch_frag<4, 2, 4, 2, false, true>(a, st) : launch_frag<4, 2, 4, 2, false>(a, st);
   } else
     return 0;
   return rc;

@@ -9,15 +9,16 @@ if os.environ.get('FC_TILES'):
     _lib.load().pgv_dbg_set_gemm_tiles(int(os.environ['FC_TILES']))
 if os.environ.get('FC_BF16'):
     ops.set_compute_dtype('bf16')
-FEAT = int(os.environ.get('FC_FEAT', 25024))
-for dz in (64, 512):
+for dz, FEAT in ((64, 25024), (512, 12288)):
     x = torch.randn(B, FEAT, device='cuda'); We = torch.randn(2 * dz, FEAT, device='cuda') * 0.01; be = torch.zeros(2 * dz, device='cuda')
     gye = torch.randn(B, 2 * dz, device='cuda'); gWe = torch.empty_like(We)
     z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(FEAT, dz, device='cuda') * 0.01; bd = torch.zeros(FEAT, device='cuda')
     gyd = torch.randn(B, FEAT, device='cuda'); gWd = torch.empty_like(Wd)
-    for pol in (0, 0, 1):
+    for pol in (0, 2, 1):
+        if pol == 2:
+            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(4096)   # second line (bf16): every covered shape on gemm_frag.hip
         if os.environ.get('FC_BF16') and pol == 1:
-            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(4096)   # third line: gemm.hip's bf16 MFMA tiles
+            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(1024)   # third line: gemm.hip's bf16 MFMA tiles
         _lib.load().pgv_set_kernel_policy(pol)
         ts = [bench.time_kernel(f, iters=5) * 1e3 for f in (
             lambda: ops.linear_fwd(x, We, be), lambda: ops.linear_dgrad(gye, We), lambda: ops.linear_wgrad(gye, x, gWe),

@@ -1619,10 +1619,16 @@ def test_linear_gemm(ops, mnk):
     assert rel_l2(gb, br.grad) < 1e-5
 
 
-@pytest.mark.parametrize("mnk", [(64, 128, 24576), (256, 1024, 3200), (256, 192, 4096), (512, 256, 1056)])
+@pytest.mark.parametrize("mnk", [(64, 128, 24576), (256, 1024, 3200), (256, 192, 4096), (512, 256, 1056),
+                                 # round 6: the fragment-streaming kernels with 32-deep bf16 chunks (gemm_frag.hip) - BASELINE config
+                                 # 2's extents (z = 512 on 12 288 features), the z = 64 ones, K splits that do not divide the chunk
+                                 # count, two-chunk K, ragged job counts
+                                 (256, 1024, 12288), (256, 12288, 512), (256, 128, 25024), (256, 25024, 64), (96, 192, 4128),
+                                 (32, 64, 64), (160, 320, 96)])
 def test_linear_gemm_bf16_operand_mode(ops, mnk):
     """pgv_gemm flags = PGV_COMPUTE_BF16: the three nn.Linear products with bf16-rounded operands (M = 256 / 512: the
-    256-row tiles of round 4, 128- and 64-wide)."""
+    256-row tiles of round 4, 128- and 64-wide; gemm_frag.hip's bf16 form where it covers the shape, and gemm.hip's tiles
+    for the same shape with the fragment kernels switched off)."""
     M, N, K = mnk
     x = synth_vec((M, K), 0.771, 0.3)
     w = synth_vec((N, K), 0.613, 0.8) / np.sqrt(K)
@@ -1632,8 +1638,9 @@ def test_linear_gemm_bf16_operand_mode(ops, mnk):
     from preset_gen_vae_amd import _lib
     ops.set_compute_dtype('bf16')
     try:
-        for tiles in ((0, 1) if M % 256 == 0 else (0,)):   # (1: the 256-row tiles, off by default - slower, gemm.hip)
-            _lib.load().pgv_dbg_set_gemm_tiles(tiles)
+        for tiles in ((0, 1, 2, 3) if M % 256 == 0 else (0, 2, 3)):   # (1: the 256-row tiles, off by default - slower, gemm.hip;
+            _lib.load().pgv_dbg_set_gemm_tiles(tiles & 1 if tiles < 3 else 0)   # 2: everything on gemm.hip's LDS tiles; 3: every
+            _lib.load().pgv_dbg_set_gemm_variant({2: 1024, 3: 4096}.get(tiles, 0))   # covered shape on gemm_frag.hip's bf16 form)
             y = ops.linear_fwd(dx, dw, db)
             assert rel_l2(y, _bf16(x) @ _bf16(w).t() + b.float().double()) < 1e-5
             assert rel_l2(y, F.linear(x, w, b)) > 2e-4
@@ -1643,6 +1650,7 @@ def test_linear_gemm_bf16_operand_mode(ops, mnk):
             assert rel_l2(gw, _bf16(gy).t() @ _bf16(x)) < 1e-5
     finally:
         _lib.load().pgv_dbg_set_gemm_tiles(0)
+        _lib.load().pgv_dbg_set_gemm_variant(0)
         ops.set_compute_dtype('fp32')
 
 
