@@ -216,7 +216,11 @@ def test_train_step_parity(name):
     # whatever side of every kink it took): 64 sampled elements + the L1 checksum per parameter, 5e-3 of the parameter's
     # largest gradient (B = 2: or 4 x the reference arithmetic's float32 noise), with the escape of the B = 256 test - ONE
     # sampled element of a parameter may sit off by the weight of an activation that took the other slope (VERDICT r5 6 ii)
-    off = {}
+    # B = 2 goldens (not strict): one activation of a 3 x 4 plane taking the other slope shifts every element of a deep
+    # BatchNorm bias gradient by up to 1.5 t, and WHICH side it takes follows the arrival order of the fc products' split-K
+    # atomics (the same library passes and fails 7.3e-3 on dec3bn.bias from run to run) - there up to three parameters may
+    # carry such a shift, none beyond 4 t
+    off, shifted = {}, []
     for k in ora['grads']:
         cs = g['grad/' + k + '/checksum']
         if cs[2] < 1e-9:
@@ -227,9 +231,11 @@ def test_train_step_parity(name):
         dev_ = (params[k].grad.double().cpu().reshape(-1)[idx] - sample).abs() / cs[2]
         r_sum = abs(params[k].grad.double().abs().sum().item() - cs[1]) / cs[1]
         n_off = int((dev_ > t).sum())
-        if n_off > 1 or dev_.max().item() > 10 * t or r_sum > t:
+        if not strict and n_off > 1 and dev_.max().item() <= 4 * t and r_sum <= t:
+            shifted.append((k, dev_.max().item(), n_off))
+        elif n_off > 1 or dev_.max().item() > 10 * t or r_sum > t:
             off[k] = (dev_.max().item(), n_off, r_sum, t)
-    assert not off, off
+    assert not off and len(shifted) <= 3, (off, shifted)
     # post-Adam parameters and BN buffers
     sd_new = ae.state_dict()
     for k, v in ora['new_sd'].items():
