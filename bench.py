@@ -50,6 +50,9 @@ def parse():
                          "product as six bf16 matrix instructions on exact three-way operand splits, fp32 accumulation "
                          "(DESIGN.md 2.3; the strict fp32 parity tests run in this mode too); native = the fp32 matrix "
                          "instruction everywhere (reported under 'extra')")
+    ap.add_argument("--gemm-variant", type=int, default=0,
+                    help="A/B timing aid: pgv_dbg_set_gemm_variant (csrc/gemm_frag.hip; 1024 = every nn.Linear product on the "
+                         "LDS-tiled kernels of gemm.hip, 4096 = the covered bf16 shapes on the fragment-streaming ones too)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--dist-mode", default="bucket-graphs", choices=["bucket-graphs", "eager", "two-graph"],
                     help="N > 1 launch mode: bucket-graphs = the captured step cut at the gradient-bucket boundaries "
@@ -676,6 +679,9 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
     from preset_gen_vae_amd.model import build as mbuild
     from preset_gen_vae_amd.train_step import VAETrainStep
     ops.set_compute_dtype(args.dtype)
+    if getattr(args, 'gemm_variant', 0):
+        from preset_gen_vae_amd import _lib
+        _lib.load().pgv_dbg_set_gemm_variant(int(args.gemm_variant))
     # (None = the library default: the headline line times exactly what the training path runs by default)
     ops.set_fp32_products(args.fp32_products if args.dtype == 'fp32' else 'native')
     mc, tc = copy.copy(config.model), copy.copy(config.train)

@@ -330,15 +330,20 @@ extern "C" int pgv_dbg_set_gemm_variant(int v) {
 int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                   float* C, int64_t ldc, const float* bias_n, int flags, hipStream_t st,
                   int (*init_c)(float*, int, int, int64_t, const float*, hipStream_t)) {
-  // PGV_COMPUTE_BF16 (round 6): the same jobs with 32-deep chunks and one bfloat16 matrix instruction per tile pair and chunk.
-  // Measured on the z = 512 products of BASELINE config 2 against gemm.hip's LDS tiles (us, same box): decoder forward
-  // [256 x 12 288, K = 512] 27.9 / 37.0 and decoder input gradient [256 x 512, K = 12 288] 25.8 / 38.6 - taken here; encoder
-  // forward 52.3 / 45.3 (47.3 with 64 x 32 macro tiles), encoder input gradient 44.5 / 44.5, weight gradients 63.4 / 34.1 and
-  // 27.9 / 20.6 - left there: 32 x 32 .. 64 x 32 macro tiles per wave re-read the operands 8 - 32 x out of L2 (800 MB for the
-  // encoder forward), which a 128 x 128 workgroup tile does not.  Bit 12 of the tuning variant sends every covered shape here.
+  // PGV_COMPUTE_BF16 (round 6): the same jobs with 32-deep chunks and one bfloat16 matrix instruction per tile pair and chunk -
+  // built, tested (tests/test_gpu_kernels.py: every covered shape), and NOT the default: bit 12 of the tuning variant sends the
+  // covered bf16 shapes here.  Measured on the z = 512 products of BASELINE config 2 against gemm.hip's LDS tiles (us, same
+  // box, operands cold): decoder forward [256 x 12 288, K = 512] 27.9 / 37.0, decoder input gradient [256 x 512, K = 12 288]
+  // 25.8 / 38.6; encoder forward 52.3 / 45.3 (47.3 with 64 x 32 macro tiles), encoder input gradient 44.5 / 44.5, weight
+  // gradients 63.4 / 34.1 and 27.9 / 20.6 - 32 x 32 .. 64 x 32 macro tiles per wave re-read the operands 8 - 32 x out of L2
+  // (800 MB for the encoder forward), which a 128 x 128 workgroup tile does not.  INSIDE the step, where the activations are
+  // still in L2 / MALL, the two winners are 43.5 / 39.9 us under the profiler (LDS tiles: 45.3 / 45.3) and the whole step of
+  // config 2 is no faster: 2.852 - 2.879 ms with them against 2.841 - 2.861 without (bench.py --gemm-variant 0 / 1024 at the
+  // time, alternating on one box); all six here: 2.97 - 2.99.
   const bool bf16 = (flags & PGV_COMPUTE_BF16) != 0;
   const int CD = bf16 ? 32 : 16;
   if (g_frag_variant & 1024) return 0;   // (A/B timing: the LDS-tiled kernels of gemm.hip)
+  if (bf16 && !(g_frag_variant & 4096)) return 0;
   if (K % CD != 0 || K < 2 * CD || ldc % 4 != 0 || !al16(A) || !al16(B) || !al16(C) || (bias_n && !al16(bias_n))) return 0;
   const bool p_kc = sbk == 1, p_ic = sbn == 1 && !p_kc, q_kc = sak == 1, q_ic = sam == 1 && !q_kc;
   if (!(p_kc || p_ic) || !(q_kc || q_ic)) return 0;
@@ -370,14 +375,12 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
     if (N % 32 != 0 || M % 32 != 0 || !fits(32, a.ldp) || !fits(32, a.ldq)) return 0;
     // (same-box A/B, us: encoder forward [256 x 128, K = 25 024] 22.8 here with two jobs per SIMD against 27.5 for the
     // LDS-tiled kernel; the short-K decoder forward [256 x 25 024, K = 64] 18.0 against 16.4: that one stays there)
-    // (bf16: the short-K forward product of z = 512 too, K >= 256: 27.9 us against 37.0 for the LDS tiles)
-    if (!long_k && !(bf16 && (K >= 256 || (g_frag_variant & 4096))) && !(g_frag_variant & 2048)) return 0;
+    if (!long_k && !(bf16 && (g_frag_variant & 4096)) && !(g_frag_variant & 2048)) return 0;
     if (!long_k && N % 64 == 0 && (int64_t)(N / 64) * (M / 32) >= 1536) {
       finish(64, 32);
       rc = bf16 ? launch_frag<1, 1, 4, 2, false, true>(a, st)
                 : ((g_frag_variant & 512) ? launch_frag<0, 0, 4, 2, false>(a, st) : launch_frag<1, 1, 4, 2, false>(a, st));
     } else {
-      if (bf16 && !(g_frag_variant & 4096)) return 0;
       finish(32, 32, 2048);
       if (a.atomic == 1 && init_c(C, M, N, ldc, bias_n, st)) return PGV_E_LAUNCH;
       rc = bf16 ? launch_frag<1, 1, 2, 2, true, true>(a, st)
@@ -386,7 +389,6 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
   } else if (p_ic && q_kc) {
     // input-gradient products: gy[m][k] . W[k][n]
     if (N % 64 != 0 || M % 32 != 0 || !fits(32, a.ldq)) return 0;
-    if (bf16 && !(long_k && N >= 256) && !(g_frag_variant & 4096)) return 0;
     finish(64, 32);
     if (a.atomic == 1 && init_c(C, M, N, ldc, bias_n, st)) return PGV_E_LAUNCH;
     rc = bf16 ? launch_frag<4, 1, 4, 2, true, true>(a, st)
@@ -394,7 +396,6 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
   } else if (p_ic && q_ic) {
     // weight-gradient products: gy[b][m]^T . x[b][n]
     if (N % 64 != 0 || long_k) return 0;
-    if (bf16 && !(g_frag_variant & 4096)) return 0;
     // (32 Q indices per job, read 2 at a time: twice the jobs of a 64 x 64 tiling - 782 instead of 391 for the decoder's
     // Linear, whose 25 024 rows otherwise fill 38 % of the chip: 14.7 against 21.5 us)
     if (M % 32 != 0) return 0;
