@@ -171,3 +171,11 @@ __device__ __forceinline__ void shadow_bigq_up_item(int it, const float* __restr
 }
 
 }  // namespace
+
+// timing aids shared by the bf16-native translation units (defined in conv_deep_bf16.hip)
+unsigned long long* pgv_deep_bf16_stamps();   // device buffer of the timing scripts: clock64() at the phase marks, or null
+int pgv_deep_bf16_dbg();                      // pgv_dbg_set_deep_bf16_variant
+#define BSTAMP(k)                                                                                   \
+  do {                                                                                              \
+    if (stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 77)) stamps[(blockIdx.x ? 16 : 0) + (k)] = clock64(); \
+  } while (0)

@@ -129,7 +129,10 @@ int pgv_act_bwd_coef_impl(const float* g, const float* a, const float* coef, int
 // cls[C][4] += sums of gy[B,C,H,W] by (row parity, column parity): pgv_bwd_fuse.cls for kernels without that by-product
 int pgv_class_sums2_impl(const float* gy, int B, int C, int H, int W, float* cls, hipStream_t st);
 
-// bf16-native kernels of the deep layers (conv_deep_bf16.hip); weights come from pgv_conv_desc.w_shadow
+// bf16-native kernels of the deep layers (conv_deep_bf16.hip, conv_deep_wgrad_bf16.hip); weights come from pgv_conv_desc.w_shadow
+// (conv_shadow.hip)
+bool pgv_k1_bf16_shape(const pgv_conv_desc* d);
+bool pgv_deep_bf16_shape(const pgv_conv_desc* d);
 int64_t pgv_conv_weight_shadow_bytes_impl(const pgv_conv_desc* d);
 int pgv_conv_weight_shadow_impl(const pgv_conv_desc* d, const float* w, void* shadow, hipStream_t st);
 int pgv_conv_down_deep_bf16(const pgv_conv_desc* d, const float* big, const float* in_scale, const float* in_shift,
