@@ -147,6 +147,8 @@ struct FragArgs {
   int nchunks;         // K / 16
   int njobs;
   int atomic;          // 0: store (+ bias); 1: atomic add; 2: atomic add, the first K split adds the bias
+  int wgred;           // split-K jobs: the four waves of a workgroup take four consecutive K splits of ONE tile and add them
+                       // up through LDS (fixed order) before the atomics - a quarter of the atomic traffic (KS % 4 == 0)
   int dbg;             // tuning builds: 1 = no MFMAs, 2 = no stores
 };
 
@@ -172,9 +174,13 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
   const int per_split = a.MPw * a.MQw;
   typename SP::vec pf[kStages][NLP];
   typename SQ::vec qf[kStages][NLQ];
+  const bool wgred = ATOMIC && a.wgred;
+  const int jend = wgred ? a.njobs / 4 : a.njobs, jstep = wgred ? (int)gridDim.x : (int)gridDim.x * 4;
 #pragma unroll 1
-  for (int job = bid * 4 + wave; job < a.njobs; job += gridDim.x * 4) {
-    const int ks = job / per_split, rem = job - ks * per_split;
+  for (int job = wgred ? bid : bid * 4 + wave; job < jend; job += jstep) {
+    int ks = job / per_split;
+    const int rem = job - ks * per_split;
+    if (wgred) ks = 4 * ks + wave;   // (the same trip count for the four waves: the reduction below has workgroup barriers)
     const int pt = rem / a.MQw, qt = rem - pt * a.MQw;
     const int kc0 = a.nchunks * ks / a.KS, kc1 = a.nchunks * (ks + 1) / a.KS;   // (32-bit: nchunks * KS is small)
     const long long p0 = (long long)pt * PEXT, q0 = (long long)qt * QEXT;
@@ -257,9 +263,23 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
         constexpr int RPI = 64 / PEXT;   // C rows per wave instruction
         static_assert(PEXT <= 64 && 64 % PEXT == 0, "atomic epilogue: a wave instruction covers whole rows of the tile");
         const int pc = lane % PEXT, qr = lane / PEXT;
+        if (wgred) {
+          // the four images of this workgroup are four K splits of the same tile: every wave adds up a quarter of the rows
+          // (splits in order 0 .. 3) and issues the atomics for it
+          __syncthreads();
+          const float bv = (a.atomic == 2 && ks < 4 && a.bias) ? a.bias[p0 + pc] : 0.f;
+#pragma unroll 2
+          for (int q = qr + RPI * wave; q < QEXT; q += 4 * RPI) {
+            const float* t0 = red + q * TROW + pc;
+            const float v = ((t0[0] + t0[QEXT * TROW]) + t0[2 * QEXT * TROW]) + t0[3 * QEXT * TROW];
+            atomicAdd(a.C + (q0 + q) * a.ldc + p0 + pc, v + bv);
+          }
+          __syncthreads();
+        } else {
         const float bv = with_bias ? a.bias[p0 + pc] : 0.f;
 #pragma unroll 4
         for (int q = qr; q < QEXT; q += RPI) atomicAdd(a.C + (q0 + q) * a.ldc + p0 + pc, tile[q * TROW + pc] + bv);
+        }
       } else {
         constexpr int LPR = PEXT / 4, RPI = 64 / LPR;   // lanes per row, rows per wave instruction
         static_assert(64 % LPR == 0 && QEXT % RPI == 0, "store epilogue");
@@ -278,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void gemm_frag_kernel(FragArgs a) {
 int g_frag_variant = 0;   // tuning knob (pgv_dbg_set_gemm_variant): bits 0-1 stages (3 / 4 / 5), bits 2-3 grid cap (1024 / 768 /
                           // 512 / 256), bits 4-5 split-K job target (1024 / 2048 / 4096), bit 6 no MFMAs, bit 7 no stores,
                           // bit 9 fragment-shaped loads of K-contiguous operands, bit 10 everything to
-                          // gemm.hip, bit 11 short-K forward products here too, bit 12 every covered bf16 shape here
+                          // gemm.hip, bit 11 short-K forward products here too, bit 12 every covered bf16 shape here,
+                          // bit 13 split-K jobs without the in-workgroup reduction
 
 // SPLITK: the tiling also exists in its split-K (atomic epilogue) form
 template <int PL, int QL, int TPW, int TQW, bool SPLITK, bool BF16 = false>
@@ -353,17 +374,21 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
   a.ldp = p_kc ? sbn : sbk, a.ldq = q_kc ? sam : sak, a.ldc = ldc;
   if (a.ldp % 4 != 0 || a.ldq % 4 != 0) return 0;
   a.nchunks = K / CD;
-  a.KS = 1, a.atomic = 0;
+  a.KS = 1, a.atomic = 0, a.wgred = 0;
   // byte offsets of a macro tile's rows must fit the 32-bit lane offsets
   auto fits = [](int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 31); };
   const int64_t work = (int64_t)M * N;   // output elements
   const bool long_k = K >= 4096 && work <= 512 * 1024;
-  auto finish = [&](int pext, int qext, int job_target = 1024) {
+  auto finish = [&](int pext, int qext, int job_target = 1024, bool wg_reduce = false) {
     a.MPw = N / pext, a.MQw = M / qext;
     if (long_k) {
       // split K until ~job_target wave jobs exist (one or two per SIMD), at least 8 chunks per job
       int ks = (int)pgv_cdiv(job_target << ((g_frag_variant >> 4) & 3), (int64_t)a.MPw * a.MQw);
       ks = (int)max((int64_t)1, min((int64_t)ks, (int64_t)a.nchunks / (bf16 ? 4 : 8)));
+      // (only where a job's tile is 64 x 32: input-gradient-shaped products 22.3 -> 16.1 us (z = 64) and 43.4 -> 38.5 (z = 512)
+      // on cold operands; the 32 x 32 jobs of the long-K forward product lost 2 - 7 us to the two barriers.  Bit 13 of the
+      // tuning variant: every wave on its own)
+      if (ks >= 4 && wg_reduce && !(g_frag_variant & 8192)) ks &= ~3, a.wgred = 1;
       a.KS = ks;
       if (ks > 1) a.atomic = (flags & PGV_PREZEROED) ? 2 : 1;
     }
@@ -389,7 +414,7 @@ int pgv_gemm_frag(int M, int N, int K, const float* A, int64_t sam, int64_t sak,
   } else if (p_ic && q_kc) {
     // input-gradient products: gy[m][k] . W[k][n]
     if (N % 64 != 0 || M % 32 != 0 || !fits(32, a.ldq)) return 0;
-    finish(64, 32);
+    finish(64, 32, 1024, true);
     if (a.atomic == 1 && init_c(C, M, N, ldc, bias_n, st)) return PGV_E_LAUNCH;
     rc = bf16 ? launch_frag<4, 1, 4, 2, true, true>(a, st)
               : ((g_frag_variant & 512) ? launch_frag<4, 0, 4, 2, true>(a, st) : launch_frag<4, 1, 4, 2, true>(a, st));

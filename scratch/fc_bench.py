@@ -15,8 +15,8 @@ for dz, FEAT in ((64, 25024), (512, 12288)):
     z = torch.randn(B, dz, device='cuda'); Wd = torch.randn(FEAT, dz, device='cuda') * 0.01; bd = torch.zeros(FEAT, device='cuda')
     gyd = torch.randn(B, FEAT, device='cuda'); gWd = torch.empty_like(Wd)
     for pol in (0, 2, 1):
-        if pol == 2:
-            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(4096)   # second line (bf16): every covered shape on gemm_frag.hip
+        if pol == 2:   # second line: bf16 - every covered shape on gemm_frag.hip; fp32 - split-K jobs without the in-workgroup reduction
+            pol = 0; _lib.load().pgv_dbg_set_gemm_variant(4096 if os.environ.get('FC_BF16') else 8192)
         if os.environ.get('FC_BF16') and pol == 1:
             pol = 0; _lib.load().pgv_dbg_set_gemm_variant(1024)   # third line: gemm.hip's bf16 MFMA tiles
         _lib.load().pgv_set_kernel_policy(pol)
