@@ -456,7 +456,10 @@ def measure_roofline(ae, B, device, step_ms, matrix_peak=F32_MATRIX_PEAK_TFLOPS,
     # 256 (the same labels on another model / operand mode are other kernels or other fusions)
     traffic = None
     try:
-        with open(traffic_file or os.path.join(ROOT, 'profiles', 'r6_traffic.json')) as f:
+        # (the front-end launch has a PMC file of its own: profiles/pmc_frontend.py)
+        tf = os.path.join(ROOT, 'profiles', 'r6_traffic_frontend.json') if worst['launch'] == 'stft_mel' else \
+            (traffic_file or os.path.join(ROOT, 'profiles', 'r6_traffic.json'))
+        with open(tf) as f:
             entry = json.load(f).get(worst['launch'])
         if entry and B == 256 and traffic_ok:
             traffic = entry['hbm_bytes_per_launch']
