@@ -718,9 +718,11 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         wav = 0.3 * torch.randn(args.batch, 88576, device=device, generator=gen)   # 173 render buffers of 512 samples
         x = frontend.batch(wav)
 
+    # (--input audio: the front-end is the step's input producer - captured with it, it writes the step's input buffer from the
+    # resident waveforms as the first launch of every replay)
+    producer = (lambda buf: frontend.batch(wav, out=buf)) if frontend is not None else None
+
     def one_step(xin):
-        if frontend is not None:
-            frontend.batch(wav, out=xin)
         return step.step(xin)
 
     # N > 1: the captured launch modes have run over gloo and over a 1-rank RCCL communicator, never over RCCL on several
@@ -738,7 +740,7 @@ def run_workload(args, rank, world, device, with_roofline, with_cpu):
         try:
             step = VAETrainStep(ae, lr=tc.initial_learning_rate, betas=tc.adam_betas, weight_decay=tc.weight_decay,
                                 beta=tc.beta, normalize_losses=tc.normalize_losses, grad_sync=sync, use_graph=graph,
-                                graph_buckets=mode == 'bucket-graphs')
+                                graph_buckets=mode == 'bucket-graphs', input_producer=producer)
             for _ in range(max(1, args.warmup) if dist_on else args.warmup):
                 out = one_step(x)
             torch.cuda.synchronize()

@@ -30,8 +30,13 @@ from .model import loss as loss_mod
 class VAETrainStep:
     def __init__(self, ae_model, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, beta=0.2, normalize_losses=True,
                  reg_model=None, grad_sync=None, use_graph=False, controls_criterion=None, monitors=None,
-                 graph_buckets=True, fp32_products=None):
-        """``fp32_products``: 'bf16x6' / 'native' selects the form of the fp32 products for the whole process
+                 graph_buckets=True, fp32_products=None, input_producer=None):
+        """``input_producer``: callable(buffer) that WRITES the step's minibatch into ``buffer`` (the tensor passed to ``step``
+        - in graph mode ``static_input``) as the first launches of the step: in graph mode they are captured with it, so a
+        front-end that turns a resident raw-audio minibatch into spectrograms (``MelSpectrogram.batch(wav, out=buffer)``,
+        BASELINE config 5) costs no launch of its own between two replays.  The producer must be capture-safe (no host
+        synchronisation, its own inputs in buffers that outlive the step) and is called in the two warm-up steps as well.
+        ``fp32_products``: 'bf16x6' / 'native' selects the form of the fp32 products for the whole process
         (``ops.set_fp32_products``; None keeps the current setting, whose default is 'bf16x6' - the mode bench.py times).
         ``controls_criterion``: callable(v_out, v_in) -> 0-d loss, the backprop criterion of the preset-regression
         output (train.py:108-116: ``model.params_loss.SynthParamsLoss``; default: MSE over all columns, the numeric branch
@@ -44,6 +49,7 @@ class VAETrainStep:
             ops.set_fp32_products(fp32_products)
         self.model = ae_model
         self.reg_model = reg_model
+        self.input_producer = input_producer
         self.beta = float(beta)
         params = list(ae_model.parameters()) + (list(reg_model.parameters()) if reg_model is not None else [])
         self.flat = optim_mod.FlatParams(params)
@@ -101,6 +107,8 @@ class VAETrainStep:
 
     def _forward_backward(self, x, v_in=None, inject=None, hooks=False):
         inject = inject or {}
+        if self.input_producer is not None:
+            self.input_producer(x)
         pending = self._rng()
         if pending is not None and pending.owed:
             # a forward whose optimizer step never came (gradient accumulation, a loss probe) left its generator advance
@@ -191,7 +199,7 @@ class VAETrainStep:
         self.optimizer.sync_lr()
         self._constants(self._static_x.device)
         # a loader that writes its minibatch straight into ``static_input`` (and passes that tensor) skips the copy
-        if x.data_ptr() != self._static_x.data_ptr():
+        if self.input_producer is None and x.data_ptr() != self._static_x.data_ptr():   # (a producer fills it inside the graph)
             self._static_x.copy_(x, non_blocking=True)
         if v_in is not None and v_in.data_ptr() != self._static_v.data_ptr():
             self._static_v.copy_(v_in, non_blocking=True)

@@ -1154,6 +1154,28 @@ def test_fused_frontend_into_step():
     l0 = step_g.step(mel.batch(torch.tensor(waves, device='cuda'), out=step_g.static_input))['recons'].item()
     l1 = step_g.step(mel.batch(torch.tensor(0.1 * waves, device='cuda'), out=step_g.static_input))['recons'].item()
     assert np.isfinite(l0) and np.isfinite(l1) and abs(l0 - l1) > 1e-3 * abs(l0)
+    # the front-end as the step's input producer: captured with the step (bench.py --input audio), it reads a resident
+    # waveform buffer and writes the step's input as the first launch of every replay - the same losses as the eager launch
+    # in front of the replay above, from the same parameters
+    wav_buf = torch.tensor(waves, device='cuda')
+    x_p = torch.zeros(B, 1, 257, 347, device='cuda')
+    totals = []
+    for producer in (lambda buf: mel.batch(wav_buf, out=buf), None):
+        torch.manual_seed(23)                      # (the same eps stream for both runs)
+        ae_i = _build(arch, dim_z, B, False, fc_dropout=0.0)
+        _load_closed_form(ae_i, arch, dim_z, False, 1234)
+        step_i = VAETrainStep(ae_i.cuda().train(), use_graph=True, input_producer=producer)
+        ts = []
+        for scale in (1.0, 0.1, 0.7):
+            wav_buf.copy_(torch.tensor(scale * waves, device='cuda'))
+            ts.append(step_i.step(x_p if producer is not None else mel.batch(wav_buf.clone()))['total'].item())
+        totals.append(ts)
+        if producer is not None:
+            step_p = step_i
+    for got, ref in zip(*totals):
+        assert np.isfinite(got) and abs(got - ref) <= 1e-3 * abs(ref), totals
+    assert abs(totals[0][0] - totals[0][1]) > 1e-3 * abs(totals[0][0])
+    assert step_p.static_input is not None and not bool(torch.isnan(step_p.static_input).any())
 
 
 def test_optimizer_step_count_survives_underflow_of_beta1_power():
