@@ -245,6 +245,9 @@ class VAETrainStep:
         if not self.use_graph:
             raise RuntimeError("prefetch_input / step_prefetched belong to the graph mode (use_graph=True): an eager step "
                                "reads the tensor it is given, there is no captured input buffer to stage into")
+        if self.input_producer is not None:
+            raise RuntimeError("prefetch_input: this step has an input_producer - the captured step writes its own input "
+                               "buffer (stage the producer's source, e.g. the waveform buffer, instead)")
         if self._static_x is None:
             raise RuntimeError("prefetch_input: run one step first (the captured step's input buffer does not exist yet)")
         if tuple(host_x.shape) != tuple(self._static_x.shape) or host_x.dtype != self._static_x.dtype:

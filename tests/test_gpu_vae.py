@@ -1176,6 +1176,8 @@ def test_fused_frontend_into_step():
         assert np.isfinite(got) and abs(got - ref) <= 1e-3 * abs(ref), totals
     assert abs(totals[0][0] - totals[0][1]) > 1e-3 * abs(totals[0][0])
     assert step_p.static_input is not None and not bool(torch.isnan(step_p.static_input).any())
+    with pytest.raises(RuntimeError, match="input_producer"):
+        step_p.prefetch_input(torch.zeros(B, 1, 257, 347).pin_memory())
 
 
 def test_optimizer_step_count_survives_underflow_of_beta1_power():
