@@ -282,6 +282,18 @@ int pgv_conv_down_bn(const pgv_conv_desc* d, const float* big, const pgv_bn_src*
                      int act, float slope, float* small_out, double* stats, void* stream);
 int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* w,
                    const float* bias, int act, float slope, float* big_out, double* stats, void* stream);
+/* pgv_conv_up (in_bn null: in_scale / in_shift, both may be null) or pgv_conv_up_bn of an OUTPUT block (no statistics) plus the
+ * squared-error reconstruction criterion where the output is produced (ABI v16; train.py:104,222 MSELoss / L2Loss against
+ * the minibatch, model/decoder.py:218-219 the output layer): with an upstream gradient of exactly 1 for the criterion's value,
+ *   g_y = act'(big_out) * 2 * scale * (big_out - target),  gbias[Cb] += sum g_y,  *loss_acc += scale * sum (big_out - target)^2,
+ *   cls[PGV_CLS_COPIES][4] += sums of g_y by (row parity, column parity) (single-channel outputs; may be null)
+ * - what pgv_sqerr_act_bwd_cls computes from big_out in a pass of its own.  *fused = 1: done; *fused = 0: this shape / mode
+ * has no fused kernel and NOTHING was launched (the caller runs pgv_conv_up[_bn] and pgv_sqerr_act_bwd[_cls]).  Accumulators
+ * are added to (the caller clears them). */
+int pgv_conv_up_sqerr(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* in_scale,
+                      const float* in_shift, const float* w, const float* bias, int act, float slope, float* big_out,
+                      const float* target, float scale, float* g_y, float* gbias, float* loss_acc, float* cls, int* fused,
+                      void* stream);
 /* Eval-mode BN folded to an affine: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
  * (validation forward, train.py:261-291). */
 int pgv_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -88,6 +88,8 @@ SIGNATURES = {
     "pgv_conv_up_fused": (c_int, [_DESC, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _FUSE, _P]),
     "pgv_conv_down_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
     "pgv_conv_up_bn": (c_int, [_DESC, _P, _BN, _P, _P, c_int, c_float, _P, _P, _P]),
+    "pgv_conv_up_sqerr": (c_int, [_DESC, _P, _BN, _P, _P, _P, _P, c_int, c_float, _P, _P, c_float, _P, _P, _P, _P,
+                                  ctypes.POINTER(c_int), _P]),
     "pgv_conv_weight_shadow_bytes": (c_int64, [_DESC]),
     "pgv_conv_weight_shadow": (c_int, [_DESC, _P, _P, _P]),
     "pgv_conv_weight_shadows": (c_int, [c_int, POINTER(_DESC), POINTER(c_void_p), POINTER(c_void_p), _P]),

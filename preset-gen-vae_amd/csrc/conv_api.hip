@@ -31,7 +31,7 @@ static int check_desc(const pgv_conv_desc* d, const char* who) {
 
 extern "C" {
 
-int pgv_abi_version(void) { return 15; }
+int pgv_abi_version(void) { return 16; }
 const char* pgv_last_error(void) { return g_err; }
 static int g_no_v2 = 0;
 int pgv_set_kernel_policy(int policy) {
@@ -202,6 +202,28 @@ int pgv_conv_up_bn(const pgv_conv_desc* d, const float* small_in, const pgv_bn_s
   }
   if ((rc = bn_src_finalize(in_bn, d->Cs, stream))) return rc;
   return pgv_conv_up(d, small_in, in_bn->scale, in_bn->shift, w, bias, act, slope, big_out, stats, stream);
+}
+
+int pgv_conv_up_sqerr(const pgv_conv_desc* d, const float* small_in, const pgv_bn_src* in_bn, const float* in_scale,
+                      const float* in_shift, const float* w, const float* bias, int act, float slope, float* big_out,
+                      const float* target, float scale, float* g_y, float* gbias, float* loss_acc, float* cls, int* fused,
+                      void* stream) {
+  PGV_CHECK_ARG(fused, "pgv_conv_up_sqerr: fused is null");
+  *fused = 0;
+  int rc = check_desc(d, "pgv_conv_up_sqerr");
+  if (rc) return rc;
+  if (in_bn && (rc = check_bn_src(in_bn, "pgv_conv_up_sqerr"))) return rc;
+  PGV_CHECK_ARG(!in_bn || (!in_scale && !in_shift), "pgv_conv_up_sqerr: in_bn excludes in_scale / in_shift");
+  PGV_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pgv_conv_up_sqerr: scale/shift must come together");
+  if (d->B == 0) return PGV_OK;
+  PGV_CHECK_ARG(small_in && w && big_out && target && g_y && gbias, "pgv_conv_up_sqerr: null tensor");
+  if (g_policy != 0 || g_no_v2) return PGV_OK;   // (the tests' kernel policies take the separate launches)
+  const pgv_ring_sq sq = {target, 2.0f * scale, scale, g_y, gbias, loss_acc, cls};
+  rc = pgv_conv_up_ring(d, small_in, in_bn ? in_bn->scale : in_scale, in_bn ? in_bn->shift : in_shift, w, bias, act, slope,
+                        big_out, nullptr, pgv_stream(stream), in_bn, &sq);
+  if (rc < 0) return rc;
+  *fused = rc > 0 ? 1 : 0;
+  return PGV_OK;
 }
 
 int pgv_conv_up_fused(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,

@@ -85,12 +85,18 @@ struct UpRingCfg {
   static_assert(S * QW <= 256, "one quad per lane");
 };
 
-template <int CS, int H, int W, int S>
+// SQ (round 6, pgv_conv_up_sqerr): the squared-error criterion and the output activation's backward in this epilogue - the
+// kernel has the output in registers, so the criterion's pass over it (read output + target, write gradient: 275 MB, 53 us)
+// becomes one more 92 MB stream in and one out of a kernel that waits for its multiply phase: 73 + 53 -> 96 us.  Per element
+// exactly sqerr_act_bwd_cls_kernel (bn.hip) with an upstream gradient of 1: g = act'(o) 2 scale (o - target); by-products: the
+// sums of g by (row parity, column parity) class - an output quad's lanes ARE the four classes - the bias gradient (their
+// total) and the criterion's value, one set of atomics per workgroup.
+template <int CS, int H, int W, int S, bool SQ = false>
 __global__ __launch_bounds__(256, 2) void up_c1_ring_kernel(int B, int nseg, const float* __restrict__ small_in,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, const float* __restrict__ w,
                                                             const float* __restrict__ bias, int act, float slope,
-                                                            float* __restrict__ out, pgv_bn_src bn) {
+                                                            float* __restrict__ out, pgv_bn_src bn, pgv_ring_sq sq) {
   using G = UpRingCfg<CS, H, W, S>;
   constexpr int Hs = G::Hs, Ws = G::Ws, Hg = G::Hg, WsP = G::WsP, ROWF = G::ROWF, NI = G::NI, NR = G::NR, QW = G::QW;
   constexpr int STEPS = G::STEPS;
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void up_c1_ring_kernel(int B, int nseg, con
   float* wsh = aff + 2 * CS;             // [25] sum_cs shift[cs] * w[cs][k]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float sq_c4[4] = {0.f, 0.f, 0.f, 0.f}, sq_err = 0.f;   // (SQ) sums of g by class [2 row parity + column parity]; sum of d^2
   if (tid < G::FRONT) lds[tid] = 0.f;
   if (tid < CS) {
     float sc = 1.f, sh = 0.f;
@@ -269,21 +276,70 @@ __global__ __launch_bounds__(256, 2) void up_c1_ring_kernel(int B, int nseg, con
             float y[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = pgv_act_apply_nan(acc[ph][i >> 1][i & 1], actp);
+            float gq[8];
+            if constexpr (SQ) {
+              const float* tg = sq.target + ((int64_t)b * H * W + (int64_t)(oh + ph) * W + ow);
+              float t[8];
+              if (n >= 8) {
+                const f4u t0 = *reinterpret_cast<const f4u*>(tg), t1 = *reinterpret_cast<const f4u*>(tg + 4);
+                t[0] = t0.x, t[1] = t0.y, t[2] = t0.z, t[3] = t0.w, t[4] = t1.x, t[5] = t1.y, t[6] = t1.z, t[7] = t1.w;
+              } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = i < n ? tg[i] : 0.f;
+              }
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float dlt = y[i] - t[i];
+                float g = sq.k * dlt;
+                if (act == PGV_ACT_LEAKY_RELU)
+                  g = y[i] > 0.f ? g : slope * g;
+                else if (act == PGV_ACT_HARDTANH)
+                  g = (y[i] > -1.f && y[i] < 1.f) ? g : 0.f;
+                const bool on = i < n;
+                gq[i] = g;
+                sq_err = on ? fmaf(dlt, dlt, sq_err) : sq_err;
+                sq_c4[2 * ph + (i & 1)] += on ? g : 0.f;   // (oh and ow are even: the row parity is ph, the column parity i & 1)
+              }
+            }
+            float* gr = SQ ? sq.gy + ((int64_t)b * H * W + (int64_t)(oh + ph) * W + ow) : nullptr;
             if (n >= 8) {
               f4u a, c;
               a.x = y[0], a.y = y[1], a.z = y[2], a.w = y[3];
               c.x = y[4], c.y = y[5], c.z = y[6], c.w = y[7];
               *reinterpret_cast<f4u*>(o) = a;
               *reinterpret_cast<f4u*>(o + 4) = c;
+              if constexpr (SQ) {
+                a.x = gq[0], a.y = gq[1], a.z = gq[2], a.w = gq[3];
+                c.x = gq[4], c.y = gq[5], c.z = gq[6], c.w = gq[7];
+                *reinterpret_cast<f4u*>(gr) = a;
+                *reinterpret_cast<f4u*>(gr + 4) = c;
+              }
             } else {
 #pragma unroll
               for (int i = 0; i < 8; ++i)
-                if (i < n) o[i] = y[i];
+                if (i < n) {
+                  o[i] = y[i];
+                  if constexpr (SQ) gr[i] = gq[i];
+                }
             }
           }
         }
       }
       ring_barrier();
+    }
+  }
+  if constexpr (SQ) {
+    // the six sums of the workgroup (as sqerr_act_bwd_cls_kernel): 4 classes, their total = the bias gradient, the squared error
+    __syncthreads();
+    float* red6 = lds;   // (the ring is dead)
+    const float v6[6] = {sq_c4[0], sq_c4[1], sq_c4[2], sq_c4[3], (sq_c4[0] + sq_c4[1]) + (sq_c4[2] + sq_c4[3]), sq_err};
+    const float r = pgv_block_sums<6>(v6, red6);
+    if (tid < 4) {
+      if (sq.cls) atomicAdd(&sq.cls[(blockIdx.x & (PGV_CLS_COPIES - 1)) * 4 + tid], r);   // (the copy of this workgroup's XCD)
+    } else if (tid == 4) {
+      if (sq.gbias) atomicAdd(&sq.gbias[0], r);
+    } else if (tid == 5) {
+      if (sq.loss_acc) atomicAdd(sq.loss_acc, sq.scale * r);
     }
   }
 }
@@ -292,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void up_c1_ring_kernel(int B, int nseg, con
 
 int pgv_conv_up_ring(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
-                     const pgv_bn_src* bn) {
+                     const pgv_bn_src* bn, const pgv_ring_sq* sq) {
   if (d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cb != 1 || d->Cs != 8 || stats) return 0;
   if (d->Hb != 257 || d->Wb != 347 || d->B <= 0 || (d->flags & PGV_COMPUTE_BF16)) return 0;
   if (bn && !in_scale) return 0;
@@ -300,22 +356,22 @@ int pgv_conv_up_ring(const pgv_conv_desc* d, const float* small_in, const float*
   using G = UpRingCfg<8, 257, 347, 5>;
   constexpr size_t bytes = sizeof(float) * G::LDS_FLOATS;
   static_assert(bytes <= (size_t)kMaxLds / 2, "two workgroups per CU");
-  auto kern = up_c1_ring_kernel<8, 257, 347, 5>;
-  static bool raised = false;
-  if (!raised) {
+  auto kern = sq ? up_c1_ring_kernel<8, 257, 347, 5, true> : up_c1_ring_kernel<8, 257, 347, 5, false>;
+  static bool raised[2] = {false, false};
+  if (!raised[sq ? 1 : 0]) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (e != hipSuccess) {
       pgv_set_error("conv_up_ring: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
       return PGV_E_LAUNCH;
     }
-    raised = true;
+    raised[sq ? 1 : 0] = true;
   }
   // segments of a sample: enough workgroups for two per CU, no more segments than steps
   int nseg = (512 + d->B - 1) / d->B;
   nseg = nseg < 1 ? 1 : (nseg > G::STEPS ? G::STEPS : nseg);
   const int units = d->B * nseg;
   hipLaunchKernelGGL(kern, dim3(units < 512 ? units : 512), dim3(256), bytes, st, d->B, nseg, small_in, in_scale, in_shift,
-                     w, bias, act, slope, out, bn ? *bn : pgv_no_bn());
+                     w, bias, act, slope, out, bn ? *bn : pgv_no_bn(), sq ? *sq : pgv_ring_sq{});
   PGV_CHECK_LAUNCH("conv_up_ring");
   return 1;
 }

@@ -56,9 +56,18 @@ int pgv_conv_up_v2(const pgv_conv_desc* d, const float* small_in, const float* i
                    const pgv_bwd_fuse* fuse, hipStream_t st, const pgv_bn_src* bn = nullptr);
 
 // Third-generation kernels of the same layers (conv_c1_ring.hip): LDS ring of image rows filled by LDS-DMA, fp32 only.
+// (sq: also the squared-error criterion against sq->target with an upstream gradient of 1, pgv_conv_up_sqerr)
+struct pgv_ring_sq {
+  const float* target;   // [B, 1, H, W]
+  float k, scale;        // 2 * scale; the criterion's scale
+  float* gy;             // [B, 1, H, W] gradient of the block's pre-activation output
+  float* gbias;          // [1] += sum gy
+  float* loss_acc;       // [1] += scale * sum (out - target)^2, or null
+  float* cls;            // [PGV_CLS_COPIES][4] += sums of gy by (row parity, column parity), or null
+};
 int pgv_conv_up_ring(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                      const float* w, const float* bias, int act, float slope, float* out, double* stats, hipStream_t st,
-                     const pgv_bn_src* bn);
+                     const pgv_bn_src* bn, const pgv_ring_sq* sq = nullptr);
 // Second-generation direct kernels (conv_direct2.hip): four pixels per lane, 16-byte LDS reads and stores.
 int pgv_conv_up_direct2(const pgv_conv_desc* d, const float* small_in, const float* in_scale, const float* in_shift,
                         const float* w, const float* bias, int act, float slope, float* out, double* stats,

@@ -132,11 +132,16 @@ class BasicVAE(nn.Module):
                 z_sampled = _ReparamFn.apply(z_mu_logvar, None)
             kind = self.fuse_recons_criterion
             if self.training and kind is not None and x.shape[1] == 1:
-                deferred = kind.endswith('+deferred')    # value delivered by the backward kernel (layer.ConvStackFn)
+                opts = kind.split('+')[1:]
+                deferred = 'deferred' in opts            # value delivered by the backward kernel (layer.ConvStackFn)
+                # 'unit' (with 'deferred'): the caller's promise that the value enters its total with gradient 1 and that
+                # x_out gets no other gradient - the criterion then rides in the output layer's forward kernel
+                from . import layer as _layer
+                unit = deferred and 'unit' in opts and _layer.UNIT_RECONS_GRADIENT
                 scale = {'mse_mean': 1.0 / x.numel(), 'l2_batch': 1.0 / x.shape[0],
                          'l2_batch_contents': 1.0 / x.numel()}[kind.split('+')[0]]
                 x_out, recons = self.decoder(z_sampled, dropout_mask=dec_dropout_mask, sq_target=x,
-                                             sq_scale=-scale if deferred else scale)
+                                             sq_scale=((-scale, 'unit') if unit else (-scale if deferred else scale)))
                 x_out._pgv_recons = (x.data_ptr(), scale, recons)
             else:
                 x_out = self.decoder(z_sampled, dropout_mask=dec_dropout_mask)

@@ -155,6 +155,12 @@ def _grad_done(*params):
                 GRAD_READY_HOOK(p)
 
 
+# True only while VAETrainStep evaluates the model for a step whose total it assembles itself (total = 1 * recons + beta *
+# latent, x_out feeds nothing else): the 'unit' form of the fused reconstruction criterion (ConvStackFn.forward) is taken only
+# then - a model used by hand, with any loss built on its outputs, never sees it.
+UNIT_RECONS_GRADIENT = False
+
+
 class ConvStackFn(torch.autograd.Function):
     """A chain of conv blocks evaluated with folded BatchNorm between consecutive blocks."""
 
@@ -171,6 +177,18 @@ class ConvStackFn(torch.autograd.Function):
         x = x.contiguous()
         B = x.shape[0]
         dev = x.device
+        # ``sq_scale`` = (scale, 'unit'): the caller PROMISES that the criterion's value enters its total with a gradient of
+        # exactly 1 and that the output receives no other gradient (VAETrainStep: total = recons + beta * latent).  The
+        # criterion and the output activation's backward then ride in the output layer's forward kernel where it has one
+        # (ops.conv_up_sq: 73 + 53 -> 96 us on the 8 -> 1 channel layer), and backward starts from the stored gradient.
+        sq_unit = False
+        if isinstance(sq_scale, tuple):
+            sq_scale, tag = sq_scale
+            sq_unit = tag == 'unit'
+        ctx.sq_fwd = None
+        fwd_sq = (sq_target is not None and sq_unit and sq_scale < 0 and out_dropout is None and blocks[-1].up and
+                  blocks[-1].bn is None and blocks[-1].c_out == 1)
+        sq_loss_acc = None
         cur, cur_scale, cur_shift = x, None, None
         pending = None
         saved = []
@@ -218,8 +236,24 @@ class ConvStackFn(torch.autograd.Function):
                 a_off += SC * 2 * C
             fn = ops.conv_up if blk.up else ops.conv_down
             w_sh = shadows[bi]
+            a = None
+            if fwd_sq and bi == len(blocks) - 1 and w_sh is None:
+                gb, gb_ret, gb_zero = _grad_dest(b, accumulated=True)
+                if not gb_zero:
+                    gb.zero_()
+                sq_loss_acc = _step_zeros(params[0], 1, torch.float32, 'sqloss', dev)
+                sq_cls = _step_zeros(params[0], ops.CLS_COPIES * 4, torch.float32, 'sqcls', dev)
+                res = ops.conv_up_sq(g, cur, w, b, blk.act, blk.slope, sq_target.contiguous(), -float(sq_scale), gb,
+                                     sq_loss_acc, sq_cls, in_scale=None if pending is not None else cur_scale,
+                                     in_shift=None if pending is not None else cur_shift, in_bn=pending)
+                if res is not None:
+                    a, g_y0 = res
+                    ctx.sq_fwd = (g_y0, gb, gb_ret, sq_cls)
+                    pending = None
             # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
-            if pending is not None:
+            if a is not None:
+                pass
+            elif pending is not None:
                 a = fn(g, cur, w, b, blk.act, blk.slope, stats=stats, prezeroed=stats is not None, in_bn=pending,
                        stats_copies=stats is not None and SC > 1, w_shadow=w_sh)
                 pending = None
@@ -271,7 +305,7 @@ class ConvStackFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if sq_scale < 0:
             ctx.sq = (sq_target, -float(sq_scale))
-            ctx.sq_deferred = _step_zeros(params[0], 1, torch.float32, 'sqloss', dev)
+            ctx.sq_deferred = sq_loss_acc if sq_loss_acc is not None else _step_zeros(params[0], 1, torch.float32, 'sqloss', dev)
             return out, ctx.sq_deferred.reshape(())
         ctx.sq = (sq_target, float(sq_scale))
         ctx.sq_deferred = None
@@ -281,7 +315,15 @@ class ConvStackFn(torch.autograd.Function):
     def backward(ctx, g_out, g_loss=None):
         blocks, saved, params = ctx.blocks, ctx.saved, ctx.params
         fused_sq = False
-        if ctx.sq is not None:
+        sq_fwd = ctx.sq_fwd
+        if sq_fwd is not None:
+            if g_out is not None:
+                raise RuntimeError("ConvStackFn: the stack was run with the 'unit' promise (the criterion is the only consumer of "
+                                   "its output) and the output received a gradient of its own")
+            if g_loss is None:
+                return (None,) * (6 + len(params))
+            fused_sq = True               # (the gradient of the output block's pre-activation exists since forward)
+        elif ctx.sq is not None:
             last = blocks[-1]
             if g_loss is not None and g_out is None and last.bn is None:
                 fused_sq = True          # criterion + output activation backward in one pass, g_out never exists
@@ -389,10 +431,20 @@ class ConvStackFn(torch.autograd.Function):
                     ggamma, grads[pi + 2] = _grad_dest(params[pi + 2])   # written by act_bn_bwd below
                     gbeta, grads[pi + 3] = _grad_dest(params[pi + 3])
                 # (eval-mode BN: gamma/beta gradients are not produced)
-                gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
                 # g_y overwrites g_o unless g_o is the caller's tensor (top block)
                 cls_cur = None
-                if fused_sq and li == nb - 1:
+                if sq_fwd is not None and li == nb - 1:
+                    # (criterion + activation backward happened in the forward kernel: g_y, the bias gradient and the class sums
+                    # are there)
+                    g_y, gb, gb_ret, cls_f = sq_fwd
+                    if wants_cls(li) and C == 1 and a.shape[2] * a.shape[3] >= 16384:
+                        cls_cur = cls_f
+                        c_off += ops.CLS_COPIES * 4       # (its slice of the arena stays unused)
+                else:
+                    gb, gb_ret, gb_zero = _grad_dest(params[pi + 1], accumulated=True)
+                if sq_fwd is not None and li == nb - 1:
+                    pass
+                elif fused_sq and li == nb - 1:
                     g_y = torch.empty_like(a)
                     if wants_cls(li) and C == 1 and a.shape[2] * a.shape[3] >= 16384:
                         cls_cur = cls_arena[c_off:c_off + ops.CLS_COPIES * 4]

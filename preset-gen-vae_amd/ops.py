@@ -262,6 +262,24 @@ def conv_up(geom, small, w, bias, act, slope, in_scale=None, in_shift=None, stat
     return out
 
 
+def conv_up_sq(geom, small, w, bias, act, slope, target, scale, gbias, loss_acc, cls, in_scale=None, in_shift=None,
+               in_bn=None):
+    """``conv_up`` of an output block + the squared-error criterion against ``target`` where the output is produced
+    (``pgv_conv_up_sqerr``; upstream gradient of the criterion = 1): returns (out, g_y) and adds into ``gbias`` / ``loss_acc``
+    / ``cls`` - or None when the shape / mode has no fused kernel (nothing was launched: the caller takes ``conv_up`` +
+    ``sqerr_act_bwd``)."""
+    B = small.shape[0]
+    out = torch.empty((B, geom.Cb, geom.Hb, geom.Wb), device=small.device, dtype=torch.float32)
+    g_y = torch.empty_like(out)
+    _chk(small, w, bias, in_scale, in_shift, out, target, gbias, loss_acc, cls)
+    fused = ctypes.c_int(0)
+    _lib.check(_lib.load().pgv_conv_up_sqerr(ctypes.byref(geom.desc(B, 0, None)), _p(small),
+                                             None if in_bn is None else ctypes.byref(in_bn), _p(in_scale), _p(in_shift),
+                                             _p(w), _p(bias), act, slope, _p(out), _p(target), scale, _p(g_y), _p(gbias),
+                                             _p(loss_acc), _p(cls), ctypes.byref(fused), _stream()), "pgv_conv_up_sqerr")
+    return (out, g_y) if fused.value else None
+
+
 _ws_cache = {}
 _ws_retired = []   # superseded workspaces: a captured hipGraph may still write its partial gradients into them
 

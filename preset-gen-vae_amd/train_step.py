@@ -70,7 +70,8 @@ class VAETrainStep:
         vae = getattr(ae_model, 'ae_model', ae_model)
         if hasattr(vae, 'fuse_recons_criterion'):
             # (deferred: this class always runs backward before anybody reads the loss values)
-            vae.fuse_recons_criterion = ('mse_mean' if normalize_losses else 'l2_batch') + '+deferred'
+            # (unit: total = 1 * recons + beta * latent below, and x_out feeds nothing else that is differentiated)
+            vae.fuse_recons_criterion = ('mse_mean' if normalize_losses else 'l2_batch') + '+deferred+unit'
         self.controls_criterion = controls_criterion if controls_criterion is not None else \
             loss_mod.MSELoss(reduction='mean')
         self.monitors = dict(monitors or {})
@@ -123,9 +124,12 @@ class VAETrainStep:
             from .rng import device_rng
             rng = device_rng(getattr(self.model, 'ae_model', self.model), x.device)
             rng.hand_over = True     # its advance rides in the optimizer's step-counter launch (_optimizer_step)
+        from .model import layer as layer_mod
+        layer_mod.UNIT_RECONS_GRADIENT = True      # (the roots and root gradients below keep the promise)
         try:
             z_mu_logvar, z0, zK, ladj, x_out = self.model(x, None, **inject)
         finally:
+            layer_mod.UNIT_RECONS_GRADIENT = False
             if rng is not None:
                 rng.hand_over = False
         recons = self.recons_criterion(x_out, x)

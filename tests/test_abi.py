@@ -27,7 +27,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.pgv_abi_version() == 15
+    assert lib.pgv_abi_version() == 16
     assert lib.pgv_set_kernel_policy(0) == 0
 
 

@@ -123,6 +123,43 @@ def test_end_layer_ring_kernels_all_batch_regimes(ops, B):
     assert (got_cls - ref_cls).abs().max().item() < 2e-5 * ref.abs().sum(dim=(0, 2, 3)).max().item()
     got_gb = gb.view(ops.CLS_COPIES, Cs).sum(0).double().cpu()
     assert (got_gb - ref.sum(dim=(0, 2, 3))).abs().max().item() < 2e-5 * ref.abs().sum(dim=(0, 2, 3)).max().item()
+    # the output layer with the reconstruction criterion in its forward epilogue (pgv_conv_up_sqerr, round 6): output, the
+    # gradient of its pre-activation for an upstream gradient of 1, criterion value, bias gradient and class sums - in float64,
+    # and the separate launches (conv_up + sqerr_act_bwd with g_loss = 1) for the by-products' layout
+    from preset_gen_vae_amd import _lib
+    target = torch.randn((B, 1, Hb, Wb), generator=gen) * 0.7
+    scale = 1.0 / target.numel()
+    for act, act_ref, dact in ((ops.PGV_ACT_HARDTANH, F.hardtanh, lambda o: ((o > -1) & (o < 1)).double()),
+                               (ops.PGV_ACT_LEAKY_RELU, lambda t_: F.leaky_relu(t_, 0.1), lambda o: torch.where(o > 0, 1.0, 0.1).double())):
+        o_ref = act_ref(F.conv_transpose2d(_affine(small, sc_s, sh_s).double(), (2.5 * w).double(), bias_b.double(), stride=s, padding=p))
+        g_ref = dact(o_ref) * 2.0 * scale * (o_ref - target.double())
+        gbias, loss, cls1 = (torch.zeros(n_, device='cuda') for n_ in (1, 1, ops.CLS_COPIES * 4))
+        res = ops.conv_up_sq(geom, dev(small), dev(2.5 * w), dev(bias_b), act, 0.1, dev(target), scale, gbias, loss, cls1,
+                             in_scale=dev(sc_s), in_shift=dev(sh_s))
+        assert res is not None, "the 8 -> 1 channel 257x347 layer has the fused kernel"
+        out, g_y = res
+        assert rel_l2(out, o_ref) < 2e-6
+        # (the gradient from the DEVICE's output: an output within rounding of the clamp sits on either side of the gate)
+        g_dev = dact(out.double().cpu()) * 2.0 * scale * (out.double().cpu() - target.double())
+        assert rel_l2(g_y, g_dev) < 1e-6
+        near = ((o_ref.abs() - 1.0).abs() < 1e-5) if act == ops.PGV_ACT_HARDTANH else (o_ref.abs() < 1e-5)
+        assert (g_y.double().cpu() - g_ref)[~near].abs().max().item() <= 1e-5 * g_ref.abs().max().item()
+        assert abs(loss.item() - scale * ((o_ref - target.double()) ** 2).sum().item()) <= 1e-5 * abs(loss.item())
+        g_abs = g_ref.abs().sum().item()
+        assert abs(gbias.item() - g_ref.sum().item()) <= 2e-5 * g_abs
+        ref_c = torch.stack([g_ref[:, 0, r::2, c::2].sum() for r in (0, 1) for c in (0, 1)])
+        assert (cls1.view(ops.CLS_COPIES, 4).sum(0).double().cpu() - ref_c).abs().max().item() <= 2e-5 * g_abs
+        # the separate launches produce the same tensors
+        o2 = ops.conv_up(geom, dev(small), dev(2.5 * w), dev(bias_b), act, 0.1, in_scale=dev(sc_s), in_shift=dev(sh_s))
+        g2, gb2, l2, c2 = torch.empty_like(o2), torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda'), torch.zeros_like(cls1)
+        ops.sqerr_act_bwd(o2, dev(target), torch.ones((), device='cuda'), scale, act, 0.1, g2, gb2, prezeroed=True, loss_acc=l2, cls=c2)
+        assert torch.equal(out, o2) and rel_l2(g_y, g2) < 1e-6
+    # kernel policies 1 - 3 and bf16 operand mode have no fused kernel: nothing is launched, the caller is told
+    _lib.load().pgv_set_kernel_policy(3)
+    try:
+        assert ops.conv_up_sq(geom, dev(small), dev(w), dev(bias_b), ops.PGV_ACT_HARDTANH, 0.0, dev(target), scale, gbias, loss, cls1) is None
+    finally:
+        _lib.load().pgv_set_kernel_policy(0)
 
 
 # kernel policies (pgv_set_kernel_policy): 0 = tuned (wave-specialised, then band kernels), 3 = the same without the
@@ -1528,7 +1565,7 @@ def test_conv_desc_validation(ops):
         ops.conv_down(geom, x, w, None, 0, 0.0)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.conv_down(ops.ConvGeom(2, 3, 4, 2, 2, 9, 9), x.cpu(), w, None, 0, 0.0)
-    assert _lib.load().pgv_abi_version() == 15
+    assert _lib.load().pgv_abi_version() == 16
 
 
 def test_empty_batch(ops):

@@ -76,6 +76,14 @@ def _record_activation_regions(run, arch):
         rec.append(((a.abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (a > 0)).cpu())
         return orig_sq(a, x, g_loss, scale, act, slope, g_y, gbias, **kw)
 
+    orig_up_sq = ops.conv_up_sq
+
+    def patched_up_sq(geom, small, w, bias, act, slope, *args, **kw):   # ... with the criterion in its FORWARD kernel (round 6)
+        res = orig_up_sq(geom, small, w, bias, act, slope, *args, **kw)
+        if res is not None:
+            rec.append(((res[0].abs() < 1.0) if act == ops.PGV_ACT_HARDTANH else (res[0] > 0)).cpu())
+        return res
+
     # blocks whose BatchNorm + activation backward rides in the consumer's input-gradient epilogue (pgv_bwd_fuse)
     orig_down, orig_up = ops.conv_down, ops.conv_up
 
@@ -91,6 +99,7 @@ def _record_activation_regions(run, arch):
     ops.act_bn_bwd = patched
     ops.bn_act_bwd_fused = patched_fused
     ops.sqerr_act_bwd = patched_sq
+    ops.conv_up_sq = patched_up_sq
     ops.conv_down, ops.conv_up = fused(orig_down), fused(orig_up)
     try:
         out = run()
@@ -98,6 +107,7 @@ def _record_activation_regions(run, arch):
         ops.act_bn_bwd = orig
         ops.bn_act_bwd_fused = orig_fused
         ops.sqerr_act_bwd = orig_sq
+        ops.conv_up_sq = orig_up_sq
         ops.conv_down, ops.conv_up = orig_down, orig_up
     names = _block_names(arch)
     assert len(rec) == len(names), (len(rec), names)
@@ -466,27 +476,30 @@ def test_fused_reconstruction_criterion_matches_separate(normalize):
     x = _cuda32(synth_input(B))
     eps = _cuda32(torch.sin(torch.arange(B * dim_z, dtype=torch.float64) * 0.37 + 0.2).reshape(B, dim_z))
     res = []
-    for fused in (True, False):
+    kind = 'mse_mean' if normalize else 'l2_batch'
+    # the three forms: in the output layer's FORWARD kernel (round 6: pgv_conv_up_sqerr, what VAETrainStep asks for), in one
+    # backward pass (pgv_sqerr_act_bwd_cls), and as separate criterion + activation backward launches
+    for form in (kind + '+deferred+unit', kind + '+deferred', None):
         ae = _build(arch, dim_z, B, False, fc_dropout=0.0)
         _load_closed_form(ae, arch, dim_z, False, 77)
         ae = ae.cuda().train()
         step = VAETrainStep(ae, lr=1e-5, normalize_losses=normalize)
-        assert ae.fuse_recons_criterion == ('mse_mean' if normalize else 'l2_batch') + '+deferred'
-        if not fused:
-            ae.fuse_recons_criterion = None
+        assert ae.fuse_recons_criterion == kind + '+deferred+unit'
+        ae.fuse_recons_criterion = form
         out = step.step(x, inject={'eps': eps})
         torch.cuda.synchronize()
         res.append((out, {k: v.grad.detach().clone() for k, v in ae.named_parameters()}))
-    (o1, g1), (o2, g2) = res
+    (o2, g2) = res[-1]
     # two runs of the same binary already differ at the 1e-6 level (float atomics in the split-K GEMMs and weight
     # gradients, amplified by BatchNorm over 3 samples): tolerances are a decade above that noise
-    for key in ('recons', 'latent', 'total'):
-        assert abs(o1[key].item() - o2[key].item()) <= 1e-5 * abs(o2[key].item()), key
-    assert rel_l2(o1['x_out'], o2['x_out']) < 1e-5
-    for k in g2:
-        if g2[k].abs().max().item() < 1e-9:
-            continue
-        assert rel_l2(g1[k], g2[k]) < 1e-4, k
+    for o1, g1 in res[:-1]:
+        for key in ('recons', 'latent', 'total'):
+            assert abs(o1[key].item() - o2[key].item()) <= 1e-5 * abs(o2[key].item()), key
+        assert rel_l2(o1['x_out'], o2['x_out']) < 1e-5
+        for k in g2:
+            if g2[k].abs().max().item() < 1e-9:
+                continue
+            assert rel_l2(g1[k], g2[k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("golden", ['vae8l_b2_c2.npz', 'vae8l_b2_c2_mix.npz', 'vae8l_b2_big.npz'])
