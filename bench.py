@@ -225,6 +225,7 @@ def launch_table(ae, B, device, frontend=None):
     prev_bn = {False: False, True: False}   # does the producer block of the same stack end in a BatchNorm (folded here)?
     layers = layer_ops(ae)
     fused_bwd = True   # (layer.BN_BACKWARD_MODE 'fused'; bf16 operand mode: from B*H*W = 2^17 per channel on)
+    sq_in_fwd = False  # the criterion rides in the output layer's forward kernel (set below where that kernel exists)
     for li, (name, (Cb, Cs, k, s, p, Hb, Wb), has_bn, is_up) in enumerate(layers):
         fold = prev_bn[is_up]
         prev_bn[is_up] = has_bn
@@ -343,6 +344,19 @@ def launch_table(ae, B, device, frontend=None):
                 label += "+bn_bwd_coef"
             if not is_dgrad and kind != 'conv_wgrad' and in_bn is not None:
                 label += "+bn_finalize"
+            if is_up and not is_dgrad and kind == 'conv_up' and big.shape[1] == 1 and li == len(layers) - 1:
+                # the output layer of the step carries the reconstruction criterion in its epilogue where it has the kernel for
+                # it (pgv_conv_up_sqerr: target in, gradient out, class sums / bias gradient / value as by-products)
+                sq_t, sq_gb = torch.randn_like(big), torch.zeros(1, device=device)
+                sq_cls = torch.zeros(ops.CLS_COPIES * 4, device=device)
+                sq_fn = (lambda geom=geom, small=small, w=w, bias_b=bias_b, in_bn=in_bn, sc_s=sc_s, sh_s=sh_s:
+                         ops.conv_up_sq(geom, small, w, bias_b, 2, 0.0, sq_t, 1.0 / sq_t.numel(), sq_gb, None, sq_cls,
+                                        in_scale=None if in_bn is not None else sc_s,
+                                        in_shift=None if in_bn is not None else sh_s, in_bn=in_bn))
+                if sq_fn() is not None:
+                    table.append((label + "+sqerr", sq_fn, nb + ns + nw + 2 * nb, flops))
+                    sq_in_fwd = True
+                    continue
             table.append((label, mk(kind), nb + ns + nw + extra, flops))
         a = big if is_up else small
         C = a.shape[1]
@@ -372,9 +386,10 @@ def launch_table(ae, B, device, frontend=None):
     xo, xt, gy = (torch.randn(B, 1, 257, 347, device=device) for _ in range(3))
     gl, gb1 = torch.ones((), device=device), torch.zeros(1, device=device)
     cls8 = torch.zeros(ops.CLS_COPIES * 4, device=device) if fused_bwd else None   # (class sums of g_y for the block below, as in the step)
-    table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1,
-                                                                    prezeroed=True, cls=cls8),
-                  3 * xo.numel() * 4, 0.0))
+    if not sq_in_fwd:
+        table.append(("sqerr_act_bwd[dec8]", lambda: ops.sqerr_act_bwd(xo, xt, gl, 1.0 / xo.numel(), 2, 0.0, gy, gb1,
+                                                                        prezeroed=True, cls=cls8),
+                      3 * xo.numel() * 4, 0.0))
     # fc layers (encoder.mlp.1 / decoder.mlp.0): forward, input gradient, weight gradient
     lin_e, lin_d = ae.encoder.mlp[1], ae.decoder.mlp[0]
     for tag, lin in (('enc_fc', lin_e), ('dec_fc', lin_d)):
