@@ -238,6 +238,7 @@ class ConvStackFn(torch.autograd.Function):
             w_sh = shadows[bi]
             a = None
             if fwd_sq and bi == len(blocks) - 1 and w_sh is None:
+                gen0 = getattr(b, '_pgv_zero_gen', -1)
                 gb, gb_ret, gb_zero = _grad_dest(b, accumulated=True)
                 if not gb_zero:
                     gb.zero_()
@@ -250,6 +251,8 @@ class ConvStackFn(torch.autograd.Function):
                     a, g_y0 = res
                     ctx.sq_fwd = (g_y0, gb, gb_ret, sq_cls)
                     pending = None
+                elif gb_zero:
+                    b._pgv_zero_gen = gen0     # (nothing was launched: backward finds the bias gradient's slice as clean as it was)
             # (pending: the producer's train-mode BatchNorm, finalized by this kernel in its prologue - ops.bn_src)
             if a is not None:
                 pass
